@@ -1,0 +1,21 @@
+"""Build oracle cone objects / models from instance descriptions (test infrastructure)."""
+from . import cones as oc
+from .solvers import Model
+
+
+def make_cone(spec):
+    kind = spec[0]
+    if kind == "nonnegative":
+        return oc.Nonnegative(spec[1])
+    if kind == "possemideftri":
+        return oc.PosSemidefTri(spec[1])
+    if kind == "epinormspectral":
+        return oc.EpiNormSpectral(spec[1], spec[2], use_dual=spec[3])
+    if kind == "wsosinterpnonnegative":
+        return oc.WSOSInterpNonnegative(spec[1], spec[2], use_dual=spec[3])
+    raise ValueError(kind)
+
+
+def make_model(inst):
+    c, A, b, G, h, specs = inst[:6]
+    return Model(c, A, b, G, h, [make_cone(s) for s in specs])

@@ -1,0 +1,656 @@
+"""Cone barrier oracles -- numpy restatement (test infrastructure; see oracle/__init__.py).
+
+Follows /root/reference/src/Cones/:
+  Cones.jl                     generic Cone{T} protocol, lazy caches, generic fallbacks
+  nonnegative.jl               Nonnegative
+  possemideftri.jl             PosSemidefTri (real)
+  epinormspectral.jl           EpiNormSpectral (real)
+  wsosinterpnonnegative.jl     WSOSInterpNonnegative (real)
+Method names mirror the Julia generics; `f!(prod, arr, cone)` becomes `cone.f(prod, arr)` writing
+into `prod` in place.  Matrices are handled as 2-D numpy arrays with one column per right-hand
+side; vectors as 1-D arrays.
+"""
+import numpy as np
+import scipy.linalg as sla
+from scipy.linalg import lapack, blas
+
+from . import arrayutil as au
+from . import linalg as la
+
+EPS = np.finfo(np.float64).eps
+
+
+def _cols(arr):
+    """view a vector or matrix as (dim, ncols)."""
+    return arr.reshape(arr.shape[0], -1)
+
+
+class Cone:
+    """Cones.jl:27-310 (abstract type Cone{T} and its generic methods)."""
+
+    use_dual_barrier_ = False
+
+    # ---- Cones.jl:34-41
+    def dimension(self):
+        return self.dim
+
+    def get_nu(self):
+        return self.nu
+
+    # ---- Cones.jl:138
+    def use_dual_barrier(self):
+        return self.use_dual_barrier_
+
+    # ---- Cones.jl:126
+    def use_dder3(self):
+        return True
+
+    # ---- Cones.jl:140-153
+    def setup_data(self):
+        self.reset_data()
+        dim = self.dimension()
+        self.point = np.zeros(dim)
+        self.dual_point = np.zeros(dim)
+        self.grad = np.zeros(dim)
+        self.dder3_ = np.zeros(dim)
+        self.vec1 = np.zeros(dim)
+        self.vec2 = np.zeros(dim)
+        self.hess_ = None
+        self.inv_hess_ = None
+        self.hess_fact = None
+        self.setup_extra_data()
+        return self
+
+    def setup_extra_data(self):
+        pass
+
+    # ---- Cones.jl:157-171
+    def load_point(self, point, scal=None):
+        if scal is None:
+            self.point[:] = point
+        else:
+            np.multiply(point, scal, out=self.point)
+
+    def load_dual_point(self, point):
+        self.dual_point[:] = point
+
+    # ---- Cones.jl:185-186
+    def reset_data(self):
+        self.feas_updated = self.grad_updated = self.hess_updated = False
+        self.inv_hess_updated = self.hess_fact_updated = False
+
+    # ---- Cones.jl:56, 63, 71
+    def is_feas(self):
+        return self.is_feas_ if self.feas_updated else self.update_feas()
+
+    def is_dual_feas(self):
+        return True
+
+    def get_grad(self):
+        return self.grad if self.grad_updated else self.update_grad()
+
+    # ---- Cones.jl:79-93
+    def hess(self):
+        return self.hess_ if self.hess_updated else self.update_hess()
+
+    def inv_hess(self):
+        return self.inv_hess_ if self.inv_hess_updated else self.update_inv_hess()
+
+    # ---- Cones.jl:101-105  (mul!(prod, Symmetric(hess,:U), arr))
+    def hess_prod(self, prod, arr):
+        if not self.hess_updated:
+            self.update_hess()
+        H = self.hess_
+        Hs = np.triu(H) + np.triu(H, 1).T
+        _cols(prod)[:] = Hs @ _cols(arr)
+        return prod
+
+    # ---- Cones.jl:113-118
+    def inv_hess_prod(self, prod, arr):
+        self.update_hess_fact()
+        _cols(prod)[:] = _cols(self.hess_fact.solve(np.array(_cols(arr), order="F")))
+        return prod
+
+    # ---- Cones.jl:189-195
+    def use_sqrt_hess_oracles(self, arr_dim):
+        if not self.hess_fact_updated:
+            if arr_dim < self.dimension():
+                return False
+            if not self.update_hess_fact():
+                return False
+        return self.hess_fact.kind == "chol"
+
+    # ---- Cones.jl:198-206  (mul!(prod, hess_fact.U, arr))
+    def sqrt_hess_prod(self, prod, arr):
+        assert self.hess_fact_updated
+        _cols(prod)[:] = blas.dtrmm(1.0, self.hess_fact.factors, np.array(_cols(arr), order="F"),
+                                    side=0, lower=0, trans_a=0, diag=0)
+        return prod
+
+    # ---- Cones.jl:209-218  (ldiv!(prod, hess_fact.U', arr))
+    def inv_sqrt_hess_prod(self, prod, arr):
+        assert self.hess_fact_updated
+        _cols(prod)[:] = blas.dtrsm(1.0, self.hess_fact.factors, np.array(_cols(arr), order="F"),
+                                    side=0, lower=0, trans_a=1, diag=0)
+        return prod
+
+    def update_hess_aux(self):
+        pass
+
+    # ---- Cones.jl:222-237
+    def update_use_hess_prod_slow(self):
+        if not self.hess_updated:
+            self.update_hess()
+        H = self.hess_
+        Hs = np.triu(H) + np.triu(H, 1).T
+        rel_viol = abs(1 - self.point @ (Hs @ self.point) / self.get_nu())
+        self.use_hess_prod_slow = rel_viol > self.dimension() * np.sqrt(EPS)
+        self.use_hess_prod_slow_updated = True
+
+    def hess_prod_slow(self, prod, arr):
+        return self.hess_prod(prod, arr)
+
+    # ---- Cones.jl:239-251 (posdef_fact_copy!(hess_fact_mat, hess, false): no diagonal shift)
+    def update_hess_fact(self):
+        if self.hess_fact_updated:
+            return True
+        if not self.hess_updated:
+            self.update_hess()
+        self.hess_fact = la.posdef_fact_copy(self.hess_, try_shift=False)
+        self.hess_fact_updated = True
+        return self.hess_fact.success
+
+    # ---- Cones.jl:253-259
+    def update_inv_hess(self):
+        self.update_hess_fact()
+        assert self.hess_fact.kind == "chol"
+        self.inv_hess_ = la.inv_fact_chol(self.hess_fact)
+        self.inv_hess_updated = True
+        return self.inv_hess_
+
+    # ---- Cones.jl:273-290
+    def check_numerics(self, gtol=np.sqrt(np.sqrt(EPS)), Htol=None):
+        if Htol is None:
+            Htol = 10 * np.sqrt(gtol)
+        g = self.get_grad()
+        dim = g.shape[0]
+        nu = self.get_nu()
+        if abs(1 + g @ self.point / nu) > gtol * dim:
+            return False
+        Hig = self.inv_hess_prod(self.vec1, g)
+        if abs(1 - Hig @ g / nu) > Htol * dim:
+            return False
+        return True
+
+    # ---- Cones.jl:294-310
+    def get_proxsqr(self, irtmu, use_max_prox, negtol=np.sqrt(EPS)):
+        g = self.get_grad()
+        vec1, vec2 = self.vec1, self.vec2
+        vec1[:] = irtmu * self.dual_point + g
+        self.inv_hess_prod(vec2, vec1)
+        prox_sqr = vec2 @ vec1
+        if prox_sqr < -negtol * g.shape[0]:
+            return np.inf
+        return abs(prox_sqr)
+
+
+# ----------------------------------------------------------------------------------------------
+class Nonnegative(Cone):
+    """nonnegative.jl:8-145."""
+
+    def __init__(self, dim):
+        assert dim >= 1
+        self.dim = dim
+
+    def reset_data(self):   # :35-36
+        self.feas_updated = self.grad_updated = self.hess_updated = self.inv_hess_updated = False
+        self.hess_fact_updated = False
+
+    def use_sqrt_hess_oracles(self, arr_dim):   # :38
+        return True
+
+    def get_nu(self):   # :40
+        return self.dim
+
+    def set_initial_point(self, arr):   # :42
+        arr[:] = 1.0
+        return arr
+
+    def update_feas(self):   # :44-49
+        assert not self.feas_updated
+        self.is_feas_ = bool(np.all(self.point > EPS))
+        self.feas_updated = True
+        return self.is_feas_
+
+    def is_dual_feas(self):   # :51
+        return bool(np.all(self.dual_point > EPS))
+
+    def update_grad(self):   # :53-58
+        assert self.is_feas_
+        self.grad[:] = -1.0 / self.point
+        self.grad_updated = True
+        return self.grad
+
+    def update_hess(self):   # :60-69 (Diagonal)
+        if not self.grad_updated:
+            self.update_grad()
+        self.hess_ = np.diag(self.grad ** 2)
+        self.hess_updated = True
+        return self.hess_
+
+    def update_inv_hess(self):   # :71-80
+        assert self.is_feas_
+        self.inv_hess_ = np.diag(self.point ** 2)
+        self.inv_hess_updated = True
+        return self.inv_hess_
+
+    def hess_prod(self, prod, arr):   # :82-90
+        _cols(prod)[:] = _cols(arr) / self.point[:, None] / self.point[:, None]
+        return prod
+
+    def inv_hess_prod(self, prod, arr):   # :92-100
+        _cols(prod)[:] = _cols(arr) * self.point[:, None] * self.point[:, None]
+        return prod
+
+    def sqrt_hess_prod(self, prod, arr):   # :102-110
+        _cols(prod)[:] = _cols(arr) / self.point[:, None]
+        return prod
+
+    def inv_sqrt_hess_prod(self, prod, arr):   # :112-120
+        _cols(prod)[:] = _cols(arr) * self.point[:, None]
+        return prod
+
+    def dder3(self, dir):   # :122-125
+        self.dder3_[:] = (dir / self.point) ** 2 / self.point
+        return self.dder3_
+
+    def get_proxsqr(self, irtmu, use_max_prox, negtol=None):   # :137-145
+        v = (self.point * self.dual_point * irtmu - 1) ** 2
+        return float(np.max(v) if use_max_prox else np.sum(v))
+
+
+# ----------------------------------------------------------------------------------------------
+class PosSemidefTri(Cone):
+    """possemideftri.jl:9-207 (real symmetric case, R = Float64)."""
+
+    def __init__(self, dim):
+        assert dim >= 1
+        self.dim = dim
+        self.rt2 = au.RT2
+        self.side = au.svec_side(dim)
+
+    def reset_data(self):   # :51-52
+        self.feas_updated = self.grad_updated = self.hess_updated = self.inv_hess_updated = False
+        self.hess_fact_updated = False
+
+    def use_sqrt_hess_oracles(self, arr_dim):   # :54
+        return True
+
+    def setup_extra_data(self):   # :56-65
+        s = self.side
+        self.mat = np.zeros((s, s), order="F")
+        self.mat3 = np.zeros((s, s), order="F")
+        self.mat4 = np.zeros((s, s), order="F")
+        self.inv_mat = np.zeros((s, s), order="F")
+        self.fact_mat = None
+
+    def get_nu(self):   # :67
+        return self.side
+
+    def set_initial_point(self, arr):   # :69-78
+        arr[:] = 0
+        k = 0
+        for i in range(1, self.side + 1):
+            arr[k] = 1
+            k += i + 1
+        return arr
+
+    def update_feas(self):   # :80-90
+        assert not self.feas_updated
+        au.svec_to_smat(self.mat, self.point, self.rt2)
+        self.fact_mat = la.chol_upper(self.mat)
+        self.is_feas_ = self.fact_mat.success
+        self.feas_updated = True
+        return self.is_feas_
+
+    def is_dual_feas(self):   # :92-95
+        au.svec_to_smat(self.mat3, self.dual_point, self.rt2)
+        return la.chol_upper(self.mat3).success
+
+    def update_grad(self):   # :97-107
+        assert self.is_feas_
+        self.inv_mat[:] = la.inv_fact_chol(self.fact_mat)
+        au.smat_to_svec(self.grad, self.inv_mat, self.rt2)
+        self.grad *= -1
+        au.copytri_upper(self.mat)
+        self.grad_updated = True
+        return self.grad
+
+    def update_hess(self):   # :109-116
+        assert self.grad_updated
+        au.copytri_upper(self.inv_mat)
+        self.hess_ = np.zeros((self.dim, self.dim))
+        au.symm_kron(self.hess_, self.inv_mat, self.rt2)
+        self.hess_updated = True
+        return self.hess_
+
+    def update_inv_hess(self):   # :118-124
+        assert self.is_feas()
+        self.inv_hess_ = np.zeros((self.dim, self.dim))
+        m = np.triu(self.mat) + np.triu(self.mat, 1).T
+        au.symm_kron(self.inv_hess_, m, self.rt2)
+        self.inv_hess_updated = True
+        return self.inv_hess_
+
+    def _unpack_full(self, col):
+        au.svec_to_smat(self.mat4, col, self.rt2)
+        au.copytri_upper(self.mat4)
+        return self.mat4
+
+    def hess_prod(self, prod, arr):   # :126-142   X^-1 V X^-1 via rdiv!/ldiv! with the Cholesky
+        assert self.is_feas()
+        P, A = _cols(prod), _cols(arr)
+        F = self.fact_mat.factors
+        for i in range(A.shape[1]):
+            V = self._unpack_full(A[:, i])
+            # rdiv!(V, fact): V <- V * X^-1 = (X^-1 V')' ; V symmetric on entry
+            T = lapack.dpotrs(F, np.asfortranarray(V.T), lower=0)[0].T
+            W = lapack.dpotrs(F, np.asfortranarray(T), lower=0)[0]
+            au.smat_to_svec(P[:, i], W, self.rt2)
+        return prod
+
+    def inv_hess_prod(self, prod, arr):   # :144-159   X V X (two symm products)
+        assert self.is_feas()
+        P, A = _cols(prod), _cols(arr)
+        X = np.triu(self.mat) + np.triu(self.mat, 1).T
+        for i in range(A.shape[1]):
+            au.svec_to_smat(self.mat4, A[:, i], self.rt2)
+            V = np.triu(self.mat4) + np.triu(self.mat4, 1).T
+            T = V @ X
+            W = X @ T
+            au.smat_to_svec(P[:, i], W, self.rt2)
+        return prod
+
+    def sqrt_hess_prod(self, prod, arr):   # :161-177   U^-T V U^-1
+        assert self.is_feas()
+        P, A = _cols(prod), _cols(arr)
+        F = self.fact_mat.factors
+        for i in range(A.shape[1]):
+            V = self._unpack_full(A[:, i])
+            T = blas.dtrsm(1.0, F, np.asfortranarray(V), side=1, lower=0, trans_a=0, diag=0)   # V U^-1
+            W = blas.dtrsm(1.0, F, T, side=0, lower=0, trans_a=1, diag=0)                        # U^-T (.)
+            au.smat_to_svec(P[:, i], W, self.rt2)
+        return prod
+
+    def inv_sqrt_hess_prod(self, prod, arr):   # :179-195   U V U'
+        assert self.is_feas()
+        P, A = _cols(prod), _cols(arr)
+        F = self.fact_mat.factors
+        for i in range(A.shape[1]):
+            V = self._unpack_full(A[:, i])
+            T = blas.dtrmm(1.0, F, np.asfortranarray(V), side=1, lower=0, trans_a=1, diag=0)   # V U'
+            W = blas.dtrmm(1.0, F, T, side=0, lower=0, trans_a=0, diag=0)                        # U (.)
+            au.smat_to_svec(P[:, i], W, self.rt2)
+        return prod
+
+    def dder3(self, dir):   # :197-207   X^-1 D X^-1 D X^-1
+        assert self.grad_updated
+        F = self.fact_mat.factors
+        S = self._unpack_full(dir)
+        S = lapack.dpotrs(F, np.asfortranarray(S), lower=0)[0]                                  # X^-1 D
+        S = blas.dtrsm(1.0, F, np.asfortranarray(S), side=1, lower=0, trans_a=0, diag=0)         # (.) U^-1
+        M = S @ S.T
+        au.smat_to_svec(self.dder3_, M, self.rt2)
+        return self.dder3_
+
+
+# ----------------------------------------------------------------------------------------------
+class EpiNormSpectral(Cone):
+    """epinormspectral.jl:13-294 (real case): (u, W) with u >= sigma_1(W), W is d1 x d2, d1 <= d2."""
+
+    def __init__(self, d1, d2, use_dual=False):
+        assert 1 <= d1 <= d2
+        self.use_dual_barrier_ = use_dual
+        self.d1, self.d2 = d1, d2
+        self.dim = 1 + d1 * d2
+
+    def reset_data(self):   # :70-72
+        self.feas_updated = self.grad_updated = self.hess_updated = self.inv_hess_updated = False
+        self.hess_aux_updated = self.hess_fact_updated = False
+
+    def setup_extra_data(self):   # :75-95
+        d1, d2 = self.d1, self.d2
+        self.W = np.zeros((d1, d2), order="F")
+        self.Zi = np.zeros((d1, d1), order="F")
+        self.tau = np.zeros((d1, d2), order="F")
+        self.HuW = np.zeros((d1, d2), order="F")
+        self.WtauI = np.zeros((d2, d2), order="F")
+        self.Zitau = np.zeros((d1, d2), order="F")
+
+    def get_nu(self):   # :97
+        return self.d1 + 1
+
+    def set_initial_point(self, arr):   # :99-105
+        arr[:] = 0
+        arr[0] = np.sqrt(self.get_nu())
+        return arr
+
+    def _mat(self, v):
+        return v.reshape(self.d1, self.d2, order="F")
+
+    def update_feas(self):   # :107-123
+        assert not self.feas_updated
+        u = self.point[0]
+        if u > EPS:
+            self.W[:] = self._mat(self.point[1:])
+            Z = u * u * np.eye(self.d1) - self.W @ self.W.T
+            self.fact_Z = la.chol_upper(Z)
+            self.is_feas_ = self.fact_Z.success
+        else:
+            self.is_feas_ = False
+        self.feas_updated = True
+        return self.is_feas_
+
+    def is_dual_feas(self):   # :125-132
+        u = self.dual_point[0]
+        if u > EPS:
+            W = self._mat(self.dual_point[1:])
+            return bool(u - np.sum(sla.svdvals(W)) > EPS)
+        return False
+
+    def update_grad(self):   # :134-150
+        assert self.is_feas_
+        u = self.point[0]
+        self.tau[:] = self.fact_Z.solve(np.asfortranarray(self.W))
+        Zi = la.inv_fact_chol(self.fact_Z)
+        au.copytri_upper(Zi)
+        self.Zi[:] = Zi
+        self.grad[0] = -u * np.trace(Zi)
+        self.grad[1:] = self.tau.reshape(-1, order="F")
+        self.grad *= 2
+        self.grad[0] += (self.d1 - 1) / u
+        self.grad_updated = True
+        return self.grad
+
+    def update_hess_aux(self):   # :152-170
+        assert self.grad_updated
+        u = self.point[0]
+        self.Zitau[:] = self.fact_Z.solve(np.asfortranarray(self.tau))
+        self.HuW[:] = -4 * u * self.Zitau
+        self.trZi2 = float(np.sum(self.Zi ** 2))
+        self.Huu = 4 * u * u * self.trZi2 + (self.grad[0] - 2 * (self.d1 - 1) / u) / u
+        self.WtauI[:] = np.eye(self.d2) + self.W.T @ self.tau
+        self.hess_aux_updated = True
+
+    def update_hess(self):   # :172-209 (explicit Hessian, upper triangle; vectorized over (l, j) blocks)
+        if not self.hess_aux_updated:
+            self.update_hess_aux()
+        d1, d2 = self.d1, self.d2
+        Zi, tau, WtauI = self.Zi, self.tau, self.WtauI
+        H = np.zeros((self.dim, self.dim))
+        # entry for row (j, i) [W index j + i*d1], column (l, k): Zi[l, j] * WtauI[i, k] + tau[l, i] * tau[j, k]
+        # H_WW = kron(WtauI, Zi) + (tau_{l i} tau_{j k}) ; built as a 4-index tensor then reshaped
+        T1 = np.einsum("lj,ik->jilk", Zi, WtauI)
+        T2 = np.einsum("li,jk->jilk", tau, tau)
+        HWW = (T1 + T2).reshape(d1 * d2, d1 * d2, order="F")   # row index j + i*d1, col index l + k*d1
+        H[1:, 1:] = 2 * np.triu(HWW)
+        H[0, 1:] = self.HuW.reshape(-1, order="F")
+        H[0, 0] = self.Huu
+        self.hess_ = H
+        self.hess_updated = True
+        return self.hess_
+
+    def hess_prod(self, prod, arr):   # :211-239
+        if not self.hess_aux_updated:
+            self.update_hess_aux()
+        u = self.point[0]
+        W = self.W
+        P, A = _cols(prod), _cols(arr)
+        for j in range(A.shape[1]):
+            a1 = A[0, j]
+            AW = self._mat(A[1:, j])
+            P[0, j] = self.Huu * a1 + np.sum(self.HuW * AW)
+            T = AW @ W.T
+            T = T + T.T
+            T[np.diag_indices(self.d1)] -= 2 * u * a1
+            R = 2 * (T @ self.tau) + 2 * AW
+            R = self.fact_Z.solve(np.asfortranarray(R))
+            P[1:, j] = R.reshape(-1, order="F")
+        return prod
+
+    def dder3(self, dir):   # :241-294
+        assert self.hess_aux_updated
+        u = self.point[0]
+        W = self.W
+        u_dir = dir[0]
+        W_dir = self._mat(dir[1:]).copy()
+        Zi, tau, Zitau, WtauI = self.Zi, self.tau, self.Zitau, self.WtauI
+        solve = lambda M: self.fact_Z.solve(np.asfortranarray(M))
+
+        d2d2b = W_dir.T @ tau
+        d1d2d = solve(W_dir)
+        d1d2b = d1d2d @ WtauI
+        d1d2c = d1d2d @ d2d2b.T
+        d1d1 = d1d2d @ W.T
+        d2d2 = d2d2b @ d2d2b
+
+        d2d2 = d2d2 + W_dir.T @ d1d2b
+        d1d2d = tau @ d2d2
+        d1d2d = d1d2d + d1d2c @ WtauI
+        d1d2d = d1d2d + d1d2b @ d2d2b
+
+        d1d2b = solve(d1d2b)
+        d1d2b = d1d2b + Zitau @ d2d2b
+
+        d1d1 = d1d1 + tau @ W_dir.T
+        d1d2b = d1d2b + d1d1 @ Zitau
+        d1d2b = d1d2b * (-2 * u)
+
+        const1 = 4 * u * u_dir * u
+        d1d2c = const1 * Zitau - u_dir * tau
+        d1d2c = solve(d1d2c)
+        d1d2b = d1d2b + d1d2c
+
+        d1d2d = -2 * u_dir * d1d2b - 2 * d1d2d
+        self.dder3_[1:] = d1d2d.reshape(-1, order="F")
+
+        # trZi3 = sum(abs2, ldiv!(tempd1d1, fact_Z.L, Zi))  = || L^-1 Zi ||_F^2 with Z = L L'
+        LiZi = sla.solve_triangular(self.fact_Z.factors, Zi, trans="T", lower=False)
+        trZi3 = float(np.sum(LiZi ** 2))
+        d1d2b = d1d2b + 3 * d1d2c
+        self.dder3_[0] = (-np.sum(W_dir * d1d2b) - u * u_dir * (6 * self.trZi2 - 8 * u * trZi3 * u) * u_dir
+                          - (self.d1 - 1) * (u_dir / u) ** 2 / u)
+        return self.dder3_
+
+
+# ----------------------------------------------------------------------------------------------
+class WSOSInterpNonnegative(Cone):
+    """wsosinterpnonnegative.jl:16-200 (real case).  The barrier is for the DUAL cone:
+    use_dual_barrier = !use_dual (:58)."""
+
+    def __init__(self, U, Ps, use_dual=False):
+        for Pk in Ps:
+            assert Pk.shape[0] == U
+        self.use_dual_barrier_ = not use_dual
+        self.dim = U
+        self.Ps = [np.asfortranarray(Pk) for Pk in Ps]
+        self.nu = sum(Pk.shape[1] for Pk in Ps)
+
+    def reset_data(self):   # :66-68
+        self.feas_updated = self.grad_updated = self.hess_updated = self.inv_hess_updated = False
+        self.hess_fact_updated = False
+        self.use_hess_prod_slow = self.use_hess_prod_slow_updated = False
+
+    def setup_extra_data(self):   # :70-85
+        K = len(self.Ps)
+        self.LamF = [None] * K
+        self.LamFLP = [None] * K
+
+    def set_initial_point(self, arr):   # :87
+        arr[:] = 1.0
+        return arr
+
+    def update_feas(self):   # :89-117 (the Ps_order timing sort only changes evaluation order)
+        assert not self.feas_updated
+        self.is_feas_ = True
+        for k, Pk in enumerate(self.Ps):
+            LUk = Pk.T * self.point[None, :]
+            LLk = LUk @ Pk
+            c, info = lapack.dpotrf(LLk, lower=1, clean=0)
+            self.LamF[k] = c
+            if info != 0:
+                self.is_feas_ = False
+                break
+        self.feas_updated = True
+        return self.is_feas_
+
+    def update_grad(self):   # :119-133
+        assert self.is_feas_
+        self.grad[:] = 0
+        for k, Pk in enumerate(self.Ps):
+            # LamFLP_k = L_k^-1 P_k'
+            LFLP = blas.dtrsm(1.0, self.LamF[k], np.asfortranarray(Pk.T), side=0, lower=1, trans_a=0, diag=0)
+            self.LamFLP[k] = LFLP
+            self.grad -= np.sum(LFLP ** 2, axis=0)
+        self.grad_updated = True
+        return self.grad
+
+    def update_hess(self):   # :135-150 (upper triangle)
+        assert self.grad_updated
+        H = np.zeros((self.dim, self.dim))
+        for k in range(len(self.Ps)):
+            UU = blas.dsyrk(1.0, self.LamFLP[k], trans=1, lower=0)
+            H += np.triu(UU) ** 2
+        self.hess_ = H
+        self.hess_updated = True
+        return self.hess_
+
+    def _partial_lambda(self, dir, LFLP):   # :186-200
+        LU = LFLP * dir[None, :]
+        LL = LU @ LFLP.T
+        LLs = np.triu(LL) + np.triu(LL, 1).T   # Hermitian(LLk) reads the upper triangle
+        return LLs @ LFLP
+
+    def hess_prod_slow(self, prod, arr):   # :152-175
+        if not self.use_hess_prod_slow_updated:
+            self.update_use_hess_prod_slow()
+        assert self.hess_updated
+        if not self.use_hess_prod_slow:
+            return self.hess_prod(prod, arr)
+        assert self.grad_updated
+        P, A = _cols(prod), _cols(arr)
+        P[:] = 0
+        for k in range(len(self.Ps)):
+            LFLP = self.LamFLP[k]
+            for j in range(A.shape[1]):
+                LU = self._partial_lambda(A[:, j], LFLP)
+                P[:, j] += np.sum(LFLP * LU, axis=0)
+        return prod
+
+    def dder3(self, dir):   # :177-188
+        assert self.grad_updated
+        self.dder3_[:] = 0
+        for k in range(len(self.Ps)):
+            LU = self._partial_lambda(dir, self.LamFLP[k])
+            self.dder3_ += np.sum(LU ** 2, axis=0)
+        return self.dder3_

@@ -1,0 +1,238 @@
+"""Instances: the reference's deterministic known-answer tests restated as data, and the synthetic
+generators for BASELINE.json's configs.  Test infrastructure (see oracle/__init__.py).
+
+Known-answer instances follow /root/reference/test/nativeinstances.jl (line ranges per function).
+Each `inst_*` returns (c, A, b, G, h, cone_specs, expect) where cone_specs is a list of tuples
+("nonnegative", dim) | ("possemideftri", dim) | ("epinormspectral", d1, d2, use_dual) |
+("wsosinterpnonnegative", U, Ps, use_dual) so both the oracle cones and the HIP cones can be built
+from the same description, and `expect` holds the pinned answers.
+"""
+import numpy as np
+
+from . import polyutils as pu
+
+RT2 = np.sqrt(2.0)
+RT3 = np.sqrt(3.0)
+
+
+def dimension1():   # nativeinstances.jl:88-108
+    return (np.array([-1.0, 0]), np.zeros((0, 2)), np.zeros(0), np.array([[1.0, 0]]), np.array([1.0]),
+            [("nonnegative", 1)], dict(status="Optimal", primal_obj=-1.0, x=[1.0, 0.0]))
+
+
+def primalinfeas1():   # :169-180
+    return (np.array([1.0, 0]), np.array([[1.0, 1]]), np.array([-2.0]), -np.eye(2), np.zeros(2),
+            [("nonnegative", 2)], dict(status="PrimalInfeasible"))
+
+
+def nonnegative4():   # :295-310
+    G = np.zeros((3, 2))
+    G[0, 0], G[0, 1], G[1, 1], G[2, 1] = 1, -1, 1, -1
+    return (np.array([-2.0, 0]), np.zeros((0, 2)), np.zeros(0), G, np.array([0.0, 2, 0]),
+            [("nonnegative", 3)],
+            dict(status="Optimal", primal_obj=-4.0, x=[2.0, 2.0], s=[0.0, 0, 2], z=[2.0, 2, 0]))
+
+
+def possemideftri1():   # :312-325
+    return (np.array([0.0, -1, 0]), np.array([[1.0, 0, 0], [0, 0, 1]]), np.array([0.5, 1]), -np.eye(3), np.zeros(3),
+            [("possemideftri", 3)], dict(status="Optimal", primal_obj=-1.0, x_at={1: 1.0}))
+
+
+def possemideftri2():   # :327-340
+    return (np.array([0.0, -1, 0]), np.array([[1.0, 0, 1]]), np.array([0.0]), -np.eye(3), np.zeros(3),
+            [("possemideftri", 3)], dict(status="Optimal", primal_obj=0.0, x_norm=0.0))
+
+
+def possemideftri3(seed=1):   # :342-360 (property-based: objective = max eigenvalue of a random matrix)
+    rng = np.random.default_rng(seed)
+    m = rng.random((2, 2))
+    m = np.triu(m) + np.triu(m, 1).T
+    h = -np.array([m[0, 0], RT2 * m[0, 1], m[1, 1]])
+    eig_max = float(np.max(np.linalg.eigvalsh(m)))
+    return (np.array([1.0]), np.zeros((0, 1)), np.zeros(0), np.array([[-1.0], [0], [-1]]), h,
+            [("possemideftri", 3)], dict(status="Optimal", primal_obj=eig_max, x=[eig_max]))
+
+
+def possemideftri4(seed=1):   # :362-380
+    rng = np.random.default_rng(seed)
+    s = 3
+    m = rng.random((s, s))
+    m = np.triu(m) + np.triu(m, 1).T
+    dim = 6
+    jj, ii = np.tril_indices(s)
+    c = -(m[ii, jj] * np.where(ii == jj, 1.0, RT2))
+    A = (np.eye(s)[ii, jj] * 1.0).reshape(1, dim)
+    return (c, A, np.array([1.0]), -np.eye(dim), np.zeros(dim), [("possemideftri", dim)],
+            dict(status="Optimal", primal_obj=-float(np.max(np.linalg.eigvalsh(m)))))
+
+
+def possemideftri8():   # :439-462
+    G = np.zeros((15, 1))
+    G[[0, 2, 5, 9, 14], 0] = -1
+    h = np.zeros(15)
+    h[[6, 7, 8, 10, 11, 12]] = RT2 * np.array([1.0, 1, 0, 1, -1, 1])
+    inv6, rt2inv6, invrt6 = 1 / 6, RT2 / 6, 1 / (RT2 * RT3)
+    return (np.array([1.0]), np.zeros((0, 1)), np.zeros(0), G, h, [("possemideftri", 15)],
+            dict(status="Optimal", primal_obj=RT3,
+                 s=[RT3, 0, RT3, 0, 0, RT3, RT2, RT2, 0, RT3, RT2, -RT2, RT2, 0, RT3],
+                 z=[inv6, -rt2inv6, inv6, rt2inv6, -rt2inv6, inv6, 0, 0, 0, 0, -invrt6, invrt6, -invrt6, 0, 0.5]))
+
+
+def possemideftri9():   # :464-491
+    G = np.zeros((16, 10))
+    for j in (1, 3, 6, 7, 9):
+        G[0, j] = 0.5
+    G[0, 0] = G[1, 1] = G[3, 3] = G[6, 6] = G[10, 7] = G[15, 9] = -1
+    G[2, 2] = G[4, 4] = G[5, 5] = G[14, 8] = -RT2
+    h = np.zeros(16)
+    h[[7, 8, 9, 11, 12, 13]] = RT2 * np.array([1.0, 1, 0, 1, -1, 1])
+    c = np.zeros(10)
+    c[0] = 1
+    invrt2, invrt3 = 1 / RT2, 1 / RT3
+    invrt6 = invrt2 * invrt3
+    return (c, np.zeros((0, 10)), np.zeros(0), G, h, [("nonnegative", 1), ("possemideftri", 15)],
+            dict(status="Optimal", primal_obj=RT2 + RT3,
+                 s=[0, invrt2 + invrt3, 1 - RT2 / RT3, invrt2 + invrt3, RT2 * invrt3, -RT2 * invrt3, invrt3, RT2, RT2, 0,
+                    RT2, RT2, -RT2, RT2, 0, RT3],
+                 z=[1, 0.5, 0, 0.5, 0, 0, 0.5, -0.5, -0.5, 0, 0.5, -invrt6, invrt6, -invrt6, 0, 0.5]))
+
+
+def epinormspectral2(use_dual, seed=1):   # :1074-1103 (real case; property-based)
+    rng = np.random.default_rng(seed)
+    Xn, Xm = 3, 4
+    dim = Xn * Xm
+    mat = rng.random((Xn, Xm))
+    c = -mat.reshape(-1, order="F")
+    G = np.vstack([np.zeros((1, dim)), -np.eye(dim)])
+    h = np.concatenate([[1.0], np.zeros(dim)])
+    sv = np.linalg.svd(mat, compute_uv=False)
+    obj = -sv[0] if use_dual else -np.sum(sv)
+    return (c, np.zeros((0, dim)), np.zeros(0), G, h, [("epinormspectral", Xn, Xm, use_dual)],
+            dict(status="Optimal", primal_obj=float(obj)))
+
+
+def epinormspectral3(Xn, Xm, use_dual):   # :1105-1125 (real cases)
+    dim = Xn * Xm
+    return (-np.ones(dim), np.zeros((0, dim)), np.zeros(0), np.vstack([np.zeros((1, dim)), -np.eye(dim)]),
+            np.zeros(dim + 1), [("epinormspectral", Xn, Xm, use_dual)],
+            dict(status="Optimal", primal_obj=0.0, x_norm=0.0))
+
+
+def epinormspectral4(use_dual):   # :1127-1155
+    G = np.zeros((7, 1))
+    G[0, 0] = -1
+    h = np.array([0.0, 1, 1, 1, -1, 0, 1])
+    invrt2, invrt3 = 1 / RT2, 1 / RT3
+    if use_dual:
+        exp = dict(status="Optimal", primal_obj=RT2 + RT3, s=[RT2 + RT3, 1, 1, 1, -1, 0, 1],
+                   z=[1, -invrt2, -invrt3, -invrt2, invrt3, 0, -invrt3])
+    else:
+        exp = dict(status="Optimal", primal_obj=RT3, s=[RT3, 1, 1, 1, -1, 0, 1], z=[1, 0, -invrt3, 0, invrt3, 0, -invrt3])
+    return (np.array([1.0]), np.zeros((0, 1)), np.zeros(0), G, h, [("epinormspectral", 2, 3, use_dual)], exp)
+
+
+def wsosinterpnonnegative1():   # :2286-2304
+    U, pts, Ps = pu.interpolate_box([0.0, 0.0], [1.0, 1.0], 2)
+    x, y = pts[:, 0], pts[:, 1]
+    h = x ** 4 + x ** 2 * y ** 2 + 4 * y ** 2 + 4
+    return (np.array([-1.0]), np.zeros((0, 1)), np.zeros(0), np.ones((U, 1)), h,
+            [("wsosinterpnonnegative", U, Ps, False)], dict(status="Optimal", primal_obj=-4.0, x=[4.0]))
+
+
+def wsosinterpnonnegative2():   # :2306-2324
+    U, pts, Ps = pu.interpolate_box([0.0, 0.0], [3.0, 3.0], 2)
+    x, y = pts[:, 0], pts[:, 1]
+    h = (x - 2) ** 2 + (x * y - 3) ** 2
+    return (np.array([-1.0]), np.zeros((0, 1)), np.zeros(0), np.ones((U, 1)), h,
+            [("wsosinterpnonnegative", U, Ps, False)], dict(status="Optimal", primal_obj=0.0, x=[0.0]))
+
+
+def wsosinterpnonnegative3():   # :2326-2343
+    U, pts, Ps = pu.interpolate_box([0.0, 0.0], [3.0, 3.0], 2)
+    x, y = pts[:, 0], pts[:, 1]
+    c = (x - 2) ** 2 + (x * y - 3) ** 2
+    return (c, np.ones((1, U)), np.array([1.0]), -np.eye(U), np.zeros(U),
+            [("wsosinterpnonnegative", U, Ps, True)], dict(status="Optimal", primal_obj=0.0))
+
+
+KNOWN_ANSWER = {
+    "dimension1": dimension1, "primalinfeas1": primalinfeas1, "nonnegative4": nonnegative4,
+    "possemideftri1": possemideftri1, "possemideftri2": possemideftri2, "possemideftri3": possemideftri3,
+    "possemideftri4": possemideftri4, "possemideftri8": possemideftri8, "possemideftri9": possemideftri9,
+    "epinormspectral2_primal": lambda: epinormspectral2(False), "epinormspectral2_dual": lambda: epinormspectral2(True),
+    "epinormspectral3_1x1": lambda: epinormspectral3(1, 1, False), "epinormspectral3_1x3_dual": lambda: epinormspectral3(1, 3, True),
+    "epinormspectral3_2x2": lambda: epinormspectral3(2, 2, False), "epinormspectral3_3x4_dual": lambda: epinormspectral3(3, 4, True),
+    "epinormspectral4_primal": lambda: epinormspectral4(False), "epinormspectral4_dual": lambda: epinormspectral4(True),
+    "wsosinterpnonnegative1": wsosinterpnonnegative1, "wsosinterpnonnegative2": wsosinterpnonnegative2,
+    "wsosinterpnonnegative3": wsosinterpnonnegative3,
+}
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic generators for the BASELINE.json configs
+# ----------------------------------------------------------------------------------------------
+def svec_identity(side):
+    v = np.zeros(side * (side + 1) // 2)
+    k = 0
+    for i in range(1, side + 1):
+        v[k] = 1
+        k += i + 1
+    return v
+
+
+def psd_blocks(n, sides, seed=1, dtype=np.float64):
+    """configs 2 and 4: product of PosSemidefTri(side_k) cones, dense random G (q x n), p = 0.
+    G = randn(q, n)/sqrt(n); h = G x0 + svec(I); c = -G' svec(I)  => strictly feasible primal/dual pair."""
+    rng = np.random.default_rng(seed)
+    dims = [s * (s + 1) // 2 for s in sides]
+    q = sum(dims)
+    G = np.asfortranarray(rng.standard_normal((q, n)) / np.sqrt(n))
+    x0 = rng.standard_normal(n)
+    e = np.concatenate([svec_identity(s) for s in sides])
+    h = G @ x0 + e
+    c = -(G.T @ e)
+    specs = [("possemideftri", d) for d in dims]
+    return (c, np.zeros((0, n)), np.zeros(0), G, h, specs, dict(status="Optimal"))
+
+
+def linearopt(m=50, n=100, seed=1):
+    """config 1: examples/linearopt/native.jl:15-30 with nz_frac = 1 (dense): A = 10 rand(m, n), b = A 1,
+    c = rand(n), G = -I, h = 0, Nonnegative(n)."""
+    rng = np.random.default_rng(seed)
+    A = 10 * rng.random((m, n))
+    b = A @ np.ones(n)
+    c = rng.random(n)
+    return (c, A, b, -np.eye(n), np.zeros(n), [("nonnegative", n)], dict(status="Optimal"))
+
+
+def polymin(nvars, halfdeg, use_primal, seed=1):
+    """config 5: examples/polymin/native.jl:56-90 (real, WSOS formulation), random_interp_data
+    (examples/polymin/data_real.jl:23-33) on the box [-1, 1]^n."""
+    rng = np.random.default_rng(seed)
+    U, pts, Ps = pu.interpolate_box([-1.0] * nvars, [1.0] * nvars, halfdeg, rng=rng)
+    vals = rng.standard_normal(U)
+    if use_primal:
+        return (np.array([-1.0]), np.zeros((0, 1)), np.zeros(0), np.ones((U, 1)), vals,
+                [("wsosinterpnonnegative", U, Ps, False)], dict(status="Optimal"))
+    return (vals, np.ones((1, U)), np.array([1.0]), -np.eye(U), np.zeros(U),
+            [("wsosinterpnonnegative", U, Ps, True)], dict(status="Optimal"))
+
+
+def matrixcompletion(d1, d2, seed=1, known_frac=0.8):
+    """config 3b: examples/matrixcompletion/native.jl:23-70 shape, spectral-norm objective with
+    EpiNormSpectral(d1, d2): minimize u s.t. (u, W) in cone, known entries of W fixed."""
+    rng = np.random.default_rng(seed)
+    mask = rng.random((d1, d2)) < known_frac
+    vals = rng.standard_normal((d1, d2))
+    unknown = np.argwhere(~mask.reshape(-1, order="F")).ravel()
+    nvar = 1 + unknown.shape[0]
+    dim = 1 + d1 * d2
+    G = np.zeros((dim, nvar))
+    G[0, 0] = -1
+    for j, idx in enumerate(unknown):
+        G[1 + idx, 1 + j] = -1
+    h = np.zeros(dim)
+    h[1:] = np.where(mask.reshape(-1, order="F"), vals.reshape(-1, order="F"), 0.0)
+    c = np.zeros(nvar)
+    c[0] = 1
+    return (c, np.zeros((0, nvar)), np.zeros(0), G, h, [("epinormspectral", d1, d2, False)], dict(status="Optimal"))

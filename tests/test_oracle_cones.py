@@ -1,0 +1,81 @@
+"""Pin the CPU oracle cones with the reference's own cone tests
+(/root/reference/test/cone.jl:23-114 identities at 1e3*eps; closed-form barriers :327-330, 342-346,
+505-513, 764-768; sizes from :321-325, 336-340, 499-503, 757-762)."""
+import numpy as np
+import pytest
+
+from oracle import cones as oc
+from oracle import arrayutil as au
+from oracle import polyutils as pu
+from cone_harness import run_test_oracles, run_test_barrier
+
+
+@pytest.mark.parametrize("d", [1, 2, 6])
+def test_nonnegative_oracles(d):
+    run_test_oracles(oc.Nonnegative(d))
+
+
+def test_nonnegative_barrier():
+    run_test_barrier(oc.Nonnegative(3), lambda s: -np.sum(np.log(s)))
+
+
+@pytest.mark.parametrize("side", [1, 2, 3, 5])
+def test_possemideftri_oracles(side):
+    run_test_oracles(oc.PosSemidefTri(au.svec_length(side)))
+
+
+def _smat_full(s, side):
+    m = np.zeros((side, side))
+    au.svec_to_smat(m, s)
+    return np.triu(m) + np.triu(m, 1).T
+
+
+def test_possemideftri_barrier():
+    side = 3
+    run_test_barrier(oc.PosSemidefTri(au.svec_length(side)), lambda s: -np.linalg.slogdet(_smat_full(s, side))[1])
+
+
+@pytest.mark.parametrize("d1,d2", [(1, 1), (1, 2), (2, 2), (2, 4), (3, 4)])
+def test_epinormspectral_oracles(d1, d2):
+    run_test_oracles(oc.EpiNormSpectral(d1, d2))
+
+
+def test_epinormspectral_barrier():
+    d1, d2 = 2, 3
+
+    def barrier(s):
+        u = s[0]
+        W = s[1:].reshape(d1, d2, order="F")
+        return -np.linalg.slogdet(u * u * np.eye(d1) - W @ W.T)[1] + (d1 - 1) * np.log(u)
+
+    run_test_barrier(oc.EpiNormSpectral(d1, d2), barrier)
+
+
+@pytest.mark.parametrize("nvars,halfdeg", [(1, 1), (1, 3), (2, 1), (2, 2), (3, 1)])
+def test_wsosinterpnonnegative_oracles(nvars, halfdeg):
+    U, _, Ps = pu.interpolate_box([-1.0] * nvars, [1.0] * nvars, halfdeg, sample=False)
+    run_test_oracles(oc.WSOSInterpNonnegative(U, Ps), init_tol=np.inf)
+
+
+def test_wsosinterpnonnegative_barrier():
+    U, _, Ps = pu.interpolate_box([-1.0, -1.0], [1.0, 1.0], 1, sample=False)
+    run_test_barrier(oc.WSOSInterpNonnegative(U, Ps),
+                     lambda s: -sum(np.linalg.slogdet(P.T @ (s[:, None] * P))[1] for P in Ps))
+
+
+def test_svec_roundtrip_and_order():
+    # arrayutilities.jl:163-181, 218-236: column-major upper triangle, sqrt(2) off-diagonals
+    side = 4
+    m = np.arange(16, dtype=float).reshape(4, 4)
+    m = m + m.T
+    v = np.zeros(au.svec_length(side))
+    au.smat_to_svec(v, m)
+    assert v[0] == m[0, 0] and np.isclose(v[1], m[0, 1] * np.sqrt(2)) and v[2] == m[1, 1]
+    assert np.isclose(v[au.svec_idx(3, 1)], m[1, 3] * np.sqrt(2))
+    m2 = np.zeros((4, 4))
+    au.svec_to_smat(m2, v)
+    assert np.allclose(np.triu(m2), np.triu(m))
+    # svec is an isometry: <svec(A), svec(B)> = tr(AB)
+    b = np.random.default_rng(0).standard_normal((4, 4)); b = b + b.T
+    vb = np.zeros(10); au.smat_to_svec(vb, b)
+    assert np.isclose(v @ vb, np.trace(m @ b))

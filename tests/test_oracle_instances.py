@@ -1,0 +1,40 @@
+"""Pin the CPU oracle's solver path with the reference's deterministic known-answer instances
+(/root/reference/test/nativeinstances.jl; option sets of test/runnativetests.jl:13-18 and :101-118:
+default options with default_tol_relax = 10, and QRCholDenseSystemSolver with reduce = false)."""
+import numpy as np
+import pytest
+
+from oracle import instances as inst_mod
+from oracle.build import make_model
+from oracle.solvers import Solver
+from instance_harness import build_solve_check
+
+
+@pytest.mark.parametrize("name", sorted(inst_mod.KNOWN_ANSWER))
+@pytest.mark.parametrize("reduce", [True, False])
+def test_known_answer(name, reduce):
+    inst = inst_mod.KNOWN_ANSWER[name]()
+    solver = Solver(default_tol_relax=10, reduce=reduce)
+    build_solve_check(solver, make_model(inst), inst)
+
+
+def test_linearopt_config1():
+    inst = inst_mod.linearopt(50, 100, seed=1)
+    s = build_solve_check(Solver(default_tol_relax=10), make_model(inst), inst)
+    assert s.model.n == 50 and s.model.p == 0 and s.model.q == 100   # reduced sizes, SURVEY 8d cfg 1
+
+
+def test_small_psd_blocks():
+    inst = inst_mod.psd_blocks(12, [4, 3, 5], seed=3)
+    build_solve_check(Solver(default_tol_relax=10), make_model(inst), inst)
+
+
+def test_small_polymin_both_forms():
+    for use_primal in (True, False):
+        inst = inst_mod.polymin(2, 2, use_primal, seed=2)
+        build_solve_check(Solver(default_tol_relax=10), make_model(inst), inst)
+
+
+def test_small_matrixcompletion():
+    inst = inst_mod.matrixcompletion(3, 4, seed=2)
+    build_solve_check(Solver(default_tol_relax=10), make_model(inst), inst)
