@@ -1,0 +1,135 @@
+"""ctypes binding of libhypatia_hip.so (include/hypatia_hip.h).  Loads lazily; fails loudly."""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhypatia_hip.so")
+
+c_int, c_dbl, c_vp = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
+P = ctypes.POINTER
+
+_lib = None
+_ctx = None
+
+
+class HypatiaHipError(RuntimeError):
+    pass
+
+
+# name -> argtypes  (every function returns int except hyp_last_error)
+SIGNATURES = {
+    "hyp_ctx_create": [c_int, P(c_vp)],
+    "hyp_ctx_destroy": [c_vp],
+    "hyp_device_count": [P(c_int)],
+    "hyp_get_timers": [c_vp, c_vp],
+    "hyp_reset_timers": [c_vp],
+    "hyp_cone_create_nonnegative": [c_vp, c_int, P(c_vp)],
+    "hyp_cone_create_possemideftri": [c_vp, c_int, P(c_vp)],
+    "hyp_cone_destroy": [c_vp],
+    "hyp_cone_dimension": [c_vp, P(c_int)],
+    "hyp_cone_get_nu": [c_vp, P(c_dbl)],
+    "hyp_cone_use_dual_barrier": [c_vp, P(c_int)],
+    "hyp_cone_set_initial_point": [c_vp, c_vp],
+    "hyp_cone_load_point": [c_vp, c_vp, c_dbl],
+    "hyp_cone_load_dual_point": [c_vp, c_vp],
+    "hyp_cone_reset_data": [c_vp],
+    "hyp_cone_get_point": [c_vp, c_vp],
+    "hyp_cone_get_dual_point": [c_vp, c_vp],
+    "hyp_cone_is_feas": [c_vp, P(c_int)],
+    "hyp_cone_is_dual_feas": [c_vp, P(c_int)],
+    "hyp_cone_grad": [c_vp, c_vp],
+    "hyp_cone_hess_prod": [c_vp, c_vp, c_int, c_vp, c_int, c_int],
+    "hyp_cone_inv_hess_prod": [c_vp, c_vp, c_int, c_vp, c_int, c_int],
+    "hyp_cone_hess_prod_slow": [c_vp, c_vp, c_int, c_vp, c_int, c_int],
+    "hyp_cone_use_sqrt_hess_oracles": [c_vp, c_int, P(c_int)],
+    "hyp_cone_sqrt_hess_prod": [c_vp, c_vp, c_int, c_vp, c_int, c_int],
+    "hyp_cone_inv_sqrt_hess_prod": [c_vp, c_vp, c_int, c_vp, c_int, c_int],
+    "hyp_cone_dder3": [c_vp, c_vp, c_vp],
+    "hyp_cone_check_numerics": [c_vp, P(c_int)],
+    "hyp_cone_get_proxsqr": [c_vp, c_dbl, c_int, P(c_dbl)],
+    "hyp_cone_hess": [c_vp, c_vp],
+    "hyp_cone_inv_hess": [c_vp, c_vp],
+    "hyp_sys_create": [c_vp, c_int, c_int, c_int, P(c_vp), c_int, P(c_vp)],
+    "hyp_sys_destroy": [c_vp],
+    "hyp_sys_load": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "hyp_sys_update_lhs_fact": [c_vp, P(c_int), P(c_int), P(c_int)],
+    "hyp_sys_solve3": [c_vp, c_vp, c_vp],
+    "hyp_sys_block_hess_prod": [c_vp, c_vp, c_vp],
+    "hyp_sys_mul_G": [c_vp, c_int, c_dbl, c_vp, c_dbl, c_vp],
+    "hyp_sys_get_lhs": [c_vp, c_vp],
+    "hyp_dense_gemm": [c_vp, c_int, c_int, c_int, c_int, c_int, c_dbl, c_vp, c_int, c_vp, c_int, c_dbl, c_vp, c_int],
+    "hyp_dense_potrf": [c_vp, c_int, c_vp, c_int, P(c_int)],
+    "hyp_dense_posv": [c_vp, c_int, c_vp, c_int, c_vp, P(c_int)],
+    "hyp_dense_gemv": [c_vp, c_int, c_int, c_int, c_dbl, c_vp, c_int, c_vp, c_dbl, c_vp],
+    "hyp_bench_syrk": [c_vp, c_int, c_int, c_int, P(c_dbl)],
+}
+
+
+def load_library():
+    """dlopen the library and declare every symbol of include/hypatia_hip.h (no GPU needed)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HypatiaHipError("libhypatia_hip.so is missing at %s: run __graft_entry__.build() "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    lib.hyp_last_error.argtypes = [c_vp]
+    lib.hyp_last_error.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+def lib():
+    return load_library()
+
+
+def ctx():
+    """the process-wide context on the local GPU (LOCAL_RANK selects the device)."""
+    global _ctx
+    if _ctx is None:
+        L = load_library()
+        n = c_int(0)
+        L.hyp_device_count(ctypes.byref(n))
+        if n.value <= 0:
+            raise HypatiaHipError("no HIP device visible: the hypatia.jl_amd path needs an MI355X (no CPU fallback)")
+        dev = int(os.environ.get("LOCAL_RANK", "0")) % n.value
+        h = c_vp()
+        rc = L.hyp_ctx_create(dev, ctypes.byref(h))
+        if rc != 0:
+            raise HypatiaHipError("hyp_ctx_create failed (%d): %s" % (rc, L.hyp_last_error(None).decode()))
+        _ctx = h
+    return _ctx
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = _lib.hyp_last_error(_ctx).decode() if _lib is not None else ""
+        raise HypatiaHipError("%s failed (%d): %s" % (what, rc, msg))
+
+
+def vec_ptr(a):
+    """pointer to a contiguous float64 vector (must already be contiguous: written in place)."""
+    assert a.dtype == np.float64 and a.ndim == 1 and (a.shape[0] <= 1 or a.strides[0] == 8), "need a contiguous float64 vector"
+    return a.ctypes.data_as(c_vp)
+
+
+def mat_view(a):
+    """(array, pointer, ld, ncols, is_copy) for a (dim x ncols) column-major operand."""
+    if a.ndim == 1:
+        assert a.dtype == np.float64 and (a.shape[0] <= 1 or a.strides[0] == 8)
+        return a, a.ctypes.data_as(c_vp), a.shape[0], 1, False
+    assert a.ndim == 2 and a.dtype == np.float64
+    dim, nc = a.shape
+    ok = (dim <= 1 or a.strides[0] == 8) and (nc <= 1 or (a.strides[1] % 8 == 0 and a.strides[1] >= 8 * dim))
+    if ok:
+        ld = a.strides[1] // 8 if nc > 1 else max(dim, 1)
+        return a, a.ctypes.data_as(c_vp), ld, nc, False
+    b = np.asfortranarray(a)
+    return b, b.ctypes.data_as(c_vp), max(dim, 1), nc, True

@@ -1,0 +1,17 @@
+"""Construct HIP cones / models from the (kind, params...) descriptions used by tests and bench."""
+from . import cones as hc
+from .models import Model
+
+
+def make_cone(spec):
+    kind = spec[0]
+    if kind == "nonnegative":
+        return hc.Nonnegative(spec[1])
+    if kind == "possemideftri":
+        return hc.PosSemidefTri(spec[1])
+    raise NotImplementedError("no HIP cone for %r yet (and there is no CPU fallback)" % (kind,))
+
+
+def make_model(inst):
+    c, A, b, G, h, specs = inst[:6]
+    return Model(c, A, b, G, h, [make_cone(s) for s in specs])

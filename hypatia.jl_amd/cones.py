@@ -1,0 +1,188 @@
+"""Host-side mirror of the reference's cone interface for the HIP cones.
+
+Each class is the Python counterpart of the Julia glue type a maintainer adds next to
+`Cones.PosSemidefTri` etc.: the same generics as /root/reference/src/Cones/Cones.jl
+(`load_point`, `is_feas`, `grad`, `hess_prod!`, ... here as methods), forwarding to the device
+object through the C-ABI.  Host mirrors of `point`, `dual_point`, `vec1`, `vec2` exist because the
+steppers read those fields directly (steppers/common.jl:37-46, 96-105).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib as L
+
+c_int, c_dbl, c_vp = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
+
+
+class Cone:
+    """Cones.jl:27-310 (the protocol); every oracle runs on the device."""
+
+    def __init__(self, handle):
+        self._h = handle
+        lib = L.lib()
+        d = c_int(0)
+        lib.hyp_cone_dimension(self._h, ctypes.byref(d))
+        self.dim = d.value
+        nu = c_dbl(0)
+        lib.hyp_cone_get_nu(self._h, ctypes.byref(nu))
+        self.nu = nu.value
+        udb = c_int(0)
+        lib.hyp_cone_use_dual_barrier(self._h, ctypes.byref(udb))
+        self._use_dual_barrier = bool(udb.value)
+        self.setup_data()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and L._lib is not None:
+                L._lib.hyp_cone_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # Cones.jl:34-41, 126, 138
+    def dimension(self):
+        return self.dim
+
+    def get_nu(self):
+        return self.nu
+
+    def use_dual_barrier(self):
+        return self._use_dual_barrier
+
+    def use_dder3(self):
+        return True
+
+    # Cones.jl:140-153
+    def setup_data(self):
+        self.reset_data()
+        self.point = np.zeros(self.dim)
+        self.dual_point = np.zeros(self.dim)
+        self.grad = np.zeros(self.dim)
+        self.dder3_ = np.zeros(self.dim)
+        self.vec1 = np.zeros(self.dim)
+        self.vec2 = np.zeros(self.dim)
+        self._grad_host_valid = False
+        return self
+
+    def set_initial_point(self, arr):
+        tmp = np.zeros(self.dim)
+        L.check(L.lib().hyp_cone_set_initial_point(self._h, L.vec_ptr(tmp)), "set_initial_point")
+        arr[:] = tmp
+        return arr
+
+    # Cones.jl:157-171
+    def load_point(self, point, scal=None):
+        pt = np.ascontiguousarray(point, dtype=np.float64)
+        s = 1.0 if scal is None else float(scal)
+        if scal is None:
+            self.point[:] = pt
+        else:
+            np.multiply(pt, s, out=self.point)
+        L.check(L.lib().hyp_cone_load_point(self._h, L.vec_ptr(pt), s), "load_point")
+
+    def load_dual_point(self, point):
+        pt = np.ascontiguousarray(point, dtype=np.float64)
+        self.dual_point[:] = pt
+        L.check(L.lib().hyp_cone_load_dual_point(self._h, L.vec_ptr(pt)), "load_dual_point")
+
+    # Cones.jl:185-186
+    def reset_data(self):
+        if getattr(self, "_h", None) is not None:
+            L.check(L.lib().hyp_cone_reset_data(self._h), "reset_data")
+        self._grad_host_valid = False
+
+    def _flag(self, fn, *args):
+        out = c_int(0)
+        L.check(fn(self._h, *args, ctypes.byref(out)), fn.__name__)
+        return bool(out.value)
+
+    # Cones.jl:56-71
+    def is_feas(self):
+        return self._flag(L.lib().hyp_cone_is_feas)
+
+    def is_dual_feas(self):
+        return self._flag(L.lib().hyp_cone_is_dual_feas)
+
+    def get_grad(self):
+        if not self._grad_host_valid:
+            L.check(L.lib().hyp_cone_grad(self._h, L.vec_ptr(self.grad)), "grad")
+            self._grad_host_valid = True
+        return self.grad
+
+    def _prod(self, fn, prod, arr):
+        pa, pp, ldp, ncp, pcopy = L.mat_view(prod)
+        aa, ap, lda, nca, _ = L.mat_view(arr)
+        assert ncp == nca and pa.shape[0] == self.dim and aa.shape[0] == self.dim
+        L.check(fn(self._h, pp, ldp, ap, lda, nca), fn.__name__)
+        if pcopy:
+            prod[...] = pa
+        return prod
+
+    # Cones.jl:101-118, 198-237
+    def hess_prod(self, prod, arr):
+        return self._prod(L.lib().hyp_cone_hess_prod, prod, arr)
+
+    def inv_hess_prod(self, prod, arr):
+        return self._prod(L.lib().hyp_cone_inv_hess_prod, prod, arr)
+
+    def hess_prod_slow(self, prod, arr):
+        return self._prod(L.lib().hyp_cone_hess_prod_slow, prod, arr)
+
+    def use_sqrt_hess_oracles(self, arr_dim):
+        return self._flag(L.lib().hyp_cone_use_sqrt_hess_oracles, int(arr_dim))
+
+    def sqrt_hess_prod(self, prod, arr):
+        return self._prod(L.lib().hyp_cone_sqrt_hess_prod, prod, arr)
+
+    def inv_sqrt_hess_prod(self, prod, arr):
+        return self._prod(L.lib().hyp_cone_inv_sqrt_hess_prod, prod, arr)
+
+    # Cones.jl:134
+    def dder3(self, dir):
+        d = np.ascontiguousarray(dir, dtype=np.float64)
+        L.check(L.lib().hyp_cone_dder3(self._h, L.vec_ptr(d), L.vec_ptr(self.dder3_)), "dder3")
+        return self.dder3_
+
+    def update_hess_aux(self):
+        pass
+
+    # Cones.jl:273-310
+    def check_numerics(self):
+        return self._flag(L.lib().hyp_cone_check_numerics)
+
+    def get_proxsqr(self, irtmu, use_max_prox):
+        out = c_dbl(0)
+        L.check(L.lib().hyp_cone_get_proxsqr(self._h, float(irtmu), int(bool(use_max_prox)), ctypes.byref(out)), "get_proxsqr")
+        return out.value
+
+    # Cones.jl:79-93 (explicit, tests only)
+    def hess(self):
+        H = np.zeros((self.dim, self.dim), order="F")
+        L.check(L.lib().hyp_cone_hess(self._h, H.ctypes.data_as(c_vp)), "hess")
+        return H
+
+    def inv_hess(self):
+        H = np.zeros((self.dim, self.dim), order="F")
+        L.check(L.lib().hyp_cone_inv_hess(self._h, H.ctypes.data_as(c_vp)), "inv_hess")
+        return H
+
+
+class Nonnegative(Cone):
+    """Cones.Nonnegative{Float64}(dim)  (nonnegative.jl:8-33)."""
+    is_nonnegative = True   # process.jl:37 special-cases `cone isa Cones.Nonnegative` in rescale_data
+
+    def __init__(self, dim):
+        h = c_vp()
+        L.check(L.lib().hyp_cone_create_nonnegative(L.ctx(), int(dim), ctypes.byref(h)), "hyp_cone_create_nonnegative")
+        super().__init__(h)
+
+
+class PosSemidefTri(Cone):
+    """Cones.PosSemidefTri{Float64, Float64}(dim)  (possemideftri.jl:9-46)."""
+
+    def __init__(self, dim):
+        h = c_vp()
+        L.check(L.lib().hyp_cone_create_possemideftri(L.ctx(), int(dim), ctypes.byref(h)), "hyp_cone_create_possemideftri")
+        super().__init__(h)
+        self.side = int(round((np.sqrt(1 + 8 * dim) - 1) / 2))

@@ -1,0 +1,404 @@
+// extern "C" boundary of libhypatia_hip.so (include/hypatia_hip.h).  Stages host buffers, forwards to
+// the device objects, converts exceptions to status codes.
+#include "../../include/hypatia_hip.h"
+#include "syssolver.hpp"
+#include <chrono>
+#include <cstring>
+
+using namespace hyp;
+
+struct hyp_ctx { Ctx c; hyp_ctx(int d) : c(d) {} };
+struct hyp_cone { hyp_ctx* ctx; Cone* cone; };
+struct hyp_sys { hyp_ctx* ctx; SysSolver* s; };
+
+static thread_local std::string g_last_error;
+
+#define API_BEGIN try {
+#define API_END(ctxp)                                                         \
+    return 0;                                                                 \
+  } catch (const HipError& e) {                                               \
+    g_last_error = e.what();                                                  \
+    if (ctxp) (ctxp)->c.last_error = e.what();                                \
+    return e.code;                                                            \
+  } catch (const std::exception& e) {                                         \
+    g_last_error = e.what();                                                  \
+    if (ctxp) (ctxp)->c.last_error = e.what();                                \
+    return -2;                                                                \
+  } catch (...) {                                                             \
+    g_last_error = "unknown error";                                           \
+    return -3;                                                                \
+  }
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+extern "C" {
+
+int hyp_device_count(int* out) {
+  hyp_ctx* none = nullptr;
+  API_BEGIN
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  *out = (e == hipSuccess) ? n : 0;
+  API_END(none)
+}
+
+int hyp_ctx_create(int device, hyp_ctx** out) {
+  hyp_ctx* none = nullptr;
+  API_BEGIN
+  *out = new hyp_ctx(device);
+  API_END(none)
+}
+int hyp_ctx_destroy(hyp_ctx* ctx) {
+  hyp_ctx* none = nullptr;
+  API_BEGIN
+  delete ctx;
+  API_END(none)
+}
+const char* hyp_last_error(hyp_ctx* ctx) { return ctx ? ctx->c.last_error.c_str() : g_last_error.c_str(); }
+int hyp_get_timers(hyp_ctx* ctx, double* out10) {
+  API_BEGIN
+  for (int i = 0; i < 10; ++i) out10[i] = ctx->c.timers[i];
+  API_END(ctx)
+}
+int hyp_reset_timers(hyp_ctx* ctx) {
+  API_BEGIN
+  for (int i = 0; i < 10; ++i) ctx->c.timers[i] = 0;
+  API_END(ctx)
+}
+
+// ---- cones ------------------------------------------------------------------------------------
+int hyp_cone_create_nonnegative(hyp_ctx* ctx, int dim, hyp_cone** out) {
+  API_BEGIN
+  HYP_CHECK(hipSetDevice(ctx->c.device));
+  *out = new hyp_cone{ctx, new NonnegCone(ctx->c, dim)};
+  ctx->c.sync();
+  API_END(ctx)
+}
+int hyp_cone_create_possemideftri(hyp_ctx* ctx, int dim, hyp_cone** out) {
+  API_BEGIN
+  HYP_CHECK(hipSetDevice(ctx->c.device));
+  *out = new hyp_cone{ctx, new PsdCone(ctx->c, dim)};
+  ctx->c.sync();
+  API_END(ctx)
+}
+int hyp_cone_destroy(hyp_cone* cone) {
+  hyp_ctx* ctx = cone ? cone->ctx : nullptr;
+  API_BEGIN
+  if (cone) {
+    ctx->c.sync();
+    delete cone->cone;
+    delete cone;
+  }
+  API_END(ctx)
+}
+int hyp_cone_dimension(hyp_cone* cone, int* out) { *out = cone->cone->dim; return 0; }
+int hyp_cone_get_nu(hyp_cone* cone, double* out) { *out = cone->cone->nu; return 0; }
+int hyp_cone_use_dual_barrier(hyp_cone* cone, int* out) { *out = cone->cone->use_dual_barrier ? 1 : 0; return 0; }
+
+int hyp_cone_set_initial_point(hyp_cone* cone, double* out) {
+  API_BEGIN
+  cone->cone->set_initial_point(out);
+  API_END(cone->ctx)
+}
+
+static double* stage_in(Ctx& c, DBuf& buf, const double* h, size_t n) {
+  buf.ensure(std::max<size_t>(n, 1) * sizeof(double));
+  c.h2d(buf.p, h, n * sizeof(double));
+  return buf.d();
+}
+
+int hyp_cone_load_point(hyp_cone* cone, const double* point, double scal) {
+  API_BEGIN
+  Ctx& c = cone->ctx->c;
+  double* d = stage_in(c, c.stage_a, point, cone->cone->dim);
+  cone->cone->load_point(d, scal);
+  c.sync();
+  API_END(cone->ctx)
+}
+int hyp_cone_load_dual_point(hyp_cone* cone, const double* point) {
+  API_BEGIN
+  Ctx& c = cone->ctx->c;
+  double* d = stage_in(c, c.stage_a, point, cone->cone->dim);
+  cone->cone->load_dual_point(d);
+  c.sync();
+  API_END(cone->ctx)
+}
+int hyp_cone_reset_data(hyp_cone* cone) {
+  API_BEGIN
+  cone->cone->reset_data();
+  API_END(cone->ctx)
+}
+int hyp_cone_get_point(hyp_cone* cone, double* out) {
+  API_BEGIN
+  Ctx& c = cone->ctx->c;
+  c.d2h(out, cone->cone->point.p, (size_t)cone->cone->dim * sizeof(double));
+  c.sync();
+  API_END(cone->ctx)
+}
+int hyp_cone_get_dual_point(hyp_cone* cone, double* out) {
+  API_BEGIN
+  Ctx& c = cone->ctx->c;
+  c.d2h(out, cone->cone->dual_point.p, (size_t)cone->cone->dim * sizeof(double));
+  c.sync();
+  API_END(cone->ctx)
+}
+int hyp_cone_is_feas(hyp_cone* cone, int* out) {
+  API_BEGIN
+  *out = cone->cone->is_feas() ? 1 : 0;
+  API_END(cone->ctx)
+}
+int hyp_cone_is_dual_feas(hyp_cone* cone, int* out) {
+  API_BEGIN
+  *out = cone->cone->is_dual_feas() ? 1 : 0;
+  API_END(cone->ctx)
+}
+int hyp_cone_grad(hyp_cone* cone, double* out) {
+  API_BEGIN
+  Ctx& c = cone->ctx->c;
+  HYP_REQUIRE(cone->cone->feas_updated && cone->cone->is_feas_, "grad: point not feasible / is_feas not called");
+  const double* g = cone->cone->get_grad();
+  c.d2h(out, g, (size_t)cone->cone->dim * sizeof(double));
+  c.sync();
+  API_END(cone->ctx)
+}
+
+enum ProdKind { P_HESS, P_INVHESS, P_SLOW, P_SQRT, P_INVSQRT };
+static int cone_prod(hyp_cone* cone, int kind, double* prod, int ldp, const double* arr, int lda, int ncols) {
+  API_BEGIN
+  Ctx& c = cone->ctx->c;
+  Cone* k = cone->cone;
+  HYP_REQUIRE(ncols >= 0 && ldp >= k->dim && lda >= k->dim, "prod: bad leading dimension");
+  HYP_REQUIRE(k->is_feas(), "prod: cone point is not feasible");
+  if (ncols == 0) return 0;
+  const size_t na = (size_t)lda * (ncols - 1) + k->dim, np = (size_t)ldp * (ncols - 1) + k->dim;
+  double* da = stage_in(c, c.stage_a, arr, na);
+  c.stage_b.ensure(np * sizeof(double));
+  double* dp = c.stage_b.d();
+  if (ldp != k->dim) c.h2d(dp, prod, np * sizeof(double));   // keep the gaps of a strided view intact
+  switch (kind) {
+    case P_HESS: k->hess_prod(dp, ldp, da, lda, ncols); break;
+    case P_INVHESS: k->inv_hess_prod(dp, ldp, da, lda, ncols); break;
+    case P_SLOW: k->hess_prod_slow(dp, ldp, da, lda, ncols); break;
+    case P_SQRT: k->sqrt_hess_prod(dp, ldp, da, lda, ncols); break;
+    default: k->inv_sqrt_hess_prod(dp, ldp, da, lda, ncols); break;
+  }
+  c.d2h(prod, dp, np * sizeof(double));
+  c.sync();
+  API_END(cone->ctx)
+}
+int hyp_cone_hess_prod(hyp_cone* cone, double* prod, int ldp, const double* arr, int lda, int ncols) { return cone_prod(cone, P_HESS, prod, ldp, arr, lda, ncols); }
+int hyp_cone_inv_hess_prod(hyp_cone* cone, double* prod, int ldp, const double* arr, int lda, int ncols) { return cone_prod(cone, P_INVHESS, prod, ldp, arr, lda, ncols); }
+int hyp_cone_hess_prod_slow(hyp_cone* cone, double* prod, int ldp, const double* arr, int lda, int ncols) { return cone_prod(cone, P_SLOW, prod, ldp, arr, lda, ncols); }
+int hyp_cone_sqrt_hess_prod(hyp_cone* cone, double* prod, int ldp, const double* arr, int lda, int ncols) { return cone_prod(cone, P_SQRT, prod, ldp, arr, lda, ncols); }
+int hyp_cone_inv_sqrt_hess_prod(hyp_cone* cone, double* prod, int ldp, const double* arr, int lda, int ncols) { return cone_prod(cone, P_INVSQRT, prod, ldp, arr, lda, ncols); }
+int hyp_cone_use_sqrt_hess_oracles(hyp_cone* cone, int arr_dim, int* out) {
+  API_BEGIN
+  *out = cone->cone->use_sqrt_hess_oracles(arr_dim) ? 1 : 0;
+  API_END(cone->ctx)
+}
+int hyp_cone_dder3(hyp_cone* cone, const double* dir, double* out) {
+  API_BEGIN
+  Ctx& c = cone->ctx->c;
+  Cone* k = cone->cone;
+  HYP_REQUIRE(k->grad_updated, "dder3: grad not updated");
+  double* dd = stage_in(c, c.stage_a, dir, k->dim);
+  const double* r = k->dder3(dd);
+  c.d2h(out, r, (size_t)k->dim * sizeof(double));
+  c.sync();
+  API_END(cone->ctx)
+}
+int hyp_cone_check_numerics(hyp_cone* cone, int* out) {
+  API_BEGIN
+  *out = cone->cone->check_numerics() ? 1 : 0;
+  API_END(cone->ctx)
+}
+int hyp_cone_get_proxsqr(hyp_cone* cone, double irtmu, int use_max_prox, double* out) {
+  API_BEGIN
+  *out = cone->cone->get_proxsqr(irtmu, use_max_prox != 0);
+  API_END(cone->ctx)
+}
+static int cone_explicit(hyp_cone* cone, bool inv, double* out) {
+  API_BEGIN
+  Ctx& c = cone->ctx->c;
+  Cone* k = cone->cone;
+  HYP_REQUIRE(k->is_feas(), "hess: cone point is not feasible");
+  DBuf H((size_t)k->dim * k->dim * sizeof(double));
+  if (inv) k->inv_hess_explicit(H.d(), k->dim);
+  else k->hess_explicit(H.d(), k->dim);
+  c.d2h(out, H.p, H.bytes);
+  c.sync();
+  API_END(cone->ctx)
+}
+int hyp_cone_hess(hyp_cone* cone, double* out) { return cone_explicit(cone, false, out); }
+int hyp_cone_inv_hess(hyp_cone* cone, double* out) { return cone_explicit(cone, true, out); }
+
+// ---- system solver ------------------------------------------------------------------------------
+int hyp_sys_create(hyp_ctx* ctx, int n, int p, int q, hyp_cone* const* cones, int ncones, hyp_sys** out) {
+  API_BEGIN
+  std::vector<Cone*> cs;
+  for (int k = 0; k < ncones; ++k) {
+    HYP_REQUIRE(cones[k] && cones[k]->ctx == ctx, "sys: cone belongs to another context");
+    cs.push_back(cones[k]->cone);
+  }
+  *out = new hyp_sys{ctx, new SysSolver(ctx->c, n, p, q, cs)};
+  ctx->c.sync();
+  API_END(ctx)
+}
+int hyp_sys_destroy(hyp_sys* sys) {
+  hyp_ctx* ctx = sys ? sys->ctx : nullptr;
+  API_BEGIN
+  if (sys) {
+    ctx->c.sync();
+    delete sys->s;
+    delete sys;
+  }
+  API_END(ctx)
+}
+int hyp_sys_load(hyp_sys* sys, const double* G, const double* GQ1, const double* GQ2, const double* Q, const double* R) {
+  API_BEGIN
+  const double t0 = now_s();
+  sys->s->load(G, GQ1, GQ2, Q, R);
+  sys->ctx->c.timers[4] += now_s() - t0;
+  API_END(sys->ctx)
+}
+int hyp_sys_update_lhs_fact(hyp_sys* sys, int* use_sqrt_out, int* info, int* used_fallback) {
+  API_BEGIN
+  const double t0 = now_s();
+  sys->s->update_lhs_fact(info, used_fallback);
+  sys->ctx->c.sync();
+  sys->ctx->c.timers[5] += now_s() - t0;
+  if (use_sqrt_out)
+    for (size_t k = 0; k < sys->s->use_sqrt.size(); ++k) use_sqrt_out[k] = sys->s->use_sqrt[k];
+  API_END(sys->ctx)
+}
+int hyp_sys_solve3(hyp_sys* sys, double* sol_vec, const double* rhs_vec) {
+  API_BEGIN
+  Ctx& c = sys->ctx->c;
+  SysSolver* s = sys->s;
+  HYP_REQUIRE(s->nmp == 0 || s->fact_ok, "solve3: no valid factorization (call hyp_sys_update_lhs_fact)");
+  const size_t len = (size_t)(s->n + s->p + s->q);
+  c.h2d(s->rhs.p, rhs_vec, len * sizeof(double));
+  s->solve3(s->sol.d(), s->rhs.d());
+  c.d2h(sol_vec, s->sol.p, len * sizeof(double));
+  c.sync();
+  API_END(sys->ctx)
+}
+int hyp_sys_block_hess_prod(hyp_sys* sys, double* out_q, const double* in_q) {
+  API_BEGIN
+  Ctx& c = sys->ctx->c;
+  SysSolver* s = sys->s;
+  c.h2d(s->tmpq.p, in_q, (size_t)s->q * sizeof(double));
+  s->block_hess_prod_vec(s->Gx.d(), s->tmpq.d());
+  c.d2h(out_q, s->Gx.p, (size_t)s->q * sizeof(double));
+  c.sync();
+  API_END(sys->ctx)
+}
+int hyp_sys_mul_G(hyp_sys* sys, int trans, double alpha, const double* x, double beta, double* y) {
+  API_BEGIN
+  Ctx& c = sys->ctx->c;
+  SysSolver* s = sys->s;
+  const int nx = trans ? s->q : s->n, ny = trans ? s->n : s->q;
+  double* dx = stage_in(c, c.stage_a, x, nx);
+  c.stage_b.ensure(std::max<size_t>(ny, 1) * sizeof(double));
+  if (beta != 0.0) c.h2d(c.stage_b.p, y, (size_t)ny * sizeof(double));
+  gemv(c, trans != 0, s->q, s->n, alpha, s->G.d(), s->q, dx, beta, c.stage_b.d());
+  c.d2h(y, c.stage_b.p, (size_t)ny * sizeof(double));
+  c.sync();
+  API_END(sys->ctx)
+}
+int hyp_sys_get_lhs(hyp_sys* sys, double* out) {
+  API_BEGIN
+  Ctx& c = sys->ctx->c;
+  c.d2h(out, sys->s->lhs.p, (size_t)sys->s->nmp * sys->s->nmp * sizeof(double));
+  c.sync();
+  API_END(sys->ctx)
+}
+
+// ---- dense kernels for tests / micro-benchmarks ---------------------------------------------------
+int hyp_dense_gemm(hyp_ctx* ctx, int transa, int upper, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
+                   int ldb, double beta, double* C, int ldc) {
+  API_BEGIN
+  Ctx& c = ctx->c;
+  const size_t na = (size_t)lda * (transa ? M : K), nb = (size_t)ldb * N, nc = (size_t)ldc * N;
+  DBuf dA(std::max<size_t>(na, 1) * 8), dB(std::max<size_t>(nb, 1) * 8), dC(std::max<size_t>(nc, 1) * 8);
+  c.h2d(dA.p, A, na * 8); c.h2d(dB.p, B, nb * 8); c.h2d(dC.p, C, nc * 8);
+  GemmArgs g{};
+  g.M = M; g.N = N; g.K = K; g.A = dA.d(); g.lda = lda; g.B = dB.d(); g.ldb = ldb; g.C = dC.d(); g.ldc = ldc;
+  g.alpha = alpha; g.beta = beta; g.tri = upper ? GEMM_UPPER : GEMM_FULL; g.krange = KR_ALL; g.batch = 1;
+  gemm(c, transa != 0, g);
+  c.d2h(C, dC.p, nc * 8);
+  c.sync();
+  API_END(ctx)
+}
+int hyp_dense_potrf(hyp_ctx* ctx, int n, double* A, int lda, int* info) {
+  API_BEGIN
+  Ctx& c = ctx->c;
+  DBuf dA((size_t)lda * n * 8), dinv(dinv_elems(n) * 8), dinfo(64);
+  c.h2d(dA.p, A, (size_t)lda * n * 8);
+  potrf_upper_batched(c, n, dA.d(), lda, 0, 1, dinv.d(), dinfo.i());
+  c.d2h(A, dA.p, (size_t)lda * n * 8);
+  c.d2h(c.h_info, dinfo.p, sizeof(int));
+  c.sync();
+  *info = c.h_info[0];
+  API_END(ctx)
+}
+int hyp_dense_posv(hyp_ctx* ctx, int n, double* A, int lda, double* x, int* info) {
+  API_BEGIN
+  Ctx& c = ctx->c;
+  DBuf dA((size_t)lda * n * 8), dinv(dinv_elems(n) * 8), dx((size_t)n * 8), dinfo(64);
+  c.h2d(dA.p, A, (size_t)lda * n * 8);
+  c.h2d(dx.p, x, (size_t)n * 8);
+  potrf_upper_batched(c, n, dA.d(), lda, 0, 1, dinv.d(), dinfo.i());
+  c.d2h(c.h_info, dinfo.p, sizeof(int));
+  c.sync();
+  *info = c.h_info[0];
+  if (*info == 0) {
+    trsv_upper(c, n, dA.d(), lda, dinv.d(), true, dx.d());
+    trsv_upper(c, n, dA.d(), lda, dinv.d(), false, dx.d());
+  }
+  c.d2h(A, dA.p, (size_t)lda * n * 8);
+  c.d2h(x, dx.p, (size_t)n * 8);
+  c.sync();
+  API_END(ctx)
+}
+int hyp_dense_gemv(hyp_ctx* ctx, int trans, int m, int n, double alpha, const double* A, int lda, const double* x, double beta,
+                   double* y) {
+  API_BEGIN
+  Ctx& c = ctx->c;
+  const int nx = trans ? m : n, ny = trans ? n : m;
+  DBuf dA((size_t)lda * n * 8), dx(std::max(nx, 1) * 8), dy(std::max(ny, 1) * 8);
+  c.h2d(dA.p, A, (size_t)lda * n * 8); c.h2d(dx.p, x, (size_t)nx * 8); c.h2d(dy.p, y, (size_t)ny * 8);
+  gemv(c, trans != 0, m, n, alpha, dA.d(), lda, dx.d(), beta, dy.d());
+  c.d2h(y, dy.p, (size_t)ny * 8);
+  c.sync();
+  API_END(ctx)
+}
+int hyp_bench_syrk(hyp_ctx* ctx, int N, int K, int reps, double* ms_out) {
+  API_BEGIN
+  Ctx& c = ctx->c;
+  DBuf dA((size_t)K * N * 8), dC((size_t)N * N * 8);
+  // deterministic pseudo-random fill on the host, chunked
+  std::vector<double> h((size_t)K * N);
+  uint64_t s = 88172645463325252ULL;
+  for (auto& v : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (double)(s >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0; }
+  c.h2d(dA.p, h.data(), h.size() * 8);
+  c.sync();
+  GemmArgs g{};
+  g.M = N; g.N = N; g.K = K; g.A = dA.d(); g.lda = K; g.B = dA.d(); g.ldb = K; g.C = dC.d(); g.ldc = N;
+  g.alpha = 1; g.beta = 0; g.tri = GEMM_UPPER; g.krange = KR_ALL; g.batch = 1;
+  gemm(c, true, g);
+  c.sync();
+  hipEvent_t e0, e1;
+  HYP_CHECK(hipEventCreate(&e0)); HYP_CHECK(hipEventCreate(&e1));
+  HYP_CHECK(hipEventRecord(e0, c.stream));
+  for (int r = 0; r < reps; ++r) gemm(c, true, g);
+  HYP_CHECK(hipEventRecord(e1, c.stream));
+  HYP_CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  HYP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = ms / std::max(reps, 1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  API_END(ctx)
+}
+
+}  // extern "C"

@@ -1,0 +1,534 @@
+// Dense factorization / triangular-solve / level-1,2 kernels for the Hypatia hot path on gfx950.
+//
+// Replaces these LAPACK/BLAS call sites of the reference (file:line in /root/reference):
+//   dpotrf 'U'      src/linearalgebra/dense.jl:189-200 (posdef_fact!), src/Cones/possemideftri.jl:85,94
+//   dpotrs          src/Solvers/systemsolvers/qrchol.jl:68 (ldiv!(x_sub2, fact, Q2div))
+//   dpotri/dtrtri   src/linearalgebra/dense.jl:15-22 (inv_fact!), src/Cones/possemideftri.jl:100
+//   dgemv N/T       qrchol.jl:52,73; systemsolvers/common.jl:91,94,144; Solvers.jl:432,450
+// Design: blocked right-looking Cholesky with NB = 128.  The diagonal block is factored AND inverted
+// by one workgroup with the block held in registers (2-D cyclic 16 x 16 thread grid, 8 x 8 elements
+// per thread, one barrier per column); the panel solve and trailing update are FP64-MFMA GEMMs
+// (gemm_f64.hpp) against the inverted diagonal block.  Triangular solves with one right-hand side
+// run block by block against the same inverted diagonal blocks (one fused launch per block).
+// All reductions have a fixed order: results are bitwise reproducible run to run.
+#include "hyp_internal.hpp"
+
+namespace hyp {
+
+void gemm(Ctx& c, bool transa, GemmArgs a) { HYP_CHECK(gemm_f64_launch(c.stream, transa, a)); }
+
+__global__ void potrf_diag_kernel(double* __restrict__ A, long lda, long strideA, int n, int k0, double* __restrict__ dinv,
+                                  long strideD, int* __restrict__ info);   // potrf_diag.hip
+
+void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int batch, double* dinv, int* d_info) {
+  if (n <= 0 || batch <= 0) return;
+  c.zero(d_info, sizeof(int) * batch);
+  const long strideD = (long)dinv_elems(n);
+  for (int k0 = 0; k0 < n; k0 += NB) {
+    const int nb = std::min(NB, n - k0);
+    const int m = n - k0 - nb;
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(256), 0, c.stream, A, lda, strideA, n, k0, dinv, strideD, d_info);
+    HYP_CHECK(hipGetLastError());
+    if (m > 0) {
+      double* A12 = A + (long)(k0 + nb) * lda + k0;
+      double* A22 = A + (long)(k0 + nb) * lda + (k0 + nb);
+      GemmArgs t{};   // A12 <- inv(U11)' A12   (single m-tile: in place is safe, see gemm_f64.hpp)
+      t.M = nb; t.N = m; t.K = nb;
+      t.A = dinv + (long)(k0 / NB) * NB * NB; t.lda = NB; t.strideA = strideD;
+      t.B = A12; t.ldb = lda; t.strideB = strideA;
+      t.C = A12; t.ldc = lda; t.strideC = strideA;
+      t.alpha = 1.0; t.beta = 0.0; t.tri = GEMM_FULL; t.krange = KR_LE_M; t.batch = batch;
+      gemm(c, true, t);
+      GemmArgs s{};   // A22 <- A22 - A12' A12 (upper triangle)
+      s.M = m; s.N = m; s.K = nb;
+      s.A = A12; s.lda = lda; s.strideA = strideA;
+      s.B = A12; s.ldb = lda; s.strideB = strideA;
+      s.C = A22; s.ldc = lda; s.strideC = strideA;
+      s.alpha = -1.0; s.beta = 1.0; s.tri = GEMM_UPPER; s.krange = KR_ALL; s.batch = batch;
+      gemm(c, true, s);
+    }
+  }
+}
+
+// =============================================================================================
+// triangular solve, one right-hand side: x <- U^-T x (forward) or U^-1 x (backward)
+// =============================================================================================
+// Solve op(T) x = y for one diagonal block T = U[k0:k0+nb, k0:k0+nb] (upper triangular, in global
+// memory) by true substitution -- dtrsv semantics, backward stable -- called by a whole workgroup of
+// 256 threads.  ys (LDS, NB doubles) holds y on entry and x on exit.  The block is processed as
+// 64 x 64 sub-blocks: each is staged through LDS (coalesced), solved by one wavefront with the
+// running right-hand side in registers (one lane per unknown, the pivot broadcast by a lane
+// shuffle), and its contribution to the rest of the block applied by all four wavefronts.
+__device__ void diag_solve(const double* __restrict__ T, long ldu, int nb, bool trans, double* ys, double* Ts /*LDS 64*65*/) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int nsb = (nb + 63) / 64;
+  for (int s = 0; s < nsb; ++s) {
+    const int sb = trans ? s : nsb - 1 - s;     // forward: top-down; backward: bottom-up
+    const int o = sb * 64;
+    const int w = min(64, nb - o);
+    // stage the sub-block: Ts[r * 65 + c] = T[o + r, o + c]
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int r = e & 63, c = e >> 6;
+      Ts[r * 65 + c] = (r < w && c < w && r <= c) ? T[(long)(o + c) * ldu + (o + r)] : ((r == c) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (wave == 0) {
+      double y = (lane < w) ? ys[o + lane] : 0.0;
+      if (trans) {   // U' x = y : x_j = y_j / U_jj ; y_l -= U[j, l] x_j for l > j
+        for (int jj = 0; jj < 64; ++jj) {
+          const double xj = __shfl(y, jj) / Ts[jj * 65 + jj];
+          if (lane == jj) y = xj;
+          else if (lane > jj) y -= Ts[jj * 65 + lane] * xj;
+        }
+      } else {       // U x = y : x_j = y_j / U_jj ; y_i -= U[i, j] x_j for i < j
+        for (int jj = 63; jj >= 0; --jj) {
+          const double xj = __shfl(y, jj) / Ts[jj * 65 + jj];
+          if (lane == jj) y = xj;
+          else if (lane < jj) y -= Ts[lane * 65 + jj] * xj;
+        }
+      }
+      if (lane < w) ys[o + lane] = y;
+    }
+    __syncthreads();
+    // apply this sub-block's solution to the other sub-block of the diagonal block (nb <= 128: one other)
+    if (nsb == 2 && s == 0) {
+      const int oo = trans ? 64 : 0;             // rows still to solve
+      const int wo = trans ? nb - 64 : 64;
+      const int l = tid >> 2, part = tid & 3;    // 4 threads per output
+      double acc = 0.0;
+      if (l < wo) {
+        for (int j = part * 16; j < part * 16 + 16; ++j) {
+          if (j < w) {
+            // trans: y[64 + l] -= U[j, 64 + l] x[j] (j in sub-block 0); notrans: y[l] -= U[l, 64 + j] x[64 + j]
+            const double u = trans ? T[(long)(64 + l) * ldu + j] : T[(long)(64 + j) * ldu + l];
+            acc += u * ys[o + j];
+          }
+        }
+      }
+      acc += __shfl_down(acc, 2, 4);
+      acc += __shfl_down(acc, 1, 4);
+      if (part == 0 && l < wo) ys[oo + l] -= acc;
+      __syncthreads();
+    }
+  }
+}
+
+// One fused step of the forward solve U' y = b (U upper).  Block kb has just been solved (x[kb-block]
+// final).  Workgroup 0 updates block kb+1 with ALL of its pending contribution from block kb and then
+// solves it; the other workgroups apply block kb's contribution to the columns beyond block kb+1.
+// With kb = -1 only workgroup 0 runs and solves block 0.
+__global__ __launch_bounds__(256) void trsv_fwd_step_kernel(const double* __restrict__ U, long ldu, const double* __restrict__ dinv,
+                                                            int n, int kb, double* __restrict__ x) {
+  __shared__ double xs[NB];
+  __shared__ double ys[NB];
+  const int tid = threadIdx.x;
+  const int k0 = kb * NB;
+  const int nbk = (kb >= 0) ? min(NB, n - k0) : 0;
+  const int next0 = (kb + 1) * NB;
+  if (kb >= 0) {
+    if (tid < NB) xs[tid] = (tid < nbk) ? x[k0 + tid] : 0.0;
+    __syncthreads();
+  }
+  const int sub = tid & 15, grp = tid >> 4;   // 16 lanes per column, 16 columns per pass
+  if (blockIdx.x == 0) {
+    const int nbn = min(NB, n - next0);
+    if (nbn <= 0) return;
+    if (kb >= 0) {
+      for (int cl = grp; cl < nbn; cl += 16) {
+        const double* col = U + (long)(next0 + cl) * ldu + k0;
+        double s = 0.0;
+        for (int i = sub; i < nbk; i += 16) s += col[i] * xs[i];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) s += __shfl_down(s, off, 16);
+        if (sub == 0) ys[cl] = x[next0 + cl] - s;
+      }
+    } else {
+      if (tid < nbn) ys[tid] = x[tid];
+    }
+    __syncthreads();
+    // solve the diagonal block by substitution: U_next' x_next = ys
+    __shared__ double Ts[64 * 65];
+    diag_solve(U + (long)next0 * ldu + next0, ldu, nbn, true, ys, Ts);
+    if (tid < nbn) x[next0 + tid] = ys[tid];
+  } else {
+    const int c0 = next0 + NB + (blockIdx.x - 1) * 64;
+    for (int cc = grp; cc < 64; cc += 16) {
+      const int l = c0 + cc;
+      if (l >= n) break;
+      const double* col = U + (long)l * ldu + k0;
+      double s = 0.0;
+      for (int i = sub; i < nbk; i += 16) s += col[i] * xs[i];
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) s += __shfl_down(s, off, 16);
+      if (sub == 0) x[l] -= s;
+    }
+  }
+}
+
+// One fused step of the backward solve U x = y.  Block kb (from the bottom) has just been solved.
+// Workgroup 0 updates block kb-1 and solves it; the others update the rows above block kb-1.
+// With kb = nblk only workgroup 0 runs and solves the last block.
+__global__ __launch_bounds__(256) void trsv_bwd_step_kernel(const double* __restrict__ U, long ldu, const double* __restrict__ dinv,
+                                                            int n, int nblk, int kb, double* __restrict__ x) {
+  __shared__ double xs[NB];
+  __shared__ double ys[NB];
+  __shared__ double part[NB];
+  const int tid = threadIdx.x;
+  const int k0 = kb * NB;
+  const int nbk = (kb < nblk) ? min(NB, n - k0) : 0;
+  if (kb < nblk) {
+    if (tid < NB) xs[tid] = (tid < nbk) ? x[k0 + tid] : 0.0;
+    __syncthreads();
+  }
+  if (blockIdx.x == 0) {
+    const int p0 = (kb - 1) * NB;   // previous block (always a full NB block)
+    if (kb - 1 < 0) return;
+    const int nbp = min(NB, n - p0);
+    const int i = tid & 127, half = tid >> 7;
+    double s = 0.0;
+    if (kb < nblk && i < nbp) {
+      const int l0 = half ? 64 : 0, l1 = half ? nbk : min(nbk, 64);
+      for (int l = l0; l < l1; ++l) s += U[(long)(k0 + l) * ldu + p0 + i] * xs[l];
+    }
+    if (half) part[i] = s;
+    __syncthreads();
+    if (!half && i < nbp) ys[i] = x[p0 + i] - (s + part[i]);
+    __syncthreads();
+    __shared__ double Ts[64 * 65];
+    diag_solve(U + (long)p0 * ldu + p0, ldu, nbp, false, ys, Ts);
+    if (tid < nbp) x[p0 + tid] = ys[tid];
+  } else {
+    const int rows_above = (kb - 1) * NB;   // rows [0, rows_above) get block kb's contribution
+    const int i = (blockIdx.x - 1) * 256 + tid;
+    if (i < rows_above) {
+      double s = 0.0;
+      for (int l = 0; l < nbk; ++l) s += U[(long)(k0 + l) * ldu + i] * xs[l];
+      x[i] -= s;
+    }
+  }
+}
+
+void trsv_upper(Ctx& c, int n, const double* U, long ldu, const double* dinv, bool trans, double* x) {
+  if (n <= 0) return;
+  const int nblk = (n + NB - 1) / NB;
+  if (trans) {
+    for (int kb = -1; kb < nblk - 1; ++kb) {
+      const int next0 = (kb + 1) * NB;
+      const int beyond = n - (next0 + NB);
+      const int grid = 1 + ((kb >= 0 && beyond > 0) ? (beyond + 63) / 64 : 0);
+      hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(grid), dim3(256), 0, c.stream, U, ldu, dinv, n, kb, x);
+    }
+  } else {
+    for (int kb = nblk; kb >= 1; --kb) {
+      const int rows_above = (kb - 1) * NB;
+      const int grid = 1 + ((kb < nblk && rows_above > 0) ? (rows_above + 255) / 256 : 0);
+      hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3(grid), dim3(256), 0, c.stream, U, ldu, dinv, n, nblk, kb, x);
+    }
+  }
+  HYP_CHECK(hipGetLastError());
+}
+
+// X <- op(U)^-1 X for nrhs right-hand sides through GEMMs against the inverted diagonal blocks.
+void trsm_upper_left(Ctx& c, int n, int nrhs, const double* U, long ldu, const double* dinv, bool trans, double* X, long ldx,
+                     double* work) {
+  if (n <= 0 || nrhs <= 0) return;
+  const int nblk = (n + NB - 1) / NB;
+  if (trans) {   // forward: for k: X_k <- Dinv_k' X_k ; X_{k+1:} -= U[k, k+1:]' X_k
+    for (int kb = 0; kb < nblk; ++kb) {
+      const int k0 = kb * NB, nb = std::min(NB, n - k0), m = n - k0 - nb;
+      GemmArgs t{};
+      t.M = nb; t.N = nrhs; t.K = nb; t.A = dinv + (long)kb * NB * NB; t.lda = NB;
+      t.B = X + k0; t.ldb = ldx; t.C = X + k0; t.ldc = ldx; t.alpha = 1; t.beta = 0; t.krange = KR_LE_M; t.batch = 1;
+      gemm(c, true, t);
+      if (m > 0) {
+        GemmArgs u{};
+        u.M = m; u.N = nrhs; u.K = nb; u.A = U + (long)(k0 + nb) * ldu + k0; u.lda = ldu;
+        u.B = X + k0; u.ldb = ldx; u.C = X + k0 + nb; u.ldc = ldx; u.alpha = -1; u.beta = 1; u.batch = 1;
+        gemm(c, true, u);
+      }
+    }
+  } else {       // backward: for k desc: X_k <- Dinv_k X_k ; X_{:k} -= U[:k, k] X_k
+    for (int kb = nblk - 1; kb >= 0; --kb) {
+      const int k0 = kb * NB, nb = std::min(NB, n - k0);
+      // Dinv_k X_k needs a non-aliased output (NN form reads rows of B = all of X_k): use work
+      GemmArgs t{};
+      t.M = nb; t.N = nrhs; t.K = nb; t.A = dinv + (long)kb * NB * NB; t.lda = NB;
+      t.B = X + k0; t.ldb = ldx; t.C = work; t.ldc = NB; t.alpha = 1; t.beta = 0; t.krange = KR_GE_M; t.batch = 1;
+      gemm(c, false, t);
+      HYP_CHECK(hipMemcpy2DAsync(X + k0, ldx * sizeof(double), work, NB * sizeof(double), nb * sizeof(double), nrhs,
+                                 hipMemcpyDeviceToDevice, c.stream));
+      if (k0 > 0) {
+        GemmArgs u{};
+        u.M = k0; u.N = nrhs; u.K = nb; u.A = U + (long)k0 * ldu; u.lda = ldu;
+        u.B = X + k0; u.ldb = ldx; u.C = X; u.ldc = ldx; u.alpha = -1; u.beta = 1; u.batch = 1;
+        gemm(c, false, u);
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// explicit inverse of small upper-triangular factors (cone matrices), from the diagonal-block inverses
+// =============================================================================================
+__global__ void place_dinv_kernel(const double* __restrict__ dinv, long strideD, double* __restrict__ Uinv, long ldi, long strideI,
+                                  int n) {
+  // Uinv <- 0 except diagonal blocks = dinv blocks
+  const int b = blockIdx.z;
+  const int l = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || l >= n) return;
+  double v = 0.0;
+  if (i / NB == l / NB) v = dinv[(long)b * strideD + (long)(l / NB) * NB * NB + (long)(l % NB) * NB + (i % NB)];
+  Uinv[(long)b * strideI + (long)l * ldi + i] = v;
+}
+
+void trtri_upper_batched(Ctx& c, int n, const double* U, long ldu, long strideU, const double* dinv, long strideD, double* Uinv,
+                         long ldi, long strideI, int batch) {
+  if (n <= 0 || batch <= 0) return;
+  hipLaunchKernelGGL(place_dinv_kernel, dim3((n + 127) / 128, n, batch), dim3(128), 0, c.stream, dinv, strideD, Uinv, ldi, strideI, n);
+  HYP_CHECK(hipGetLastError());
+  const int nblk = (n + NB - 1) / NB;
+  if (nblk == 1) return;
+  // block column j: Uinv[0:j0, J] = -Uinv[0:j0, 0:j0] * (U[0:j0, J] * Dinv_J)
+  DBuf& ws = c.work_tri;
+  ws.ensure((size_t)batch * n * NB * sizeof(double));
+  for (int jb = 1; jb < nblk; ++jb) {
+    const int j0 = jb * NB, nb = std::min(NB, n - j0);
+    GemmArgs t{};
+    t.M = j0; t.N = nb; t.K = nb; t.A = U + (long)j0 * ldu; t.lda = ldu; t.strideA = strideU;
+    t.B = dinv + (long)jb * NB * NB; t.ldb = NB; t.strideB = strideD;
+    t.C = ws.d(); t.ldc = n; t.strideC = (long)n * NB; t.alpha = 1; t.beta = 0; t.krange = KR_LE_N; t.batch = batch;
+    gemm(c, false, t);
+    GemmArgs u{};
+    u.M = j0; u.N = nb; u.K = j0; u.A = Uinv; u.lda = ldi; u.strideA = strideI;
+    u.B = ws.d(); u.ldb = n; u.strideB = (long)n * NB;
+    u.C = Uinv + (long)j0 * ldi; u.ldc = ldi; u.strideC = strideI; u.alpha = -1; u.beta = 0; u.krange = KR_GE_M; u.batch = batch;
+    gemm(c, false, u);
+  }
+}
+
+// =============================================================================================
+// gemv (deterministic), level-1 helpers
+// =============================================================================================
+// y = alpha A' x + beta y : one workgroup per output element (column of A), fixed reduction tree
+__global__ __launch_bounds__(256) void gemv_t_kernel(int m, int n, double alpha, const double* __restrict__ A, long lda,
+                                                     const double* __restrict__ x, double beta, double* __restrict__ y) {
+  __shared__ double red[4];
+  const int col = blockIdx.x;
+  const double* a = A + (long)col * lda;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 768 < m; i += 1024) {
+    s0 += a[i] * x[i];
+    s1 += a[i + 256] * x[i + 256];
+    s2 += a[i + 512] * x[i + 512];
+    s3 += a[i + 768] * x[i + 768];
+  }
+  for (; i < m; i += 256) s0 += a[i] * x[i];
+  double s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = (red[0] + red[1]) + (red[2] + red[3]);
+    y[col] = alpha * t + (beta != 0.0 ? beta * y[col] : 0.0);
+  }
+}
+
+// partial[chunk][row] = sum_{cols in chunk} A[row, col] x[col]
+constexpr int GEMV_N_CHUNK = 256;
+__global__ __launch_bounds__(256) void gemv_n_partial_kernel(int m, int n, const double* __restrict__ A, long lda,
+                                                             const double* __restrict__ x, double* __restrict__ partial) {
+  __shared__ double xs[GEMV_N_CHUNK];
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  const int c0 = blockIdx.y * GEMV_N_CHUNK;
+  const int nc = min(GEMV_N_CHUNK, n - c0);
+  if (threadIdx.x < nc) xs[threadIdx.x] = x[c0 + threadIdx.x];
+  __syncthreads();
+  if (row >= m) return;
+  const double* a = A + (long)c0 * lda + row;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int cidx = 0;
+  for (; cidx + 3 < nc; cidx += 4) {
+    s0 += a[(long)cidx * lda] * xs[cidx];
+    s1 += a[(long)(cidx + 1) * lda] * xs[cidx + 1];
+    s2 += a[(long)(cidx + 2) * lda] * xs[cidx + 2];
+    s3 += a[(long)(cidx + 3) * lda] * xs[cidx + 3];
+  }
+  for (; cidx < nc; ++cidx) s0 += a[(long)cidx * lda] * xs[cidx];
+  partial[(long)blockIdx.y * m + row] = (s0 + s1) + (s2 + s3);
+}
+
+__global__ void gemv_n_reduce_kernel(int m, int nchunks, double alpha, const double* __restrict__ partial, double beta,
+                                     double* __restrict__ y) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= m) return;
+  double s = 0.0;
+  for (int k = 0; k < nchunks; ++k) s += partial[(long)k * m + row];
+  y[row] = alpha * s + (beta != 0.0 ? beta * y[row] : 0.0);
+}
+
+void gemv(Ctx& c, bool trans, int m, int n, double alpha, const double* A, long lda, const double* x, double beta, double* y) {
+  if (trans) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(gemv_t_kernel, dim3(n), dim3(256), 0, c.stream, m, n, alpha, A, lda, x, beta, y);
+  } else {
+    if (m <= 0) return;
+    const int nchunks = (n + GEMV_N_CHUNK - 1) / GEMV_N_CHUNK;
+    c.scratch.ensure(std::max<size_t>((size_t)nchunks * m * sizeof(double), 4096));
+    if (nchunks > 0)
+      hipLaunchKernelGGL(gemv_n_partial_kernel, dim3((m + 255) / 256, nchunks), dim3(256), 0, c.stream, m, n, A, lda, x, c.scratch.d());
+    hipLaunchKernelGGL(gemv_n_reduce_kernel, dim3((m + 255) / 256), dim3(256), 0, c.stream, m, nchunks, alpha, c.scratch.d(), beta, y);
+  }
+  HYP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(1024) void dot_kernel(int n, const double* __restrict__ x, const double* __restrict__ y,
+                                                   double* __restrict__ out) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) s += x[i] * y[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < 16; ++k) t += red[k];
+    *out = t;
+  }
+}
+void dev_dot(Ctx& c, int n, const double* x, const double* y, double* d_out) {
+  hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(1024), 0, c.stream, n, x, y, d_out);
+  HYP_CHECK(hipGetLastError());
+}
+
+__global__ void axpby_kernel(int n, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = a * x[i] + (b != 0.0 ? b * y[i] : 0.0);
+}
+void dev_axpby(Ctx& c, int n, double a, const double* x, double b, double* y) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, c.stream, n, a, x, b, y);
+  HYP_CHECK(hipGetLastError());
+}
+void dev_scale_copy(Ctx& c, int n, double a, const double* x, double* y) { dev_axpby(c, n, a, x, 0.0, y); }
+
+__global__ void transpose_kernel(int m, int n, const double* __restrict__ A, long lda, double* __restrict__ B, long ldb, long strideA,
+                                 long strideB) {
+  __shared__ double tile[32][33];
+  const double* a = A + (long)blockIdx.z * strideA;
+  double* b = B + (long)blockIdx.z * strideB;
+  const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+  for (int jj = threadIdx.y; jj < 32; jj += 8) {
+    const int i = i0 + threadIdx.x, j = j0 + jj;
+    if (i < m && j < n) tile[jj][threadIdx.x] = a[(long)j * lda + i];
+  }
+  __syncthreads();
+  for (int ii = threadIdx.y; ii < 32; ii += 8) {
+    const int j = j0 + threadIdx.x, i = i0 + ii;
+    if (i < m && j < n) b[(long)i * ldb + j] = tile[threadIdx.x][ii];
+  }
+}
+void dev_transpose(Ctx& c, int m, int n, const double* A, long lda, double* B, long ldb, int batch, long strideA, long strideB) {
+  if (m <= 0 || n <= 0 || batch <= 0) return;
+  hipLaunchKernelGGL(transpose_kernel, dim3((m + 31) / 32, (n + 31) / 32, batch), dim3(32, 8), 0, c.stream, m, n, A, lda, B, ldb,
+                     strideA, strideB);
+  HYP_CHECK(hipGetLastError());
+}
+
+__global__ void identity_kernel(int n, double* A, long lda) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  if (i < n) A[(long)j * lda + i] = (i == j) ? 1.0 : 0.0;
+}
+void dev_fill_identity(Ctx& c, int n, double* A, long lda) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(identity_kernel, dim3((n + 255) / 256, n), dim3(256), 0, c.stream, n, A, lda);
+  HYP_CHECK(hipGetLastError());
+}
+
+__global__ void symmetrize_kernel(int n, double* A, long lda, long stride) {
+  double* a = A + (long)blockIdx.z * stride;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // row
+  const int j = blockIdx.y;                               // col
+  if (i < n && i > j) a[(long)j * lda + i] = a[(long)i * lda + j];
+}
+void dev_symmetrize_from_upper(Ctx& c, int n, double* A, long lda, int batch, long stride) {
+  if (n <= 0 || batch <= 0) return;
+  hipLaunchKernelGGL(symmetrize_kernel, dim3((n + 127) / 128, n, batch), dim3(128), 0, c.stream, n, A, lda, stride);
+  HYP_CHECK(hipGetLastError());
+}
+__global__ void zero_lower_kernel(int n, double* A, long lda, long stride) {
+  double* a = A + (long)blockIdx.z * stride;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  if (i < n && i > j) a[(long)j * lda + i] = 0.0;
+}
+void dev_zero_strict_lower(Ctx& c, int n, double* A, long lda, int batch, long stride) {
+  if (n <= 0 || batch <= 0) return;
+  hipLaunchKernelGGL(zero_lower_kernel, dim3((n + 127) / 128, n, batch), dim3(128), 0, c.stream, n, A, lda, stride);
+  HYP_CHECK(hipGetLastError());
+}
+
+// =============================================================================================
+// svec <-> smat (src/Cones/arrayutilities.jl:163-181, 218-236): column-major upper triangle,
+// (i <= j) -> j(j+1)/2 + i, off-diagonals scaled by sqrt(2)
+// =============================================================================================
+__global__ void svec_unpack_div_kernel(int side, const double* __restrict__ arr, long ldarr, double* __restrict__ mats) {
+  const int col = blockIdx.z;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  if (i >= side) return;
+  const int hi = max(i, j), lo = min(i, j);
+  double v = arr[(long)col * ldarr + (long)hi * (hi + 1) / 2 + lo];
+  if (i != j) v = v / 1.4142135623730951;   // vec[k] / rt2 exactly as arrayutilities.jl:231
+  mats[(long)col * side * side + (long)j * side + i] = v;
+}
+void svec_unpack(Ctx& c, int side, int ncols, const double* arr, long ldarr, double* mats) {
+  if (ncols <= 0) return;
+  for (int c0 = 0; c0 < ncols; c0 += 65535) {
+    const int nc = std::min(65535, ncols - c0);
+    hipLaunchKernelGGL(svec_unpack_div_kernel, dim3((side + 63) / 64, side, nc), dim3(64), 0, c.stream, side, arr + (long)c0 * ldarr,
+                       ldarr, mats + (long)c0 * side * side);
+  }
+  HYP_CHECK(hipGetLastError());
+}
+__global__ void svec_pack_kernel(int side, const double* __restrict__ mats, double* __restrict__ arr, long ldarr, double scale) {
+  const int col = blockIdx.z;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  if (i > j) return;
+  double v = mats[(long)col * side * side + (long)j * side + i];
+  if (i != j) v *= 1.4142135623730951;   // mat[i, j] * rt2, arrayutilities.jl:176
+  arr[(long)col * ldarr + (long)j * (j + 1) / 2 + i] = scale * v;
+}
+void svec_pack(Ctx& c, int side, int ncols, const double* mats, double* arr, long ldarr, double scale) {
+  if (ncols <= 0) return;
+  for (int c0 = 0; c0 < ncols; c0 += 65535) {
+    const int nc = std::min(65535, ncols - c0);
+    hipLaunchKernelGGL(svec_pack_kernel, dim3((side + 63) / 64, side, nc), dim3(64), 0, c.stream, side, mats + (long)c0 * side * side,
+                       arr + (long)c0 * ldarr, ldarr, scale);
+  }
+  HYP_CHECK(hipGetLastError());
+}
+
+// =============================================================================================
+Ctx::Ctx(int dev) : device(dev) {
+  HYP_CHECK(hipSetDevice(dev));
+  HYP_CHECK(hipStreamCreate(&stream));
+  scratch.alloc(1 << 20);
+  dscal.alloc(64 * sizeof(double));
+  HYP_CHECK(hipHostMalloc((void**)&h_info, 64 * sizeof(int), hipHostMallocDefault));
+  h_pinned_n = 1 << 16;
+  HYP_CHECK(hipHostMalloc((void**)&h_pinned, h_pinned_n * sizeof(double), hipHostMallocDefault));
+}
+Ctx::~Ctx() {
+  if (h_info) (void)hipHostFree(h_info);
+  if (h_pinned) (void)hipHostFree(h_pinned);
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+}  // namespace hyp

@@ -51,187 +51,12 @@ struct GemmArgs {
   int krange;   // GemmKRange
   int batch;
   int tiles_m, tiles_n;
-  // optional second-level batch (for "batch of batches": cone index x column index)
+  // composite row index of C (0 = off): row m is stored at (m / cm_blk) * cm_stride + (m % cm_blk).
+  // Lets an M-stacked batch (rows = (matrix j, row a)) write each j into its own contiguous block.
+  int cm_blk; long cm_stride;
 };
 
-constexpr int BM = 128, BN = 128, BK = 16, LDS_S = BK + 2;
-constexpr int GEMM_THREADS = 256;
-
-// map a linear index over the upper triangle (tn >= tm) of a T x T tile grid to (tm, tn),
-// column by column: idx = tn*(tn+1)/2 + tm.
-__device__ __forceinline__ void upper_tile_from_linear(int idx, int& tm, int& tn) {
-  int t = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
-  while ((long)(t + 1) * (t + 2) / 2 <= idx) ++t;
-  while ((long)t * (t + 1) / 2 > idx) --t;
-  tn = t;
-  tm = idx - t * (t + 1) / 2;
-}
-
-template <bool TRANSA>
-__global__ __launch_bounds__(GEMM_THREADS, 2)
-void gemm_f64_kernel(GemmArgs p) {
-  __shared__ double lds[2][2][BM * LDS_S];   // [buffer][A/B][row*LDS_S + k]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
-
-  int tm, tn;
-  const int bz = blockIdx.y;   // batch index
-  if (p.tri == GEMM_UPPER) {
-    upper_tile_from_linear(blockIdx.x, tm, tn);
-  } else {
-    tm = blockIdx.x % p.tiles_m;
-    tn = blockIdx.x / p.tiles_m;
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  const double* __restrict__ A = p.A + (long)bz * p.strideA;
-  const double* __restrict__ B = p.B + (long)bz * p.strideB;
-  double* __restrict__ C = p.C + (long)bz * p.strideC;
-
-  // K range
-  int kbeg = 0, kend = p.K;
-  switch (p.krange) {
-    case KR_LE_M: kend = min(p.K, m0 + BM); break;
-    case KR_GE_M: kbeg = min(p.K, m0) & ~(BK - 1); break;
-    case KR_LE_N: kend = min(p.K, n0 + BN); break;
-    case KR_GE_N: kbeg = min(p.K, n0) & ~(BK - 1); break;
-    default: break;
-  }
-
-  d4_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
-
-  // staging registers: 8 doubles of the A tile, 8 of the B tile per thread
-  double ra[8], rb[8];
-
-  // TN loader: k = tid & 15, row = (tid >> 4) + 16 * rep  (16 lanes read 128 contiguous bytes)
-  // NN loader (A only): row = tid & 127, k = (tid >> 7) + 2 * rep (128 lanes read 1 KiB contiguous)
-  const int lk = tid & 15, lr = tid >> 4;
-  const int nn_r = tid & 127, nn_k = tid >> 7;
-
-  auto load_tiles = [&](int k0) {
-    if (TRANSA) {
-      const int k = k0 + lk;
-      const bool kok = (k < kend);
-#pragma unroll
-      for (int rep = 0; rep < 8; ++rep) {
-        const int m = m0 + lr + 16 * rep;
-        ra[rep] = (kok && m < p.M) ? A[(long)m * p.lda + k] : 0.0;
-      }
-    } else {
-      const int m = m0 + nn_r;
-      const bool mok = (m < p.M);
-#pragma unroll
-      for (int rep = 0; rep < 8; ++rep) {
-        const int k = k0 + nn_k + 2 * rep;
-        ra[rep] = (mok && k < kend) ? A[(long)k * p.lda + m] : 0.0;
-      }
-    }
-    {
-      const int k = k0 + lk;
-      const bool kok = (k < kend);
-#pragma unroll
-      for (int rep = 0; rep < 8; ++rep) {
-        const int n = n0 + lr + 16 * rep;
-        rb[rep] = (kok && n < p.N) ? B[(long)n * p.ldb + k] : 0.0;
-      }
-    }
-  };
-
-  auto store_tiles = [&](int buf) {
-    double* As = lds[buf][0];
-    double* Bs = lds[buf][1];
-    if (TRANSA) {
-#pragma unroll
-      for (int rep = 0; rep < 8; ++rep) As[(lr + 16 * rep) * LDS_S + lk] = ra[rep];
-    } else {
-#pragma unroll
-      for (int rep = 0; rep < 8; ++rep) As[nn_r * LDS_S + nn_k + 2 * rep] = ra[rep];
-    }
-#pragma unroll
-    for (int rep = 0; rep < 8; ++rep) Bs[(lr + 16 * rep) * LDS_S + lk] = rb[rep];
-  };
-
-  const int fr = lane & 15, fk = lane >> 4;
-
-  auto compute = [&](int buf) {
-    const double* As = lds[buf][0] + (wm * 64 + fr) * LDS_S + fk;
-    const double* Bs = lds[buf][1] + (wn * 64 + fr) * LDS_S + fk;
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 4) {
-      double af[4], bf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = As[i * 16 * LDS_S + kk];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = Bs[j * 16 * LDS_S + kk];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[j][i], 0, 0, 0);
-    }
-  };
-
-  const int nkt = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
-  if (nkt > 0) {
-    load_tiles(kbeg);
-    store_tiles(0);
-    __syncthreads();
-    for (int t = 0; t < nkt; ++t) {
-      const int buf = t & 1;
-      if (t + 1 < nkt) load_tiles(kbeg + (t + 1) * BK);
-      compute(buf);
-      if (t + 1 < nkt) store_tiles(buf ^ 1);
-      __syncthreads();
-    }
-  }
-
-  // epilogue: lane (fr, fk), accumulator register r of tile (j, i) is
-  //   C[m0 + wm*64 + i*16 + fr, n0 + wn*64 + j*16 + fk + 4r]
-  const bool upper = (p.tri == GEMM_UPPER);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = n0 + wn * 64 + j * 16 + fk + 4 * r;
-      if (n >= p.N) continue;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + fr;
-        if (m >= p.M) continue;
-        if (upper && m > n) continue;
-        double* cp = C + (long)n * p.ldc + m;
-        double v = p.alpha * acc[j][i][r];
-        if (p.beta != 0.0) v += p.beta * (*cp);
-        *cp = v;
-      }
-    }
-  }
-}
-
-inline hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a) {
-  if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return hipSuccess;
-  a.tiles_m = (a.M + BM - 1) / BM;
-  a.tiles_n = (a.N + BN - 1) / BN;
-  long nblk;
-  if (a.tri == GEMM_UPPER) {
-    int T = a.tiles_n;   // square
-    nblk = (long)T * (T + 1) / 2;
-  } else {
-    nblk = (long)a.tiles_m * a.tiles_n;
-  }
-  dim3 grid((unsigned)nblk, (unsigned)a.batch, 1);
-  if (transa)
-    hipLaunchKernelGGL(gemm_f64_kernel<true>, grid, dim3(GEMM_THREADS), 0, st, a);
-  else
-    hipLaunchKernelGGL(gemm_f64_kernel<false>, grid, dim3(GEMM_THREADS), 0, st, a);
-  return hipGetLastError();
-}
+// launch on `st`; returns the HIP launch status
+hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a);
 
 }  // namespace hyp

@@ -1,0 +1,131 @@
+// Internal declarations shared by the translation units of libhypatia_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include "gemm_f64.hpp"
+
+namespace hyp {
+
+struct HipError : std::runtime_error {
+  int code;
+  HipError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define HYP_CHECK(expr)                                                                         \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      throw hyp::HipError(-(int)e_ - 1000, std::string(#expr) + ": " + hipGetErrorString(e_) +  \
+                                                " at " __FILE__ ":" + std::to_string(__LINE__)); \
+  } while (0)
+
+#define HYP_REQUIRE(cond, msg)                                                     \
+  do {                                                                             \
+    if (!(cond)) throw hyp::HipError(-1, std::string("bad argument: ") + (msg));   \
+  } while (0)
+
+// Device buffer of doubles (or raw bytes) owned by the library.
+struct DBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DBuf() {}
+  explicit DBuf(size_t nbytes) { alloc(nbytes); }
+  DBuf(const DBuf&) = delete;
+  DBuf& operator=(const DBuf&) = delete;
+  ~DBuf() { release(); }
+  void alloc(size_t nbytes) {
+    release();
+    if (nbytes == 0) return;
+    HYP_CHECK(hipMalloc(&p, nbytes));
+    bytes = nbytes;
+  }
+  void ensure(size_t nbytes) {
+    if (nbytes > bytes) alloc(nbytes);
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  double* d() const { return (double*)p; }
+  int* i() const { return (int*)p; }
+};
+
+constexpr int NB = 128;   // Cholesky / triangular-solve block size
+
+// Context: one HIP device, one stream; owns scratch and the host<->device staging buffers.
+struct Ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+  double timers[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  DBuf scratch;       // general device scratch (gemv partial sums)
+  DBuf dscal;         // 64 device doubles for scalar results (dots, counts)
+  DBuf stage_a, stage_b;   // device staging for host-pointer entry points
+  DBuf work_tri;           // workspace of trtri_upper_batched
+  int* h_info = nullptr;    // pinned host word(s)
+  double* h_pinned = nullptr;   // pinned host staging (small vectors / scalars)
+  size_t h_pinned_n = 0;
+  Ctx(int dev);
+  ~Ctx();
+  void sync() { HYP_CHECK(hipStreamSynchronize(stream)); }
+  void h2d(void* dst, const void* src, size_t bytes) {
+    if (bytes) HYP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+  }
+  void d2h(void* dst, const void* src, size_t bytes) {
+    if (bytes) HYP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+  }
+  void d2d(void* dst, const void* src, size_t bytes) {
+    if (bytes) HYP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));
+  }
+  void zero(void* dst, size_t bytes) {
+    if (bytes) HYP_CHECK(hipMemsetAsync(dst, 0, bytes, stream));
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// dense.hip : factorizations, triangular solves, level-1/2 kernels (all on ctx.stream, device ptrs)
+// ---------------------------------------------------------------------------------------------
+
+// Blocked upper Cholesky A = U'U in place (upper triangle of each n x n matrix of the batch).
+// dinv receives inv(U_kk) for every NB-diagonal block: layout [batch][block][NB*NB] col-major, ld NB.
+// d_info[b] = 0 or the 1-based index of the first non-positive pivot (LAPACK dpotrf convention).
+void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int batch, double* dinv, int* d_info);
+inline size_t dinv_elems(int n) { return (size_t)((n + NB - 1) / NB) * NB * NB; }
+
+// x <- U^-T x (trans = true) or U^-1 x (trans = false), U upper triangular n x n with inverted
+// diagonal blocks dinv; nrhs right-hand sides, x col-major with leading dimension ldx.
+void trsv_upper(Ctx& c, int n, const double* U, long ldu, const double* dinv, bool trans, double* x);
+void trsm_upper_left(Ctx& c, int n, int nrhs, const double* U, long ldu, const double* dinv, bool trans, double* X,
+                     long ldx, double* work /* NB x nrhs */);
+// explicit inverse of an upper triangular matrix from its inverted diagonal blocks: Uinv (upper, full
+// storage, strictly-lower part zero).  Used for the small cone matrices.
+void trtri_upper_batched(Ctx& c, int n, const double* U, long ldu, long strideU, const double* dinv, long strideD,
+                         double* Uinv, long ldi, long strideI, int batch);
+
+// y = alpha * op(A) x + beta * y, A m x n col-major.  Deterministic (fixed reduction tree).
+void gemv(Ctx& c, bool trans, int m, int n, double alpha, const double* A, long lda, const double* x, double beta,
+          double* y);
+
+// level-1 helpers (device scalars are read back through ctx pinned memory by the callers)
+void dev_dot(Ctx& c, int n, const double* x, const double* y, double* d_out);          // *d_out = <x,y>
+void dev_axpby(Ctx& c, int n, double a, const double* x, double b, double* y);          // y = a x + b y
+void dev_scale_copy(Ctx& c, int n, double a, const double* x, double* y);               // y = a x
+void dev_transpose(Ctx& c, int m, int n, const double* A, long lda, double* B, long ldb, int batch, long strideA,
+                   long strideB);   // B = A' (B is n x m)
+void dev_fill_identity(Ctx& c, int n, double* A, long lda);
+void dev_symmetrize_from_upper(Ctx& c, int n, double* A, long lda, int batch, long stride);   // copytri!(A,'U')
+void dev_zero_strict_lower(Ctx& c, int n, double* A, long lda, int batch, long stride);
+
+// svec <-> smat for batches of columns: arr is (d x ncols, ld = ldarr); mats is ncols blocks of s x s
+// (col-major, contiguous).  unpack fills BOTH triangles (symmetric); pack reads the upper triangle.
+void svec_unpack(Ctx& c, int side, int ncols, const double* arr, long ldarr, double* mats);
+void svec_pack(Ctx& c, int side, int ncols, const double* mats, double* arr, long ldarr, double scale);
+
+// gemm wrapper on ctx.stream
+void gemm(Ctx& c, bool transa, GemmArgs a);
+
+}  // namespace hyp

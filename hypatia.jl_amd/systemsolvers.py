@@ -1,0 +1,167 @@
+"""QRCholDenseSystemSolver on the MI355X: host mirror of the reference's SystemSolver interface
+(/root/reference/src/Solvers/systemsolvers/qrchol.jl:104-257 and common.jl:129-208).
+
+`load`, `update_lhs`, `solve_subsystem3` are the three methods Hypatia requires of a
+`QRCholSystemSolver` subtype; they forward to hyp_sys_* of the C-ABI.  The shared
+reductions `solve_system` / `solve_subsystem4` / `setup_rhs3` are kept on the host exactly as the
+reference inherits them.
+"""
+import ctypes
+import time
+
+import numpy as np
+
+from . import _lib as L
+
+c_int, c_vp = ctypes.c_int, ctypes.c_void_p
+
+
+class SubPoint:
+    """(x, y, z) point of the 3x3 subsystem (common.jl:184-208)."""
+
+    def __init__(self, model):
+        n, p, q = model.n, model.p, model.q
+        self.vec = np.zeros(n + p + q)
+        self.x = self.vec[:n]
+        self.y = self.vec[n:n + p]
+        self.z = self.vec[n + p:]
+        self.z_views = [self.z[idx] for idx in model.cone_idxs]
+
+
+def dot_obj(model, point):   # common.jl:210-211
+    return model.c @ point.x + model.b @ point.y + model.h @ point.z
+
+
+class QRCholDenseSystemSolver:
+    def __init__(self):
+        self._h = None
+
+    def __del__(self):
+        try:
+            if self._h is not None and L._lib is not None:
+                L._lib.hyp_sys_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- qrchol.jl:138-179
+    def load(self, solver):
+        model = solver.model
+        n, p, q = model.n, model.p, model.q
+        lib = L.lib()
+        if self._h is not None:
+            lib.hyp_sys_destroy(self._h)
+            self._h = None
+        handles = (c_vp * len(model.cones))(*[cone._h for cone in model.cones])
+        h = c_vp()
+        L.check(lib.hyp_sys_create(L.ctx(), n, p, q, handles, len(model.cones), ctypes.byref(h)), "hyp_sys_create")
+        self._h = h
+        self.n, self.p, self.q = n, p, q
+        G = np.asfortranarray(model.G)
+        if p == 0:
+            L.check(lib.hyp_sys_load(h, G.ctypes.data_as(c_vp), None, None, None, None), "hyp_sys_load")
+        else:
+            GQ = model.G @ solver.Ap_Q            # qrchol.jl:154 (once per solve, host)
+            GQ1 = np.asfortranarray(GQ[:, :p])
+            GQ2 = np.asfortranarray(GQ[:, p:])
+            Q = np.asfortranarray(solver.Ap_Q)
+            R = np.asfortranarray(solver.Ap_R)
+            L.check(lib.hyp_sys_load(h, G.ctypes.data_as(c_vp), GQ1.ctypes.data_as(c_vp), GQ2.ctypes.data_as(c_vp),
+                                     Q.ctypes.data_as(c_vp), R.ctypes.data_as(c_vp)), "hyp_sys_load")
+        self.use_sqrt_hess_cones = [False] * len(model.cones)
+        # setup_point_sub (common.jl:184-208)
+        self.sol_sub = SubPoint(model)
+        self.rhs_sub = SubPoint(model)
+        self.rhs_const = SubPoint(model)
+        self.sol_const = SubPoint(model)
+        self.rhs_const.x[:] = -model.c
+        self.rhs_const.y[:] = model.b
+        self.rhs_const.z[:] = model.h
+        self.last_info = 0
+        self.used_fallback = False
+        return self
+
+    # y = alpha * op(G) x + beta * y on the device-resident model.G
+    def mul_G(self, trans, x, alpha=1.0, beta=0.0, y=None):
+        xx = np.ascontiguousarray(x, dtype=np.float64)
+        ny = self.n if trans else self.q
+        if y is None:
+            y = np.zeros(ny)
+        L.check(L.lib().hyp_sys_mul_G(self._h, int(trans), float(alpha), L.vec_ptr(xx), float(beta), L.vec_ptr(y)), "hyp_sys_mul_G")
+        return y
+
+    # ---- qrchol.jl:181-199
+    def update_lhs(self, solver):
+        model = solver.model
+        if model.n - model.p > 0:
+            self.update_lhs_fact(solver)
+        hh = np.ascontiguousarray(model.h)
+        L.check(L.lib().hyp_sys_block_hess_prod(self._h, L.vec_ptr(self.rhs_const.z), L.vec_ptr(hh)), "hyp_sys_block_hess_prod")
+        self.solve_subsystem3(solver, self.sol_const, self.rhs_const)
+        return self
+
+    # ---- qrchol.jl:201-257
+    def update_lhs_fact(self, solver):
+        nc = len(solver.model.cones)
+        flags = (c_int * max(nc, 1))()
+        info, fb = c_int(0), c_int(0)
+        t0 = time.perf_counter()
+        L.check(L.lib().hyp_sys_update_lhs_fact(self._h, flags, ctypes.byref(info), ctypes.byref(fb)), "hyp_sys_update_lhs_fact")
+        solver.time_upfact += time.perf_counter() - t0   # (assembly + factor; the split is in hyp_get_timers)
+        self.use_sqrt_hess_cones = [bool(flags[k]) for k in range(nc)]
+        self.last_info, self.used_fallback = info.value, bool(fb.value)
+        if info.value != 0:
+            print("positive definite linear system factorization failed")
+
+    # ---- qrchol.jl:39-85
+    def solve_subsystem3(self, solver, sol, rhs):
+        L.check(L.lib().hyp_sys_solve3(self._h, L.vec_ptr(sol.vec), L.vec_ptr(rhs.vec)), "hyp_sys_solve3")
+        return sol
+
+    # ---- qrchol.jl:16-37
+    def setup_rhs3(self, model, rhs, sol, rhs_sub):
+        for k, cone_k in enumerate(model.cones):
+            rhs_z_k = rhs.z_views[k]
+            rhs_s_k = rhs.s_views[k]
+            rhs_sub_z_k = rhs_sub.z_views[k]
+            if cone_k.use_dual_barrier():
+                z_temp_k = sol.z_views[k]
+                z_temp_k[:] = -rhs_z_k - rhs_s_k
+                cone_k.inv_hess_prod(rhs_sub_z_k, z_temp_k)
+            else:
+                cone_k.hess_prod(rhs_sub_z_k, rhs_z_k)
+                rhs_sub_z_k[:] = -rhs_s_k - rhs_sub_z_k
+
+    # ---- common.jl:129-182
+    def solve_system(self, solver, sol, rhs):
+        model = solver.model
+        self.solve_subsystem4(solver, sol, rhs)
+        tau = sol.tau
+        sol.s[:] = model.h * tau - rhs.z
+        self.mul_G(False, sol.x, alpha=-1.0, beta=1.0, y=sol.s)
+        taubar = solver.point.tau
+        sol.kap = -solver.mu / taubar / taubar * tau + rhs.kap
+        return sol
+
+    def solve_subsystem4(self, solver, sol, rhs):
+        model = solver.model
+        rhs_sub, sol_sub = self.rhs_sub, self.sol_sub
+        rhs_sub.x[:] = rhs.x
+        rhs_sub.y[:] = -rhs.y
+        self.setup_rhs3(model, rhs, sol, rhs_sub)
+        self.solve_subsystem3(solver, sol_sub, rhs_sub)
+        sol_const = self.sol_const
+        tau_num = rhs.tau + rhs.kap + dot_obj(model, sol_sub)
+        taubar = solver.point.tau
+        tau_denom = solver.mu / taubar / taubar - dot_obj(model, sol_const)
+        sol_tau = tau_num / tau_denom
+        dim3 = sol_sub.vec.shape[0]
+        sol.vec[:dim3] = sol_sub.vec + sol_tau * sol_const.vec
+        sol.tau = sol_tau
+        return sol
+
+    def get_lhs(self):
+        nmp = self.n - self.p
+        out = np.zeros((nmp, nmp), order="F")
+        L.check(L.lib().hyp_sys_get_lhs(self._h, out.ctypes.data_as(c_vp)), "hyp_sys_get_lhs")
+        return out

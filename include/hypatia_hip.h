@@ -1,0 +1,106 @@
+/* C-ABI of libhypatia_hip.so: the MI355X-native replacement for Hypatia.jl's per-iteration hot path.
+ *
+ * What binds to this: a Julia `ccall` glue that defines new subtypes of
+ * `Hypatia.Cones.Cone{Float64}` and `Hypatia.Solvers.QRCholSystemSolver{Float64}`; in this repo the
+ * Python mirror `hypatia.jl_amd` (ctypes) and the tests.  Citations are file:line in the reference
+ * tree (chriscoey/Hypatia.jl v0.5.1).
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, < 0 = bad argument / HIP error (see hyp_last_error),
+ *     numerical outcomes (LAPACK-style info, booleans) come back through out-pointers;
+ *   - all arrays are HOST pointers to Float64, column-major; the library copies what it keeps and
+ *     never returns pointers to its own memory; leading dimensions are passed explicitly;
+ *   - calls are synchronous; one caller thread per context; no C++ exception crosses the boundary;
+ *   - handles are opaque and freed only by the matching destroy.
+ */
+#ifndef HYPATIA_HIP_H
+#define HYPATIA_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hyp_ctx hyp_ctx;
+typedef struct hyp_cone hyp_cone;
+typedef struct hyp_sys hyp_sys;
+
+/* ---- context -------------------------------------------------------------------------------- */
+int hyp_ctx_create(int device, hyp_ctx** out);
+int hyp_ctx_destroy(hyp_ctx* ctx);
+const char* hyp_last_error(hyp_ctx* ctx);
+int hyp_device_count(int* out);
+/* timers in the order of Solvers.jl:86-96 (rescale, initx, inity, unproc, loadsys, upsys, upfact,
+ * uprhs, getdir, search); the library fills upsys/upfact, the caller the rest */
+int hyp_get_timers(hyp_ctx* ctx, double* out10);
+int hyp_reset_timers(hyp_ctx* ctx);
+
+/* ---- cone lifecycle: constructors of src/Cones/nonnegative.jl:27-33, possemideftri.jl:36-46 --- */
+int hyp_cone_create_nonnegative(hyp_ctx* ctx, int dim, hyp_cone** out);
+int hyp_cone_create_possemideftri(hyp_ctx* ctx, int dim, hyp_cone** out);
+int hyp_cone_destroy(hyp_cone* cone);
+int hyp_cone_dimension(hyp_cone* cone, int* out);            /* Cones.jl:34 */
+int hyp_cone_get_nu(hyp_cone* cone, double* out);            /* Cones.jl:41 */
+int hyp_cone_use_dual_barrier(hyp_cone* cone, int* out);     /* Cones.jl:138 */
+
+/* ---- cone state (Cones.jl:140-171, 185-186) -------------------------------------------------- */
+int hyp_cone_set_initial_point(hyp_cone* cone, double* out_dim);
+int hyp_cone_load_point(hyp_cone* cone, const double* point, double scal);   /* cone.point = scal * point */
+int hyp_cone_load_dual_point(hyp_cone* cone, const double* point);
+int hyp_cone_reset_data(hyp_cone* cone);
+int hyp_cone_get_point(hyp_cone* cone, double* out_dim);        /* mirrors the field cone.point */
+int hyp_cone_get_dual_point(hyp_cone* cone, double* out_dim);
+
+/* ---- cone oracles (Cones.jl:56-134, 189-237, 273-310) ----------------------------------------- */
+int hyp_cone_is_feas(hyp_cone* cone, int* out);
+int hyp_cone_is_dual_feas(hyp_cone* cone, int* out);
+int hyp_cone_grad(hyp_cone* cone, double* out_dim);
+/* prod, arr: dim x ncols, leading dimensions ldp, lda (SubArray views of HGQ2, qrchol.jl:162-165) */
+int hyp_cone_hess_prod(hyp_cone* cone, double* prod, int ldp, const double* arr, int lda, int ncols);
+int hyp_cone_inv_hess_prod(hyp_cone* cone, double* prod, int ldp, const double* arr, int lda, int ncols);
+int hyp_cone_hess_prod_slow(hyp_cone* cone, double* prod, int ldp, const double* arr, int lda, int ncols);
+int hyp_cone_use_sqrt_hess_oracles(hyp_cone* cone, int arr_dim, int* out);
+int hyp_cone_sqrt_hess_prod(hyp_cone* cone, double* prod, int ldp, const double* arr, int lda, int ncols);
+int hyp_cone_inv_sqrt_hess_prod(hyp_cone* cone, double* prod, int ldp, const double* arr, int lda, int ncols);
+int hyp_cone_dder3(hyp_cone* cone, const double* dir, double* out_dim);
+int hyp_cone_check_numerics(hyp_cone* cone, int* out);
+int hyp_cone_get_proxsqr(hyp_cone* cone, double irtmu, int use_max_prox, double* out);
+int hyp_cone_hess(hyp_cone* cone, double* out_dimxdim);        /* explicit, tests / sparse solvers only */
+int hyp_cone_inv_hess(hyp_cone* cone, double* out_dimxdim);
+
+/* ---- QRCholDenseSystemSolver (systemsolvers/qrchol.jl:104-257) -------------------------------- */
+/* cones[k] occupies rows sum(dim[0..k-1]) .. of z / s (Models.jl:54-66 cone_idxs) */
+int hyp_sys_create(hyp_ctx* ctx, int n, int p, int q, hyp_cone* const* cones, int ncones, hyp_sys** out);
+int hyp_sys_destroy(hyp_sys* sys);
+/* load (qrchol.jl:138-179): G = model.G (q x n).  When p == 0 pass NULL for GQ1, GQ2, Q, R (GQ2 = G,
+ * Ap_Q = I).  Otherwise GQ1 = (G*Ap_Q)[:, 1:p], GQ2 = (G*Ap_Q)[:, p+1:n], Q = Ap_Q (n x n), R = Ap_R (p x p). */
+int hyp_sys_load(hyp_sys* sys, const double* G, const double* GQ1, const double* GQ2, const double* Q, const double* R);
+/* update_lhs_fact (qrchol.jl:201-257): Schur assembly + posdef_fact_copy!.  use_sqrt_out[ncones]
+ * receives use_sqrt_hess_cones; info = 0 or leading-minor index of the failed Cholesky after the
+ * fallback; used_fallback = 1 when the first Cholesky failed. */
+int hyp_sys_update_lhs_fact(hyp_sys* sys, int* use_sqrt_out, int* info, int* used_fallback);
+/* solve_subsystem3 (qrchol.jl:39-85): vectors of length n + p + q laid out [x; y; z] */
+int hyp_sys_solve3(hyp_sys* sys, double* sol_vec, const double* rhs_vec);
+/* block_hess_prod!.(out_k, in_k, cones) on a q-vector (qrchol.jl:87-98, 191-195) */
+int hyp_sys_block_hess_prod(hyp_sys* sys, double* out_q, const double* in_q);
+/* y = alpha * op(G) x + beta * y with the device-resident model.G (qrchol.jl:52,73; common.jl:91,94,144;
+ * Solvers.jl:432,450).  trans = 0: x has n entries, y has q; trans = 1: x has q, y has n. */
+int hyp_sys_mul_G(hyp_sys* sys, int trans, double alpha, const double* x, double beta, double* y);
+int hyp_sys_get_lhs(hyp_sys* sys, double* out_nmpxnmp);        /* upper triangle meaningful (tests) */
+
+/* ---- dense kernels exposed for parity tests and micro-benchmarks ------------------------------- */
+/* C = alpha * op(A) * B + beta * C (col-major; transa: A is K x M; upper != 0: only col >= row) */
+int hyp_dense_gemm(hyp_ctx* ctx, int transa, int upper, int M, int N, int K, double alpha, const double* A, int lda,
+                   const double* B, int ldb, double beta, double* C, int ldc);
+/* in-place upper Cholesky (dpotrf 'U'); info as LAPACK */
+int hyp_dense_potrf(hyp_ctx* ctx, int n, double* A, int lda, int* info);
+/* dposv 'U': A (upper triangle read) is overwritten by its Cholesky factor U, x (in: b) by A^-1 b */
+int hyp_dense_posv(hyp_ctx* ctx, int n, double* A, int lda, double* x, int* info);
+/* y = alpha * op(A) x + beta * y */
+int hyp_dense_gemv(hyp_ctx* ctx, int trans, int m, int n, double alpha, const double* A, int lda, const double* x, double beta,
+                   double* y);
+/* time `reps` launches of the syrk C = A'A (A is K x N) with HIP events on the library stream; ms per launch */
+int hyp_bench_syrk(hyp_ctx* ctx, int N, int K, int reps, double* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

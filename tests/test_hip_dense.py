@@ -1,0 +1,89 @@
+"""GPU parity of the dense kernels (through the C-ABI) against numpy/LAPACK."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+c_int, c_vp = ctypes.c_int, ctypes.c_void_p
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import hypatia_jl_amd as H
+    return H._lib.lib(), H._lib.ctx(), H._lib
+
+
+def fp(a):
+    return a.ctypes.data_as(c_vp)
+
+
+@pytest.mark.parametrize("transa,M,N,K,upper", [(1, 300, 200, 100, 0), (0, 131, 77, 45, 0), (1, 260, 260, 513, 1), (1, 5, 3, 2, 0)])
+def test_gemm(hip, transa, M, N, K, upper):
+    lib, ctx, L = hip
+    rng = np.random.default_rng(0)
+    A = np.asfortranarray(rng.standard_normal((K, M) if transa else (M, K)))
+    B = np.asfortranarray(rng.standard_normal((K, N)))
+    C = np.asfortranarray(rng.standard_normal((M, N)))
+    C0 = C.copy()
+    L.check(lib.hyp_dense_gemm(ctx, transa, upper, M, N, K, 0.7, fp(A), A.shape[0], fp(B), K, -0.3, fp(C), M), "gemm")
+    ref = 0.7 * ((A.T if transa else A) @ B) - 0.3 * C0
+    if upper:
+        iu = np.triu_indices(M)
+        assert np.allclose(C[iu], ref[iu], rtol=1e-13, atol=1e-12)
+        il = np.tril_indices(M, -1)
+        assert np.array_equal(C[il], C0[il])
+    else:
+        assert np.allclose(C, ref, rtol=1e-13, atol=1e-12)
+
+
+@pytest.mark.parametrize("n", [1, 7, 128, 129, 200, 515])
+def test_potrf_and_posv(hip, n):
+    lib, ctx, L = hip
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, n + 3))
+    A = np.asfortranarray(M @ M.T + 0.5 * np.eye(n))
+    b = rng.standard_normal(n)
+    Uref = np.linalg.cholesky(A).T
+    Ad = A.copy(order="F")
+    info = c_int(-1)
+    L.check(lib.hyp_dense_potrf(ctx, n, fp(Ad), n, ctypes.byref(info)), "potrf")
+    assert info.value == 0
+    assert np.allclose(np.triu(Ad), Uref, rtol=1e-11, atol=1e-12)
+    # strictly lower triangle untouched (dpotrf 'U' semantics)
+    assert np.array_equal(np.tril(Ad, -1), np.tril(A, -1))
+    Ad = A.copy(order="F")
+    x = b.copy()
+    L.check(lib.hyp_dense_posv(ctx, n, fp(Ad), n, fp(x), ctypes.byref(info)), "posv")
+    assert info.value == 0
+    xref = np.linalg.solve(A, b)
+    assert np.linalg.norm(x - xref) <= 1e-10 * np.linalg.norm(xref) * np.linalg.cond(A)
+
+
+def test_potrf_reports_failed_minor(hip):
+    lib, ctx, L = hip
+    n = 200
+    rng = np.random.default_rng(3)
+    M = rng.standard_normal((n, n))
+    A = M @ M.T + np.eye(n)
+    A[150, 150] = -1.0     # leading minor 151 is not positive definite
+    Ad = np.asfortranarray(A)
+    info = c_int(0)
+    L.check(lib.hyp_dense_potrf(ctx, n, fp(Ad), n, ctypes.byref(info)), "potrf")
+    import scipy.linalg.lapack as lp
+    _, iref = lp.dpotrf(A, lower=0)
+    assert info.value == iref == 151
+
+
+@pytest.mark.parametrize("trans,m,n", [(0, 1000, 300), (1, 1000, 300), (0, 3, 5), (1, 20100, 64)])
+def test_gemv(hip, trans, m, n):
+    lib, ctx, L = hip
+    rng = np.random.default_rng(1)
+    A = np.asfortranarray(rng.standard_normal((m, n)))
+    x = rng.standard_normal(m if trans else n)
+    y = rng.standard_normal(n if trans else m)
+    y0 = y.copy()
+    L.check(lib.hyp_dense_gemv(ctx, trans, m, n, 1.5, fp(A), m, fp(x), -0.5, fp(y)), "gemv")
+    ref = 1.5 * ((A.T if trans else A) @ x) - 0.5 * y0
+    assert np.allclose(y, ref, rtol=1e-12, atol=1e-11)

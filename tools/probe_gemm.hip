@@ -7,7 +7,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <vector>
-#include "../hypatia.jl_amd/csrc/gemm_f64.hpp"
+#include "../hypatia.jl_amd/csrc/gemm_f64_kernel.hpp"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
 
