@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- IPM iterations/sec of the MI355X hot path on BASELINE.json's headline configuration.
+
+A "step" is ONE interior-point iteration of Hypatia's CombinedStepper (update_lhs: sqrt-Hessian
+products + Schur syrk + Cholesky; four direction solves with refinement; line search) on the synthetic
+dense instance of configs[1]: a single PosSemidefTri cone of side 200 (q = 20100) with a dense random
+G (q x n, n = 5000), p = 0.  Inputs are resident in HBM when the timed region starts.  If the solver
+converges inside the timed region it is put back at its initial iterate and keeps stepping.
+
+    python bench.py --gpus N --steps K --warmup W
+prints ONE JSON line (rank 0): metric/value/unit + roofline (dominant kernel = the FP64-MFMA Schur
+syrk, timed with HIP events on the library stream) + cpu_baseline (the numpy/scipy restatement in
+oracle/, timed on the host cores for a bounded number of iterations of the same instance).
+
+N > 1: one process per GPU (torch.distributed / RCCL).  The cone products of the workload are sharded
+one PosSemidefTri(side 200) block per rank ("weak" scaling: per-GPU work fixed); every iteration's
+partial Schur matrices are summed with one all-reduce.  value = blocks processed per second over all
+ranks = N * iterations/sec.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix spec; measured 77.8 with tools/probe_mfma.hip (profiles/)
+
+
+def gen_instance(n, sides, seed):
+    """configs[1] generator: G = randn(q, n)/sqrt(n), h = G x0 + svec(I), c = -G' svec(I)."""
+    rng = np.random.default_rng(seed)
+    dims = [s * (s + 1) // 2 for s in sides]
+    q = sum(dims)
+    G = np.asfortranarray(rng.standard_normal((q, n)) / np.sqrt(n))
+    x0 = rng.standard_normal(n)
+    e = np.zeros(q)
+    off = 0
+    for s, d in zip(sides, dims):
+        k = 0
+        for i in range(1, s + 1):
+            e[off + k] = 1.0
+            k += i + 1
+        off += d
+    h = G @ x0 + e
+    c = -(G.T @ e)
+    specs = [("possemideftri", d) for d in dims]
+    return (c, np.zeros((0, n)), np.zeros(0), G, h, specs, dict(status="Optimal"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=5000)
+    ap.add_argument("--side", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cpu-iters", type=int, default=2, help="oracle iterations timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--verbose", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group(backend="nccl")
+        dist = dist_mod
+
+    import hypatia_jl_amd as H
+
+    if world > 1:
+        raise SystemExit("multi-GPU bench path is wired in a later commit of this round")
+
+    inst = gen_instance(args.n, [args.side], args.seed)
+    q = inst[3].shape[0]
+    t_setup = time.perf_counter()
+    solver = H.Solver(verbose=args.verbose)
+    solver.load(H.make_model(inst))
+    solver.setup()
+    t_setup = time.perf_counter() - t_setup
+    lib, ctx = H._lib.lib(), H._lib.ctx()
+
+    def step():
+        if not solver.iterate():
+            solver.reset_iterate()
+
+    for _ in range(args.warmup):
+        step()
+    lib.hyp_reset_timers(ctx)
+    if hasattr(lib, "reset"):
+        lib.reset()
+    n_solves0 = solver.n_solves
+    n_trials0 = solver.stepper.searcher.n_trials
+    for f in ("upsys", "upfact", "uprhs", "getdir", "search"):
+        setattr(solver, "time_" + f, 0.0)
+    lib.hyp_ctx_synchronize(ctx)      # (every C-ABI call is synchronous; this is the device-wide fence)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    lib.hyp_ctx_synchronize(ctx)
+    elapsed = time.perf_counter() - t0
+
+    ks = (ctypes.c_double * 8)()
+    lib.hyp_get_kernel_stats(ctx, ks)
+    syrk_ms = ks[1] / max(ks[4], 1)
+    nmp = solver.model.n - solver.model.p
+    syrk_flops = float(nmp) * nmp * q                     # algorithmic: n^2 q
+    achieved = syrk_flops / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
+    ms_per_step = elapsed / args.steps * 1e3
+    n_solves = solver.n_solves - n_solves0
+    n_trials = solver.stepper.searcher.n_trials - n_trials0
+
+    out = {
+        "metric": "IPM iterations/sec, dense n=%d PSD-%d (Float64, QRCholDense + CombinedStepper)" % (args.n, args.side),
+        "value": args.steps / elapsed,
+        "unit": "iterations/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "configs[1]: single PosSemidefTri side=%d (q=%d), dense random G q x n, n=%d, p=0" % (args.side, q, args.n),
+                   "n": args.n, "q": q, "seed": args.seed},
+        "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<true> (Schur syrk, upper)", "achieved": achieved,
+                     "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                     "traffic": None, "launch_ms": syrk_ms, "flops_per_launch": syrk_flops},
+        "phases_ms_per_step": {"sqrt_hess_prod": ks[0] / args.steps, "syrk": ks[1] / args.steps, "cholesky": ks[2] / args.steps,
+                               "update_lhs": solver.time_upsys / args.steps * 1e3, "get_directions": solver.time_getdir / args.steps * 1e3,
+                               "update_rhs": solver.time_uprhs / args.steps * 1e3, "search": solver.time_search / args.steps * 1e3},
+        "kkt_solves_per_step": n_solves / args.steps,
+        "ms_per_kkt_solve": solver.time_getdir / max(n_solves, 1) * 1e3,
+        "search_trials_per_step": n_trials / args.steps,
+        "setup_s": t_setup,
+    }
+
+    if args.cpu_iters > 0:
+        # CPU baseline: the oracle restatement ("port") on the host cores, a bounded number of iterations
+        from oracle.build import make_model as omodel
+        from oracle.solvers import Solver as OSolver
+        os_ = OSolver(verbose=False, iter_limit=args.cpu_iters)
+        os_.load(omodel(inst))
+        os_.solve()
+        cpu_it_s = os_.num_iters / os_.iter_time if os_.iter_time > 0 else 0.0
+        out["cpu_baseline"] = {"value": cpu_it_s, "unit": "iterations/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": "first %d IPM iterations of the same instance, numpy/scipy (OpenBLAS threads = all cores)" % os_.num_iters,
+                               "s_per_iteration": (os_.iter_time / max(os_.num_iters, 1))}
+        out["speedup_vs_cpu_port"] = out["value"] / cpu_it_s if cpu_it_s > 0 else None
+    if hasattr(lib, "report"):
+        print(lib.report(), file=sys.stderr)
+        print("host wall in timed region: %.1f ms/step" % ms_per_step, file=sys.stderr)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

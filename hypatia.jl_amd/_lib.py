@@ -22,9 +22,11 @@ class HypatiaHipError(RuntimeError):
 SIGNATURES = {
     "hyp_ctx_create": [c_int, P(c_vp)],
     "hyp_ctx_destroy": [c_vp],
+    "hyp_ctx_synchronize": [c_vp],
     "hyp_device_count": [P(c_int)],
     "hyp_get_timers": [c_vp, c_vp],
     "hyp_reset_timers": [c_vp],
+    "hyp_get_kernel_stats": [c_vp, c_vp],
     "hyp_cone_create_nonnegative": [c_vp, c_int, P(c_vp)],
     "hyp_cone_create_possemideftri": [c_vp, c_int, P(c_vp)],
     "hyp_cone_destroy": [c_vp],
@@ -82,8 +84,44 @@ def load_library():
         fn.restype = c_int
     lib.hyp_last_error.argtypes = [c_vp]
     lib.hyp_last_error.restype = ctypes.c_char_p
+    if os.environ.get("HYP_PROFILE"):
+        lib = _ProfiledLib(lib)
     _lib = lib
     return lib
+
+
+class _ProfiledLib:
+    """HYP_PROFILE=1: accumulate wall time and call counts per C-ABI entry point (host-side view)."""
+
+    def __init__(self, lib):
+        import time
+        self._lib = lib
+        self.stats = {}
+        self._time = time.perf_counter
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if not name.startswith("hyp_") or name == "hyp_last_error":
+            return fn
+        stats, clock = self.stats, self._time
+
+        def wrapped(*a):
+            t0 = clock()
+            r = fn(*a)
+            st = stats.setdefault(name, [0, 0.0])
+            st[0] += 1
+            st[1] += clock() - t0
+            return r
+        wrapped.__name__ = name
+        setattr(self, name, wrapped)
+        return wrapped
+
+    def report(self):
+        rows = sorted(self.stats.items(), key=lambda kv: -kv[1][1])
+        return "\n".join("%-36s calls %6d  total %9.3f ms  avg %8.1f us" % (k, v[0], v[1] * 1e3, v[1] / v[0] * 1e6) for k, v in rows)
+
+    def reset(self):
+        self.stats.clear()
 
 
 def lib():

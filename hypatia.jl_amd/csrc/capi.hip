@@ -55,6 +55,12 @@ int hyp_ctx_destroy(hyp_ctx* ctx) {
   API_END(none)
 }
 const char* hyp_last_error(hyp_ctx* ctx) { return ctx ? ctx->c.last_error.c_str() : g_last_error.c_str(); }
+int hyp_ctx_synchronize(hyp_ctx* ctx) {
+  API_BEGIN
+  HYP_CHECK(hipSetDevice(ctx->c.device));
+  HYP_CHECK(hipDeviceSynchronize());
+  API_END(ctx)
+}
 int hyp_get_timers(hyp_ctx* ctx, double* out10) {
   API_BEGIN
   for (int i = 0; i < 10; ++i) out10[i] = ctx->c.timers[i];
@@ -63,6 +69,12 @@ int hyp_get_timers(hyp_ctx* ctx, double* out10) {
 int hyp_reset_timers(hyp_ctx* ctx) {
   API_BEGIN
   for (int i = 0; i < 10; ++i) ctx->c.timers[i] = 0;
+  for (int i = 0; i < 8; ++i) ctx->c.kstat[i] = 0;
+  API_END(ctx)
+}
+int hyp_get_kernel_stats(hyp_ctx* ctx, double* out8) {
+  API_BEGIN
+  for (int i = 0; i < 8; ++i) out8[i] = ctx->c.kstat[i];
   API_END(ctx)
 }
 

@@ -38,6 +38,7 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
       t.B = A12; t.ldb = lda; t.strideB = strideA;
       t.C = A12; t.ldc = lda; t.strideC = strideA;
       t.alpha = 1.0; t.beta = 0.0; t.tri = GEMM_FULL; t.krange = KR_LE_M; t.batch = batch;
+      t.tile_hint = 128;   // in place: all rows of a column block must belong to ONE workgroup
       gemm(c, true, t);
       GemmArgs s{};   // A22 <- A22 - A12' A12 (upper triangle)
       s.M = m; s.N = m; s.K = nb;
@@ -55,63 +56,80 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
 // =============================================================================================
 // Solve op(T) x = y for one diagonal block T = U[k0:k0+nb, k0:k0+nb] (upper triangular, in global
 // memory) by true substitution -- dtrsv semantics, backward stable -- called by a whole workgroup of
-// 256 threads.  ys (LDS, NB doubles) holds y on entry and x on exit.  The block is processed as
-// 64 x 64 sub-blocks: each is staged through LDS (coalesced), solved by one wavefront with the
-// running right-hand side in registers (one lane per unknown, the pivot broadcast by a lane
-// shuffle), and its contribution to the rest of the block applied by all four wavefronts.
-__device__ void diag_solve(const double* __restrict__ T, long ldu, int nb, bool trans, double* ys, double* Ts /*LDS 64*65*/) {
+// 256 threads.  ys (LDS, NB doubles) holds y on entry and x on exit.  The triangle is staged through
+// LDS (coalesced), the reciprocals of its diagonal are formed once, and one wavefront runs the 128
+// substitution steps with the running right-hand side in registers (two unknowns per lane, the
+// pivot broadcast by a lane shuffle, branch-free updates).  TS_LD = 129 keeps both the row reads
+// (forward) and the column reads (backward) free of LDS bank conflicts.
+constexpr int TS_LD = NB + 1;
+// broadcast lane `src` (wave-uniform) of a double: two v_readlane_b32 instead of the two ds_bpermute
+// round trips that __shfl costs on the substitution's critical path
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, src);
+  hi = __builtin_amdgcn_readlane(hi, src);
+  return __hiloint2double(hi, lo);
+}
+// issue the 64 loads of this thread's share of the diagonal block (row r = tid & 127, columns
+// (tid >> 7) + 2 k) -- called first thing in the kernel so the HBM latency overlaps the gather
+__device__ __forceinline__ void diag_issue_loads(const double* __restrict__ T, long ldu, int nb, double (&dv)[64]) {
+  const int r = threadIdx.x & (NB - 1), cb = threadIdx.x >> 7;
+#pragma unroll
+  for (int k = 0; k < 64; ++k) {
+    const int c = cb + 2 * k;
+    dv[k] = (r < nb && c < nb && r <= c) ? T[(long)c * ldu + r] : ((r == c) ? 1.0 : 0.0);
+  }
+}
+
+__device__ void diag_solve(const double (&dv)[64], int nb, bool trans, double* ys, double* Ts, double* rdiag) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int nsb = (nb + 63) / 64;
-  for (int s = 0; s < nsb; ++s) {
-    const int sb = trans ? s : nsb - 1 - s;     // forward: top-down; backward: bottom-up
-    const int o = sb * 64;
-    const int w = min(64, nb - o);
-    // stage the sub-block: Ts[r * 65 + c] = T[o + r, o + c]
-    for (int e = tid; e < 64 * 64; e += 256) {
-      const int r = e & 63, c = e >> 6;
-      Ts[r * 65 + c] = (r < w && c < w && r <= c) ? T[(long)(o + c) * ldu + (o + r)] : ((r == c) ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    if (wave == 0) {
-      double y = (lane < w) ? ys[o + lane] : 0.0;
-      if (trans) {   // U' x = y : x_j = y_j / U_jj ; y_l -= U[j, l] x_j for l > j
-        for (int jj = 0; jj < 64; ++jj) {
-          const double xj = __shfl(y, jj) / Ts[jj * 65 + jj];
-          if (lane == jj) y = xj;
-          else if (lane > jj) y -= Ts[jj * 65 + lane] * xj;
-        }
-      } else {       // U x = y : x_j = y_j / U_jj ; y_i -= U[i, j] x_j for i < j
-        for (int jj = 63; jj >= 0; --jj) {
-          const double xj = __shfl(y, jj) / Ts[jj * 65 + jj];
-          if (lane == jj) y = xj;
-          else if (lane < jj) y -= Ts[lane * 65 + jj] * xj;
-        }
-      }
-      if (lane < w) ys[o + lane] = y;
-    }
-    __syncthreads();
-    // apply this sub-block's solution to the other sub-block of the diagonal block (nb <= 128: one other)
-    if (nsb == 2 && s == 0) {
-      const int oo = trans ? 64 : 0;             // rows still to solve
-      const int wo = trans ? nb - 64 : 64;
-      const int l = tid >> 2, part = tid & 3;    // 4 threads per output
-      double acc = 0.0;
-      if (l < wo) {
-        for (int j = part * 16; j < part * 16 + 16; ++j) {
-          if (j < w) {
-            // trans: y[64 + l] -= U[j, 64 + l] x[j] (j in sub-block 0); notrans: y[l] -= U[l, 64 + j] x[64 + j]
-            const double u = trans ? T[(long)(64 + l) * ldu + j] : T[(long)(64 + j) * ldu + l];
-            acc += u * ys[o + j];
-          }
-        }
-      }
-      acc += __shfl_down(acc, 2, 4);
-      acc += __shfl_down(acc, 1, 4);
-      if (part == 0 && l < wo) ys[oo + l] -= acc;
-      __syncthreads();
-    }
+  {
+    const int r = tid & (NB - 1), cb = tid >> 7;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) Ts[r * TS_LD + cb + 2 * k] = dv[k];
   }
+  __syncthreads();
+  if (tid < NB) rdiag[tid] = 1.0 / Ts[tid * TS_LD + tid];
+  __syncthreads();
+  if (wave == 0) {
+    double y0 = (lane < nb) ? ys[lane] : 0.0;
+    double y1 = (lane + 64 < nb) ? ys[lane + 64] : 0.0;
+    if (trans) {   // U' x = y : x_j = y_j / U_jj ; y_l -= U[j, l] x_j for l > j
+#pragma unroll 4
+      for (int j = 0; j < 64; ++j) {
+        const double xj = readlane_f64(y0, j) * rdiag[j];
+        const double u0 = Ts[j * TS_LD + lane], u1 = Ts[j * TS_LD + 64 + lane];
+        y0 = (lane == j) ? xj : ((lane > j) ? y0 - u0 * xj : y0);
+        y1 = y1 - u1 * xj;
+      }
+#pragma unroll 4
+      for (int jj = 0; jj < 64; ++jj) {
+        const int j = 64 + jj;
+        const double xj = readlane_f64(y1, jj) * rdiag[j];
+        const double u1 = Ts[j * TS_LD + 64 + lane];
+        y1 = (lane == jj) ? xj : ((lane > jj) ? y1 - u1 * xj : y1);
+      }
+    } else {       // U x = y : x_j = y_j / U_jj ; y_i -= U[i, j] x_j for i < j
+#pragma unroll 4
+      for (int jj = 63; jj >= 0; --jj) {
+        const int j = 64 + jj;
+        const double xj = readlane_f64(y1, jj) * rdiag[j];
+        const double u0 = Ts[lane * TS_LD + j], u1 = Ts[(64 + lane) * TS_LD + j];
+        y1 = (lane == jj) ? xj : ((lane < jj) ? y1 - u1 * xj : y1);
+        y0 = y0 - u0 * xj;
+      }
+#pragma unroll 4
+      for (int j = 63; j >= 0; --j) {
+        const double xj = readlane_f64(y0, j) * rdiag[j];
+        const double u0 = Ts[lane * TS_LD + j];
+        y0 = (lane == j) ? xj : ((lane < j) ? y0 - u0 * xj : y0);
+      }
+    }
+    if (lane < nb) ys[lane] = y0;
+    if (lane + 64 < nb) ys[lane + 64] = y1;
+  }
+  __syncthreads();
 }
 
 // One fused step of the forward solve U' y = b (U upper).  Block kb has just been solved (x[kb-block]
@@ -122,6 +140,8 @@ __global__ __launch_bounds__(256) void trsv_fwd_step_kernel(const double* __rest
                                                             int n, int kb, double* __restrict__ x) {
   __shared__ double xs[NB];
   __shared__ double ys[NB];
+  __shared__ double rdiag[NB];
+  __shared__ double Ts[NB * TS_LD];
   const int tid = threadIdx.x;
   const int k0 = kb * NB;
   const int nbk = (kb >= 0) ? min(NB, n - k0) : 0;
@@ -134,34 +154,50 @@ __global__ __launch_bounds__(256) void trsv_fwd_step_kernel(const double* __rest
   if (blockIdx.x == 0) {
     const int nbn = min(NB, n - next0);
     if (nbn <= 0) return;
+    double dv[64];
+    diag_issue_loads(U + (long)next0 * ldu + next0, ldu, nbn, dv);
     if (kb >= 0) {
-      for (int cl = grp; cl < nbn; cl += 16) {
-        const double* col = U + (long)(next0 + cl) * ldu + k0;
+      double xr[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) xr[k] = xs[sub + 16 * k];
+#pragma unroll 2
+      for (int cl = grp; cl < NB; cl += 16) {   // 16 lanes per column, 8 independent loads per lane
+        const double* col = U + (long)(next0 + min(cl, nbn - 1)) * ldu + k0;
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (sub + 16 * k < nbk) ? col[sub + 16 * k] : 0.0;
         double s = 0.0;
-        for (int i = sub; i < nbk; i += 16) s += col[i] * xs[i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k] * xr[k];
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) s += __shfl_down(s, off, 16);
-        if (sub == 0) ys[cl] = x[next0 + cl] - s;
+        if (sub == 0 && cl < nbn) ys[cl] = x[next0 + cl] - s;
       }
     } else {
       if (tid < nbn) ys[tid] = x[tid];
     }
     __syncthreads();
     // solve the diagonal block by substitution: U_next' x_next = ys
-    __shared__ double Ts[64 * 65];
-    diag_solve(U + (long)next0 * ldu + next0, ldu, nbn, true, ys, Ts);
+    diag_solve(dv, nbn, true, ys, Ts, rdiag);
     if (tid < nbn) x[next0 + tid] = ys[tid];
   } else {
     const int c0 = next0 + NB + (blockIdx.x - 1) * 64;
+    double xr[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xr[k] = xs[sub + 16 * k];
+#pragma unroll
     for (int cc = grp; cc < 64; cc += 16) {
       const int l = c0 + cc;
-      if (l >= n) break;
-      const double* col = U + (long)l * ldu + k0;
+      const double* col = U + (long)min(l, n - 1) * ldu + k0;
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = (sub + 16 * k < nbk) ? col[sub + 16 * k] : 0.0;
       double s = 0.0;
-      for (int i = sub; i < nbk; i += 16) s += col[i] * xs[i];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[k] * xr[k];
 #pragma unroll
       for (int off = 8; off > 0; off >>= 1) s += __shfl_down(s, off, 16);
-      if (sub == 0) x[l] -= s;
+      if (sub == 0 && l < n) x[l] -= s;
     }
   }
 }
@@ -174,6 +210,8 @@ __global__ __launch_bounds__(256) void trsv_bwd_step_kernel(const double* __rest
   __shared__ double xs[NB];
   __shared__ double ys[NB];
   __shared__ double part[NB];
+  __shared__ double rdiag[NB];
+  __shared__ double Ts[NB * TS_LD];
   const int tid = threadIdx.x;
   const int k0 = kb * NB;
   const int nbk = (kb < nblk) ? min(NB, n - k0) : 0;
@@ -185,25 +223,42 @@ __global__ __launch_bounds__(256) void trsv_bwd_step_kernel(const double* __rest
     const int p0 = (kb - 1) * NB;   // previous block (always a full NB block)
     if (kb - 1 < 0) return;
     const int nbp = min(NB, n - p0);
+    double dv[64];
+    diag_issue_loads(U + (long)p0 * ldu + p0, ldu, nbp, dv);
     const int i = tid & 127, half = tid >> 7;
     double s = 0.0;
     if (kb < nblk && i < nbp) {
-      const int l0 = half ? 64 : 0, l1 = half ? nbk : min(nbk, 64);
-      for (int l = l0; l < l1; ++l) s += U[(long)(k0 + l) * ldu + p0 + i] * xs[l];
+      const int l0 = half ? 64 : 0;
+      const double* up = U + (long)(k0 + l0) * ldu + p0 + i;
+#pragma unroll
+      for (int lb = 0; lb < 64; lb += 16) {   // 16 independent loads in flight
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = (l0 + lb + k < nbk) ? up[(long)(lb + k) * ldu] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += v[k] * xs[l0 + lb + k];
+      }
     }
     if (half) part[i] = s;
     __syncthreads();
     if (!half && i < nbp) ys[i] = x[p0 + i] - (s + part[i]);
     __syncthreads();
-    __shared__ double Ts[64 * 65];
-    diag_solve(U + (long)p0 * ldu + p0, ldu, nbp, false, ys, Ts);
+    diag_solve(dv, nbp, false, ys, Ts, rdiag);
     if (tid < nbp) x[p0 + tid] = ys[tid];
   } else {
     const int rows_above = (kb - 1) * NB;   // rows [0, rows_above) get block kb's contribution
     const int i = (blockIdx.x - 1) * 256 + tid;
     if (i < rows_above) {
       double s = 0.0;
-      for (int l = 0; l < nbk; ++l) s += U[(long)(k0 + l) * ldu + i] * xs[l];
+      const double* up = U + (long)k0 * ldu + i;
+#pragma unroll
+      for (int lb = 0; lb < NB; lb += 16) {
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = (lb + k < nbk) ? up[(long)(lb + k) * ldu] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += v[k] * xs[lb + k];
+      }
       x[i] -= s;
     }
   }
@@ -240,6 +295,7 @@ void trsm_upper_left(Ctx& c, int n, int nrhs, const double* U, long ldu, const d
       GemmArgs t{};
       t.M = nb; t.N = nrhs; t.K = nb; t.A = dinv + (long)kb * NB * NB; t.lda = NB;
       t.B = X + k0; t.ldb = ldx; t.C = X + k0; t.ldc = ldx; t.alpha = 1; t.beta = 0; t.krange = KR_LE_M; t.batch = 1;
+      t.tile_hint = 128;   // in place (see potrf_upper_batched)
       gemm(c, true, t);
       if (m > 0) {
         GemmArgs u{};
@@ -521,11 +577,14 @@ Ctx::Ctx(int dev) : device(dev) {
   HYP_CHECK(hipStreamCreate(&stream));
   scratch.alloc(1 << 20);
   dscal.alloc(64 * sizeof(double));
+  for (int i = 0; i < 6; ++i) HYP_CHECK(hipEventCreate(&ev[i]));
   HYP_CHECK(hipHostMalloc((void**)&h_info, 64 * sizeof(int), hipHostMallocDefault));
   h_pinned_n = 1 << 16;
   HYP_CHECK(hipHostMalloc((void**)&h_pinned, h_pinned_n * sizeof(double), hipHostMallocDefault));
 }
 Ctx::~Ctx() {
+  for (int i = 0; i < 6; ++i)
+    if (ev[i]) (void)hipEventDestroy(ev[i]);
   if (h_info) (void)hipHostFree(h_info);
   if (h_pinned) (void)hipHostFree(h_pinned);
   if (stream) (void)hipStreamDestroy(stream);

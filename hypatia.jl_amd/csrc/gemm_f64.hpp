@@ -54,6 +54,7 @@ struct GemmArgs {
   // composite row index of C (0 = off): row m is stored at (m / cm_blk) * cm_stride + (m % cm_blk).
   // Lets an M-stacked batch (rows = (matrix j, row a)) write each j into its own contiguous block.
   int cm_blk; long cm_stride;
+  int tile_hint;   // 0 = automatic, 64 / 128 = force the block tile edge
 };
 
 // launch on `st`; returns the HIP launch status

@@ -5,7 +5,7 @@
 
 namespace hyp {
 
-constexpr int BM = 128, BN = 128, BK = 16, LDS_S = BK + 2;
+constexpr int BK = 16, LDS_S = BK + 2;
 constexpr int GEMM_THREADS = 256;
 
 // map a linear index over the upper triangle (tn >= tm) of a T x T tile grid to (tm, tn),
@@ -18,9 +18,14 @@ __device__ __forceinline__ void upper_tile_from_linear(int idx, int& tm, int& tn
   tm = idx - t * (t + 1) / 2;
 }
 
-template <bool TRANSA>
+// TW = MFMA tiles per wavefront per dimension: 4 -> 128 x 128 block tile (big products),
+//      2 -> 64 x 64 block tile (small matrices: 4x the workgroups, 1/4 the serial MFMA chain each)
+template <bool TRANSA, int TW>
 __global__ __launch_bounds__(GEMM_THREADS, 2)
 void gemm_f64_kernel(GemmArgs p) {
+  constexpr int BM = 32 * TW, BN = 32 * TW;
+  constexpr int REPS = 2 * TW;              // staged elements per thread per operand per K tile
+  constexpr int WT = 16 * TW;               // wavefront sub-tile edge
   __shared__ double lds[2][2][BM * LDS_S];   // [buffer][A/B][row*LDS_S + k]
 
   const int tid = threadIdx.x;
@@ -52,26 +57,27 @@ void gemm_f64_kernel(GemmArgs p) {
     default: break;
   }
 
-  d4_t acc[4][4];
+  d4_t acc[TW][TW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TW; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < TW; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
 
-  // staging registers: 8 doubles of the A tile, 8 of the B tile per thread
-  double ra[8], rb[8];
+  // staging registers: REPS doubles of the A tile, REPS of the B tile per thread
+  double ra[REPS], rb[REPS];
 
   // TN loader: k = tid & 15, row = (tid >> 4) + 16 * rep  (16 lanes read 128 contiguous bytes)
-  // NN loader (A only): row = tid & 127, k = (tid >> 7) + 2 * rep (128 lanes read 1 KiB contiguous)
+  // NN loader (A only): row = tid % BM, k = tid / BM + (256 / BM) * rep (BM lanes read contiguous rows)
   const int lk = tid & 15, lr = tid >> 4;
-  const int nn_r = tid & 127, nn_k = tid >> 7;
+  constexpr int NN_KSTEP = GEMM_THREADS / BM;
+  const int nn_r = tid % BM, nn_k = tid / BM;
 
   auto load_tiles = [&](int k0) {
     if (TRANSA) {
       const int k = k0 + lk;
       const bool kok = (k < kend);
 #pragma unroll
-      for (int rep = 0; rep < 8; ++rep) {
+      for (int rep = 0; rep < REPS; ++rep) {
         const int m = m0 + lr + 16 * rep;
         ra[rep] = (kok && m < p.M) ? A[(long)m * p.lda + k] : 0.0;
       }
@@ -79,8 +85,8 @@ void gemm_f64_kernel(GemmArgs p) {
       const int m = m0 + nn_r;
       const bool mok = (m < p.M);
 #pragma unroll
-      for (int rep = 0; rep < 8; ++rep) {
-        const int k = k0 + nn_k + 2 * rep;
+      for (int rep = 0; rep < REPS; ++rep) {
+        const int k = k0 + nn_k + NN_KSTEP * rep;
         ra[rep] = (mok && k < kend) ? A[(long)k * p.lda + m] : 0.0;
       }
     }
@@ -88,7 +94,7 @@ void gemm_f64_kernel(GemmArgs p) {
       const int k = k0 + lk;
       const bool kok = (k < kend);
 #pragma unroll
-      for (int rep = 0; rep < 8; ++rep) {
+      for (int rep = 0; rep < REPS; ++rep) {
         const int n = n0 + lr + 16 * rep;
         rb[rep] = (kok && n < p.N) ? B[(long)n * p.ldb + k] : 0.0;
       }
@@ -100,31 +106,31 @@ void gemm_f64_kernel(GemmArgs p) {
     double* Bs = lds[buf][1];
     if (TRANSA) {
 #pragma unroll
-      for (int rep = 0; rep < 8; ++rep) As[(lr + 16 * rep) * LDS_S + lk] = ra[rep];
+      for (int rep = 0; rep < REPS; ++rep) As[(lr + 16 * rep) * LDS_S + lk] = ra[rep];
     } else {
 #pragma unroll
-      for (int rep = 0; rep < 8; ++rep) As[nn_r * LDS_S + nn_k + 2 * rep] = ra[rep];
+      for (int rep = 0; rep < REPS; ++rep) As[nn_r * LDS_S + nn_k + NN_KSTEP * rep] = ra[rep];
     }
 #pragma unroll
-    for (int rep = 0; rep < 8; ++rep) Bs[(lr + 16 * rep) * LDS_S + lk] = rb[rep];
+    for (int rep = 0; rep < REPS; ++rep) Bs[(lr + 16 * rep) * LDS_S + lk] = rb[rep];
   };
 
   const int fr = lane & 15, fk = lane >> 4;
 
   auto compute = [&](int buf) {
-    const double* As = lds[buf][0] + (wm * 64 + fr) * LDS_S + fk;
-    const double* Bs = lds[buf][1] + (wn * 64 + fr) * LDS_S + fk;
+    const double* As = lds[buf][0] + (wm * WT + fr) * LDS_S + fk;
+    const double* Bs = lds[buf][1] + (wn * WT + fr) * LDS_S + fk;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
-      double af[4], bf[4];
+      double af[TW], bf[TW];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = As[i * 16 * LDS_S + kk];
+      for (int i = 0; i < TW; ++i) af[i] = As[i * 16 * LDS_S + kk];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = Bs[j * 16 * LDS_S + kk];
+      for (int j = 0; j < TW; ++j) bf[j] = Bs[j * 16 * LDS_S + kk];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < TW; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TW; ++i)
           acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[j][i], 0, 0, 0);
     }
   };
@@ -144,17 +150,17 @@ void gemm_f64_kernel(GemmArgs p) {
   }
 
   // epilogue: lane (fr, fk), accumulator register r of tile (j, i) is
-  //   C[m0 + wm*64 + i*16 + fr, n0 + wn*64 + j*16 + fk + 4r]
+  //   C[m0 + wm*WT + i*16 + fr, n0 + wn*WT + j*16 + fk + 4r]
   const bool upper = (p.tri == GEMM_UPPER);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < TW; ++j) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int n = n0 + wn * 64 + j * 16 + fk + 4 * r;
+      const int n = n0 + wn * WT + j * 16 + fk + 4 * r;
       if (n >= p.N) continue;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + fr;
+      for (int i = 0; i < TW; ++i) {
+        const int m = m0 + wm * WT + i * 16 + fr;
         if (m >= p.M) continue;
         if (upper && m > n) continue;
         const long moff = p.cm_blk ? (long)(m / p.cm_blk) * p.cm_stride + (m % p.cm_blk) : (long)m;
@@ -169,8 +175,12 @@ void gemm_f64_kernel(GemmArgs p) {
 
 hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a) {
   if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return hipSuccess;
-  a.tiles_m = (a.M + BM - 1) / BM;
-  a.tiles_n = (a.N + BN - 1) / BN;
+  // tile choice: the 128 x 128 tile unless the product is too small to fill the chip with it
+  const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
+  const bool small = (a.tile_hint == 64) || (a.tile_hint == 0 && t128 < 192);
+  const int BT = small ? 64 : 128;
+  a.tiles_m = (a.M + BT - 1) / BT;
+  a.tiles_n = (a.N + BT - 1) / BT;
   long nblk;
   if (a.tri == GEMM_UPPER) {
     int T = a.tiles_n;   // square
@@ -179,10 +189,13 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a) {
     nblk = (long)a.tiles_m * a.tiles_n;
   }
   dim3 grid((unsigned)nblk, (unsigned)a.batch, 1);
-  if (transa)
-    hipLaunchKernelGGL(gemm_f64_kernel<true>, grid, dim3(GEMM_THREADS), 0, st, a);
-  else
-    hipLaunchKernelGGL(gemm_f64_kernel<false>, grid, dim3(GEMM_THREADS), 0, st, a);
+  if (transa) {
+    if (small) hipLaunchKernelGGL((gemm_f64_kernel<true, 2>), grid, dim3(GEMM_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((gemm_f64_kernel<true, 4>), grid, dim3(GEMM_THREADS), 0, st, a);
+  } else {
+    if (small) hipLaunchKernelGGL((gemm_f64_kernel<false, 2>), grid, dim3(GEMM_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((gemm_f64_kernel<false, 4>), grid, dim3(GEMM_THREADS), 0, st, a);
+  }
   return hipGetLastError();
 }
 

@@ -62,6 +62,10 @@ struct Ctx {
   hipStream_t stream = nullptr;
   std::string last_error;
   double timers[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // HIP-event timings of the update_lhs phases, accumulated in ms: [0] sqrt-Hessian products,
+  // [1] Schur syrk, [2] Cholesky, [3] number of update_lhs_fact calls, [4] syrk launches
+  double kstat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   DBuf scratch;       // general device scratch (gemv partial sums)
   DBuf dscal;         // 64 device doubles for scalar results (dots, counts)
   DBuf stage_a, stage_b;   // device staging for host-pointer entry points

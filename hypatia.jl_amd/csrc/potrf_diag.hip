@@ -37,6 +37,7 @@ void potrf_diag_kernel(double* __restrict__ A, long lda, long strideA, int n, in
       a[UIDX(r, c)] = v;
     }
 
+  const double dmask = (tc >= tr) ? 1.0 : 0.0;
   int fail = 0;
   if (tr == 0) {
 #pragma unroll
@@ -47,6 +48,7 @@ void potrf_diag_kernel(double* __restrict__ A, long lda, long strideA, int n, in
   // ---- factorization: right-looking, one barrier per column
 #pragma unroll
   for (int r0 = 0; r0 < 8; ++r0) {
+#pragma unroll 1
     for (int jj = 0; jj < 16; ++jj) {
       const int j = 16 * r0 + jj;
       const int cur = j & 1;
@@ -56,20 +58,19 @@ void potrf_diag_kernel(double* __restrict__ A, long lda, long strideA, int n, in
         piv = 1.0;
       }
       const double rpiv = 1.0 / piv;
+      // branch-free rank-1 update: rows i <= j contribute a zero multiplier; within the diagonal
+      // register block (c == r) only columns l >= i are touched (dmask), for c > r always l > i
       double rl[8];
 #pragma unroll
       for (int c = r0; c < 8; ++c) rl[c] = rowbuf[cur][16 * c + tc];
 #pragma unroll
       for (int r = r0; r < 8; ++r) {
         const int i = 16 * r + tr;
-        if (i > j) {
-          const double f = rowbuf[cur][i] * rpiv;
+        double f = rowbuf[cur][i] * rpiv;
+        f = (i > j) ? f : 0.0;
+        a[UIDX(r, r)] -= (f * dmask) * rl[r];
 #pragma unroll
-          for (int c = r; c < 8; ++c) {
-            const int l = 16 * c + tc;
-            if (l >= i) a[UIDX(r, c)] -= f * rl[c];
-          }
-        }
+        for (int c = r + 1; c < 8; ++c) a[UIDX(r, c)] -= f * rl[c];
       }
       if (tr == jj) {   // owner of row j: U[j, l] = A[j, l] / sqrt(piv)
         const double sq = sqrt(piv);
@@ -127,23 +128,22 @@ void potrf_diag_kernel(double* __restrict__ A, long lda, long strideA, int n, in
 
 #pragma unroll
   for (int r0 = 7; r0 >= 0; --r0) {
+#pragma unroll 1
     for (int jj = 15; jj >= 0; --jj) {
       const int j = 16 * r0 + jj;
       const int cur = j & 1;
+      // branch-free: rows i >= j get a zero multiplier; in register column block r0 only l >= j
       double rl[8];
 #pragma unroll
       for (int c = r0; c < 8; ++c) rl[c] = rowbuf[cur][16 * c + tc];
+      rl[r0] = (tc >= jj) ? rl[r0] : 0.0;
 #pragma unroll
       for (int r = 0; r <= r0; ++r) {
         const int i = 16 * r + tr;
-        if (i < j) {
-          const double f = colbuf[cur][i];
+        double f = colbuf[cur][i];
+        f = (i < j) ? f : 0.0;
 #pragma unroll
-          for (int c = r0; c < 8; ++c) {
-            const int l = 16 * c + tc;
-            if (l >= j) x[UIDX(r, c)] -= f * rl[c];
-          }
-        }
+        for (int c = r0; c < 8; ++c) x[UIDX(r, c)] -= f * rl[c];
       }
       // publish row j - 1 of X (scaled by 1 / U[j-1, j-1]) and column j - 1 of U
       if (jj > 0) {

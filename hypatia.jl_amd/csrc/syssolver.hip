@@ -83,6 +83,9 @@ void SysSolver::update_lhs_fact(int* info, int* used_fallback) {   // qrchol.jl:
   for (size_t k = 0; k < cones.size(); ++k) use_sqrt[k] = cones[k]->use_sqrt_hess_oracles(nmp) ? 1 : 0;   // :214-216
   bool any_sqrt = false;
   for (int v : use_sqrt) any_sqrt |= (v != 0);
+  HYP_CHECK(hipEventRecord(ctx.ev[0], ctx.stream));
+  HYP_CHECK(hipEventRecord(ctx.ev[1], ctx.stream));
+  HYP_CHECK(hipEventRecord(ctx.ev[2], ctx.stream));
   if (any_sqrt) {   // :219-234
     int idx = 0;
     for (size_t k = 0; k < cones.size(); ++k) {
@@ -92,10 +95,13 @@ void SysSolver::update_lhs_fact(int* info, int* used_fallback) {   // qrchol.jl:
       else ck->sqrt_hess_prod(HGQ2.d() + idx, q, gq2 + offs[k], q, nmp);
       idx += ck->dim;
     }
+    HYP_CHECK(hipEventRecord(ctx.ev[1], ctx.stream));
     GemmArgs s{};   // lhs = HGQ2[1:idx, :]' HGQ2[1:idx, :]  (outer_prod!, dense.jl:80-86)
     s.M = nmp; s.N = nmp; s.K = idx; s.A = HGQ2.d(); s.lda = q; s.B = HGQ2.d(); s.ldb = q; s.C = lhs.d(); s.ldc = nmp;
     s.alpha = 1; s.beta = 0; s.tri = GEMM_UPPER; s.krange = KR_ALL; s.batch = 1;
     gemm(ctx, true, s);
+    HYP_CHECK(hipEventRecord(ctx.ev[2], ctx.stream));
+    ctx.kstat[4] += 1;
   } else {
     ctx.zero(lhs.p, (size_t)nmp * nmp * sizeof(double));
   }
@@ -114,10 +120,19 @@ void SysSolver::update_lhs_fact(int* info, int* used_fallback) {   // qrchol.jl:
   // then a diagonal shift + Bunch-Kaufman.  Device Bunch-Kaufman is not built yet: the
   // fallback here is diagonal shift + Cholesky, reported through used_fallback.
   ctx.d2d(lhs_fact.p, lhs.p, (size_t)nmp * nmp * sizeof(double));
+  HYP_CHECK(hipEventRecord(ctx.ev[3], ctx.stream));
   potrf_upper_batched(ctx, nmp, lhs_fact.d(), nmp, 0, 1, dinv.d(), d_info.i());
+  HYP_CHECK(hipEventRecord(ctx.ev[4], ctx.stream));
   ctx.d2h(ctx.h_info, d_info.p, sizeof(int));
   ctx.sync();
   *info = ctx.h_info[0];
+  {
+    float ms = 0;
+    HYP_CHECK(hipEventElapsedTime(&ms, ctx.ev[0], ctx.ev[1])); ctx.kstat[0] += ms;
+    HYP_CHECK(hipEventElapsedTime(&ms, ctx.ev[1], ctx.ev[2])); ctx.kstat[1] += ms;
+    HYP_CHECK(hipEventElapsedTime(&ms, ctx.ev[3], ctx.ev[4])); ctx.kstat[2] += ms;
+    ctx.kstat[3] += 1;
+  }
   if (*info != 0) {
     *used_fallback = 1;
     ctx.d2d(lhs_fact.p, lhs.p, (size_t)nmp * nmp * sizeof(double));

@@ -21,6 +21,29 @@ from .models import Model
 from .systemsolvers import QRCholDenseSystemSolver
 
 EPS = np.finfo(np.float64).eps
+
+try:   # keep the host BLAS pool small inside the iteration loop: the driver's numpy calls are tiny, and a
+    # large pool of spinning OpenBLAS workers starves the HIP runtime's own threads (measured: 3x slower)
+    from threadpoolctl import threadpool_limits as _threadpool_limits
+except Exception:   # pragma: no cover
+    _threadpool_limits = None
+
+
+class _blas_limit:
+    def __init__(self, n=4):
+        self.n = n
+        self.cm = None
+
+    def __enter__(self):
+        if _threadpool_limits is not None:
+            self.cm = _threadpool_limits(limits=self.n, user_api="blas")
+            self.cm.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.cm is not None:
+            self.cm.__exit__(*a)
+        return False
 # status codes (Solvers.jl:34-49)
 STATUSES = ("NotLoaded", "Loaded", "SolveCalled", "Optimal", "PrimalInfeasible", "DualInfeasible",
             "IllPosed", "PrimalInconsistent", "DualInconsistent", "SlowProgress", "IterationLimit",
@@ -437,6 +460,7 @@ class Solver:
         self.syssolver = syssolver if syssolver is not None else QRCholDenseSystemSolver()
         self.status = "NotLoaded"
         self.iter_callback = None
+        self._setup_only = False
 
     def load(self, model):   # Solvers.jl:566-571
         self.orig_model = model
@@ -508,41 +532,13 @@ class Solver:
             if self.verbose:
                 self.print_header()
 
+            self._start_time = start_time
+            self._initial_point_vec = point.vec.copy()
+            if self._setup_only:
+                return self
             self.iter_start_time = time.perf_counter()
-            while True:
-                improv = self.calc_convergence_params()
-                if self.verbose:
-                    self.print_iteration()
-                if self.iter_callback is not None:
-                    self.iter_callback(self)
-                if self.check_convergence():
-                    break
-                if self.num_iters == self.iter_limit:
-                    self.status = "IterationLimit"
-                    break
-                if time.perf_counter() - start_time >= self.time_limit:
-                    self.status = "TimeLimit"
-                    break
-                if improv < self.tol_slow:
-                    if self.prev_is_slow and self.prev2_is_slow:
-                        self.status = "SlowProgress"
-                        break
-                    self.prev2_is_slow = self.prev_is_slow
-                    self.prev_is_slow = True
-                else:
-                    self.prev2_is_slow = self.prev_is_slow
-                    self.prev_is_slow = False
-
-                self.res_norm_cutoff = 1e-4 * max(self.x_norm_res, self.y_norm_res, self.z_norm_res, self.tau_feas)
-                self.worst_dir_res = 0.0
-
-                if not stepper.step(self):
-                    break
-                self.calc_mu()
-                if min(point.tau, point.kap, self.mu) <= 0:
-                    self.status = "NumericalFailure"
-                    break
-                self.num_iters += 1
+            while self.iterate():
+                pass
             self.iter_time = time.perf_counter() - self.iter_start_time
 
             t0 = time.perf_counter(); postprocess(self); self.time_unproc = time.perf_counter() - t0
@@ -551,6 +547,75 @@ class Solver:
         if self.verbose:
             print(f"\nstatus is {self.status} after {self.num_iters} iterations and {self.solve_time:.3f} seconds\n")
         return self
+
+    def setup(self):
+        """everything of `solve` up to (not including) the iteration loop: preprocessing, initial point,
+        stepper and system-solver load.  Then drive with `iterate()` (used by bench.py)."""
+        self._setup_only = True
+        try:
+            self.solve()
+        finally:
+            self._setup_only = False
+        return self
+
+    def iterate(self):
+        """one pass of the `while true` body of Solvers.solve (Solvers.jl:340-398); False when it stops."""
+        with _blas_limit():
+            return self._iterate()
+
+    def _iterate(self):
+        point, stepper = self.point, self.stepper
+        improv = self.calc_convergence_params()
+        if self.verbose:
+            self.print_iteration()
+        if self.iter_callback is not None:
+            self.iter_callback(self)
+        if self.check_convergence():
+            return False
+        if self.num_iters == self.iter_limit:
+            self.status = "IterationLimit"
+            return False
+        if time.perf_counter() - self._start_time >= self.time_limit:
+            self.status = "TimeLimit"
+            return False
+        if improv < self.tol_slow:
+            if self.prev_is_slow and self.prev2_is_slow:
+                self.status = "SlowProgress"
+                return False
+            self.prev2_is_slow = self.prev_is_slow
+            self.prev_is_slow = True
+        else:
+            self.prev2_is_slow = self.prev_is_slow
+            self.prev_is_slow = False
+
+        self.res_norm_cutoff = 1e-4 * max(self.x_norm_res, self.y_norm_res, self.z_norm_res, self.tau_feas)
+        self.worst_dir_res = 0.0
+
+        if not stepper.step(self):
+            return False
+        self.calc_mu()
+        if min(point.tau, point.kap, self.mu) <= 0:
+            self.status = "NumericalFailure"
+            return False
+        self.num_iters += 1
+        return True
+
+    def reset_iterate(self):
+        """put the solver back at its initial iterate (bench.py: keep stepping after convergence)."""
+        model, point = self.model, self.point
+        point.vec[:] = self._initial_point_vec
+        self.calc_mu()
+        for k, cone in enumerate(model.cones):
+            cone.reset_data()
+            cone.load_point(point.primal_views[k])
+            cone.load_dual_point(point.dual_views[k])
+            assert cone.is_feas()
+            cone.get_grad()
+        self.status = "SolveCalled"
+        self.x_feas = self.y_feas = self.z_feas = self.tau_feas = float("nan")
+        self.prev_is_slow = self.prev2_is_slow = False
+        self.stepper.prev_alpha = 1.0
+        self.stepper.searcher.prev_sched = 0
 
     def calc_mu(self):   # :418-423
         pt = self.point
@@ -716,7 +781,7 @@ def find_initial_x(solver, init_s):   # process.jl:64-178
     solver.x_keep_idxs = np.arange(n)
     rhs = np.concatenate([model.b, model.h - init_s])
     AG = G.copy() if p == 0 else np.vstack([A, G])
-    Qf, R, piv = sla.qr(AG, mode="full", pivoting=True)
+    Qf, R, piv = sla.qr(AG, mode="economic", pivoting=True, overwrite_a=True)   # Q: (p+q) x n
     AG_rank = get_rank_est(R, solver.init_tol_qr)
 
     if (not solver.preprocess) or AG_rank == n:
@@ -732,9 +797,7 @@ def find_initial_x(solver, init_s):   # process.jl:64-178
     x_keep_idxs = piv[:AG_rank]
     AG_R = R[:AG_rank, :AG_rank]
     c_sub = model.c[x_keep_idxs]
-    yz_sub = np.zeros(p + q)
-    yz_sub[:AG_rank] = sla.solve_triangular(AG_R, c_sub, trans="T", lower=False)
-    yz_sub = Qf @ yz_sub
+    yz_sub = Qf[:, :AG_rank] @ sla.solve_triangular(AG_R, c_sub, trans="T", lower=False)
     residual = _norm_inf(A.T @ yz_sub[:p] + G.T @ yz_sub[p:] - model.c)
     if residual > solver.init_tol_qr:
         solver.status = "DualInconsistent"

@@ -26,12 +26,16 @@ typedef struct hyp_sys hyp_sys;
 /* ---- context -------------------------------------------------------------------------------- */
 int hyp_ctx_create(int device, hyp_ctx** out);
 int hyp_ctx_destroy(hyp_ctx* ctx);
+int hyp_ctx_synchronize(hyp_ctx* ctx);   /* hipDeviceSynchronize on the context's device */
 const char* hyp_last_error(hyp_ctx* ctx);
 int hyp_device_count(int* out);
 /* timers in the order of Solvers.jl:86-96 (rescale, initx, inity, unproc, loadsys, upsys, upfact,
  * uprhs, getdir, search); the library fills upsys/upfact, the caller the rest */
 int hyp_get_timers(hyp_ctx* ctx, double* out10);
 int hyp_reset_timers(hyp_ctx* ctx);
+/* HIP-event timings (ms, accumulated since the last reset) of the update_lhs phases measured on the
+ * library stream: out8 = [sqrt-Hessian products, Schur syrk, Cholesky, #update_lhs_fact, #syrk launches, 0, 0, 0] */
+int hyp_get_kernel_stats(hyp_ctx* ctx, double* out8);
 
 /* ---- cone lifecycle: constructors of src/Cones/nonnegative.jl:27-33, possemideftri.jl:36-46 --- */
 int hyp_cone_create_nonnegative(hyp_ctx* ctx, int dim, hyp_cone** out);

@@ -927,7 +927,7 @@ def find_initial_x(solver, init_s):   # process.jl:64-178
     solver.x_keep_idxs = np.arange(n)
     rhs = np.concatenate([model.b, model.h - init_s])
     AG = G.copy() if p == 0 else np.vstack([A, G])
-    Qf, R, piv = sla.qr(AG, mode="full", pivoting=True)
+    Qf, R, piv = sla.qr(AG, mode="economic", pivoting=True, overwrite_a=True)   # Q: (p+q) x n
     AG_rank = get_rank_est(R, solver.init_tol_qr)
 
     if (not solver.preprocess) or AG_rank == n:
@@ -943,9 +943,7 @@ def find_initial_x(solver, init_s):   # process.jl:64-178
     x_keep_idxs = piv[:AG_rank]
     AG_R = R[:AG_rank, :AG_rank]
     c_sub = model.c[x_keep_idxs]
-    yz_sub = np.zeros(p + q)
-    yz_sub[:AG_rank] = sla.solve_triangular(AG_R, c_sub, trans="T", lower=False)
-    yz_sub = Qf @ yz_sub
+    yz_sub = Qf[:, :AG_rank] @ sla.solve_triangular(AG_R, c_sub, trans="T", lower=False)
     residual = _norm_inf(A.T @ yz_sub[:p] + G.T @ yz_sub[p:] - model.c)
     if residual > solver.init_tol_qr:
         solver.status = "DualInconsistent"
