@@ -54,13 +54,98 @@ def gen_instance(n, sides, seed):
     return (c, np.zeros((0, n)), np.zeros(0), G, h, specs, dict(status="Optimal"))
 
 
+def main_multi(args, world, rank, local_rank):
+    """N > 1: one PosSemidefTri(side) block per rank (weak scaling), Schur matrices summed by all-reduce."""
+    import torch                      # before the HIP library: one HIP runtime per process (torch's)
+    import torch.distributed as dist
+    backend = os.environ.get("HYP_DIST_BACKEND", "nccl")
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    dist.init_process_group(backend=backend)
+    import hypatia_jl_amd as H
+    from hypatia_jl_amd import distributed as D
+    comm = D.Comm(device="cuda")
+    n, side = args.n, args.side
+    dim = side * (side + 1) // 2
+    q = dim * world
+    # this rank's block of the instance (same generator as configs[1], one seed per block)
+    rng = np.random.default_rng(args.seed + 1000 * rank)
+    G_r = np.asfortranarray(rng.standard_normal((dim, n)) / np.sqrt(n))
+    x0 = np.random.default_rng(args.seed).standard_normal(n)
+    e_r = np.zeros(dim)
+    k = 0
+    for i in range(1, side + 1):
+        e_r[k] = 1.0
+        k += i + 1
+    h = np.zeros(q)
+    h[rank * dim:(rank + 1) * dim] = G_r @ x0 + e_r
+    comm.allreduce(h)
+    c = -(G_r.T @ e_r)
+    comm.allreduce(c)
+    owners = list(range(world))
+    cones = [D.ShardedCone(comm, r, H.PosSemidefTri(dim) if r == rank else None, dim, side) for r in range(world)]
+    model = D.DistModel(comm, c, h, G_r, cones, owners)
+    t_setup = time.perf_counter()
+    solver = H.Solver(verbose=args.verbose and rank == 0, syssolver=D.DistQRCholDenseSystemSolver(comm))
+    solver.load(model)
+    solver.setup()
+    t_setup = time.perf_counter() - t_setup
+    lib, ctx = H._lib.lib(), H._lib.ctx()
+
+    def step():
+        if not solver.iterate():
+            solver.reset_iterate()
+
+    for _ in range(args.warmup):
+        step()
+    lib.hyp_reset_timers(ctx)
+    n_solves0 = solver.n_solves
+    for f in ("upsys", "upfact", "uprhs", "getdir", "search"):
+        setattr(solver, "time_" + f, 0.0)
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    comm.barrier()
+    el = np.array([time.perf_counter() - t0])
+    comm.allreduce(el, "max")
+    elapsed = float(el[0])
+    ks = (ctypes.c_double * 8)()
+    lib.hyp_get_kernel_stats(ctx, ks)
+    if rank == 0:
+        syrk_ms = ks[1] / max(ks[4], 1)
+        syrk_flops = float(n) * n * dim
+        achieved = syrk_flops / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
+        out = {
+            "metric": "IPM iterations/sec x PSD-%d blocks, dense n=%d (Float64, QRCholDense + CombinedStepper)" % (side, n),
+            "value": world * args.steps / elapsed,
+            "unit": "block-iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "iterations_per_s": args.steps / elapsed,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1] block per GPU: %d x PosSemidefTri side=%d (q=%d total), dense random G, n=%d, p=0; "
+                                   "cones sharded one per rank, Schur all-reduce (sum, f64, n x n) per iteration" % (world, side, q, n),
+                       "n": n, "q": q, "seed": args.seed, "parallelism": "cone-shard x%d" % world},
+            "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<true, 4> (per-rank Schur syrk, upper)", "achieved": achieved,
+                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launch_ms": syrk_ms, "flops_per_launch": syrk_flops},
+            "kkt_solves_per_step": (solver.n_solves - n_solves0) / args.steps,
+            "collectives_per_step": comm.n_collectives / max(args.steps + args.warmup, 1),
+            "setup_s": t_setup,
+        }
+        print(json.dumps(out))
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=5000)
-    ap.add_argument("--side", type=int, default=200)
+    ap.add_argument("--nvars", dest="n", type=int, default=5000)
+    ap.add_argument("--psd-side", dest="side", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-iters", type=int, default=2, help="oracle iterations timed for cpu_baseline (0 = skip)")
     ap.add_argument("--verbose", action="store_true")
@@ -69,18 +154,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
     if world > 1:
-        import torch
-        import torch.distributed as dist_mod
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group(backend="nccl")
-        dist = dist_mod
+        return main_multi(args, world, rank, local_rank)
 
     import hypatia_jl_amd as H
-
-    if world > 1:
-        raise SystemExit("multi-GPU bench path is wired in a later commit of this round")
 
     inst = gen_instance(args.n, [args.side], args.seed)
     q = inst[3].shape[0]

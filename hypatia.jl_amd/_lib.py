@@ -58,6 +58,12 @@ SIGNATURES = {
     "hyp_sys_load": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "hyp_sys_update_lhs_fact": [c_vp, P(c_int), P(c_int), P(c_int)],
     "hyp_sys_solve3": [c_vp, c_vp, c_vp],
+    "hyp_sys_assemble_lhs": [c_vp, P(c_int)],
+    "hyp_sys_factor_lhs": [c_vp, P(c_int), P(c_int)],
+    "hyp_sys_lhs_export_dev": [c_vp, c_vp],
+    "hyp_sys_lhs_import_dev": [c_vp, c_vp],
+    "hyp_sys_set_lhs": [c_vp, c_vp],
+    "hyp_sys_potrs": [c_vp, c_vp],
     "hyp_sys_block_hess_prod": [c_vp, c_vp, c_vp],
     "hyp_sys_mul_G": [c_vp, c_int, c_dbl, c_vp, c_dbl, c_vp],
     "hyp_sys_get_lhs": [c_vp, c_vp],

@@ -283,6 +283,56 @@ int hyp_sys_update_lhs_fact(hyp_sys* sys, int* use_sqrt_out, int* info, int* use
     for (size_t k = 0; k < sys->s->use_sqrt.size(); ++k) use_sqrt_out[k] = sys->s->use_sqrt[k];
   API_END(sys->ctx)
 }
+int hyp_sys_assemble_lhs(hyp_sys* sys, int* use_sqrt_out) {
+  API_BEGIN
+  const double t0 = now_s();
+  sys->s->assemble_lhs();
+  sys->ctx->c.sync();
+  sys->ctx->c.timers[5] += now_s() - t0;
+  if (use_sqrt_out)
+    for (size_t k = 0; k < sys->s->use_sqrt.size(); ++k) use_sqrt_out[k] = sys->s->use_sqrt[k];
+  API_END(sys->ctx)
+}
+int hyp_sys_factor_lhs(hyp_sys* sys, int* info, int* used_fallback) {
+  API_BEGIN
+  const double t0 = now_s();
+  sys->s->factor_lhs(info, used_fallback);
+  sys->ctx->c.sync();
+  sys->ctx->c.timers[6] += now_s() - t0;
+  API_END(sys->ctx)
+}
+int hyp_sys_lhs_export_dev(hyp_sys* sys, void* dst_device) {
+  API_BEGIN
+  Ctx& c = sys->ctx->c;
+  c.d2d(dst_device, sys->s->lhs.p, (size_t)sys->s->nmp * sys->s->nmp * sizeof(double));
+  c.sync();
+  API_END(sys->ctx)
+}
+int hyp_sys_lhs_import_dev(hyp_sys* sys, const void* src_device) {
+  API_BEGIN
+  Ctx& c = sys->ctx->c;
+  c.d2d(sys->s->lhs.p, src_device, (size_t)sys->s->nmp * sys->s->nmp * sizeof(double));
+  c.sync();
+  API_END(sys->ctx)
+}
+int hyp_sys_set_lhs(hyp_sys* sys, const double* in) {
+  API_BEGIN
+  Ctx& c = sys->ctx->c;
+  c.h2d(sys->s->lhs.p, in, (size_t)sys->s->nmp * sys->s->nmp * sizeof(double));
+  c.sync();
+  API_END(sys->ctx)
+}
+int hyp_sys_potrs(hyp_sys* sys, double* x) {
+  API_BEGIN
+  Ctx& c = sys->ctx->c;
+  SysSolver* s = sys->s;
+  HYP_REQUIRE(s->fact_ok, "potrs: no valid factorization");
+  c.h2d(s->tmpn.p, x, (size_t)s->nmp * sizeof(double));
+  s->potrs(s->tmpn.d());
+  c.d2h(x, s->tmpn.p, (size_t)s->nmp * sizeof(double));
+  c.sync();
+  API_END(sys->ctx)
+}
 int hyp_sys_solve3(hyp_sys* sys, double* sol_vec, const double* rhs_vec) {
   API_BEGIN
   Ctx& c = sys->ctx->c;

@@ -79,6 +79,12 @@ void SysSolver::update_lhs_fact(int* info, int* used_fallback) {   // qrchol.jl:
   *info = 0;
   *used_fallback = 0;
   if (nmp == 0) return;
+  assemble_lhs();
+  factor_lhs(info, used_fallback);
+}
+
+void SysSolver::assemble_lhs() {   // qrchol.jl:214-246 (this process's cones only; the multi-GPU glue sums the result)
+  if (nmp == 0) return;
   const double* gq2 = GQ2();
   for (size_t k = 0; k < cones.size(); ++k) use_sqrt[k] = cones[k]->use_sqrt_hess_oracles(nmp) ? 1 : 0;   // :214-216
   bool any_sqrt = false;
@@ -116,6 +122,12 @@ void SysSolver::update_lhs_fact(int* info, int* used_fallback) {   // qrchol.jl:
     g.alpha = 1; g.beta = 1; g.tri = GEMM_UPPER; g.krange = KR_ALL; g.batch = 1;
     gemm(ctx, true, g);
   }
+}
+
+void SysSolver::factor_lhs(int* info, int* used_fallback) {   // qrchol.jl:249-250
+  *info = 0;
+  *used_fallback = 0;
+  if (nmp == 0) return;
   // posdef_fact_copy! (dense.jl:194-215).  Cholesky; on failure the reference tries Bunch-Kaufman and
   // then a diagonal shift + Bunch-Kaufman.  Device Bunch-Kaufman is not built yet: the
   // fallback here is diagonal shift + Cholesky, reported through used_fallback.
@@ -143,6 +155,11 @@ void SysSolver::update_lhs_fact(int* info, int* used_fallback) {   // qrchol.jl:
     *info = ctx.h_info[0];
   }
   fact_ok = (*info == 0);
+}
+
+void SysSolver::potrs(double* d_x) {
+  trsv_upper(ctx, nmp, lhs_fact.d(), nmp, dinv.d(), true, d_x);
+  trsv_upper(ctx, nmp, lhs_fact.d(), nmp, dinv.d(), false, d_x);
 }
 
 void SysSolver::solve3(double* d_sol, const double* d_rhs) {   // qrchol.jl:39-85

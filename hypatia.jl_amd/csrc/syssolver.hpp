@@ -29,6 +29,9 @@ struct SysSolver {
   void load(const double* hG, const double* hGQ1, const double* hGQ2, const double* hQ, const double* hR);
   void block_hess_prod_vec(double* d_out, const double* d_in);                 // qrchol.jl:87-98 on a q-vector
   void update_lhs_fact(int* info, int* used_fallback);                         // qrchol.jl:201-257
+  void assemble_lhs();                                                         //   :214-246 (Schur sum over this process's cones)
+  void factor_lhs(int* info, int* used_fallback);                              //   :249-250
+  void potrs(double* d_x);                                                     // x <- lhs^-1 x with the current factor (:66-69)
   void solve3(double* d_sol, const double* d_rhs);                             // qrchol.jl:39-85
 };
 

@@ -1,0 +1,463 @@
+"""Multi-GPU path: cone-sharded interior-point iterations, one process per GPU.
+
+SURVEY.md 8(e): `lhs = sum_k G_k' (mu H_k) G_k` is a sum over cones (qrchol.jl:219-246) and cone oracles
+are independent per cone (search.jl:118-134), so cones -- and with them the matching row blocks of G,
+h, z, s -- are partitioned across ranks.  Every rank runs the same (replicated, deterministic) driver on
+the full point vector; cone k's oracles run on its owner and the result is broadcast; products with G
+are local row-block products followed by one all-reduce; the only large exchange is the all-reduce
+(sum, f64) of the n x n Schur matrix once per iteration, after which every rank factors it.
+
+Collectives go through `torch.distributed`: backend "nccl" (= RCCL over xGMI) on the GPU box, "gloo" in
+the CPU tests.  The local numerical back end is injected (`local_backend`): the HIP system solver /
+cones here, the numpy oracle in tests/test_distributed_gloo.py (there is no CPU fallback in the
+product: the default back end needs the GPU).
+"""
+import numpy as np
+
+from . import _lib as L
+from .models import Model
+from .systemsolvers import QRCholDenseSystemSolver, SubPoint
+
+EPS = np.finfo(np.float64).eps
+
+
+class Comm:
+    """numpy-facing wrapper over an initialised torch.distributed process group."""
+
+    def __init__(self, device=None):
+        import torch
+        import torch.distributed as dist
+        assert dist.is_initialized(), "call torch.distributed.init_process_group first"
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device = device or ("cuda" if dist.get_backend() == "nccl" else "cpu")
+        self._ops = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}
+        self.n_collectives = 0
+
+    def _to(self, arr):
+        t = self.torch.from_numpy(np.ascontiguousarray(arr))
+        return t.to(self.device) if self.device != "cpu" else t.clone()
+
+    def allreduce(self, arr, op="sum"):
+        """in-place all-reduce of a float64 numpy array"""
+        t = self._to(arr)
+        self.dist.all_reduce(t, op=self._ops[op])
+        arr[...] = t.cpu().numpy().reshape(arr.shape)
+        self.n_collectives += 1
+        return arr
+
+    def bcast(self, arr, src):
+        t = self._to(arr)
+        self.dist.broadcast(t, src=src)
+        arr[...] = t.cpu().numpy().reshape(arr.shape)
+        self.n_collectives += 1
+        return arr
+
+    def bcast_scalar(self, value, src):
+        a = np.array([float(value)])
+        return float(self.bcast(a, src)[0])
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+def partition_cones(ncones, world):
+    """contiguous blocks of cones per rank (config 4: 64 cones -> 8 per GPU)"""
+    base, rem = divmod(ncones, world)
+    owners = []
+    for r in range(world):
+        owners += [r] * (base + (1 if r < rem else 0))
+    return owners
+
+
+class ShardedCone:
+    """Proxy with the Cone interface (Cones.jl:27-310): the owner rank runs the oracle on its local cone
+    (a HIP cone on the GPU), every rank receives the result.  All ranks must call in the same order."""
+
+    def __init__(self, comm, owner, local_cone, dim, nu, use_dual_barrier=False, is_nonnegative=False):
+        self.comm, self.owner, self.local = comm, owner, local_cone
+        self.mine = (comm.rank == owner)
+        assert self.mine == (local_cone is not None)
+        self.dim, self.nu = dim, nu
+        self._udb = use_dual_barrier
+        self.is_nonnegative = is_nonnegative
+        self.setup_data()
+
+    def dimension(self): return self.dim
+    def get_nu(self): return self.nu
+    def use_dual_barrier(self): return self._udb
+    def use_dder3(self): return True
+
+    def setup_data(self):
+        d = self.dim
+        self.point, self.dual_point = np.zeros(d), np.zeros(d)
+        self.grad, self.dder3_ = np.zeros(d), np.zeros(d)
+        self.vec1, self.vec2 = np.zeros(d), np.zeros(d)
+        self._grad_valid = False
+        if self.mine:
+            self.local.setup_data()
+        return self
+
+    def set_initial_point(self, arr):
+        tmp = np.zeros(self.dim)
+        if self.mine:
+            self.local.set_initial_point(tmp)
+        arr[:] = self.comm.bcast(tmp, self.owner)
+        return arr
+
+    def load_point(self, point, scal=None):
+        if scal is None:
+            self.point[:] = point
+        else:
+            np.multiply(point, scal, out=self.point)
+        if self.mine:
+            self.local.load_point(np.ascontiguousarray(point), scal)
+
+    def load_dual_point(self, point):
+        self.dual_point[:] = point
+        if self.mine:
+            self.local.load_dual_point(np.ascontiguousarray(point))
+
+    def reset_data(self):
+        self._grad_valid = False
+        if self.mine:
+            self.local.reset_data()
+
+    def _flag(self, name, *a):
+        v = float(getattr(self.local, name)(*a)) if self.mine else 0.0
+        return bool(self.comm.bcast_scalar(v, self.owner))
+
+    def is_feas(self): return self._flag("is_feas")
+    def is_dual_feas(self): return self._flag("is_dual_feas")
+    def check_numerics(self): return self._flag("check_numerics")
+
+    def use_sqrt_hess_oracles(self, arr_dim):
+        return self._flag("use_sqrt_hess_oracles", arr_dim)
+
+    def get_grad(self):
+        if not self._grad_valid:
+            if self.mine:
+                self.grad[:] = self.local.get_grad()
+            self.comm.bcast(self.grad, self.owner)
+            self._grad_valid = True
+        return self.grad
+
+    def _prod(self, name, prod, arr):
+        tmp = np.zeros(np.shape(arr), order="F")
+        if self.mine:
+            getattr(self.local, name)(tmp, np.asfortranarray(arr) if np.ndim(arr) == 2 else np.ascontiguousarray(arr))
+        self.comm.bcast(tmp, self.owner)
+        prod[...] = tmp
+        return prod
+
+    def hess_prod(self, prod, arr): return self._prod("hess_prod", prod, arr)
+    def inv_hess_prod(self, prod, arr): return self._prod("inv_hess_prod", prod, arr)
+    def hess_prod_slow(self, prod, arr): return self._prod("hess_prod_slow", prod, arr)
+    def sqrt_hess_prod(self, prod, arr): return self._prod("sqrt_hess_prod", prod, arr)
+    def inv_sqrt_hess_prod(self, prod, arr): return self._prod("inv_sqrt_hess_prod", prod, arr)
+
+    def dder3(self, dir):
+        if self.mine:
+            self.dder3_[:] = self.local.dder3(np.ascontiguousarray(dir))
+        self.comm.bcast(self.dder3_, self.owner)
+        return self.dder3_
+
+    def update_hess_aux(self):
+        if self.mine:
+            self.local.update_hess_aux()
+
+    def get_proxsqr(self, irtmu, use_max_prox):
+        v = self.local.get_proxsqr(irtmu, use_max_prox) if self.mine else 0.0
+        return self.comm.bcast_scalar(v, self.owner)
+
+
+class DistModel:
+    """Models.Model with G held as this rank's row blocks only (rows of the cones it owns)."""
+
+    def __init__(self, comm, c, h, G_local, cones, owners, obj_offset=0.0):
+        self.comm = comm
+        self.c = np.array(c, dtype=np.float64)
+        self.h = np.array(h, dtype=np.float64)
+        self.b = np.zeros(0)
+        self.n, self.p, self.q = self.c.shape[0], 0, self.h.shape[0]
+        self.A = np.zeros((0, self.n))
+        self.obj_offset = float(obj_offset)
+        self.cones, self.owners = list(cones), list(owners)
+        self.cone_idxs = []
+        prev = 0
+        for cone in self.cones:
+            self.cone_idxs.append(slice(prev, prev + cone.dimension()))
+            prev += cone.dimension()
+        assert prev == self.q
+        self.nu = float(sum(cone.get_nu() for cone in self.cones))
+        self.local_ks = [k for k, o in enumerate(self.owners) if o == comm.rank]
+        self.local_rows = (np.concatenate([np.arange(self.cone_idxs[k].start, self.cone_idxs[k].stop) for k in self.local_ks])
+                           if self.local_ks else np.zeros(0, dtype=int))
+        self.G_local = np.asfortranarray(G_local, dtype=np.float64).reshape(self.local_rows.shape[0], self.n)
+        self.G = None   # never materialised: products go through the system solver
+
+    def copy(self):
+        return DistModel(self.comm, self.c, self.h, self.G_local.copy(order="F"), self.cones, self.owners, self.obj_offset)
+
+
+# ---------------------------------------------------------------------------------------------------
+# local numerical back end on the GPU (one hyp_sys over this rank's cones and rows)
+# ---------------------------------------------------------------------------------------------------
+class HipLocalSys:
+    def __init__(self, comm, model):
+        import ctypes
+        self.ct = ctypes
+        self.comm = comm
+        self.n = model.n
+        self.q_local = model.local_rows.shape[0]
+        lib = L.lib()
+        locs = [model.cones[k].local for k in model.local_ks]
+        handles = (ctypes.c_void_p * max(len(locs), 1))(*[c._h for c in locs])
+        h = ctypes.c_void_p()
+        L.check(lib.hyp_sys_create(L.ctx(), self.n, 0, self.q_local, handles, len(locs), ctypes.byref(h)), "hyp_sys_create")
+        self._h = h
+        G = np.asfortranarray(model.G_local)
+        L.check(lib.hyp_sys_load(h, G.ctypes.data_as(ctypes.c_void_p), None, None, None, None), "hyp_sys_load")
+        self._lhs_dev = None
+        if comm.device == "cuda":
+            self._lhs_dev = comm.torch.empty(self.n * self.n, dtype=comm.torch.float64, device="cuda")
+
+    def __del__(self):
+        try:
+            if self._h is not None and L._lib is not None:
+                L._lib.hyp_sys_destroy(self._h)
+        except Exception:
+            pass
+
+    def assemble_lhs(self):
+        L.check(L.lib().hyp_sys_assemble_lhs(self._h, None), "hyp_sys_assemble_lhs")
+
+    def allreduce_lhs(self):
+        lib, ct = L.lib(), self.ct
+        if self._lhs_dev is not None:   # RCCL on the device buffer, no host round trip
+            L.check(lib.hyp_sys_lhs_export_dev(self._h, ct.c_void_p(self._lhs_dev.data_ptr())), "lhs_export")
+            self.comm.dist.all_reduce(self._lhs_dev)
+            self.comm.torch.cuda.synchronize()
+            L.check(lib.hyp_sys_lhs_import_dev(self._h, ct.c_void_p(self._lhs_dev.data_ptr())), "lhs_import")
+            self.comm.n_collectives += 1
+        else:
+            buf = np.zeros((self.n, self.n), order="F")
+            L.check(lib.hyp_sys_get_lhs(self._h, buf.ctypes.data_as(ct.c_void_p)), "get_lhs")
+            self.comm.allreduce(buf)
+            L.check(lib.hyp_sys_set_lhs(self._h, buf.ctypes.data_as(ct.c_void_p)), "set_lhs")
+
+    def factor_lhs(self):
+        ct = self.ct
+        info, fb = ct.c_int(0), ct.c_int(0)
+        L.check(L.lib().hyp_sys_factor_lhs(self._h, ct.byref(info), ct.byref(fb)), "hyp_sys_factor_lhs")
+        return info.value, bool(fb.value)
+
+    def potrs(self, x):
+        L.check(L.lib().hyp_sys_potrs(self._h, L.vec_ptr(x)), "hyp_sys_potrs")
+        return x
+
+    def mul_G(self, trans, x, out):
+        """out = G_local x (trans False: x is n, out q_local) or G_local' x (trans True)"""
+        if self.q_local == 0:
+            out[:] = 0
+            return out
+        L.check(L.lib().hyp_sys_mul_G(self._h, int(trans), 1.0, L.vec_ptr(np.ascontiguousarray(x)), 0.0, L.vec_ptr(out)), "hyp_sys_mul_G")
+        return out
+
+    def block_hess_prod(self, out_local, in_local):
+        if self.q_local:
+            L.check(L.lib().hyp_sys_block_hess_prod(self._h, L.vec_ptr(out_local), L.vec_ptr(np.ascontiguousarray(in_local))), "block_hess_prod")
+        return out_local
+
+    def get_lhs(self):
+        out = np.zeros((self.n, self.n), order="F")
+        L.check(L.lib().hyp_sys_get_lhs(self._h, out.ctypes.data_as(self.ct.c_void_p)), "hyp_sys_get_lhs")
+        return out
+
+
+class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
+    """QRCholDenseSystemSolver over cone-sharded data (p = 0, i.e. the default reduce = true path)."""
+
+    def __init__(self, comm, local_backend=HipLocalSys):
+        super().__init__()
+        self.comm = comm
+        self.local_backend = local_backend
+
+    def load(self, solver):
+        model = solver.model
+        assert model.p == 0, "the sharded solver assumes the reduced model (p = 0)"
+        self.n, self.p, self.q = model.n, 0, model.q
+        self.model = model
+        self.local = self.local_backend(self.comm, model)
+        self.rows = model.local_rows
+        self.use_sqrt_hess_cones = [True] * len(model.cones)
+        self.sol_sub, self.rhs_sub = SubPoint(model), SubPoint(model)
+        self.rhs_const, self.sol_const = SubPoint(model), SubPoint(model)
+        self.rhs_const.x[:] = -model.c
+        self.rhs_const.z[:] = model.h
+        self.last_info, self.used_fallback = 0, False
+        self._ql = np.zeros(self.rows.shape[0])
+        self._ql2 = np.zeros(self.rows.shape[0])
+        return self
+
+    # y = alpha op(G) x + beta y over ALL rows: local row-block product + one all-reduce
+    def mul_G(self, trans, x, alpha=1.0, beta=0.0, y=None):
+        if trans:
+            part = np.zeros(self.n)
+            self.local.mul_G(True, np.ascontiguousarray(np.asarray(x)[self.rows]), part)
+            self.comm.allreduce(part)
+        else:
+            part = np.zeros(self.q)
+            self.local.mul_G(False, x, self._ql)
+            part[self.rows] = self._ql
+            self.comm.allreduce(part)
+        if y is None:
+            return alpha * part
+        y[:] = alpha * part + (beta * y if beta != 0.0 else 0.0)
+        return y
+
+    def block_hess_prod_full(self, out_full, in_full):
+        """block_hess_prod!.(out_k, in_k, cones) on a full q-vector: owners compute, one all-reduce"""
+        out_full[:] = 0
+        self.local.block_hess_prod(self._ql2, np.ascontiguousarray(in_full[self.rows]))
+        out_full[self.rows] = self._ql2
+        self.comm.allreduce(out_full)
+        return out_full
+
+    def update_lhs_fact(self, solver):
+        self.local.assemble_lhs()        # sum over this rank's cones
+        self.local.allreduce_lhs()       # the one large exchange: n x n, sum, f64
+        self.last_info, self.used_fallback = self.local.factor_lhs()
+        if self.last_info != 0:
+            print("positive definite linear system factorization failed")
+
+    def update_lhs(self, solver):
+        model = solver.model
+        self.update_lhs_fact(solver)
+        self.block_hess_prod_full(self.rhs_const.z, model.h)
+        self.solve_subsystem3(solver, self.sol_const, self.rhs_const)
+        return self
+
+    def setup_rhs3(self, model, rhs, sol, rhs_sub):   # qrchol.jl:16-37 (primal-barrier cones)
+        tmp = np.zeros(self.q)
+        self.block_hess_prod_full(tmp, rhs.z)
+        rhs_sub.z[:] = -rhs.s - tmp
+
+    def solve_subsystem3(self, solver, sol, rhs):   # qrchol.jl:39-85 with p = 0, Ap_Q = I
+        sol.vec[:] = rhs.vec
+        x, z = sol.x, sol.z
+        t = self.mul_G(True, z)
+        t += x
+        self.local.potrs(t)
+        x[:] = t
+        Gx = self.mul_G(False, x)
+        HGx = np.zeros(self.q)
+        self.block_hess_prod_full(HGx, Gx)
+        z[:] = HGx - z
+        return sol
+
+
+# ---------------------------------------------------------------------------------------------------
+# distributed versions of the two preprocessing steps that touch all of G
+# ---------------------------------------------------------------------------------------------------
+def rescale_data_dist(solver):
+    """process.jl:13-60 with the column / cone maxima of G reduced over ranks"""
+    if not solver.rescale:
+        return False
+    model = solver.model
+    comm = model.comm
+    minval = np.sqrt(EPS)
+    Gl = model.G_local
+    colmax = np.max(np.abs(Gl), axis=0) if Gl.shape[0] else np.zeros(model.n)
+    comm.allreduce(colmax, "max")
+    c_scale = np.sqrt(np.maximum(np.maximum(np.abs(model.c), colmax), minval))
+    h_scale = np.ones(model.q)
+    conemax = np.zeros(len(model.cones))
+    rowmax = np.zeros(model.q)
+    off = 0
+    for k in model.local_ks:
+        d = model.cones[k].dimension()
+        blk = np.abs(Gl[off:off + d, :])
+        conemax[k] = blk.max() if blk.size else 0.0
+        rowmax[model.cone_idxs[k]] = blk.max(axis=1)
+        off += d
+    comm.allreduce(conemax, "max")
+    comm.allreduce(rowmax, "max")
+    for k, cone in enumerate(model.cones):
+        idxs = model.cone_idxs[k]
+        if getattr(cone, "is_nonnegative", False):
+            h_scale[idxs] = np.sqrt(np.maximum(np.maximum(np.abs(model.h[idxs]), rowmax[idxs]), minval))
+        else:
+            h_scale[idxs] = np.sqrt(max(minval, float(np.max(np.abs(model.h[idxs]))), conemax[k]))
+    solver.c_scale, solver.b_scale, solver.h_scale = c_scale, np.zeros(0), h_scale
+    model.c = model.c / c_scale
+    model.G_local = np.asfortranarray((Gl / c_scale[None, :]) / h_scale[model.local_rows][:, None])
+    model.h = model.h / h_scale
+    return True
+
+
+class _GOnly:
+    """matrix-free access to the sharded G before the system solver exists (initial point only)"""
+
+    def __init__(self, model):
+        self.model, self.comm = model, model.comm
+
+    def mul(self, x):
+        out = np.zeros(self.model.q)
+        out[self.model.local_rows] = self.model.G_local @ x
+        return self.comm.allreduce(out)
+
+    def mul_t(self, z):
+        return self.comm.allreduce(self.model.G_local.T @ z[self.model.local_rows])
+
+
+def lsqr(op, b, atol=1e-14, btol=1e-14, maxiter=None):
+    """Paige & Saunders LSQR for min ||G x - b||: the reference's `init_use_indirect` initial point
+    (process.jl:81-95 calls IterativeSolvers.lsqr); only products with G and G' are needed."""
+    u = b.copy()
+    beta = np.linalg.norm(u)
+    n = op.model.n
+    x = np.zeros(n)
+    if beta == 0:
+        return x
+    u /= beta
+    v = op.mul_t(u)
+    alpha = np.linalg.norm(v)
+    v /= alpha
+    w = v.copy()
+    phibar, rhobar = beta, alpha
+    bnorm = beta
+    anorm2 = 0.0
+    maxiter = maxiter or 4 * n
+    for _ in range(maxiter):
+        u = op.mul(v) - alpha * u
+        beta = np.linalg.norm(u)
+        if beta > 0:
+            u /= beta
+        anorm2 += alpha * alpha + beta * beta
+        v = op.mul_t(u) - beta * v
+        alpha = np.linalg.norm(v)
+        if alpha > 0:
+            v /= alpha
+        rho = np.hypot(rhobar, beta)
+        cs, sn = rhobar / rho, beta / rho
+        theta = sn * alpha
+        rhobar = -cs * alpha
+        phi = cs * phibar
+        phibar = sn * phibar
+        x += (phi / rho) * w
+        w = v - (theta / rho) * w
+        rnorm = phibar
+        arnorm = phibar * alpha * abs(cs)
+        if rnorm <= btol * bnorm + atol * np.sqrt(anorm2) * np.linalg.norm(x):
+            break
+        if arnorm <= atol * np.sqrt(anorm2) * max(rnorm, 1e-300):
+            break
+    return x
+
+
+def find_initial_x_dist(solver, init_s):
+    """least-squares x for G x = h - s over all ranks (process.jl:64-95, indirect branch)"""
+    model = solver.model
+    solver.x_keep_idxs = np.arange(model.n)
+    return lsqr(_GOnly(model), model.h - init_s)

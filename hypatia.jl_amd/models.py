@@ -20,3 +20,6 @@ class Model:
             prev += d
         assert prev == self.q
         self.nu = float(sum(cone.get_nu() for cone in self.cones)) if self.cones else 0.0
+
+    def copy(self):
+        return Model(self.c, self.A, self.b, self.G, self.h, self.cones, obj_offset=self.obj_offset)

@@ -486,7 +486,7 @@ class Solver:
 
         om = self.orig_model
         self.result = Point(om)
-        model = self.model = Model(om.c, om.A, om.b, om.G, om.h, om.cones, obj_offset=om.obj_offset)
+        model = self.model = om.copy()
         init_z, init_s = initialize_cone_point(om)
 
         t0 = time.perf_counter()
@@ -739,6 +739,9 @@ def rescale_data(solver):   # process.jl:13-60
     if not solver.rescale:
         return False
     model = solver.model
+    if getattr(model, "comm", None) is not None:   # cone-sharded model: maxima of G reduced over ranks
+        from .distributed import rescale_data_dist
+        return rescale_data_dist(solver)
     c, A, b, G, h = model.c, model.A, model.b, model.G, model.h
     minval = np.sqrt(EPS)
 
@@ -773,6 +776,9 @@ def find_initial_x(solver, init_s):   # process.jl:64-178
     if solver.status != "SolveCalled":
         return np.zeros(0)
     model = solver.model
+    if getattr(model, "comm", None) is not None:   # cone-sharded model: matrix-free least squares (LSQR)
+        from .distributed import find_initial_x_dist
+        return find_initial_x_dist(solver, init_s)
     n, p, q = model.n, model.p, model.q
     if n == 0:
         solver.x_keep_idxs = np.zeros(0, dtype=int)

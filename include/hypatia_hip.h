@@ -81,6 +81,17 @@ int hyp_sys_load(hyp_sys* sys, const double* G, const double* GQ1, const double*
  * receives use_sqrt_hess_cones; info = 0 or leading-minor index of the failed Cholesky after the
  * fallback; used_fallback = 1 when the first Cholesky failed. */
 int hyp_sys_update_lhs_fact(hyp_sys* sys, int* use_sqrt_out, int* info, int* used_fallback);
+/* the two halves of update_lhs_fact, for the multi-GPU path: each process assembles the Schur sum over
+ * ITS cones (qrchol.jl:214-246), the partial n x n matrices are summed across processes (RCCL
+ * all-reduce on a caller-owned device buffer, or through the host), then every process factors
+ * (qrchol.jl:249-250).  *_dev take DEVICE pointers to (n-p)^2 doubles. */
+int hyp_sys_assemble_lhs(hyp_sys* sys, int* use_sqrt_out);
+int hyp_sys_factor_lhs(hyp_sys* sys, int* info, int* used_fallback);
+int hyp_sys_lhs_export_dev(hyp_sys* sys, void* dst_device);
+int hyp_sys_lhs_import_dev(hyp_sys* sys, const void* src_device);
+int hyp_sys_set_lhs(hyp_sys* sys, const double* in_nmpxnmp);
+/* x <- lhs^-1 x with the current factorization (ldiv!(x_sub2, fact, Q2div), qrchol.jl:66-69); n - p entries */
+int hyp_sys_potrs(hyp_sys* sys, double* x);
 /* solve_subsystem3 (qrchol.jl:39-85): vectors of length n + p + q laid out [x; y; z] */
 int hyp_sys_solve3(hyp_sys* sys, double* sol_vec, const double* rhs_vec);
 /* block_hess_prod!.(out_k, in_k, cones) on a q-vector (qrchol.jl:87-98, 191-195) */
