@@ -29,6 +29,10 @@ SIGNATURES = {
     "hyp_get_kernel_stats": [c_vp, c_vp],
     "hyp_cone_create_nonnegative": [c_vp, c_int, P(c_vp)],
     "hyp_cone_create_possemideftri": [c_vp, c_int, P(c_vp)],
+    "hyp_cone_create_epinormspectral": [c_vp, c_int, c_int, c_int, P(c_vp)],
+    "hyp_cone_create_wsosinterpnonnegative": [c_vp, c_int, c_int, P(c_int), P(c_vp), c_int, P(c_vp)],
+    "hyp_cone_update_use_hess_prod_slow": [c_vp, P(c_int)],
+    "hyp_cone_set_use_hess_prod_slow": [c_vp, c_int],
     "hyp_cone_destroy": [c_vp],
     "hyp_cone_dimension": [c_vp, P(c_int)],
     "hyp_cone_get_nu": [c_vp, P(c_dbl)],

@@ -186,3 +186,57 @@ class PosSemidefTri(Cone):
         L.check(L.lib().hyp_cone_create_possemideftri(L.ctx(), int(dim), ctypes.byref(h)), "hyp_cone_create_possemideftri")
         super().__init__(h)
         self.side = int(round((np.sqrt(1 + 8 * dim) - 1) / 2))
+
+
+class _GenericHessMixin:
+    """cones that carry Hypatia's `use_hess_prod_slow` switch (Cones.jl:222-237)"""
+
+    @property
+    def use_hess_prod_slow(self):
+        return self._slow
+
+    @use_hess_prod_slow.setter
+    def use_hess_prod_slow(self, v):
+        self._slow = bool(v)
+        if getattr(self, "_h", None) is not None and v:
+            L.check(L.lib().hyp_cone_set_use_hess_prod_slow(self._h, 1), "set_use_hess_prod_slow")
+
+    def update_use_hess_prod_slow(self):
+        out = c_int(0)
+        L.check(L.lib().hyp_cone_update_use_hess_prod_slow(self._h, ctypes.byref(out)), "update_use_hess_prod_slow")
+        self._slow = bool(out.value)
+        self.use_hess_prod_slow_updated = True
+
+    def reset_data(self):
+        super().reset_data()
+        self._slow = False
+        self.use_hess_prod_slow_updated = False
+
+
+class EpiNormSpectral(_GenericHessMixin, Cone):
+    """Cones.EpiNormSpectral{Float64, Float64}(d1, d2; use_dual)  (epinormspectral.jl:13-66)."""
+
+    def __init__(self, d1, d2, use_dual=False):
+        self._slow = False
+        h = c_vp()
+        L.check(L.lib().hyp_cone_create_epinormspectral(L.ctx(), int(d1), int(d2), int(bool(use_dual)), ctypes.byref(h)),
+                "hyp_cone_create_epinormspectral")
+        self.d1, self.d2 = d1, d2
+        super().__init__(h)
+
+
+class WSOSInterpNonnegative(_GenericHessMixin, Cone):
+    """Cones.WSOSInterpNonnegative{Float64, Float64}(U, Ps; use_dual)  (wsosinterpnonnegative.jl:16-63)."""
+
+    def __init__(self, U, Ps, use_dual=False):
+        self._slow = False
+        Ps = [np.asfortranarray(P, dtype=np.float64) for P in Ps]
+        for P in Ps:
+            assert P.shape[0] == U
+        K = len(Ps)
+        Ls = (c_int * K)(*[P.shape[1] for P in Ps])
+        ptrs = (c_vp * K)(*[P.ctypes.data_as(c_vp) for P in Ps])
+        h = c_vp()
+        L.check(L.lib().hyp_cone_create_wsosinterpnonnegative(L.ctx(), int(U), K, Ls, ptrs, int(bool(use_dual)), ctypes.byref(h)),
+                "hyp_cone_create_wsosinterpnonnegative")
+        super().__init__(h)

@@ -93,6 +93,40 @@ int hyp_cone_create_possemideftri(hyp_ctx* ctx, int dim, hyp_cone** out) {
   ctx->c.sync();
   API_END(ctx)
 }
+int hyp_cone_create_epinormspectral(hyp_ctx* ctx, int d1, int d2, int use_dual, hyp_cone** out) {
+  API_BEGIN
+  HYP_CHECK(hipSetDevice(ctx->c.device));
+  *out = new hyp_cone{ctx, new EpiNormSpectralCone(ctx->c, d1, d2, use_dual != 0)};
+  ctx->c.sync();
+  API_END(ctx)
+}
+int hyp_cone_create_wsosinterpnonnegative(hyp_ctx* ctx, int U, int K, const int* Ls, const double* const* Ps, int use_dual, hyp_cone** out) {
+  API_BEGIN
+  HYP_CHECK(hipSetDevice(ctx->c.device));
+  *out = new hyp_cone{ctx, new WsosCone(ctx->c, U, K, Ls, Ps, use_dual != 0)};
+  ctx->c.sync();
+  API_END(ctx)
+}
+int hyp_cone_update_use_hess_prod_slow(hyp_cone* cone, int* out) {
+  API_BEGIN
+  GenericHessCone* g = dynamic_cast<GenericHessCone*>(cone->cone);
+  *out = 0;
+  if (g) {
+    HYP_REQUIRE(g->is_feas(), "update_use_hess_prod_slow: cone point is not feasible");
+    g->update_use_hess_prod_slow();
+    *out = g->use_hess_prod_slow ? 1 : 0;
+  }
+  API_END(cone->ctx)
+}
+int hyp_cone_set_use_hess_prod_slow(hyp_cone* cone, int value) {
+  API_BEGIN
+  GenericHessCone* g = dynamic_cast<GenericHessCone*>(cone->cone);
+  if (g) {
+    g->use_hess_prod_slow = (value != 0);
+    g->use_hess_prod_slow_updated = true;
+  }
+  API_END(cone->ctx)
+}
 int hyp_cone_destroy(hyp_cone* cone) {
   hyp_ctx* ctx = cone ? cone->ctx : nullptr;
   API_BEGIN

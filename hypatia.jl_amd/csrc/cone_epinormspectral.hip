@@ -1,0 +1,330 @@
+// EpiNormSpectral on the device: (u, W), u >= sigma_1(W), W is d1 x d2 (column-stacked), d1 <= d2.
+// Reference: /root/reference/src/Cones/epinormspectral.jl (real case; line ranges inline).
+// Dual feasibility needs the nuclear norm of a d1 x d2 matrix (svdvals!, :125-132): computed by a
+// one-sided Jacobi (Hestenes) iteration on the rows, one workgroup per row pair per round.
+#include "cones.hpp"
+
+namespace hyp {
+
+static const double EPS = 2.220446049250313e-16;
+
+__global__ void scaled_identity_kernel(int n, double* A, long lda, double val) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  if (i < n) A[(long)j * lda + i] = (i == j) ? val : 0.0;
+}
+__global__ void trace_kernel(int n, const double* A, long lda, double* out) {   // single block
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += A[(long)i * lda + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+__global__ void sum_sqrt_kernel(int n, const double* x, double* out) {   // single block
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += sqrt(fmax(x[i], 0.0));
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+// S_j = T_j + T_j' - 2 u a_u[j] I   (batched d1 x d1; a_u[j] = arr[0 + j * lda])
+__global__ void symm_shift_kernel(int d1, const double* __restrict__ T, double* __restrict__ S, const double* __restrict__ arr, long lda,
+                                  double u) {
+  const int j = blockIdx.z;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y;
+  if (r >= d1) return;
+  const double* t = T + (long)j * d1 * d1;
+  double v = t[(long)c * d1 + r] + t[(long)r * d1 + c];
+  if (r == c) v -= 2.0 * u * arr[(long)j * lda];
+  S[(long)j * d1 * d1 + (long)c * d1 + r] = v;
+}
+// out[0, j] = Huu * arr[0, j] + <HuW, arr[1:, j]>
+__global__ __launch_bounds__(256) void hp_first_row_kernel(int dw, double Huu, const double* __restrict__ HuW, const double* __restrict__ arr,
+                                                           long lda, double* __restrict__ prod, long ldp) {
+  __shared__ double red[256];
+  const int j = blockIdx.x;
+  const double* a = arr + (long)j * lda;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < dw; i += 256) s += HuW[i] * a[1 + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) prod[(long)j * ldp] = Huu * a[0] + red[0];
+}
+// explicit Hessian, upper triangle (epinormspectral.jl:172-209): rows/cols 1.. indexed (j + i*d1), (l + k*d1)
+__global__ void ens_hess_kernel(int d1, int d2, const double* __restrict__ Zi, const double* __restrict__ tau, const double* __restrict__ WtauI,
+                                const double* __restrict__ HuW, double Huu, double* __restrict__ H, long ldh) {
+  const int dw = d1 * d2;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;   // 0 .. dw (0 = u row)
+  const int c = blockIdx.y;                                // 0 .. dw
+  if (r > dw || r > c) return;
+  double v;
+  if (r == 0) {
+    v = (c == 0) ? Huu : HuW[c - 1];
+  } else {
+    const int rr = r - 1, cc = c - 1;
+    const int j = rr % d1, i = rr / d1, l = cc % d1, k = cc / d1;
+    v = 2.0 * (Zi[(long)j * d1 + l] * WtauI[(long)k * d2 + i] + tau[(long)i * d1 + l] * tau[(long)k * d1 + j]);
+  }
+  H[(long)c * ldh + r] = v;
+}
+// one-sided Jacobi round: workgroup b rotates columns (p, q) of V (len x m, ld = len) chosen by the
+// round-robin tournament; flag[0] counts rotations above the threshold in this sweep
+__global__ __launch_bounds__(256) void jacobi_round_kernel(int len, int m, int mm, int t, double* __restrict__ V, long ldv, int* __restrict__ flag) {
+  __shared__ double red[3][256];
+  const int i = blockIdx.x;
+  int p, q;
+  if (i == 0) { p = mm - 1; q = t; }
+  else { p = (t + i) % (mm - 1); q = (t - i + (mm - 1)) % (mm - 1); }
+  if (p >= m || q >= m) return;   // dummy player of an odd tournament
+  double* vp = V + (long)p * ldv;
+  double* vq = V + (long)q * ldv;
+  double a = 0.0, b = 0.0, g = 0.0;
+  for (int r = threadIdx.x; r < len; r += 256) {
+    const double x = vp[r], y = vq[r];
+    a += x * x; b += y * y; g += x * y;
+  }
+  red[0][threadIdx.x] = a; red[1][threadIdx.x] = b; red[2][threadIdx.x] = g;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + off];
+      red[1][threadIdx.x] += red[1][threadIdx.x + off];
+      red[2][threadIdx.x] += red[2][threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  a = red[0][0]; b = red[1][0]; g = red[2][0];
+  if (fabs(g) <= 1e-15 * sqrt(a * b) || g == 0.0) return;
+  if (threadIdx.x == 0) atomicAdd(flag, 1);
+  const double zeta = (b - a) / (2.0 * g);
+  const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+  const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+  for (int r = threadIdx.x; r < len; r += 256) {
+    const double x = vp[r], y = vq[r];
+    vp[r] = cs * x - sn * y;
+    vq[r] = sn * x + cs * y;
+  }
+}
+
+static void mm(Ctx& c, bool transa, int M, int N, int K, const double* A, long lda, const double* B, long ldb, double* C, long ldc,
+               double alpha, double beta, int batch = 1, long sA = 0, long sB = 0, long sC = 0) {
+  GemmArgs g{};
+  g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.strideA = sA; g.B = B; g.ldb = ldb; g.strideB = sB; g.C = C; g.ldc = ldc; g.strideC = sC;
+  g.alpha = alpha; g.beta = beta; g.batch = batch;
+  gemm(c, transa, g);
+}
+static double read_scalar(Ctx& ctx, const double* d) {
+  ctx.d2h(ctx.h_pinned, d, sizeof(double));
+  ctx.sync();
+  return ctx.h_pinned[0];
+}
+static int read_info(Ctx& ctx, const int* d_info) {
+  ctx.d2h(ctx.h_info, d_info, sizeof(int));
+  ctx.sync();
+  return ctx.h_info[0];
+}
+
+EpiNormSpectralCone::EpiNormSpectralCone(Ctx& c, int d1_, int d2_, bool use_dual) : GenericHessCone(c, CONE_EPINORMSPECTRAL) {
+  HYP_REQUIRE(1 <= d1_ && d1_ <= d2_, "EpiNormSpectral: 1 <= d1 <= d2");
+  d1 = d1_; d2 = d2_;
+  dim = 1 + d1 * d2;
+  nu = d1 + 1;   // :97
+  use_dual_barrier = use_dual;
+  alloc_common();
+  alloc_generic();
+  const size_t b12 = (size_t)d1 * d2 * 8, b11 = (size_t)d1 * d1 * 8, b22 = (size_t)d2 * d2 * 8;
+  W.alloc(b12); WT.alloc(b12); tau.alloc(b12); HuW.alloc(b12); Zitau.alloc(b12);
+  t12a.alloc(b12); t12b.alloc(b12); t12c.alloc(b12); t12d.alloc(b12);
+  Z.alloc(b11); Zfact.alloc(b11); Zi.alloc(b11); t11.alloc(b11);
+  WtauI.alloc(b22); t22.alloc(b22); t22b.alloc(b22);
+  Zdinv.alloc(dinv_elems(d1) * 8);
+  Zinfo.alloc(64);
+}
+
+void EpiNormSpectralCone::set_initial_point(double* h) {   // :99-105
+  for (int i = 0; i < dim; ++i) h[i] = 0.0;
+  h[0] = sqrt((double)(d1 + 1));
+}
+
+void EpiNormSpectralCone::zsolve(double* X, long ldx, int nrhs) {   // ldiv!(fact_Z, X)
+  trsm_work.ensure((size_t)NB * std::max(nrhs, 1) * 8);
+  trsm_upper_left(ctx, d1, nrhs, Zfact.d(), d1, Zdinv.d(), true, X, ldx, trsm_work.d());
+  trsm_upper_left(ctx, d1, nrhs, Zfact.d(), d1, Zdinv.d(), false, X, ldx, trsm_work.d());
+}
+
+bool EpiNormSpectralCone::update_feas() {   // :107-123
+  u = read_scalar(ctx, point.d());
+  if (u > EPS) {
+    ctx.d2d(W.p, point.d() + 1, (size_t)d1 * d2 * 8);
+    dev_transpose(ctx, d1, d2, W.d(), d1, WT.d(), d2, 1, 0, 0);
+    hipLaunchKernelGGL(scaled_identity_kernel, dim3((d1 + 127) / 128, d1), dim3(128), 0, ctx.stream, d1, Z.d(), (long)d1, u * u);
+    mm(ctx, false, d1, d1, d2, W.d(), d1, WT.d(), d2, Z.d(), d1, -1.0, 1.0);   // Z = u^2 I - W W'
+    ctx.d2d(Zfact.p, Z.p, (size_t)d1 * d1 * 8);
+    potrf_upper_batched(ctx, d1, Zfact.d(), d1, 0, 1, Zdinv.d(), Zinfo.i());
+    is_feas_ = (read_info(ctx, Zinfo.i()) == 0);
+    if (is_feas_) dev_zero_strict_lower(ctx, d1, Zfact.d(), d1, 1, 0);
+  } else {
+    is_feas_ = false;
+  }
+  feas_updated = true;
+  return is_feas_;
+}
+
+double EpiNormSpectralCone::nuclear_norm(const double* d_mat) {
+  // rows of the d1 x d2 matrix = columns of its transpose V (d2 x d1): orthogonalise them pairwise
+  double* V = t12a.d();
+  dev_transpose(ctx, d1, d2, d_mat, d1, V, d2, 1, 0, 0);
+  const int m = d1, mm = (m % 2 == 0) ? m : m + 1;
+  if (m > 1) {
+    for (int sweep = 0; sweep < 40; ++sweep) {
+      ctx.zero(Zinfo.p, sizeof(int));
+      for (int t = 0; t < mm - 1; ++t)
+        hipLaunchKernelGGL(jacobi_round_kernel, dim3(mm / 2), dim3(256), 0, ctx.stream, d2, m, mm, t, V, (long)d2, Zinfo.i());
+      if (read_info(ctx, Zinfo.i()) == 0) break;
+    }
+  }
+  // singular values = column norms
+  double* norms2 = tmpd.d();
+  // column sums of squares
+  for (int j0 = 0; j0 < m; j0 += 1) {
+    dev_dot(ctx, d2, V + (long)j0 * d2, V + (long)j0 * d2, norms2 + j0);
+  }
+  hipLaunchKernelGGL(sum_sqrt_kernel, dim3(1), dim3(256), 0, ctx.stream, m, norms2, ctx.dscal.d());
+  return read_scalar(ctx, ctx.dscal.d());
+}
+
+bool EpiNormSpectralCone::is_dual_feas() {   // :125-132
+  const double ud = read_scalar(ctx, dual_point.d());
+  if (ud > EPS) return (ud - nuclear_norm(dual_point.d() + 1)) > EPS;
+  return false;
+}
+
+void EpiNormSpectralCone::update_grad() {   // :134-150
+  ctx.d2d(tau.p, W.p, (size_t)d1 * d2 * 8);
+  zsolve(tau.d(), d1, d2);                                              // tau = Z^-1 W
+  // Zi = Z^-1 = U^-1 U^-T
+  trtri_upper_batched(ctx, d1, Zfact.d(), d1, 0, Zdinv.d(), 0, t11.d(), d1, 0, 1);
+  dev_transpose(ctx, d1, d1, t11.d(), d1, Z.d(), d1, 1, 0, 0);         // Z buffer reused for U^-T (Z itself is no longer needed)
+  GemmArgs g{};
+  g.M = d1; g.N = d1; g.K = d1; g.A = t11.d(); g.lda = d1; g.B = Z.d(); g.ldb = d1; g.C = Zi.d(); g.ldc = d1;
+  g.alpha = 1; g.beta = 0; g.krange = KR_GE_M; g.batch = 1;
+  gemm(ctx, false, g);
+  hipLaunchKernelGGL(trace_kernel, dim3(1), dim3(256), 0, ctx.stream, d1, Zi.d(), (long)d1, ctx.dscal.d());
+  const double trZi = read_scalar(ctx, ctx.dscal.d());
+  g0_host = (-u * trZi) * 2.0 + (d1 - 1) / u;
+  dev_scale_copy(ctx, d1 * d2, 2.0, tau.d(), grad.d() + 1);
+  ctx.h2d(grad.p, &g0_host, sizeof(double));
+  ctx.sync();
+  grad_updated = true;
+}
+
+void EpiNormSpectralCone::update_hess_aux() {   // :152-170
+  get_grad();
+  ctx.d2d(Zitau.p, tau.p, (size_t)d1 * d2 * 8);
+  zsolve(Zitau.d(), d1, d2);
+  dev_scale_copy(ctx, d1 * d2, -4.0 * u, Zitau.d(), HuW.d());
+  trZi2 = dot_host(d1 * d1, Zi.d(), Zi.d());
+  Huu = 4.0 * u * u * trZi2 + (g0_host - 2.0 * (d1 - 1) / u) / u;
+  hipLaunchKernelGGL(scaled_identity_kernel, dim3((d2 + 127) / 128, d2), dim3(128), 0, ctx.stream, d2, WtauI.d(), (long)d2, 1.0);
+  mm(ctx, true, d2, d2, d1, W.d(), d1, tau.d(), d1, WtauI.d(), d2, 1.0, 1.0);   // I + W' tau
+  hess_aux_updated = true;
+}
+
+void EpiNormSpectralCone::update_hess() {   // :172-209
+  if (!hess_aux_updated) update_hess_aux();
+  hipLaunchKernelGGL(ens_hess_kernel, dim3((dim + 127) / 128, dim), dim3(128), 0, ctx.stream, d1, d2, Zi.d(), tau.d(), WtauI.d(), HuW.d(), Huu,
+                     H.d(), (long)dim);
+  HYP_CHECK(hipGetLastError());
+  dev_symmetrize_from_upper(ctx, dim, H.d(), dim, 1, 0);
+  hess_updated = true;
+}
+
+void EpiNormSpectralCone::hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) {   // :211-239
+  if (!hess_aux_updated) update_hess_aux();
+  if (ncols <= 0) return;
+  const int dw = d1 * d2;
+  const long cap = 1L << 25;   // doubles per workspace
+  int chunk = (int)std::min<long>(std::min(ncols, 32768), std::max<long>(1, cap / std::max((long)d1 * d1, (long)dw)));
+  wsA.ensure((size_t)chunk * d1 * d1 * 8);
+  wsB.ensure((size_t)chunk * d1 * d1 * 8);
+  wsC.ensure((size_t)chunk * dw * 8);
+  for (int c0 = 0; c0 < ncols; c0 += chunk) {
+    const int nc = std::min(chunk, ncols - c0);
+    const double* a = arr + (long)c0 * lda;
+    double* p = prod + (long)c0 * ldp;
+    hipLaunchKernelGGL(hp_first_row_kernel, dim3(nc), dim3(256), 0, ctx.stream, dw, Huu, HuW.d(), a, lda, p, ldp);
+    // T_j = A_W_j W'
+    mm(ctx, false, d1, d1, d2, a + 1, d1, WT.d(), d2, wsA.d(), d1, 1.0, 0.0, nc, lda, 0, (long)d1 * d1);
+    hipLaunchKernelGGL(symm_shift_kernel, dim3((d1 + 63) / 64, d1, nc), dim3(64), 0, ctx.stream, d1, wsA.d(), wsB.d(), a, lda, u);
+    // R_j = 2 S_j tau + 2 A_W_j
+    HYP_CHECK(hipMemcpy2DAsync(wsC.p, (size_t)dw * 8, a + 1, (size_t)lda * 8, (size_t)dw * 8, nc, hipMemcpyDeviceToDevice, ctx.stream));
+    mm(ctx, true, d1, d2, d1, wsB.d(), d1, tau.d(), d1, wsC.d(), d1, 2.0, 2.0, nc, (long)d1 * d1, 0, (long)dw);
+    zsolve(wsC.d(), d1, nc * d2);
+    HYP_CHECK(hipMemcpy2DAsync(p + 1, (size_t)ldp * 8, wsC.p, (size_t)dw * 8, (size_t)dw * 8, nc, hipMemcpyDeviceToDevice, ctx.stream));
+  }
+  HYP_CHECK(hipGetLastError());
+}
+
+const double* EpiNormSpectralCone::dder3(const double* d_dir) {   // :241-294
+  if (!hess_aux_updated) update_hess_aux();
+  const int dw = d1 * d2;
+  const double u_dir = read_scalar(ctx, d_dir);
+  const double* Wd = d_dir + 1;                       // W_dir (d1 x d2)
+  double* d22b = t22b.d(); double* d22 = t22.d();
+  double* b12 = t12b.d(); double* c12 = t12c.d(); double* dd12 = t12d.d(); double* a12 = t12a.d();
+  double* d11 = t11.d();
+  mm(ctx, true, d2, d2, d1, Wd, d1, tau.d(), d1, d22b, d2, 1.0, 0.0);          // d22b = W_dir' tau
+  ctx.d2d(dd12, Wd, (size_t)dw * 8);
+  zsolve(dd12, d1, d2);                                                         // dd = Z^-1 W_dir
+  mm(ctx, false, d1, d2, d2, dd12, d1, WtauI.d(), d2, b12, d1, 1.0, 0.0);      // b = dd WtauI
+  dev_transpose(ctx, d2, d2, d22b, d2, d22, d2, 1, 0, 0);                       // d22 <- d22b' (temporary)
+  mm(ctx, false, d1, d2, d2, dd12, d1, d22, d2, c12, d1, 1.0, 0.0);            // c = dd d22b'
+  mm(ctx, false, d1, d1, d2, dd12, d1, WT.d(), d2, d11, d1, 1.0, 0.0);         // d11 = dd W'
+  mm(ctx, false, d2, d2, d2, d22b, d2, d22b, d2, d22, d2, 1.0, 0.0);           // d22 = d22b d22b
+  mm(ctx, true, d2, d2, d1, Wd, d1, b12, d1, d22, d2, 1.0, 1.0);               // d22 += W_dir' b
+  mm(ctx, false, d1, d2, d2, tau.d(), d1, d22, d2, dd12, d1, 1.0, 0.0);        // dd = tau d22
+  mm(ctx, false, d1, d2, d2, c12, d1, WtauI.d(), d2, dd12, d1, 1.0, 1.0);      // dd += c WtauI
+  mm(ctx, false, d1, d2, d2, b12, d1, d22b, d2, dd12, d1, 1.0, 1.0);           // dd += b d22b
+  zsolve(b12, d1, d2);                                                          // b = Z^-1 b
+  mm(ctx, false, d1, d2, d2, Zitau.d(), d1, d22b, d2, b12, d1, 1.0, 1.0);      // b += Zitau d22b
+  dev_transpose(ctx, d1, d2, Wd, d1, a12, d2, 1, 0, 0);                         // a12 = W_dir' (d2 x d1)
+  mm(ctx, false, d1, d1, d2, tau.d(), d1, a12, d2, d11, d1, 1.0, 1.0);         // d11 += tau W_dir'
+  mm(ctx, false, d1, d2, d1, d11, d1, Zitau.d(), d1, b12, d1, 1.0, 1.0);       // b += d11 Zitau
+  dev_axpby(ctx, dw, 0.0, b12, -2.0 * u, b12);                                  // b *= -2u
+  const double const1 = 4.0 * u * u_dir * u;
+  dev_scale_copy(ctx, dw, const1, Zitau.d(), c12);
+  dev_axpby(ctx, dw, -u_dir, tau.d(), 1.0, c12);                                // c = const1 Zitau - u_dir tau
+  zsolve(c12, d1, d2);
+  dev_axpby(ctx, dw, 1.0, c12, 1.0, b12);                                       // b += c
+  dev_axpby(ctx, dw, -2.0 * u_dir, b12, -2.0, dd12);                            // dd = -2 u_dir b - 2 dd
+  ctx.d2d(dder3v.d() + 1, dd12, (size_t)dw * 8);
+  // trZi3 = || L^-1 Zi ||_F^2, Z = L L' with L = U'
+  ctx.d2d(d11, Zi.p, (size_t)d1 * d1 * 8);
+  trsm_work.ensure((size_t)NB * d1 * 8);
+  trsm_upper_left(ctx, d1, d1, Zfact.d(), d1, Zdinv.d(), true, d11, d1, trsm_work.d());
+  const double trZi3 = dot_host(d1 * d1, d11, d11);
+  dev_axpby(ctx, dw, 3.0, c12, 1.0, b12);                                       // b += 3 c
+  const double wb = dot_host(dw, Wd, b12);
+  const double r = u_dir / u;
+  const double d0 = -wb - u * u_dir * (6.0 * trZi2 - 8.0 * u * trZi3 * u) * u_dir - (d1 - 1) * r * r / u;
+  ctx.h2d(dder3v.p, &d0, sizeof(double));
+  ctx.sync();
+  return dder3v.d();
+}
+
+}  // namespace hyp

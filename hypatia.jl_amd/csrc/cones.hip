@@ -33,6 +33,7 @@ bool Cone::check_numerics() {   // Cones.jl:273-290
   const double gtol = sqrt(sqrt(EPS)), Htol = 10 * sqrt(gtol);
   const double* g = get_grad();
   if (fabs(1 + dot_host(dim, g, point.d()) / nu) > gtol * dim) return false;
+  if (!inv_hess_ready()) return false;
   inv_hess_prod(vec1.d(), dim, g, dim, 1);
   if (fabs(1 - dot_host(dim, vec1.d(), g) / nu) > Htol * dim) return false;
   return true;
@@ -44,6 +45,7 @@ double Cone::get_proxsqr(double irtmu, bool) {   // Cones.jl:294-310
   // vec1 = irtmu * dual_point + g
   ctx.d2d(vec1.p, g, (size_t)dim * sizeof(double));
   dev_axpby(ctx, dim, irtmu, dual_point.d(), 1.0, vec1.d());
+  if (!inv_hess_ready()) return INFINITY;
   inv_hess_prod(vec2.d(), dim, vec1.d(), dim, 1);
   const double prox_sqr = dot_host(dim, vec2.d(), vec1.d());
   if (prox_sqr < -negtol * dim) return INFINITY;

@@ -57,6 +57,10 @@ struct Cone {
   // Cones.jl:273-310 (generic; Nonnegative overrides get_proxsqr)
   virtual bool check_numerics();
   virtual double get_proxsqr(double irtmu, bool use_max_prox);
+  // false when inv_hess_prod has no usable factorization at this point (generic cones whose explicit
+  // Hessian fails its Cholesky: the reference would continue with Bunch-Kaufman, Cones.jl:239-251 --
+  // here the trial point is rejected instead)
+  virtual bool inv_hess_ready() { return true; }
 
   double dot_host(int n, const double* dx, const double* dy);   // synchronous <x,y>
 };
@@ -107,6 +111,70 @@ struct PsdCone : Cone {   // src/Cones/possemideftri.jl (real symmetric)
   void sqrt_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;
   void inv_sqrt_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;
   const double* dder3(const double* d_dir) override;
+};
+
+// Cones whose Hessian is formed explicitly and factored (the generic fallbacks of Cones.jl:101-118,
+// 189-259): WSOSInterpNonnegative and EpiNormSpectral in this Hypatia version.
+struct GenericHessCone : Cone {
+  DBuf H;          // dim x dim explicit Hessian, BOTH triangles (symmetrised after update_hess)
+  DBuf Hfact;      // Cholesky factor of H (upper), strict lower zeroed
+  DBuf Hdinv, Hinfo, trsm_work, tmpd, tmpd2;
+  bool hess_fact_ok = false;
+  bool use_hess_prod_slow = false, use_hess_prod_slow_updated = false;
+  GenericHessCone(Ctx& c, int kind) : Cone(c, kind) {}
+  void alloc_generic();
+  void reset_data() override {
+    Cone::reset_data();
+    use_hess_prod_slow = use_hess_prod_slow_updated = false;
+  }
+  virtual void update_hess() = 0;                 // fills H (both triangles), sets hess_updated
+  bool update_hess_fact();                        // Cones.jl:239-251
+  bool inv_hess_ready() override { return update_hess_fact(); }
+  void update_use_hess_prod_slow();               // Cones.jl:222-231
+  void hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;        // :101-105
+  void inv_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;    // :113-118
+  bool use_sqrt_hess_oracles(int arr_dim) override;                                                // :189-195
+  void sqrt_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;   // :198-206
+  void inv_sqrt_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;   // :209-218
+  void hess_explicit(double* d_out, long ld) override;
+};
+
+struct WsosCone : GenericHessCone {   // src/Cones/wsosinterpnonnegative.jl (real)
+  int U, K;
+  std::vector<int> Ls;
+  std::vector<DBuf> P, PT, SP, Lam, LamDinv, LFLP, LFLPT, LU, LL;   // per k
+  DBuf tmpUU, infos;
+  WsosCone(Ctx& c, int U, int K, const int* Ls, const double* const* hPs, bool use_dual);
+  bool update_feas() override;
+  void update_grad() override;
+  void update_hess() override;
+  void set_initial_point(double* h_out) override;
+  void hess_prod_slow(double* prod, long ldp, const double* arr, long lda, int ncols) override;   // :152-175
+  const double* dder3(const double* d_dir) override;                                               // :177-188
+  void partial_lambda(int k, const double* d_dir);                                                 // :190-200 -> LU[k]
+};
+
+struct EpiNormSpectralCone : GenericHessCone {   // src/Cones/epinormspectral.jl (real)
+  int d1, d2;
+  bool hess_aux_updated = false;
+  double u = 0, Huu = 0, trZi2 = 0, g0_host = 0;
+  DBuf W, WT, Z, Zfact, Zdinv, Zi, tau, HuW, WtauI, Zitau, Zinfo;
+  DBuf t12a, t12b, t12c, t12d, t11, t22, t22b, wsA, wsB, wsC;
+  EpiNormSpectralCone(Ctx& c, int d1, int d2, bool use_dual);
+  void reset_data() override {
+    GenericHessCone::reset_data();
+    hess_aux_updated = false;
+  }
+  bool update_feas() override;
+  bool is_dual_feas() override;
+  void update_grad() override;
+  void update_hess_aux();
+  void update_hess() override;
+  void set_initial_point(double* h_out) override;
+  void hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;   // :211-239
+  const double* dder3(const double* d_dir) override;                                          // :241-294
+  void zsolve(double* X, long ldx, int nrhs);    // X <- Z^-1 X
+  double nuclear_norm(const double* d_mat /* d1 x d2 col-major */);
 };
 
 }  // namespace hyp

@@ -1,0 +1,258 @@
+// Cones with an explicitly formed and factored Hessian: the generic fallbacks of
+// /root/reference/src/Cones/Cones.jl:101-118, 189-259, and WSOSInterpNonnegative
+// (/root/reference/src/Cones/wsosinterpnonnegative.jl).
+#include "cones.hpp"
+
+namespace hyp {
+
+static const double EPS = 2.220446049250313e-16;
+
+// ---------------------------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------------------------
+// out[i, j] = s[i] * in[i, j]   (row scaling, m x n col-major)
+__global__ void row_scale_kernel(int m, int n, const double* __restrict__ s, const double* __restrict__ in, long ldi,
+                                 double* __restrict__ out, long ldo) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const double si = s[i];
+  for (int j = blockIdx.y; j < n; j += gridDim.y) out[(long)j * ldo + i] = si * in[(long)j * ldi + i];
+}
+// out[j] (+)= sign * sum_i A[i, j] * B[i, j]  (column dots of two m x n matrices); one wavefront per column
+__global__ __launch_bounds__(256) void col_dot_kernel(int m, int n, const double* __restrict__ A, long lda, const double* __restrict__ B,
+                                                      long ldb, double sign, int accumulate, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (col >= n) return;
+  const double* a = A + (long)col * lda;
+  const double* b = B + (long)col * ldb;
+  double s = 0.0;
+  for (int i = lane; i < m; i += 64) s += a[i] * b[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if (lane == 0) out[col] = (accumulate ? out[col] : 0.0) + sign * s;
+}
+
+static void row_scale(Ctx& c, int m, int n, const double* s, const double* in, long ldi, double* out, long ldo) {
+  hipLaunchKernelGGL(row_scale_kernel, dim3((m + 255) / 256, std::min(n, 2048)), dim3(256), 0, c.stream, m, n, s, in, ldi, out, ldo);
+  HYP_CHECK(hipGetLastError());
+}
+static void col_dot(Ctx& c, int m, int n, const double* A, long lda, const double* B, long ldb, double sign, bool acc, double* out) {
+  hipLaunchKernelGGL(col_dot_kernel, dim3((n + 3) / 4), dim3(256), 0, c.stream, m, n, A, lda, B, ldb, sign, acc ? 1 : 0, out);
+  HYP_CHECK(hipGetLastError());
+}
+static int read_info(Ctx& ctx, const int* d_info) {
+  ctx.d2h(ctx.h_info, d_info, sizeof(int));
+  ctx.sync();
+  return ctx.h_info[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// GenericHessCone
+// ---------------------------------------------------------------------------------------------
+void GenericHessCone::alloc_generic() {
+  const size_t mb = (size_t)dim * dim * sizeof(double);
+  H.alloc(mb);
+  Hfact.alloc(mb);
+  Hdinv.alloc(dinv_elems(dim) * sizeof(double));
+  Hinfo.alloc(64);
+  tmpd.alloc((size_t)dim * sizeof(double));
+  tmpd2.alloc((size_t)dim * sizeof(double));
+}
+
+bool GenericHessCone::update_hess_fact() {   // Cones.jl:239-251: posdef_fact_copy!(hess_fact_mat, hess, false)
+  if (hess_fact_updated) return hess_fact_ok;
+  if (!hess_updated) update_hess();
+  ctx.d2d(Hfact.p, H.p, (size_t)dim * dim * sizeof(double));
+  potrf_upper_batched(ctx, dim, Hfact.d(), dim, 0, 1, Hdinv.d(), Hinfo.i());
+  // Cholesky only: the reference's Bunch-Kaufman second attempt is not on the device;
+  // a failed Cholesky reports "no valid factorization", which the callers treat like a failed BK.
+  hess_fact_ok = (read_info(ctx, Hinfo.i()) == 0);
+  if (hess_fact_ok) dev_zero_strict_lower(ctx, dim, Hfact.d(), dim, 1, 0);
+  hess_fact_updated = true;
+  return hess_fact_ok;
+}
+
+void GenericHessCone::update_use_hess_prod_slow() {   // Cones.jl:222-231
+  if (!hess_updated) update_hess();
+  gemv(ctx, false, dim, dim, 1.0, H.d(), dim, point.d(), 0.0, tmpd.d());
+  const double rel_viol = fabs(1.0 - dot_host(dim, point.d(), tmpd.d()) / nu);
+  use_hess_prod_slow = (rel_viol > dim * sqrt(EPS));
+  use_hess_prod_slow_updated = true;
+}
+
+void GenericHessCone::hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) {   // :101-105
+  if (!hess_updated) update_hess();
+  if (ncols <= 0) return;
+  if (ncols == 1) {
+    gemv(ctx, false, dim, dim, 1.0, H.d(), dim, arr, 0.0, prod);
+    return;
+  }
+  GemmArgs g{};   // prod = H * arr (H symmetric, both triangles stored: the K-contiguous "TN" form)
+  g.M = dim; g.N = ncols; g.K = dim; g.A = H.d(); g.lda = dim; g.B = arr; g.ldb = lda; g.C = prod; g.ldc = ldp;
+  g.alpha = 1; g.beta = 0; g.batch = 1;
+  gemm(ctx, true, g);
+}
+
+void GenericHessCone::inv_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) {   // :113-118
+  update_hess_fact();
+  HYP_REQUIRE(hess_fact_ok, "inv_hess_prod: the cone Hessian has no Cholesky factorization");
+  if (ncols <= 0) return;
+  if (prod != arr) HYP_CHECK(hipMemcpy2DAsync(prod, ldp * sizeof(double), arr, lda * sizeof(double), (size_t)dim * sizeof(double), ncols,
+                                              hipMemcpyDeviceToDevice, ctx.stream));
+  if (ncols == 1) {
+    trsv_upper(ctx, dim, Hfact.d(), dim, Hdinv.d(), true, prod);
+    trsv_upper(ctx, dim, Hfact.d(), dim, Hdinv.d(), false, prod);
+  } else {
+    trsm_work.ensure((size_t)NB * ncols * sizeof(double));
+    trsm_upper_left(ctx, dim, ncols, Hfact.d(), dim, Hdinv.d(), true, prod, ldp, trsm_work.d());
+    trsm_upper_left(ctx, dim, ncols, Hfact.d(), dim, Hdinv.d(), false, prod, ldp, trsm_work.d());
+  }
+}
+
+bool GenericHessCone::use_sqrt_hess_oracles(int arr_dim) {   // :189-195
+  if (!hess_fact_updated) {
+    if (arr_dim < dim) return false;
+    if (!update_hess_fact()) return false;
+  }
+  return hess_fact_ok;   // (hess_fact isa Cholesky)
+}
+
+void GenericHessCone::sqrt_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) {   // :198-206  U * arr
+  HYP_REQUIRE(hess_fact_updated && hess_fact_ok, "sqrt_hess_prod: no Cholesky factor");
+  GemmArgs g{};
+  g.M = dim; g.N = ncols; g.K = dim; g.A = Hfact.d(); g.lda = dim; g.B = arr; g.ldb = lda; g.C = prod; g.ldc = ldp;
+  g.alpha = 1; g.beta = 0; g.krange = KR_GE_M; g.batch = 1;
+  gemm(ctx, false, g);
+}
+
+void GenericHessCone::inv_sqrt_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) {   // :209-218  U'^-1 arr
+  HYP_REQUIRE(hess_fact_updated && hess_fact_ok, "inv_sqrt_hess_prod: no Cholesky factor");
+  if (prod != arr) HYP_CHECK(hipMemcpy2DAsync(prod, ldp * sizeof(double), arr, lda * sizeof(double), (size_t)dim * sizeof(double), ncols,
+                                              hipMemcpyDeviceToDevice, ctx.stream));
+  trsm_work.ensure((size_t)NB * std::max(ncols, 1) * sizeof(double));
+  trsm_upper_left(ctx, dim, ncols, Hfact.d(), dim, Hdinv.d(), true, prod, ldp, trsm_work.d());
+}
+
+void GenericHessCone::hess_explicit(double* d_out, long ld) {
+  if (!hess_updated) update_hess();
+  HYP_CHECK(hipMemcpy2DAsync(d_out, ld * sizeof(double), H.p, (size_t)dim * sizeof(double), (size_t)dim * sizeof(double), dim,
+                             hipMemcpyDeviceToDevice, ctx.stream));
+  ctx.sync();
+}
+
+// ---------------------------------------------------------------------------------------------
+// WSOSInterpNonnegative (wsosinterpnonnegative.jl:16-200).  The barrier is for the DUAL cone:
+// use_dual_barrier = !use_dual (:58).  Lambda_k = P_k' diag(pt) P_k = U_k' U_k (upper factor; the
+// reference keeps the lower one, L_k = U_k').
+// ---------------------------------------------------------------------------------------------
+WsosCone::WsosCone(Ctx& c, int U_, int K_, const int* Ls_, const double* const* hPs, bool use_dual) : GenericHessCone(c, CONE_WSOS) {
+  HYP_REQUIRE(U_ >= 1 && K_ >= 1, "WSOS: sizes");
+  U = U_; K = K_;
+  dim = U;
+  use_dual_barrier = !use_dual;
+  nu = 0;
+  for (int k = 0; k < K; ++k) {
+    HYP_REQUIRE(Ls_[k] >= 1 && Ls_[k] <= U, "WSOS: 1 <= L_k <= U");
+    Ls.push_back(Ls_[k]);
+    nu += Ls_[k];
+  }
+  alloc_common();
+  alloc_generic();
+  infos.alloc(64 * sizeof(int));
+  for (int k = 0; k < K; ++k) {
+    const int Lk = Ls[k];
+    const size_t pb = (size_t)U * Lk * sizeof(double);
+    P.emplace_back(pb); PT.emplace_back(pb); SP.emplace_back(pb); LFLP.emplace_back(pb); LFLPT.emplace_back(pb); LU.emplace_back(pb);
+    Lam.emplace_back((size_t)Lk * Lk * sizeof(double));
+    LL.emplace_back((size_t)Lk * Lk * sizeof(double));
+    LamDinv.emplace_back(dinv_elems(Lk) * sizeof(double));
+    ctx.h2d(P[k].p, hPs[k], pb);
+    dev_transpose(ctx, U, Lk, P[k].d(), U, PT[k].d(), Lk, 1, 0, 0);
+  }
+  ctx.sync();
+}
+
+void WsosCone::set_initial_point(double* h) {   // :87
+  for (int i = 0; i < dim; ++i) h[i] = 1.0;
+}
+
+bool WsosCone::update_feas() {   // :89-117
+  is_feas_ = true;
+  for (int k = 0; k < K && is_feas_; ++k) {
+    const int Lk = Ls[k];
+    row_scale(ctx, U, Lk, point.d(), P[k].d(), U, SP[k].d(), U);           // diag(pt) P_k
+    GemmArgs g{};   // Lambda = (diag(pt) P_k)' P_k, upper triangle
+    g.M = Lk; g.N = Lk; g.K = U; g.A = SP[k].d(); g.lda = U; g.B = P[k].d(); g.ldb = U; g.C = Lam[k].d(); g.ldc = Lk;
+    g.alpha = 1; g.beta = 0; g.tri = GEMM_UPPER; g.batch = 1;
+    gemm(ctx, true, g);
+    potrf_upper_batched(ctx, Lk, Lam[k].d(), Lk, 0, 1, LamDinv[k].d(), infos.i());
+    if (read_info(ctx, infos.i()) != 0) is_feas_ = false;
+  }
+  feas_updated = true;
+  return is_feas_;
+}
+
+void WsosCone::update_grad() {   // :119-133
+  for (int k = 0; k < K; ++k) {
+    const int Lk = Ls[k];
+    // LFLP_k = L_k^-1 P_k' = U_k'^-1 P_k'   (L_k x U)
+    ctx.d2d(LFLP[k].p, PT[k].p, (size_t)U * Lk * sizeof(double));
+    trsm_work.ensure((size_t)NB * U * sizeof(double));
+    trsm_upper_left(ctx, Lk, U, Lam[k].d(), Lk, LamDinv[k].d(), true, LFLP[k].d(), Lk, trsm_work.d());
+    col_dot(ctx, Lk, U, LFLP[k].d(), Lk, LFLP[k].d(), Lk, -1.0, k > 0, grad.d());     // grad_j -= ||LFLP_k[:, j]||^2
+    dev_transpose(ctx, Lk, U, LFLP[k].d(), Lk, LFLPT[k].d(), U, 1, 0, 0);
+  }
+  grad_updated = true;
+}
+
+void WsosCone::update_hess() {   // :135-150: H = sum_k (LFLP_k' LFLP_k) .^ 2
+  get_grad();
+  for (int k = 0; k < K; ++k) {
+    GemmArgs g{};
+    g.M = U; g.N = U; g.K = Ls[k]; g.A = LFLP[k].d(); g.lda = Ls[k]; g.B = LFLP[k].d(); g.ldb = Ls[k]; g.C = H.d(); g.ldc = U;
+    g.alpha = 1; g.beta = (k > 0) ? 1.0 : 0.0; g.tri = GEMM_UPPER; g.epi = 1; g.batch = 1;
+    gemm(ctx, true, g);
+  }
+  dev_symmetrize_from_upper(ctx, U, H.d(), U, 1, 0);
+  hess_updated = true;
+}
+
+void WsosCone::partial_lambda(int k, const double* d_dir) {   // :190-200
+  const int Lk = Ls[k];
+  // LU' = diag(dir) LFLP'  (U x L) ; LL = LU LFLP' = (diag(dir) LFLP')' LFLP'
+  row_scale(ctx, U, Lk, d_dir, LFLPT[k].d(), U, SP[k].d(), U);
+  GemmArgs a{};
+  a.M = Lk; a.N = Lk; a.K = U; a.A = SP[k].d(); a.lda = U; a.B = LFLPT[k].d(); a.ldb = U; a.C = LL[k].d(); a.ldc = Lk;
+  a.alpha = 1; a.beta = 0; a.tri = GEMM_UPPER; a.batch = 1;
+  gemm(ctx, true, a);
+  dev_symmetrize_from_upper(ctx, Lk, LL[k].d(), Lk, 1, 0);   // Hermitian(LLk)
+  GemmArgs b{};   // LU = LL * LFLP  (L x U)
+  b.M = Lk; b.N = U; b.K = Lk; b.A = LL[k].d(); b.lda = Lk; b.B = LFLP[k].d(); b.ldb = Lk; b.C = LU[k].d(); b.ldc = Lk;
+  b.alpha = 1; b.beta = 0; b.batch = 1;
+  gemm(ctx, true, b);
+}
+
+void WsosCone::hess_prod_slow(double* prod, long ldp, const double* arr, long lda, int ncols) {   // :152-175
+  if (!use_hess_prod_slow_updated) update_use_hess_prod_slow();
+  if (!use_hess_prod_slow) {
+    hess_prod(prod, ldp, arr, lda, ncols);
+    return;
+  }
+  for (int j = 0; j < ncols; ++j) {
+    for (int k = 0; k < K; ++k) {
+      partial_lambda(k, arr + (long)j * lda);
+      col_dot(ctx, Ls[k], U, LFLP[k].d(), Ls[k], LU[k].d(), Ls[k], 1.0, k > 0, prod + (long)j * ldp);
+    }
+  }
+}
+
+const double* WsosCone::dder3(const double* d_dir) {   // :177-188
+  for (int k = 0; k < K; ++k) {
+    partial_lambda(k, d_dir);
+    col_dot(ctx, Ls[k], U, LU[k].d(), Ls[k], LU[k].d(), Ls[k], 1.0, k > 0, dder3v.d());
+  }
+  return dder3v.d();
+}
+
+}  // namespace hyp

@@ -55,6 +55,7 @@ struct GemmArgs {
   // Lets an M-stacked batch (rows = (matrix j, row a)) write each j into its own contiguous block.
   int cm_blk; long cm_stride;
   int tile_hint;   // 0 = automatic, 64 / 128 = force the block tile edge
+  int epi;         // 0: C = alpha*acc + beta*C ; 1: C = (alpha*acc)^2 + beta*C (Hadamard square, WSOS Hessian)
 };
 
 // launch on `st`; returns the HIP launch status

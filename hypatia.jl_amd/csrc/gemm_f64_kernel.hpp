@@ -166,6 +166,7 @@ void gemm_f64_kernel(GemmArgs p) {
         const long moff = p.cm_blk ? (long)(m / p.cm_blk) * p.cm_stride + (m % p.cm_blk) : (long)m;
         double* cp = C + (long)n * p.ldc + moff;
         double v = p.alpha * acc[j][i][r];
+        if (p.epi == 1) v = v * v;
         if (p.beta != 0.0) v += p.beta * (*cp);
         *cp = v;
       }

@@ -33,6 +33,7 @@ struct DBuf {
   size_t bytes = 0;
   DBuf() {}
   explicit DBuf(size_t nbytes) { alloc(nbytes); }
+  DBuf(DBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
   DBuf(const DBuf&) = delete;
   DBuf& operator=(const DBuf&) = delete;
   ~DBuf() { release(); }

@@ -40,6 +40,11 @@ int hyp_get_kernel_stats(hyp_ctx* ctx, double* out8);
 /* ---- cone lifecycle: constructors of src/Cones/nonnegative.jl:27-33, possemideftri.jl:36-46 --- */
 int hyp_cone_create_nonnegative(hyp_ctx* ctx, int dim, hyp_cone** out);
 int hyp_cone_create_possemideftri(hyp_ctx* ctx, int dim, hyp_cone** out);
+/* Cones.EpiNormSpectral{Float64,Float64}(d1, d2; use_dual) (epinormspectral.jl:53-66): dim = 1 + d1*d2 */
+int hyp_cone_create_epinormspectral(hyp_ctx* ctx, int d1, int d2, int use_dual, hyp_cone** out);
+/* Cones.WSOSInterpNonnegative{Float64,Float64}(U, Ps; use_dual) (wsosinterpnonnegative.jl:49-63):
+ * Ps[k] is U x Ls[k], column-major; the matrices are copied to the device */
+int hyp_cone_create_wsosinterpnonnegative(hyp_ctx* ctx, int U, int K, const int* Ls, const double* const* Ps, int use_dual, hyp_cone** out);
 int hyp_cone_destroy(hyp_cone* cone);
 int hyp_cone_dimension(hyp_cone* cone, int* out);            /* Cones.jl:34 */
 int hyp_cone_get_nu(hyp_cone* cone, double* out);            /* Cones.jl:41 */
@@ -65,6 +70,10 @@ int hyp_cone_use_sqrt_hess_oracles(hyp_cone* cone, int arr_dim, int* out);
 int hyp_cone_sqrt_hess_prod(hyp_cone* cone, double* prod, int ldp, const double* arr, int lda, int ncols);
 int hyp_cone_inv_sqrt_hess_prod(hyp_cone* cone, double* prod, int ldp, const double* arr, int lda, int ncols);
 int hyp_cone_dder3(hyp_cone* cone, const double* dir, double* out_dim);
+/* update_use_hess_prod_slow (Cones.jl:222-231) and the field cone.use_hess_prod_slow (test/cone.jl:89-95);
+ * no-ops for cones without the slow path */
+int hyp_cone_update_use_hess_prod_slow(hyp_cone* cone, int* out);
+int hyp_cone_set_use_hess_prod_slow(hyp_cone* cone, int value);
 int hyp_cone_check_numerics(hyp_cone* cone, int* out);
 int hyp_cone_get_proxsqr(hyp_cone* cone, double irtmu, int use_max_prox, double* out);
 int hyp_cone_hess(hyp_cone* cone, double* out_dimxdim);        /* explicit, tests / sparse solvers only */

@@ -101,3 +101,104 @@ def test_infeasible_points_detected():
     n.load_point(np.array([1.0, 0.0, 1.0, 2.0]))
     n.reset_data()
     assert not n.is_feas()
+
+
+# ---------------------------------------------------------------------------------------------
+# EpiNormSpectral and WSOSInterpNonnegative (generic explicit-Hessian cones)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d1,d2", [(1, 1), (1, 2), (2, 2), (2, 4), (3, 4)])
+def test_epinormspectral_identities(d1, d2):
+    import hypatia_jl_amd as H
+    run_test_oracles(H.EpiNormSpectral(d1, d2), tol=1e5 * np.finfo(float).eps)
+
+
+@pytest.mark.parametrize("nvars,halfdeg", [(1, 1), (1, 3), (2, 1), (2, 2), (3, 1)])
+def test_wsos_identities(nvars, halfdeg):
+    import hypatia_jl_amd as H
+    from oracle import polyutils as pu
+    U, _, Ps = pu.interpolate_box([-1.0] * nvars, [1.0] * nvars, halfdeg, sample=False)
+    run_test_oracles(H.WSOSInterpNonnegative(U, Ps), init_tol=np.inf, tol=1e5 * np.finfo(float).eps)
+
+
+def _generic_pair(kind, *args):
+    import hypatia_jl_amd as H
+    from oracle import cones as oc
+    if kind == "ens":
+        return H.EpiNormSpectral(*args), oc.EpiNormSpectral(*args)
+    from oracle import polyutils as pu
+    nvars, halfdeg = args
+    U, _, Ps = pu.interpolate_box([-1.0] * nvars, [1.0] * nvars, halfdeg, sample=(U_big(nvars, halfdeg)), rng=np.random.default_rng(5))
+    return H.WSOSInterpNonnegative(U, Ps), oc.WSOSInterpNonnegative(U, Ps)
+
+
+def U_big(nvars, halfdeg):
+    return None if nvars < 3 else False
+
+
+@pytest.mark.parametrize("kind,args", [("ens", (3, 4)), ("ens", (20, 33)), ("ens", (130, 140)), ("wsos", (2, 3)), ("wsos", (3, 3)), ("wsos", (2, 10))])
+def test_generic_oracle_vs_hip(kind, args):
+    hc, oc = _generic_pair(kind, *args)
+    dim = hc.dimension()
+    assert dim == oc.dimension() and hc.get_nu() == oc.get_nu() and hc.use_dual_barrier() == oc.use_dual_barrier()
+    rng = np.random.default_rng(dim)
+    for c in (hc, oc):
+        c.setup_data()
+    pt = np.zeros(dim)
+    oc.set_initial_point(pt)
+    pt2 = np.zeros(dim)
+    hc.set_initial_point(pt2)
+    assert np.array_equal(pt, pt2)
+    scale = 0.1 / np.sqrt(max(1.0, dim / 20.0))
+    pt = pt + scale * (2 * rng.random(dim) - 1)
+    dual = pt + 0.3 * scale * (2 * rng.random(dim) - 1)
+    for c in (hc, oc):
+        c.reset_data()
+        c.load_point(pt, 0.7)
+        c.load_dual_point(dual)
+        assert c.is_feas()
+        assert c.is_dual_feas()
+    g_h, g_o = np.array(hc.get_grad()), np.array(oc.get_grad())
+    assert rel(g_h, g_o) < 1e-10
+    V = np.asfortranarray(rng.standard_normal((dim, 3)))
+    for name in ("hess_prod", "inv_hess_prod", "hess_prod_slow"):
+        Ph = np.zeros((dim, 3), order="F")
+        Po = np.zeros((dim, 3), order="F")
+        getattr(hc, name)(Ph, V)
+        getattr(oc, name)(Po, V)
+        assert rel(Ph, Po) < 1e-8, name
+    assert hc.use_sqrt_hess_oracles(dim - 1) == oc.use_sqrt_hess_oracles(dim - 1) == True   # factor exists after inv_hess_prod
+    for name in ("sqrt_hess_prod", "inv_sqrt_hess_prod"):
+        Ph = np.zeros((dim, 3), order="F")
+        Po = np.zeros((dim, 3), order="F")
+        getattr(hc, name)(Ph, V)
+        getattr(oc, name)(Po, V)
+        assert rel(Ph, Po) < 1e-8, name
+    for c in (hc, oc):
+        c.update_hess_aux()
+    d3h = np.array(hc.dder3(V[:, 0].copy() * scale))
+    d3o = np.array(oc.dder3(V[:, 0].copy() * scale))
+    assert rel(d3h, d3o) < 1e-8
+    assert hc.check_numerics() == oc.check_numerics()
+    ph, po = hc.get_proxsqr(0.9, True), oc.get_proxsqr(0.9, True)
+    assert abs(ph - po) <= 1e-7 * max(1.0, abs(po))
+    if kind == "wsos":   # forced slow Hessian product (test/cone.jl:89-95)
+        hc.use_hess_prod_slow = True
+        oc.use_hess_prod_slow = True
+        oc.use_hess_prod_slow_updated = True
+        Ph = np.zeros((dim, 3), order="F")
+        Po = np.zeros((dim, 3), order="F")
+        hc.hess_prod_slow(Ph, V)
+        oc.hess_prod_slow(Po, V)
+        assert rel(Ph, Po) < 1e-8
+
+
+def test_epinormspectral_dual_feasibility_nuclear_norm():
+    import hypatia_jl_amd as H
+    rng = np.random.default_rng(0)
+    for (d1, d2) in [(1, 5), (4, 6), (7, 7), (40, 55)]:
+        c = H.EpiNormSpectral(d1, d2)
+        Wm = rng.standard_normal((d1, d2))
+        nn = np.linalg.svd(Wm, compute_uv=False).sum()
+        for margin, expect in ((1e-6, True), (-1e-6, False)):
+            c.load_dual_point(np.concatenate([[nn * (1 + margin)], Wm.reshape(-1, order="F")]))
+            assert c.is_dual_feas() == expect, (d1, d2, margin)

@@ -7,7 +7,7 @@ from instance_harness import build_solve_check
 
 pytestmark = pytest.mark.gpu
 
-HIP_KINDS = ("nonnegative", "possemideftri")
+HIP_KINDS = ("nonnegative", "possemideftri", "epinormspectral", "wsosinterpnonnegative")
 
 
 def _hip_ok(inst):
@@ -19,8 +19,12 @@ def _instances():
     return {k: v for k, v in I.KNOWN_ANSWER.items() if _hip_ok(v())}
 
 
-@pytest.mark.parametrize("name", sorted(["dimension1", "primalinfeas1", "nonnegative4", "possemideftri1", "possemideftri2",
-                                         "possemideftri3", "possemideftri4", "possemideftri8", "possemideftri9"]))
+def _all_names():
+    from oracle import instances as I
+    return sorted(I.KNOWN_ANSWER)
+
+
+@pytest.mark.parametrize("name", _all_names())
 @pytest.mark.parametrize("reduce", [True, False])
 def test_known_answer_hip(name, reduce):
     import hypatia_jl_amd as H
@@ -106,3 +110,16 @@ def test_linearopt_config1_hip():
     inst = I.linearopt(50, 100, seed=1)
     s = build_solve_check(H.Solver(default_tol_relax=10), H.make_model(inst), inst)
     assert s.model.n == 50 and s.model.p == 0 and s.model.q == 100
+
+
+def test_small_polymin_and_matrixcompletion_hip():
+    """configs 5 and 3b at small size through the HIP path (WSOS both forms, EpiNormSpectral)"""
+    import hypatia_jl_amd as H
+    from oracle import instances as I
+    from oracle.build import make_model as omodel
+    from oracle.solvers import Solver as OSolver
+    for inst in (I.polymin(2, 3, True, seed=2), I.polymin(2, 3, False, seed=2), I.polymin(3, 2, False, seed=4), I.matrixcompletion(4, 6, seed=2)):
+        hs = build_solve_check(H.Solver(default_tol_relax=10), H.make_model(inst), inst)
+        os_ = build_solve_check(OSolver(default_tol_relax=10), omodel(inst), inst)
+        assert abs(hs.primal_obj - os_.primal_obj) <= 1e-6 * (1 + abs(os_.primal_obj))
+        assert abs(hs.num_iters - os_.num_iters) <= 2
