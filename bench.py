@@ -128,7 +128,7 @@ def main_multi(args, world, rank, local_rank):
             "config": {"workload": "configs[1] block per GPU: %d x PosSemidefTri side=%d (q=%d total), dense random G, n=%d, p=0; "
                                    "cones sharded one per rank, Schur all-reduce (sum, f64, n x n) per iteration" % (world, side, q, n),
                        "n": n, "q": q, "seed": args.seed, "parallelism": "cone-shard x%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<true, 4> (per-rank Schur syrk, upper)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<true, 4, 1> + splitk_reduce (per-rank Schur syrk, upper)", "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                          "launch_ms": syrk_ms, "flops_per_launch": syrk_flops},
             "kkt_solves_per_step": (solver.n_solves - n_solves0) / args.steps,
@@ -213,7 +213,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "configs[1]: single PosSemidefTri side=%d (q=%d), dense random G q x n, n=%d, p=0" % (args.side, q, args.n),
                    "n": args.n, "q": q, "seed": args.seed},
-        "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<true> (Schur syrk, upper)", "achieved": achieved,
+        "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<true, 4, 1> (Schur syrk, upper)", "achieved": achieved,
                      "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                      "traffic": None, "launch_ms": syrk_ms, "flops_per_launch": syrk_flops},
         "phases_ms_per_step": {"sqrt_hess_prod": ks[0] / args.steps, "syrk": ks[1] / args.steps, "cholesky": ks[2] / args.steps,

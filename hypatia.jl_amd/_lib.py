@@ -72,6 +72,7 @@ SIGNATURES = {
     "hyp_sys_mul_G": [c_vp, c_int, c_dbl, c_vp, c_dbl, c_vp],
     "hyp_sys_get_lhs": [c_vp, c_vp],
     "hyp_dense_gemm": [c_vp, c_int, c_int, c_int, c_int, c_int, c_dbl, c_vp, c_int, c_vp, c_int, c_dbl, c_vp, c_int],
+    "hyp_dense_syrk": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int],
     "hyp_dense_potrf": [c_vp, c_int, c_vp, c_int, P(c_int)],
     "hyp_dense_posv": [c_vp, c_int, c_vp, c_int, c_vp, P(c_int)],
     "hyp_dense_gemv": [c_vp, c_int, c_int, c_int, c_dbl, c_vp, c_int, c_vp, c_dbl, c_vp],

@@ -426,6 +426,20 @@ int hyp_dense_gemm(hyp_ctx* ctx, int transa, int upper, int M, int N, int K, dou
   c.sync();
   API_END(ctx)
 }
+int hyp_dense_syrk(hyp_ctx* ctx, int N, int K, const double* A, int lda, double* C, int ldc) {
+  API_BEGIN
+  Ctx& c = ctx->c;
+  DBuf dA((size_t)lda * N * 8), dC((size_t)ldc * N * 8);
+  c.h2d(dA.p, A, (size_t)lda * N * 8);
+  c.h2d(dC.p, C, (size_t)ldc * N * 8);
+  GemmArgs g{};
+  g.M = N; g.N = N; g.K = K; g.A = dA.d(); g.lda = lda; g.B = dA.d(); g.ldb = lda; g.C = dC.d(); g.ldc = ldc;
+  g.alpha = 1; g.beta = 0; g.tri = GEMM_UPPER; g.krange = KR_ALL; g.batch = 1; g.tag = 1;
+  gemm(c, true, g);
+  c.d2h(C, dC.p, (size_t)ldc * N * 8);
+  c.sync();
+  API_END(ctx)
+}
 int hyp_dense_potrf(hyp_ctx* ctx, int n, double* A, int lda, int* info) {
   API_BEGIN
   Ctx& c = ctx->c;
@@ -481,7 +495,7 @@ int hyp_bench_syrk(hyp_ctx* ctx, int N, int K, int reps, double* ms_out) {
   c.sync();
   GemmArgs g{};
   g.M = N; g.N = N; g.K = K; g.A = dA.d(); g.lda = K; g.B = dA.d(); g.ldb = K; g.C = dC.d(); g.ldc = N;
-  g.alpha = 1; g.beta = 0; g.tri = GEMM_UPPER; g.krange = KR_ALL; g.batch = 1;
+  g.alpha = 1; g.beta = 0; g.tri = GEMM_UPPER; g.krange = KR_ALL; g.batch = 1; g.tag = 1;
   gemm(c, true, g);
   c.sync();
   hipEvent_t e0, e1;

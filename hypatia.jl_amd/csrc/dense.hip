@@ -34,7 +34,7 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
       double* A22 = A + (long)(k0 + nb) * lda + (k0 + nb);
       GemmArgs t{};   // A12 <- inv(U11)' A12   (single m-tile: in place is safe, see gemm_f64.hpp)
       t.M = nb; t.N = m; t.K = nb;
-      t.A = dinv + (long)(k0 / NB) * NB * NB; t.lda = NB; t.strideA = strideD;
+      t.A = dinv + (long)(k0 / NB) * DINV_BLK; t.lda = NB; t.strideA = strideD;
       t.B = A12; t.ldb = lda; t.strideB = strideA;
       t.C = A12; t.ldc = lda; t.strideC = strideA;
       t.alpha = 1.0; t.beta = 0.0; t.tri = GEMM_FULL; t.krange = KR_LE_M; t.batch = batch;
@@ -54,81 +54,88 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
 // =============================================================================================
 // triangular solve, one right-hand side: x <- U^-T x (forward) or U^-1 x (backward)
 // =============================================================================================
-// Solve op(T) x = y for one diagonal block T = U[k0:k0+nb, k0:k0+nb] (upper triangular, in global
-// memory) by true substitution -- dtrsv semantics, backward stable -- called by a whole workgroup of
-// 256 threads.  ys (LDS, NB doubles) holds y on entry and x on exit.  The triangle is staged through
-// LDS (coalesced), the reciprocals of its diagonal are formed once, and one wavefront runs the 128
-// substitution steps with the running right-hand side in registers (two unknowns per lane, the
-// pivot broadcast by a lane shuffle, branch-free updates).  TS_LD = 129 keeps both the row reads
-// (forward) and the column reads (backward) free of LDS bank conflicts.
+// ---- diagonal block solve of the blocked substitution -----------------------------------------
+// x = op(T)^-1 y for one diagonal block T = U[k0:k0+nb, k0:k0+nb] (op = transpose for the forward
+// sweep).  A serial substitution costs 128 dependent steps per block on the critical path of 40
+// launches; instead the block is applied through its explicit inverse D = inv(T) (kept from the
+// factorization, both D and D' are stored) and then corrected by TWO steps of iterative refinement
+// against T itself:  x0 = D y;  x += D (y - T x)  twice.  Each step is a dense 128 x 128
+// matrix-vector product spread over the whole workgroup.  With cond(T) eps << 1 the refined x has the
+// backward error of substitution (the plain D y product does not: it cost the late-iteration
+// residuals).  TS_LD = 129 keeps row and column reads of T conflict-free in LDS.
 constexpr int TS_LD = NB + 1;
-// broadcast lane `src` (wave-uniform) of a double: two v_readlane_b32 instead of the two ds_bpermute
-// round trips that __shfl costs on the substitution's critical path
-__device__ __forceinline__ double readlane_f64(double v, int src) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_readlane(lo, src);
-  hi = __builtin_amdgcn_readlane(hi, src);
-  return __hiloint2double(hi, lo);
-}
-// issue the 64 loads of this thread's share of the diagonal block (row r = tid & 127, columns
-// (tid >> 7) + 2 k) -- called first thing in the kernel so the HBM latency overlaps the gather
-__device__ __forceinline__ void diag_issue_loads(const double* __restrict__ T, long ldu, int nb, double (&dv)[64]) {
+
+// thread (r = tid & 127, cb = tid >> 7) loads row r, columns cb + 2k (k < 64) of a 128 x 128 block
+// tri: 1 = upper triangular with identity padding (the factor block), 2 = upper, 3 = lower (inverse blocks):
+// structural zeros are not fetched
+__device__ __forceinline__ void block_issue_loads(const double* __restrict__ B, long ld, int nb, int tri, double (&v)[64]) {
   const int r = threadIdx.x & (NB - 1), cb = threadIdx.x >> 7;
 #pragma unroll
   for (int k = 0; k < 64; ++k) {
     const int c = cb + 2 * k;
-    dv[k] = (r < nb && c < nb && r <= c) ? T[(long)c * ldu + r] : ((r == c) ? 1.0 : 0.0);
+    const bool ok = (r < nb && c < nb) && (tri == 3 ? r >= c : r <= c);
+    v[k] = ok ? B[(long)c * ld + r] : ((tri == 1 && r == c) ? 1.0 : 0.0);
   }
 }
 
-__device__ void diag_solve(const double (&dv)[64], int nb, bool trans, double* ys, double* Ts, double* rdiag) {
+// out[i] = (add ? out[i] : 0) + sum_c M[i, c] vin[c], M rows held in registers (see block_issue_loads)
+__device__ __forceinline__ void block_matvec_regs(const double (&m)[64], const double* vin, double* part, double* out, bool add) {
+  const int tid = threadIdx.x, cb = tid >> 7;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 64; k += 4) {
+    s0 += m[k] * vin[cb + 2 * k];
+    s1 += m[k + 1] * vin[cb + 2 * k + 2];
+    s2 += m[k + 2] * vin[cb + 2 * k + 4];
+    s3 += m[k + 3] * vin[cb + 2 * k + 6];
+  }
+  part[tid] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (tid < NB) out[tid] = (add ? out[tid] : 0.0) + (part[tid] + part[tid + NB]);
+  __syncthreads();
+}
+
+// res[i] = y[i] - sum_l opT[i, l] x[l] with T in LDS (Ts[r * TS_LD + c] = T[r, c])
+__device__ __forceinline__ void block_residual(const double* Ts, bool trans, const double* y, const double* x, double* part, double* res) {
+  const int tid = threadIdx.x, i = tid & (NB - 1), half = tid >> 7;
+  double s0 = 0.0, s1 = 0.0;
+  const int l0 = half * 64;
+  if (trans) {
+#pragma unroll 8
+    for (int l = 0; l < 64; l += 2) {
+      s0 += Ts[(l0 + l) * TS_LD + i] * x[l0 + l];
+      s1 += Ts[(l0 + l + 1) * TS_LD + i] * x[l0 + l + 1];
+    }
+  } else {
+#pragma unroll 8
+    for (int l = 0; l < 64; l += 2) {
+      s0 += Ts[i * TS_LD + l0 + l] * x[l0 + l];
+      s1 += Ts[i * TS_LD + l0 + l + 1] * x[l0 + l + 1];
+    }
+  }
+  part[tid] = s0 + s1;
+  __syncthreads();
+  if (tid < NB) res[tid] = y[tid] - (part[tid] + part[tid + NB]);
+  __syncthreads();
+}
+
+// ys (LDS): y on entry, x on exit.  tv = T block in registers (written to LDS here), dv = inverse block rows.
+__device__ void diag_solve(const double (&tv)[64], const double (&dv)[64], bool trans, double* ys, double* Ts, double* xv, double* rv,
+                           double* part) {
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
   {
     const int r = tid & (NB - 1), cb = tid >> 7;
 #pragma unroll
-    for (int k = 0; k < 64; ++k) Ts[r * TS_LD + cb + 2 * k] = dv[k];
+    for (int k = 0; k < 64; ++k) Ts[r * TS_LD + cb + 2 * k] = tv[k];
   }
   __syncthreads();
-  if (tid < NB) rdiag[tid] = 1.0 / Ts[tid * TS_LD + tid];
-  __syncthreads();
-  if (wave == 0) {
-    double y0 = (lane < nb) ? ys[lane] : 0.0;
-    double y1 = (lane + 64 < nb) ? ys[lane + 64] : 0.0;
-    if (trans) {   // U' x = y : x_j = y_j / U_jj ; y_l -= U[j, l] x_j for l > j
-#pragma unroll 4
-      for (int j = 0; j < 64; ++j) {
-        const double xj = readlane_f64(y0, j) * rdiag[j];
-        const double u0 = Ts[j * TS_LD + lane], u1 = Ts[j * TS_LD + 64 + lane];
-        y0 = (lane == j) ? xj : ((lane > j) ? y0 - u0 * xj : y0);
-        y1 = y1 - u1 * xj;
-      }
-#pragma unroll 4
-      for (int jj = 0; jj < 64; ++jj) {
-        const int j = 64 + jj;
-        const double xj = readlane_f64(y1, jj) * rdiag[j];
-        const double u1 = Ts[j * TS_LD + 64 + lane];
-        y1 = (lane == jj) ? xj : ((lane > jj) ? y1 - u1 * xj : y1);
-      }
-    } else {       // U x = y : x_j = y_j / U_jj ; y_i -= U[i, j] x_j for i < j
-#pragma unroll 4
-      for (int jj = 63; jj >= 0; --jj) {
-        const int j = 64 + jj;
-        const double xj = readlane_f64(y1, jj) * rdiag[j];
-        const double u0 = Ts[lane * TS_LD + j], u1 = Ts[(64 + lane) * TS_LD + j];
-        y1 = (lane == jj) ? xj : ((lane < jj) ? y1 - u1 * xj : y1);
-        y0 = y0 - u0 * xj;
-      }
-#pragma unroll 4
-      for (int j = 63; j >= 0; --j) {
-        const double xj = readlane_f64(y0, j) * rdiag[j];
-        const double u0 = Ts[lane * TS_LD + j];
-        y0 = (lane == j) ? xj : ((lane < j) ? y0 - u0 * xj : y0);
-      }
-    }
-    if (lane < nb) ys[lane] = y0;
-    if (lane + 64 < nb) ys[lane + 64] = y1;
+  block_matvec_regs(dv, ys, part, xv, false);          // x0 = D y
+#pragma unroll 1
+  for (int it = 0; it < 2; ++it) {
+    block_residual(Ts, trans, ys, xv, part, rv);       // r = y - op(T) x
+    block_matvec_regs(dv, rv, part, xv, true);         // x += D r
   }
+  if (tid < NB) ys[tid] = xv[tid];
   __syncthreads();
 }
 
@@ -136,65 +143,85 @@ __device__ void diag_solve(const double (&dv)[64], int nb, bool trans, double* y
 // final).  Workgroup 0 updates block kb+1 with ALL of its pending contribution from block kb and then
 // solves it; the other workgroups apply block kb's contribution to the columns beyond block kb+1.
 // With kb = -1 only workgroup 0 runs and solves block 0.
-__global__ __launch_bounds__(256) void trsv_fwd_step_kernel(const double* __restrict__ U, long ldu, const double* __restrict__ dinv,
-                                                            int n, int kb, double* __restrict__ x) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void trsv_fwd_step_kernel(const double* __restrict__ U, long ldu, const double* __restrict__ dinv, int n, int kb, double* __restrict__ x) {
   __shared__ double xs[NB];
   __shared__ double ys[NB];
-  __shared__ double rdiag[NB];
+  __shared__ double xv[NB];
+  __shared__ double rv[NB];
+  __shared__ double part[2 * NB];
   __shared__ double Ts[NB * TS_LD];
   const int tid = threadIdx.x;
   const int k0 = kb * NB;
   const int nbk = (kb >= 0) ? min(NB, n - k0) : 0;
   const int next0 = (kb + 1) * NB;
-  if (kb >= 0) {
-    if (tid < NB) xs[tid] = (tid < nbk) ? x[k0 + tid] : 0.0;
-    __syncthreads();
-  }
   const int sub = tid & 15, grp = tid >> 4;   // 16 lanes per column, 16 columns per pass
   if (blockIdx.x == 0) {
     const int nbn = min(NB, n - next0);
     if (nbn <= 0) return;
-    double dv[64];
-    diag_issue_loads(U + (long)next0 * ldu + next0, ldu, nbn, dv);
+    // issue order = need order (loads return in order): x_k / pending rhs, the gather panel, then the blocks
+    double xk = 0.0, yk = 0.0;
+    if (tid < NB) {
+      xk = (tid < nbk) ? x[k0 + tid] : 0.0;
+      yk = (tid < nbn) ? x[next0 + tid] : 0.0;
+    }
+    double v[8][8];
+    if (kb >= 0) {
+#pragma unroll
+      for (int pp = 0; pp < 8; ++pp) {   // 16 lanes per column, 8 passes of 16 columns: 64 independent loads per lane
+        const int cl = grp + 16 * pp;
+        const double* col = U + (long)(next0 + min(cl, nbn - 1)) * ldu + k0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[pp][k] = (sub + 16 * k < nbk) ? col[sub + 16 * k] : 0.0;
+      }
+    }
+    double tv[64], dv[64];
+    block_issue_loads(U + (long)next0 * ldu + next0, ldu, nbn, 1, tv);                   // T = U_next (upper)
+    block_issue_loads(dinv + (long)(kb + 1) * DINV_BLK + NB * NB, NB, nbn, 3, dv);      // rows of inv(T)' (lower)
+    if (tid < NB) {
+      xs[tid] = xk;
+      ys[tid] = yk;
+    }
+    __syncthreads();
     if (kb >= 0) {
       double xr[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) xr[k] = xs[sub + 16 * k];
-#pragma unroll 2
-      for (int cl = grp; cl < NB; cl += 16) {   // 16 lanes per column, 8 independent loads per lane
-        const double* col = U + (long)(next0 + min(cl, nbn - 1)) * ldu + k0;
-        double v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = (sub + 16 * k < nbk) ? col[sub + 16 * k] : 0.0;
-        double s = 0.0;
+      for (int pp = 0; pp < 8; ++pp) {
+        const int cl = grp + 16 * pp;
+        double sacc = 0.0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s += v[k] * xr[k];
+        for (int k = 0; k < 8; ++k) sacc += v[pp][k] * xr[k];
 #pragma unroll
-        for (int off = 8; off > 0; off >>= 1) s += __shfl_down(s, off, 16);
-        if (sub == 0 && cl < nbn) ys[cl] = x[next0 + cl] - s;
+        for (int off = 8; off > 0; off >>= 1) sacc += __shfl_down(sacc, off, 16);
+        if (sub == 0 && cl < nbn) ys[cl] -= sacc;
       }
-    } else {
-      if (tid < nbn) ys[tid] = x[tid];
+      __syncthreads();
     }
-    __syncthreads();
-    // solve the diagonal block by substitution: U_next' x_next = ys
-    diag_solve(dv, nbn, true, ys, Ts, rdiag);
+    diag_solve(tv, dv, true, ys, Ts, xv, rv, part);
     if (tid < nbn) x[next0 + tid] = ys[tid];
   } else {
+    if (tid < NB) xs[tid] = (tid < nbk) ? x[k0 + tid] : 0.0;
+    __syncthreads();
     const int c0 = next0 + NB + (blockIdx.x - 1) * 64;
     double xr[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) xr[k] = xs[sub + 16 * k];
+    double v[4][8];
 #pragma unroll
-    for (int cc = grp; cc < 64; cc += 16) {
-      const int l = c0 + cc;
+    for (int pp = 0; pp < 4; ++pp) {
+      const int l = c0 + grp + 16 * pp;
       const double* col = U + (long)min(l, n - 1) * ldu + k0;
-      double v[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = (sub + 16 * k < nbk) ? col[sub + 16 * k] : 0.0;
+      for (int k = 0; k < 8; ++k) v[pp][k] = (sub + 16 * k < nbk) ? col[sub + 16 * k] : 0.0;
+    }
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const int l = c0 + grp + 16 * pp;
       double s = 0.0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) s += v[k] * xr[k];
+      for (int k = 0; k < 8; ++k) s += v[pp][k] * xr[k];
 #pragma unroll
       for (int off = 8; off > 0; off >>= 1) s += __shfl_down(s, off, 16);
       if (sub == 0 && l < n) x[l] -= s;
@@ -205,59 +232,68 @@ __global__ __launch_bounds__(256) void trsv_fwd_step_kernel(const double* __rest
 // One fused step of the backward solve U x = y.  Block kb (from the bottom) has just been solved.
 // Workgroup 0 updates block kb-1 and solves it; the others update the rows above block kb-1.
 // With kb = nblk only workgroup 0 runs and solves the last block.
-__global__ __launch_bounds__(256) void trsv_bwd_step_kernel(const double* __restrict__ U, long ldu, const double* __restrict__ dinv,
-                                                            int n, int nblk, int kb, double* __restrict__ x) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void trsv_bwd_step_kernel(const double* __restrict__ U, long ldu, const double* __restrict__ dinv, int n, int nblk, int kb, double* __restrict__ x) {
   __shared__ double xs[NB];
   __shared__ double ys[NB];
-  __shared__ double part[NB];
-  __shared__ double rdiag[NB];
+  __shared__ double xv[NB];
+  __shared__ double rv[NB];
+  __shared__ double part[2 * NB];
   __shared__ double Ts[NB * TS_LD];
   const int tid = threadIdx.x;
   const int k0 = kb * NB;
   const int nbk = (kb < nblk) ? min(NB, n - k0) : 0;
-  if (kb < nblk) {
-    if (tid < NB) xs[tid] = (tid < nbk) ? x[k0 + tid] : 0.0;
-    __syncthreads();
-  }
   if (blockIdx.x == 0) {
-    const int p0 = (kb - 1) * NB;   // previous block (always a full NB block)
+    const int p0 = (kb - 1) * NB;
     if (kb - 1 < 0) return;
     const int nbp = min(NB, n - p0);
-    double dv[64];
-    diag_issue_loads(U + (long)p0 * ldu + p0, ldu, nbp, dv);
-    const int i = tid & 127, half = tid >> 7;
-    double s = 0.0;
-    if (kb < nblk && i < nbp) {
-      const int l0 = half ? 64 : 0;
-      const double* up = U + (long)(k0 + l0) * ldu + p0 + i;
-#pragma unroll
-      for (int lb = 0; lb < 64; lb += 16) {   // 16 independent loads in flight
-        double v[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = (l0 + lb + k < nbk) ? up[(long)(lb + k) * ldu] : 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s += v[k] * xs[l0 + lb + k];
-      }
+    double xk = 0.0, yk = 0.0;
+    if (tid < NB) {
+      xk = (tid < nbk) ? x[k0 + tid] : 0.0;
+      yk = (tid < nbp) ? x[p0 + tid] : 0.0;
     }
-    if (half) part[i] = s;
+    const int bi = tid & 127, bhalf = tid >> 7;
+    const int bl0 = bhalf ? 64 : 0;
+    double v[64];
+    if (kb < nblk) {   // this thread's 64 entries of row p0 + bi of the panel U[p-block, k-block]
+      const double* up = U + (long)(k0 + bl0) * ldu + p0 + min(bi, nbp - 1);
+#pragma unroll
+      for (int k = 0; k < 64; ++k) v[k] = (bl0 + k < nbk) ? up[(long)k * ldu] : 0.0;
+    }
+    double tv[64], dv[64];
+    block_issue_loads(U + (long)p0 * ldu + p0, ldu, nbp, 1, tv);
+    block_issue_loads(dinv + (long)(kb - 1) * DINV_BLK, NB, nbp, 2, dv);                  // rows of inv(T) (upper)
+    if (tid < NB) {
+      xs[tid] = xk;
+      ys[tid] = yk;
+    }
     __syncthreads();
-    if (!half && i < nbp) ys[i] = x[p0 + i] - (s + part[i]);
-    __syncthreads();
-    diag_solve(dv, nbp, false, ys, Ts, rdiag);
+    if (kb < nblk) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int k = 0; k < 64; ++k) sacc += v[k] * xs[bl0 + k];
+      part[tid] = sacc;
+      __syncthreads();
+      if (tid < nbp) ys[tid] -= (part[tid] + part[tid + NB]);
+      __syncthreads();
+    }
+    diag_solve(tv, dv, false, ys, Ts, xv, rv, part);
     if (tid < nbp) x[p0 + tid] = ys[tid];
   } else {
+    if (tid < NB) xs[tid] = (tid < nbk) ? x[k0 + tid] : 0.0;
+    __syncthreads();
     const int rows_above = (kb - 1) * NB;   // rows [0, rows_above) get block kb's contribution
     const int i = (blockIdx.x - 1) * 256 + tid;
     if (i < rows_above) {
       double s = 0.0;
       const double* up = U + (long)k0 * ldu + i;
 #pragma unroll
-      for (int lb = 0; lb < NB; lb += 16) {
-        double v[16];
+      for (int lb = 0; lb < NB; lb += 32) {
+        double v[32];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = (lb + k < nbk) ? up[(long)(lb + k) * ldu] : 0.0;
+        for (int k = 0; k < 32; ++k) v[k] = (lb + k < nbk) ? up[(long)(lb + k) * ldu] : 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) s += v[k] * xs[lb + k];
+        for (int k = 0; k < 32; ++k) s += v[k] * xs[lb + k];
       }
       x[i] -= s;
     }
@@ -293,7 +329,7 @@ void trsm_upper_left(Ctx& c, int n, int nrhs, const double* U, long ldu, const d
     for (int kb = 0; kb < nblk; ++kb) {
       const int k0 = kb * NB, nb = std::min(NB, n - k0), m = n - k0 - nb;
       GemmArgs t{};
-      t.M = nb; t.N = nrhs; t.K = nb; t.A = dinv + (long)kb * NB * NB; t.lda = NB;
+      t.M = nb; t.N = nrhs; t.K = nb; t.A = dinv + (long)kb * DINV_BLK; t.lda = NB;
       t.B = X + k0; t.ldb = ldx; t.C = X + k0; t.ldc = ldx; t.alpha = 1; t.beta = 0; t.krange = KR_LE_M; t.batch = 1;
       t.tile_hint = 128;   // in place (see potrf_upper_batched)
       gemm(c, true, t);
@@ -309,7 +345,7 @@ void trsm_upper_left(Ctx& c, int n, int nrhs, const double* U, long ldu, const d
       const int k0 = kb * NB, nb = std::min(NB, n - k0);
       // Dinv_k X_k needs a non-aliased output (NN form reads rows of B = all of X_k): use work
       GemmArgs t{};
-      t.M = nb; t.N = nrhs; t.K = nb; t.A = dinv + (long)kb * NB * NB; t.lda = NB;
+      t.M = nb; t.N = nrhs; t.K = nb; t.A = dinv + (long)kb * DINV_BLK; t.lda = NB;
       t.B = X + k0; t.ldb = ldx; t.C = work; t.ldc = NB; t.alpha = 1; t.beta = 0; t.krange = KR_GE_M; t.batch = 1;
       gemm(c, false, t);
       HYP_CHECK(hipMemcpy2DAsync(X + k0, ldx * sizeof(double), work, NB * sizeof(double), nb * sizeof(double), nrhs,
@@ -335,7 +371,7 @@ __global__ void place_dinv_kernel(const double* __restrict__ dinv, long strideD,
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || l >= n) return;
   double v = 0.0;
-  if (i / NB == l / NB) v = dinv[(long)b * strideD + (long)(l / NB) * NB * NB + (long)(l % NB) * NB + (i % NB)];
+  if (i / NB == l / NB) v = dinv[(long)b * strideD + (long)(l / NB) * DINV_BLK + (long)(l % NB) * NB + (i % NB)];
   Uinv[(long)b * strideI + (long)l * ldi + i] = v;
 }
 
@@ -353,7 +389,7 @@ void trtri_upper_batched(Ctx& c, int n, const double* U, long ldu, long strideU,
     const int j0 = jb * NB, nb = std::min(NB, n - j0);
     GemmArgs t{};
     t.M = j0; t.N = nb; t.K = nb; t.A = U + (long)j0 * ldu; t.lda = ldu; t.strideA = strideU;
-    t.B = dinv + (long)jb * NB * NB; t.ldb = NB; t.strideB = strideD;
+    t.B = dinv + (long)jb * DINV_BLK; t.ldb = NB; t.strideB = strideD;
     t.C = ws.d(); t.ldc = n; t.strideC = (long)n * NB; t.alpha = 1; t.beta = 0; t.krange = KR_LE_N; t.batch = batch;
     gemm(c, false, t);
     GemmArgs u{};

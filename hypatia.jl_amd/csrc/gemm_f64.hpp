@@ -56,6 +56,10 @@ struct GemmArgs {
   int cm_blk; long cm_stride;
   int tile_hint;   // 0 = automatic, 64 / 128 = force the block tile edge
   int epi;         // 0: C = alpha*acc + beta*C ; 1: C = (alpha*acc)^2 + beta*C (Hadamard square, WSOS Hessian)
+  int tag;         // 1 = the Schur-complement syrk (own kernel symbol, so profiles can tell it apart)
+  // split-K (set by the launcher): blockIdx.z = slice; slices write raw partial sums to `part`
+  // (slice-major copies of C's layout, ldc = part_ld) and a second kernel adds them in slice order
+  int splitk; int kchunk; double* part; long part_ld; long part_stride;
 };
 
 // launch on `st`; returns the HIP launch status

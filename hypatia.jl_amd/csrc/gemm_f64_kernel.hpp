@@ -20,7 +20,7 @@ __device__ __forceinline__ void upper_tile_from_linear(int idx, int& tm, int& tn
 
 // TW = MFMA tiles per wavefront per dimension: 4 -> 128 x 128 block tile (big products),
 //      2 -> 64 x 64 block tile (small matrices: 4x the workgroups, 1/4 the serial MFMA chain each)
-template <bool TRANSA, int TW>
+template <bool TRANSA, int TW, int TAG>
 __global__ __launch_bounds__(GEMM_THREADS, 2)
 void gemm_f64_kernel(GemmArgs p) {
   constexpr int BM = 32 * TW, BN = 32 * TW;
@@ -47,8 +47,12 @@ void gemm_f64_kernel(GemmArgs p) {
   const double* __restrict__ B = p.B + (long)bz * p.strideB;
   double* __restrict__ C = p.C + (long)bz * p.strideC;
 
-  // K range
+  // K range (split-K: this slice's chunk)
   int kbeg = 0, kend = p.K;
+  if (p.splitk > 1) {
+    kbeg = blockIdx.z * p.kchunk;
+    kend = min(p.K, kbeg + p.kchunk);
+  }
   switch (p.krange) {
     case KR_LE_M: kend = min(p.K, m0 + BM); break;
     case KR_GE_M: kbeg = min(p.K, m0) & ~(BK - 1); break;
@@ -152,6 +156,23 @@ void gemm_f64_kernel(GemmArgs p) {
   // epilogue: lane (fr, fk), accumulator register r of tile (j, i) is
   //   C[m0 + wm*WT + i*16 + fr, n0 + wn*WT + j*16 + fk + 4r]
   const bool upper = (p.tri == GEMM_UPPER);
+  if (p.splitk > 1) {   // raw partial sums; alpha / beta / epilogue are applied by splitk_reduce_kernel
+    double* __restrict__ W = p.part + (long)blockIdx.z * p.part_stride;
+#pragma unroll
+    for (int j = 0; j < TW; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * WT + j * 16 + fk + 4 * r;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < TW; ++i) {
+          const int m = m0 + wm * WT + i * 16 + fr;
+          if (m >= p.M || (upper && m > n)) continue;
+          W[(long)n * p.part_ld + m] = acc[j][i][r];
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TW; ++j) {
 #pragma unroll
@@ -174,6 +195,21 @@ void gemm_f64_kernel(GemmArgs p) {
   }
 }
 
+// C = alpha * (sum of the split-K slices, in slice order) + beta * C
+__global__ void splitk_reduce_kernel(int M, int N, int upper, int S, const double* __restrict__ part, long part_ld, long part_stride,
+                                     double alpha, double beta, double* __restrict__ C, long ldc) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = blockIdx.y;
+  if (m >= M || (upper && m > n)) return;
+  double s = 0.0;
+  for (int z = 0; z < S; ++z) s += part[(long)z * part_stride + (long)n * part_ld + m];
+  double* cp = C + (long)n * ldc + m;
+  *cp = alpha * s + (beta != 0.0 ? beta * (*cp) : 0.0);
+}
+
+static double* g_splitk_ws = nullptr;
+static size_t g_splitk_ws_bytes = 0;
+
 hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a) {
   if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return hipSuccess;
   // tile choice: the 128 x 128 tile unless the product is too small to fill the chip with it
@@ -189,14 +225,43 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a) {
   } else {
     nblk = (long)a.tiles_m * a.tiles_n;
   }
-  dim3 grid((unsigned)nblk, (unsigned)a.batch, 1);
-  if (transa) {
-    if (small) hipLaunchKernelGGL((gemm_f64_kernel<true, 2>), grid, dim3(GEMM_THREADS), 0, st, a);
-    else hipLaunchKernelGGL((gemm_f64_kernel<true, 4>), grid, dim3(GEMM_THREADS), 0, st, a);
-  } else {
-    if (small) hipLaunchKernelGGL((gemm_f64_kernel<false, 2>), grid, dim3(GEMM_THREADS), 0, st, a);
-    else hipLaunchKernelGGL((gemm_f64_kernel<false, 4>), grid, dim3(GEMM_THREADS), 0, st, a);
+  // split-K for the tall Schur syrk: pick the slice count that minimises the number of rounds of
+  // 512 resident workgroups (2 per CU) per unit of work, so the last round is not mostly empty
+  a.splitk = 1;
+  if (a.tag == 1 && !small && a.batch == 1 && a.epi == 0 && a.krange == KR_ALL && a.K >= 4096) {
+    double best = 1e30;
+    for (int S = 1; S <= 4; ++S) {
+      if (a.K / S < 1024) break;
+      const double rounds = (double)((nblk * S + 511) / 512) / S;
+      if (rounds < best - 1e-9) { best = rounds; a.splitk = S; }
+    }
   }
+  if (a.splitk > 1) {
+    a.kchunk = (((a.K + a.splitk - 1) / a.splitk) + BK - 1) / BK * BK;
+    a.part_ld = a.M;
+    a.part_stride = (long)a.M * a.N;
+    const size_t need = (size_t)a.splitk * a.part_stride * sizeof(double);
+    if (need > g_splitk_ws_bytes) {
+      if (g_splitk_ws) (void)hipFree(g_splitk_ws);
+      hipError_t e = hipMalloc((void**)&g_splitk_ws, need);
+      if (e != hipSuccess) return e;
+      g_splitk_ws_bytes = need;
+    }
+    a.part = g_splitk_ws;
+  }
+  dim3 grid((unsigned)nblk, (unsigned)a.batch, (unsigned)a.splitk);
+  if (a.tag == 1 && transa && !small) {
+    hipLaunchKernelGGL((gemm_f64_kernel<true, 4, 1>), grid, dim3(GEMM_THREADS), 0, st, a);
+  } else if (transa) {
+    if (small) hipLaunchKernelGGL((gemm_f64_kernel<true, 2, 0>), grid, dim3(GEMM_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((gemm_f64_kernel<true, 4, 0>), grid, dim3(GEMM_THREADS), 0, st, a);
+  } else {
+    if (small) hipLaunchKernelGGL((gemm_f64_kernel<false, 2, 0>), grid, dim3(GEMM_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((gemm_f64_kernel<false, 4, 0>), grid, dim3(GEMM_THREADS), 0, st, a);
+  }
+  if (a.splitk > 1)
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((a.M + 255) / 256, a.N), dim3(256), 0, st, a.M, a.N, a.tri == GEMM_UPPER ? 1 : 0, a.splitk,
+                       a.part, a.part_ld, a.part_stride, a.alpha, a.beta, a.C, a.ldc);
   return hipGetLastError();
 }
 

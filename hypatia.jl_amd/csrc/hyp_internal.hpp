@@ -96,10 +96,12 @@ struct Ctx {
 // ---------------------------------------------------------------------------------------------
 
 // Blocked upper Cholesky A = U'U in place (upper triangle of each n x n matrix of the batch).
-// dinv receives inv(U_kk) for every NB-diagonal block: layout [batch][block][NB*NB] col-major, ld NB.
+// dinv receives, for every NB-diagonal block, inv(U_kk) followed by its transpose:
+// layout [batch][block][2][NB*NB] col-major, ld NB (DINV_BLK doubles per block).
 // d_info[b] = 0 or the 1-based index of the first non-positive pivot (LAPACK dpotrf convention).
 void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int batch, double* dinv, int* d_info);
-inline size_t dinv_elems(int n) { return (size_t)((n + NB - 1) / NB) * NB * NB; }
+constexpr long DINV_BLK = 2L * NB * NB;
+inline size_t dinv_elems(int n) { return (size_t)((n + NB - 1) / NB) * DINV_BLK; }
 
 // x <- U^-T x (trans = true) or U^-1 x (trans = false), U upper triangular n x n with inverted
 // diagonal blocks dinv; nrhs right-hand sides, x col-major with leading dimension ldx.

@@ -14,17 +14,27 @@ namespace hyp {
 // index of (r, c), r <= c, in the packed per-thread upper block array (row-major over r)
 #define UIDX(r, c) ((r) * 8 - (r) * ((r) - 1) / 2 + ((c) - (r)))
 
+// 1 / x on the critical path of every column step: v_rcp_f64 + two Newton steps (the IEEE division
+// expansion is a ~30-instruction dependent chain); dpotf2 itself scales by the reciprocal of the pivot
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void potrf_diag_kernel(double* __restrict__ A, long lda, long strideA, int n, int k0, double* __restrict__ dinv, long strideD,
                        int* __restrict__ info) {
   __shared__ double rowbuf[2][NB];
   __shared__ double colbuf[2][NB];
   __shared__ double dsq[NB];
+  __shared__ double rdsq[NB];
   const int tid = threadIdx.x;
   const int tr = tid & 15, tc = tid >> 4;
   const int nb = min(NB, n - k0);
   double* Ab = A + (long)blockIdx.x * strideA + (long)k0 * lda + k0;
-  double* Db = dinv + (long)blockIdx.x * strideD + (long)(k0 / NB) * NB * NB;
+  double* Db = dinv + (long)blockIdx.x * strideD + (long)(k0 / NB) * DINV_BLK;
 
   double a[36];
 #pragma unroll
@@ -57,7 +67,7 @@ void potrf_diag_kernel(double* __restrict__ A, long lda, long strideA, int n, in
         if (!fail) fail = j + 1;
         piv = 1.0;
       }
-      const double rpiv = 1.0 / piv;
+      const double rpiv = fast_rcp(piv);
       // branch-free rank-1 update: rows i <= j contribute a zero multiplier; within the diagonal
       // register block (c == r) only columns l >= i are touched (dmask), for c > r always l > i
       double rl[8];
@@ -72,13 +82,7 @@ void potrf_diag_kernel(double* __restrict__ A, long lda, long strideA, int n, in
 #pragma unroll
         for (int c = r + 1; c < 8; ++c) a[UIDX(r, c)] -= f * rl[c];
       }
-      if (tr == jj) {   // owner of row j: U[j, l] = A[j, l] / sqrt(piv)
-        const double sq = sqrt(piv);
-        const double rs = 1.0 / sq;
-#pragma unroll
-        for (int c = r0; c < 8; ++c) a[UIDX(r0, c)] *= rs;
-        if (tc == jj) dsq[j] = sq;
-      }
+      if (tr == jj && tc == jj) dsq[j] = piv;   // pivot kept; row scaling U[j,:] = A[j,:]/sqrt(piv) is deferred
       // publish row j + 1 (current values, before its own scaling); columns < 16 r' of that row are
       // never read (they are left of the diagonal), so only c >= r' is stored
       if (jj < 15) {
@@ -94,6 +98,21 @@ void potrf_diag_kernel(double* __restrict__ A, long lda, long strideA, int n, in
       }
       __syncthreads();
     }
+  }
+
+  // deferred row scaling, all rows at once (keeps sqrt / division off the per-column critical path):
+  // dsq <- sqrt(pivot), rdsq <- 1 / sqrt(pivot)
+  if (tid < NB) {
+    const double sq = sqrt(dsq[tid]);
+    dsq[tid] = sq;
+    rdsq[tid] = 1.0 / sq;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const double rs = rdsq[16 * r + tr];
+#pragma unroll
+    for (int c = r; c < 8; ++c) a[UIDX(r, c)] *= rs;
   }
 
   // write U back (upper triangle of the nb x nb block)
@@ -116,7 +135,7 @@ void potrf_diag_kernel(double* __restrict__ A, long lda, long strideA, int n, in
 
   // publish row 127 of X (scaled) and column 127 of U
   if (tr == 15) {
-    const double rd = 1.0 / dsq[NB - 1];
+    const double rd = rdsq[NB - 1];
     x[UIDX(7, 7)] *= rd;
     rowbuf[1][16 * 7 + tc] = x[UIDX(7, 7)];
   }
@@ -148,7 +167,7 @@ void potrf_diag_kernel(double* __restrict__ A, long lda, long strideA, int n, in
       // publish row j - 1 of X (scaled by 1 / U[j-1, j-1]) and column j - 1 of U
       if (jj > 0) {
         if (tr == jj - 1) {
-          const double rd = 1.0 / dsq[j - 1];
+          const double rd = rdsq[j - 1];
 #pragma unroll
           for (int c = r0; c < 8; ++c) {
             x[UIDX(r0, c)] *= rd;
@@ -161,7 +180,7 @@ void potrf_diag_kernel(double* __restrict__ A, long lda, long strideA, int n, in
         }
       } else if (r0 > 0) {
         if (tr == 15) {
-          const double rd = 1.0 / dsq[j - 1];
+          const double rd = rdsq[j - 1];
 #pragma unroll
           for (int c = (r0 + 7) & 7; c < 8; ++c) {
             x[UIDX((r0 + 7) & 7, c)] *= rd;
@@ -185,6 +204,17 @@ void potrf_diag_kernel(double* __restrict__ A, long lda, long strideA, int n, in
       double v = 0.0;
       if (c >= r) v = (i < nb && l < nb && i <= l) ? x[UIDX(r, c < r ? r : c)] : 0.0;
       Db[(long)l * NB + i] = v;
+    }
+  // and its transpose inv(U)' (lower triangular): every thread stores its own elements at the
+  // mirrored position; the parallel diagonal solve of the forward substitution reads it row-major
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int i = 16 * r + tr, l = 16 * c + tc;
+      double v = 0.0;
+      if (c >= r) v = (i < nb && l < nb && i <= l) ? x[UIDX(r, c < r ? r : c)] : 0.0;
+      Db[NB * NB + (long)i * NB + l] = v;
     }
 }
 

@@ -104,7 +104,7 @@ void SysSolver::assemble_lhs() {   // qrchol.jl:214-246 (this process's cones on
     HYP_CHECK(hipEventRecord(ctx.ev[1], ctx.stream));
     GemmArgs s{};   // lhs = HGQ2[1:idx, :]' HGQ2[1:idx, :]  (outer_prod!, dense.jl:80-86)
     s.M = nmp; s.N = nmp; s.K = idx; s.A = HGQ2.d(); s.lda = q; s.B = HGQ2.d(); s.ldb = q; s.C = lhs.d(); s.ldc = nmp;
-    s.alpha = 1; s.beta = 0; s.tri = GEMM_UPPER; s.krange = KR_ALL; s.batch = 1;
+    s.alpha = 1; s.beta = 0; s.tri = GEMM_UPPER; s.krange = KR_ALL; s.batch = 1; s.tag = 1;
     gemm(ctx, true, s);
     HYP_CHECK(hipEventRecord(ctx.ev[2], ctx.stream));
     ctx.kstat[4] += 1;

@@ -114,6 +114,8 @@ int hyp_sys_get_lhs(hyp_sys* sys, double* out_nmpxnmp);        /* upper triangle
 /* C = alpha * op(A) * B + beta * C (col-major; transa: A is K x M; upper != 0: only col >= row) */
 int hyp_dense_gemm(hyp_ctx* ctx, int transa, int upper, int M, int N, int K, double alpha, const double* A, int lda,
                    const double* B, int ldb, double beta, double* C, int ldc);
+/* C = A'A, upper triangle only (dsyrk 'U','T'; A is K x N): the Schur-assembly kernel path incl. split-K */
+int hyp_dense_syrk(hyp_ctx* ctx, int N, int K, const double* A, int lda, double* C, int ldc);
 /* in-place upper Cholesky (dpotrf 'U'); info as LAPACK */
 int hyp_dense_potrf(hyp_ctx* ctx, int n, double* A, int lda, int* info);
 /* dposv 'U': A (upper triangle read) is overwritten by its Cholesky factor U, x (in: b) by A^-1 b */

@@ -87,3 +87,22 @@ def test_gemv(hip, trans, m, n):
     L.check(lib.hyp_dense_gemv(ctx, trans, m, n, 1.5, fp(A), m, fp(x), -0.5, fp(y)), "gemv")
     ref = 1.5 * ((A.T if trans else A) @ x) - 0.5 * y0
     assert np.allclose(y, ref, rtol=1e-12, atol=1e-11)
+
+
+@pytest.mark.parametrize("N,K", [(300, 5000), (130, 4100), (257, 900)])
+def test_syrk_schur_path_with_splitk(hip, N, K):
+    """the Schur-assembly syrk (split-K slices + ordered reduction when K is long)"""
+    lib, ctx, L = hip
+    rng = np.random.default_rng(N + K)
+    A = np.asfortranarray(rng.standard_normal((K, N)))
+    C = np.full((N, N), 3.0, order="F")
+    L.check(lib.hyp_dense_syrk(ctx, N, K, fp(A), K, fp(C), N), "syrk")
+    ref = A.T @ A
+    iu = np.triu_indices(N)
+    assert np.allclose(C[iu], ref[iu], rtol=1e-12, atol=1e-10)
+    il = np.tril_indices(N, -1)
+    assert np.all(C[il] == 3.0)
+    # deterministic: bitwise identical on a second run
+    C2 = np.full((N, N), 3.0, order="F")
+    L.check(lib.hyp_dense_syrk(ctx, N, K, fp(A), K, fp(C2), N), "syrk")
+    assert np.array_equal(C, C2)
