@@ -60,6 +60,7 @@ struct GemmArgs {
   // split-K (set by the launcher): blockIdx.z = slice; slices write raw partial sums to `part`
   // (slice-major copies of C's layout, ldc = part_ld) and a second kernel adds them in slice order
   int splitk; int kchunk; double* part; long part_ld; long part_stride;
+  int vec2;        // set by the launcher: operands are 16-byte aligned with even leading dimensions
 };
 
 // launch on `st`; returns the HIP launch status

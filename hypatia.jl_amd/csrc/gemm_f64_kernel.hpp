@@ -76,7 +76,40 @@ void gemm_f64_kernel(GemmArgs p) {
   constexpr int NN_KSTEP = GEMM_THREADS / BM;
   const int nn_r = tid % BM, nn_k = tid / BM;
 
+  // ---- fast path (TN, tile fully inside M x N, 16-byte aligned operands): unpredicated double2 loads,
+  //      k pair = 2 * (tid & 7), row = (tid >> 3) + 32 * rep; 8 lanes read 128 contiguous bytes
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  constexpr int REPS2 = REPS / 2;
+  const bool fast = TRANSA && p.vec2 && (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  const int vk = (tid & 7) * 2, vr = tid >> 3;
+  const double* __restrict__ fa = A + (long)(m0 + vr) * p.lda + vk;
+  const double* __restrict__ fb = B + (long)(n0 + vr) * p.ldb + vk;
+
+  auto load_tiles_fast = [&](int k0) {   // (shares the staging registers ra / rb with the general loader)
+#pragma unroll
+    for (int rep = 0; rep < REPS2; ++rep) {
+      const d2_t ta = *reinterpret_cast<const d2_t*>(fa + (long)(32 * rep) * p.lda + k0);
+      const d2_t tb = *reinterpret_cast<const d2_t*>(fb + (long)(32 * rep) * p.ldb + k0);
+      ra[2 * rep] = ta.x; ra[2 * rep + 1] = ta.y;
+      rb[2 * rep] = tb.x; rb[2 * rep + 1] = tb.y;
+    }
+  };
+  auto store_tiles_fast = [&](int buf) {
+    double* As = lds[buf][0];
+    double* Bs = lds[buf][1];
+#pragma unroll
+    for (int rep = 0; rep < REPS2; ++rep) {
+      *reinterpret_cast<d2_t*>(As + (vr + 32 * rep) * LDS_S + vk) = (d2_t){ra[2 * rep], ra[2 * rep + 1]};
+      *reinterpret_cast<d2_t*>(Bs + (vr + 32 * rep) * LDS_S + vk) = (d2_t){rb[2 * rep], rb[2 * rep + 1]};
+    }
+  };
+
   auto load_tiles = [&](int k0) {
+    if (fast && k0 + BK <= kend) {
+      load_tiles_fast(k0);
+      return;
+    }
+
     if (TRANSA) {
       const int k = k0 + lk;
       const bool kok = (k < kend);
@@ -105,7 +138,11 @@ void gemm_f64_kernel(GemmArgs p) {
     }
   };
 
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, int k0) {
+    if (fast && k0 + BK <= kend) {
+      store_tiles_fast(buf);
+      return;
+    }
     double* As = lds[buf][0];
     double* Bs = lds[buf][1];
     if (TRANSA) {
@@ -124,6 +161,8 @@ void gemm_f64_kernel(GemmArgs p) {
   auto compute = [&](int buf) {
     const double* As = lds[buf][0] + (wm * WT + fr) * LDS_S + fk;
     const double* Bs = lds[buf][1] + (wn * WT + fr) * LDS_S + fk;
+    // (a register-double-buffered version of these fragment reads was tried: at 2 workgroups per CU it
+    //  spills past 256 VGPRs and loses 15 %; the second resident workgroup already covers the LDS latency)
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
       double af[TW], bf[TW];
@@ -142,13 +181,13 @@ void gemm_f64_kernel(GemmArgs p) {
   const int nkt = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
   if (nkt > 0) {
     load_tiles(kbeg);
-    store_tiles(0);
+    store_tiles(0, kbeg);
     __syncthreads();
     for (int t = 0; t < nkt; ++t) {
       const int buf = t & 1;
       if (t + 1 < nkt) load_tiles(kbeg + (t + 1) * BK);
       compute(buf);
-      if (t + 1 < nkt) store_tiles(buf ^ 1);
+      if (t + 1 < nkt) store_tiles(buf ^ 1, kbeg + (t + 1) * BK);
       __syncthreads();
     }
   }
@@ -249,6 +288,8 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a) {
     }
     a.part = g_splitk_ws;
   }
+  a.vec2 = (transa && ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.B % 16 == 0) && (a.lda % 2 == 0) && (a.ldb % 2 == 0) &&
+            (a.strideA % 2 == 0) && (a.strideB % 2 == 0) && a.krange != KR_GE_M && a.krange != KR_GE_N) ? 1 : 0;
   dim3 grid((unsigned)nblk, (unsigned)a.batch, (unsigned)a.splitk);
   if (a.tag == 1 && transa && !small) {
     hipLaunchKernelGGL((gemm_f64_kernel<true, 4, 1>), grid, dim3(GEMM_THREADS), 0, st, a);

@@ -160,6 +160,37 @@ int main(int argc, char** argv) {
     }
     printf("syrk spot check rel err %.3e %s\n", me, me < 1e-11 ? "OK" : "FAIL");
     if (!(me < 1e-11)) ++fails;
+    // DVFS check: the same syrk on zero-filled operands (no data toggling) and with the split-K path
+    {
+      std::vector<double> z((size_t)q * n, 0.0);
+      double* dZ; CK(hipMalloc(&dZ, (size_t)q * n * 8));
+      CK(hipMemcpy(dZ, z.data(), z.size() * 8, hipMemcpyHostToDevice));
+      hyp::GemmArgs gz = g; gz.A = dZ; gz.B = dZ;
+      for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        CK(hyp::gemm_f64_launch(0, true, gz));
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("syrk upper ZERO operands: %.3f ms, %.2f TFLOP/s\n", ms, (double)n * n * q / ms * 1e-9);
+      }
+      hyp::GemmArgs gs = g; gs.tag = 1;
+      for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        CK(hyp::gemm_f64_launch(0, true, gs));
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("syrk upper split-K (tag 1) random: %.3f ms, %.2f TFLOP/s\n", ms, (double)n * n * q / ms * 1e-9);
+      }
+      gs.A = dZ; gs.B = dZ;
+      for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        CK(hyp::gemm_f64_launch(0, true, gs));
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("syrk upper split-K ZERO operands: %.3f ms, %.2f TFLOP/s\n", ms, (double)n * n * q / ms * 1e-9);
+      }
+      hipFree(dZ);
+    }
     g.tri = hyp::GEMM_FULL;
     for (int rep = 0; rep < 2; ++rep) {
       hipEventRecord(e0);

@@ -50,6 +50,26 @@ __global__ __launch_bounds__(1024) void k_mfma1024(double* out, long long* cyc, 
   out[(blockIdx.x * blockDim.x + threadIdx.x) % 4096] = s;
 }
 
+__global__ __launch_bounds__(1024) void k_mfma1024_rand(double* out, int iters) {
+  d4_t acc[4];
+  for (int i = 0; i < 4; ++i) acc[i] = (d4_t){0, 0, 0, 0};
+  unsigned long long s = 88172645463325252ULL + threadIdx.x * 7919ULL + blockIdx.x * 104729ULL;
+  double a[4], b[4];
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // cheap xorshift -> doubles in [1, 2)
+      s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+      a[i] = __longlong_as_double((long long)((s >> 12) | 0x3FF0000000000000ULL)) - 1.5;
+      b[i] = __longlong_as_double((long long)(((s * 2654435761ULL) >> 12) | 0x3FF0000000000000ULL)) - 1.5;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[i], acc[i], 0, 0, 0);
+  }
+  double t = 0;
+  for (int i = 0; i < 4; ++i) t += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[(blockIdx.x * blockDim.x + threadIdx.x) % 4096] = t;
+}
+
 __global__ __launch_bounds__(512) void k_mixed(double* out, int iters) {
   int wave = threadIdx.x >> 6;
   double s = 0;
@@ -108,6 +128,16 @@ int main() {
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       if (rep == 1) printf("mfma_f64 1024-thread blocks=%d: %.3f ms  ns per MFMA per SIMD = %.2f  (%.2f TFLOP/s)\n", blocks, ms,
                            ms * 1e6 / (iters * 4.0 * 4.0 * ((blocks + cus - 1) / cus)), (double)blocks * 16 * iters * 4 * 2048.0 / ms * 1e-9);
+    }
+  }
+  // random-ish operand data that changes every iteration (DVFS: data toggling lowers the sustained clock)
+  for (int blocks : {256, 512}) {
+    for (int rep = 0; rep < 2; ++rep) {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(k_mfma1024_rand, dim3(blocks), dim3(1024), 0, 0, out, iters);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep == 1) printf("mfma_f64 1024-thread RANDOM operands blocks=%d: %.3f ms (%.2f TFLOP/s)\n", blocks, ms, (double)blocks * 16 * iters * 4 * 2048.0 / ms * 1e-9);
     }
   }
   // concurrent MFMA + VALU FMA (mixed kernel: even waves MFMA, odd waves VALU)
