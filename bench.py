@@ -234,7 +234,9 @@ def main():
         os_.solve()
         cpu_it_s = os_.num_iters / os_.iter_time if os_.iter_time > 0 else 0.0
         out["cpu_baseline"] = {"value": cpu_it_s, "unit": "iterations/s", "cores": os.cpu_count(), "kind": "port",
-                               "sample": "first %d IPM iterations of the same instance, numpy/scipy (OpenBLAS threads = all cores)" % os_.num_iters,
+                               "sample": "first %d IPM iterations of the same instance; numpy/scipy restatement: OpenBLAS on all cores for the syrk / "
+                                         "Cholesky / gemv, the per-column dtrsm loop of the PSD products is sequential as in the reference "
+                                         "(possemideftri.jl:168-174) and Python-bound here" % os_.num_iters,
                                "s_per_iteration": (os_.iter_time / max(os_.num_iters, 1))}
         out["speedup_vs_cpu_port"] = out["value"] / cpu_it_s if cpu_it_s > 0 else None
     if hasattr(lib, "report"):

@@ -61,6 +61,7 @@ struct GemmArgs {
   // (slice-major copies of C's layout, ldc = part_ld) and a second kernel adds them in slice order
   int splitk; int kchunk; double* part; long part_ld; long part_stride;
   int vec2;        // set by the launcher: operands are 16-byte aligned with even leading dimensions
+  const int* tile_map;   // optional (tm, tn) per blockIdx.x: XCD-aware tile order (set by the launcher)
 };
 
 // launch on `st`; returns the HIP launch status

@@ -2,6 +2,7 @@
 // gemm_f64.hip (the library instantiation) and by tools/probe_gemm.hip.
 #pragma once
 #include "gemm_f64.hpp"
+#include <vector>
 
 namespace hyp {
 
@@ -35,7 +36,10 @@ void gemm_f64_kernel(GemmArgs p) {
 
   int tm, tn;
   const int bz = blockIdx.y;   // batch index
-  if (p.tri == GEMM_UPPER) {
+  if (p.tile_map) {
+    tm = p.tile_map[2 * blockIdx.x];
+    tn = p.tile_map[2 * blockIdx.x + 1];
+  } else if (p.tri == GEMM_UPPER) {
     upper_tile_from_linear(blockIdx.x, tm, tn);
   } else {
     tm = blockIdx.x % p.tiles_m;
@@ -249,6 +253,40 @@ __global__ void splitk_reduce_kernel(int M, int N, int upper, int S, const doubl
 static double* g_splitk_ws = nullptr;
 static size_t g_splitk_ws_bytes = 0;
 
+// XCD-aware order of the upper tiles of a T x T grid.  Hardware workgroup b runs on XCD b % 8 (observed,
+// used for speed only): give every XCD a contiguous run of a super-tile-major enumeration (8 x 8 tiles
+// per super-tile), so that the ~64 tiles resident on one XCD at a time share 16 operand panels in its
+// private L2 instead of touching up to 128 different ones.
+static int* g_tile_map = nullptr;
+static int g_tile_map_T = -1;
+static const int* upper_tile_map(int T, long nblk) {
+  if (g_tile_map_T == T) return g_tile_map;
+  std::vector<int> logical;
+  logical.reserve(2 * nblk);
+  const int ST = 8, nst = (T + ST - 1) / ST;
+  for (int J = 0; J < nst; ++J)
+    for (int I = 0; I <= J; ++I)
+      for (int j = 0; j < ST; ++j)
+        for (int i = 0; i < ST; ++i) {
+          const int tm = I * ST + i, tn = J * ST + j;
+          if (tm < T && tn < T && tm <= tn) { logical.push_back(tm); logical.push_back(tn); }
+        }
+  std::vector<int> hw(2 * nblk);
+  const long q = nblk / 8, r = nblk % 8;   // XCD x owns logical [start_x, start_x + q + (x < r))
+  for (long b = 0; b < nblk; ++b) {
+    const long x = b % 8, k = b / 8;
+    const long start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    const long L = start + k;
+    hw[2 * b] = logical[2 * L];
+    hw[2 * b + 1] = logical[2 * L + 1];
+  }
+  if (g_tile_map) (void)hipFree(g_tile_map);
+  if (hipMalloc((void**)&g_tile_map, hw.size() * sizeof(int)) != hipSuccess) { g_tile_map = nullptr; g_tile_map_T = -1; return nullptr; }
+  if (hipMemcpy(g_tile_map, hw.data(), hw.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  g_tile_map_T = T;
+  return g_tile_map;
+}
+
 hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a) {
   if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return hipSuccess;
   // tile choice: the 128 x 128 tile unless the product is too small to fill the chip with it
@@ -290,6 +328,8 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a) {
   }
   a.vec2 = (transa && ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.B % 16 == 0) && (a.lda % 2 == 0) && (a.ldb % 2 == 0) &&
             (a.strideA % 2 == 0) && (a.strideB % 2 == 0) && a.krange != KR_GE_M && a.krange != KR_GE_N) ? 1 : 0;
+  a.tile_map = nullptr;
+  if (a.tag == 1 && a.tri == GEMM_UPPER && !small && a.batch == 1 && nblk >= 64) a.tile_map = upper_tile_map(a.tiles_n, nblk);
   dim3 grid((unsigned)nblk, (unsigned)a.batch, (unsigned)a.splitk);
   if (a.tag == 1 && transa && !small) {
     hipLaunchKernelGGL((gemm_f64_kernel<true, 4, 1>), grid, dim3(GEMM_THREADS), 0, st, a);
