@@ -154,7 +154,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("HYP_FORCE_DIST"):   # HYP_FORCE_DIST=1: exercise the RCCL path with a single rank
         return main_multi(args, world, rank, local_rank)
 
     import hypatia_jl_amd as H

@@ -20,40 +20,76 @@ void gemm(Ctx& c, bool transa, GemmArgs a) { HYP_CHECK(gemm_f64_launch(c.stream,
 __global__ void potrf_diag_kernel(double* __restrict__ A, long lda, long strideA, int n, int k0, double* __restrict__ dinv,
                                   long strideD, int* __restrict__ info);   // potrf_diag.hip
 
+static void potrf_step_gemms(Ctx& c, hipStream_t st, int nb, int M, int N, const double* U12a, const double* U12b, long lda, long strideA,
+                             double* C, int tri, int batch) {
+  GemmArgs s{};   // C <- C - U12a' U12b
+  s.M = M; s.N = N; s.K = nb;
+  s.A = U12a; s.lda = lda; s.strideA = strideA;
+  s.B = U12b; s.ldb = lda; s.strideB = strideA;
+  s.C = C; s.ldc = lda; s.strideC = strideA;
+  s.alpha = -1.0; s.beta = 1.0; s.tri = tri; s.krange = KR_ALL; s.batch = batch;
+  HYP_CHECK(gemm_f64_launch(st, true, s));
+}
+
+hipEvent_t Ctx::pool_event(size_t i) {
+  while (ev_pool.size() <= i) {
+    hipEvent_t e;
+    HYP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ev_pool.push_back(e);
+  }
+  return ev_pool[i];
+}
+
 void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int batch, double* dinv, int* d_info) {
   if (n <= 0 || batch <= 0) return;
   c.zero(d_info, sizeof(int) * batch);
   const long strideD = (long)dinv_elems(n);
-  for (int k0 = 0; k0 < n; k0 += NB) {
+  const int nblk = (n + NB - 1) / NB;
+  // Look-ahead (one big matrix): after the panel solve of step k, the main stream only updates block
+  // row k+1 of the trailing matrix (all the next diagonal / panel step needs); the rest of the rank-128
+  // update runs on the helper stream underneath the next diagonal-block kernel, which is pure latency.
+  const bool lookahead = (batch == 1 && nblk >= 6);
+  for (int kb = 0; kb < nblk; ++kb) {
+    const int k0 = kb * NB;
     const int nb = std::min(NB, n - k0);
     const int m = n - k0 - nb;
     hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(256), 0, c.stream, A, lda, strideA, n, k0, dinv, strideD, d_info);
     HYP_CHECK(hipGetLastError());
-    if (m > 0) {
-      double* A12 = A + (long)(k0 + nb) * lda + k0;
-      double* A22 = A + (long)(k0 + nb) * lda + (k0 + nb);
-      GemmArgs t{};   // A12 <- inv(U11)' A12   (single m-tile: in place is safe, see gemm_f64.hpp)
-      t.M = nb; t.N = m; t.K = nb;
-      t.A = dinv + (long)(k0 / NB) * DINV_BLK; t.lda = NB; t.strideA = strideD;
-      t.B = A12; t.ldb = lda; t.strideB = strideA;
-      t.C = A12; t.ldc = lda; t.strideC = strideA;
-      t.alpha = 1.0; t.beta = 0.0; t.tri = GEMM_FULL; t.krange = KR_LE_M; t.batch = batch;
-      t.tile_hint = 128;   // in place: all rows of a column block must belong to ONE workgroup
-      gemm(c, true, t);
-      GemmArgs s{};   // A22 <- A22 - A12' A12 (upper triangle)
-      s.M = m; s.N = m; s.K = nb;
-      s.A = A12; s.lda = lda; s.strideA = strideA;
-      s.B = A12; s.ldb = lda; s.strideB = strideA;
-      s.C = A22; s.ldc = lda; s.strideC = strideA;
-      s.alpha = -1.0; s.beta = 1.0; s.tri = GEMM_UPPER; s.krange = KR_ALL; s.batch = batch;
-      gemm(c, true, s);
+    if (m <= 0) break;
+    double* A12 = A + (long)(k0 + nb) * lda + k0;
+    double* A22 = A + (long)(k0 + nb) * lda + (k0 + nb);
+    GemmArgs t{};   // A12 <- inv(U11)' A12   (single m-tile: in place is safe, see gemm_f64.hpp)
+    t.M = nb; t.N = m; t.K = nb;
+    t.A = dinv + (long)kb * DINV_BLK; t.lda = NB; t.strideA = strideD;
+    t.B = A12; t.ldb = lda; t.strideB = strideA;
+    t.C = A12; t.ldc = lda; t.strideC = strideA;
+    t.alpha = 1.0; t.beta = 0.0; t.tri = GEMM_FULL; t.krange = KR_LE_M; t.batch = batch;
+    t.tile_hint = 128;   // in place: all rows of a column block must belong to ONE workgroup
+    gemm(c, true, t);
+    if (!lookahead) {
+      potrf_step_gemms(c, c.stream, nb, m, m, A12, A12, lda, strideA, A22, GEMM_UPPER, batch);   // A22 -= A12' A12 (upper)
+      continue;
     }
+    const int nb1 = std::min(NB, m);       // block row k+1
+    const int mr = m - nb1;                // rows beyond it
+    hipEvent_t Tk = c.pool_event(2 * kb), Rk = c.pool_event(2 * kb + 1);
+    if (kb >= 1) HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(2 * (kb - 1) + 1), 0));   // rest(k-1) touched block row k+1 too
+    potrf_step_gemms(c, c.stream, nb, nb1, nb1, A12, A12, lda, strideA, A22, GEMM_UPPER, 1);                  // diagonal block k+1
+    if (mr > 0)
+      potrf_step_gemms(c, c.stream, nb, nb1, mr, A12, A12 + (long)nb1 * lda, lda, strideA, A22 + (long)nb1 * lda, GEMM_FULL, 1);   // its row panel
+    // the big remainder starts only after the main stream's small updates are queued: it then runs
+    // underneath the next diagonal-block kernel + panel solve instead of competing with them
+    HYP_CHECK(hipEventRecord(Tk, c.stream));
+    if (mr > 0) {
+      HYP_CHECK(hipStreamWaitEvent(c.stream2, Tk, 0));
+      potrf_step_gemms(c, c.stream2, nb, mr, mr, A12 + (long)nb1 * lda, A12 + (long)nb1 * lda, lda, strideA,
+                       A22 + (long)nb1 * lda + nb1, GEMM_UPPER, 1);                                            // everything below, on the helper stream
+    }
+    HYP_CHECK(hipEventRecord(Rk, c.stream2));
   }
+  if (lookahead && nblk >= 2) HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(2 * (nblk - 2) + 1), 0));
 }
 
-// =============================================================================================
-// triangular solve, one right-hand side: x <- U^-T x (forward) or U^-1 x (backward)
-// =============================================================================================
 // ---- diagonal block solve of the blocked substitution -----------------------------------------
 // x = op(T)^-1 y for one diagonal block T = U[k0:k0+nb, k0:k0+nb] (op = transpose for the forward
 // sweep).  A serial substitution costs 128 dependent steps per block on the critical path of 40
@@ -569,48 +605,79 @@ void dev_zero_strict_lower(Ctx& c, int n, double* A, long lda, int batch, long s
 // svec <-> smat (src/Cones/arrayutilities.jl:163-181, 218-236): column-major upper triangle,
 // (i <= j) -> j(j+1)/2 + i, off-diagonals scaled by sqrt(2)
 // =============================================================================================
-__global__ void svec_unpack_div_kernel(int side, const double* __restrict__ arr, long ldarr, double* __restrict__ mats) {
-  const int col = blockIdx.z;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y;
-  if (i >= side) return;
-  const int hi = max(i, j), lo = min(i, j);
-  double v = arr[(long)col * ldarr + (long)hi * (hi + 1) / 2 + lo];
-  if (i != j) v = v / 1.4142135623730951;   // vec[k] / rt2 exactly as arrayutilities.jl:231
-  mats[(long)col * side * side + (long)j * side + i] = v;
+// unpack: one workgroup per (32 x 32 tile of the upper triangle, column of arr).  The tile is read from the
+// packed column (rows contiguous), written to V[i, j] and -- through an LDS transpose -- to V[j, i], so
+// that every global access is a contiguous 256-byte run.
+__global__ __launch_bounds__(256) void svec_unpack_div_kernel(int side, int ntile, const double* __restrict__ arr, long ldarr,
+                                                              double* __restrict__ mats, int ncols) {
+  __shared__ double tile[32][33];
+  // blockIdx.x enumerates upper tiles (ti <= tj) column by column: idx = tj (tj + 1) / 2 + ti
+  int tj = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+  while ((tj + 1) * (tj + 2) / 2 <= (int)blockIdx.x) ++tj;
+  while (tj * (tj + 1) / 2 > (int)blockIdx.x) --tj;
+  const int ti = blockIdx.x - tj * (tj + 1) / 2;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int col = blockIdx.y; col < ncols; col += gridDim.y) {
+    const double* a = arr + (long)col * ldarr;
+    double* V = mats + (long)col * side * side;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = tj * 32 + ty + 8 * r, i = ti * 32 + tx;
+      double v = 0.0;
+      if (i < side && j < side && i <= j) {
+        v = a[(long)j * (j + 1) / 2 + i];
+        if (i != j) v = v / 1.4142135623730951;   // vec[k] / rt2 exactly as arrayutilities.jl:231
+        V[(long)j * side + i] = v;
+      }
+      tile[ty + 8 * r][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      // mirrored element V[jj, ii] with jj in the tj block (contiguous over tx), ii in the ti block
+      const int jj = tj * 32 + tx, ii = ti * 32 + ty + 8 * r;
+      if (jj < side && ii < side && ii < jj) V[(long)ii * side + jj] = tile[tx][ty + 8 * r];
+    }
+    __syncthreads();
+  }
 }
 void svec_unpack(Ctx& c, int side, int ncols, const double* arr, long ldarr, double* mats) {
   if (ncols <= 0) return;
-  for (int c0 = 0; c0 < ncols; c0 += 65535) {
-    const int nc = std::min(65535, ncols - c0);
-    hipLaunchKernelGGL(svec_unpack_div_kernel, dim3((side + 63) / 64, side, nc), dim3(64), 0, c.stream, side, arr + (long)c0 * ldarr,
-                       ldarr, mats + (long)c0 * side * side);
-  }
+  const int nt = (side + 31) / 32;
+  hipLaunchKernelGGL(svec_unpack_div_kernel, dim3(nt * (nt + 1) / 2, std::min(ncols, 4096)), dim3(256), 0, c.stream, side, nt, arr, ldarr, mats,
+                     ncols);
   HYP_CHECK(hipGetLastError());
 }
-__global__ void svec_pack_kernel(int side, const double* __restrict__ mats, double* __restrict__ arr, long ldarr, double scale) {
-  const int col = blockIdx.z;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y;
-  if (i > j) return;
-  double v = mats[(long)col * side * side + (long)j * side + i];
-  if (i != j) v *= 1.4142135623730951;   // mat[i, j] * rt2, arrayutilities.jl:176
-  arr[(long)col * ldarr + (long)j * (j + 1) / 2 + i] = scale * v;
+// pack: thread per packed entry run; one workgroup handles (32-column band j, column of arr)
+__global__ __launch_bounds__(256) void svec_pack_kernel(int side, const double* __restrict__ mats, double* __restrict__ arr, long ldarr,
+                                                        double scale, int ncols) {
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 rows x 4 columns per pass
+  for (int col = blockIdx.y; col < ncols; col += gridDim.y) {
+    const double* V = mats + (long)col * side * side;
+    double* a = arr + (long)col * ldarr;
+    for (int j = blockIdx.x * 4 + ty; j < side; j += gridDim.x * 4) {
+      for (int i = tx; i <= j; i += 64) {
+        double v = V[(long)j * side + i];
+        if (i != j) v *= 1.4142135623730951;   // mat[i, j] * rt2, arrayutilities.jl:176
+        a[(long)j * (j + 1) / 2 + i] = scale * v;
+      }
+    }
+  }
 }
 void svec_pack(Ctx& c, int side, int ncols, const double* mats, double* arr, long ldarr, double scale) {
   if (ncols <= 0) return;
-  for (int c0 = 0; c0 < ncols; c0 += 65535) {
-    const int nc = std::min(65535, ncols - c0);
-    hipLaunchKernelGGL(svec_pack_kernel, dim3((side + 63) / 64, side, nc), dim3(64), 0, c.stream, side, mats + (long)c0 * side * side,
-                       arr + (long)c0 * ldarr, ldarr, scale);
-  }
+  const int gx = std::max(1, std::min((side + 3) / 4, ncols >= 64 ? 8 : 64));
+  hipLaunchKernelGGL(svec_pack_kernel, dim3(gx, std::min(ncols, 8192)), dim3(256), 0, c.stream, side, mats, arr, ldarr, scale, ncols);
   HYP_CHECK(hipGetLastError());
 }
 
 // =============================================================================================
 Ctx::Ctx(int dev) : device(dev) {
   HYP_CHECK(hipSetDevice(dev));
-  HYP_CHECK(hipStreamCreate(&stream));
+  int plo = 0, phi = 0;
+  HYP_CHECK(hipDeviceGetStreamPriorityRange(&plo, &phi));   // (numerically lower = higher priority)
+  HYP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, phi));
+  HYP_CHECK(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, plo));
   scratch.alloc(1 << 20);
   dscal.alloc(64 * sizeof(double));
   for (int i = 0; i < 6; ++i) HYP_CHECK(hipEventCreate(&ev[i]));
@@ -623,6 +690,8 @@ Ctx::~Ctx() {
     if (ev[i]) (void)hipEventDestroy(ev[i]);
   if (h_info) (void)hipHostFree(h_info);
   if (h_pinned) (void)hipHostFree(h_pinned);
+  for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+  if (stream2) (void)hipStreamDestroy(stream2);
   if (stream) (void)hipStreamDestroy(stream);
 }
 

@@ -67,6 +67,9 @@ struct Ctx {
   // [1] Schur syrk, [2] Cholesky, [3] number of update_lhs_fact calls, [4] syrk launches
   double kstat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipStream_t stream2 = nullptr;            // helper stream: look-ahead trailing updates of the blocked Cholesky
+  std::vector<hipEvent_t> ev_pool;          // ordering events between stream and stream2
+  hipEvent_t pool_event(size_t i);
   DBuf scratch;       // general device scratch (gemv partial sums)
   DBuf dscal;         // 64 device doubles for scalar results (dots, counts)
   DBuf stage_a, stage_b;   // device staging for host-pointer entry points

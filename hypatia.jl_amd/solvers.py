@@ -433,7 +433,7 @@ class Solver:
     def __init__(self, verbose=False, iter_limit=1000, time_limit=np.inf, tol_rel_opt=None, tol_abs_opt=None,
                  tol_feas=None, tol_infeas=None, tol_illposed=None, default_tol_power=None,
                  default_tol_relax=None, tol_slow=1e-3, preprocess=True, reduce=True, rescale=True,
-                 init_tol_qr=1000 * EPS, stepper=None, syssolver=None):   # Solvers.jl:162-240
+                 init_use_indirect=False, init_tol_qr=1000 * EPS, stepper=None, syssolver=None):   # Solvers.jl:162-240
         if reduce:
             assert preprocess
         if default_tol_power is None:
@@ -456,6 +456,7 @@ class Solver:
         self.reduce = reduce
         self.rescale = rescale
         self.init_tol_qr = init_tol_qr
+        self.init_use_indirect = init_use_indirect   # Solvers.jl:176: LSQR initial x instead of the pivoted QR of [A; G]
         self.stepper = stepper if stepper is not None else CombinedStepper()
         self.syssolver = syssolver if syssolver is not None else QRCholDenseSystemSolver()
         self.status = "NotLoaded"
@@ -786,6 +787,21 @@ def find_initial_x(solver, init_s):   # process.jl:64-178
     A, G = model.A, model.G
     solver.x_keep_idxs = np.arange(n)
     rhs = np.concatenate([model.b, model.h - init_s])
+    if solver.init_use_indirect:   # process.jl:81-95 (IterativeSolvers.lsqr on [A; G])
+        from .distributed import lsqr
+
+        class _AG:
+            class model:   # lsqr only needs .model.n, .mul, .mul_t
+                pass
+
+            def mul(self, x):
+                return np.concatenate([A @ x, G @ x]) if p else G @ x
+
+            def mul_t(self, z):
+                return (A.T @ z[:p] + G.T @ z[p:]) if p else G.T @ z
+        op = _AG()
+        op.model.n = n
+        return lsqr(op, rhs)
     AG = G.copy() if p == 0 else np.vstack([A, G])
     Qf, R, piv = sla.qr(AG, mode="economic", pivoting=True, overwrite_a=True)   # Q: (p+q) x n
     AG_rank = get_rank_est(R, solver.init_tol_qr)
