@@ -463,8 +463,16 @@ int hyp_dense_posv(hyp_ctx* ctx, int n, double* A, int lda, double* x, int* info
   c.sync();
   *info = c.h_info[0];
   if (*info == 0) {
-    trsv_upper(c, n, dA.d(), lda, dinv.d(), true, dx.d());
-    trsv_upper(c, n, dA.d(), lda, dinv.d(), false, dx.d());
+    if (c.trsv_sb > 0 && n >= 2 * c.trsv_sb) {   // same dispatch as SysSolver::tri_solves
+      TriSolvePlan tri;
+      tri.build(c, n, dA.d(), lda, dinv.d());
+      tri.solve(c, dA.d(), lda, true, dx.d());
+      tri.solve(c, dA.d(), lda, false, dx.d());
+      c.sync();
+    } else {
+      trsv_upper(c, n, dA.d(), lda, dinv.d(), true, dx.d());
+      trsv_upper(c, n, dA.d(), lda, dinv.d(), false, dx.d());
+    }
   }
   c.d2h(A, dA.p, (size_t)lda * n * 8);
   c.d2h(x, dx.p, (size_t)n * 8);

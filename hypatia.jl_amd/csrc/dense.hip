@@ -437,6 +437,98 @@ void trtri_upper_batched(Ctx& c, int n, const double* U, long ldu, long strideU,
 }
 
 // =============================================================================================
+// super-block one-RHS triangular solves (TriSolvePlan)
+// =============================================================================================
+// out[j] = base[j] + alpha * sum_{i in rows(j)} M[i, j] v[i], one wavefront per column j (coalesced
+// down the column, fixed reduction order).  mode 0: rows [0, m); 1: rows [0, j] (upper triangular M);
+// 2: rows [j, m) (lower triangular M).  out may alias base; v must not alias out.
+__global__ __launch_bounds__(256) void coldot_kernel(int m, int ncols, int mode, const double* __restrict__ M, long ld,
+                                                     const double* __restrict__ v, const double* base, double alpha, double* out) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= ncols) return;
+  const int lane = threadIdx.x & 63;
+  int i0 = 0, i1 = m;
+  if (mode == 1) i1 = min(j + 1, m);
+  else if (mode == 2) i0 = min(j, m);
+  const double* a = M + (long)j * ld;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int i = i0 + lane;
+  for (; i + 192 < i1; i += 256) {
+    const double a0 = a[i], a1 = a[i + 64], a2 = a[i + 128], a3 = a[i + 192];
+    s0 += a0 * v[i];
+    s1 += a1 * v[i + 64];
+    s2 += a2 * v[i + 128];
+    s3 += a3 * v[i + 192];
+  }
+  for (; i < i1; i += 64) s0 += a[i] * v[i];
+  double s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if (lane == 0) out[j] = (base ? base[j] : 0.0) + alpha * s;
+}
+
+static void coldot(Ctx& c, int m, int ncols, int mode, const double* M, long ld, const double* v, const double* base, double alpha,
+                   double* out) {
+  if (ncols <= 0) return;
+  hipLaunchKernelGGL(coldot_kernel, dim3((ncols + 3) / 4), dim3(256), 0, c.stream, m, ncols, mode, M, ld, v, base, alpha, out);
+}
+
+void TriSolvePlan::build(Ctx& c, int n_, const double* U, long ldu, const double* dinv) {
+  n = 0;
+  sb = c.trsv_sb;
+  if (sb <= 0 || n_ <= 0) return;
+  const int nsb = (n_ + sb - 1) / sb;
+  const size_t blk = (size_t)sb * sb;
+  Binv.ensure(nsb * blk * sizeof(double));
+  BinvT.ensure(nsb * blk * sizeof(double));
+  UT.ensure((size_t)n_ * n_ * sizeof(double));
+  work.ensure((size_t)2 * sb * sizeof(double));
+  const int nfull = n_ / sb, last = n_ - nfull * sb;
+  const long strideU = (long)sb * (ldu + 1), strideD = (long)(sb / NB) * DINV_BLK;
+  if (nfull > 0) trtri_upper_batched(c, sb, U, ldu, strideU, dinv, strideD, Binv.d(), sb, (long)blk, nfull);
+  if (last > 0)
+    trtri_upper_batched(c, last, U + (long)nfull * strideU, ldu, 0, dinv + (long)nfull * strideD, 0, Binv.d() + nfull * blk, sb, 0, 1);
+  if (nfull > 0) dev_transpose(c, sb, sb, Binv.d(), sb, BinvT.d(), sb, nfull, (long)blk, (long)blk);
+  if (last > 0) dev_transpose(c, last, last, Binv.d() + nfull * blk, sb, BinvT.d() + nfull * blk, sb, 1, 0, 0);
+  dev_transpose(c, n_, n_, U, ldu, UT.d(), n_, 1, 0, 0);
+  n = n_;
+}
+
+void TriSolvePlan::solve(Ctx& c, const double* U, long ldu, bool trans, double* x) {
+  const int nsb = (n + sb - 1) / sb;
+  const size_t blk = (size_t)sb * sb;
+  double* t = work.d();
+  double* e = work.d() + sb;
+  for (int s = 0; s < nsb; ++s) {
+    const int b = trans ? s : nsb - 1 - s;
+    const int r0 = b * sb, m = std::min(sb, n - r0);
+    double* xb = x + r0;
+    // forward (U' y = x): columns of U / Binv, upper ranges; backward (U x = y): columns of U' / Binv', lower ranges
+    const double* Dm = trans ? U + (long)r0 * ldu + r0 : UT.d() + (long)r0 * n + r0;
+    const long ldd = trans ? ldu : n;
+    const double* Bm = (trans ? Binv.d() : BinvT.d()) + b * blk;
+    const int mode = trans ? 1 : 2;
+    if (refine == 0) {
+      coldot(c, m, m, mode, Bm, sb, xb, nullptr, 1.0, t);
+      HYP_CHECK(hipMemcpyAsync(xb, t, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, c.stream));
+    } else {
+      coldot(c, m, m, mode, Bm, sb, xb, nullptr, 1.0, t);              // t = B x_b
+      for (int it = 0; it < refine; ++it) {
+        coldot(c, m, m, mode, Dm, ldd, t, xb, -1.0, e);                // e = x_b - T t
+        coldot(c, m, m, mode, Bm, sb, e, t, 1.0, it + 1 == refine ? xb : t);   // t += B e
+      }
+    }
+    if (trans) {
+      const int rest = n - (r0 + m);   // x[rest] -= U[block rows, rest cols]' x_b
+      coldot(c, m, rest, 0, U + (long)(r0 + m) * ldu + r0, ldu, xb, x + r0 + m, -1.0, x + r0 + m);
+    } else {
+      coldot(c, m, r0, 0, UT.d() + r0, n, xb, x, -1.0, x);   // x[0:r0] -= U[0:r0, block cols] x_b
+    }
+  }
+  HYP_CHECK(hipGetLastError());
+}
+
+// =============================================================================================
 // gemv (deterministic), level-1 helpers
 // =============================================================================================
 // y = alpha A' x + beta y : one workgroup per output element (column of A), fixed reduction tree
@@ -678,6 +770,7 @@ Ctx::Ctx(int dev) : device(dev) {
   HYP_CHECK(hipDeviceGetStreamPriorityRange(&plo, &phi));   // (numerically lower = higher priority)
   HYP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, phi));
   HYP_CHECK(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, plo));
+  if (const char* e = getenv("HYP_TRSV_SB")) trsv_sb = (atoi(e) / NB) * NB;
   scratch.alloc(1 << 20);
   dscal.alloc(64 * sizeof(double));
   for (int i = 0; i < 6; ++i) HYP_CHECK(hipEventCreate(&ev[i]));

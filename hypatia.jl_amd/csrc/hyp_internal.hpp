@@ -74,6 +74,7 @@ struct Ctx {
   DBuf dscal;         // 64 device doubles for scalar results (dots, counts)
   DBuf stage_a, stage_b;   // device staging for host-pointer entry points
   DBuf work_tri;           // workspace of trtri_upper_batched
+  int trsv_sb = 1024;      // super-block of the one-right-hand-side triangular solves (HYP_TRSV_SB; 0 = per-128-block path)
   int* h_info = nullptr;    // pinned host word(s)
   double* h_pinned = nullptr;   // pinned host staging (small vectors / scalars)
   size_t h_pinned_n = 0;
@@ -111,6 +112,19 @@ inline size_t dinv_elems(int n) { return (size_t)((n + NB - 1) / NB) * DINV_BLK;
 void trsv_upper(Ctx& c, int n, const double* U, long ldu, const double* dinv, bool trans, double* x);
 void trsm_upper_left(Ctx& c, int n, int nrhs, const double* U, long ldu, const double* dinv, bool trans, double* X,
                      long ldx, double* work /* NB x nrhs */);
+// One-right-hand-side solves with a LARGE upper Cholesky factor (the potrs of qrchol.jl:68).  The
+// factor is cut into super-blocks of sb rows; build() inverts the diagonal super-blocks and keeps a
+// transposed copy of U, so that every step of solve() is a set of coalesced column dot products:
+// x_b = Binv y_b followed by `refine` steps of fixed-precision iterative refinement against the
+// factor itself (the result has substitution's backward error), then one rank-sb update of the rest.
+struct TriSolvePlan {
+  int n = 0, sb = 0, refine = 2;
+  DBuf Binv, BinvT, UT, work;
+  bool ready(int n_) const { return n == n_ && n_ > 0; }
+  void invalidate() { n = 0; }
+  void build(Ctx& c, int n_, const double* U, long ldu, const double* dinv);
+  void solve(Ctx& c, const double* U, long ldu, bool trans, double* x);
+};
 // explicit inverse of an upper triangular matrix from its inverted diagonal blocks: Uinv (upper, full
 // storage, strictly-lower part zero).  Used for the small cone matrices.
 void trtri_upper_batched(Ctx& c, int n, const double* U, long ldu, long strideU, const double* dinv, long strideD,

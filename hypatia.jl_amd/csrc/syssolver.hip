@@ -155,12 +155,21 @@ void SysSolver::factor_lhs(int* info, int* used_fallback) {   // qrchol.jl:249-2
     *info = ctx.h_info[0];
   }
   fact_ok = (*info == 0);
+  tri.invalidate();
+  if (fact_ok && ctx.trsv_sb > 0 && nmp >= 2 * ctx.trsv_sb) tri.build(ctx, nmp, lhs_fact.d(), nmp, dinv.d());
 }
 
-void SysSolver::potrs(double* d_x) {
-  trsv_upper(ctx, nmp, lhs_fact.d(), nmp, dinv.d(), true, d_x);
-  trsv_upper(ctx, nmp, lhs_fact.d(), nmp, dinv.d(), false, d_x);
+void SysSolver::tri_solves(double* d_x) {
+  if (tri.ready(nmp)) {
+    tri.solve(ctx, lhs_fact.d(), nmp, true, d_x);
+    tri.solve(ctx, lhs_fact.d(), nmp, false, d_x);
+  } else {
+    trsv_upper(ctx, nmp, lhs_fact.d(), nmp, dinv.d(), true, d_x);
+    trsv_upper(ctx, nmp, lhs_fact.d(), nmp, dinv.d(), false, d_x);
+  }
 }
+
+void SysSolver::potrs(double* d_x) { tri_solves(d_x); }
 
 void SysSolver::solve3(double* d_sol, const double* d_rhs) {   // qrchol.jl:39-85
   const size_t d = sizeof(double);
@@ -187,8 +196,7 @@ void SysSolver::solve3(double* d_sol, const double* d_rhs) {   // qrchol.jl:39-8
   }
   if (nmp > 0) {                                                         // :66-69
     ctx.d2d(x + p, t + p, (size_t)nmp * d);
-    trsv_upper(ctx, nmp, lhs_fact.d(), nmp, dinv.d(), true, x + p);
-    trsv_upper(ctx, nmp, lhs_fact.d(), nmp, dinv.d(), false, x + p);
+    tri_solves(x + p);
   }
   if (p > 0) {                                                           // :71  x = Q x
     gemv(ctx, false, n, n, 1.0, Qm.d(), n, x, 0.0, tmpn.d());

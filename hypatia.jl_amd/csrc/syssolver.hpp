@@ -18,6 +18,7 @@ struct SysSolver {
   DBuf HGQ2;    // q x nmp
   DBuf lhs;     // nmp x nmp (upper)
   DBuf lhs_fact, dinv, d_info;
+  TriSolvePlan tri;   // super-block inverses of lhs_fact for the one-RHS solves
   // vectors
   DBuf QpbxGHbz, Gx, HGx, GQ1x, HGQ1x, tmpn, sol, rhs, tmpq;
   std::vector<int> use_sqrt;
@@ -31,6 +32,7 @@ struct SysSolver {
   void update_lhs_fact(int* info, int* used_fallback);                         // qrchol.jl:201-257
   void assemble_lhs();                                                         //   :214-246 (Schur sum over this process's cones)
   void factor_lhs(int* info, int* used_fallback);                              //   :249-250
+  void tri_solves(double* d_x);                                                // both triangular solves of the potrs
   void potrs(double* d_x);                                                     // x <- lhs^-1 x with the current factor (:66-69)
   void solve3(double* d_sol, const double* d_rhs);                             // qrchol.jl:39-85
 };

@@ -61,6 +61,27 @@ def test_potrf_and_posv(hip, n):
     assert np.linalg.norm(x - xref) <= 1e-10 * np.linalg.norm(xref) * np.linalg.cond(A)
 
 
+@pytest.mark.parametrize("n,cond", [(2048, 1e2), (2500, 1e10), (3333, 1e13)])
+def test_posv_superblock_solves(hip, n, cond):
+    """n >= 2 * 1024: the one-RHS solves go through the inverted super-blocks + refinement against the
+    factor (TriSolvePlan).  Bar: the backward error of LAPACK's substitution-based dpotrs."""
+    import scipy.linalg as sla
+    lib, ctx, L = hip
+    rng = np.random.default_rng(n)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    ev = np.logspace(0, -np.log10(cond), n)
+    A = np.asfortranarray((Q * ev) @ Q.T)
+    A = np.asfortranarray(0.5 * (A + A.T))
+    b = rng.standard_normal(n)
+    Ad, x, info = A.copy(order="F"), b.copy(), c_int(-1)
+    L.check(lib.hyp_dense_posv(ctx, n, fp(Ad), n, fp(x), ctypes.byref(info)), "posv")
+    assert info.value == 0
+    xref = sla.cho_solve(sla.cho_factor(A), b)
+    berr = lambda v: np.linalg.norm(A @ v - b) / (np.linalg.norm(A, 2) * np.linalg.norm(v) + np.linalg.norm(b))
+    assert berr(x) <= 4 * berr(xref) + 1e-16, (berr(x), berr(xref))
+    assert np.linalg.norm(x - xref) <= 1e-12 * cond * np.linalg.norm(xref)
+
+
 def test_potrf_reports_failed_minor(hip):
     lib, ctx, L = hip
     n = 200
