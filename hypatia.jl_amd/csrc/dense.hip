@@ -17,8 +17,10 @@ namespace hyp {
 
 void gemm(Ctx& c, bool transa, GemmArgs a) { HYP_CHECK(gemm_f64_launch(c.stream, transa, a)); }
 
-__global__ void potrf_diag_kernel(double* __restrict__ A, long lda, long strideA, int n, int k0, double* __restrict__ dinv,
-                                  long strideD, int* __restrict__ info);   // potrf_diag.hip
+// potrf_diag.hip: diagonal-block factor / inverse kernels and the substitution panel solve
+void potrf_diag_launch(hipStream_t st, bool factor, bool invert, int batch, int nblocks, double* A, long lda, long strideA, int n, int k0,
+                       double* dinv, long strideD, int* info);
+void potrf_panel_solve_launch(hipStream_t st, int batch, double* A, long lda, long strideA, int k0, int mcols);
 
 static void potrf_step_gemms(Ctx& c, hipStream_t st, int nb, int M, int N, const double* U12a, const double* U12b, long lda, long strideA,
                              double* C, int tri, int batch) {
@@ -53,19 +55,12 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
     const int k0 = kb * NB;
     const int nb = std::min(NB, n - k0);
     const int m = n - k0 - nb;
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(256), 0, c.stream, A, lda, strideA, n, k0, dinv, strideD, d_info);
-    HYP_CHECK(hipGetLastError());
+    // factor only: the inverses of all diagonal blocks are produced by ONE launch after the loop
+    potrf_diag_launch(c.stream, true, false, batch, 1, A, lda, strideA, n, k0, dinv, strideD, d_info);
     if (m <= 0) break;
     double* A12 = A + (long)(k0 + nb) * lda + k0;
     double* A22 = A + (long)(k0 + nb) * lda + (k0 + nb);
-    GemmArgs t{};   // A12 <- inv(U11)' A12   (single m-tile: in place is safe, see gemm_f64.hpp)
-    t.M = nb; t.N = m; t.K = nb;
-    t.A = dinv + (long)kb * DINV_BLK; t.lda = NB; t.strideA = strideD;
-    t.B = A12; t.ldb = lda; t.strideB = strideA;
-    t.C = A12; t.ldc = lda; t.strideC = strideA;
-    t.alpha = 1.0; t.beta = 0.0; t.tri = GEMM_FULL; t.krange = KR_LE_M; t.batch = batch;
-    t.tile_hint = 128;   // in place: all rows of a column block must belong to ONE workgroup
-    gemm(c, true, t);
+    potrf_panel_solve_launch(c.stream, batch, A, lda, strideA, k0, m);   // A12 <- U11^-T A12 (substitution)
     if (!lookahead) {
       potrf_step_gemms(c, c.stream, nb, m, m, A12, A12, lda, strideA, A22, GEMM_UPPER, batch);   // A22 -= A12' A12 (upper)
       continue;
@@ -74,9 +69,7 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
     const int mr = m - nb1;                // rows beyond it
     hipEvent_t Tk = c.pool_event(2 * kb), Rk = c.pool_event(2 * kb + 1);
     if (kb >= 1) HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(2 * (kb - 1) + 1), 0));   // rest(k-1) touched block row k+1 too
-    potrf_step_gemms(c, c.stream, nb, nb1, nb1, A12, A12, lda, strideA, A22, GEMM_UPPER, 1);                  // diagonal block k+1
-    if (mr > 0)
-      potrf_step_gemms(c, c.stream, nb, nb1, mr, A12, A12 + (long)nb1 * lda, lda, strideA, A22 + (long)nb1 * lda, GEMM_FULL, 1);   // its row panel
+    potrf_step_gemms(c, c.stream, nb, nb1, m, A12, A12, lda, strideA, A22, GEMM_UPPER_RECT, 1);   // block row k+1: diagonal block (upper) + its row panel
     // the big remainder starts only after the main stream's small updates are queued: it then runs
     // underneath the next diagonal-block kernel + panel solve instead of competing with them
     HYP_CHECK(hipEventRecord(Tk, c.stream));
@@ -88,6 +81,7 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
     HYP_CHECK(hipEventRecord(Rk, c.stream2));
   }
   if (lookahead && nblk >= 2) HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(2 * (nblk - 2) + 1), 0));
+  potrf_diag_launch(c.stream, false, true, batch, nblk, A, lda, strideA, n, 0, dinv, strideD, d_info);
 }
 
 // ---- diagonal block solve of the blocked substitution -----------------------------------------

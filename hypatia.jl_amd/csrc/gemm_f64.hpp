@@ -30,6 +30,7 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 enum GemmTri : int {
   GEMM_FULL = 0,        // all tiles
   GEMM_UPPER = 1,       // only tiles/elements with col >= row are computed and stored (syrk 'U')
+  GEMM_UPPER_RECT = 2,  // same element rule for a rectangular C (M <= N, an upper trapezoid): full tile grid, tiles below the diagonal exit
 };
 
 // K-range restriction for triangular operands (tile-granular skipping of structural zeros).

@@ -46,6 +46,7 @@ void gemm_f64_kernel(GemmArgs p) {
     tn = blockIdx.x / p.tiles_m;
   }
   const int m0 = tm * BM, n0 = tn * BN;
+  if (p.tri == GEMM_UPPER_RECT && m0 > n0 + BN - 1) return;
 
   const double* __restrict__ A = p.A + (long)bz * p.strideA;
   const double* __restrict__ B = p.B + (long)bz * p.strideB;
@@ -198,7 +199,7 @@ void gemm_f64_kernel(GemmArgs p) {
 
   // epilogue: lane (fr, fk), accumulator register r of tile (j, i) is
   //   C[m0 + wm*WT + i*16 + fr, n0 + wn*WT + j*16 + fk + 4r]
-  const bool upper = (p.tri == GEMM_UPPER);
+  const bool upper = (p.tri != GEMM_FULL);
   if (p.splitk > 1) {   // raw partial sums; alpha / beta / epilogue are applied by splitk_reduce_kernel
     double* __restrict__ W = p.part + (long)blockIdx.z * p.part_stride;
 #pragma unroll

@@ -8,6 +8,7 @@
 // step publishes one pivot row (and, for the inverse, one column of U) through LDS and costs one
 // barrier.
 #include "hyp_internal.hpp"
+#include <utility>
 
 namespace hyp {
 
@@ -23,9 +24,14 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return r;
 }
 
+// FACTOR: factor the block in place;  INVERT: emit inv(U_kk) and its transpose.  <true,false> is the
+// critical-path kernel of the blocked Cholesky; <false,true> runs once at the end for ALL diagonal
+// blocks at once (grid.y = block index), off the critical path.
+template <bool FACTOR, bool INVERT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void potrf_diag_kernel(double* __restrict__ A, long lda, long strideA, int n, int k0, double* __restrict__ dinv, long strideD,
-                       int* __restrict__ info) {
+void potrf_diag_kernel_t(double* __restrict__ A, long lda, long strideA, int n, int k0_, double* __restrict__ dinv, long strideD,
+                         int* __restrict__ info) {
+  const int k0 = k0_ + blockIdx.y * NB;
   __shared__ double rowbuf[2][NB];
   __shared__ double colbuf[2][NB];
   __shared__ double dsq[NB];
@@ -47,6 +53,7 @@ void potrf_diag_kernel(double* __restrict__ A, long lda, long strideA, int n, in
       a[UIDX(r, c)] = v;
     }
 
+  if (FACTOR) {
   const double dmask = (tc >= tr) ? 1.0 : 0.0;
   int fail = 0;
   if (tr == 0) {
@@ -124,6 +131,14 @@ void potrf_diag_kernel(double* __restrict__ A, long lda, long strideA, int n, in
       if (i < nb && l < nb && i <= l) Ab[(long)l * lda + i] = a[UIDX(r, c)];
     }
   if (tid == 0 && fail && fail <= nb) atomicCAS(&info[blockIdx.x], 0, k0 + fail);
+  } else {   // inverse only: the factored block was just loaded; 1 / U_jj from its diagonal
+    if (tr == tc) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) rdsq[16 * r + tr] = 1.0 / a[UIDX(r, r)];
+    }
+    __syncthreads();
+  }
+  if (!INVERT) return;
 
   // ---- inverse of U: Gauss-Jordan on [U | I], columns in descending order (row j of the U part is
   //      already reduced to its diagonal when it is used), one barrier per column
@@ -216,6 +231,128 @@ void potrf_diag_kernel(double* __restrict__ A, long lda, long strideA, int n, in
       if (c >= r) v = (i < nb && l < nb && i <= l) ? x[UIDX(r, c < r ? r : c)] : 0.0;
       Db[NB * NB + (long)i * NB + l] = v;
     }
+}
+
+template __global__ void potrf_diag_kernel_t<true, true>(double*, long, long, int, int, double*, long, int*);
+template __global__ void potrf_diag_kernel_t<true, false>(double*, long, long, int, int, double*, long, int*);
+template __global__ void potrf_diag_kernel_t<false, true>(double*, long, long, int, int, double*, long, int*);
+
+void potrf_diag_launch(hipStream_t st, bool factor, bool invert, int batch, int nblocks, double* A, long lda, long strideA, int n, int k0,
+                       double* dinv, long strideD, int* info) {
+  const dim3 grid(batch, nblocks), blk(256);
+  if (factor && invert) hipLaunchKernelGGL((potrf_diag_kernel_t<true, true>), grid, blk, 0, st, A, lda, strideA, n, k0, dinv, strideD, info);
+  else if (factor) hipLaunchKernelGGL((potrf_diag_kernel_t<true, false>), grid, blk, 0, st, A, lda, strideA, n, k0, dinv, strideD, info);
+  else hipLaunchKernelGGL((potrf_diag_kernel_t<false, true>), grid, blk, 0, st, A, lda, strideA, n, k0, dinv, strideD, info);
+  HYP_CHECK(hipGetLastError());
+}
+
+// =============================================================================================
+// Panel solve of the blocked Cholesky: X = U11^-T A12 in place (dtrsm 'L','U','T','N'), by forward
+// substitution -- no inverse of U11 on the critical path, and dtrsm's own rounding behaviour.
+// Every column of A12 is independent.  16 lanes (one DPP row) share a column: lane t owns rows
+// i = 16 k + t (8 values per column, PS_NC columns per thread).  Step j: the owner of row j scales
+// it by 1 / U_jj, the value is broadcast inside the DPP row (row_newbcast), and every lane applies
+// a_i -= U[j, i] x_j to its rows i > j.  U11 sits in LDS packed by rows (66 KB), so a step reads 16
+// consecutive doubles per k (conflict-free, broadcast across the four columns of a wavefront).  No
+// barrier inside the 128 steps.
+// =============================================================================================
+constexpr int PS_NC = 2;                 // columns per thread
+constexpr int PS_COLS = 16 * PS_NC;      // columns per workgroup (256 threads = 16 column groups x 16 lanes)
+#define PS_OFF(j) ((j) * NB - (j) * ((j) - 1) / 2)
+
+template <int L>
+__device__ __forceinline__ double row_bcast(double v) {   // value of lane L of each 16-lane row
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + L, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + L, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// one substitution step for row J = 16 kj + TJ of the current 16-row block.  The register rows are
+// ROTATED after every 16 steps so that the current block is always a[0] (static register indices with a
+// rolled outer loop: the fully unrolled 128-step body was instruction-fetch bound); KMAX = how many of
+// the 8 register rows can still be live (rows past the end hold zeros and meet finite garbage of U).
+template <int TJ, int KMAX>
+__device__ __forceinline__ void panel_step(double (&a)[8][PS_NC], const double* __restrict__ Urow, double rj, int t) {
+  double xj[PS_NC];
+#pragma unroll
+  for (int cc = 0; cc < PS_NC; ++cc) {
+    const double own = a[0][cc] * rj;
+    xj[cc] = row_bcast<TJ>(own);
+    a[0][cc] = (t == TJ) ? own : a[0][cc];
+  }
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    double u = Urow[16 * k + t - TJ];        // U[J, 16 (kj + k) + t]   (k == 0, t < TJ: in-bounds read, masked)
+    if (k == 0) u = (t > TJ) ? u : 0.0;
+#pragma unroll
+    for (int cc = 0; cc < PS_NC; ++cc) a[k][cc] -= u * xj[cc];
+  }
+}
+template <int KMAX, int... TJs>
+__device__ __forceinline__ void panel_block(std::integer_sequence<int, TJs...>, double (&a)[8][PS_NC], const double* Us, const double* rinv,
+                                            int kj, int t) {
+  (panel_step<TJs, KMAX>(a, Us + PS_OFF(16 * kj + TJs), rinv[16 * kj + TJs], t), ...);
+}
+
+__global__ __launch_bounds__(256) void potrf_panel_solve_kernel(double* __restrict__ A, long lda, long strideA, int k0, int mcols) {
+  extern __shared__ double ps_lds[];
+  double* Us = ps_lds;                         // packed rows of U11: NB (NB + 1) / 2 doubles
+  double* rinv = ps_lds + NB * (NB + 1) / 2;   // 1 / U_jj  (also the finite landing zone of reads past the last rows)
+  const int tid = threadIdx.x, t = tid & 15, cg = tid >> 4;
+  double* Ab = A + (long)blockIdx.y * strideA;
+  const double* U11 = Ab + (long)k0 * lda + k0;
+  double* A12 = Ab + (long)(k0 + NB) * lda + k0;
+  {   // U11 -> LDS.  Loads are unconditional and issued 16 at a time (a predicated load makes the compiler
+      // wait for each one: 64 serial round trips); the strictly-lower part of the block is valid memory.
+    const int j = tid & (NB - 1), ih = tid >> 7;    // row j, columns ih + 2 u (coalesced down the columns)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = U11[(long)(ih + 2 * (16 * b + u)) * lda + j];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int i = ih + 2 * (16 * b + u);
+        if (j <= i) Us[PS_OFF(j) + i - j] = v[u];
+      }
+    }
+  }
+  const int c0 = blockIdx.x * PS_COLS + cg * PS_NC;
+  double a[8][PS_NC];
+#pragma unroll
+  for (int cc = 0; cc < PS_NC; ++cc) {
+    const int col = min(c0 + cc, mcols - 1);        // (clamped: out-of-range columns are computed and dropped)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k][cc] = A12[(long)col * lda + 16 * k + t];
+  }
+  __syncthreads();
+  if (tid < NB) rinv[tid] = 1.0 / Us[PS_OFF(tid)];
+  __syncthreads();
+#pragma unroll 1
+  for (int kj = 0; kj < 8; ++kj) {
+    if (kj < 4) panel_block<8>(std::make_integer_sequence<int, 16>{}, a, Us, rinv, kj, t);
+    else panel_block<4>(std::make_integer_sequence<int, 16>{}, a, Us, rinv, kj, t);
+#pragma unroll
+    for (int cc = 0; cc < PS_NC; ++cc) {
+      if (c0 + cc < mcols) A12[(long)(c0 + cc) * lda + 16 * kj + t] = a[0][cc];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) a[k][cc] = a[k + 1][cc];
+      a[7][cc] = 0.0;
+    }
+  }
+}
+
+void potrf_panel_solve_launch(hipStream_t st, int batch, double* A, long lda, long strideA, int k0, int mcols) {
+  if (mcols <= 0) return;
+  const size_t lds = (size_t)(NB * (NB + 1) / 2 + NB) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HYP_CHECK(hipFuncSetAttribute((const void*)potrf_panel_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(potrf_panel_solve_kernel, dim3((mcols + PS_COLS - 1) / PS_COLS, batch), dim3(256), lds, st, A, lda, strideA, k0, mcols);
+  HYP_CHECK(hipGetLastError());
 }
 
 }  // namespace hyp
