@@ -402,6 +402,37 @@ int hyp_sys_mul_G(hyp_sys* sys, int trans, double alpha, const double* x, double
   c.sync();
   API_END(sys->ctx)
 }
+int hyp_sys_load_model(hyp_sys* sys, const double* c, const double* b, const double* h, const double* A) {
+  API_BEGIN
+  sys->s->load_model(c, b, h, A);
+  API_END(sys->ctx)
+}
+int hyp_sys_update_lhs(hyp_sys* sys, int* use_sqrt_out, int* info, int* used_fallback, double* sol_const_out) {
+  API_BEGIN
+  Ctx& c = sys->ctx->c;
+  SysSolver* s = sys->s;
+  *info = 0;
+  *used_fallback = 0;
+  if (s->nmp > 0) s->update_lhs_fact(info, used_fallback);
+  if (use_sqrt_out)
+    for (size_t k = 0; k < s->cones.size(); ++k) use_sqrt_out[k] = s->use_sqrt[k];
+  if (*info == 0) {
+    s->update_const();
+    if (sol_const_out) {
+      c.d2h(sol_const_out, s->sol_const.p, (size_t)(s->n + s->p + s->q) * sizeof(double));
+      c.sync();
+    }
+  }
+  API_END(sys->ctx)
+}
+int hyp_sys_get_directions(hyp_sys* sys, double* dir_vec, const double* rhs_vec, double mu, double tau, int max_ref_steps,
+                           double res_norm_cutoff, double min_impr_tol, double* res_norm, int* n_solves) {
+  API_BEGIN
+  SysSolver* s = sys->s;
+  HYP_REQUIRE(s->nmp == 0 || s->fact_ok, "get_directions: no valid factorization (call hyp_sys_update_lhs)");
+  *res_norm = s->get_directions(dir_vec, rhs_vec, mu, tau, max_ref_steps, res_norm_cutoff, min_impr_tol, n_solves);
+  API_END(sys->ctx)
+}
 int hyp_sys_get_lhs(hyp_sys* sys, double* out) {
   API_BEGIN
   Ctx& c = sys->ctx->c;

@@ -223,7 +223,7 @@ bool PsdCone::update_feas() {   // :80-90
   const size_t mb = (size_t)side * side * sizeof(double);
   svec_unpack(ctx, side, 1, point.d(), dim, X.d());          // svec_to_smat! (both triangles filled)
   ctx.d2d(U.p, X.p, mb);
-  potrf_upper_batched(ctx, side, U.d(), side, 0, 1, dinvb.d(), d_info.i());
+  potrf_upper_batched(ctx, side, U.d(), side, 0, 1, nullptr, d_info.i());   // block inverses on demand (ensure_inverses)
   is_feas_ = (read_info(ctx, d_info.i()) == 0);
   feas_updated = true;
   inv_ready = false;
@@ -232,13 +232,14 @@ bool PsdCone::update_feas() {   // :80-90
 
 bool PsdCone::is_dual_feas() {   // :92-95
   svec_unpack(ctx, side, 1, dual_point.d(), dim, tmpmat.d());
-  potrf_upper_batched(ctx, side, tmpmat.d(), side, 0, 1, dinvb.d() + dinv_elems(side), d_info.i() + 1);
+  potrf_upper_batched(ctx, side, tmpmat.d(), side, 0, 1, nullptr, d_info.i() + 1);
   return read_info(ctx, d_info.i() + 1) == 0;
 }
 
 void PsdCone::ensure_inverses() {
   if (inv_ready) return;
   dev_zero_strict_lower(ctx, side, U.d(), side, 1, 0);
+  potrf_invert_diag_blocks(ctx, side, U.d(), side, 0, 1, dinvb.d());
   trtri_upper_batched(ctx, side, U.d(), side, 0, dinvb.d(), 0, Uinv.d(), side, 0, 1);
   dev_transpose(ctx, side, side, Uinv.d(), side, UinvT.d(), side, 1, 0, 0);
   dev_transpose(ctx, side, side, U.d(), side, UT.d(), side, 1, 0, 0);

@@ -81,7 +81,12 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
     HYP_CHECK(hipEventRecord(Rk, c.stream2));
   }
   if (lookahead && nblk >= 2) HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(2 * (nblk - 2) + 1), 0));
-  potrf_diag_launch(c.stream, false, true, batch, nblk, A, lda, strideA, n, 0, dinv, strideD, d_info);
+  if (dinv) potrf_invert_diag_blocks(c, n, A, lda, strideA, batch, dinv);
+}
+
+void potrf_invert_diag_blocks(Ctx& c, int n, double* A, long lda, long strideA, int batch, double* dinv) {
+  const int nblk = (n + NB - 1) / NB;
+  potrf_diag_launch(c.stream, false, true, batch, nblk, A, lda, strideA, n, 0, dinv, (long)dinv_elems(n), nullptr);
 }
 
 // ---- diagonal block solve of the blocked substitution -----------------------------------------

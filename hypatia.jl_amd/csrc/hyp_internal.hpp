@@ -103,7 +103,9 @@ struct Ctx {
 // dinv receives, for every NB-diagonal block, inv(U_kk) followed by its transpose:
 // layout [batch][block][2][NB*NB] col-major, ld NB (DINV_BLK doubles per block).
 // d_info[b] = 0 or the 1-based index of the first non-positive pivot (LAPACK dpotrf convention).
+// dinv == nullptr: factor only (feasibility checks); potrf_invert_diag_blocks produces the block inverses later.
 void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int batch, double* dinv, int* d_info);
+void potrf_invert_diag_blocks(Ctx& c, int n, double* A /* factored */, long lda, long strideA, int batch, double* dinv);
 constexpr long DINV_BLK = 2L * NB * NB;
 inline size_t dinv_elems(int n) { return (size_t)((n + NB - 1) / NB) * DINV_BLK; }
 

@@ -212,4 +212,230 @@ void SysSolver::solve3(double* d_sol, const double* d_rhs) {   // qrchol.jl:39-8
   }
 }
 
+// =============================================================================================
+// device-resident get_directions (systemsolvers/common.jl:15-182)
+// =============================================================================================
+// out[0] = max_i |a_i - b_i| over n entries; a <- a - b in place
+__global__ __launch_bounds__(1024) void sub_absmax_kernel(int n, double* __restrict__ a, const double* __restrict__ b,
+                                                          double* __restrict__ out) {
+  __shared__ double red[16];
+  double m = 0.0;
+  bool bad = false;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const double v = a[i] - b[i];
+    a[i] = v;
+    bad |= (v != v);
+    m = fmax(m, fabs(v));
+  }
+  if (bad) m = __builtin_nan("");
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_down(m, off);
+    m = (m != m || o != o) ? __builtin_nan("") : fmax(m, o);
+  }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double r = red[0];
+    for (int w = 1; w < 16; ++w) r = (r != r || red[w] != red[w]) ? __builtin_nan("") : fmax(r, red[w]);
+    out[0] = r;
+  }
+}
+
+void SysSolver::load_model(const double* hc, const double* hb, const double* hh, const double* hA) {
+  const size_t d = sizeof(double);
+  mc.ensure(std::max(n, 1) * d); mb.ensure(std::max(p, 1) * d); mh.ensure(std::max(q, 1) * d);
+  ctx.h2d(mc.p, hc, (size_t)n * d);
+  ctx.h2d(mb.p, hb, (size_t)p * d);
+  ctx.h2d(mh.p, hh, (size_t)q * d);
+  if (p > 0) {
+    HYP_REQUIRE(hA != nullptr, "sys: model.A is required when p > 0");
+    mA.ensure((size_t)p * n * d);
+    ctx.h2d(mA.p, hA, (size_t)p * n * d);
+  }
+  for (DBuf* b : {&v_rhs, &v_dir, &v_res, &v_tmp}) {
+    b->ensure((size_t)dimv() * d);
+    ctx.zero(b->p, (size_t)dimv() * d);
+  }
+  for (DBuf* b : {&sub_rhs, &sub_sol, &sol_const}) b->ensure((size_t)(n + p + q) * d);
+  Gx_dir.ensure(std::max(q, 1) * d);
+  ctx.sync();
+  model_loaded = true;
+}
+
+// rhs_const = [-c; b; H h], sol_const = solve_subsystem3(rhs_const)   (qrchol.jl:191-197)
+void SysSolver::update_const() {
+  HYP_REQUIRE(model_loaded, "sys: load_model first");
+  double* r = sub_rhs.d();
+  dev_scale_copy(ctx, n, -1.0, mc.d(), r);
+  if (p > 0) ctx.d2d(r + n, mb.p, (size_t)p * sizeof(double));
+  block_hess_prod_vec(r + n + p, mh.d());
+  solve3(sol_const.d(), r);
+  double* ds = ctx.dscal.d();
+  dev_dot(ctx, n, mc.d(), sol_const.d(), ds);
+  dev_dot(ctx, p, mb.d(), sol_const.d() + n, ds + 1);
+  dev_dot(ctx, q, mh.d(), sol_const.d() + n + p, ds + 2);
+  ctx.d2h(ctx.h_pinned, ds, 3 * sizeof(double));
+  ctx.sync();
+  dot_const = ctx.h_pinned[0] + (p > 0 ? ctx.h_pinned[1] : 0.0) + ctx.h_pinned[2];
+}
+
+SysSolver::Scal SysSolver::solve_system(double* sol, const double* rhs, Scal rs, double mu, double taubar) {
+  const size_t d = sizeof(double);
+  const int oz = n + p, os = n + p + q + 1;
+  double* sr = sub_rhs.d();
+  double* ss = sub_sol.d();
+  // solve_subsystem4 (common.jl:146-182): rhs_sub.x = rhs.x; rhs_sub.y = -rhs.y; setup_rhs3 (qrchol.jl:16-37)
+  ctx.d2d(sr, rhs, (size_t)n * d);
+  if (p > 0) dev_scale_copy(ctx, p, -1.0, rhs + n, sr + n);
+  for (size_t k = 0; k < cones.size(); ++k) {
+    Cone* ck = cones[k];
+    const int o = offs[k], dk = ck->dim;
+    if (ck->use_dual_barrier) {
+      double* tmp = ss + oz + o;   // (z_temp_k = sol.z_k in the reference)
+      dev_scale_copy(ctx, dk, -1.0, rhs + oz + o, tmp);
+      dev_axpby(ctx, dk, -1.0, rhs + os + o, 1.0, tmp);
+      ck->inv_hess_prod(sr + oz + o, q, tmp, q, 1);
+    } else {
+      ck->hess_prod(sr + oz + o, q, rhs + oz + o, q, 1);
+      dev_axpby(ctx, dk, -1.0, rhs + os + o, -1.0, sr + oz + o);
+    }
+  }
+  solve3(ss, sr);
+  double* ds = ctx.dscal.d();
+  dev_dot(ctx, n, mc.d(), ss, ds);
+  dev_dot(ctx, p, mb.d(), ss + n, ds + 1);
+  dev_dot(ctx, q, mh.d(), ss + oz, ds + 2);
+  ctx.d2h(ctx.h_pinned, ds, 3 * d);
+  ctx.sync();
+  const double dot_sub = ctx.h_pinned[0] + (p > 0 ? ctx.h_pinned[1] : 0.0) + ctx.h_pinned[2];
+  const double tau_num = rs.tau + rs.kap + dot_sub;
+  const double tau_denom = mu / taubar / taubar - dot_const;
+  const double sol_tau = tau_num / tau_denom;
+  // sol[1:dim3] = sol_sub + sol_tau * sol_const
+  ctx.d2d(sol, ss, (size_t)(n + p + q) * d);
+  dev_axpby(ctx, n + p + q, sol_tau, sol_const.d(), 1.0, sol);
+  // sol.s = h * tau - rhs.z - G sol.x     (common.jl:139-141).  G sol.x is formed from the rounded sol.x itself
+  // (NOT as G sol_sub.x + tau G sol_const.x: when the two parts cancel, that sum loses the consistency
+  // between x and s that the residual check relies on); it is kept for the residual, which needs the same product.
+  gemv(ctx, false, q, n, 1.0, G.d(), q, sol, 0.0, Gx_dir.d());
+  Gx_dir_valid = true;
+  dev_scale_copy(ctx, q, sol_tau, mh.d(), sol + os);
+  dev_axpby(ctx, q, -1.0, rhs + oz, 1.0, sol + os);
+  dev_axpby(ctx, q, -1.0, Gx_dir.d(), 1.0, sol + os);
+  Scal out;
+  out.tau = sol_tau;
+  out.kap = -mu / taubar / taubar * sol_tau + rs.kap;
+  return out;
+}
+
+SysSolver::Scal SysSolver::apply_lhs(double* res, const double* dir, Scal ds_, double mu, double taubar) {
+  const size_t d = sizeof(double);
+  const int oz = n + p, os = n + p + q + 1;
+  const double tau_dir = ds_.tau, kap_dir = ds_.kap;
+  // res.x = c tau + G' z (+ A' y)
+  dev_scale_copy(ctx, n, tau_dir, mc.d(), res);
+  gemv(ctx, true, q, n, 1.0, G.d(), q, dir + oz, 1.0, res);
+  // res.z = h tau - s - G x
+  dev_scale_copy(ctx, q, tau_dir, mh.d(), res + oz);
+  dev_axpby(ctx, q, -1.0, dir + os, 1.0, res + oz);
+  if (Gx_dir_valid) dev_axpby(ctx, q, -1.0, Gx_dir.d(), 1.0, res + oz);   // G dir.x was just formed by solve_system
+  else gemv(ctx, false, q, n, -1.0, G.d(), q, dir, 1.0, res + oz);
+  double* dsc = ctx.dscal.d();
+  dev_dot(ctx, n, mc.d(), dir, dsc);
+  dev_dot(ctx, q, mh.d(), dir + oz, dsc + 1);
+  if (p > 0) {
+    gemv(ctx, true, p, n, 1.0, mA.d(), p, dir + n, 1.0, res);                  // res.x += A' y
+    dev_scale_copy(ctx, p, tau_dir, mb.d(), res + n);                           // res.y = b tau - A x
+    gemv(ctx, false, p, n, -1.0, mA.d(), p, dir, 1.0, res + n);
+    dev_dot(ctx, p, mb.d(), dir + n, dsc + 2);
+  }
+  for (size_t k = 0; k < cones.size(); ++k) {   // res.s_k = H_k prim_dir_k + dual_dir_k
+    Cone* ck = cones[k];
+    const int o = offs[k], dk = ck->dim;
+    const double* prim = ck->use_dual_barrier ? dir + oz + o : dir + os + o;
+    const double* dual = ck->use_dual_barrier ? dir + os + o : dir + oz + o;
+    ck->hess_prod_slow(res + os + o, q, prim, q, 1);
+    dev_axpby(ctx, dk, 1.0, dual, 1.0, res + os + o);
+  }
+  ctx.d2h(ctx.h_pinned + 8, dsc, 3 * d);
+  ctx.sync();
+  Scal out;
+  out.tau = -ctx.h_pinned[8] - ctx.h_pinned[9] - kap_dir - (p > 0 ? ctx.h_pinned[10] : 0.0);
+  out.kap = mu / taubar * tau_dir / taubar + kap_dir;
+  return out;
+}
+
+double SysSolver::get_directions(double* h_dir, const double* h_rhs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
+                                 double min_impr_tol, int* n_solves) {
+  HYP_REQUIRE(model_loaded, "sys: load_model first");
+  const size_t d = sizeof(double);
+  const int dv = dimv(), it = n + p + q, ik = dv - 1;
+  double* rhs = v_rhs.d();
+  double* dir = v_dir.d();
+  double* res = v_res.d();
+  double* tmp = v_tmp.d();
+  ctx.h2d(rhs, h_rhs, (size_t)dv * d);
+  ctx.zero(rhs + it, d);   // tau / kap travel as host scalars: their device slots stay zero in every work vector
+  ctx.zero(rhs + ik, d);
+  const Scal rs{h_rhs[it], h_rhs[ik]};
+  *n_solves = 0;
+  Scal dsc = solve_system(dir, rhs, rs, mu, taubar);
+  ++*n_solves;
+  double res_norm = 0.0;
+  auto residual = [&](Scal dcur, Scal& rsc) -> double {   // res = K dir - rhs ; returns the inf-norm
+    rsc = apply_lhs(res, dir, dcur, mu, taubar);
+    rsc.tau -= rs.tau;
+    rsc.kap -= rs.kap;
+    // (the tau / kap slots of the device vectors are kept at zero: the scalars travel on the host)
+    hipLaunchKernelGGL(sub_absmax_kernel, dim3(1), dim3(1024), 0, ctx.stream, dv, res, rhs, ctx.dscal.d() + 8);
+    ctx.d2h(ctx.h_pinned + 16, ctx.dscal.d() + 8, d);
+    ctx.sync();
+    double m = ctx.h_pinned[16];
+    if (getenv("HYP_DEBUG_DIR")) fprintf(stderr, "[dir] absmax %.3e  tau res %.3e (lhs %.6e rhs %.6e)  kap res %.3e (lhs %.6e rhs %.6e)\n", m, rsc.tau,
+                                         rsc.tau + rs.tau, rs.tau, rsc.kap, rsc.kap + rs.kap, rs.kap);
+    if (m != m || rsc.tau != rsc.tau || rsc.kap != rsc.kap) return __builtin_nan("");
+    return std::max(m, std::max(std::fabs(rsc.tau), std::fabs(rsc.kap)));
+  };
+  if (max_ref_steps > 0) {
+    Scal tsc = dsc, rsc{0, 0};
+    ctx.d2d(tmp, dir, (size_t)dv * d);
+    res_norm = residual(dsc, rsc);
+    if (res_norm > res_norm_cutoff) {
+      bool is_prev_slow = false;
+      double prev_res_norm = res_norm;
+      for (int step = 0; step < max_ref_steps; ++step) {
+        // dir = dir_temp - solve(res)
+        Scal csc = solve_system(dir, res, rsc, mu, taubar);
+        ++*n_solves;
+        dev_axpby(ctx, dv, 1.0, tmp, -1.0, dir);
+        Gx_dir_valid = false;   // dir is no longer the raw output of solve_system
+        dsc.tau = tsc.tau - csc.tau;
+        dsc.kap = tsc.kap - csc.kap;
+        Scal rsc2{0, 0};
+        const double res_norm_new = residual(dsc, rsc2);
+        if (!(res_norm_new < res_norm)) {   // (>= or NaN: keep the previous direction)
+          ctx.d2d(dir, tmp, (size_t)dv * d);
+          dsc = tsc;
+          break;
+        }
+        ctx.d2d(tmp, dir, (size_t)dv * d);
+        tsc = dsc;
+        rsc = rsc2;
+        res_norm = res_norm_new;
+        if (res_norm < res_norm_cutoff) break;
+        const bool is_curr_slow = res_norm > min_impr_tol * prev_res_norm;
+        if (is_prev_slow && is_curr_slow) break;
+        prev_res_norm = res_norm;
+        is_prev_slow = is_curr_slow;
+      }
+    }
+  }
+  ctx.d2h(h_dir, dir, (size_t)dv * d);
+  ctx.sync();
+  h_dir[it] = dsc.tau;
+  h_dir[ik] = dsc.kap;
+  return res_norm;
+}
+
 }  // namespace hyp

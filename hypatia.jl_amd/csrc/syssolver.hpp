@@ -35,6 +35,26 @@ struct SysSolver {
   void tri_solves(double* d_x);                                                // both triangular solves of the potrs
   void potrs(double* d_x);                                                     // x <- lhs^-1 x with the current factor (:66-69)
   void solve3(double* d_sol, const double* d_rhs);                             // qrchol.jl:39-85
+
+  // ---- device-resident direction solves (systemsolvers/common.jl:15-182): the 6x6 system of one
+  // stepper direction, reduced 6 -> 4 -> 3 on the device, with the reference's iterative refinement.
+  // Vectors use the Point layout [x(n); y(p); z(q); tau; s(q); kap]; tau / kap travel as host scalars.
+  DBuf mc, mb, mh, mA;                  // model.c, b, h, A (p x n) after preprocessing
+  DBuf v_rhs, v_dir, v_res, v_tmp;      // Point-layout work vectors
+  DBuf sub_rhs, sub_sol, sol_const;     // 3x3 subsystem vectors [x; y; z]
+  bool model_loaded = false;
+  double dot_const = 0.0;               // dot_obj(model, sol_const)
+  DBuf Gx_dir;                          // G * (x of the direction solve_system just produced), reused by its residual
+  bool Gx_dir_valid = false;
+  int dimv() const { return n + p + q + 1 + q + 1; }
+  void load_model(const double* hc, const double* hb, const double* hh, const double* hA);
+  void update_const();                                                          // qrchol.jl:191-197
+  struct Scal { double tau, kap; };
+  Scal solve_system(double* d_sol, const double* d_rhs, Scal rhs, double mu, double taubar);   // common.jl:129-182
+  Scal apply_lhs(double* d_res, const double* d_dir, Scal dir, double mu, double taubar);      // common.jl:79-121
+  // returns res_norm; dir / rhs are HOST Point vectors (common.jl:15-76)
+  double get_directions(double* h_dir, const double* h_rhs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
+                        double min_impr_tol, int* n_solves);
 };
 
 }  // namespace hyp

@@ -125,6 +125,14 @@ def get_directions(stepper, solver, min_impr_tol=0.5):   # common.jl:15-76
     res_norm_cutoff = solver.res_norm_cutoff
     max_ref_steps = solver.max_ref_steps
 
+    if getattr(syssolver, "native_directions", False):   # the whole routine on the device (hyp_sys_get_directions)
+        res_norm, ns = syssolver.get_directions_native(solver, dir, rhs, min_impr_tol)
+        solver.n_solves += ns
+        assert not np.isnan(res_norm)
+        if max_ref_steps > 0:
+            solver.worst_dir_res = max(solver.worst_dir_res, res_norm)
+        return dir
+
     syssolver.solve_system(solver, dir, rhs)
     solver.n_solves += 1
     if max_ref_steps == 0:

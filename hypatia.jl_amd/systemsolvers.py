@@ -79,6 +79,12 @@ class QRCholDenseSystemSolver:
         self.rhs_const.z[:] = model.h
         self.last_info = 0
         self.used_fallback = False
+        # device-resident get_directions (hyp_sys_get_directions): model vectors live on the GPU too
+        cc, bb, hh = (np.ascontiguousarray(v, dtype=np.float64) for v in (model.c, model.b, model.h))
+        AA = np.asfortranarray(model.A, dtype=np.float64) if p > 0 else None
+        L.check(lib.hyp_sys_load_model(h, L.vec_ptr(cc), L.vec_ptr(bb), L.vec_ptr(hh),
+                                       AA.ctypes.data_as(c_vp) if AA is not None else None), "hyp_sys_load_model")
+        self.native_directions = True
         return self
 
     # y = alpha * op(G) x + beta * y on the device-resident model.G
@@ -93,12 +99,33 @@ class QRCholDenseSystemSolver:
     # ---- qrchol.jl:181-199
     def update_lhs(self, solver):
         model = solver.model
+        if self.native_directions:   # one call: factorization + the constant-column solve, both kept on the device
+            nc = len(model.cones)
+            flags = (c_int * max(nc, 1))()
+            info, fb = c_int(0), c_int(0)
+            t0 = time.perf_counter()
+            L.check(L.lib().hyp_sys_update_lhs(self._h, flags, ctypes.byref(info), ctypes.byref(fb), L.vec_ptr(self.sol_const.vec)),
+                    "hyp_sys_update_lhs")
+            solver.time_upfact += time.perf_counter() - t0
+            self.use_sqrt_hess_cones = [bool(flags[k]) for k in range(nc)]
+            self.last_info, self.used_fallback = info.value, bool(fb.value)
+            if info.value != 0:
+                print("positive definite linear system factorization failed")
+            return self
         if model.n - model.p > 0:
             self.update_lhs_fact(solver)
         hh = np.ascontiguousarray(model.h)
         L.check(L.lib().hyp_sys_block_hess_prod(self._h, L.vec_ptr(self.rhs_const.z), L.vec_ptr(hh)), "hyp_sys_block_hess_prod")
         self.solve_subsystem3(solver, self.sol_const, self.rhs_const)
         return self
+
+    # ---- common.jl:15-76 on the device
+    def get_directions_native(self, solver, dir, rhs, min_impr_tol=0.5):
+        res_norm, ns = ctypes.c_double(0.0), c_int(0)
+        L.check(L.lib().hyp_sys_get_directions(self._h, L.vec_ptr(dir.vec), L.vec_ptr(rhs.vec), float(solver.mu), float(solver.point.tau),
+                                               int(solver.max_ref_steps), float(solver.res_norm_cutoff), float(min_impr_tol),
+                                               ctypes.byref(res_norm), ctypes.byref(ns)), "hyp_sys_get_directions")
+        return res_norm.value, ns.value
 
     # ---- qrchol.jl:201-257
     def update_lhs_fact(self, solver):

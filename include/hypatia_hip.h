@@ -108,6 +108,19 @@ int hyp_sys_block_hess_prod(hyp_sys* sys, double* out_q, const double* in_q);
 /* y = alpha * op(G) x + beta * y with the device-resident model.G (qrchol.jl:52,73; common.jl:91,94,144;
  * Solvers.jl:432,450).  trans = 0: x has n entries, y has q; trans = 1: x has q, y has n. */
 int hyp_sys_mul_G(hyp_sys* sys, int trans, double alpha, const double* x, double beta, double* y);
+/* ---- device-resident direction solves: Solvers.get_directions (systemsolvers/common.jl:15-76) with
+ * solve_system / solve_subsystem4 (common.jl:129-182), setup_rhs3 (qrchol.jl:16-37) and the residual
+ * apply_lhs (common.jl:79-121) all on the GPU; only the right-hand side goes in and the direction
+ * comes out.  Vectors use Hypatia's Point layout [x(n); y(p); z(q); tau; s(q); kap] (point.jl:5-54). */
+/* model.c (n), model.b (p), model.h (q), model.A (p x n col-major, NULL when p = 0) after preprocessing */
+int hyp_sys_load_model(hyp_sys* sys, const double* c, const double* b, const double* h, const double* A);
+/* update_lhs (qrchol.jl:181-199): update_lhs_fact + sol_const = solve_subsystem3([-c; b; H h]); the
+ * constant solution stays on the device (sol_const_out, n + p + q entries, may be NULL) */
+int hyp_sys_update_lhs(hyp_sys* sys, int* use_sqrt_hess_cones_out, int* info, int* used_fallback, double* sol_const_out);
+/* get_directions(stepper, solver): dir <- K^-1 rhs with up to max_ref_steps refinement steps; mu = solver.mu,
+ * tau = solver.point.tau[]; res_norm_cutoff / min_impr_tol as in common.jl:15-20; n_solves counts solve_system calls */
+int hyp_sys_get_directions(hyp_sys* sys, double* dir_vec, const double* rhs_vec, double mu, double tau, int max_ref_steps,
+                           double res_norm_cutoff, double min_impr_tol, double* res_norm, int* n_solves);
 int hyp_sys_get_lhs(hyp_sys* sys, double* out_nmpxnmp);        /* upper triangle meaningful (tests) */
 
 /* ---- dense kernels exposed for parity tests and micro-benchmarks ------------------------------- */

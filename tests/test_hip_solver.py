@@ -123,3 +123,42 @@ def test_small_polymin_and_matrixcompletion_hip():
         os_ = build_solve_check(OSolver(default_tol_relax=10), omodel(inst), inst)
         assert abs(hs.primal_obj - os_.primal_obj) <= 1e-6 * (1 + abs(os_.primal_obj))
         assert abs(hs.num_iters - os_.num_iters) <= 2
+
+
+@pytest.mark.parametrize("name,reduce", [("possemideftri2", True), ("possemideftri2", False), ("nonnegative4", False),
+                                         ("epinormspectral2_primal", True), ("epinormspectral3_3x4_dual", True),
+                                         ("wsosinterpnonnegative2", True)])
+def test_device_get_directions_matches_host_composition_and_oracle(name, reduce):
+    """hyp_sys_get_directions (6x6 solve + residual + refinement, all on the device) against (a) the same
+    routine composed on the host from solve_subsystem3 / cone oracles / mul_G as the reference composes it
+    (common.jl:15-182), and (b) the CPU oracle's get_directions, for the four right-hand sides of a step."""
+    import hypatia_jl_amd as H
+    from hypatia_jl_amd import solvers as HS
+    from oracle import instances as I
+    from oracle import solvers as OS
+    from oracle.build import make_model as omodel
+    inst = I.KNOWN_ANSWER[name]()
+    hs = H.Solver(iter_limit=3, reduce=reduce)
+    hs.load(H.make_model(inst)); hs.solve()          # a few iterations in: a generic interior point
+    os_ = OS.Solver(iter_limit=3, reduce=reduce)
+    os_.load(omodel(inst)); os_.solve()
+    assert np.linalg.norm(hs.point.vec - os_.point.vec) <= 1e-8 * np.linalg.norm(os_.point.vec)
+    st, sysv = hs.stepper, hs.syssolver
+    assert sysv.native_directions
+    sysv.update_lhs(hs)
+    os_.syssolver.update_lhs(os_)
+    for upd, oupd in ((HS.update_rhs_cent, OS.update_rhs_cent), (HS.update_rhs_pred, OS.update_rhs_pred)):
+        upd(hs, st.rhs)
+        sysv.native_directions = True
+        HS.get_directions(st, hs)
+        d_dev = st.dir.vec.copy()
+        sysv.native_directions = False
+        HS.get_directions(st, hs)
+        d_host = st.dir.vec.copy()
+        sysv.native_directions = True
+        oupd(os_, os_.stepper.rhs)
+        OS.get_directions(os_.stepper, os_)
+        d_orc = os_.stepper.dir.vec
+        scale = np.linalg.norm(d_orc)
+        assert np.linalg.norm(d_dev - d_host) <= 1e-11 * scale, name
+        assert np.linalg.norm(d_dev - d_orc) <= 1e-7 * scale, name
