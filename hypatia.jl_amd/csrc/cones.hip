@@ -280,12 +280,23 @@ void PsdCone::two_sided(const double* R, int kr2, int kr3, double* prod, long ld
   int chunk = (int)std::min<long>(ncols, std::max<long>(1, ws_cap / s2));
   ws1.ensure((size_t)chunk * s2 * sizeof(double));
   ws2.ensure((size_t)chunk * s2 * sizeof(double));
+  const bool fused = use_fused(ncols);
   for (int c0 = 0; c0 < ncols; c0 += chunk) {
     const int nc = std::min(chunk, ncols - c0);
+    if (fused) {   // one workgroup per matrix, svec conversions fused (psd_twosided.hip)
+      psd_two_sided_fused(ctx, side, nc, R, kr2 == KR_LE_N ? 1 : (kr2 == KR_GE_N ? 2 : 0), arr + (long)c0 * lda, lda,
+                          prod + (long)c0 * ldp, ldp, ws1.d());
+      continue;
+    }
     svec_unpack(ctx, side, nc, arr + (long)c0 * lda, lda, ws1.d());
     two_sided_core(ctx, side, nc, R, kr2, kr3, ws1.d(), ws2.d());
     svec_pack(ctx, side, nc, ws1.d(), prod + (long)c0 * ldp, ldp, 1.0);
   }
+}
+
+bool PsdCone::use_fused(int ncols) const {
+  static const bool enabled = [] { const char* e = getenv("HYP_PSD_FUSED"); return !(e && e[0] == '0'); }();
+  return enabled && ncols >= 4 && psd_two_sided_fused_ok(side);
 }
 
 void PsdCone::hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) {   // :126-142  X^-1 V X^-1
@@ -299,8 +310,15 @@ void PsdCone::hess_prod(double* prod, long ldp, const double* arr, long lda, int
   int chunk = (int)std::min<long>(ncols, std::max<long>(1, ws_cap / s2));
   ws1.ensure((size_t)chunk * s2 * sizeof(double));
   ws2.ensure((size_t)chunk * s2 * sizeof(double));
+  const bool fused = use_fused(ncols);
   for (int c0 = 0; c0 < ncols; c0 += chunk) {
     const int nc = std::min(chunk, ncols - c0);
+    if (fused) {
+      double* pc = prod + (long)c0 * ldp;
+      psd_two_sided_fused(ctx, side, nc, Uinv.d(), 1, arr + (long)c0 * lda, lda, pc, ldp, ws1.d());   // U^-T V U^-1
+      psd_two_sided_fused(ctx, side, nc, UinvT.d(), 2, pc, ldp, pc, ldp, ws1.d());                     // U^-1 (.) U^-T
+      continue;
+    }
     svec_unpack(ctx, side, nc, arr + (long)c0 * lda, lda, ws1.d());
     two_sided_core(ctx, side, nc, Uinv.d(), KR_LE_N, KR_LE_M, ws1.d(), ws2.d());    // U^-T V U^-1
     two_sided_core(ctx, side, nc, UinvT.d(), KR_GE_N, KR_GE_M, ws1.d(), ws2.d());   // U^-1 (.) U^-T

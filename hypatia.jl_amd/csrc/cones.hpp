@@ -8,6 +8,11 @@
 
 namespace hyp {
 
+// psd_twosided.hip: prod[:, j] = svec(R' smat(arr[:, j]) R) with the svec conversions fused (side <= 208)
+bool psd_two_sided_fused_ok(int side);
+void psd_two_sided_fused(Ctx& c, int side, int ncols, const double* R, int rstruct /* 0 full, 1 upper, 2 lower */, const double* arr,
+                         long lda, double* prod, long ldp, double* zws /* ncols * side^2 */);
+
 enum ConeKind { CONE_NONNEG = 0, CONE_PSD = 1, CONE_EPINORMSPECTRAL = 2, CONE_WSOS = 3 };
 
 struct Cone {
@@ -103,6 +108,7 @@ struct PsdCone : Cone {   // src/Cones/possemideftri.jl (real symmetric)
   void update_grad() override;
   void set_initial_point(double* h_out) override;
   void ensure_inverses();
+  bool use_fused(int ncols) const;   // psd_twosided.hip path for this side / column count
   // W_j = R' V_j R for every column j; kr_b / kr_a describe R's triangularity (see cones.hip)
   void two_sided(const double* R, int kr_step2, int kr_step3, double* prod, long ldp, const double* arr, long lda, int ncols);
   void hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;

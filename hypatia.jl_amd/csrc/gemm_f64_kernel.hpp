@@ -115,30 +115,37 @@ void gemm_f64_kernel(GemmArgs p) {
       return;
     }
 
+    // General (edge / unaligned) loader.  Loads are unconditional on clamped indices and out-of-range
+    // elements are zeroed by a MULTIPLY with a 0 / 1 mask: with a select the compiler sinks each load
+    // under its predicate and waits for every single one (2 REPS serial round trips per K tile).
+    const int klast = kend - 1;
     if (TRANSA) {
       const int k = k0 + lk;
-      const bool kok = (k < kend);
+      const int kc = min(k, klast);
+      const double kmask = (k < kend) ? 1.0 : 0.0;
 #pragma unroll
       for (int rep = 0; rep < REPS; ++rep) {
         const int m = m0 + lr + 16 * rep;
-        ra[rep] = (kok && m < p.M) ? A[(long)m * p.lda + k] : 0.0;
+        ra[rep] = A[(long)min(m, p.M - 1) * p.lda + kc] * ((m < p.M) ? kmask : 0.0);
       }
     } else {
       const int m = m0 + nn_r;
-      const bool mok = (m < p.M);
+      const int mc = min(m, p.M - 1);
+      const double mmask = (m < p.M) ? 1.0 : 0.0;
 #pragma unroll
       for (int rep = 0; rep < REPS; ++rep) {
         const int k = k0 + nn_k + NN_KSTEP * rep;
-        ra[rep] = (mok && k < kend) ? A[(long)k * p.lda + m] : 0.0;
+        ra[rep] = A[(long)min(k, klast) * p.lda + mc] * ((k < kend) ? mmask : 0.0);
       }
     }
     {
       const int k = k0 + lk;
-      const bool kok = (k < kend);
+      const int kc = min(k, klast);
+      const double kmask = (k < kend) ? 1.0 : 0.0;
 #pragma unroll
       for (int rep = 0; rep < REPS; ++rep) {
         const int n = n0 + lr + 16 * rep;
-        rb[rep] = (kok && n < p.N) ? B[(long)n * p.ldb + k] : 0.0;
+        rb[rep] = B[(long)min(n, p.N - 1) * p.ldb + kc] * ((n < p.N) ? kmask : 0.0);
       }
     }
   };
@@ -215,6 +222,39 @@ void gemm_f64_kernel(GemmArgs p) {
           W[(long)n * p.part_ld + m] = acc[j][i][r];
         }
       }
+    return;
+  }
+  if (p.beta != 0.0 && p.cm_blk == 0) {
+    // read-modify-write of C (rank-k updates of the factorizations).  Written naively, every element is a
+    // load that must wait for the previous element's store (C may alias itself): 4 TW^2 serial round
+    // trips per thread.  Instead each group of 4 TW old values is fetched at once, on clamped addresses so
+    // the loads are unconditional, and pinned before the first store of the group.
+#pragma unroll
+    for (int j = 0; j < TW; ++j) {
+      double cold[4][TW];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nc = min(n0 + wn * WT + j * 16 + fk + 4 * r, p.N - 1);
+#pragma unroll
+        for (int i = 0; i < TW; ++i) cold[r][i] = C[(long)nc * p.ldc + min(m0 + wm * WT + i * 16 + fr, p.M - 1)];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < TW; ++i) asm volatile("" : "+v"(cold[r][i]));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * WT + j * 16 + fk + 4 * r;
+#pragma unroll
+        for (int i = 0; i < TW; ++i) {
+          const int m = m0 + wm * WT + i * 16 + fr;
+          double v = p.alpha * acc[j][i][r];
+          if (p.epi == 1) v = v * v;
+          v += p.beta * cold[r][i];
+          if (n < p.N && m < p.M && !(upper && m > n)) C[(long)n * p.ldc + m] = v;
+        }
+      }
+    }
     return;
   }
 #pragma unroll

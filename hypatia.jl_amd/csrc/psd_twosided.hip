@@ -1,0 +1,236 @@
+// Two-sided products W_j = R' V_j R on batches of svec columns.
+//
+// This is the body of PosSemidefTri's sqrt_hess_prod! / inv_sqrt_hess_prod! / hess_prod! / inv_hess_prod!
+// (/root/reference/src/Cones/possemideftri.jl:126-195) applied to the q x n block of G in update_lhs_fact
+// (src/Solvers/systemsolvers/qrchol.jl:219-233): for every column, svec_to_smat!, two triangular or
+// symmetric products with the s x s cone matrix, smat_to_svec!.
+//
+// The generic GEMM (gemm_f64_kernel.hpp) handles it as two tall stacked products, but with 128 x 128
+// tiles a side of 200 is padded to 256 and the triangular operand is only skipped tile by tile: 2.1x
+// the useful MFMA work, plus separate unpack / pack passes over 1.6 GB.  Here the work is cut at the
+// MFMA's own 16 x 16 granularity and the svec <-> smat conversions are fused into loader / epilogue:
+//
+//   pass 1  Z_j = V_j R      A side: V_j gathered straight from the svec column (off-diagonals / sqrt(2))
+//   pass 2  W_j = Z_j' R     (= R' V_j R, V symmetric) A side: Z_j, K-contiguous; only tiles on or above
+//                            the diagonal; epilogue writes the packed svec column (off-diagonals * sqrt(2))
+//
+// Both passes are one kernel: C[m, c] = sum_k A[m, k] R[k, c].  The T x T grid of 16 x 16 tiles of a
+// matrix (T = ceil(s / 16)) is split into nb x nb workgroup tiles of at most 7 x 7 MFMA tiles (s = 200:
+// 7 + 6), 256 threads each; wavefront w owns tile rows {w, w + 4} of the workgroup tile and all its
+// columns, so every fragment read from LDS feeds 2 or 7 MFMAs.  K blocks of 16, register-staged double
+// buffering as in the big GEMM; K ranges follow R's triangularity tile by tile.  The MFMA operands are
+// swapped (R fragment as the row operand) so that 16 lanes hold 16 consecutive ROWS of a column of C:
+// 128-byte stores into column-major Z and into the packed svec column alike.  The workgroups of one
+// matrix are 8 apart in launch order = on the same XCD, sharing V_j / Z_j in its L2.
+// Fixed summation order: bitwise reproducible.
+#include "gemm_f64.hpp"
+#include "hyp_internal.hpp"
+
+namespace hyp {
+
+constexpr int TS_THREADS = 256;
+constexpr int TS_BT = 7;                      // MFMA tiles per workgroup-tile edge (112 rows / columns)
+constexpr int TS_WR = 2;                      // tile rows per wavefront: w and w + 4
+constexpr int TS_LDK = 18;                    // LDS row stride (16 k + 2): conflict-free b64 fragment reads
+constexpr int TS_NREP = TS_BT;                // staged elements per thread per operand per K block (112 * 16 / 256)
+constexpr int TS_OPSZ = 16 * TS_BT * TS_LDK;  // doubles per operand per buffer
+
+struct TsArgs {
+  int s, T, rstruct;          // side, ceil(side / 16), 0 full / 1 upper / 2 lower triangular R
+  int nb, ncols;              // workgroup tiles per dimension; matrices
+  const double* A;            // pass 1: svec columns (lda = column stride); pass 2: Z workspace (s*s per matrix)
+  long lda;
+  const double* R;            // s x s col-major, ld s
+  double* C;                  // pass 1: Z workspace; pass 2: svec columns (ldc = column stride)
+  long ldc;
+};
+
+// x / sqrt(2), correctly rounded like the IEEE division of the reference, in three FMA-class operations
+// (q = x c; r = x - q d; q + r c with c = fl(1 / d): Markstein's division by a constant) instead of the
+// ~15-instruction v_div sequence, seven times per thread and K block
+__device__ __forceinline__ double div_rt2(double x) {
+  const double d = 1.4142135623730951, c = 0.70710678118654746;
+  const double q = x * c;
+  const double r = fma(-q, d, x);
+  return fma(r, c, q);
+}
+
+// first tile and tile count of block b when T tiles are split into nb nearly equal blocks
+__device__ __forceinline__ void ts_block_range(int T, int nb, int b, int& t0, int& cnt) {
+  const int base = T / nb, extra = T - base * nb;
+  t0 = b * base + min(b, extra);
+  cnt = base + (b < extra ? 1 : 0);
+}
+
+template <int PASS>
+__global__ __launch_bounds__(TS_THREADS, 2) void psd_ts_kernel(TsArgs p) {
+  __shared__ double lds[2][2][TS_OPSZ];   // [buffer][A / B][row * LDK + k]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s = p.s, T = p.T;
+
+  // workgroup -> (matrix, row block, column block); the nb^2 workgroups of a matrix sit on one XCD
+  const int nbb = p.nb * p.nb;
+  const int g = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+  const long j = (long)(g / nbb) * 8 + xcd;
+  if (j >= p.ncols) return;
+  const int sub = g % nbb;
+  int mt0, TR, ct0, TC;
+  ts_block_range(T, p.nb, sub % p.nb, mt0, TR);
+  ts_block_range(T, p.nb, sub / p.nb, ct0, TC);
+  if (PASS == 2 && mt0 > ct0 + TC - 1) return;   // entirely below the diagonal
+
+  const double* __restrict__ Aj = (PASS == 1) ? p.A + j * p.lda : p.A + j * (long)s * s;
+  const double* __restrict__ R = p.R;
+
+  // K blocks that can contribute to this workgroup tile
+  int kt_lo = 0, kt_hi = T;
+  if (p.rstruct == 1) kt_hi = min(T, ct0 + TC);   // upper R: R[k, c] = 0 for k > c
+  else if (p.rstruct == 2) kt_lo = ct0;            // lower R: R[k, c] = 0 for k < c
+
+  d4_t acc[TS_WR][TS_BT];
+#pragma unroll
+  for (int i = 0; i < TS_WR; ++i)
+#pragma unroll
+    for (int c = 0; c < TS_BT; ++c) acc[i][c] = (d4_t){0.0, 0.0, 0.0, 0.0};
+
+  const int lk = tid & 15, lr = tid >> 4;   // staging: k within the block; row / column lr + 16 rep
+  double ra[TS_NREP], rb[TS_NREP];
+  const int sm1 = s - 1;
+  const int arow0 = 16 * mt0, bcol0 = 16 * ct0;
+
+  // Loads are unconditional on clamped indices and nothing is done with the values until store_tiles, after
+  // the MFMAs of the current K block: any arithmetic (or select) on a loaded value right here makes the
+  // compiler wait for the load -- or sink the load under the predicate -- and serialises the round trips.
+  auto load_tiles = [&](int kt) {
+    const int kk = min(16 * kt + lk, sm1);
+#pragma unroll
+    for (int rep = 0; rep < TS_NREP; ++rep) {
+      const int mm = min(arow0 + lr + 16 * rep, sm1);
+      if (PASS == 1) {   // V[m, k] from the svec column: column-major upper triangle
+        const int lo = min(mm, kk), hi = max(mm, kk);
+        ra[rep] = Aj[hi * (hi + 1) / 2 + lo];   // (32-bit: s <= 2048)
+      } else {           // Z[k, m]: column m of Z is contiguous in k
+        ra[rep] = Aj[mm * s + kk];
+      }
+      rb[rep] = R[min(bcol0 + lr + 16 * rep, sm1) * s + kk];   // R[k, c]
+    }
+  };
+  auto store_tiles = [&](int buf, int kt) {
+    const int kp = 16 * kt + lk;
+    const double kmask = (kp < s) ? 1.0 : 0.0;
+#pragma unroll
+    for (int rep = 0; rep < TS_NREP; ++rep) {
+      const int m = arow0 + lr + 16 * rep, c = bcol0 + lr + 16 * rep;
+      double va = ra[rep];
+      if (PASS == 1) va = (m == kp) ? va : div_rt2(va);   // off-diagonals: vec[k] / rt2 (arrayutilities.jl:231)
+      lds[buf][0][(lr + 16 * rep) * TS_LDK + lk] = va * ((m < s) ? kmask : 0.0);
+      lds[buf][1][(lr + 16 * rep) * TS_LDK + lk] = rb[rep] * ((c < s) ? kmask : 0.0);
+    }
+  };
+
+  const int fr = lane & 15, fk = lane >> 4;
+  // Which of this wavefront's 2 x 7 tiles exist (bit 2 c + i): rows li = wave + 4 i < TR, columns c < TC,
+  // pass 2 only on / above the diagonal.  Per K block the mask is narrowed by R's triangularity; the MFMA
+  // loop then costs ONE scalar bit test + branch per tile (4 back-to-back MFMAs on its accumulator) --
+  // evaluating the predicates per MFMA was ~20 scalar instructions each and held the pipe at 30 %.
+  unsigned tmask = 0;
+#pragma unroll
+  for (int c = 0; c < TS_BT; ++c)
+#pragma unroll
+    for (int i = 0; i < TS_WR; ++i) {
+      const int li = wave + 4 * i;
+      bool ok = (li < TR) && (c < TC);
+      if (PASS == 2) ok = ok && (mt0 + li <= ct0 + c);
+      tmask |= (ok ? 1u : 0u) << (2 * c + i);
+    }
+  tmask = __builtin_amdgcn_readfirstlane(tmask);
+
+  auto compute = [&](int kt, int buf) {
+    unsigned need = tmask;
+    if (p.rstruct == 1) {        // columns with ct >= kt: c >= kt - ct0
+      const int cmin = max(0, kt - ct0);
+      need = (cmin >= TS_BT) ? 0u : (need & (~0u << (2 * cmin)));
+    } else if (p.rstruct == 2) { // columns with ct <= kt: c <= kt - ct0
+      const int cmax = kt - ct0;
+      need = (cmax < 0) ? 0u : ((cmax >= TS_BT - 1) ? need : (need & ((1u << (2 * cmax + 2)) - 1u)));
+    }
+    if (need == 0u) return;
+    const double* as = lds[buf][0] + fr * TS_LDK + fk;
+    const double* bs = lds[buf][1] + fr * TS_LDK + fk;
+    double af[TS_WR][4], bf[TS_BT][4];
+#pragma unroll
+    for (int i = 0; i < TS_WR; ++i)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) af[i][q4] = as[(wave + 4 * i) * 16 * TS_LDK + 4 * q4];
+#pragma unroll
+    for (int c = 0; c < TS_BT; ++c)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) bf[c][q4] = bs[c * 16 * TS_LDK + 4 * q4];
+#pragma unroll
+    for (int c = 0; c < TS_BT; ++c)
+#pragma unroll
+      for (int i = 0; i < TS_WR; ++i) {
+        if (!((need >> (2 * c + i)) & 1u)) continue;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) acc[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[c][q4], af[i][q4], acc[i][c], 0, 0, 0);
+      }
+  };
+
+  if (kt_hi > kt_lo) {
+    load_tiles(kt_lo);
+    store_tiles(0, kt_lo);
+    __syncthreads();
+    for (int kt = kt_lo; kt < kt_hi; ++kt) {
+      const int buf = (kt - kt_lo) & 1;
+      if (kt + 1 < kt_hi) load_tiles(kt + 1);
+      compute(kt, buf);
+      if (kt + 1 < kt_hi) store_tiles(buf ^ 1, kt + 1);
+      __syncthreads();
+    }
+  }
+
+  // epilogue: register r of tile (i, c) is C[row = 16 (mt0 + li) + fr, col = 16 (ct0 + c) + fk + 4 r]
+#pragma unroll
+  for (int i = 0; i < TS_WR; ++i) {
+    const int li = wave + 4 * i;
+    if (li >= TR) continue;
+    const int m = 16 * (mt0 + li) + fr;
+#pragma unroll
+    for (int c = 0; c < TS_BT; ++c) {
+      if (c >= TC) continue;
+      if (PASS == 2 && mt0 + li > ct0 + c) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = 16 * (ct0 + c) + fk + 4 * r;
+        if (PASS == 1) {
+          if (m < s && col < s) p.C[j * (long)s * s + (long)col * s + m] = acc[i][c][r];
+        } else {
+          if (m <= col && col < s) {
+            const double v = acc[i][c][r];
+            p.C[j * p.ldc + (long)col * (col + 1) / 2 + m] = (m == col) ? v : v * 1.4142135623730951;   // mat[i, j] * rt2 (arrayutilities.jl:176)
+          }
+        }
+      }
+    }
+  }
+}
+
+bool psd_two_sided_fused_ok(int side) { return side >= 1 && side <= 2048; }
+
+// prod[:, j] = svec(R' smat(arr[:, j]) R), j < ncols.  zws: ncols * side^2 doubles.  arr may alias prod.
+void psd_two_sided_fused(Ctx& c, int side, int ncols, const double* R, int rstruct, const double* arr, long lda, double* prod, long ldp,
+                         double* zws) {
+  if (ncols <= 0) return;
+  TsArgs a{};
+  a.s = side; a.T = (side + 15) / 16; a.rstruct = rstruct; a.R = R; a.ncols = ncols;
+  a.nb = (a.T + TS_BT - 1) / TS_BT;
+  const int grid = ((ncols + 7) / 8) * a.nb * a.nb * 8;
+  a.A = arr; a.lda = lda; a.C = zws; a.ldc = 0;
+  hipLaunchKernelGGL(psd_ts_kernel<1>, dim3(grid), dim3(TS_THREADS), 0, c.stream, a);
+  a.A = zws; a.lda = 0; a.C = prod; a.ldc = ldp;
+  hipLaunchKernelGGL(psd_ts_kernel<2>, dim3(grid), dim3(TS_THREADS), 0, c.stream, a);
+  HYP_CHECK(hipGetLastError());
+}
+
+}  // namespace hyp
