@@ -86,6 +86,16 @@ class Cone:
         self.dual_point[:] = pt
         L.check(L.lib().hyp_cone_load_dual_point(self._h, L.vec_ptr(pt)), "load_dual_point")
 
+    # host mirrors after a device-side load_point / load_dual_point / reset_data (hyp_sys_check_cone_points)
+    def _mirror_loaded(self, point, scal, dual_point):
+        np.multiply(point, scal, out=self.point)
+        self.dual_point[:] = dual_point
+        self._grad_host_valid = False
+        self._reset_host_flags()
+
+    def _reset_host_flags(self):
+        pass
+
     # Cones.jl:185-186
     def reset_data(self):
         if getattr(self, "_h", None) is not None:
@@ -209,6 +219,9 @@ class _GenericHessMixin:
 
     def reset_data(self):
         super().reset_data()
+        self._reset_host_flags()
+
+    def _reset_host_flags(self):
         self._slow = False
         self.use_hess_prod_slow_updated = False
 

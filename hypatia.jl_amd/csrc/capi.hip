@@ -433,6 +433,12 @@ int hyp_sys_get_directions(hyp_sys* sys, double* dir_vec, const double* rhs_vec,
   *res_norm = s->get_directions(dir_vec, rhs_vec, mu, tau, max_ref_steps, res_norm_cutoff, min_impr_tol, n_solves);
   API_END(sys->ctx)
 }
+int hyp_sys_check_cone_points(hyp_sys* sys, const double* cand_ztsk, double min_prox, double prox_bound, int use_max_prox, double nup1,
+                              int* accept, double* prox, int* n_loaded, double* irtmu) {
+  API_BEGIN
+  *accept = sys->s->check_cone_points(cand_ztsk, min_prox, prox_bound, use_max_prox != 0, nup1, prox, n_loaded, irtmu) ? 1 : 0;
+  API_END(sys->ctx)
+}
 int hyp_sys_get_lhs(hyp_sys* sys, double* out) {
   API_BEGIN
   Ctx& c = sys->ctx->c;

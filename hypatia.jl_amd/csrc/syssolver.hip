@@ -341,14 +341,10 @@ SysSolver::Scal SysSolver::apply_lhs(double* res, const double* dir, Scal ds_, d
   dev_axpby(ctx, q, -1.0, dir + os, 1.0, res + oz);
   if (Gx_dir_valid) dev_axpby(ctx, q, -1.0, Gx_dir.d(), 1.0, res + oz);   // G dir.x was just formed by solve_system
   else gemv(ctx, false, q, n, -1.0, G.d(), q, dir, 1.0, res + oz);
-  double* dsc = ctx.dscal.d();
-  dev_dot(ctx, n, mc.d(), dir, dsc);
-  dev_dot(ctx, q, mh.d(), dir + oz, dsc + 1);
   if (p > 0) {
     gemv(ctx, true, p, n, 1.0, mA.d(), p, dir + n, 1.0, res);                  // res.x += A' y
     dev_scale_copy(ctx, p, tau_dir, mb.d(), res + n);                           // res.y = b tau - A x
     gemv(ctx, false, p, n, -1.0, mA.d(), p, dir, 1.0, res + n);
-    dev_dot(ctx, p, mb.d(), dir + n, dsc + 2);
   }
   for (size_t k = 0; k < cones.size(); ++k) {   // res.s_k = H_k prim_dir_k + dual_dir_k
     Cone* ck = cones[k];
@@ -358,12 +354,83 @@ SysSolver::Scal SysSolver::apply_lhs(double* res, const double* dir, Scal ds_, d
     ck->hess_prod_slow(res + os + o, q, prim, q, 1);
     dev_axpby(ctx, dk, 1.0, dual, 1.0, res + os + o);
   }
+  // (the dots come AFTER the cone loop: cone oracles use ctx.dscal for their own scalar read-backs)
+  double* dsc = ctx.dscal.d();
+  dev_dot(ctx, n, mc.d(), dir, dsc);
+  dev_dot(ctx, q, mh.d(), dir + oz, dsc + 1);
+  if (p > 0) dev_dot(ctx, p, mb.d(), dir + n, dsc + 2);
   ctx.d2h(ctx.h_pinned + 8, dsc, 3 * d);
   ctx.sync();
   Scal out;
   out.tau = -ctx.h_pinned[8] - ctx.h_pinned[9] - kap_dir - (p > 0 ? ctx.h_pinned[10] : 0.0);
   out.kap = mu / taubar * tau_dir / taubar + kap_dir;
   return out;
+}
+
+bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_bound, bool use_max_prox, double nup1, double* prox_out,
+                                  int* n_loaded, double* irtmu_out) {
+  const double EPS = 2.220446049250313e-16;
+  *n_loaded = 0;
+  *prox_out = 0.0;
+  *irtmu_out = 0.0;
+  const double* hz = h;
+  const double tau = h[q];
+  const double* hs = h + q + 1;
+  const double kap = h[2 * q + 1];
+  const double proxsqr_bound = prox_bound * prox_bound;
+  const double taukap = tau * kap;
+  if (std::min(std::min(tau, kap), taukap) < EPS) return false;                     // search.jl:86-88
+  const size_t nc = cones.size();
+  std::vector<double> szk(nc);
+  double szsum = 0.0;
+  for (size_t k = 0; k < nc; ++k) {                                                   // :90-95
+    const double* a = hz + offs[k];
+    const double* b = hs + offs[k];
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+    const int dk = cones[k]->dim;
+    int i = 0;
+    for (; i + 3 < dk; i += 4) { d0 += a[i] * b[i]; d1 += a[i + 1] * b[i + 1]; d2 += a[i + 2] * b[i + 2]; d3 += a[i + 3] * b[i + 3]; }
+    for (; i < dk; ++i) d0 += a[i] * b[i];
+    szk[k] = (d0 + d1) + (d2 + d3);
+    if (szk[k] < EPS) return false;
+    szsum += szk[k];
+  }
+  const double mu = (szsum + taukap) / nup1;                                          // :97-100
+  if (mu < EPS) return false;
+  const double taukap_rel = taukap / mu;                                              // :102-108
+  if (taukap_rel < min_prox) return false;
+  const double taukap_proxsqr = (taukap_rel - 1.0) * (taukap_rel - 1.0);
+  if (taukap_proxsqr > proxsqr_bound) return false;
+  for (size_t k = 0; k < nc; ++k) {                                                   // :110-116
+    const double nu_k = cones[k]->nu;
+    const double rel = szk[k] / (mu * nu_k);
+    if (rel < min_prox || nu_k * (rel - 1.0) * (rel - 1.0) > proxsqr_bound) return false;
+  }
+  const double irtmu = 1.0 / std::sqrt(mu);
+  *irtmu_out = irtmu;
+  cand_d.ensure((size_t)(2 * q + 2) * sizeof(double));
+  ctx.h2d(cand_d.p, h, (size_t)(2 * q + 2) * sizeof(double));
+  const double* dz = cand_d.d();
+  const double* dsv = cand_d.d() + q + 1;
+  double agg = taukap_proxsqr;
+  for (size_t k = 0; k < nc; ++k) {                                                   // :118-136
+    Cone* ck = cones[k];
+    const double* prim = ck->use_dual_barrier ? dz + offs[k] : dsv + offs[k];
+    const double* dual = ck->use_dual_barrier ? dsv + offs[k] : dz + offs[k];
+    ck->load_point(prim, irtmu);
+    ck->load_dual_point(dual);
+    ck->reset_data();
+    *n_loaded = (int)k + 1;
+    bool in_prox = false;
+    if (ck->is_feas() && ck->is_dual_feas() && ck->check_numerics()) {
+      const double pk = ck->get_proxsqr(irtmu, use_max_prox);
+      agg = use_max_prox ? std::max(agg, pk) : agg + pk;
+      in_prox = agg < proxsqr_bound;
+    }
+    if (!in_prox) return false;
+  }
+  *prox_out = std::sqrt(agg);
+  return true;
 }
 
 double SysSolver::get_directions(double* h_dir, const double* h_rhs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,

@@ -52,6 +52,12 @@ struct SysSolver {
   struct Scal { double tau, kap; };
   Scal solve_system(double* d_sol, const double* d_rhs, Scal rhs, double mu, double taubar);   // common.jl:129-182
   Scal apply_lhs(double* d_res, const double* d_dir, Scal dir, double mu, double taubar);      // common.jl:79-121
+  // line-search acceptance test of one candidate (search.jl:74-138) for all cones in one call: cand = host
+  // [z(q); tau; s(q); kap].  Cones are visited in order and the first failure stops the sweep, exactly as the
+  // reference's loop; n_loaded = number of cones whose points were (re)loaded.
+  DBuf cand_d;
+  bool check_cone_points(const double* h_ztsk, double min_prox, double prox_bound, bool use_max_prox, double nup1, double* prox_out,
+                         int* n_loaded, double* irtmu_out);
   // returns res_norm; dir / rhs are HOST Point vectors (common.jl:15-76)
   double get_directions(double* h_dir, const double* h_rhs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
                         double min_impr_tol, int* n_solves);

@@ -12,6 +12,7 @@ replaced.  This mirror follows the reference call for call:
 Every product with the constraint matrix G goes through the system solver's device-resident copy
 (`syssolver.mul_G`); cone oracles and the KKT solves are C-ABI calls.  Nothing here imports `oracle/`.
 """
+import os
 import time
 
 import numpy as np
@@ -30,7 +31,7 @@ except Exception:   # pragma: no cover
 
 
 class _blas_limit:
-    def __init__(self, n=4):
+    def __init__(self, n=int(os.environ.get("HYP_HOST_BLAS_THREADS", "1"))):
         self.n = n
         self.cm = None
 
@@ -286,6 +287,9 @@ def search_alpha(point, model, stepper, sched=None):   # search.jl:46-69
 def check_cone_points(model, stepper):   # search.jl:74-138
     searcher = stepper.searcher
     cand = stepper.temp
+    sysv = getattr(stepper, "syssolver", None)
+    if sysv is not None and getattr(sysv, "native_directions", False):   # one C-ABI call for the whole test
+        return sysv.check_cone_points_native(model, cand, searcher)
     szk = searcher.szk
     cones = model.cones
     min_prox = searcher.min_prox
@@ -354,6 +358,7 @@ class CombinedStepper:
         self.dir_temp = np.zeros(self.rhs.vec.shape[0])
         self.searcher = StepSearcher(model, **self.searcher_options)
         self.unadj_only = self.cent_only = False
+        self.syssolver = solver.syssolver
         return self
 
     def step(self, solver):   # :53-120

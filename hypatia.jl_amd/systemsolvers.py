@@ -119,6 +119,19 @@ class QRCholDenseSystemSolver:
         self.solve_subsystem3(solver, self.sol_const, self.rhs_const)
         return self
 
+    # ---- search.jl:74-138 for all cones in one call; keeps the host mirrors of the reloaded cones in step
+    def check_cone_points_native(self, model, cand, searcher):
+        acc, nl = c_int(0), c_int(0)
+        prox, irtmu = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        L.check(L.lib().hyp_sys_check_cone_points(self._h, L.vec_ptr(cand.ztsk), float(searcher.min_prox), float(searcher.prox_bound),
+                                                  int(bool(searcher.use_max_prox)), float(searcher.nup1), ctypes.byref(acc),
+                                                  ctypes.byref(prox), ctypes.byref(nl), ctypes.byref(irtmu)), "hyp_sys_check_cone_points")
+        for k in range(nl.value):
+            model.cones[k]._mirror_loaded(cand.primal_views[k], irtmu.value, cand.dual_views[k])
+        if acc.value:
+            searcher.prox = prox.value
+        return bool(acc.value)
+
     # ---- common.jl:15-76 on the device
     def get_directions_native(self, solver, dir, rhs, min_impr_tol=0.5):
         res_norm, ns = ctypes.c_double(0.0), c_int(0)

@@ -121,6 +121,13 @@ int hyp_sys_update_lhs(hyp_sys* sys, int* use_sqrt_hess_cones_out, int* info, in
  * tau = solver.point.tau[]; res_norm_cutoff / min_impr_tol as in common.jl:15-20; n_solves counts solve_system calls */
 int hyp_sys_get_directions(hyp_sys* sys, double* dir_vec, const double* rhs_vec, double mu, double tau, int max_ref_steps,
                            double res_norm_cutoff, double min_impr_tol, double* res_norm, int* n_solves);
+/* check_cone_points (steppers/search.jl:74-138) for one line-search candidate, all cones in one call:
+ * cand_ztsk = [z(q); tau; s(q); kap] (the `ztsk` view of the candidate Point); min_prox / prox_bound /
+ * use_max_prox / nup1 are the StepSearcher fields (search.jl:8-39).  accept = the function's Bool; prox =
+ * searcher.prox on acceptance; n_loaded = number of leading cones whose point / dual_point were reloaded
+ * (scaled by irtmu) before the sweep stopped -- the host mirrors of exactly those cones must follow. */
+int hyp_sys_check_cone_points(hyp_sys* sys, const double* cand_ztsk, double min_prox, double prox_bound, int use_max_prox, double nup1,
+                              int* accept, double* prox, int* n_loaded, double* irtmu);
 int hyp_sys_get_lhs(hyp_sys* sys, double* out_nmpxnmp);        /* upper triangle meaningful (tests) */
 
 /* ---- dense kernels exposed for parity tests and micro-benchmarks ------------------------------- */

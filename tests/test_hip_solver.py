@@ -150,8 +150,13 @@ def test_device_get_directions_matches_host_composition_and_oracle(name, reduce)
     for upd, oupd in ((HS.update_rhs_cent, OS.update_rhs_cent), (HS.update_rhs_pred, OS.update_rhs_pred)):
         upd(hs, st.rhs)
         sysv.native_directions = True
+        hs.worst_dir_res = 0.0
         HS.get_directions(st, hs)
         d_dev = st.dir.vec.copy()
+        res_dev = hs.worst_dir_res          # the residual the device routine reports (drives its refinement)
+        HS.apply_lhs(st, hs)
+        res_true = np.max(np.abs(st.temp.vec - st.rhs.vec))
+        assert res_dev <= 10 * res_true + 1e-13 * (1 + np.max(np.abs(st.rhs.vec))), (name, res_dev, res_true)
         sysv.native_directions = False
         HS.get_directions(st, hs)
         d_host = st.dir.vec.copy()
