@@ -60,6 +60,8 @@ struct GemmArgs {
   int tag;         // 1 = the Schur-complement syrk (own kernel symbol, so profiles can tell it apart)
   // split-K (set by the launcher): blockIdx.z = slice; slices write raw partial sums to `part`
   // (slice-major copies of C's layout, ldc = part_ld) and a second kernel adds them in slice order
+  int tri_off;     // upper forms keep elements with row <= col + tri_off (0 except for off-diagonal strips)
+  int splitk_req;  // requested split-K slices (0 / 1: the launcher decides)
   int splitk; int kchunk; double* part; long part_ld; long part_stride;
   int vec2;        // set by the launcher: operands are 16-byte aligned with even leading dimensions
   const int* tile_map;   // optional (tm, tn) per blockIdx.x: XCD-aware tile order (set by the launcher)

@@ -46,7 +46,7 @@ void gemm_f64_kernel(GemmArgs p) {
     tn = blockIdx.x / p.tiles_m;
   }
   const int m0 = tm * BM, n0 = tn * BN;
-  if (p.tri == GEMM_UPPER_RECT && m0 > n0 + BN - 1) return;
+  if (p.tri == GEMM_UPPER_RECT && m0 > n0 + BN - 1 + p.tri_off) return;
 
   const double* __restrict__ A = p.A + (long)bz * p.strideA;
   const double* __restrict__ B = p.B + (long)bz * p.strideB;
@@ -218,7 +218,7 @@ void gemm_f64_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < TW; ++i) {
           const int m = m0 + wm * WT + i * 16 + fr;
-          if (m >= p.M || (upper && m > n)) continue;
+          if (m >= p.M || (upper && m > n + p.tri_off)) continue;
           W[(long)n * p.part_ld + m] = acc[j][i][r];
         }
       }
@@ -251,7 +251,7 @@ void gemm_f64_kernel(GemmArgs p) {
           double v = p.alpha * acc[j][i][r];
           if (p.epi == 1) v = v * v;
           v += p.beta * cold[r][i];
-          if (n < p.N && m < p.M && !(upper && m > n)) C[(long)n * p.ldc + m] = v;
+          if (n < p.N && m < p.M && !(upper && m > n + p.tri_off)) C[(long)n * p.ldc + m] = v;
         }
       }
     }
@@ -267,7 +267,7 @@ void gemm_f64_kernel(GemmArgs p) {
       for (int i = 0; i < TW; ++i) {
         const int m = m0 + wm * WT + i * 16 + fr;
         if (m >= p.M) continue;
-        if (upper && m > n) continue;
+        if (upper && m > n + p.tri_off) continue;
         const long moff = p.cm_blk ? (long)(m / p.cm_blk) * p.cm_stride + (m % p.cm_blk) : (long)m;
         double* cp = C + (long)n * p.ldc + moff;
         double v = p.alpha * acc[j][i][r];
@@ -280,11 +280,11 @@ void gemm_f64_kernel(GemmArgs p) {
 }
 
 // C = alpha * (sum of the split-K slices, in slice order) + beta * C
-__global__ void splitk_reduce_kernel(int M, int N, int upper, int S, const double* __restrict__ part, long part_ld, long part_stride,
+__global__ void splitk_reduce_kernel(int M, int N, int upper, int tri_off, int S, const double* __restrict__ part, long part_ld, long part_stride,
                                      double alpha, double beta, double* __restrict__ C, long ldc) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = blockIdx.y;
-  if (m >= M || (upper && m > n)) return;
+  if (m >= M || (upper && m > n + tri_off)) return;
   double s = 0.0;
   for (int z = 0; z < S; ++z) s += part[(long)z * part_stride + (long)n * part_ld + m];
   double* cp = C + (long)n * ldc + m;
@@ -330,6 +330,24 @@ static const int* upper_tile_map(int T, long nblk) {
 
 hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a) {
   if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return hipSuccess;
+  // Schur syrk with a thin last tile column (n = 5000 = 39 x 128 + 8): the 128-wide edge workgroup tiles
+  // would do full work for r / 128 useful output (10 % of all tiles at n = 5000).  The r <= 32 edge
+  // columns are computed separately as a skinny product with 64-wide tiles and deeper split-K.
+  if (a.tag == 1 && transa && a.tri == GEMM_UPPER && a.A == a.B && a.lda == a.ldb && a.batch == 1 && a.epi == 0 &&
+      a.krange == KR_ALL && a.M == a.N && a.N >= 1024 && a.N % 128 != 0 && a.N % 128 <= 32 && a.K >= 4096) {
+    const int r = a.N % 128, N0 = a.N - r;
+    GemmArgs m = a;
+    m.M = m.N = N0;
+    hipError_t e = gemm_f64_launch(st, transa, m);
+    if (e != hipSuccess) return e;
+    GemmArgs s = a;                      // C[0:N, N0:N], rows <= columns
+    s.tag = 0; s.M = a.N; s.N = r;
+    s.B = a.A + (long)N0 * a.lda;
+    s.C = a.C + (long)N0 * a.ldc;
+    s.tri = GEMM_UPPER_RECT; s.tri_off = N0;
+    s.tile_hint = 64; s.splitk_req = 8;
+    return gemm_f64_launch(st, transa, s);
+  }
   // tile choice: the 128 x 128 tile unless the product is too small to fill the chip with it
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
   const bool small = (a.tile_hint == 64) || (a.tile_hint == 0 && t128 < 192);
@@ -354,6 +372,7 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a) {
       if (rounds < best - 1e-9) { best = rounds; a.splitk = S; }
     }
   }
+  if (a.splitk_req > 1 && a.batch == 1 && a.epi == 0 && a.krange == KR_ALL && a.cm_blk == 0 && a.K / a.splitk_req >= 256) a.splitk = a.splitk_req;
   if (a.splitk > 1) {
     a.kchunk = (((a.K + a.splitk - 1) / a.splitk) + BK - 1) / BK * BK;
     a.part_ld = a.M;
@@ -382,7 +401,7 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a) {
     else hipLaunchKernelGGL((gemm_f64_kernel<false, 4, 0>), grid, dim3(GEMM_THREADS), 0, st, a);
   }
   if (a.splitk > 1)
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((a.M + 255) / 256, a.N), dim3(256), 0, st, a.M, a.N, a.tri == GEMM_UPPER ? 1 : 0, a.splitk,
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((a.M + 255) / 256, a.N), dim3(256), 0, st, a.M, a.N, a.tri != GEMM_FULL ? 1 : 0, a.tri_off, a.splitk,
                        a.part, a.part_ld, a.part_stride, a.alpha, a.beta, a.C, a.ldc);
   return hipGetLastError();
 }

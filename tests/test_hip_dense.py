@@ -110,7 +110,7 @@ def test_gemv(hip, trans, m, n):
     assert np.allclose(y, ref, rtol=1e-12, atol=1e-11)
 
 
-@pytest.mark.parametrize("N,K", [(300, 5000), (130, 4100), (257, 900)])
+@pytest.mark.parametrize("N,K", [(300, 5000), (130, 4100), (257, 900), (1032, 4500), (1300, 4100)])
 def test_syrk_schur_path_with_splitk(hip, N, K):
     """the Schur-assembly syrk (split-K slices + ordered reduction when K is long)"""
     lib, ctx, L = hip
