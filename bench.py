@@ -96,6 +96,9 @@ def main_multi(args, world, rank, local_rank):
         if not solver.iterate():
             solver.reset_iterate()
 
+    from hypatia_jl_amd.solvers import _blas_limit
+    blas_cap = _blas_limit()     # (iterate() alone re-enters the host BLAS cap per call; hold it across the run)
+    blas_cap.__enter__()
     for _ in range(args.warmup):
         step()
     lib.hyp_reset_timers(ctx)
@@ -172,6 +175,9 @@ def main():
         if not solver.iterate():
             solver.reset_iterate()
 
+    from hypatia_jl_amd.solvers import _blas_limit
+    blas_cap = _blas_limit()     # (iterate() alone re-enters the host BLAS cap per call; hold it across the run)
+    blas_cap.__enter__()
     for _ in range(args.warmup):
         step()
     lib.hyp_reset_timers(ctx)

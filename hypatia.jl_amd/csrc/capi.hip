@@ -433,6 +433,14 @@ int hyp_sys_get_directions(hyp_sys* sys, double* dir_vec, const double* rhs_vec,
   *res_norm = s->get_directions(dir_vec, rhs_vec, mu, tau, max_ref_steps, res_norm_cutoff, min_impr_tol, n_solves);
   API_END(sys->ctx)
 }
+int hyp_sys_get_directions2(hyp_sys* sys, double* dir_vecs, const double* rhs_vecs, double mu, double tau, int max_ref_steps,
+                            double res_norm_cutoff, double min_impr_tol, double* res_norms, int* n_solves) {
+  API_BEGIN
+  SysSolver* s = sys->s;
+  HYP_REQUIRE(s->nmp == 0 || s->fact_ok, "get_directions2: no valid factorization (call hyp_sys_update_lhs)");
+  s->get_directions2(dir_vecs, rhs_vecs, mu, tau, max_ref_steps, res_norm_cutoff, min_impr_tol, res_norms, n_solves);
+  API_END(sys->ctx)
+}
 int hyp_sys_check_cone_points(hyp_sys* sys, const double* cand_ztsk, double min_prox, double prox_bound, int use_max_prox, double nup1,
                               int* accept, double* prox, int* n_loaded, double* irtmu) {
   API_BEGIN

@@ -1,0 +1,360 @@
+// Two stepper directions per pass.  CombinedStepper (/root/reference/src/Solvers/steppers/combined.jl:53-95)
+// asks for four directions per iteration; (cent, pred) do not depend on each other and neither do
+// (centadj, predadj), so each pair is solved together: the products with G (804 MB at config 2), the
+// triangular solves with the 100 MB factor and the cone Hessian products are each ONE pass that serves
+// both right-hand sides.  Arithmetic per column is the reference's (systemsolvers/common.jl:15-182,
+// qrchol.jl:16-98); a column whose residual calls for refinement continues alone through the
+// single-right-hand-side routines of syssolver.hip.
+#include "syssolver.hpp"
+
+namespace hyp {
+
+constexpr int MR = 2;   // right-hand sides per pass
+
+// ---- Y[:, r] = alpha A' X[:, r] + beta Y[:, r]: one workgroup per column of A, A read once --------------
+template <int NR>
+__global__ __launch_bounds__(256) void gemv_t_multi_kernel(int m, double alpha, const double* __restrict__ A, long lda,
+                                                           const double* __restrict__ X, long ldx, double beta, double* __restrict__ Y,
+                                                           long ldy) {
+  __shared__ double red[NR][4];
+  const int col = blockIdx.x;
+  const double* a = A + (long)col * lda;
+  double s[NR][2];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) s[r][0] = s[r][1] = 0.0;
+  int i = threadIdx.x;
+  for (; i + 256 < m; i += 512) {
+    const double a0 = a[i], a1 = a[i + 256];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      s[r][0] += a0 * X[(long)r * ldx + i];
+      s[r][1] += a1 * X[(long)r * ldx + i + 256];
+    }
+  }
+  for (; i < m; i += 256) {
+    const double a0 = a[i];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) s[r][0] += a0 * X[(long)r * ldx + i];
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    double t = s[r][0] + s[r][1];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+    if ((threadIdx.x & 63) == 0) red[r][threadIdx.x >> 6] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < NR) {
+    const int r = threadIdx.x;
+    const double t = (red[r][0] + red[r][1]) + (red[r][2] + red[r][3]);
+    double* y = Y + (long)r * ldy + col;
+    *y = alpha * t + (beta != 0.0 ? beta * (*y) : 0.0);
+  }
+}
+
+// ---- Y[:, r] = alpha A X[:, r] + beta Y[:, r]: partial sums over 256-column chunks, then an ordered reduce
+constexpr int GM_CHUNK = 256;
+template <int NR>
+__global__ __launch_bounds__(256) void gemv_n_multi_partial_kernel(int m, int n, const double* __restrict__ A, long lda,
+                                                                   const double* __restrict__ X, long ldx, double* __restrict__ partial) {
+  __shared__ double xs[NR][GM_CHUNK];
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  const int c0 = blockIdx.y * GM_CHUNK;
+  const int nc = min(GM_CHUNK, n - c0);
+#pragma unroll
+  for (int r = 0; r < NR; ++r) xs[r][threadIdx.x] = (threadIdx.x < nc) ? X[(long)r * ldx + c0 + threadIdx.x] : 0.0;
+  __syncthreads();
+  if (row >= m) return;
+  const double* a = A + (long)c0 * lda + row;
+  double s[NR][2];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) s[r][0] = s[r][1] = 0.0;
+  int c = 0;
+  for (; c + 1 < nc; c += 2) {
+    const double a0 = a[(long)c * lda], a1 = a[(long)(c + 1) * lda];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      s[r][0] += a0 * xs[r][c];
+      s[r][1] += a1 * xs[r][c + 1];
+    }
+  }
+  if (c < nc) {
+    const double a0 = a[(long)c * lda];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) s[r][0] += a0 * xs[r][c];
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) partial[((long)blockIdx.y * NR + r) * m + row] = s[r][0] + s[r][1];
+}
+template <int NR>
+__global__ void gemv_n_multi_reduce_kernel(int m, int nchunks, double alpha, const double* __restrict__ partial, double beta,
+                                           double* __restrict__ Y, long ldy) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (row >= m) return;
+  double s = 0.0;
+  for (int k = 0; k < nchunks; ++k) s += partial[((long)k * NR + r) * m + row];
+  double* y = Y + (long)r * ldy + row;
+  *y = alpha * s + (beta != 0.0 ? beta * (*y) : 0.0);
+}
+
+void gemv_multi(Ctx& c, bool trans, int m, int n, int nr, double alpha, const double* A, long lda, const double* X, long ldx, double beta,
+                double* Y, long ldy) {
+  if (nr == 1) {
+    gemv(c, trans, m, n, alpha, A, lda, X, beta, Y);
+    return;
+  }
+  HYP_REQUIRE(nr == MR, "gemv_multi: 1 or 2 right-hand sides");
+  if (trans) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL((gemv_t_multi_kernel<MR>), dim3(n), dim3(256), 0, c.stream, m, alpha, A, lda, X, ldx, beta, Y, ldy);
+  } else {
+    if (m <= 0) return;
+    const int nchunks = (n + GM_CHUNK - 1) / GM_CHUNK;
+    c.scratch.ensure(std::max<size_t>((size_t)nchunks * MR * m * sizeof(double), 4096));
+    if (nchunks > 0)
+      hipLaunchKernelGGL((gemv_n_multi_partial_kernel<MR>), dim3((m + 255) / 256, nchunks), dim3(256), 0, c.stream, m, n, A, lda, X, ldx,
+                         c.scratch.d());
+    hipLaunchKernelGGL((gemv_n_multi_reduce_kernel<MR>), dim3((m + 255) / 256, MR), dim3(256), 0, c.stream, m, nchunks, alpha, c.scratch.d(),
+                       beta, Y, ldy);
+  }
+  HYP_CHECK(hipGetLastError());
+}
+
+// ---- super-block triangular solves with two right-hand sides (see TriSolvePlan in dense.hip) -------------
+// out[j, r] = base[j, r] + alpha sum_{i in rows(j)} M[i, j] v[i, r]; M is read once for both columns
+__global__ __launch_bounds__(256) void coldot2_kernel(int m, int ncols, int mode, const double* __restrict__ M, long ld,
+                                                      const double* __restrict__ v, long ldv, const double* base, long ldb, double alpha,
+                                                      double* out, long ldo) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= ncols) return;
+  const int lane = threadIdx.x & 63;
+  int i0 = 0, i1 = m;
+  if (mode == 1) i1 = min(j + 1, m);
+  else if (mode == 2) i0 = min(j, m);
+  const double* a = M + (long)j * ld;
+  double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
+  int i = i0 + lane;
+  for (; i + 64 < i1; i += 128) {
+    const double a0 = a[i], a1 = a[i + 64];
+    s0 += a0 * v[i];
+    s1 += a1 * v[i + 64];
+    t0 += a0 * v[ldv + i];
+    t1 += a1 * v[ldv + i + 64];
+  }
+  if (i < i1) {
+    const double a0 = a[i];
+    s0 += a0 * v[i];
+    t0 += a0 * v[ldv + i];
+  }
+  double s = s0 + s1, t = t0 + t1;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_down(s, off);
+    t += __shfl_down(t, off);
+  }
+  if (lane == 0) {
+    out[j] = (base ? base[j] : 0.0) + alpha * s;
+    out[ldo + j] = (base ? base[ldb + j] : 0.0) + alpha * t;
+  }
+}
+static void coldot2(Ctx& c, int m, int ncols, int mode, const double* M, long ld, const double* v, long ldv, const double* base, long ldb,
+                    double alpha, double* out, long ldo) {
+  if (ncols <= 0) return;
+  hipLaunchKernelGGL(coldot2_kernel, dim3((ncols + 3) / 4), dim3(256), 0, c.stream, m, ncols, mode, M, ld, v, ldv, base, ldb, alpha, out, ldo);
+}
+
+void TriSolvePlan::solve_multi(Ctx& c, const double* U, long ldu, bool trans, double* x, long ldx, int nr) {
+  if (nr == 1) {
+    solve(c, U, ldu, trans, x);
+    return;
+  }
+  HYP_REQUIRE(nr == MR, "TriSolvePlan: 1 or 2 right-hand sides");
+  const int nsb = (n + sb - 1) / sb;
+  const size_t blk = (size_t)sb * sb;
+  work.ensure((size_t)2 * MR * sb * sizeof(double));
+  double* t = work.d();               // [sb x 2]
+  double* e = work.d() + MR * sb;     // [sb x 2]
+  for (int s = 0; s < nsb; ++s) {
+    const int b = trans ? s : nsb - 1 - s;
+    const int r0 = b * sb, m = std::min(sb, n - r0);
+    double* xb = x + r0;
+    const double* Dm = trans ? U + (long)r0 * ldu + r0 : UT.d() + (long)r0 * n + r0;
+    const long ldd = trans ? ldu : n;
+    const double* Bm = (trans ? Binv.d() : BinvT.d()) + b * blk;
+    const int mode = trans ? 1 : 2;
+    coldot2(c, m, m, mode, Bm, sb, xb, ldx, nullptr, 0, 1.0, t, sb);                 // t = B x_b
+    for (int it = 0; it < refine; ++it) {
+      coldot2(c, m, m, mode, Dm, ldd, t, sb, xb, ldx, -1.0, e, sb);                   // e = x_b - T t
+      const bool last = (it + 1 == refine);
+      coldot2(c, m, m, mode, Bm, sb, e, sb, t, sb, 1.0, last ? xb : t, last ? ldx : sb);   // t += B e
+    }
+    if (refine == 0) {
+      HYP_CHECK(hipMemcpy2DAsync(xb, ldx * sizeof(double), t, sb * sizeof(double), m * sizeof(double), MR, hipMemcpyDeviceToDevice, c.stream));
+    }
+    if (trans) {
+      const int rest = n - (r0 + m);
+      coldot2(c, m, rest, 0, U + (long)(r0 + m) * ldu + r0, ldu, xb, ldx, x + r0 + m, ldx, -1.0, x + r0 + m, ldx);
+    } else {
+      coldot2(c, m, r0, 0, UT.d() + r0, n, xb, ldx, x, ldx, -1.0, x, ldx);
+    }
+  }
+  HYP_CHECK(hipGetLastError());
+}
+
+// ---- solve_subsystem3 for nr columns (qrchol.jl:39-85 with p = 0: Q = I) --------------------------------
+void SysSolver::solve3_multi(double* sol, const double* rhs, int nr) {
+  const size_t d = sizeof(double);
+  const long ld3 = n + q;
+  HYP_REQUIRE(p == 0, "solve3_multi: p = 0 only");
+  if (sol != rhs) ctx.d2d(sol, rhs, (size_t)nr * ld3 * d);
+  // x <- lhs^-1 (x + G' z)
+  gemv_multi(ctx, true, q, n, nr, 1.0, G.d(), q, sol + n, ld3, 1.0, sol, ld3);
+  if (tri.ready(nmp)) {
+    tri.solve_multi(ctx, lhs_fact.d(), nmp, true, sol, ld3, nr);
+    tri.solve_multi(ctx, lhs_fact.d(), nmp, false, sol, ld3, nr);
+  } else {
+    for (int r = 0; r < nr; ++r) tri_solves(sol + r * ld3);
+  }
+  // z <- H (G x) - z
+  gemv_multi(ctx, false, q, n, nr, 1.0, G.d(), q, sol, ld3, 0.0, m_Gx.d(), q);
+  for (size_t k = 0; k < cones.size(); ++k) {
+    Cone* ck = cones[k];
+    if (ck->use_dual_barrier) ck->inv_hess_prod(m_HGx.d() + offs[k], q, m_Gx.d() + offs[k], q, nr);
+    else ck->hess_prod(m_HGx.d() + offs[k], q, m_Gx.d() + offs[k], q, nr);
+  }
+  for (int r = 0; r < nr; ++r) dev_axpby(ctx, q, 1.0, m_HGx.d() + (long)r * q, -1.0, sol + r * ld3 + n);
+}
+
+void SysSolver::get_directions2(double* h_dirs, const double* h_rhss, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
+                                double min_impr_tol, double* res_norms, int* n_solves) {
+  HYP_REQUIRE(model_loaded, "sys: load_model first");
+  const size_t d = sizeof(double);
+  const int dv = dimv(), it = n + p + q, ik = dv - 1;
+  *n_solves = 0;
+  if (p > 0) {   // (equalities kept: the pair goes through the single-column routine)
+    for (int r = 0; r < MR; ++r) {
+      int ns = 0;
+      res_norms[r] = get_directions(h_dirs + (long)r * dv, h_rhss + (long)r * dv, mu, taubar, max_ref_steps, res_norm_cutoff, min_impr_tol, &ns);
+      *n_solves += ns;
+    }
+    return;
+  }
+  const int oz = n, os = n + q + 1;
+  const long ld3 = n + q;
+  for (DBuf* b : {&m_rhs, &m_dir, &m_res}) b->ensure((size_t)MR * dv * d);
+  for (DBuf* b : {&m_subr, &m_subs}) b->ensure((size_t)MR * ld3 * d);
+  for (DBuf* b : {&m_Gx, &m_HGx, &m_Gxd}) b->ensure((size_t)MR * q * d);
+  double* rhs = m_rhs.d();
+  double* dir = m_dir.d();
+  double* res = m_res.d();
+  double* sr = m_subr.d();
+  double* ss = m_subs.d();
+  ctx.h2d(rhs, h_rhss, (size_t)MR * dv * d);
+  Scal rs[MR], dsc[MR], rsc[MR];
+  for (int r = 0; r < MR; ++r) {
+    ctx.zero(rhs + (long)r * dv + it, d);
+    ctx.zero(rhs + (long)r * dv + ik, d);
+    ctx.zero(dir + (long)r * dv + it, d);
+    ctx.zero(dir + (long)r * dv + ik, d);
+    ctx.zero(res + (long)r * dv + it, d);
+    ctx.zero(res + (long)r * dv + ik, d);
+    rs[r] = Scal{h_rhss[(long)r * dv + it], h_rhss[(long)r * dv + ik]};
+  }
+
+  // ---- solve_system for both columns (common.jl:129-182, qrchol.jl:16-37)
+  for (int r = 0; r < MR; ++r) ctx.d2d(sr + r * ld3, rhs + (long)r * dv, (size_t)n * d);
+  for (size_t k = 0; k < cones.size(); ++k) {
+    Cone* ck = cones[k];
+    const int o = offs[k], dk = ck->dim;
+    if (ck->use_dual_barrier) {
+      for (int r = 0; r < MR; ++r) {
+        double* tmp = ss + r * ld3 + oz + o;
+        dev_scale_copy(ctx, dk, -1.0, rhs + (long)r * dv + oz + o, tmp);
+        dev_axpby(ctx, dk, -1.0, rhs + (long)r * dv + os + o, 1.0, tmp);
+      }
+      ck->inv_hess_prod(sr + oz + o, ld3, ss + oz + o, ld3, MR);
+    } else {
+      ck->hess_prod(sr + oz + o, ld3, rhs + oz + o, dv, MR);
+      for (int r = 0; r < MR; ++r) dev_axpby(ctx, dk, -1.0, rhs + (long)r * dv + os + o, -1.0, sr + r * ld3 + oz + o);
+    }
+  }
+  solve3_multi(ss, sr, MR);
+  double* ds = ctx.dscal.d();
+  for (int r = 0; r < MR; ++r) {
+    dev_dot(ctx, n, mc.d(), ss + r * ld3, ds + 2 * r);
+    dev_dot(ctx, q, mh.d(), ss + r * ld3 + oz, ds + 2 * r + 1);
+  }
+  ctx.d2h(ctx.h_pinned, ds, 2 * MR * d);
+  ctx.sync();
+  for (int r = 0; r < MR; ++r) {
+    const double dot_sub = ctx.h_pinned[2 * r] + ctx.h_pinned[2 * r + 1];
+    const double sol_tau = (rs[r].tau + rs[r].kap + dot_sub) / (mu / taubar / taubar - dot_const);
+    double* sol = dir + (long)r * dv;
+    ctx.d2d(sol, ss + r * ld3, (size_t)ld3 * d);
+    dev_axpby(ctx, (int)ld3, sol_tau, sol_const.d(), 1.0, sol);
+    dsc[r].tau = sol_tau;
+    dsc[r].kap = -mu / taubar / taubar * sol_tau + rs[r].kap;
+  }
+  // sol.s = h tau - rhs.z - G sol.x  (G sol.x from the rounded sol.x, see solve_system; kept for the residual)
+  gemv_multi(ctx, false, q, n, MR, 1.0, G.d(), q, dir, dv, 0.0, m_Gxd.d(), q);
+  for (int r = 0; r < MR; ++r) {
+    double* sol = dir + (long)r * dv;
+    dev_scale_copy(ctx, q, dsc[r].tau, mh.d(), sol + os);
+    dev_axpby(ctx, q, -1.0, rhs + (long)r * dv + oz, 1.0, sol + os);
+    dev_axpby(ctx, q, -1.0, m_Gxd.d() + (long)r * q, 1.0, sol + os);
+  }
+  *n_solves += MR;
+  for (int r = 0; r < MR; ++r) res_norms[r] = 0.0;
+
+  if (max_ref_steps > 0) {
+    // ---- residual of both columns (apply_lhs, common.jl:79-121)
+    for (int r = 0; r < MR; ++r) {
+      double* rr = res + (long)r * dv;
+      dev_scale_copy(ctx, n, dsc[r].tau, mc.d(), rr);                                   // res.x = c tau (+ G' z below)
+      dev_scale_copy(ctx, q, dsc[r].tau, mh.d(), rr + oz);                              // res.z = h tau - s - G x
+      dev_axpby(ctx, q, -1.0, dir + (long)r * dv + os, 1.0, rr + oz);
+      dev_axpby(ctx, q, -1.0, m_Gxd.d() + (long)r * q, 1.0, rr + oz);
+    }
+    gemv_multi(ctx, true, q, n, MR, 1.0, G.d(), q, dir + oz, dv, 1.0, res, dv);
+    for (size_t k = 0; k < cones.size(); ++k) {   // res.s_k = H_k prim_dir_k + dual_dir_k
+      Cone* ck = cones[k];
+      const int o = offs[k], dk = ck->dim;
+      const int po = ck->use_dual_barrier ? oz + o : os + o, du = ck->use_dual_barrier ? os + o : oz + o;
+      ck->hess_prod_slow(res + os + o, dv, dir + po, dv, MR);
+      for (int r = 0; r < MR; ++r) dev_axpby(ctx, dk, 1.0, dir + (long)r * dv + du, 1.0, res + (long)r * dv + os + o);
+    }
+    for (int r = 0; r < MR; ++r) {
+      dev_dot(ctx, n, mc.d(), dir + (long)r * dv, ds + 2 * r);
+      dev_dot(ctx, q, mh.d(), dir + (long)r * dv + oz, ds + 2 * r + 1);
+      dev_sub_absmax(ctx, dv, res + (long)r * dv, rhs + (long)r * dv, ds + 8 + r);
+    }
+    ctx.d2h(ctx.h_pinned, ds, 16 * d);
+    ctx.sync();
+    for (int r = 0; r < MR; ++r) {
+      rsc[r].tau = -ctx.h_pinned[2 * r] - ctx.h_pinned[2 * r + 1] - dsc[r].kap - rs[r].tau;
+      rsc[r].kap = mu / taubar * dsc[r].tau / taubar + dsc[r].kap - rs[r].kap;
+      const double m = ctx.h_pinned[8 + r];
+      res_norms[r] = (m != m || rsc[r].tau != rsc[r].tau || rsc[r].kap != rsc[r].kap)
+                         ? __builtin_nan("")
+                         : std::max(m, std::max(std::fabs(rsc[r].tau), std::fabs(rsc[r].kap)));
+    }
+    // ---- a column that needs refinement continues alone (single-column routines)
+    Gx_dir_valid = false;
+    for (int r = 0; r < MR; ++r) {
+      if (!(res_norms[r] > res_norm_cutoff)) continue;
+      double* tmp = v_tmp.d();
+      ctx.d2d(tmp, dir + (long)r * dv, (size_t)dv * d);
+      res_norms[r] = refine(rhs + (long)r * dv, dir + (long)r * dv, res + (long)r * dv, tmp, rs[r], dsc[r], rsc[r], res_norms[r], mu, taubar,
+                            max_ref_steps, res_norm_cutoff, min_impr_tol, n_solves);
+    }
+  }
+  ctx.d2h(h_dirs, dir, (size_t)MR * dv * d);
+  ctx.sync();
+  for (int r = 0; r < MR; ++r) {
+    h_dirs[(long)r * dv + it] = dsc[r].tau;
+    h_dirs[(long)r * dv + ik] = dsc[r].kap;
+  }
+}
+
+}  // namespace hyp

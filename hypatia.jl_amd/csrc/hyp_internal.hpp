@@ -126,7 +126,11 @@ struct TriSolvePlan {
   void invalidate() { n = 0; }
   void build(Ctx& c, int n_, const double* U, long ldu, const double* dinv);
   void solve(Ctx& c, const double* U, long ldu, bool trans, double* x);
+  void solve_multi(Ctx& c, const double* U, long ldu, bool trans, double* x, long ldx, int nr);   // nr <= 2 right-hand sides
 };
+// Y[:, r] = alpha op(A) X[:, r] + beta Y[:, r] for r < nr <= 2: one pass over A serves all right-hand sides
+void gemv_multi(Ctx& c, bool trans, int m, int n, int nr, double alpha, const double* A, long lda, const double* X, long ldx, double beta,
+                double* Y, long ldy);
 // explicit inverse of an upper triangular matrix from its inverted diagonal blocks: Uinv (upper, full
 // storage, strictly-lower part zero).  Used for the small cone matrices.
 void trtri_upper_batched(Ctx& c, int n, const double* U, long ldu, long strideU, const double* dinv, long strideD,

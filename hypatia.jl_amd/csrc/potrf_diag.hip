@@ -65,6 +65,7 @@ void potrf_diag_kernel_t(double* __restrict__ A, long lda, long strideA, int n, 
   // ---- factorization: right-looking, one barrier per column
 #pragma unroll
   for (int r0 = 0; r0 < 8; ++r0) {
+    if (16 * r0 >= nb) break;   // (a short last block: the identity padding needs no elimination steps)
 #pragma unroll 1
     for (int jj = 0; jj < 16; ++jj) {
       const int j = 16 * r0 + jj;
@@ -110,6 +111,7 @@ void potrf_diag_kernel_t(double* __restrict__ A, long lda, long strideA, int n, 
   // deferred row scaling, all rows at once (keeps sqrt / division off the per-column critical path):
   // dsq <- sqrt(pivot), rdsq <- 1 / sqrt(pivot)
   if (tid < NB) {
+    if (tid >= ((nb + 15) & ~15)) dsq[tid] = 1.0;   // rows whose elimination steps were skipped (identity padding)
     const double sq = sqrt(dsq[tid]);
     dsq[tid] = sq;
     rdsq[tid] = 1.0 / sq;

@@ -242,6 +242,11 @@ __global__ __launch_bounds__(1024) void sub_absmax_kernel(int n, double* __restr
   }
 }
 
+void dev_sub_absmax(Ctx& c, int n, double* a, const double* b, double* d_out) {
+  hipLaunchKernelGGL(sub_absmax_kernel, dim3(1), dim3(1024), 0, c.stream, n, a, b, d_out);
+  HYP_CHECK(hipGetLastError());
+}
+
 void SysSolver::load_model(const double* hc, const double* hb, const double* hh, const double* hA) {
   const size_t d = sizeof(double);
   mc.ensure(std::max(n, 1) * d); mb.ensure(std::max(p, 1) * d); mh.ensure(std::max(q, 1) * d);
@@ -433,6 +438,57 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
   return true;
 }
 
+// res = K dir - rhs (in place in res); returns the inf-norm including the host-side tau / kap rows
+double SysSolver::residual(double* res, const double* dir, const double* rhs, Scal rs, Scal dcur, Scal& rsc, double mu, double taubar) {
+  const size_t d = sizeof(double);
+  rsc = apply_lhs(res, dir, dcur, mu, taubar);
+  rsc.tau -= rs.tau;
+  rsc.kap -= rs.kap;
+  // (the tau / kap slots of the device vectors are kept at zero: the scalars travel on the host)
+  hipLaunchKernelGGL(sub_absmax_kernel, dim3(1), dim3(1024), 0, ctx.stream, dimv(), res, rhs, ctx.dscal.d() + 8);
+  ctx.d2h(ctx.h_pinned + 16, ctx.dscal.d() + 8, d);
+  ctx.sync();
+  const double m = ctx.h_pinned[16];
+  if (m != m || rsc.tau != rsc.tau || rsc.kap != rsc.kap) return __builtin_nan("");
+  return std::max(m, std::max(std::fabs(rsc.tau), std::fabs(rsc.kap)));
+}
+
+// the refinement loop of get_directions (common.jl:38-72) on device vectors; tmp holds the best direction so far
+double SysSolver::refine(double* rhs, double* dir, double* res, double* tmp, Scal rs, Scal& dsc, Scal rsc, double res_norm, double mu,
+                         double taubar, int max_ref_steps, double res_norm_cutoff, double min_impr_tol, int* n_solves) {
+  const size_t d = sizeof(double);
+  const int dv = dimv();
+  Scal tsc = dsc;
+  bool is_prev_slow = false;
+  double prev_res_norm = res_norm;
+  for (int step = 0; step < max_ref_steps; ++step) {
+    // dir = dir_temp - solve(res)
+    Scal csc = solve_system(dir, res, rsc, mu, taubar);
+    ++*n_solves;
+    dev_axpby(ctx, dv, 1.0, tmp, -1.0, dir);
+    Gx_dir_valid = false;   // dir is no longer the raw output of solve_system
+    dsc.tau = tsc.tau - csc.tau;
+    dsc.kap = tsc.kap - csc.kap;
+    Scal rsc2{0, 0};
+    const double res_norm_new = residual(res, dir, rhs, rs, dsc, rsc2, mu, taubar);
+    if (!(res_norm_new < res_norm)) {   // (>= or NaN: keep the previous direction)
+      ctx.d2d(dir, tmp, (size_t)dv * d);
+      dsc = tsc;
+      break;
+    }
+    ctx.d2d(tmp, dir, (size_t)dv * d);
+    tsc = dsc;
+    rsc = rsc2;
+    res_norm = res_norm_new;
+    if (res_norm < res_norm_cutoff) break;
+    const bool is_curr_slow = res_norm > min_impr_tol * prev_res_norm;
+    if (is_prev_slow && is_curr_slow) break;
+    prev_res_norm = res_norm;
+    is_prev_slow = is_curr_slow;
+  }
+  return res_norm;
+}
+
 double SysSolver::get_directions(double* h_dir, const double* h_rhs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
                                  double min_impr_tol, int* n_solves) {
   HYP_REQUIRE(model_loaded, "sys: load_model first");
@@ -450,53 +506,12 @@ double SysSolver::get_directions(double* h_dir, const double* h_rhs, double mu, 
   Scal dsc = solve_system(dir, rhs, rs, mu, taubar);
   ++*n_solves;
   double res_norm = 0.0;
-  auto residual = [&](Scal dcur, Scal& rsc) -> double {   // res = K dir - rhs ; returns the inf-norm
-    rsc = apply_lhs(res, dir, dcur, mu, taubar);
-    rsc.tau -= rs.tau;
-    rsc.kap -= rs.kap;
-    // (the tau / kap slots of the device vectors are kept at zero: the scalars travel on the host)
-    hipLaunchKernelGGL(sub_absmax_kernel, dim3(1), dim3(1024), 0, ctx.stream, dv, res, rhs, ctx.dscal.d() + 8);
-    ctx.d2h(ctx.h_pinned + 16, ctx.dscal.d() + 8, d);
-    ctx.sync();
-    double m = ctx.h_pinned[16];
-    if (getenv("HYP_DEBUG_DIR")) fprintf(stderr, "[dir] absmax %.3e  tau res %.3e (lhs %.6e rhs %.6e)  kap res %.3e (lhs %.6e rhs %.6e)\n", m, rsc.tau,
-                                         rsc.tau + rs.tau, rs.tau, rsc.kap, rsc.kap + rs.kap, rs.kap);
-    if (m != m || rsc.tau != rsc.tau || rsc.kap != rsc.kap) return __builtin_nan("");
-    return std::max(m, std::max(std::fabs(rsc.tau), std::fabs(rsc.kap)));
-  };
   if (max_ref_steps > 0) {
-    Scal tsc = dsc, rsc{0, 0};
+    Scal rsc{0, 0};
     ctx.d2d(tmp, dir, (size_t)dv * d);
-    res_norm = residual(dsc, rsc);
-    if (res_norm > res_norm_cutoff) {
-      bool is_prev_slow = false;
-      double prev_res_norm = res_norm;
-      for (int step = 0; step < max_ref_steps; ++step) {
-        // dir = dir_temp - solve(res)
-        Scal csc = solve_system(dir, res, rsc, mu, taubar);
-        ++*n_solves;
-        dev_axpby(ctx, dv, 1.0, tmp, -1.0, dir);
-        Gx_dir_valid = false;   // dir is no longer the raw output of solve_system
-        dsc.tau = tsc.tau - csc.tau;
-        dsc.kap = tsc.kap - csc.kap;
-        Scal rsc2{0, 0};
-        const double res_norm_new = residual(dsc, rsc2);
-        if (!(res_norm_new < res_norm)) {   // (>= or NaN: keep the previous direction)
-          ctx.d2d(dir, tmp, (size_t)dv * d);
-          dsc = tsc;
-          break;
-        }
-        ctx.d2d(tmp, dir, (size_t)dv * d);
-        tsc = dsc;
-        rsc = rsc2;
-        res_norm = res_norm_new;
-        if (res_norm < res_norm_cutoff) break;
-        const bool is_curr_slow = res_norm > min_impr_tol * prev_res_norm;
-        if (is_prev_slow && is_curr_slow) break;
-        prev_res_norm = res_norm;
-        is_prev_slow = is_curr_slow;
-      }
-    }
+    res_norm = residual(res, dir, rhs, rs, dsc, rsc, mu, taubar);
+    if (res_norm > res_norm_cutoff)
+      res_norm = refine(rhs, dir, res, tmp, rs, dsc, rsc, res_norm, mu, taubar, max_ref_steps, res_norm_cutoff, min_impr_tol, n_solves);
   }
   ctx.d2h(h_dir, dir, (size_t)dv * d);
   ctx.sync();

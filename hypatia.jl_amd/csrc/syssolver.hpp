@@ -4,6 +4,9 @@
 
 namespace hyp {
 
+// a <- a - b in place and *d_out = max |a_i| (NaN if any), one launch
+void dev_sub_absmax(Ctx& c, int n, double* a, const double* b, double* d_out);
+
 struct SysSolver {
   Ctx& ctx;
   int n, p, q, nmp;
@@ -58,6 +61,15 @@ struct SysSolver {
   DBuf cand_d;
   bool check_cone_points(const double* h_ztsk, double min_prox, double prox_bound, bool use_max_prox, double nup1, double* prox_out,
                          int* n_loaded, double* irtmu_out);
+  double residual(double* res, const double* dir, const double* rhs, Scal rs, Scal dcur, Scal& rsc, double mu, double taubar);
+  double refine(double* rhs, double* dir, double* res, double* tmp, Scal rs, Scal& dsc, Scal rsc, double res_norm, double mu, double taubar,
+                int max_ref_steps, double res_norm_cutoff, double min_impr_tol, int* n_solves);
+  // ---- two right-hand sides at once (directions_multi.hip): the stepper's (cent, pred) and (centadj, predadj)
+  // pairs are independent, and every pass over G / the factor / the cone matrices serves both columns
+  DBuf m_rhs, m_dir, m_res, m_subr, m_subs, m_t, m_Gx, m_HGx, m_Gxd;
+  void solve3_multi(double* sol, const double* rhs, int nr);   // p == 0 only; columns n + q apart
+  void get_directions2(double* h_dirs, const double* h_rhss, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
+                       double min_impr_tol, double* res_norms, int* n_solves);
   // returns res_norm; dir / rhs are HOST Point vectors (common.jl:15-76)
   double get_directions(double* h_dir, const double* h_rhs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
                         double min_impr_tol, int* n_solves);

@@ -25,26 +25,39 @@ EPS = np.finfo(np.float64).eps
 
 try:   # keep the host BLAS pool small inside the iteration loop: the driver's numpy calls are tiny, and a
     # large pool of spinning OpenBLAS workers starves the HIP runtime's own threads (measured: 3x slower)
-    from threadpoolctl import threadpool_limits as _threadpool_limits
+    from threadpoolctl import ThreadpoolController as _ThreadpoolController
 except Exception:   # pragma: no cover
-    _threadpool_limits = None
+    _ThreadpoolController = None
+_controller = None
 
 
 class _blas_limit:
+    """context manager: cap the host BLAS pools while the IPM loop runs.  The controller (a scan of the loaded
+    shared libraries, ~0.4 ms) is built once; re-entering with the limit already in force is free."""
+    _depth = 0
+
     def __init__(self, n=int(os.environ.get("HYP_HOST_BLAS_THREADS", "1"))):
         self.n = n
         self.cm = None
 
     def __enter__(self):
-        if _threadpool_limits is not None:
-            self.cm = _threadpool_limits(limits=self.n, user_api="blas")
+        global _controller
+        if _ThreadpoolController is not None and _blas_limit._depth == 0:
+            if _controller is None:
+                _controller = _ThreadpoolController()
+            self.cm = _controller.limit(limits=self.n, user_api="blas")
             self.cm.__enter__()
+        _blas_limit._depth += 1
         return self
 
     def __exit__(self, *a):
+        _blas_limit._depth -= 1
         if self.cm is not None:
             self.cm.__exit__(*a)
+            self.cm = None
         return False
+
+
 # status codes (Solvers.jl:34-49)
 STATUSES = ("NotLoaded", "Loaded", "SolveCalled", "Optimal", "PrimalInfeasible", "DualInfeasible",
             "IllPosed", "PrimalInconsistent", "DualInconsistent", "SlowProgress", "IterationLimit",
@@ -356,6 +369,8 @@ class CombinedStepper:
         self.dir_centadj = Point(model)
         self.dir_predadj = Point(model)
         self.dir_temp = np.zeros(self.rhs.vec.shape[0])
+        self.rhs2 = np.zeros((2, self.rhs.vec.shape[0]))   # the two right-hand sides / directions of a paired solve
+        self.dir2 = np.zeros((2, self.rhs.vec.shape[0]))
         self.searcher = StepSearcher(model, **self.searcher_options)
         self.unadj_only = self.cent_only = False
         self.syssolver = solver.syssolver
@@ -368,19 +383,35 @@ class CombinedStepper:
 
         t0 = T(); solver.syssolver.update_lhs(solver); solver.time_upsys += T() - t0
 
-        t0 = T(); update_rhs_cent(solver, rhs); solver.time_uprhs += T() - t0
-        t0 = T(); get_directions(self, solver); solver.time_getdir += T() - t0
-        self.dir_cent.vec[:] = dir.vec
-        t0 = T(); update_rhs_centadj(solver, rhs, dir); solver.time_uprhs += T() - t0
-        t0 = T(); get_directions(self, solver); solver.time_getdir += T() - t0
-        self.dir_centadj.vec[:] = dir.vec
+        sysv = solver.syssolver
+        if getattr(sysv, "native_directions", False) and hasattr(sysv, "get_directions2_native") and not os.environ.get("HYP_NO_PAIR"):
+            # (cent, pred) and (centadj, predadj) are independent pairs: each pair is one device call in which
+            # every pass over G, the factor and the cone matrices serves both right-hand sides
+            r2, d2 = self.rhs2, self.dir2
+            t0 = T()
+            update_rhs_cent(solver, rhs); r2[0] = rhs.vec
+            update_rhs_pred(solver, rhs); r2[1] = rhs.vec
+            solver.time_uprhs += T() - t0
+            t0 = T(); self._pair(solver, self.dir_cent, self.dir_pred); solver.time_getdir += T() - t0
+            t0 = T()
+            update_rhs_centadj(solver, rhs, self.dir_cent); r2[0] = rhs.vec
+            update_rhs_predadj(solver, rhs, self.dir_pred); r2[1] = rhs.vec
+            solver.time_uprhs += T() - t0
+            t0 = T(); self._pair(solver, self.dir_centadj, self.dir_predadj); solver.time_getdir += T() - t0
+        else:
+            t0 = T(); update_rhs_cent(solver, rhs); solver.time_uprhs += T() - t0
+            t0 = T(); get_directions(self, solver); solver.time_getdir += T() - t0
+            self.dir_cent.vec[:] = dir.vec
+            t0 = T(); update_rhs_centadj(solver, rhs, dir); solver.time_uprhs += T() - t0
+            t0 = T(); get_directions(self, solver); solver.time_getdir += T() - t0
+            self.dir_centadj.vec[:] = dir.vec
 
-        t0 = T(); update_rhs_pred(solver, rhs); solver.time_uprhs += T() - t0
-        t0 = T(); get_directions(self, solver); solver.time_getdir += T() - t0
-        self.dir_pred.vec[:] = dir.vec
-        t0 = T(); update_rhs_predadj(solver, rhs, dir); solver.time_uprhs += T() - t0
-        t0 = T(); get_directions(self, solver); solver.time_getdir += T() - t0
-        self.dir_predadj.vec[:] = dir.vec
+            t0 = T(); update_rhs_pred(solver, rhs); solver.time_uprhs += T() - t0
+            t0 = T(); get_directions(self, solver); solver.time_getdir += T() - t0
+            self.dir_pred.vec[:] = dir.vec
+            t0 = T(); update_rhs_predadj(solver, rhs, dir); solver.time_uprhs += T() - t0
+            t0 = T(); get_directions(self, solver); solver.time_getdir += T() - t0
+            self.dir_predadj.vec[:] = dir.vec
 
         self.unadj_only = self.cent_only = False
         t0 = T(); alpha = search_alpha(point, model, self); solver.time_search += T() - t0
@@ -401,6 +432,15 @@ class CombinedStepper:
         self.update_stepper_points(alpha, point, False)
         self.prev_alpha = alpha
         return True
+
+    def _pair(self, solver, dir_a, dir_b):
+        (ra, rb), ns = solver.syssolver.get_directions2_native(solver, self.dir2, self.rhs2)
+        dir_a.vec[:] = self.dir2[0]
+        dir_b.vec[:] = self.dir2[1]
+        solver.n_solves += ns
+        assert not (np.isnan(ra) or np.isnan(rb))
+        if solver.max_ref_steps > 0:
+            solver.worst_dir_res = max(solver.worst_dir_res, ra, rb)
 
     def update_stepper_points(self, alpha, point, ztsk_only):   # :124-170
         if ztsk_only:
@@ -551,8 +591,9 @@ class Solver:
             if self._setup_only:
                 return self
             self.iter_start_time = time.perf_counter()
-            while self.iterate():
-                pass
+            with _blas_limit():
+                while self.iterate():
+                    pass
             self.iter_time = time.perf_counter() - self.iter_start_time
 
             t0 = time.perf_counter(); postprocess(self); self.time_unproc = time.perf_counter() - t0

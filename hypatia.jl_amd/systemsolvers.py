@@ -7,6 +7,7 @@ reductions `solve_system` / `solve_subsystem4` / `setup_rhs3` are kept on the ho
 reference inherits them.
 """
 import ctypes
+import os
 import time
 
 import numpy as np
@@ -84,7 +85,7 @@ class QRCholDenseSystemSolver:
         AA = np.asfortranarray(model.A, dtype=np.float64) if p > 0 else None
         L.check(lib.hyp_sys_load_model(h, L.vec_ptr(cc), L.vec_ptr(bb), L.vec_ptr(hh),
                                        AA.ctypes.data_as(c_vp) if AA is not None else None), "hyp_sys_load_model")
-        self.native_directions = True
+        self.native_directions = not os.environ.get("HYP_NO_NATIVE")
         return self
 
     # y = alpha * op(G) x + beta * y on the device-resident model.G
@@ -118,6 +119,16 @@ class QRCholDenseSystemSolver:
         L.check(L.lib().hyp_sys_block_hess_prod(self._h, L.vec_ptr(self.rhs_const.z), L.vec_ptr(hh)), "hyp_sys_block_hess_prod")
         self.solve_subsystem3(solver, self.sol_const, self.rhs_const)
         return self
+
+    # ---- two independent right-hand sides per pass (hyp_sys_get_directions2)
+    def get_directions2_native(self, solver, dirs2, rhss2, min_impr_tol=0.5):
+        """dirs2 / rhss2: (2 x len(Point.vec)) C-contiguous arrays; returns (res_norms[2], n_solves)"""
+        res = (ctypes.c_double * 2)()
+        ns = c_int(0)
+        L.check(L.lib().hyp_sys_get_directions2(self._h, dirs2.ctypes.data_as(c_vp), rhss2.ctypes.data_as(c_vp), float(solver.mu),
+                                                float(solver.point.tau), int(solver.max_ref_steps), float(solver.res_norm_cutoff),
+                                                float(min_impr_tol), res, ctypes.byref(ns)), "hyp_sys_get_directions2")
+        return (res[0], res[1]), ns.value
 
     # ---- search.jl:74-138 for all cones in one call; keeps the host mirrors of the reloaded cones in step
     def check_cone_points_native(self, model, cand, searcher):

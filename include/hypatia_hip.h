@@ -121,6 +121,11 @@ int hyp_sys_update_lhs(hyp_sys* sys, int* use_sqrt_hess_cones_out, int* info, in
  * tau = solver.point.tau[]; res_norm_cutoff / min_impr_tol as in common.jl:15-20; n_solves counts solve_system calls */
 int hyp_sys_get_directions(hyp_sys* sys, double* dir_vec, const double* rhs_vec, double mu, double tau, int max_ref_steps,
                            double res_norm_cutoff, double min_impr_tol, double* res_norm, int* n_solves);
+/* the same for TWO independent right-hand sides at once (the stepper's (cent, pred) and (centadj, predadj)
+ * pairs, steppers/combined.jl:60-95): dir_vecs / rhs_vecs hold two Point vectors back to back; every pass over
+ * G, the factor and the cone matrices serves both.  res_norms[2]; n_solves counts solve_system calls (2 + refinements). */
+int hyp_sys_get_directions2(hyp_sys* sys, double* dir_vecs, const double* rhs_vecs, double mu, double tau, int max_ref_steps,
+                            double res_norm_cutoff, double min_impr_tol, double* res_norms, int* n_solves);
 /* check_cone_points (steppers/search.jl:74-138) for one line-search candidate, all cones in one call:
  * cand_ztsk = [z(q); tau; s(q); kap] (the `ztsk` view of the candidate Point); min_prox / prox_bound /
  * use_max_prox / nup1 are the StepSearcher fields (search.jl:8-39).  accept = the function's Bool; prox =

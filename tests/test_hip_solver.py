@@ -69,7 +69,10 @@ def test_trajectory_parity_psd(n, sides, seed):
     same = (ht[:k, 8] == ot[:k, 8])
     stable = (pt[:k, 8] == ot[:k, 8])
     kp = k if stable.all() else int(np.argmin(stable))
-    kp = min(kp, int(np.sum(ot[:k, 7] >= 1e-8)) + 1)   # row i holds the step taken from iterate i-1
+    # row i holds the step taken from iterate i-1.  Below mu ~ 1e-7 the trajectory deviation (measured: 1e-5 .. 4e-4
+    # relative in mu for EVERY variant of this path and for the perturbed oracle alike) is enough to tip the discrete
+    # line search either way, so step sizes are only compared above it.
+    kp = min(kp, int(np.sum(ot[:k, 7] >= 1e-7)) + 1)
     assert same[:kp].all(), "line-search step sizes differ where the oracle is stable"
     assert kp >= int(np.sum(ot[:, 7] >= 1e-7)), "stable prefix unexpectedly short"
     assert abs(hs.num_iters - os_.num_iters) <= (0 if kp == max(len(ht), len(ot)) else 3)
@@ -167,3 +170,30 @@ def test_device_get_directions_matches_host_composition_and_oracle(name, reduce)
         scale = np.linalg.norm(d_orc)
         assert np.linalg.norm(d_dev - d_host) <= 1e-11 * scale, name
         assert np.linalg.norm(d_dev - d_orc) <= 1e-7 * scale, name
+
+
+@pytest.mark.parametrize("name,reduce", [("possemideftri2", True), ("possemideftri2", False), ("wsosinterpnonnegative2", True),
+                                         ("epinormspectral3_3x4_dual", True)])
+def test_paired_directions_match_single(name, reduce):
+    """hyp_sys_get_directions2 (two right-hand sides per pass over G / the factor / the cone matrices) against two
+    calls of the single-column routine, on the (cent, pred) pair of an interior iterate."""
+    import hypatia_jl_amd as H
+    from hypatia_jl_amd import solvers as HS
+    from oracle import instances as I
+    inst = I.KNOWN_ANSWER[name]()
+    hs = H.Solver(iter_limit=3, reduce=reduce)
+    hs.load(H.make_model(inst)); hs.solve()
+    st, sysv = hs.stepper, hs.syssolver
+    sysv.update_lhs(hs)
+    singles = []
+    for k, upd in enumerate((HS.update_rhs_cent, HS.update_rhs_pred)):
+        upd(hs, st.rhs)
+        st.rhs2[k] = st.rhs.vec
+        HS.get_directions(st, hs)
+        singles.append(st.dir.vec.copy())
+    (ra, rb), ns = sysv.get_directions2_native(hs, st.dir2, st.rhs2)
+    assert ns >= 2 and np.isfinite(ra) and np.isfinite(rb)
+    for k in range(2):
+        scale = np.linalg.norm(singles[k])
+        # (1e-8: near-converged iterates have directions ~1e-6 while the intermediates of the 6x6 reduction are O(1))
+        assert np.linalg.norm(st.dir2[k] - singles[k]) <= 1e-8 * scale, (name, k)
