@@ -30,7 +30,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# one metric for every N (weak scaling: one PosSemidefTri block per GPU, n shared).  At N = 1 a block-iteration IS an
+# IPM iteration of BASELINE.json's headline instance (configs[1]).
+METRIC = "IPM block-iterations/sec: dense n=%d, one PosSemidefTri(%d) block per GPU (Float64, QRCholDense + CombinedStepper)"
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix spec; measured 77.8 with tools/probe_mfma.hip (profiles/)
+
+
+def pmc_traffic(n, q):
+    """HBM bytes per syrk launch from the committed PMC passes (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE); only
+    valid for the configuration they were collected on, else None."""
+    try:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_summary.json")
+        with open(path) as f:
+            rec = json.load(f)["syrk"]
+        if rec["algorithmic_bytes_per_launch"] == q * n * 8 + n * (n + 1) // 2 * 8:
+            return rec["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def gen_instance(n, sides, seed):
@@ -113,6 +130,7 @@ def main_multi(args, world, rank, local_rank):
     torch.cuda.synchronize()
     comm.barrier()
     el = np.array([time.perf_counter() - t0])
+    blas_cap.__exit__(None, None, None)
     comm.allreduce(el, "max")
     elapsed = float(el[0])
     ks = (ctypes.c_double * 8)()
@@ -122,7 +140,7 @@ def main_multi(args, world, rank, local_rank):
         syrk_flops = float(n) * n * dim
         achieved = syrk_flops / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
         out = {
-            "metric": "IPM iterations/sec x PSD-%d blocks, dense n=%d (Float64, QRCholDense + CombinedStepper)" % (side, n),
+            "metric": METRIC % (n, side),
             "value": world * args.steps / elapsed,
             "unit": "block-iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -151,6 +169,7 @@ def main():
     ap.add_argument("--psd-side", dest="side", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-iters", type=int, default=2, help="oracle iterations timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=8, help="host BLAS threads for the cpu_baseline leg and the host-side setup")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
@@ -165,9 +184,11 @@ def main():
     inst = gen_instance(args.n, [args.side], args.seed)
     q = inst[3].shape[0]
     t_setup = time.perf_counter()
-    solver = H.Solver(verbose=args.verbose)
-    solver.load(H.make_model(inst))
-    solver.setup()
+    from threadpoolctl import threadpool_limits
+    with threadpool_limits(limits=args.cpu_threads, user_api="blas"):   # host preprocessing (rescale, QR for the initial x): untimed setup
+        solver = H.Solver(verbose=args.verbose)
+        solver.load(H.make_model(inst))
+        solver.setup()
     t_setup = time.perf_counter() - t_setup
     lib, ctx = H._lib.lib(), H._lib.ctx()
 
@@ -193,6 +214,7 @@ def main():
         step()
     lib.hyp_ctx_synchronize(ctx)
     elapsed = time.perf_counter() - t0
+    blas_cap.__exit__(None, None, None)   # (the CPU baseline below runs with the full host BLAS pool)
 
     ks = (ctypes.c_double * 8)()
     lib.hyp_get_kernel_stats(ctx, ks)
@@ -205,9 +227,10 @@ def main():
     n_trials = solver.stepper.searcher.n_trials - n_trials0
 
     out = {
-        "metric": "IPM iterations/sec, dense n=%d PSD-%d (Float64, QRCholDense + CombinedStepper)" % (args.n, args.side),
-        "value": args.steps / elapsed,
-        "unit": "iterations/s",
+        "metric": METRIC % (args.n, args.side),
+        "value": args.steps / elapsed,          # one block on one GPU: block-iterations/s = IPM iterations/s
+        "unit": "block-iterations/s",
+        "iterations_per_s": args.steps / elapsed,
         "n_gpus": 1,
         "steps": args.steps,
         "warmup": args.warmup,
@@ -221,7 +244,8 @@ def main():
                    "n": args.n, "q": q, "seed": args.seed},
         "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<true, 4, 1> (Schur syrk, upper)", "achieved": achieved,
                      "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                     "traffic": None, "launch_ms": syrk_ms, "flops_per_launch": syrk_flops},
+                     "traffic": pmc_traffic(args.n, q), "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 PMC, profiles/r01_pmc_summary.json)",
+                     "launch_ms": syrk_ms, "flops_per_launch": syrk_flops},
         "phases_ms_per_step": {"sqrt_hess_prod": ks[0] / args.steps, "syrk": ks[1] / args.steps, "cholesky": ks[2] / args.steps,
                                "update_lhs": solver.time_upsys / args.steps * 1e3, "get_directions": solver.time_getdir / args.steps * 1e3,
                                "update_rhs": solver.time_uprhs / args.steps * 1e3, "search": solver.time_search / args.steps * 1e3},
@@ -235,14 +259,19 @@ def main():
         # CPU baseline: the oracle restatement ("port") on the host cores, a bounded number of iterations
         from oracle.build import make_model as omodel
         from oracle.solvers import Solver as OSolver
-        os_ = OSolver(verbose=False, iter_limit=args.cpu_iters)
-        os_.load(omodel(inst))
-        os_.solve()
+        # host BLAS pool of the baseline: 8 threads is the fastest setting measured for this port on the GPU box
+        # (tools/cpu_baseline_threads.py: 1 -> 8.4 s, 8 -> 3.7 s, 32 -> 7.0 s, 256 -> 17.6 s per iteration; the
+        # per-column loop of the PSD products is many small BLAS calls, which large pools slow down)
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=args.cpu_threads, user_api="blas"):
+            os_ = OSolver(verbose=False, iter_limit=args.cpu_iters)
+            os_.load(omodel(inst))
+            os_.solve()
         cpu_it_s = os_.num_iters / os_.iter_time if os_.iter_time > 0 else 0.0
-        out["cpu_baseline"] = {"value": cpu_it_s, "unit": "iterations/s", "cores": os.cpu_count(), "kind": "port",
-                               "sample": "first %d IPM iterations of the same instance; numpy/scipy restatement: OpenBLAS on all cores for the syrk / "
+        out["cpu_baseline"] = {"value": cpu_it_s, "unit": "block-iterations/s", "cores": args.cpu_threads, "host_cores": os.cpu_count(), "kind": "port",
+                               "sample": "first %d IPM iterations of the same instance; numpy/scipy restatement: OpenBLAS (%d threads) for the syrk / "
                                          "Cholesky / gemv, the per-column dtrsm loop of the PSD products is sequential as in the reference "
-                                         "(possemideftri.jl:168-174) and Python-bound here" % os_.num_iters,
+                                         "(possemideftri.jl:168-174) and Python-bound here" % (os_.num_iters, args.cpu_threads),
                                "s_per_iteration": (os_.iter_time / max(os_.num_iters, 1))}
         out["speedup_vs_cpu_port"] = out["value"] / cpu_it_s if cpu_it_s > 0 else None
     if hasattr(lib, "report"):
