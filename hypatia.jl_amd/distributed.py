@@ -195,6 +195,7 @@ class DistModel:
                            if self.local_ks else np.zeros(0, dtype=int))
         self.G_local = np.asfortranarray(G_local, dtype=np.float64).reshape(self.local_rows.shape[0], self.n)
         self.G = None   # never materialised: products go through the system solver
+        self.dist_hooks = DistHooks(comm, self)
 
     def copy(self):
         return DistModel(self.comm, self.c, self.h, self.G_local.copy(order="F"), self.cones, self.owners, self.obj_offset)
@@ -355,6 +356,95 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
         self.block_hess_prod_full(HGx, Gx)
         z[:] = HGx - z
         return sol
+
+
+# ---------------------------------------------------------------------------------------------------
+# per-cone loops of the driver, batched: every rank evaluates the oracles of ITS cones concurrently and one
+# all-reduce assembles the result (the proxies above would run the cones one after another, each with its
+# own broadcast: the line search alone is 4 collectives per cone per trial)
+# ---------------------------------------------------------------------------------------------------
+class DistHooks:
+    def __init__(self, comm, model):
+        self.comm, self.model = comm, model
+
+    def _locals(self):
+        m = self.model
+        return [(k, m.cones[k].local) for k in m.local_ks]
+
+    # steppers/common.jl:63-84
+    def update_rhs_cent(self, solver, rhs):
+        rhs.x[:] = 0; rhs.y[:] = 0; rhs.z[:] = 0; rhs.tau = 0
+        rtmu = np.sqrt(solver.mu)
+        rhs.s[:] = 0
+        for k, cone in self._locals():
+            rhs.s_views[k][:] = -solver.point.dual_views[k] - rtmu * cone.get_grad()
+        self.comm.allreduce(rhs.s)
+        rhs.kap = -solver.point.kap + solver.mu / solver.point.tau
+        return rhs
+
+    # steppers/common.jl:27-60 (adj = "pred") and :87-118 (adj = "cent")
+    def update_rhs_adj(self, solver, rhs, dir, which):
+        rhs.vec[:] = 0
+        rteps = np.sqrt(np.finfo(np.float64).eps)
+        irtrtmu = 1.0 / np.sqrt(np.sqrt(solver.mu))
+        for k, cone in self._locals():
+            prim_dir_k = dir.primal_views[k]
+            scal = irtrtmu * prim_dir_k
+            H = np.zeros(cone.dim)
+            if which == "pred":
+                cone.hess_prod_slow(H, np.ascontiguousarray(prim_dir_k))
+                d3 = cone.dder3(scal)
+                dot1 = d3 @ cone.point
+                dot2 = irtrtmu * (scal @ H)
+                if abs(dot1 - dot2) / (rteps + abs(dot2)) < 1e-4:
+                    rhs.s_views[k][:] = H + d3
+            else:
+                cone.hess_prod_slow(H, scal)
+                d3 = cone.dder3(scal)
+                dot1 = d3 @ cone.point
+                dot2 = scal @ H
+                if abs(dot1 - dot2) / (rteps + abs(dot2)) < 1e-4:
+                    rhs.s_views[k][:] = d3
+        self.comm.allreduce(rhs.s)
+        taubar = solver.point.tau
+        t = dir.tau / taubar
+        rhs.kap = t * solver.mu / taubar * ((1 + t) if which == "pred" else t)
+        return rhs
+
+    # the cone rows of apply_lhs (systemsolvers/common.jl:107-115)
+    def apply_lhs_cones(self, res, dir):
+        res.s[:] = 0
+        for k, cone in self._locals():
+            out = np.zeros(cone.dim)
+            cone.hess_prod_slow(out, np.ascontiguousarray(dir.primal_views[k]))
+            res.s_views[k][:] = out + dir.dual_views[k]
+        self.comm.allreduce(res.s)
+
+    # the cone sweep of check_cone_points (search.jl:118-136): all owners test their cones at once
+    def check_cones(self, cand, irtmu, use_max_prox, taukap_proxsqr, proxsqr_bound):
+        ok, agg = 1.0, 0.0
+        m = self.model
+        for k, proxy in enumerate(m.cones):          # host mirrors of every cone follow the candidate
+            np.multiply(cand.primal_views[k], irtmu, out=proxy.point)
+            proxy.dual_point[:] = cand.dual_views[k]
+            proxy._grad_valid = False
+        for k, cone in self._locals():
+            cone.load_point(np.ascontiguousarray(cand.primal_views[k]), irtmu)
+            cone.load_dual_point(np.ascontiguousarray(cand.dual_views[k]))
+            cone.reset_data()
+            if ok and cone.is_feas() and cone.is_dual_feas() and cone.check_numerics():
+                pk = cone.get_proxsqr(irtmu, use_max_prox)
+                agg = max(agg, pk) if use_max_prox else agg + pk
+            else:
+                ok = 0.0
+        flag = np.array([ok])
+        self.comm.allreduce(flag, "min")
+        val = np.array([agg])
+        self.comm.allreduce(val, "max" if use_max_prox else "sum")
+        if flag[0] < 0.5:
+            return False, 0.0
+        total = max(taukap_proxsqr, val[0]) if use_max_prox else taukap_proxsqr + val[0]
+        return bool(total < proxsqr_bound), total
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -123,10 +123,14 @@ def apply_lhs(stepper, solver):   # common.jl:79-121
         res.x += model.A.T @ dir.y
         res.y[:] = model.b * tau_dir - model.A @ dir.x
         res.tau = res.tau - model.b @ dir.y
-    for k, cone_k in enumerate(model.cones):
-        s_res_k = res.s_views[k]
-        cone_k.hess_prod_slow(s_res_k, dir.primal_views[k])
-        s_res_k += dir.dual_views[k]
+    hooks = getattr(model, "dist_hooks", None)
+    if hooks is not None:      # cone-sharded model: owners compute concurrently, one all-reduce
+        hooks.apply_lhs_cones(res, dir)
+    else:
+        for k, cone_k in enumerate(model.cones):
+            s_res_k = res.s_views[k]
+            cone_k.hess_prod_slow(s_res_k, dir.primal_views[k])
+            s_res_k += dir.dual_views[k]
     tau = solver.point.tau
     res.kap = solver.mu / tau * tau_dir / tau + kap_dir
     return res
@@ -200,6 +204,9 @@ def update_rhs_pred(solver, rhs):   # :7-24
 
 
 def update_rhs_predadj(solver, rhs, dir):   # :27-60
+    hooks = getattr(solver.model, "dist_hooks", None)
+    if hooks is not None:
+        return hooks.update_rhs_adj(solver, rhs, dir, "pred")
     rhs.vec[:] = 0
     rteps = np.sqrt(EPS)
     irtrtmu = 1.0 / np.sqrt(np.sqrt(solver.mu))
@@ -224,6 +231,9 @@ def update_rhs_predadj(solver, rhs, dir):   # :27-60
 
 
 def update_rhs_cent(solver, rhs):   # :63-84
+    hooks = getattr(solver.model, "dist_hooks", None)
+    if hooks is not None:
+        return hooks.update_rhs_cent(solver, rhs)
     rhs.x[:] = 0
     rhs.y[:] = 0
     rhs.z[:] = 0
@@ -238,6 +248,9 @@ def update_rhs_cent(solver, rhs):   # :63-84
 
 
 def update_rhs_centadj(solver, rhs, dir):   # :87-118
+    hooks = getattr(solver.model, "dist_hooks", None)
+    if hooks is not None:
+        return hooks.update_rhs_adj(solver, rhs, dir, "cent")
     rhs.vec[:] = 0
     rteps = np.sqrt(EPS)
     irtrtmu = 1.0 / np.sqrt(np.sqrt(solver.mu))
@@ -333,6 +346,12 @@ def check_cone_points(model, stepper):   # search.jl:74-138
 
     # (the reference visits cones in order of last measured oracle time: affects order only)
     irtmu = 1.0 / np.sqrt(mu)
+    hooks = getattr(model, "dist_hooks", None)
+    if hooks is not None:      # cone-sharded model: every owner tests its cones at once, two scalar all-reduces
+        ok, agg = hooks.check_cones(cand, irtmu, use_max_prox, taukap_proxsqr, proxsqr_bound)
+        if ok:
+            searcher.prox = np.sqrt(agg)
+        return ok
     agg_proxsqr = taukap_proxsqr
     for k in range(len(cones)):
         cone_k = cones[k]
