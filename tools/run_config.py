@@ -30,7 +30,10 @@ elif args.config in ("5p", "5d"):
     rng = np.random.default_rng(args.seed)
     from oracle import polyutils as pu
     U, pts, Ps = pu.interpolate_box([-1.0] * 4, [1.0] * 4, 8, rng=rng, sample_factor=args.sample_factor)
-    vals = rng.standard_normal(U)
+    # a genuine polynomial of degree 4 sampled at the interpolation points (random VALUES at the points would
+    # define a wildly oscillating degree-16 interpolant: objective ~1e5 and a numerically hopeless instance)
+    a = rng.uniform(-0.5, 0.5, 4)
+    vals = np.sum((pts - a) ** 2, axis=1) + (pts[:, 0] * pts[:, 1] - pts[:, 2] * pts[:, 3]) ** 2 + 0.3 * pts[:, 0] * pts[:, 2]
     if args.config == "5p":
         inst = (np.array([-1.0]), np.zeros((0, 1)), np.zeros(0), np.ones((U, 1)), vals, [("wsosinterpnonnegative", U, Ps, False)], {})
     else:
