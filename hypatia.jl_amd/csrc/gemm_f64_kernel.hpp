@@ -365,12 +365,18 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a) {
   // 512 resident workgroups (2 per CU) per unit of work, so the last round is not mostly empty
   a.splitk = 1;
   if (a.tag == 1 && !small && a.batch == 1 && a.epi == 0 && a.krange == KR_ALL && a.K >= 4096) {
+    // cost in units of one full-K round of 512 workgroups: rounds(S) / S, plus the partial-sum traffic of S
+    // slices (N^2 / 2 doubles written and read back per slice at ~3.5 TB/s against 2.6e-7 K s per round;
+    // measured at n = 5000, q = 20100: S = 3 -> 8.71 ms, S = 5 -> 8.42 ms, S = 7 -> 8.45 ms)
+    const double eps = ((double)a.N * a.N * 2.3e-12) / (2.6e-7 * a.K);
     double best = 1e30;
-    for (int S = 1; S <= 4; ++S) {
+    for (int S = 1; S <= 8; ++S) {
       if (a.K / S < 1024) break;
-      const double rounds = (double)((nblk * S + 511) / 512) / S;
-      if (rounds < best - 1e-9) { best = rounds; a.splitk = S; }
+      const double cost = (double)((nblk * S + 511) / 512) / S + (S > 1 ? S * eps : 0.0);
+      if (cost < best - 1e-9) { best = cost; a.splitk = S; }
     }
+    static const int s_env = [] { const char* e = getenv("HYP_SYRK_S"); return e ? atoi(e) : 0; }();
+    if (s_env > 0 && a.K / s_env >= 512) a.splitk = s_env;
   }
   if (a.splitk_req > 1 && a.batch == 1 && a.epi == 0 && a.krange == KR_ALL && a.cm_blk == 0 && a.K / a.splitk_req >= 256) a.splitk = a.splitk_req;
   if (a.splitk > 1) {
