@@ -447,6 +447,15 @@ int hyp_sys_check_cone_points(hyp_sys* sys, const double* cand_ztsk, double min_
   *accept = sys->s->check_cone_points(cand_ztsk, min_prox, prox_bound, use_max_prox != 0, nup1, prox, n_loaded, irtmu) ? 1 : 0;
   API_END(sys->ctx)
 }
+int hyp_sys_search_alpha(hyp_sys* sys, const double* point_ztsk, const double* dir_cent, const double* dir_pred, const double* dir_centadj,
+                         const double* dir_predadj, int unadj_only, int cent_only, const double* alpha_sched, int nsched, int start,
+                         double min_prox, double prox_bound, int use_max_prox, double nup1, double* cand_ztsk, int* accepted_index,
+                         double* prox, int* n_trials, int* n_loaded, double* irtmu) {
+  API_BEGIN
+  *accepted_index = sys->s->search_alpha(point_ztsk, dir_cent, dir_pred, dir_centadj, dir_predadj, unadj_only != 0, cent_only != 0, alpha_sched,
+                                         nsched, start, min_prox, prox_bound, use_max_prox != 0, nup1, cand_ztsk, prox, n_trials, n_loaded, irtmu);
+  API_END(sys->ctx)
+}
 int hyp_sys_get_lhs(hyp_sys* sys, double* out) {
   API_BEGIN
   Ctx& c = sys->ctx->c;

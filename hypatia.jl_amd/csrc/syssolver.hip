@@ -438,6 +438,38 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
   return true;
 }
 
+int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp, const double* dca, const double* dpa, bool unadj_only,
+                            bool cent_only, const double* sched, int nsched, int start, double min_prox, double prox_bound,
+                            bool use_max_prox, double nup1, double* cand, double* prox_out, int* n_trials, int* n_loaded,
+                            double* irtmu_out) {
+  const int len = 2 * q + 2;
+  *n_trials = 0;
+  *n_loaded = 0;
+  for (int idx = start; idx < nsched; ++idx) {
+    const double alpha = sched[idx];
+    // update_stepper_points (combined.jl:124-170), same operation order as the host mirror
+    if (unadj_only) {
+      if (cent_only) {
+        for (int i = 0; i < len; ++i) cand[i] = pt[i] + alpha * dc[i];
+      } else {
+        const double am1 = 1.0 - alpha;
+        for (int i = 0; i < len; ++i) cand[i] = pt[i] + (alpha * dp[i] + am1 * dc[i]);
+      }
+    } else {
+      const double a2 = alpha * alpha;
+      if (cent_only) {
+        for (int i = 0; i < len; ++i) cand[i] = pt[i] + (alpha * dc[i] + a2 * dca[i]);
+      } else {
+        const double am1 = 1.0 - alpha, am1s = am1 * am1;
+        for (int i = 0; i < len; ++i) cand[i] = pt[i] + (((alpha * dp[i] + a2 * dpa[i]) + am1 * dc[i]) + am1s * dca[i]);
+      }
+    }
+    ++*n_trials;
+    if (check_cone_points(cand, min_prox, prox_bound, use_max_prox, nup1, prox_out, n_loaded, irtmu_out)) return idx;
+  }
+  return -1;
+}
+
 // res = K dir - rhs (in place in res); returns the inf-norm including the host-side tau / kap rows
 double SysSolver::residual(double* res, const double* dir, const double* rhs, Scal rs, Scal dcur, Scal& rsc, double mu, double taubar) {
   const size_t d = sizeof(double);

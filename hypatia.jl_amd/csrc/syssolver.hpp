@@ -70,6 +70,12 @@ struct SysSolver {
   void solve3_multi(double* sol, const double* rhs, int nr);   // p == 0 only; columns n + q apart
   void get_directions2(double* h_dirs, const double* h_rhss, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
                        double min_impr_tol, double* res_norms, int* n_solves);
+  // search_alpha (search.jl:46-69) with the candidate of update_stepper_points (combined.jl:124-170) formed here:
+  // walks alpha_sched from index `start`, returns the index of the first accepted step (or -1); all vectors are
+  // host `ztsk` views (length 2 q + 2): the current point and the four stepper directions
+  int search_alpha(const double* pt, const double* d_cent, const double* d_pred, const double* d_centadj, const double* d_predadj,
+                   bool unadj_only, bool cent_only, const double* sched, int nsched, int start, double min_prox, double prox_bound,
+                   bool use_max_prox, double nup1, double* cand_out, double* prox_out, int* n_trials, int* n_loaded, double* irtmu_out);
   // returns res_norm; dir / rhs are HOST Point vectors (common.jl:15-76)
   double get_directions(double* h_dir, const double* h_rhs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
                         double min_impr_tol, int* n_solves);

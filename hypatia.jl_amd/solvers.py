@@ -298,6 +298,9 @@ def search_alpha(point, model, stepper, sched=None):   # search.jl:46-69
     searcher = stepper.searcher
     if sched is None:
         sched = stepper.start_sched(searcher)
+    sysv = getattr(stepper, "syssolver", None)
+    if sysv is not None and getattr(sysv, "native_directions", False) and hasattr(sysv, "search_alpha_native"):
+        return sysv.search_alpha_native(model, point, stepper, sched)   # the whole schedule walk in one device call
     while sched <= len(searcher.alpha_sched):
         alpha = searcher.alpha_sched[sched - 1]
         stepper.update_stepper_points(alpha, point, True)
@@ -449,6 +452,9 @@ class CombinedStepper:
                         self.prev_alpha = alpha
                         return False
         self.update_stepper_points(alpha, point, False)
+        sysv = solver.syssolver
+        if getattr(sysv, "native_directions", False) and hasattr(sysv, "search_alpha_native"):
+            point.ztsk[:] = self.temp.ztsk   # exactly the accepted candidate the cones were loaded with (formed natively)
         self.prev_alpha = alpha
         return True
 

@@ -143,6 +143,30 @@ class QRCholDenseSystemSolver:
             searcher.prox = prox.value
         return bool(acc.value)
 
+    # ---- search.jl:46-69 for one stepper mode in one call (candidates formed natively)
+    def search_alpha_native(self, model, point, stepper, sched):
+        """sched: 1-based start index into searcher.alpha_sched (as search_alpha); returns (alpha, next prev_sched)"""
+        searcher = stepper.searcher
+        sc = np.ascontiguousarray(searcher.alpha_sched, dtype=np.float64)
+        cand = stepper.temp
+        idx, nt, nl = c_int(-1), c_int(0), c_int(0)
+        prox, irtmu = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        L.check(L.lib().hyp_sys_search_alpha(
+            self._h, L.vec_ptr(point.ztsk), L.vec_ptr(stepper.dir_cent.ztsk), L.vec_ptr(stepper.dir_pred.ztsk),
+            L.vec_ptr(stepper.dir_centadj.ztsk), L.vec_ptr(stepper.dir_predadj.ztsk), int(stepper.unadj_only), int(stepper.cent_only),
+            L.vec_ptr(sc), len(sc), int(sched - 1), float(searcher.min_prox), float(searcher.prox_bound), int(bool(searcher.use_max_prox)),
+            float(searcher.nup1), L.vec_ptr(cand.ztsk), ctypes.byref(idx), ctypes.byref(prox), ctypes.byref(nt), ctypes.byref(nl),
+            ctypes.byref(irtmu)), "hyp_sys_search_alpha")
+        searcher.n_trials += nt.value
+        for k in range(nl.value):
+            model.cones[k]._mirror_loaded(cand.primal_views[k], irtmu.value, cand.dual_views[k])
+        if idx.value >= 0:
+            searcher.prox = prox.value
+            searcher.prev_sched = idx.value + 1
+            return float(sc[idx.value])
+        searcher.prev_sched = len(sc) + 1
+        return 0.0
+
     # ---- common.jl:15-76 on the device
     def get_directions_native(self, solver, dir, rhs, min_impr_tol=0.5):
         res_norm, ns = ctypes.c_double(0.0), c_int(0)

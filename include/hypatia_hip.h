@@ -133,6 +133,15 @@ int hyp_sys_get_directions2(hyp_sys* sys, double* dir_vecs, const double* rhs_ve
  * (scaled by irtmu) before the sweep stopped -- the host mirrors of exactly those cones must follow. */
 int hyp_sys_check_cone_points(hyp_sys* sys, const double* cand_ztsk, double min_prox, double prox_bound, int use_max_prox, double nup1,
                               int* accept, double* prox, int* n_loaded, double* irtmu);
+/* search_alpha (steppers/search.jl:46-69) for one stepper mode: forms each candidate exactly as update_stepper_points
+ * (steppers/combined.jl:124-170) does -- all vectors are `ztsk` views [z(q); tau; s(q); kap] of the current point and of the
+ * four directions -- and runs check_cone_points on it, from alpha_sched[start] on.  accepted_index = 0-based index of the first
+ * accepted step or -1; cand_ztsk (caller buffer) holds the last candidate tried; n_loaded / irtmu as in
+ * hyp_sys_check_cone_points (host mirrors of the first n_loaded cones follow the last candidate). */
+int hyp_sys_search_alpha(hyp_sys* sys, const double* point_ztsk, const double* dir_cent, const double* dir_pred, const double* dir_centadj,
+                         const double* dir_predadj, int unadj_only, int cent_only, const double* alpha_sched, int nsched, int start,
+                         double min_prox, double prox_bound, int use_max_prox, double nup1, double* cand_ztsk, int* accepted_index,
+                         double* prox, int* n_trials, int* n_loaded, double* irtmu);
 int hyp_sys_get_lhs(hyp_sys* sys, double* out_nmpxnmp);        /* upper triangle meaningful (tests) */
 
 /* ---- dense kernels exposed for parity tests and micro-benchmarks ------------------------------- */
