@@ -447,6 +447,19 @@ int hyp_sys_check_cone_points(hyp_sys* sys, const double* cand_ztsk, double min_
   *accept = sys->s->check_cone_points(cand_ztsk, min_prox, prox_bound, use_max_prox != 0, nup1, prox, n_loaded, irtmu) ? 1 : 0;
   API_END(sys->ctx)
 }
+int hyp_sys_step_directions(hyp_sys* sys, const double* point_vec, const double* residuals, double tau_residual, double mu, int max_ref_steps,
+                            double res_norm_cutoff, double min_impr_tol, double* dir_vecs4, double* res_norms4, int* n_solves,
+                            int* use_sqrt_out, int* info, int* used_fallback, double* sol_const_out) {
+  API_BEGIN
+  sys->s->step_directions(point_vec, residuals, tau_residual, mu, max_ref_steps, res_norm_cutoff, min_impr_tol, dir_vecs4, res_norms4, n_solves,
+                          use_sqrt_out, info, used_fallback, sol_const_out);
+  API_END(sys->ctx)
+}
+int hyp_sys_last_update_lhs_seconds(hyp_sys* sys, double* out) {
+  API_BEGIN
+  *out = sys->s->last_update_lhs_s;
+  API_END(sys->ctx)
+}
 int hyp_sys_search_alpha(hyp_sys* sys, const double* point_ztsk, const double* dir_cent, const double* dir_pred, const double* dir_centadj,
                          const double* dir_predadj, int unadj_only, int cent_only, const double* alpha_sched, int nsched, int start,
                          double min_prox, double prox_bound, int use_max_prox, double nup1, double* cand_ztsk, int* accepted_index,

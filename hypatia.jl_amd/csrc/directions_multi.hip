@@ -6,6 +6,7 @@
 // qrchol.jl:16-98); a column whose residual calls for refinement continues alone through the
 // single-right-hand-side routines of syssolver.hip.
 #include "syssolver.hpp"
+#include <chrono>
 
 namespace hyp {
 
@@ -240,26 +241,46 @@ void SysSolver::get_directions2(double* h_dirs, const double* h_rhss, double mu,
     }
     return;
   }
+  m_rhs.ensure((size_t)MR * dv * d);
+  double* rhs = m_rhs.d();
+  ctx.h2d(rhs, h_rhss, (size_t)MR * dv * d);
+  Scal rs[MR], dsc[MR];
+  for (int r = 0; r < MR; ++r) {
+    ctx.zero(rhs + (long)r * dv + it, d);   // tau / kap travel as host scalars
+    ctx.zero(rhs + (long)r * dv + ik, d);
+    rs[r] = Scal{h_rhss[(long)r * dv + it], h_rhss[(long)r * dv + ik]};
+  }
+  pair_solve_device(rhs, rs, mu, taubar, max_ref_steps, res_norm_cutoff, min_impr_tol, dsc, res_norms, n_solves);
+  ctx.d2h(h_dirs, m_dir.d(), (size_t)MR * dv * d);
+  ctx.sync();
+  for (int r = 0; r < MR; ++r) {
+    h_dirs[(long)r * dv + it] = dsc[r].tau;
+    h_dirs[(long)r * dv + ik] = dsc[r].kap;
+  }
+}
+
+// two right-hand sides already on the device (rhs2 = two Point vectors, tau / kap slots zero, scalars in rs):
+// directions are left in m_dir, their tau / kap in dsc
+void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
+                                  double min_impr_tol, Scal* dsc, double* res_norms, int* n_solves) {
+  const size_t d = sizeof(double);
+  const int dv = dimv(), it = n + p + q, ik = dv - 1;
+  HYP_REQUIRE(p == 0, "pair_solve_device: p = 0 only");
   const int oz = n, os = n + q + 1;
   const long ld3 = n + q;
-  for (DBuf* b : {&m_rhs, &m_dir, &m_res}) b->ensure((size_t)MR * dv * d);
+  for (DBuf* b : {&m_dir, &m_res}) b->ensure((size_t)MR * dv * d);
   for (DBuf* b : {&m_subr, &m_subs}) b->ensure((size_t)MR * ld3 * d);
   for (DBuf* b : {&m_Gx, &m_HGx, &m_Gxd}) b->ensure((size_t)MR * q * d);
-  double* rhs = m_rhs.d();
   double* dir = m_dir.d();
   double* res = m_res.d();
   double* sr = m_subr.d();
   double* ss = m_subs.d();
-  ctx.h2d(rhs, h_rhss, (size_t)MR * dv * d);
-  Scal rs[MR], dsc[MR], rsc[MR];
+  Scal rsc[MR];
   for (int r = 0; r < MR; ++r) {
-    ctx.zero(rhs + (long)r * dv + it, d);
-    ctx.zero(rhs + (long)r * dv + ik, d);
     ctx.zero(dir + (long)r * dv + it, d);
     ctx.zero(dir + (long)r * dv + ik, d);
     ctx.zero(res + (long)r * dv + it, d);
     ctx.zero(res + (long)r * dv + ik, d);
-    rs[r] = Scal{h_rhss[(long)r * dv + it], h_rhss[(long)r * dv + ik]};
   }
 
   // ---- solve_system for both columns (common.jl:129-182, qrchol.jl:16-37)
@@ -349,11 +370,147 @@ void SysSolver::get_directions2(double* h_dirs, const double* h_rhss, double mu,
                             max_ref_steps, res_norm_cutoff, min_impr_tol, n_solves);
     }
   }
-  ctx.d2h(h_dirs, dir, (size_t)MR * dv * d);
+}
+
+
+// ---- right-hand sides of the stepper on the device (steppers/common.jl:7-118) -----------------------------
+// stage 0: columns (cent, pred); stage 1: columns (centadj from dir_cent, predadj from dir_pred).  rhs2 = two
+// Point vectors on the device (tau / kap slots zero, the scalars go to rs).
+void SysSolver::build_rhs_pair(int stage, double* rhs2, const double* pt, double mu, double tau, double kap, double tau_residual,
+                               const double* dirs2, const double* dir_tau2, double* rs_flat) {
+  const size_t d = sizeof(double);
+  const int dv = dimv(), oz = n + p, os = n + p + q + 1;
+  ctx.zero(rhs2, (size_t)MR * dv * d);
+  double* c0 = rhs2;
+  double* c1 = rhs2 + dv;
+  Scal* rs = reinterpret_cast<Scal*>(rs_flat);
+  if (stage == 0) {
+    const double rtmu = std::sqrt(mu);
+    ctx.d2d(c1, s_resid.d(), (size_t)n * d);                       // pred: x, z residuals (:7-24); cent: zeros (:63-84)
+    ctx.d2d(c1 + oz, s_resid.d() + n + p, (size_t)q * d);
+    for (size_t k = 0; k < cones.size(); ++k) {
+      Cone* ck = cones[k];
+      const int o = offs[k], dk = ck->dim;
+      const double* dual = pt + (ck->use_dual_barrier ? os : oz) + o;
+      dev_scale_copy(ctx, dk, -1.0, dual, c0 + os + o);            // cent: -dual - sqrt(mu) grad
+      dev_axpby(ctx, dk, -rtmu, ck->get_grad(), 1.0, c0 + os + o);
+      dev_scale_copy(ctx, dk, -1.0, dual, c1 + os + o);            // pred: -dual
+    }
+    rs[0] = Scal{0.0, -kap + mu / tau};
+    rs[1] = Scal{tau_residual, -kap};
+    return;
+  }
+  // stage 1: third-order adjustments; all cone products first, the acceptance tests (host scalars) after ONE sync
+  const double rteps = std::sqrt(2.220446049250313e-16);
+  const double irtrtmu = 1.0 / std::sqrt(std::sqrt(mu));
+  for (DBuf* b : {&m_Gx, &m_HGx, &m_Gxd}) b->ensure((size_t)MR * q * d);
+  double* scal = m_Gx.d();     // [q x 2] irtrtmu * prim_dir
+  double* Hq = m_HGx.d();      // [q x 2] H * (scaled / unscaled) prim_dir
+  double* D3 = m_Gxd.d();      // [q x 2] dder3
+  const size_t nc = cones.size();
+  s_dots.ensure(std::max<size_t>(4 * nc, 4) * d);
+  double* dots = s_dots.d();
+  for (size_t k = 0; k < nc; ++k) {
+    Cone* ck = cones[k];
+    if (!ck->use_dder3()) continue;
+    const int o = offs[k], dk = ck->dim;
+    const int po = (ck->use_dual_barrier ? oz : os) + o;
+    for (int r = 0; r < MR; ++r) {
+      const double* prim = dirs2 + (long)r * dv + po;
+      double* sc = scal + (long)r * q + o;
+      double* hh = Hq + (long)r * q + o;
+      dev_scale_copy(ctx, dk, irtrtmu, prim, sc);
+      ck->hess_prod_slow(hh, q, r == 0 ? sc : prim, q, 1);          // centadj: H (scaled dir); predadj: H dir
+      const double* d3 = ck->dder3(sc);
+      ctx.d2d(D3 + (long)r * q + o, d3, (size_t)dk * d);
+    }
+  }
+  for (size_t k = 0; k < nc; ++k) {   // (after all cone calls: they use ctx.dscal themselves)
+    Cone* ck = cones[k];
+    if (!ck->use_dder3()) continue;
+    const int o = offs[k], dk = ck->dim;
+    for (int r = 0; r < MR; ++r) {
+      dev_dot(ctx, dk, D3 + (long)r * q + o, ck->point.d(), dots + 4 * k + 2 * r);
+      dev_dot(ctx, dk, scal + (long)r * q + o, Hq + (long)r * q + o, dots + 4 * k + 2 * r + 1);
+    }
+  }
+  std::vector<double> hd(4 * std::max<size_t>(nc, 1));
+  ctx.d2h(hd.data(), dots, 4 * nc * d);
+  ctx.sync();
+  for (size_t k = 0; k < nc; ++k) {
+    Cone* ck = cones[k];
+    if (!ck->use_dder3()) continue;
+    const int o = offs[k], dk = ck->dim;
+    {   // centadj (:96-113): rhs.s_k = dder3
+      const double dot1 = hd[4 * k], dot2 = hd[4 * k + 1];
+      if (std::fabs(dot1 - dot2) / (rteps + std::fabs(dot2)) < 1e-4) ctx.d2d(c0 + os + o, D3 + o, (size_t)dk * d);
+    }
+    {   // predadj (:37-55): rhs.s_k = H dir + dder3
+      const double dot1 = hd[4 * k + 2], dot2 = irtrtmu * hd[4 * k + 3];
+      if (std::fabs(dot1 - dot2) / (rteps + std::fabs(dot2)) < 1e-4) {
+        ctx.d2d(c1 + os + o, Hq + q + o, (size_t)dk * d);
+        dev_axpby(ctx, dk, 1.0, D3 + q + o, 1.0, c1 + os + o);
+      }
+    }
+  }
+  const double tc = dir_tau2[0] / tau, tp = dir_tau2[1] / tau;
+  rs[0] = Scal{0.0, tc * mu / tau * tc};
+  rs[1] = Scal{0.0, tp * mu / tau * (1.0 + tp)};
+}
+
+void SysSolver::step_directions(const double* h_point, const double* h_res, double tau_residual, double mu, int max_ref_steps,
+                                double res_norm_cutoff, double min_impr_tol, double* h_dirs, double* res_norms, int* n_solves,
+                                int* use_sqrt_out, int* info, int* used_fallback, double* h_sol_const) {
+  HYP_REQUIRE(model_loaded, "sys: load_model first");
+  HYP_REQUIRE(p == 0, "step_directions: p = 0 only");
+  const size_t d = sizeof(double);
+  const int dv = dimv(), it = n + p + q, ik = dv - 1;
+  *n_solves = 0;
+  *info = 0;
+  *used_fallback = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  if (nmp > 0) update_lhs_fact(info, used_fallback);                 // combined.jl:64
+  if (use_sqrt_out)
+    for (size_t k = 0; k < cones.size(); ++k) use_sqrt_out[k] = use_sqrt[k];
+  if (*info != 0) return;
+  update_const();
+  if (h_sol_const) ctx.d2h(h_sol_const, sol_const.p, (size_t)(n + p + q) * sizeof(double));   // (host mirror of sys.sol_const)
+  last_update_lhs_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  const double tau = h_point[it], kap = h_point[ik];
+  s_point.ensure((size_t)dv * d);
+  s_resid.ensure((size_t)(n + p + q) * d);
+  ctx.h2d(s_point.p, h_point, (size_t)dv * d);
+  ctx.h2d(s_resid.p, h_res, (size_t)(n + p + q) * d);
+  m_rhs.ensure((size_t)MR * dv * d);
+  v_tmp.ensure((size_t)MR * dv * d);   // (also the keeper of dir_cent / dir_pred between the two pairs: v_res below)
+  Scal rs[MR], dsc[MR];
+  double rn[MR];
+  int ns = 0;
+  // (cent, pred)
+  build_rhs_pair(0, m_rhs.d(), s_point.d(), mu, tau, kap, tau_residual, nullptr, nullptr, reinterpret_cast<double*>(rs));
+  pair_solve_device(m_rhs.d(), rs, mu, tau, max_ref_steps, res_norm_cutoff, min_impr_tol, dsc, rn, &ns);
+  *n_solves += ns;
+  res_norms[0] = rn[0];
+  res_norms[1] = rn[1];
+  ctx.d2h(h_dirs, m_dir.d(), (size_t)MR * dv * d);
+  s_dirs.ensure((size_t)MR * dv * d);
+  ctx.d2d(s_dirs.p, m_dir.p, (size_t)MR * dv * d);
+  const double dtau[MR] = {dsc[0].tau, dsc[1].tau};
+  const Scal d01[MR] = {dsc[0], dsc[1]};
+  // (centadj, predadj)
+  build_rhs_pair(1, m_rhs.d(), s_point.d(), mu, tau, kap, tau_residual, s_dirs.d(), dtau, reinterpret_cast<double*>(rs));
+  ns = 0;
+  pair_solve_device(m_rhs.d(), rs, mu, tau, max_ref_steps, res_norm_cutoff, min_impr_tol, dsc, rn, &ns);
+  *n_solves += ns;
+  res_norms[2] = rn[0];
+  res_norms[3] = rn[1];
+  ctx.d2h(h_dirs + (long)MR * dv, m_dir.d(), (size_t)MR * dv * d);
   ctx.sync();
   for (int r = 0; r < MR; ++r) {
-    h_dirs[(long)r * dv + it] = dsc[r].tau;
-    h_dirs[(long)r * dv + ik] = dsc[r].kap;
+    h_dirs[(long)r * dv + it] = d01[r].tau;
+    h_dirs[(long)r * dv + ik] = d01[r].kap;
+    h_dirs[(long)(MR + r) * dv + it] = dsc[r].tau;
+    h_dirs[(long)(MR + r) * dv + ik] = dsc[r].kap;
   }
 }
 

@@ -76,6 +76,19 @@ struct SysSolver {
   int search_alpha(const double* pt, const double* d_cent, const double* d_pred, const double* d_centadj, const double* d_predadj,
                    bool unadj_only, bool cent_only, const double* sched, int nsched, int start, double min_prox, double prox_bound,
                    bool use_max_prox, double nup1, double* cand_out, double* prox_out, int* n_trials, int* n_loaded, double* irtmu_out);
+  // ---- the direction phase of CombinedStepper.step (steppers/combined.jl:60-95) in one call: update_lhs, the four
+  // right-hand sides of steppers/common.jl:7-118 built on the device, and the two paired solves.  h_point = current
+  // Point vector; h_res = [x_residual(n); y_residual(p); z_residual(q)] and tau_residual from calc_convergence_params;
+  // h_dirs receives dir_cent, dir_pred, dir_centadj, dir_predadj (4 Point vectors).  p = 0 only (callers fall back).
+  DBuf s_point, s_resid, s_dots, s_dirs;
+  double last_update_lhs_s = 0.0;   // wall seconds of the update_lhs part of the last step_directions call
+  void build_rhs_pair(int stage, double* rhs2, const double* d_point, double mu, double tau, double kap, double tau_residual,
+                      const double* d_dirs2, const double* dir_tau2, double* rs_flat /* 2 x (tau, kap) */);
+  void step_directions(const double* h_point, const double* h_res, double tau_residual, double mu, int max_ref_steps,
+                       double res_norm_cutoff, double min_impr_tol, double* h_dirs, double* res_norms, int* n_solves, int* use_sqrt_out,
+                       int* info, int* used_fallback, double* h_sol_const);
+  void pair_solve_device(double* rhs2, const Scal* rs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
+                         double min_impr_tol, Scal* dsc, double* res_norms, int* n_solves);
   // returns res_norm; dir / rhs are HOST Point vectors (common.jl:15-76)
   double get_directions(double* h_dir, const double* h_rhs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
                         double min_impr_tol, int* n_solves);

@@ -23,6 +23,12 @@ from .systemsolvers import QRCholDenseSystemSolver
 
 EPS = np.finfo(np.float64).eps
 
+
+def _env_on(name):
+    """experiment switches: set and not "0" """
+    v = os.environ.get(name)
+    return v is not None and v not in ("", "0")
+
 try:   # keep the host BLAS pool small inside the iteration loop: the driver's numpy calls are tiny, and a
     # large pool of spinning OpenBLAS workers starves the HIP runtime's own threads (measured: 3x slower)
     from threadpoolctl import ThreadpoolController as _ThreadpoolController
@@ -391,6 +397,7 @@ class CombinedStepper:
         self.dir_centadj = Point(model)
         self.dir_predadj = Point(model)
         self.dir_temp = np.zeros(self.rhs.vec.shape[0])
+        self.dirs4 = np.zeros((4, self.rhs.vec.shape[0]))  # dir_cent, dir_pred, dir_centadj, dir_predadj from the fused device call
         self.rhs2 = np.zeros((2, self.rhs.vec.shape[0]))   # the two right-hand sides / directions of a paired solve
         self.dir2 = np.zeros((2, self.rhs.vec.shape[0]))
         self.searcher = StepSearcher(model, **self.searcher_options)
@@ -403,10 +410,24 @@ class CombinedStepper:
         rhs, dir = self.rhs, self.dir
         T = time.perf_counter
 
-        t0 = T(); solver.syssolver.update_lhs(solver); solver.time_upsys += T() - t0
-
         sysv = solver.syssolver
-        if getattr(sysv, "native_directions", False) and hasattr(sysv, "get_directions2_native") and not os.environ.get("HYP_NO_PAIR"):
+        fused = (getattr(sysv, "native_directions", False) and hasattr(sysv, "step_directions_native") and model.p == 0
+                 and not _env_on("HYP_NO_PAIR") and not _env_on("HYP_NO_FUSED_STEP"))
+        if fused:   # update_lhs + the four right-hand sides + the two paired solves: one device call
+            lib_t0 = T()
+            ok = sysv.step_directions_native(solver, self)
+            dt = T() - lib_t0
+            up = sysv.last_update_lhs_seconds() if hasattr(sysv, "last_update_lhs_seconds") else 0.0
+            solver.time_upsys += up
+            solver.time_getdir += dt - up
+            if not ok:   # factorization failed: leave the decision to the unfused path (reference behaviour)
+                fused = False
+        if not fused:
+            t0 = T(); solver.syssolver.update_lhs(solver); solver.time_upsys += T() - t0
+
+        if fused:
+            pass
+        elif getattr(sysv, "native_directions", False) and hasattr(sysv, "get_directions2_native") and not _env_on("HYP_NO_PAIR"):
             # (cent, pred) and (centadj, predadj) are independent pairs: each pair is one device call in which
             # every pass over G, the factor and the cone matrices serves both right-hand sides
             r2, d2 = self.rhs2, self.dir2

@@ -85,7 +85,7 @@ class QRCholDenseSystemSolver:
         AA = np.asfortranarray(model.A, dtype=np.float64) if p > 0 else None
         L.check(lib.hyp_sys_load_model(h, L.vec_ptr(cc), L.vec_ptr(bb), L.vec_ptr(hh),
                                        AA.ctypes.data_as(c_vp) if AA is not None else None), "hyp_sys_load_model")
-        self.native_directions = not os.environ.get("HYP_NO_NATIVE")
+        self.native_directions = os.environ.get("HYP_NO_NATIVE", "0") in ("", "0")
         return self
 
     # y = alpha * op(G) x + beta * y on the device-resident model.G
@@ -119,6 +119,37 @@ class QRCholDenseSystemSolver:
         L.check(L.lib().hyp_sys_block_hess_prod(self._h, L.vec_ptr(self.rhs_const.z), L.vec_ptr(hh)), "hyp_sys_block_hess_prod")
         self.solve_subsystem3(solver, self.sol_const, self.rhs_const)
         return self
+
+    # ---- the direction phase of CombinedStepper.step in one call (p = 0): update_lhs + 4 right-hand sides + 2 paired solves
+    def step_directions_native(self, solver, stepper):
+        model = solver.model
+        nc = len(model.cones)
+        flags = (c_int * max(nc, 1))()
+        info, fb, ns = c_int(0), c_int(0), c_int(0)
+        resn = (ctypes.c_double * 4)()
+        resid = np.concatenate([solver.x_residual, solver.y_residual, solver.z_residual])
+        dirs4 = stepper.dirs4
+        L.check(L.lib().hyp_sys_step_directions(self._h, L.vec_ptr(solver.point.vec), L.vec_ptr(resid), float(solver.tau_residual), float(solver.mu),
+                                                int(solver.max_ref_steps), float(solver.res_norm_cutoff), 0.5, dirs4.ctypes.data_as(c_vp), resn,
+                                                ctypes.byref(ns), flags, ctypes.byref(info), ctypes.byref(fb), L.vec_ptr(self.sol_const.vec)),
+                "hyp_sys_step_directions")
+        self.use_sqrt_hess_cones = [bool(flags[k]) for k in range(nc)]
+        self.last_info, self.used_fallback = info.value, bool(fb.value)
+        if info.value != 0:
+            print("positive definite linear system factorization failed")
+            return False
+        for k, pt in enumerate((stepper.dir_cent, stepper.dir_pred, stepper.dir_centadj, stepper.dir_predadj)):
+            pt.vec[:] = dirs4[k]
+        solver.n_solves += ns.value
+        assert not any(np.isnan(resn[k]) for k in range(4))
+        if solver.max_ref_steps > 0:
+            solver.worst_dir_res = max(solver.worst_dir_res, *[resn[k] for k in range(4)])
+        return True
+
+    def last_update_lhs_seconds(self):
+        out = ctypes.c_double(0.0)
+        L.check(L.lib().hyp_sys_last_update_lhs_seconds(self._h, ctypes.byref(out)), "hyp_sys_last_update_lhs_seconds")
+        return out.value
 
     # ---- two independent right-hand sides per pass (hyp_sys_get_directions2)
     def get_directions2_native(self, solver, dirs2, rhss2, min_impr_tol=0.5):

@@ -133,6 +133,16 @@ int hyp_sys_get_directions2(hyp_sys* sys, double* dir_vecs, const double* rhs_ve
  * (scaled by irtmu) before the sweep stopped -- the host mirrors of exactly those cones must follow. */
 int hyp_sys_check_cone_points(hyp_sys* sys, const double* cand_ztsk, double min_prox, double prox_bound, int use_max_prox, double nup1,
                               int* accept, double* prox, int* n_loaded, double* irtmu);
+/* The direction phase of step(::CombinedStepper) (steppers/combined.jl:60-95) in one call, p = 0 (the default reduce = true
+ * path): update_lhs, the right-hand sides update_rhs_cent / _pred / _centadj / _predadj (steppers/common.jl:7-118) built on the
+ * device, and the two paired solves.  point_vec = solver.point.vec; residuals = [x_residual(n); y_residual(p); z_residual(q)] and
+ * tau_residual as left by calc_convergence_params (Solvers.jl:425-483); dir_vecs4 receives dir_cent, dir_pred, dir_centadj,
+ * dir_predadj (four Point vectors back to back), res_norms4 their residual norms; info != 0: the factorization failed. */
+int hyp_sys_step_directions(hyp_sys* sys, const double* point_vec, const double* residuals, double tau_residual, double mu, int max_ref_steps,
+                            double res_norm_cutoff, double min_impr_tol, double* dir_vecs4, double* res_norms4, int* n_solves,
+                            int* use_sqrt_hess_cones_out, int* info, int* used_fallback, double* sol_const_out /* n + p + q or NULL */);
+/* wall seconds the update_lhs part (solver.time_upsys) took inside the last hyp_sys_step_directions call */
+int hyp_sys_last_update_lhs_seconds(hyp_sys* sys, double* out);
 /* search_alpha (steppers/search.jl:46-69) for one stepper mode: forms each candidate exactly as update_stepper_points
  * (steppers/combined.jl:124-170) does -- all vectors are `ztsk` views [z(q); tau; s(q); kap] of the current point and of the
  * four directions -- and runs check_cone_points on it, from alpha_sched[start] on.  accepted_index = 0-based index of the first
