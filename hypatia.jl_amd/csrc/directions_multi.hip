@@ -20,16 +20,39 @@ __global__ __launch_bounds__(256) void gemv_t_multi_kernel(int m, double alpha, 
   __shared__ double red[NR][4];
   const int col = blockIdx.x;
   const double* a = A + (long)col * lda;
-  double s[NR][2];
+  double s[NR][4];
 #pragma unroll
-  for (int r = 0; r < NR; ++r) s[r][0] = s[r][1] = 0.0;
-  int i = threadIdx.x;
-  for (; i + 256 < m; i += 512) {
-    const double a0 = a[i], a1 = a[i + 256];
+  for (int r = 0; r < NR; ++r) s[r][0] = s[r][1] = s[r][2] = s[r][3] = 0.0;
+  int i = 0;
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  const bool wide = (((uintptr_t)a | (uintptr_t)X | ((uintptr_t)ldx * sizeof(double))) & 15) == 0;   // 16-byte pairs everywhere
+  if (wide) {   // two pairs (4 doubles) in flight per thread and iteration
+    const int nfull = m / 1024;       // whole 1024-row blocks: thread t takes the pairs at 2 t and 2 t + 512 of each
+    for (int b = 0; b < nfull; ++b) {
+      const int j = 1024 * b + 2 * threadIdx.x;
+      const d2_t a0 = *reinterpret_cast<const d2_t*>(a + j), a1 = *reinterpret_cast<const d2_t*>(a + j + 512);
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      s[r][0] += a0 * X[(long)r * ldx + i];
-      s[r][1] += a1 * X[(long)r * ldx + i + 256];
+      for (int r = 0; r < NR; ++r) {
+        const d2_t x0 = *reinterpret_cast<const d2_t*>(X + (long)r * ldx + j), x1 = *reinterpret_cast<const d2_t*>(X + (long)r * ldx + j + 512);
+        s[r][0] += a0.x * x0.x;
+        s[r][1] += a0.y * x0.y;
+        s[r][2] += a1.x * x1.x;
+        s[r][3] += a1.y * x1.y;
+      }
+    }
+    i = 1024 * nfull + threadIdx.x;   // the tail below is element-wise
+  } else {
+    i = threadIdx.x;
+    for (; i + 768 < m; i += 1024) {   // four independent column loads in flight per thread
+      const double a0 = a[i], a1 = a[i + 256], a2 = a[i + 512], a3 = a[i + 768];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const double* x = X + (long)r * ldx + i;
+        s[r][0] += a0 * x[0];
+        s[r][1] += a1 * x[256];
+        s[r][2] += a2 * x[512];
+        s[r][3] += a3 * x[768];
+      }
     }
   }
   for (; i < m; i += 256) {
@@ -39,7 +62,7 @@ __global__ __launch_bounds__(256) void gemv_t_multi_kernel(int m, double alpha, 
   }
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
-    double t = s[r][0] + s[r][1];
+    double t = (s[r][0] + s[r][1]) + (s[r][2] + s[r][3]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
     if ((threadIdx.x & 63) == 0) red[r][threadIdx.x >> 6] = t;
