@@ -411,14 +411,14 @@ __global__ void place_dinv_kernel(const double* __restrict__ dinv, long strideD,
 }
 
 void trtri_upper_batched(Ctx& c, int n, const double* U, long ldu, long strideU, const double* dinv, long strideD, double* Uinv,
-                         long ldi, long strideI, int batch) {
+                         long ldi, long strideI, int batch, DBuf* ws_override) {
   if (n <= 0 || batch <= 0) return;
   hipLaunchKernelGGL(place_dinv_kernel, dim3((n + 127) / 128, n, batch), dim3(128), 0, c.stream, dinv, strideD, Uinv, ldi, strideI, n);
   HYP_CHECK(hipGetLastError());
   const int nblk = (n + NB - 1) / NB;
   if (nblk == 1) return;
   // block column j: Uinv[0:j0, J] = -Uinv[0:j0, 0:j0] * (U[0:j0, J] * Dinv_J)
-  DBuf& ws = c.work_tri;
+  DBuf& ws = ws_override ? *ws_override : c.work_tri;
   ws.ensure((size_t)batch * n * NB * sizeof(double));
   for (int jb = 1; jb < nblk; ++jb) {
     const int j0 = jb * NB, nb = std::min(NB, n - j0);
@@ -484,12 +484,28 @@ void TriSolvePlan::build(Ctx& c, int n_, const double* U, long ldu, const double
   work.ensure((size_t)2 * sb * sizeof(double));
   const int nfull = n_ / sb, last = n_ - nfull * sb;
   const long strideU = (long)sb * (ldu + 1), strideD = (long)(sb / NB) * DINV_BLK;
+  // the two inversions (the full super-blocks as one batch, the shorter last one) are latency-bound chains of small
+  // GEMMs: the last block runs on the helper stream at the same time (own workspace)
+  const bool split = (nfull > 0 && last > 0);
+  hipEvent_t e0 = c.pool_event(200), e1 = c.pool_event(201);
+  if (split) {
+    work2.ensure((size_t)last * NB * sizeof(double));
+    HYP_CHECK(hipEventRecord(e0, c.stream));
+    HYP_CHECK(hipStreamWaitEvent(c.stream2, e0, 0));
+    std::swap(c.stream, c.stream2);
+    trtri_upper_batched(c, last, U + (long)nfull * strideU, ldu, 0, dinv + (long)nfull * strideD, 0, Binv.d() + nfull * blk, sb, 0, 1, &work2);
+    dev_transpose(c, last, last, Binv.d() + nfull * blk, sb, BinvT.d() + nfull * blk, sb, 1, 0, 0);
+    HYP_CHECK(hipEventRecord(e1, c.stream));
+    std::swap(c.stream, c.stream2);
+  }
   if (nfull > 0) trtri_upper_batched(c, sb, U, ldu, strideU, dinv, strideD, Binv.d(), sb, (long)blk, nfull);
-  if (last > 0)
+  if (!split && last > 0) {
     trtri_upper_batched(c, last, U + (long)nfull * strideU, ldu, 0, dinv + (long)nfull * strideD, 0, Binv.d() + nfull * blk, sb, 0, 1);
+    dev_transpose(c, last, last, Binv.d() + nfull * blk, sb, BinvT.d() + nfull * blk, sb, 1, 0, 0);
+  }
   if (nfull > 0) dev_transpose(c, sb, sb, Binv.d(), sb, BinvT.d(), sb, nfull, (long)blk, (long)blk);
-  if (last > 0) dev_transpose(c, last, last, Binv.d() + nfull * blk, sb, BinvT.d() + nfull * blk, sb, 1, 0, 0);
   dev_transpose(c, n_, n_, U, ldu, UT.d(), n_, 1, 0, 0);
+  if (split) HYP_CHECK(hipStreamWaitEvent(c.stream, e1, 0));
   n = n_;
 }
 

@@ -121,7 +121,7 @@ void trsm_upper_left(Ctx& c, int n, int nrhs, const double* U, long ldu, const d
 // factor itself (the result has substitution's backward error), then one rank-sb update of the rest.
 struct TriSolvePlan {
   int n = 0, sb = 0, refine = 2;
-  DBuf Binv, BinvT, UT, work;
+  DBuf Binv, BinvT, UT, work, work2;
   bool ready(int n_) const { return n == n_ && n_ > 0; }
   void invalidate() { n = 0; }
   void build(Ctx& c, int n_, const double* U, long ldu, const double* dinv);
@@ -134,7 +134,7 @@ void gemv_multi(Ctx& c, bool trans, int m, int n, int nr, double alpha, const do
 // explicit inverse of an upper triangular matrix from its inverted diagonal blocks: Uinv (upper, full
 // storage, strictly-lower part zero).  Used for the small cone matrices.
 void trtri_upper_batched(Ctx& c, int n, const double* U, long ldu, long strideU, const double* dinv, long strideD,
-                         double* Uinv, long ldi, long strideI, int batch);
+                         double* Uinv, long ldi, long strideI, int batch, DBuf* ws_override = nullptr);
 
 // y = alpha * op(A) x + beta * y, A m x n col-major.  Deterministic (fixed reduction tree).
 void gemv(Ctx& c, bool trans, int m, int n, double alpha, const double* A, long lda, const double* x, double beta,
