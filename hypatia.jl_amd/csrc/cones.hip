@@ -230,7 +230,36 @@ bool PsdCone::update_feas() {   // :80-90
   return is_feas_;
 }
 
+// The two feasibility Choleskys of a line-search candidate (smat(point), smat(dual_point)) are independent
+// latency-bound chains (2 diagonal-block kernels + panel + update each): run them side by side on the two streams
+// and read both LAPACK infos after one synchronisation.
+void PsdCone::prefetch_feas() {
+  if (feas_updated) return;
+  const size_t mb = (size_t)side * side * sizeof(double);
+  hipEvent_t e0 = ctx.pool_event(202), e1 = ctx.pool_event(203);
+  HYP_CHECK(hipEventRecord(e0, ctx.stream));                 // (the loads of point / dual_point were queued on the main stream)
+  HYP_CHECK(hipStreamWaitEvent(ctx.stream2, e0, 0));
+  std::swap(ctx.stream, ctx.stream2);
+  svec_unpack(ctx, side, 1, dual_point.d(), dim, tmpmat.d());
+  potrf_upper_batched(ctx, side, tmpmat.d(), side, 0, 1, nullptr, d_info.i() + 1);
+  ctx.d2h(ctx.h_info + 1, d_info.i() + 1, sizeof(int));
+  HYP_CHECK(hipEventRecord(e1, ctx.stream));
+  std::swap(ctx.stream, ctx.stream2);
+  svec_unpack(ctx, side, 1, point.d(), dim, X.d());
+  ctx.d2d(U.p, X.p, mb);
+  potrf_upper_batched(ctx, side, U.d(), side, 0, 1, nullptr, d_info.i());
+  ctx.d2h(ctx.h_info, d_info.i(), sizeof(int));
+  HYP_CHECK(hipStreamWaitEvent(ctx.stream, e1, 0));
+  ctx.sync();
+  is_feas_ = (ctx.h_info[0] == 0);
+  dual_feas_ = (ctx.h_info[1] == 0);
+  feas_updated = true;
+  dual_cached = true;
+  inv_ready = false;
+}
+
 bool PsdCone::is_dual_feas() {   // :92-95
+  if (dual_cached) return dual_feas_;
   svec_unpack(ctx, side, 1, dual_point.d(), dim, tmpmat.d());
   potrf_upper_batched(ctx, side, tmpmat.d(), side, 0, 1, nullptr, d_info.i() + 1);
   return read_info(ctx, d_info.i() + 1) == 0;

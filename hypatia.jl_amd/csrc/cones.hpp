@@ -37,6 +37,9 @@ struct Cone {
   // Cones.jl:56, 63, 71
   bool is_feas() { return feas_updated ? is_feas_ : update_feas(); }
   virtual bool is_dual_feas() { return true; }
+  // optional: start everything is_feas() and is_dual_feas() need at once (independent chains on the two streams);
+  // the line search calls it right after loading a candidate
+  virtual void prefetch_feas() {}
   const double* get_grad() {
     if (!grad_updated) update_grad();
     return grad.d();
@@ -98,11 +101,14 @@ struct PsdCone : Cone {   // src/Cones/possemideftri.jl (real symmetric)
   DBuf tmpmat, tmpmat2, d_info;
   DBuf ws1, ws2; // batched workspaces (chunk * side^2)
   bool inv_ready = false;   // Uinv / UinvT / Xinv computed for the current point
+  bool dual_cached = false, dual_feas_ = false;   // is_dual_feas() answered ahead of time by prefetch_feas()
   PsdCone(Ctx& c, int dim);
   void reset_data() override {
     Cone::reset_data();
     inv_ready = false;
+    dual_cached = false;
   }
+  void prefetch_feas() override;
   bool update_feas() override;
   bool is_dual_feas() override;
   void update_grad() override;

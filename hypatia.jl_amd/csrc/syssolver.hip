@@ -425,6 +425,7 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
     ck->load_point(prim, irtmu);
     ck->load_dual_point(dual);
     ck->reset_data();
+    ck->prefetch_feas();
     *n_loaded = (int)k + 1;
     bool in_prox = false;
     if (ck->is_feas() && ck->is_dual_feas() && ck->check_numerics()) {
