@@ -239,12 +239,13 @@ void PsdCone::prefetch_feas() {
   hipEvent_t e0 = ctx.pool_event(202), e1 = ctx.pool_event(203);
   HYP_CHECK(hipEventRecord(e0, ctx.stream));                 // (the loads of point / dual_point were queued on the main stream)
   HYP_CHECK(hipStreamWaitEvent(ctx.stream2, e0, 0));
-  std::swap(ctx.stream, ctx.stream2);
-  svec_unpack(ctx, side, 1, dual_point.d(), dim, tmpmat.d());
-  potrf_upper_batched(ctx, side, tmpmat.d(), side, 0, 1, nullptr, d_info.i() + 1);
-  ctx.d2h(ctx.h_info + 1, d_info.i() + 1, sizeof(int));
-  HYP_CHECK(hipEventRecord(e1, ctx.stream));
-  std::swap(ctx.stream, ctx.stream2);
+  {
+    StreamSwap on_helper(ctx);
+    svec_unpack(ctx, side, 1, dual_point.d(), dim, tmpmat.d());
+    potrf_upper_batched(ctx, side, tmpmat.d(), side, 0, 1, nullptr, d_info.i() + 1);
+    ctx.d2h(ctx.h_info + 1, d_info.i() + 1, sizeof(int));
+    HYP_CHECK(hipEventRecord(e1, ctx.stream));
+  }
   svec_unpack(ctx, side, 1, point.d(), dim, X.d());
   ctx.d2d(U.p, X.p, mb);
   potrf_upper_batched(ctx, side, U.d(), side, 0, 1, nullptr, d_info.i());
@@ -325,7 +326,8 @@ void PsdCone::two_sided(const double* R, int kr2, int kr3, double* prod, long ld
 
 bool PsdCone::use_fused(int ncols) const {
   static const bool enabled = [] { const char* e = getenv("HYP_PSD_FUSED"); return !(e && e[0] == '0'); }();
-  return enabled && ncols >= 4 && psd_two_sided_fused_ok(side);
+  static const int min_cols = [] { const char* e = getenv("HYP_PSD_FUSED_MIN"); return e ? atoi(e) : 4; }();
+  return enabled && ncols >= min_cols && psd_two_sided_fused_ok(side);
 }
 
 void PsdCone::hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) {   // :126-142  X^-1 V X^-1

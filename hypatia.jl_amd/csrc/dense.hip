@@ -492,11 +492,12 @@ void TriSolvePlan::build(Ctx& c, int n_, const double* U, long ldu, const double
     work2.ensure((size_t)last * NB * sizeof(double));
     HYP_CHECK(hipEventRecord(e0, c.stream));
     HYP_CHECK(hipStreamWaitEvent(c.stream2, e0, 0));
-    std::swap(c.stream, c.stream2);
-    trtri_upper_batched(c, last, U + (long)nfull * strideU, ldu, 0, dinv + (long)nfull * strideD, 0, Binv.d() + nfull * blk, sb, 0, 1, &work2);
-    dev_transpose(c, last, last, Binv.d() + nfull * blk, sb, BinvT.d() + nfull * blk, sb, 1, 0, 0);
-    HYP_CHECK(hipEventRecord(e1, c.stream));
-    std::swap(c.stream, c.stream2);
+    {
+      StreamSwap on_helper(c);
+      trtri_upper_batched(c, last, U + (long)nfull * strideU, ldu, 0, dinv + (long)nfull * strideD, 0, Binv.d() + nfull * blk, sb, 0, 1, &work2);
+      dev_transpose(c, last, last, Binv.d() + nfull * blk, sb, BinvT.d() + nfull * blk, sb, 1, 0, 0);
+      HYP_CHECK(hipEventRecord(e1, c.stream));
+    }
   }
   if (nfull > 0) trtri_upper_batched(c, sb, U, ldu, strideU, dinv, strideD, Binv.d(), sb, (long)blk, nfull);
   if (!split && last > 0) {

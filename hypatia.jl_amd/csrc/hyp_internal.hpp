@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <string>
 #include <vector>
+#include <utility>
 #include <stdexcept>
 #include "gemm_f64.hpp"
 
@@ -93,6 +94,16 @@ struct Ctx {
   void zero(void* dst, size_t bytes) {
     if (bytes) HYP_CHECK(hipMemsetAsync(dst, 0, bytes, stream));
   }
+};
+
+// Run a section on the helper stream: every launcher takes the stream from ctx.stream, so the two members are
+// exchanged for the lifetime of the guard (restored on scope exit, also when a HIP error throws).
+struct StreamSwap {
+  Ctx& c;
+  explicit StreamSwap(Ctx& ctx) : c(ctx) { std::swap(c.stream, c.stream2); }
+  ~StreamSwap() { std::swap(c.stream, c.stream2); }
+  StreamSwap(const StreamSwap&) = delete;
+  StreamSwap& operator=(const StreamSwap&) = delete;
 };
 
 // ---------------------------------------------------------------------------------------------
