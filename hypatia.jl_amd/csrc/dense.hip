@@ -50,7 +50,8 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
   // Look-ahead (one big matrix): after the panel solve of step k, the main stream only updates block
   // row k+1 of the trailing matrix (all the next diagonal / panel step needs); the rest of the rank-128
   // update runs on the helper stream underneath the next diagonal-block kernel, which is pure latency.
-  const bool lookahead = (batch == 1 && nblk >= 6);
+  static const int la_env = [] { const char* e = getenv("HYP_POTRF_LOOKAHEAD"); return e ? atoi(e) : 1; }();
+  const bool lookahead = (la_env != 0 && batch == 1 && nblk >= 6);
   for (int kb = 0; kb < nblk; ++kb) {
     const int k0 = kb * NB;
     const int nb = std::min(NB, n - k0);

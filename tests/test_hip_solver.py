@@ -197,3 +197,61 @@ def test_paired_directions_match_single(name, reduce):
         scale = np.linalg.norm(singles[k])
         # (1e-8: near-converged iterates have directions ~1e-6 while the intermediates of the 6x6 reduction are O(1))
         assert np.linalg.norm(st.dir2[k] - singles[k]) <= 1e-8 * scale, (name, k)
+
+
+@pytest.mark.parametrize("name", ["possemideftri2", "epinormspectral3_3x4_dual", "wsosinterpnonnegative2", "nonnegative4"])
+def test_fused_step_directions_match_unfused(name):
+    """hyp_sys_step_directions (update_lhs + right-hand sides built on the device + two paired solves) against the same
+    step composed from update_lhs, the host right-hand-side builders and hyp_sys_get_directions2."""
+    import hypatia_jl_amd as H
+    from hypatia_jl_amd import solvers as HS
+    from oracle import instances as I
+    inst = I.KNOWN_ANSWER[name]()
+    hs = H.Solver(iter_limit=3)
+    hs.load(H.make_model(inst)); hs.solve()
+    if hs.model.p != 0:
+        pytest.skip("fused step is the reduced-model path")
+    st, sysv = hs.stepper, hs.syssolver
+    hs.calc_convergence_params()
+    hs.res_norm_cutoff = 1e-4 * max(hs.x_norm_res, hs.y_norm_res, hs.z_norm_res, hs.tau_feas)
+    assert sysv.step_directions_native(hs, st)
+    fused = [d.vec.copy() for d in (st.dir_cent, st.dir_pred, st.dir_centadj, st.dir_predadj)]
+    # unfused composition at the same state
+    sysv.update_lhs(hs)
+    HS.update_rhs_cent(hs, st.rhs); st.rhs2[0] = st.rhs.vec
+    HS.update_rhs_pred(hs, st.rhs); st.rhs2[1] = st.rhs.vec
+    st._pair(hs, st.dir_cent, st.dir_pred)
+    HS.update_rhs_centadj(hs, st.rhs, st.dir_cent); st.rhs2[0] = st.rhs.vec
+    HS.update_rhs_predadj(hs, st.rhs, st.dir_pred); st.rhs2[1] = st.rhs.vec
+    st._pair(hs, st.dir_centadj, st.dir_predadj)
+    unf = [d.vec.copy() for d in (st.dir_cent, st.dir_pred, st.dir_centadj, st.dir_predadj)]
+    for k in range(4):
+        scale = np.linalg.norm(unf[k]) + 1e-300
+        assert np.linalg.norm(fused[k] - unf[k]) <= 1e-8 * scale + 1e-14, (name, k, np.linalg.norm(fused[k] - unf[k]) / scale)
+
+
+def test_native_search_alpha_matches_host_walk():
+    """hyp_sys_search_alpha (candidates formed natively, whole schedule in one call) against the host walk of the
+    alpha schedule through hyp_sys_check_cone_points, from the same iterate and directions."""
+    import hypatia_jl_amd as H
+    from hypatia_jl_amd import solvers as HS
+    from oracle import instances as I
+    inst = I.psd_blocks(60, [10, 8, 3], seed=2)
+    hs = H.Solver(iter_limit=4)
+    hs.load(H.make_model(inst)); hs.solve()
+    st, sysv = hs.stepper, hs.syssolver
+    hs.calc_convergence_params()
+    hs.res_norm_cutoff = 1e-4 * max(hs.x_norm_res, hs.y_norm_res, hs.z_norm_res, hs.tau_feas)
+    assert sysv.step_directions_native(hs, st)
+    st.unadj_only = st.cent_only = False
+    a_native = sysv.search_alpha_native(hs.model, hs.point, st, 1)
+    prox_native = st.searcher.prox
+    # host walk
+    a_host = 0.0
+    for alpha in st.searcher.alpha_sched:
+        st.update_stepper_points(alpha, hs.point, True)
+        if sysv.check_cone_points_native(hs.model, st.temp, st.searcher):
+            a_host = alpha
+            break
+    assert a_native == a_host and a_native > 0
+    assert abs(prox_native - st.searcher.prox) <= 1e-9 * (1 + prox_native)
