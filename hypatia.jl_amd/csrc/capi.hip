@@ -455,6 +455,17 @@ int hyp_sys_step_directions(hyp_sys* sys, const double* point_vec, const double*
                           use_sqrt_out, info, used_fallback, sol_const_out);
   API_END(sys->ctx)
 }
+int hyp_sys_set_comm(hyp_sys* sys, int (*allreduce)(void* user, long count, int op), void* user, void* device_staging, long capacity_doubles) {
+  API_BEGIN
+  SysSolver* s = sys->s;
+  HYP_REQUIRE(allreduce == nullptr || (device_staging != nullptr && capacity_doubles >= (long)s->nmp * s->nmp),
+              "set_comm: the staging buffer must hold the n x n Schur matrix");
+  s->comm_fn = allreduce;
+  s->comm_user = user;
+  s->comm_stage = (double*)device_staging;
+  s->comm_cap = capacity_doubles;
+  API_END(sys->ctx)
+}
 int hyp_sys_last_update_lhs_seconds(hyp_sys* sys, double* out) {
   API_BEGIN
   *out = sys->s->last_update_lhs_s;

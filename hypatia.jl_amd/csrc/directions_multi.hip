@@ -233,7 +233,14 @@ void SysSolver::solve3_multi(double* sol, const double* rhs, int nr) {
   HYP_REQUIRE(p == 0, "solve3_multi: p = 0 only");
   if (sol != rhs) ctx.d2d(sol, rhs, (size_t)nr * ld3 * d);
   // x <- lhs^-1 (x + G' z)
-  gemv_multi(ctx, true, q, n, nr, 1.0, G.d(), q, sol + n, ld3, 1.0, sol, ld3);
+  if (dist()) {   // sum the ranks' partial G' z, then add the replicated x once
+    m_t.ensure((size_t)nr * n * d);
+    gemv_multi(ctx, true, q, n, nr, 1.0, G.d(), q, sol + n, ld3, 0.0, m_t.d(), n);
+    allreduce_dev(m_t.d(), (long)nr * n, 0);
+    for (int r = 0; r < nr; ++r) dev_axpby(ctx, n, 1.0, m_t.d() + (long)r * n, 1.0, sol + r * ld3);
+  } else {
+    gemv_multi(ctx, true, q, n, nr, 1.0, G.d(), q, sol + n, ld3, 1.0, sol, ld3);
+  }
   if (tri.ready(nmp)) {
     tri.solve_multi(ctx, lhs_fact.d(), nmp, true, sol, ld3, nr);
     tri.solve_multi(ctx, lhs_fact.d(), nmp, false, sol, ld3, nr);
@@ -331,6 +338,12 @@ void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double
   }
   ctx.d2h(ctx.h_pinned, ds, 2 * MR * d);
   ctx.sync();
+  if (dist()) {   // h' z over all ranks' rows
+    double hz[MR] = {ctx.h_pinned[1], ctx.h_pinned[3]};
+    allreduce_host(hz, MR, 0);
+    ctx.h_pinned[1] = hz[0];
+    ctx.h_pinned[3] = hz[1];
+  }
   for (int r = 0; r < MR; ++r) {
     const double dot_sub = ctx.h_pinned[2 * r] + ctx.h_pinned[2 * r + 1];
     const double sol_tau = (rs[r].tau + rs[r].kap + dot_sub) / (mu / taubar / taubar - dot_const);
@@ -360,7 +373,14 @@ void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double
       dev_axpby(ctx, q, -1.0, dir + (long)r * dv + os, 1.0, rr + oz);
       dev_axpby(ctx, q, -1.0, m_Gxd.d() + (long)r * q, 1.0, rr + oz);
     }
-    gemv_multi(ctx, true, q, n, MR, 1.0, G.d(), q, dir + oz, dv, 1.0, res, dv);
+    if (dist()) {
+      m_t.ensure((size_t)MR * n * d);
+      gemv_multi(ctx, true, q, n, MR, 1.0, G.d(), q, dir + oz, dv, 0.0, m_t.d(), n);
+      allreduce_dev(m_t.d(), (long)MR * n, 0);
+      for (int r = 0; r < MR; ++r) dev_axpby(ctx, n, 1.0, m_t.d() + (long)r * n, 1.0, res + (long)r * dv);
+    } else {
+      gemv_multi(ctx, true, q, n, MR, 1.0, G.d(), q, dir + oz, dv, 1.0, res, dv);
+    }
     for (size_t k = 0; k < cones.size(); ++k) {   // res.s_k = H_k prim_dir_k + dual_dir_k
       Cone* ck = cones[k];
       const int o = offs[k], dk = ck->dim;
@@ -375,6 +395,20 @@ void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double
     }
     ctx.d2h(ctx.h_pinned, ds, 16 * d);
     ctx.sync();
+    if (dist()) {
+      double hz[MR] = {ctx.h_pinned[1], ctx.h_pinned[3]};
+      allreduce_host(hz, MR, 0);
+      ctx.h_pinned[1] = hz[0];
+      ctx.h_pinned[3] = hz[1];
+      double v[2 * MR];   // residual norms: max over the ranks, NaN flags first
+      for (int r = 0; r < MR; ++r) {
+        const double m = ctx.h_pinned[8 + r];
+        v[r] = (m != m) ? 1.0 : 0.0;
+        v[MR + r] = (m != m) ? 0.0 : m;
+      }
+      allreduce_host(v, 2 * MR, 1);
+      for (int r = 0; r < MR; ++r) ctx.h_pinned[8 + r] = (v[r] > 0.5) ? __builtin_nan("") : v[MR + r];
+    }
     for (int r = 0; r < MR; ++r) {
       rsc[r].tau = -ctx.h_pinned[2 * r] - ctx.h_pinned[2 * r + 1] - dsc[r].kap - rs[r].tau;
       rsc[r].kap = mu / taubar * dsc[r].tau / taubar + dsc[r].kap - rs[r].kap;

@@ -67,6 +67,24 @@ void SysSolver::load(const double* hG, const double* hGQ1, const double* hGQ2, c
   ctx.sync();
 }
 
+void SysSolver::allreduce_dev(double* d_buf, long count, int op) {
+  if (!comm_fn || count <= 0) return;
+  HYP_REQUIRE(count <= comm_cap, "sys: all-reduce payload exceeds the registered staging buffer");
+  ctx.d2d(comm_stage, d_buf, (size_t)count * sizeof(double));
+  ctx.sync();
+  HYP_REQUIRE(comm_fn(comm_user, count, op) == 0, "sys: all-reduce callback failed");
+  ctx.d2d(d_buf, comm_stage, (size_t)count * sizeof(double));
+}
+void SysSolver::allreduce_host(double* h_buf, int count, int op) {
+  if (!comm_fn || count <= 0) return;
+  HYP_REQUIRE(count <= comm_cap, "sys: all-reduce payload exceeds the registered staging buffer");
+  ctx.h2d(comm_stage, h_buf, (size_t)count * sizeof(double));
+  ctx.sync();
+  HYP_REQUIRE(comm_fn(comm_user, count, op) == 0, "sys: all-reduce callback failed");
+  ctx.d2h(h_buf, comm_stage, (size_t)count * sizeof(double));
+  ctx.sync();
+}
+
 void SysSolver::block_hess_prod_vec(double* d_out, const double* d_in) {   // qrchol.jl:87-98
   for (size_t k = 0; k < cones.size(); ++k) {
     Cone* ck = cones[k];
@@ -122,6 +140,7 @@ void SysSolver::assemble_lhs() {   // qrchol.jl:214-246 (this process's cones on
     g.alpha = 1; g.beta = 1; g.tri = GEMM_UPPER; g.krange = KR_ALL; g.batch = 1;
     gemm(ctx, true, g);
   }
+  if (dist()) allreduce_dev(lhs.d(), (long)nmp * nmp, 0);   // the one large exchange: sum of the ranks' Schur contributions
 }
 
 void SysSolver::factor_lhs(int* info, int* used_fallback) {   // qrchol.jl:249-250
@@ -179,8 +198,15 @@ void SysSolver::solve3(double* d_sol, const double* d_rhs) {   // qrchol.jl:39-8
   double* z = d_sol + n + p;
   double* t = QpbxGHbz.d();
   // t = Q' (x + G' z)                                                   :51-53
-  ctx.d2d(t, x, (size_t)n * d);
-  gemv(ctx, true, q, n, 1.0, G.d(), q, z, 1.0, t);
+  if (dist()) {   // G = this rank's rows: sum the partial G' z over the ranks, then add the (replicated) x once
+    HYP_REQUIRE(p == 0, "sys: the sharded path assumes the reduced model (p = 0)");
+    gemv(ctx, true, q, n, 1.0, G.d(), q, z, 0.0, t);
+    allreduce_dev(t, n, 0);
+    dev_axpby(ctx, n, 1.0, x, 1.0, t);
+  } else {
+    ctx.d2d(t, x, (size_t)n * d);
+    gemv(ctx, true, q, n, 1.0, G.d(), q, z, 1.0, t);
+  }
   if (p > 0) {
     gemv(ctx, true, n, n, 1.0, Qm.d(), n, t, 0.0, tmpn.d());
     ctx.d2d(t, tmpn.p, (size_t)n * d);
@@ -282,7 +308,9 @@ void SysSolver::update_const() {
   dev_dot(ctx, q, mh.d(), sol_const.d() + n + p, ds + 2);
   ctx.d2h(ctx.h_pinned, ds, 3 * sizeof(double));
   ctx.sync();
-  dot_const = ctx.h_pinned[0] + (p > 0 ? ctx.h_pinned[1] : 0.0) + ctx.h_pinned[2];
+  double hz = ctx.h_pinned[2];
+  if (dist()) allreduce_host(&hz, 1, 0);   // h' z runs over all ranks' rows; c' x is replicated
+  dot_const = ctx.h_pinned[0] + (p > 0 ? ctx.h_pinned[1] : 0.0) + hz;
 }
 
 SysSolver::Scal SysSolver::solve_system(double* sol, const double* rhs, Scal rs, double mu, double taubar) {
@@ -313,7 +341,9 @@ SysSolver::Scal SysSolver::solve_system(double* sol, const double* rhs, Scal rs,
   dev_dot(ctx, q, mh.d(), ss + oz, ds + 2);
   ctx.d2h(ctx.h_pinned, ds, 3 * d);
   ctx.sync();
-  const double dot_sub = ctx.h_pinned[0] + (p > 0 ? ctx.h_pinned[1] : 0.0) + ctx.h_pinned[2];
+  double hz_sub = ctx.h_pinned[2];
+  if (dist()) allreduce_host(&hz_sub, 1, 0);
+  const double dot_sub = ctx.h_pinned[0] + (p > 0 ? ctx.h_pinned[1] : 0.0) + hz_sub;
   const double tau_num = rs.tau + rs.kap + dot_sub;
   const double tau_denom = mu / taubar / taubar - dot_const;
   const double sol_tau = tau_num / tau_denom;
@@ -339,8 +369,14 @@ SysSolver::Scal SysSolver::apply_lhs(double* res, const double* dir, Scal ds_, d
   const int oz = n + p, os = n + p + q + 1;
   const double tau_dir = ds_.tau, kap_dir = ds_.kap;
   // res.x = c tau + G' z (+ A' y)
-  dev_scale_copy(ctx, n, tau_dir, mc.d(), res);
-  gemv(ctx, true, q, n, 1.0, G.d(), q, dir + oz, 1.0, res);
+  if (dist()) {
+    gemv(ctx, true, q, n, 1.0, G.d(), q, dir + oz, 0.0, res);
+    allreduce_dev(res, n, 0);
+    dev_axpby(ctx, n, tau_dir, mc.d(), 1.0, res);
+  } else {
+    dev_scale_copy(ctx, n, tau_dir, mc.d(), res);
+    gemv(ctx, true, q, n, 1.0, G.d(), q, dir + oz, 1.0, res);
+  }
   // res.z = h tau - s - G x
   dev_scale_copy(ctx, q, tau_dir, mh.d(), res + oz);
   dev_axpby(ctx, q, -1.0, dir + os, 1.0, res + oz);
@@ -366,8 +402,10 @@ SysSolver::Scal SysSolver::apply_lhs(double* res, const double* dir, Scal ds_, d
   if (p > 0) dev_dot(ctx, p, mb.d(), dir + n, dsc + 2);
   ctx.d2h(ctx.h_pinned + 8, dsc, 3 * d);
   ctx.sync();
+  double hz_dir = ctx.h_pinned[9];
+  if (dist()) allreduce_host(&hz_dir, 1, 0);
   Scal out;
-  out.tau = -ctx.h_pinned[8] - ctx.h_pinned[9] - kap_dir - (p > 0 ? ctx.h_pinned[10] : 0.0);
+  out.tau = -ctx.h_pinned[8] - hz_dir - kap_dir - (p > 0 ? ctx.h_pinned[10] : 0.0);
   out.kap = mu / taubar * tau_dir / taubar + kap_dir;
   return out;
 }
@@ -384,10 +422,11 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
   const double kap = h[2 * q + 1];
   const double proxsqr_bound = prox_bound * prox_bound;
   const double taukap = tau * kap;
-  if (std::min(std::min(tau, kap), taukap) < EPS) return false;                     // search.jl:86-88
+  if (std::min(std::min(tau, kap), taukap) < EPS) return false;                     // search.jl:86-88 (tau, kap: same on every rank)
   const size_t nc = cones.size();
   std::vector<double> szk(nc);
   double szsum = 0.0;
+  bool ok = true;
   for (size_t k = 0; k < nc; ++k) {                                                   // :90-95
     const double* a = hz + offs[k];
     const double* b = hs + offs[k];
@@ -397,9 +436,18 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
     for (; i + 3 < dk; i += 4) { d0 += a[i] * b[i]; d1 += a[i + 1] * b[i + 1]; d2 += a[i + 2] * b[i + 2]; d3 += a[i + 3] * b[i + 3]; }
     for (; i < dk; ++i) d0 += a[i] * b[i];
     szk[k] = (d0 + d1) + (d2 + d3);
-    if (szk[k] < EPS) return false;
+    if (szk[k] < EPS) ok = false;
     szsum += szk[k];
   }
+  // (sharded: this rank's cones only -- every decision below is taken on all-reduced quantities, so that all
+  //  ranks leave through the same exit and issue the same sequence of collectives)
+  if (dist()) {
+    double v[2] = {szsum, ok ? 0.0 : 1.0};
+    allreduce_host(v, 2, 0);
+    szsum = v[0];
+    ok = (v[1] < 0.5);
+  }
+  if (!ok) return false;
   const double mu = (szsum + taukap) / nup1;                                          // :97-100
   if (mu < EPS) return false;
   const double taukap_rel = taukap / mu;                                              // :102-108
@@ -409,15 +457,21 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
   for (size_t k = 0; k < nc; ++k) {                                                   // :110-116
     const double nu_k = cones[k]->nu;
     const double rel = szk[k] / (mu * nu_k);
-    if (rel < min_prox || nu_k * (rel - 1.0) * (rel - 1.0) > proxsqr_bound) return false;
+    if (rel < min_prox || nu_k * (rel - 1.0) * (rel - 1.0) > proxsqr_bound) ok = false;
   }
+  if (dist()) {
+    double v = ok ? 0.0 : 1.0;
+    allreduce_host(&v, 1, 0);
+    ok = (v < 0.5);
+  }
+  if (!ok) return false;
   const double irtmu = 1.0 / std::sqrt(mu);
   *irtmu_out = irtmu;
   cand_d.ensure((size_t)(2 * q + 2) * sizeof(double));
   ctx.h2d(cand_d.p, h, (size_t)(2 * q + 2) * sizeof(double));
   const double* dz = cand_d.d();
   const double* dsv = cand_d.d() + q + 1;
-  double agg = taukap_proxsqr;
+  double agg = dist() ? 0.0 : taukap_proxsqr;
   for (size_t k = 0; k < nc; ++k) {                                                   // :118-136
     Cone* ck = cones[k];
     const double* prim = ck->use_dual_barrier ? dz + offs[k] : dsv + offs[k];
@@ -431,10 +485,25 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
     if (ck->is_feas() && ck->is_dual_feas() && ck->check_numerics()) {
       const double pk = ck->get_proxsqr(irtmu, use_max_prox);
       agg = use_max_prox ? std::max(agg, pk) : agg + pk;
-      in_prox = agg < proxsqr_bound;
+      in_prox = dist() ? true : (agg < proxsqr_bound);   // (sharded: the bound is applied to the all-reduced aggregate)
     }
-    if (!in_prox) return false;
+    if (!in_prox) {
+      ok = false;
+      break;
+    }
   }
+  if (dist()) {
+    double v[2] = {ok ? 0.0 : 1.0, agg};   // [any failure, proximity aggregate]
+    if (use_max_prox) {
+      allreduce_host(v, 2, 1);             // one MAX serves both
+    } else {
+      allreduce_host(v, 2, 0);             // SUM: failures count, proximities add
+    }
+    ok = (v[0] < 0.5);
+    agg = use_max_prox ? std::max(taukap_proxsqr, v[1]) : taukap_proxsqr + v[1];
+    if (ok) ok = (agg < proxsqr_bound);
+  }
+  if (!ok) return false;
   *prox_out = std::sqrt(agg);
   return true;
 }
@@ -481,7 +550,12 @@ double SysSolver::residual(double* res, const double* dir, const double* rhs, Sc
   hipLaunchKernelGGL(sub_absmax_kernel, dim3(1), dim3(1024), 0, ctx.stream, dimv(), res, rhs, ctx.dscal.d() + 8);
   ctx.d2h(ctx.h_pinned + 16, ctx.dscal.d() + 8, d);
   ctx.sync();
-  const double m = ctx.h_pinned[16];
+  double m = ctx.h_pinned[16];
+  if (dist()) {   // max over the ranks' rows (NaN on any rank must win: max of a flag, then of the value)
+    double v[2] = {(m != m) ? 1.0 : 0.0, (m != m) ? 0.0 : m};
+    allreduce_host(v, 2, 1);
+    m = (v[0] > 0.5) ? __builtin_nan("") : v[1];
+  }
   if (m != m || rsc.tau != rsc.tau || rsc.kap != rsc.kap) return __builtin_nan("");
   return std::max(m, std::max(std::fabs(rsc.tau), std::fabs(rsc.kap)));
 }

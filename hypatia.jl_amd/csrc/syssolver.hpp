@@ -39,6 +39,19 @@ struct SysSolver {
   void potrs(double* d_x);                                                     // x <- lhs^-1 x with the current factor (:66-69)
   void solve3(double* d_sol, const double* d_rhs);                             // qrchol.jl:39-85
 
+  // ---- multi-GPU (cone sharding): this solver then holds only ITS rank's cones and rows of G (z / s vectors are the
+  // local rows, x-space vectors are replicated).  At the exchange points -- the Schur sum, G' z, the scalar products
+  // over z, the residual norm, the line-search flags -- the payload is copied into a device staging buffer owned by
+  // the host framework (a torch tensor) and `comm_fn` all-reduces it in place over RCCL.  Unset: single GPU.
+  typedef int (*CommFn)(void* user, long count, int op);   // op 0 sum, 1 max, 2 min; returns 0 on success
+  CommFn comm_fn = nullptr;
+  void* comm_user = nullptr;
+  double* comm_stage = nullptr;
+  long comm_cap = 0;
+  bool dist() const { return comm_fn != nullptr; }
+  void allreduce_dev(double* d_buf, long count, int op);
+  void allreduce_host(double* h_buf, int count, int op);
+
   // ---- device-resident direction solves (systemsolvers/common.jl:15-182): the 6x6 system of one
   // stepper direction, reduced 6 -> 4 -> 3 on the device, with the reference's iterative refinement.
   // Vectors use the Point layout [x(n); y(p); z(q); tau; s(q); kap]; tau / kap travel as host scalars.

@@ -299,7 +299,132 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
         self.last_info, self.used_fallback = 0, False
         self._ql = np.zeros(self.rows.shape[0])
         self._ql2 = np.zeros(self.rows.shape[0])
+        self._install_native(model)
         return self
+
+    # ---- device-resident distributed step: the rank's hyp_sys runs the fused native routines on ITS rows and
+    # cones; at the exchange points it calls back here and the payload (already in a torch device tensor) is
+    # all-reduced in place over RCCL.  HYP_DIST_NATIVE=0 keeps the host-composed path.
+    native_directions = False
+    native_caps = frozenset()
+
+    def _install_native(self, model):
+        import os
+        self._hooked = False
+        if not isinstance(self.local, HipLocalSys) or self.comm.device != "cuda" or os.environ.get("HYP_DIST_NATIVE", "1") in ("0",):
+            return
+        import ctypes
+        torch, dist = self.comm.torch, self.comm.dist
+        n = self.n
+        self._stage = torch.empty(max(n * n, 1024), dtype=torch.float64, device="cuda")
+        ops = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MAX, 2: dist.ReduceOp.MIN}
+        comm, stage = self.comm, self._stage
+
+        def _allreduce(user, count, op):
+            try:
+                dist.all_reduce(stage[:count], op=ops[op])
+                torch.cuda.synchronize()
+                comm.n_collectives += 1
+                return 0
+            except Exception as e:   # never let an exception cross the C boundary
+                print("all-reduce callback failed:", e)
+                return 1
+
+        self._cb = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_int)(_allreduce)
+        lib, h = L.lib(), self.local._h
+        L.check(lib.hyp_sys_set_comm(h, ctypes.cast(self._cb, ctypes.c_void_p), None, ctypes.c_void_p(stage.data_ptr()), int(stage.numel())),
+                "hyp_sys_set_comm")
+        cc = np.ascontiguousarray(model.c, dtype=np.float64)
+        hl = np.ascontiguousarray(model.h[self.rows], dtype=np.float64)
+        bb = np.zeros(1)
+        L.check(lib.hyp_sys_load_model(h, L.vec_ptr(cc), L.vec_ptr(bb), L.vec_ptr(hl), None), "hyp_sys_load_model")
+        self._hooked = True
+        self.native_directions = True
+        self.native_caps = frozenset({"fused", "search"})
+        self.cand_in_temp = False
+        self._ql_n = self.rows.shape[0]
+
+    def _local_ztsk(self, pt):
+        return np.concatenate([pt.z[self.rows], [pt.tau], pt.s[self.rows], [pt.kap]])
+
+    def step_directions_native(self, solver, stepper):
+        import ctypes
+        model, rows, n, ql = solver.model, self.rows, self.n, self._ql_n
+        c_int = ctypes.c_int
+        pt = solver.point
+        vec_l = np.concatenate([pt.x, pt.z[rows], [pt.tau], pt.s[rows], [pt.kap]])
+        res_l = np.concatenate([solver.x_residual, solver.z_residual[rows]])
+        dv_l = n + 2 * ql + 2
+        dirs_l = np.zeros((4, dv_l))
+        nc_l = len(model.local_ks)
+        flags = (c_int * max(nc_l, 1))()
+        info, fb, ns = c_int(0), c_int(0), c_int(0)
+        resn = (ctypes.c_double * 4)()
+        L.check(L.lib().hyp_sys_step_directions(self.local._h, L.vec_ptr(vec_l), L.vec_ptr(res_l), float(solver.tau_residual), float(solver.mu),
+                                                int(solver.max_ref_steps), float(solver.res_norm_cutoff), 0.5,
+                                                dirs_l.ctypes.data_as(ctypes.c_void_p), resn, ctypes.byref(ns), flags, ctypes.byref(info),
+                                                ctypes.byref(fb), None), "hyp_sys_step_directions")
+        self.last_info, self.used_fallback = info.value, bool(fb.value)
+        if info.value != 0:
+            print("positive definite linear system factorization failed")
+            return False
+        # global z / s parts of the four directions: every rank contributes its rows, one all-reduce
+        q = self.q
+        zs = np.zeros((4, 2 * q))
+        for k in range(4):
+            zs[k, rows] = dirs_l[k, n:n + ql]
+            zs[k, q + rows] = dirs_l[k, n + ql + 1:n + 2 * ql + 1]
+        self.comm.allreduce(zs)
+        for k, d in enumerate((stepper.dir_cent, stepper.dir_pred, stepper.dir_centadj, stepper.dir_predadj)):
+            d.x[:] = dirs_l[k, :n]
+            d.z[:] = zs[k, :q]
+            d.s[:] = zs[k, q:]
+            d.tau = dirs_l[k, n + ql]
+            d.kap = dirs_l[k, -1]
+        solver.n_solves += ns.value
+        assert not any(np.isnan(resn[k]) for k in range(4))
+        if solver.max_ref_steps > 0:
+            solver.worst_dir_res = max(solver.worst_dir_res, *[resn[k] for k in range(4)])
+        return True
+
+    def last_update_lhs_seconds(self):
+        import ctypes
+        out = ctypes.c_double(0.0)
+        L.check(L.lib().hyp_sys_last_update_lhs_seconds(self.local._h, ctypes.byref(out)), "hyp_sys_last_update_lhs_seconds")
+        return out.value
+
+    def search_alpha_native(self, model, point, stepper, sched):
+        import ctypes
+        c_int = ctypes.c_int
+        searcher = stepper.searcher
+        sc = np.ascontiguousarray(searcher.alpha_sched, dtype=np.float64)
+        ql = self._ql_n
+        loc = [self._local_ztsk(p) for p in (point, stepper.dir_cent, stepper.dir_pred, stepper.dir_centadj, stepper.dir_predadj)]
+        cand = np.zeros(2 * ql + 2)
+        idx, nt, nl = c_int(-1), c_int(0), c_int(0)
+        prox, irtmu = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        L.check(L.lib().hyp_sys_search_alpha(
+            self.local._h, L.vec_ptr(loc[0]), L.vec_ptr(loc[1]), L.vec_ptr(loc[2]), L.vec_ptr(loc[3]), L.vec_ptr(loc[4]),
+            int(stepper.unadj_only), int(stepper.cent_only), L.vec_ptr(sc), len(sc), int(sched - 1), float(searcher.min_prox),
+            float(searcher.prox_bound), int(bool(searcher.use_max_prox)), float(searcher.nup1), L.vec_ptr(cand), ctypes.byref(idx),
+            ctypes.byref(prox), ctypes.byref(nt), ctypes.byref(nl), ctypes.byref(irtmu)), "hyp_sys_search_alpha")
+        searcher.n_trials += nt.value
+        # host mirrors of this rank's cones follow the last candidate they were loaded with
+        off = 0
+        for j, k in enumerate(model.local_ks):
+            cone = model.cones[k].local
+            dk = cone.dim
+            if j < nl.value:
+                zk, sk = cand[off:off + dk], cand[ql + 1 + off:ql + 1 + off + dk]
+                prim, dual = (zk, sk) if cone.use_dual_barrier() else (sk, zk)
+                cone._mirror_loaded(prim, irtmu.value, dual)
+            off += dk
+        if idx.value >= 0:
+            searcher.prox = prox.value
+            searcher.prev_sched = idx.value + 1
+            return float(sc[idx.value])
+        searcher.prev_sched = len(sc) + 1
+        return 0.0
 
     # y = alpha op(G) x + beta y over ALL rows: local row-block product + one all-reduce
     def mul_G(self, trans, x, alpha=1.0, beta=0.0, y=None):
@@ -326,8 +451,9 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
         return out_full
 
     def update_lhs_fact(self, solver):
-        self.local.assemble_lhs()        # sum over this rank's cones
-        self.local.allreduce_lhs()       # the one large exchange: n x n, sum, f64
+        self.local.assemble_lhs()        # sum over this rank's cones (with the native hook installed: already all-reduced)
+        if not getattr(self, "_hooked", False):
+            self.local.allreduce_lhs()   # the one large exchange: n x n, sum, f64
         self.last_info, self.used_fallback = self.local.factor_lhs()
         if self.last_info != 0:
             print("positive definite linear system factorization failed")

@@ -24,6 +24,15 @@ from .systemsolvers import QRCholDenseSystemSolver
 EPS = np.finfo(np.float64).eps
 
 
+def _cap(sysv, what):
+    """which device-resident routines a system solver offers (single-GPU solver: all; sharded solver: the fused step
+    and the schedule walk, on its local rows)"""
+    if not getattr(sysv, "native_directions", False):
+        return False
+    caps = getattr(sysv, "native_caps", None)
+    return True if caps is None else (what in caps)
+
+
 def _env_on(name):
     """experiment switches: set and not "0" """
     v = os.environ.get(name)
@@ -149,7 +158,7 @@ def get_directions(stepper, solver, min_impr_tol=0.5):   # common.jl:15-76
     res_norm_cutoff = solver.res_norm_cutoff
     max_ref_steps = solver.max_ref_steps
 
-    if getattr(syssolver, "native_directions", False):   # the whole routine on the device (hyp_sys_get_directions)
+    if _cap(syssolver, "single"):   # the whole routine on the device (hyp_sys_get_directions)
         res_norm, ns = syssolver.get_directions_native(solver, dir, rhs, min_impr_tol)
         solver.n_solves += ns
         assert not np.isnan(res_norm)
@@ -305,7 +314,7 @@ def search_alpha(point, model, stepper, sched=None):   # search.jl:46-69
     if sched is None:
         sched = stepper.start_sched(searcher)
     sysv = getattr(stepper, "syssolver", None)
-    if sysv is not None and getattr(sysv, "native_directions", False) and hasattr(sysv, "search_alpha_native"):
+    if sysv is not None and _cap(sysv, "search"):
         return sysv.search_alpha_native(model, point, stepper, sched)   # the whole schedule walk in one device call
     while sched <= len(searcher.alpha_sched):
         alpha = searcher.alpha_sched[sched - 1]
@@ -323,7 +332,7 @@ def check_cone_points(model, stepper):   # search.jl:74-138
     searcher = stepper.searcher
     cand = stepper.temp
     sysv = getattr(stepper, "syssolver", None)
-    if sysv is not None and getattr(sysv, "native_directions", False):   # one C-ABI call for the whole test
+    if sysv is not None and _cap(sysv, "check"):   # one C-ABI call for the whole test
         return sysv.check_cone_points_native(model, cand, searcher)
     szk = searcher.szk
     cones = model.cones
@@ -411,8 +420,7 @@ class CombinedStepper:
         T = time.perf_counter
 
         sysv = solver.syssolver
-        fused = (getattr(sysv, "native_directions", False) and hasattr(sysv, "step_directions_native") and model.p == 0
-                 and not _env_on("HYP_NO_PAIR") and not _env_on("HYP_NO_FUSED_STEP"))
+        fused = (_cap(sysv, "fused") and model.p == 0 and not _env_on("HYP_NO_PAIR") and not _env_on("HYP_NO_FUSED_STEP"))
         if fused:   # update_lhs + the four right-hand sides + the two paired solves: one device call
             lib_t0 = T()
             ok = sysv.step_directions_native(solver, self)
@@ -427,7 +435,7 @@ class CombinedStepper:
 
         if fused:
             pass
-        elif getattr(sysv, "native_directions", False) and hasattr(sysv, "get_directions2_native") and not _env_on("HYP_NO_PAIR"):
+        elif _cap(sysv, "pair") and not _env_on("HYP_NO_PAIR"):
             # (cent, pred) and (centadj, predadj) are independent pairs: each pair is one device call in which
             # every pass over G, the factor and the cone matrices serves both right-hand sides
             r2, d2 = self.rhs2, self.dir2
@@ -474,7 +482,7 @@ class CombinedStepper:
                         return False
         self.update_stepper_points(alpha, point, False)
         sysv = solver.syssolver
-        if getattr(sysv, "native_directions", False) and hasattr(sysv, "search_alpha_native"):
+        if _cap(sysv, "search") and getattr(sysv, "cand_in_temp", True):
             point.ztsk[:] = self.temp.ztsk   # exactly the accepted candidate the cones were loaded with (formed natively)
         self.prev_alpha = alpha
         return True

@@ -141,6 +141,14 @@ int hyp_sys_check_cone_points(hyp_sys* sys, const double* cand_ztsk, double min_
 int hyp_sys_step_directions(hyp_sys* sys, const double* point_vec, const double* residuals, double tau_residual, double mu, int max_ref_steps,
                             double res_norm_cutoff, double min_impr_tol, double* dir_vecs4, double* res_norms4, int* n_solves,
                             int* use_sqrt_hess_cones_out, int* info, int* used_fallback, double* sol_const_out /* n + p + q or NULL */);
+/* Multi-GPU (one process per GPU, cones sharded): the hyp_sys of a rank is created over ITS cones and its rows of G only;
+ * z / s vectors passed to the calls below are the local rows, x-space vectors are replicated.  At every exchange point
+ * (the n x n Schur sum once per iteration; G' z, the scalar products over z, the residual norm and the line-search flags
+ * per solve / trial) the library copies the payload into `device_staging` (a device buffer owned by the caller's
+ * communication framework, >= n*n doubles) and calls allreduce(user, count, op) -- op 0 sum, 1 max, 2 min -- which must
+ * all-reduce the first `count` doubles of that buffer IN PLACE over all ranks (RCCL) and return 0.  Every rank issues the
+ * same sequence of calls.  allreduce = NULL restores single-GPU behaviour.  (qrchol.jl:219-246, search.jl:118-134) */
+int hyp_sys_set_comm(hyp_sys* sys, int (*allreduce)(void* user, long count, int op), void* user, void* device_staging, long capacity_doubles);
 /* wall seconds the update_lhs part (solver.time_upsys) took inside the last hyp_sys_step_directions call */
 int hyp_sys_last_update_lhs_seconds(hyp_sys* sys, double* out);
 /* search_alpha (steppers/search.jl:46-69) for one stepper mode: forms each candidate exactly as update_stepper_points

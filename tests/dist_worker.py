@@ -87,6 +87,7 @@ def run(rank, world, port, inst_args, out_path, backend="oracle"):
         solver.solve()
         if rank == 0:
             np.savez(out_path, status=solver.status, iters=solver.num_iters, p_obj=solver.primal_obj, d_obj=solver.dual_obj,
-                     x=solver.get_x(), s=solver.get_s(), z=solver.get_z(), ncoll=comm.n_collectives)
+                     x=solver.get_x(), s=solver.get_s(), z=solver.get_z(), ncoll=comm.n_collectives,
+                     hooked=bool(getattr(solver.syssolver, "_hooked", False)), worst_dir_res=solver.worst_dir_res)
     finally:
         dist.destroy_process_group()

@@ -13,7 +13,15 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.timeout(600)
-def test_sharded_hip_solve_matches_oracle():
+@pytest.mark.parametrize("native", ["1", "0"])
+def test_sharded_hip_solve_matches_oracle(native, monkeypatch):
+    """native = 1: every rank runs the fused device routines on its rows / cones and the library calls back for the
+    all-reduces (hyp_sys_set_comm); native = 0: the host-composed distributed driver."""
+    monkeypatch.setenv("HYP_DIST_NATIVE", native)
+    _run_sharded(native)
+
+
+def _run_sharded(native):
     import dist_worker
     from oracle import instances as I
     from oracle.build import make_model
@@ -32,6 +40,7 @@ def test_sharded_hip_solve_matches_oracle():
     ref = OSolver(verbose=False)
     ref.load(make_model(I.psd_blocks(*inst_args)))
     ref.solve()
+    assert bool(res["hooked"]) == (native == "1")
     assert str(res["status"]) == ref.status == "Optimal"
     assert abs(int(res["iters"]) - ref.num_iters) <= 1
     assert abs(float(res["p_obj"]) - ref.primal_obj) <= 1e-7 * (1 + abs(ref.primal_obj))
