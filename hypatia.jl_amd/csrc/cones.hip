@@ -233,30 +233,42 @@ bool PsdCone::update_feas() {   // :80-90
 // The two feasibility Choleskys of a line-search candidate (smat(point), smat(dual_point)) are independent
 // latency-bound chains (2 diagonal-block kernels + panel + update each): run them side by side on the two streams
 // and read both LAPACK infos after one synchronisation.
-void PsdCone::prefetch_feas() {
-  if (feas_updated) return;
+bool PsdCone::prefetch_launch(int slot) {
+  if (feas_updated || slot < 0 || 64 + 2 * slot + 1 >= 8192) return false;
   const size_t mb = (size_t)side * side * sizeof(double);
-  hipEvent_t e0 = ctx.pool_event(202), e1 = ctx.pool_event(203);
+  int* hi = ctx.h_info + 64 + 2 * slot;
+  hipEvent_t e0 = ctx.pool_event(202);
   HYP_CHECK(hipEventRecord(e0, ctx.stream));                 // (the loads of point / dual_point were queued on the main stream)
   HYP_CHECK(hipStreamWaitEvent(ctx.stream2, e0, 0));
   {
     StreamSwap on_helper(ctx);
     svec_unpack(ctx, side, 1, dual_point.d(), dim, tmpmat.d());
     potrf_upper_batched(ctx, side, tmpmat.d(), side, 0, 1, nullptr, d_info.i() + 1);
-    ctx.d2h(ctx.h_info + 1, d_info.i() + 1, sizeof(int));
-    HYP_CHECK(hipEventRecord(e1, ctx.stream));
+    ctx.d2h(hi + 1, d_info.i() + 1, sizeof(int));
   }
   svec_unpack(ctx, side, 1, point.d(), dim, X.d());
   ctx.d2d(U.p, X.p, mb);
   potrf_upper_batched(ctx, side, U.d(), side, 0, 1, nullptr, d_info.i());
-  ctx.d2h(ctx.h_info, d_info.i(), sizeof(int));
-  HYP_CHECK(hipStreamWaitEvent(ctx.stream, e1, 0));
-  ctx.sync();
-  is_feas_ = (ctx.h_info[0] == 0);
-  dual_feas_ = (ctx.h_info[1] == 0);
+  ctx.d2h(hi, d_info.i(), sizeof(int));
+  return true;
+}
+
+void PsdCone::prefetch_finish(int slot) {
+  const int* hi = ctx.h_info + 64 + 2 * slot;
+  is_feas_ = (hi[0] == 0);
+  dual_feas_ = (hi[1] == 0);
   feas_updated = true;
   dual_cached = true;
   inv_ready = false;
+}
+
+void PsdCone::prefetch_feas() {
+  if (!prefetch_launch(0)) return;
+  hipEvent_t e1 = ctx.pool_event(203);
+  HYP_CHECK(hipEventRecord(e1, ctx.stream2));
+  HYP_CHECK(hipStreamWaitEvent(ctx.stream, e1, 0));
+  ctx.sync();
+  prefetch_finish(0);
 }
 
 bool PsdCone::is_dual_feas() {   // :92-95

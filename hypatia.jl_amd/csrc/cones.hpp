@@ -40,6 +40,11 @@ struct Cone {
   // optional: start everything is_feas() and is_dual_feas() need at once (independent chains on the two streams);
   // the line search calls it right after loading a candidate
   virtual void prefetch_feas() {}
+  // the same in two halves, so that a sweep over many cones queues ALL their chains before the one synchronisation:
+  // prefetch_launch(slot) queues the work and the read-back of its flags into pinned words 64 + 2 slot (+1);
+  // prefetch_finish(slot) (after ctx.sync() and a wait for the helper stream) takes them over.  Default: nothing queued.
+  virtual bool prefetch_launch(int slot) { (void)slot; return false; }
+  virtual void prefetch_finish(int slot) { (void)slot; }
   const double* get_grad() {
     if (!grad_updated) update_grad();
     return grad.d();
@@ -109,6 +114,8 @@ struct PsdCone : Cone {   // src/Cones/possemideftri.jl (real symmetric)
     dual_cached = false;
   }
   void prefetch_feas() override;
+  bool prefetch_launch(int slot) override;
+  void prefetch_finish(int slot) override;
   bool update_feas() override;
   bool is_dual_feas() override;
   void update_grad() override;

@@ -476,6 +476,8 @@ static void coldot(Ctx& c, int m, int ncols, int mode, const double* M, long ld,
 void TriSolvePlan::build(Ctx& c, int n_, const double* U, long ldu, const double* dinv) {
   n = 0;
   sb = c.trsv_sb;
+  static const int refine_env = [] { const char* e = getenv("HYP_TRSV_REFINE"); return e ? atoi(e) : -1; }();
+  if (refine_env >= 0) refine = refine_env;
   if (sb <= 0 || n_ <= 0) return;
   const int nsb = (n_ + sb - 1) / sb;
   const size_t blk = (size_t)sb * sb;
@@ -791,7 +793,7 @@ Ctx::Ctx(int dev) : device(dev) {
   scratch.alloc(1 << 20);
   dscal.alloc(64 * sizeof(double));
   for (int i = 0; i < 6; ++i) HYP_CHECK(hipEventCreate(&ev[i]));
-  HYP_CHECK(hipHostMalloc((void**)&h_info, 64 * sizeof(int), hipHostMallocDefault));
+  HYP_CHECK(hipHostMalloc((void**)&h_info, 8192 * sizeof(int), hipHostMallocDefault));   // [0..63] general; [64 + 2 k, 64 + 2 k + 1] cone k of a batched feasibility sweep
   h_pinned_n = 1 << 16;
   HYP_CHECK(hipHostMalloc((void**)&h_pinned, h_pinned_n * sizeof(double), hipHostMallocDefault));
 }

@@ -472,15 +472,36 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
   const double* dz = cand_d.d();
   const double* dsv = cand_d.d() + q + 1;
   double agg = dist() ? 0.0 : taukap_proxsqr;
+  // With several cones, the feasibility work of ALL of them is queued first (two chains per cone on the two
+  // streams) and one synchronisation collects every flag; the reference's sweep (:118-136) visits the cones in
+  // order and stops at the first failure, which only the points loaded beyond it could tell apart -- and nothing
+  // reads those before the next candidate reloads them.
+  std::vector<char> launched(nc, 0);
+  if (nc > 1) {
+    for (size_t k = 0; k < nc; ++k) {
+      Cone* ck = cones[k];
+      ck->load_point((ck->use_dual_barrier ? dz : dsv) + offs[k], irtmu);
+      ck->load_dual_point((ck->use_dual_barrier ? dsv : dz) + offs[k]);
+      ck->reset_data();
+      launched[k] = ck->prefetch_launch((int)k) ? 1 : 0;
+    }
+    hipEvent_t e1 = ctx.pool_event(203);
+    HYP_CHECK(hipEventRecord(e1, ctx.stream2));
+    HYP_CHECK(hipStreamWaitEvent(ctx.stream, e1, 0));
+    ctx.sync();
+    for (size_t k = 0; k < nc; ++k)
+      if (launched[k]) cones[k]->prefetch_finish((int)k);
+    *n_loaded = (int)nc;
+  }
   for (size_t k = 0; k < nc; ++k) {                                                   // :118-136
     Cone* ck = cones[k];
-    const double* prim = ck->use_dual_barrier ? dz + offs[k] : dsv + offs[k];
-    const double* dual = ck->use_dual_barrier ? dsv + offs[k] : dz + offs[k];
-    ck->load_point(prim, irtmu);
-    ck->load_dual_point(dual);
-    ck->reset_data();
-    ck->prefetch_feas();
-    *n_loaded = (int)k + 1;
+    if (nc == 1) {
+      ck->load_point((ck->use_dual_barrier ? dz : dsv) + offs[k], irtmu);
+      ck->load_dual_point((ck->use_dual_barrier ? dsv : dz) + offs[k]);
+      ck->reset_data();
+      ck->prefetch_feas();
+      *n_loaded = 1;
+    }
     bool in_prox = false;
     if (ck->is_feas() && ck->is_dual_feas() && ck->check_numerics()) {
       const double pk = ck->get_proxsqr(irtmu, use_max_prox);
