@@ -237,7 +237,7 @@ bool PsdCone::prefetch_launch(int slot) {
   if (feas_updated || slot < 0 || 64 + 2 * slot + 1 >= 8192) return false;
   const size_t mb = (size_t)side * side * sizeof(double);
   int* hi = ctx.h_info + 64 + 2 * slot;
-  hipEvent_t e0 = ctx.pool_event(202);
+  hipEvent_t e0 = ctx.aux_event(2);
   HYP_CHECK(hipEventRecord(e0, ctx.stream));                 // (the loads of point / dual_point were queued on the main stream)
   HYP_CHECK(hipStreamWaitEvent(ctx.stream2, e0, 0));
   {
@@ -264,7 +264,7 @@ void PsdCone::prefetch_finish(int slot) {
 
 void PsdCone::prefetch_feas() {
   if (!prefetch_launch(0)) return;
-  hipEvent_t e1 = ctx.pool_event(203);
+  hipEvent_t e1 = ctx.aux_event(3);
   HYP_CHECK(hipEventRecord(e1, ctx.stream2));
   HYP_CHECK(hipStreamWaitEvent(ctx.stream, e1, 0));
   ctx.sync();

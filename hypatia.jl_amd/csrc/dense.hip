@@ -33,6 +33,11 @@ static void potrf_step_gemms(Ctx& c, hipStream_t st, int nb, int M, int N, const
   HYP_CHECK(gemm_f64_launch(st, true, s));
 }
 
+hipEvent_t Ctx::aux_event(int i) {
+  if (!aux[i]) HYP_CHECK(hipEventCreateWithFlags(&aux[i], hipEventDisableTiming));
+  return aux[i];
+}
+
 hipEvent_t Ctx::pool_event(size_t i) {
   while (ev_pool.size() <= i) {
     hipEvent_t e;
@@ -490,7 +495,7 @@ void TriSolvePlan::build(Ctx& c, int n_, const double* U, long ldu, const double
   // the two inversions (the full super-blocks as one batch, the shorter last one) are latency-bound chains of small
   // GEMMs: the last block runs on the helper stream at the same time (own workspace)
   const bool split = (nfull > 0 && last > 0);
-  hipEvent_t e0 = c.pool_event(200), e1 = c.pool_event(201);
+  hipEvent_t e0 = c.aux_event(0), e1 = c.aux_event(1);
   if (split) {
     work2.ensure((size_t)last * NB * sizeof(double));
     HYP_CHECK(hipEventRecord(e0, c.stream));
@@ -803,6 +808,8 @@ Ctx::~Ctx() {
   if (h_info) (void)hipHostFree(h_info);
   if (h_pinned) (void)hipHostFree(h_pinned);
   for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : aux)
+    if (e) (void)hipEventDestroy(e);
   if (stream2) (void)hipStreamDestroy(stream2);
   if (stream) (void)hipStreamDestroy(stream);
 }

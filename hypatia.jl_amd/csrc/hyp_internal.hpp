@@ -71,6 +71,8 @@ struct Ctx {
   hipStream_t stream2 = nullptr;            // helper stream: look-ahead trailing updates of the blocked Cholesky
   std::vector<hipEvent_t> ev_pool;          // ordering events between stream and stream2
   hipEvent_t pool_event(size_t i);
+  hipEvent_t aux[4] = {nullptr, nullptr, nullptr, nullptr};   // fork / join events of the two-stream sections (not the look-ahead pool)
+  hipEvent_t aux_event(int i);
   DBuf scratch;       // general device scratch (gemv partial sums)
   DBuf dscal;         // 64 device doubles for scalar results (dots, counts)
   DBuf stage_a, stage_b;   // device staging for host-pointer entry points

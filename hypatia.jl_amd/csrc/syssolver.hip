@@ -485,7 +485,7 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
       ck->reset_data();
       launched[k] = ck->prefetch_launch((int)k) ? 1 : 0;
     }
-    hipEvent_t e1 = ctx.pool_event(203);
+    hipEvent_t e1 = ctx.aux_event(3);
     HYP_CHECK(hipEventRecord(e1, ctx.stream2));
     HYP_CHECK(hipStreamWaitEvent(ctx.stream, e1, 0));
     ctx.sync();
