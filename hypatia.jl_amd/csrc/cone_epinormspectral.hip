@@ -246,6 +246,7 @@ void EpiNormSpectralCone::update_hess_aux() {   // :152-170
 }
 
 void EpiNormSpectralCone::update_hess() {   // :172-209
+  ensure_hess_storage(false);
   if (!hess_aux_updated) update_hess_aux();
   hipLaunchKernelGGL(ens_hess_kernel, dim3((dim + 127) / 128, dim), dim3(128), 0, ctx.stream, d1, d2, Zi.d(), tau.d(), WtauI.d(), HuW.d(), Huu,
                      H.d(), (long)dim);

@@ -142,6 +142,7 @@ struct GenericHessCone : Cone {
   bool use_hess_prod_slow = false, use_hess_prod_slow_updated = false;
   GenericHessCone(Ctx& c, int kind) : Cone(c, kind) {}
   void alloc_generic();
+  void ensure_hess_storage(bool with_fact);   // explicit Hessian (and its factor) on first use
   void reset_data() override {
     Cone::reset_data();
     use_hess_prod_slow = use_hess_prod_slow_updated = false;

@@ -50,11 +50,19 @@ static int read_info(Ctx& ctx, const int* d_info) {
 // ---------------------------------------------------------------------------------------------
 // GenericHessCone
 // ---------------------------------------------------------------------------------------------
-void GenericHessCone::alloc_generic() {
+// The dim x dim explicit Hessian and its factor are allocated on first use: the closed-form oracles of a large cone
+// (EpiNormSpectral 500 x 500: dim = 250 001, an explicit Hessian of 500 GB) work without them, exactly as in the
+// reference, where only `inv_hess_prod!` / `check_numerics` / `get_proxsqr` reach the generic explicit path.
+void GenericHessCone::ensure_hess_storage(bool with_fact) {
   const size_t mb = (size_t)dim * dim * sizeof(double);
-  H.alloc(mb);
-  Hfact.alloc(mb);
-  Hdinv.alloc(dinv_elems(dim) * sizeof(double));
+  H.ensure(mb);
+  if (with_fact) {
+    Hfact.ensure(mb);
+    Hdinv.ensure(dinv_elems(dim) * sizeof(double));
+  }
+}
+
+void GenericHessCone::alloc_generic() {
   Hinfo.alloc(64);
   tmpd.alloc((size_t)dim * sizeof(double));
   tmpd2.alloc((size_t)dim * sizeof(double));
@@ -63,6 +71,7 @@ void GenericHessCone::alloc_generic() {
 bool GenericHessCone::update_hess_fact() {   // Cones.jl:239-251: posdef_fact_copy!(hess_fact_mat, hess, false)
   if (hess_fact_updated) return hess_fact_ok;
   if (!hess_updated) update_hess();
+  ensure_hess_storage(true);
   ctx.d2d(Hfact.p, H.p, (size_t)dim * dim * sizeof(double));
   potrf_upper_batched(ctx, dim, Hfact.d(), dim, 0, 1, Hdinv.d(), Hinfo.i());
   // Cholesky only: the reference's Bunch-Kaufman second attempt is not on the device;
@@ -207,6 +216,7 @@ void WsosCone::update_grad() {   // :119-133
 }
 
 void WsosCone::update_hess() {   // :135-150: H = sum_k (LFLP_k' LFLP_k) .^ 2
+  ensure_hess_storage(false);
   get_grad();
   for (int k = 0; k < K; ++k) {
     GemmArgs g{};
