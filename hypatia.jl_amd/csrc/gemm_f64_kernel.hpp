@@ -115,38 +115,24 @@ void gemm_f64_kernel(GemmArgs p) {
       return;
     }
 
-    // General (edge / unaligned) loader.  Loads are unconditional on clamped indices and out-of-range
-    // elements are zeroed by a MULTIPLY with a 0 / 1 mask: with a select the compiler sinks each load
-    // under its predicate and waits for every single one (2 REPS serial round trips per K tile).
+    // General (edge / unaligned) loader.  Loads are unconditional on clamped indices; out-of-range elements are
+    // zeroed by a MULTIPLY with a 0 / 1 mask in store_tiles, AFTER the MFMAs of the current tile.  (With a select
+    // the compiler sinks each load under its predicate and waits for every single one; with the multiply right
+    // here it waits for the loads before the MFMA block: either way the prefetch is lost.)
     const int klast = kend - 1;
     if (TRANSA) {
-      const int k = k0 + lk;
-      const int kc = min(k, klast);
-      const double kmask = (k < kend) ? 1.0 : 0.0;
+      const int kc = min(k0 + lk, klast);
 #pragma unroll
-      for (int rep = 0; rep < REPS; ++rep) {
-        const int m = m0 + lr + 16 * rep;
-        ra[rep] = A[(long)min(m, p.M - 1) * p.lda + kc] * ((m < p.M) ? kmask : 0.0);
-      }
+      for (int rep = 0; rep < REPS; ++rep) ra[rep] = A[(long)min(m0 + lr + 16 * rep, p.M - 1) * p.lda + kc];
     } else {
-      const int m = m0 + nn_r;
-      const int mc = min(m, p.M - 1);
-      const double mmask = (m < p.M) ? 1.0 : 0.0;
+      const int mc = min(m0 + nn_r, p.M - 1);
 #pragma unroll
-      for (int rep = 0; rep < REPS; ++rep) {
-        const int k = k0 + nn_k + NN_KSTEP * rep;
-        ra[rep] = A[(long)min(k, klast) * p.lda + mc] * ((k < kend) ? mmask : 0.0);
-      }
+      for (int rep = 0; rep < REPS; ++rep) ra[rep] = A[(long)min(k0 + nn_k + NN_KSTEP * rep, klast) * p.lda + mc];
     }
     {
-      const int k = k0 + lk;
-      const int kc = min(k, klast);
-      const double kmask = (k < kend) ? 1.0 : 0.0;
+      const int kc = min(k0 + lk, klast);
 #pragma unroll
-      for (int rep = 0; rep < REPS; ++rep) {
-        const int n = n0 + lr + 16 * rep;
-        rb[rep] = B[(long)min(n, p.N - 1) * p.ldb + kc] * ((n < p.N) ? kmask : 0.0);
-      }
+      for (int rep = 0; rep < REPS; ++rep) rb[rep] = B[(long)min(n0 + lr + 16 * rep, p.N - 1) * p.ldb + kc];
     }
   };
 
@@ -157,15 +143,18 @@ void gemm_f64_kernel(GemmArgs p) {
     }
     double* As = lds[buf][0];
     double* Bs = lds[buf][1];
+    const double kmask = (k0 + lk < kend) ? 1.0 : 0.0;
     if (TRANSA) {
 #pragma unroll
-      for (int rep = 0; rep < REPS; ++rep) As[(lr + 16 * rep) * LDS_S + lk] = ra[rep];
+      for (int rep = 0; rep < REPS; ++rep) As[(lr + 16 * rep) * LDS_S + lk] = ra[rep] * ((m0 + lr + 16 * rep < p.M) ? kmask : 0.0);
     } else {
+      const double mmask = (m0 + nn_r < p.M) ? 1.0 : 0.0;
 #pragma unroll
-      for (int rep = 0; rep < REPS; ++rep) As[nn_r * LDS_S + nn_k + NN_KSTEP * rep] = ra[rep];
+      for (int rep = 0; rep < REPS; ++rep)
+        As[nn_r * LDS_S + nn_k + NN_KSTEP * rep] = ra[rep] * ((k0 + nn_k + NN_KSTEP * rep < kend) ? mmask : 0.0);
     }
 #pragma unroll
-    for (int rep = 0; rep < REPS; ++rep) Bs[(lr + 16 * rep) * LDS_S + lk] = rb[rep];
+    for (int rep = 0; rep < REPS; ++rep) Bs[(lr + 16 * rep) * LDS_S + lk] = rb[rep] * ((n0 + lr + 16 * rep < p.N) ? kmask : 0.0);
   };
 
   const int fr = lane & 15, fk = lane >> 4;
