@@ -29,11 +29,10 @@
 namespace hyp {
 
 constexpr int TS_THREADS = 256;
-constexpr int TS_BT = 7;                      // MFMA tiles per workgroup-tile edge (112 rows / columns)
-constexpr int TS_WR = 2;                      // tile rows per wavefront: w and w + 4
 constexpr int TS_LDK = 18;                    // LDS row stride (16 k + 2): conflict-free b64 fragment reads
-constexpr int TS_NREP = TS_BT;                // staged elements per thread per operand per K block (112 * 16 / 256)
-constexpr int TS_OPSZ = 16 * TS_BT * TS_LDK;  // doubles per operand per buffer
+// BT = MFMA tiles per workgroup-tile edge (template parameter).  Smaller tiles re-read operands from L2 more often but
+// leave room for 3 - 4 resident workgroups per CU, which hides the staging / barrier latency of this short-K kernel:
+// measured on 3000 matrices of side 200 (pass 1 / pass 2, us): BT 7: 1233 / 1103, BT 5: 1271 / 824, BT 4: 1100 / 977, BT 3: 1085 / 700.
 
 struct TsArgs {
   int s, T, rstruct;          // side, ceil(side / 16), 0 full / 1 upper / 2 lower triangular R
@@ -62,8 +61,11 @@ __device__ __forceinline__ void ts_block_range(int T, int nb, int b, int& t0, in
   cnt = base + (b < extra ? 1 : 0);
 }
 
-template <int PASS>
-__global__ __launch_bounds__(TS_THREADS, 2) void psd_ts_kernel(TsArgs p) {
+template <int PASS, int TS_BT>
+__global__ __launch_bounds__(TS_THREADS, (TS_BT <= 4 ? 4 : (TS_BT <= 5 ? 3 : 2))) void psd_ts_kernel(TsArgs p) {
+  constexpr int TS_WR = (TS_BT + 3) / 4;        // tile rows per wavefront: w, w + 4
+  constexpr int TS_NREP = TS_BT;                // staged elements per thread per operand per K block (16 BT * 16 / 256)
+  constexpr int TS_OPSZ = 16 * TS_BT * TS_LDK;  // doubles per operand per buffer
   __shared__ double lds[2][2][TS_OPSZ];   // [buffer][A / B][row * LDK + k]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -219,17 +221,29 @@ __global__ __launch_bounds__(TS_THREADS, 2) void psd_ts_kernel(TsArgs p) {
 bool psd_two_sided_fused_ok(int side) { return side >= 1 && side <= 2048; }
 
 // prod[:, j] = svec(R' smat(arr[:, j]) R), j < ncols.  zws: ncols * side^2 doubles.  arr may alias prod.
+template <int PASS>
+static void ts_launch(Ctx& c, TsArgs a, int bt) {
+  a.nb = (a.T + bt - 1) / bt;
+  const int grid = ((a.ncols + 7) / 8) * a.nb * a.nb * 8;
+  switch (bt) {
+    case 3: hipLaunchKernelGGL((psd_ts_kernel<PASS, 3>), dim3(grid), dim3(TS_THREADS), 0, c.stream, a); break;
+    case 4: hipLaunchKernelGGL((psd_ts_kernel<PASS, 4>), dim3(grid), dim3(TS_THREADS), 0, c.stream, a); break;
+    case 5: hipLaunchKernelGGL((psd_ts_kernel<PASS, 5>), dim3(grid), dim3(TS_THREADS), 0, c.stream, a); break;
+    default: hipLaunchKernelGGL((psd_ts_kernel<PASS, 7>), dim3(grid), dim3(TS_THREADS), 0, c.stream, a); break;
+  }
+}
+
 void psd_two_sided_fused(Ctx& c, int side, int ncols, const double* R, int rstruct, const double* arr, long lda, double* prod, long ldp,
                          double* zws) {
   if (ncols <= 0) return;
+  static const int bt1 = [] { const char* e = getenv("HYP_TS_BT1"); return e ? atoi(e) : 4; }();   // pass 1: 64 x 64 workgroup tiles
+  static const int bt2 = [] { const char* e = getenv("HYP_TS_BT2"); return e ? atoi(e) : 3; }();   // pass 2 (upper triangle only): 48 x 48, finer triangular skipping and 5 resident workgroups
   TsArgs a{};
   a.s = side; a.T = (side + 15) / 16; a.rstruct = rstruct; a.R = R; a.ncols = ncols;
-  a.nb = (a.T + TS_BT - 1) / TS_BT;
-  const int grid = ((ncols + 7) / 8) * a.nb * a.nb * 8;
   a.A = arr; a.lda = lda; a.C = zws; a.ldc = 0;
-  hipLaunchKernelGGL(psd_ts_kernel<1>, dim3(grid), dim3(TS_THREADS), 0, c.stream, a);
+  ts_launch<1>(c, a, bt1);
   a.A = zws; a.lda = 0; a.C = prod; a.ldc = ldp;
-  hipLaunchKernelGGL(psd_ts_kernel<2>, dim3(grid), dim3(TS_THREADS), 0, c.stream, a);
+  ts_launch<2>(c, a, bt2);
   HYP_CHECK(hipGetLastError());
 }
 
