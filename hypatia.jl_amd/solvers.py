@@ -82,14 +82,18 @@ STATUSES = ("NotLoaded", "Loaded", "SolveCalled", "Optimal", "PrimalInfeasible",
 class Point:
     """point.jl:5-54: flat vector [x(n); y(p); z(q); tau; s(q); kap] with views."""
 
-    def __init__(self, model=None, dims=None):
+    def __init__(self, model=None, dims=None, storage=None):
         if model is not None:
             n, p, q = model.n, model.p, model.q
         else:
             n, p, q = dims
         self.n, self.p, self.q = n, p, q
         self.tau_idx = n + p + q
-        self.vec = np.zeros(self.tau_idx + q + 2)
+        if storage is None:
+            self.vec = np.zeros(self.tau_idx + q + 2)
+        else:   # a caller-owned contiguous row (the fused device call writes the four directions straight into these)
+            assert storage.shape == (self.tau_idx + q + 2,) and storage.flags.c_contiguous
+            self.vec = storage
         v = self.vec
         self.x = v[:n]
         self.y = v[n:n + p]
@@ -401,12 +405,12 @@ class CombinedStepper:
         self.rhs = Point(model)
         self.dir = Point(model)
         self.temp = Point(model)
-        self.dir_cent = Point(model)
-        self.dir_pred = Point(model)
-        self.dir_centadj = Point(model)
-        self.dir_predadj = Point(model)
+        self.dirs4 = np.zeros((4, self.rhs.vec.shape[0]))  # dir_cent, dir_pred, dir_centadj, dir_predadj: one block the fused call fills
+        self.dir_cent = Point(model, storage=self.dirs4[0])
+        self.dir_pred = Point(model, storage=self.dirs4[1])
+        self.dir_centadj = Point(model, storage=self.dirs4[2])
+        self.dir_predadj = Point(model, storage=self.dirs4[3])
         self.dir_temp = np.zeros(self.rhs.vec.shape[0])
-        self.dirs4 = np.zeros((4, self.rhs.vec.shape[0]))  # dir_cent, dir_pred, dir_centadj, dir_predadj from the fused device call
         self.rhs2 = np.zeros((2, self.rhs.vec.shape[0]))   # the two right-hand sides / directions of a paired solve
         self.dir2 = np.zeros((2, self.rhs.vec.shape[0]))
         self.searcher = StepSearcher(model, **self.searcher_options)

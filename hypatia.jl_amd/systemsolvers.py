@@ -138,8 +138,7 @@ class QRCholDenseSystemSolver:
         if info.value != 0:
             print("positive definite linear system factorization failed")
             return False
-        for k, pt in enumerate((stepper.dir_cent, stepper.dir_pred, stepper.dir_centadj, stepper.dir_predadj)):
-            pt.vec[:] = dirs4[k]
+        # (stepper.dir_cent / dir_pred / dir_centadj / dir_predadj are views of the rows of dirs4: nothing to copy)
         solver.n_solves += ns.value
         assert not any(np.isnan(resn[k]) for k in range(4))
         if solver.max_ref_steps > 0:
