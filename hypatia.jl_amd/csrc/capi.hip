@@ -557,6 +557,26 @@ int hyp_dense_posv(hyp_ctx* ctx, int n, double* A, int lda, double* x, int* info
   c.sync();
   API_END(ctx)
 }
+int hyp_dense_sysv_rook(hyp_ctx* ctx, int n, double* A, int lda, double* x, int nrhs, int ldx, int* info, int* perm, int* blk,
+                        double* d_out, double* e_out) {
+  API_BEGIN
+  Ctx& c = ctx->c;
+  HYP_REQUIRE(n >= 1 && lda >= n && nrhs >= 0 && ldx >= n, "sysv_rook: sizes");
+  DBuf dA((size_t)lda * n * 8), dinv(dinv_elems(n) * 8), dx((size_t)ldx * std::max(nrhs, 1) * 8), work;
+  c.h2d(dA.p, A, (size_t)lda * n * 8);
+  if (nrhs > 0) c.h2d(dx.p, x, (size_t)ldx * nrhs * 8);
+  BKFact bk;
+  *info = bk.factor(c, n, dA.d(), lda, dinv.d());
+  if (*info == 0 && nrhs > 0) bk.solve(c, dA.d(), lda, dinv.d(), dx.d(), ldx, nrhs, work);
+  c.d2h(A, dA.p, (size_t)lda * n * 8);
+  if (nrhs > 0) c.d2h(x, dx.p, (size_t)ldx * nrhs * 8);
+  if (perm) c.d2h(perm, bk.perm.p, (size_t)n * sizeof(int));
+  if (blk) c.d2h(blk, bk.blk.p, (size_t)n * sizeof(int));
+  if (d_out) c.d2h(d_out, bk.dd.p, (size_t)n * 8);
+  if (e_out) c.d2h(e_out, bk.de.p, (size_t)n * 8);
+  c.sync();
+  API_END(ctx)
+}
 int hyp_dense_gemv(hyp_ctx* ctx, int trans, int m, int n, double alpha, const double* A, int lda, const double* x, double beta,
                    double* y) {
   API_BEGIN

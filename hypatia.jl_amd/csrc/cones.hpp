@@ -71,8 +71,8 @@ struct Cone {
   virtual bool check_numerics();
   virtual double get_proxsqr(double irtmu, bool use_max_prox);
   // false when inv_hess_prod has no usable factorization at this point (generic cones whose explicit
-  // Hessian fails its Cholesky: the reference would continue with Bunch-Kaufman, Cones.jl:239-251 --
-  // here the trial point is rejected instead)
+  // Hessian fails both its Cholesky and its Bunch-Kaufman factorization, Cones.jl:239-251: the
+  // reference's ldiv! throws a SingularException there; here the trial point is rejected)
   virtual bool inv_hess_ready() { return true; }
 
   double dot_host(int n, const double* dx, const double* dy);   // synchronous <x,y>
@@ -136,9 +136,11 @@ struct PsdCone : Cone {   // src/Cones/possemideftri.jl (real symmetric)
 // 189-259): WSOSInterpNonnegative and EpiNormSpectral in this Hypatia version.
 struct GenericHessCone : Cone {
   DBuf H;          // dim x dim explicit Hessian, BOTH triangles (symmetrised after update_hess)
-  DBuf Hfact;      // Cholesky factor of H (upper), strict lower zeroed
+  DBuf Hfact;      // Cholesky factor of H (upper), strict lower zeroed; or the unit factor of the Bunch-Kaufman fallback
   DBuf Hdinv, Hinfo, trsm_work, tmpd, tmpd2;
-  bool hess_fact_ok = false;
+  bool hess_fact_ok = false;   // issuccess(hess_fact)
+  bool hess_fact_bk = false;   // hess_fact is the Bunch-Kaufman fallback of a failed Cholesky (posdef_fact_copy!(.., false), Cones.jl:247)
+  BKFact Hbk;
   bool use_hess_prod_slow = false, use_hess_prod_slow_updated = false;
   GenericHessCone(Ctx& c, int kind) : Cone(c, kind) {}
   void alloc_generic();

@@ -72,12 +72,23 @@ bool GenericHessCone::update_hess_fact() {   // Cones.jl:239-251: posdef_fact_co
   if (hess_fact_updated) return hess_fact_ok;
   if (!hess_updated) update_hess();
   ensure_hess_storage(true);
-  ctx.d2d(Hfact.p, H.p, (size_t)dim * dim * sizeof(double));
-  potrf_upper_batched(ctx, dim, Hfact.d(), dim, 0, 1, Hdinv.d(), Hinfo.i());
-  // Cholesky only: the reference's Bunch-Kaufman second attempt is not on the device;
-  // a failed Cholesky reports "no valid factorization", which the callers treat like a failed BK.
-  hess_fact_ok = (read_info(ctx, Hinfo.i()) == 0);
-  if (hess_fact_ok) dev_zero_strict_lower(ctx, dim, Hfact.d(), dim, 1, 0);
+  // posdef_fact_copy!(hess_fact_mat, hess, false), dense.jl:194-215: Cholesky, else Bunch-Kaufman (rook), no shift
+  const char* fb = getenv("HYP_FORCE_BK");   // tests: treat the Cholesky as failed
+  const bool force_bk = fb && fb[0] && fb[0] != '0';
+  hess_fact_bk = false;
+  hess_fact_ok = false;
+  if (!force_bk) {
+    ctx.d2d(Hfact.p, H.p, (size_t)dim * dim * sizeof(double));
+    potrf_upper_batched(ctx, dim, Hfact.d(), dim, 0, 1, Hdinv.d(), Hinfo.i());
+    hess_fact_ok = (read_info(ctx, Hinfo.i()) == 0);
+  }
+  if (hess_fact_ok) {
+    dev_zero_strict_lower(ctx, dim, Hfact.d(), dim, 1, 0);
+  } else {
+    hess_fact_bk = true;
+    ctx.d2d(Hfact.p, H.p, (size_t)dim * dim * sizeof(double));
+    hess_fact_ok = (Hbk.factor(ctx, dim, Hfact.d(), dim, Hdinv.d()) == 0);
+  }
   hess_fact_updated = true;
   return hess_fact_ok;
 }
@@ -105,11 +116,13 @@ void GenericHessCone::hess_prod(double* prod, long ldp, const double* arr, long 
 
 void GenericHessCone::inv_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) {   // :113-118
   update_hess_fact();
-  HYP_REQUIRE(hess_fact_ok, "inv_hess_prod: the cone Hessian has no Cholesky factorization");
+  HYP_REQUIRE(hess_fact_ok, "inv_hess_prod: the cone Hessian has no factorization (singular)");
   if (ncols <= 0) return;
   if (prod != arr) HYP_CHECK(hipMemcpy2DAsync(prod, ldp * sizeof(double), arr, lda * sizeof(double), (size_t)dim * sizeof(double), ncols,
                                               hipMemcpyDeviceToDevice, ctx.stream));
-  if (ncols == 1) {
+  if (hess_fact_bk) {   // ldiv!(::BunchKaufman, .)
+    Hbk.solve(ctx, Hfact.d(), dim, Hdinv.d(), prod, ldp, ncols, trsm_work);
+  } else if (ncols == 1) {
     trsv_upper(ctx, dim, Hfact.d(), dim, Hdinv.d(), true, prod);
     trsv_upper(ctx, dim, Hfact.d(), dim, Hdinv.d(), false, prod);
   } else {
@@ -124,11 +137,11 @@ bool GenericHessCone::use_sqrt_hess_oracles(int arr_dim) {   // :189-195
     if (arr_dim < dim) return false;
     if (!update_hess_fact()) return false;
   }
-  return hess_fact_ok;   // (hess_fact isa Cholesky)
+  return hess_fact_ok && !hess_fact_bk;   // (hess_fact isa Cholesky)
 }
 
 void GenericHessCone::sqrt_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) {   // :198-206  U * arr
-  HYP_REQUIRE(hess_fact_updated && hess_fact_ok, "sqrt_hess_prod: no Cholesky factor");
+  HYP_REQUIRE(hess_fact_updated && hess_fact_ok && !hess_fact_bk, "sqrt_hess_prod: no Cholesky factor");
   GemmArgs g{};
   g.M = dim; g.N = ncols; g.K = dim; g.A = Hfact.d(); g.lda = dim; g.B = arr; g.ldb = lda; g.C = prod; g.ldc = ldp;
   g.alpha = 1; g.beta = 0; g.krange = KR_GE_M; g.batch = 1;
@@ -136,7 +149,7 @@ void GenericHessCone::sqrt_hess_prod(double* prod, long ldp, const double* arr, 
 }
 
 void GenericHessCone::inv_sqrt_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) {   // :209-218  U'^-1 arr
-  HYP_REQUIRE(hess_fact_updated && hess_fact_ok, "inv_sqrt_hess_prod: no Cholesky factor");
+  HYP_REQUIRE(hess_fact_updated && hess_fact_ok && !hess_fact_bk, "inv_sqrt_hess_prod: no Cholesky factor");
   if (prod != arr) HYP_CHECK(hipMemcpy2DAsync(prod, ldp * sizeof(double), arr, lda * sizeof(double), (size_t)dim * sizeof(double), ncols,
                                               hipMemcpyDeviceToDevice, ctx.stream));
   trsm_work.ensure((size_t)NB * std::max(ncols, 1) * sizeof(double));

@@ -242,8 +242,12 @@ void SysSolver::solve3_multi(double* sol, const double* rhs, int nr) {
     gemv_multi(ctx, true, q, n, nr, 1.0, G.d(), q, sol + n, ld3, 1.0, sol, ld3);
   }
   if (tri.ready(nmp)) {
-    tri.solve_multi(ctx, lhs_fact.d(), nmp, true, sol, ld3, nr);
-    tri.solve_multi(ctx, lhs_fact.d(), nmp, false, sol, ld3, nr);
+    double* y = use_bk ? bk.gather(ctx, sol, ld3, nr) : sol;   // Bunch-Kaufman factor: P before, D^-1 between, P' after
+    const long ldy = use_bk ? nmp : ld3;
+    tri.solve_multi(ctx, lhs_fact.d(), nmp, true, y, ldy, nr);
+    if (use_bk) bk.dsolve(ctx, y, ldy, nr);
+    tri.solve_multi(ctx, lhs_fact.d(), nmp, false, y, ldy, nr);
+    if (use_bk) bk.scatter(ctx, y, sol, ld3, nr);
   } else {
     for (int r = 0; r < nr; ++r) tri_solves(sol + r * ld3);
   }

@@ -141,6 +141,24 @@ struct TriSolvePlan {
   void solve(Ctx& c, const double* U, long ldu, bool trans, double* x);
   void solve_multi(Ctx& c, const double* U, long ldu, bool trans, double* x, long ldx, int nr);   // nr <= 2 right-hand sides
 };
+// bunchkaufman.hip : symmetric indefinite factorization with rook pivoting, the reference's fallback of a failed
+// Cholesky (symm_fact!, dense.jl:164-165; posdef_fact_copy!, dense.jl:194-215).  P A P' = U' D U with U unit upper
+// triangular (written over the upper triangle of A, unit diagonal explicit) and D block diagonal with 1x1 / 2x2 blocks,
+// so the solve is gather(P) -> U'^-1 -> D^-1 -> U^-1 -> scatter(P') around the same triangular solves as the Cholesky.
+struct BKFact {
+  int n = 0;
+  int n_2x2 = 0;                  // number of 2x2 pivot blocks of the last factorization
+  DBuf dd, de, blk, perm;         // diagonal / off-diagonal of D, block marks (0: 1x1, 1 / 2: rows of a 2x2), P as a gather map
+  DBuf state, wl, tmp;
+  // A: upper triangle in, U out.  dinv (dinv_elems(n) doubles, may be null) receives the inverted diagonal
+  // blocks for trsv_upper / trsm_upper_left / TriSolvePlan.  Returns LAPACK's info: 0 or the 1-based index of the
+  // first exactly singular pivot (issuccess(fact) = info == 0).  Synchronizes.
+  int factor(Ctx& c, int n_, double* A, long lda, double* dinv);
+  double* gather(Ctx& c, const double* x, long ldx, int nr);          // tmp[:, r] = P x[:, r]; returns tmp (ld n)
+  void dsolve(Ctx& c, double* y, long ldy, int nr);                   // y <- D^-1 y
+  void scatter(Ctx& c, const double* y, double* x, long ldx, int nr); // x[:, r] = P' y[:, r] (y with ld n)
+  void solve(Ctx& c, const double* U, long ldu, const double* dinv, double* x, long ldx, int nr, DBuf& trsm_work);
+};
 // Y[:, r] = alpha op(A) X[:, r] + beta Y[:, r] for r < nr <= 2: one pass over A serves all right-hand sides
 void gemv_multi(Ctx& c, bool trans, int m, int n, int nr, double alpha, const double* A, long lda, const double* X, long ldx, double beta,
                 double* Y, long ldy);

@@ -147,45 +147,55 @@ void SysSolver::factor_lhs(int* info, int* used_fallback) {   // qrchol.jl:249-2
   *info = 0;
   *used_fallback = 0;
   if (nmp == 0) return;
-  // posdef_fact_copy! (dense.jl:194-215).  Cholesky; on failure the reference tries Bunch-Kaufman and
-  // then a diagonal shift + Bunch-Kaufman.  Device Bunch-Kaufman is not built yet: the
-  // fallback here is diagonal shift + Cholesky, reported through used_fallback.
-  ctx.d2d(lhs_fact.p, lhs.p, (size_t)nmp * nmp * sizeof(double));
-  HYP_CHECK(hipEventRecord(ctx.ev[3], ctx.stream));
-  potrf_upper_batched(ctx, nmp, lhs_fact.d(), nmp, 0, 1, dinv.d(), d_info.i());
-  HYP_CHECK(hipEventRecord(ctx.ev[4], ctx.stream));
-  ctx.d2h(ctx.h_info, d_info.p, sizeof(int));
-  ctx.sync();
-  *info = ctx.h_info[0];
-  {
+  // posdef_fact_copy! (dense.jl:194-215): Cholesky; on failure Bunch-Kaufman with rook pivoting (symm_fact!,
+  // dense.jl:164-165); if that finds an exactly singular pivot, increase_diag! (dense.jl:106-113) and Bunch-Kaufman
+  // again.  used_fallback: 0 Cholesky, 1 Bunch-Kaufman, 2 diagonal shift + Bunch-Kaufman.
+  // HYP_FORCE_BK=1 (tests) treats the Cholesky as failed.
+  const char* fb = getenv("HYP_FORCE_BK");
+  const bool force_bk = fb && fb[0] && fb[0] != '0';
+  use_bk = false;
+  if (!force_bk) {
+    ctx.d2d(lhs_fact.p, lhs.p, (size_t)nmp * nmp * sizeof(double));
+    HYP_CHECK(hipEventRecord(ctx.ev[3], ctx.stream));
+    potrf_upper_batched(ctx, nmp, lhs_fact.d(), nmp, 0, 1, dinv.d(), d_info.i());
+    HYP_CHECK(hipEventRecord(ctx.ev[4], ctx.stream));
+    ctx.d2h(ctx.h_info, d_info.p, sizeof(int));
+    ctx.sync();
+    *info = ctx.h_info[0];
     float ms = 0;
     HYP_CHECK(hipEventElapsedTime(&ms, ctx.ev[0], ctx.ev[1])); ctx.kstat[0] += ms;
     HYP_CHECK(hipEventElapsedTime(&ms, ctx.ev[1], ctx.ev[2])); ctx.kstat[1] += ms;
     HYP_CHECK(hipEventElapsedTime(&ms, ctx.ev[3], ctx.ev[4])); ctx.kstat[2] += ms;
     ctx.kstat[3] += 1;
   }
-  if (*info != 0) {
+  if (force_bk || *info != 0) {
+    use_bk = true;
     *used_fallback = 1;
     ctx.d2d(lhs_fact.p, lhs.p, (size_t)nmp * nmp * sizeof(double));
-    hipLaunchKernelGGL(increase_diag_kernel, dim3((nmp + 255) / 256), dim3(256), 0, ctx.stream, nmp, lhs_fact.d(), (long)nmp);
-    potrf_upper_batched(ctx, nmp, lhs_fact.d(), nmp, 0, 1, dinv.d(), d_info.i());
-    ctx.d2h(ctx.h_info, d_info.p, sizeof(int));
-    ctx.sync();
-    *info = ctx.h_info[0];
+    *info = bk.factor(ctx, nmp, lhs_fact.d(), nmp, dinv.d());
+    if (*info != 0) {
+      *used_fallback = 2;
+      ctx.d2d(lhs_fact.p, lhs.p, (size_t)nmp * nmp * sizeof(double));
+      hipLaunchKernelGGL(increase_diag_kernel, dim3((nmp + 255) / 256), dim3(256), 0, ctx.stream, nmp, lhs_fact.d(), (long)nmp);
+      *info = bk.factor(ctx, nmp, lhs_fact.d(), nmp, dinv.d());
+    }
   }
   fact_ok = (*info == 0);
   tri.invalidate();
   if (fact_ok && ctx.trsv_sb > 0 && nmp >= 2 * ctx.trsv_sb) tri.build(ctx, nmp, lhs_fact.d(), nmp, dinv.d());
 }
 
+// x <- lhs^-1 x.  Cholesky: U'^-1 then U^-1.  Bunch-Kaufman: the same two sweeps with the unit factor, between a
+// gather by P, the block-diagonal solve and a scatter.
 void SysSolver::tri_solves(double* d_x) {
-  if (tri.ready(nmp)) {
-    tri.solve(ctx, lhs_fact.d(), nmp, true, d_x);
-    tri.solve(ctx, lhs_fact.d(), nmp, false, d_x);
-  } else {
-    trsv_upper(ctx, nmp, lhs_fact.d(), nmp, dinv.d(), true, d_x);
-    trsv_upper(ctx, nmp, lhs_fact.d(), nmp, dinv.d(), false, d_x);
+  double* y = use_bk ? bk.gather(ctx, d_x, nmp, 1) : d_x;
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool trans = (pass == 0);
+    if (tri.ready(nmp)) tri.solve(ctx, lhs_fact.d(), nmp, trans, y);
+    else trsv_upper(ctx, nmp, lhs_fact.d(), nmp, dinv.d(), trans, y);
+    if (use_bk && pass == 0) bk.dsolve(ctx, y, nmp, 1);
   }
+  if (use_bk) bk.scatter(ctx, y, d_x, nmp, 1);
 }
 
 void SysSolver::potrs(double* d_x) { tri_solves(d_x); }

@@ -26,6 +26,9 @@ struct SysSolver {
   DBuf QpbxGHbz, Gx, HGx, GQ1x, HGQ1x, tmpn, sol, rhs, tmpq;
   std::vector<int> use_sqrt;
   bool fact_ok = false;
+  BKFact bk;              // the factorization after a failed Cholesky (posdef_fact_copy!, dense.jl:194-215)
+  bool use_bk = false;    // lhs_fact holds U of P lhs P' = U' D U instead of the Cholesky factor
+  DBuf bk_work;
 
   SysSolver(Ctx& c, int n_, int p_, int q_, const std::vector<Cone*>& cs);
   const double* GQ2() const { return p == 0 ? G.d() : GQ2s.d(); }

@@ -365,6 +365,7 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
                                                 dirs_l.ctypes.data_as(ctypes.c_void_p), resn, ctypes.byref(ns), flags, ctypes.byref(info),
                                                 ctypes.byref(fb), None), "hyp_sys_step_directions")
         self.last_info, self.used_fallback = info.value, bool(fb.value)
+        self.fallback_kind = fb.value   # 0 Cholesky, 1 Bunch-Kaufman, 2 diagonal shift + Bunch-Kaufman
         if info.value != 0:
             print("positive definite linear system factorization failed")
             return False

@@ -80,6 +80,7 @@ class QRCholDenseSystemSolver:
         self.rhs_const.z[:] = model.h
         self.last_info = 0
         self.used_fallback = False
+        self.fallback_kind = 0
         # device-resident get_directions (hyp_sys_get_directions): model vectors live on the GPU too
         cc, bb, hh = (np.ascontiguousarray(v, dtype=np.float64) for v in (model.c, model.b, model.h))
         AA = np.asfortranarray(model.A, dtype=np.float64) if p > 0 else None
@@ -110,6 +111,7 @@ class QRCholDenseSystemSolver:
             solver.time_upfact += time.perf_counter() - t0
             self.use_sqrt_hess_cones = [bool(flags[k]) for k in range(nc)]
             self.last_info, self.used_fallback = info.value, bool(fb.value)
+            self.fallback_kind = fb.value   # 0 Cholesky, 1 Bunch-Kaufman, 2 diagonal shift + Bunch-Kaufman
             if info.value != 0:
                 print("positive definite linear system factorization failed")
             return self
@@ -135,6 +137,7 @@ class QRCholDenseSystemSolver:
                 "hyp_sys_step_directions")
         self.use_sqrt_hess_cones = [bool(flags[k]) for k in range(nc)]
         self.last_info, self.used_fallback = info.value, bool(fb.value)
+        self.fallback_kind = fb.value   # 0 Cholesky, 1 Bunch-Kaufman, 2 diagonal shift + Bunch-Kaufman
         if info.value != 0:
             print("positive definite linear system factorization failed")
             return False
@@ -215,6 +218,7 @@ class QRCholDenseSystemSolver:
         solver.time_upfact += time.perf_counter() - t0   # (assembly + factor; the split is in hyp_get_timers)
         self.use_sqrt_hess_cones = [bool(flags[k]) for k in range(nc)]
         self.last_info, self.used_fallback = info.value, bool(fb.value)
+        self.fallback_kind = fb.value   # 0 Cholesky, 1 Bunch-Kaufman, 2 diagonal shift + Bunch-Kaufman
         if info.value != 0:
             print("positive definite linear system factorization failed")
 

@@ -173,6 +173,14 @@ int hyp_dense_potrf(hyp_ctx* ctx, int n, double* A, int lda, int* info);
 /* dposv 'U': A (upper triangle read) is overwritten by its Cholesky factor U, x (in: b) by A^-1 b */
 int hyp_dense_posv(hyp_ctx* ctx, int n, double* A, int lda, double* x, int* info);
 /* y = alpha * op(A) x + beta * y */
+/* Symmetric indefinite solve through the rook-pivoted factorization P A P' = U' D U (the reference's
+ * bunchkaufman!(Symmetric(A, :U), true, check = false) + ldiv!: symm_fact!, src/linearalgebra/dense.jl:164-165).
+ * A: upper triangle in, U (unit upper, diagonal explicit) out.  perm / blk / d / e (length n, each may be NULL)
+ * describe the factorization: perm[i] = original index in position i; blk[i] = 0 for a 1x1 pivot d[i], 1 / 2 for
+ * the two rows of a 2x2 pivot [[d[i], e[i]], [e[i], d[i+1]]].  x (n x nrhs, ld ldx) is overwritten with A^-1 x.
+ * info = 0, or the 1-based position of the first exactly singular pivot (LAPACK dsytrf_rook). */
+int hyp_dense_sysv_rook(hyp_ctx* ctx, int n, double* A, int lda, double* x, int nrhs, int ldx, int* info, int* perm, int* blk,
+                        double* d, double* e);
 int hyp_dense_gemv(hyp_ctx* ctx, int trans, int m, int n, double alpha, const double* A, int lda, const double* x, double beta,
                    double* y);
 /* time `reps` launches of the syrk C = A'A (A is K x N) with HIP events on the library stream; ms per launch */

@@ -128,6 +128,136 @@ def bk_rook(mat):
     return BKFact(a, ipiv, info.value)
 
 
+def sytrf_rook_lapack(mat, uplo="U"):
+    """Raw LAPACK dsytrf_rook on a copy: (factors, ipiv (1-based, LAPACK convention), info)."""
+    n = mat.shape[0]
+    a = np.array(mat, dtype=np.float64, order="F", copy=True)
+    fn = _rook_sym("dsytrf_rook")
+    assert fn is not None, "this LAPACK build has no dsytrf_rook"
+    ipiv = np.zeros(n, dtype=np.int32)
+    lwork = max(1, 64 * n)
+    work = np.zeros(lwork)
+    info = ctypes.c_int(0)
+    fn(ctypes.c_char_p(uplo.encode()), ctypes.byref(ctypes.c_int(n)), a.ctypes.data_as(ctypes.c_void_p),
+       ctypes.byref(ctypes.c_int(n)), ipiv.ctypes.data_as(ctypes.c_void_p),
+       work.ctypes.data_as(ctypes.c_void_p), ctypes.byref(ctypes.c_int(lwork)), ctypes.byref(info),
+       ctypes.c_size_t(1))
+    return a, ipiv, info.value
+
+
+def decode_rook_lower(a, ipiv):
+    """LAPACK dsytrf_rook(uplo = 'L') output -> (perm, blk, d, e, L): P A P' = L D L' with perm[i] the original
+    index in position i, blk[i] = 0 (1x1) or 1 / 2 (rows of a 2x2 block), D = diag(d) + offdiag(e), L unit lower.
+    With uplo = 'L' LAPACK eliminates forwards (columns 1, 2, ...), the order of the device factorization."""
+    n = a.shape[0]
+    perm = np.arange(n)
+    blk = np.zeros(n, dtype=np.int32)
+    d = np.diag(a).copy()
+    e = np.zeros(n)
+    L = np.tril(a, -1) + np.eye(n)
+
+    def swap(r1, r2, k):   # LAPACK stores L as a product P1 L1 P2 L2 ...: later interchanges act on the earlier columns
+        if r1 != r2:
+            perm[[r1, r2]] = perm[[r2, r1]]
+            L[[r1, r2], :k] = L[[r2, r1], :k]
+
+    k = 0
+    while k < n:
+        if ipiv[k] > 0:
+            swap(k, ipiv[k] - 1, k)
+            k += 1
+        else:
+            swap(k, -ipiv[k] - 1, k)
+            swap(k + 1, -ipiv[k + 1] - 1, k)
+            blk[k], blk[k + 1] = 1, 2
+            e[k] = a[k + 1, k]
+            L[k + 1, k] = 0.0
+            k += 2
+    return perm, blk, d, e, L
+
+
+def ldl_rook_forward(mat):
+    """Unblocked restatement of the rook-pivoted symmetric indefinite factorization (the algorithm behind
+    bunchkaufman!(A, true), dense.jl:164-165 = LAPACK dsytf2_rook), eliminating forwards.  Reads the UPPER
+    triangle of `mat`.  Returns (perm, blk, d, e, L, info) with P A P' = L D L' as in decode_rook_lower."""
+    n = mat.shape[0]
+    A = np.triu(mat) + np.triu(mat, 1).T
+    A = np.array(A, dtype=np.float64)
+    alpha = (1.0 + np.sqrt(17.0)) / 8.0
+    perm = np.arange(n)
+    blk = np.zeros(n, dtype=np.int32)
+    d = np.zeros(n)
+    e = np.zeros(n)
+    L = np.eye(n)
+    info = 0
+
+    def swap(a_, b_):
+        if a_ == b_:
+            return
+        A[[a_, b_], :] = A[[b_, a_], :]
+        A[:, [a_, b_]] = A[:, [b_, a_]]
+        L[[a_, b_], :a_] = L[[b_, a_], :a_]
+        perm[[a_, b_]] = perm[[b_, a_]]
+
+    k = 0
+    while k < n:
+        absakk = abs(A[k, k])
+        if k + 1 < n:
+            col = np.abs(A[k + 1:, k])
+            imax = k + 1 + int(np.argmax(col))
+            colmax = col[imax - k - 1]
+        else:
+            imax, colmax = k, 0.0
+        kstep, kp, p, skip = 1, k, k, False
+        if max(absakk, colmax) == 0.0 or np.isnan(absakk):
+            skip = True
+            if info == 0:
+                info = k + 1
+        elif not (absakk < alpha * colmax):
+            kp = k
+        else:
+            while True:
+                row = np.abs(A[imax, k:]).copy()
+                row[imax - k] = -1.0
+                jmax = k + int(np.argmax(row))
+                rowmax = max(row[jmax - k], 0.0)
+                if not (abs(A[imax, imax]) < alpha * rowmax):
+                    kp, kstep = imax, 1
+                    break
+                if p == jmax or rowmax <= colmax:
+                    kp, kstep = imax, 2
+                    break
+                p, colmax, imax = imax, rowmax, jmax
+        if kstep == 2 and p != k:
+            swap(k, p)
+        kk = k + kstep - 1
+        if kp != kk:
+            swap(kk, kp)
+        if skip:
+            d[k] = A[k, k]
+        elif kstep == 1:
+            d[k] = A[k, k]
+            w = A[k + 1:, k].copy()
+            l = w / d[k]
+            A[k + 1:, k + 1:] -= np.outer(l, w)
+            L[k + 1:, k] = l
+        else:
+            d11, d12, d22 = A[k, k], A[k + 1, k], A[k + 1, k + 1]
+            d[k], d[k + 1], e[k] = d11, d22, d12
+            blk[k], blk[k + 1] = 1, 2
+            D11, D22 = d22 / d12, d11 / d12
+            T = 1.0 / (D11 * D22 - 1.0)
+            w1 = A[k + 2:, k].copy()
+            w2 = A[k + 2:, k + 1].copy()
+            l1 = T * (D11 * w1 - w2) / d12
+            l2 = T * (D22 * w2 - w1) / d12
+            A[k + 2:, k + 2:] -= np.outer(l1, w1) + np.outer(l2, w2)
+            L[k + 2:, k] = l1
+            L[k + 2:, k + 1] = l2
+        k += kstep
+    return perm, blk, d, e, L, info
+
+
 def increase_diag(A):
     """dense.jl:106-113."""
     d = np.diagonal(A).copy()
