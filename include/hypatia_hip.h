@@ -86,9 +86,11 @@ int hyp_sys_destroy(hyp_sys* sys);
 /* load (qrchol.jl:138-179): G = model.G (q x n).  When p == 0 pass NULL for GQ1, GQ2, Q, R (GQ2 = G,
  * Ap_Q = I).  Otherwise GQ1 = (G*Ap_Q)[:, 1:p], GQ2 = (G*Ap_Q)[:, p+1:n], Q = Ap_Q (n x n), R = Ap_R (p x p). */
 int hyp_sys_load(hyp_sys* sys, const double* G, const double* GQ1, const double* GQ2, const double* Q, const double* R);
-/* update_lhs_fact (qrchol.jl:201-257): Schur assembly + posdef_fact_copy!.  use_sqrt_out[ncones]
- * receives use_sqrt_hess_cones; info = 0 or leading-minor index of the failed Cholesky after the
- * fallback; used_fallback = 1 when the first Cholesky failed. */
+/* update_lhs_fact (qrchol.jl:201-257): Schur assembly + posdef_fact_copy! (src/linearalgebra/dense.jl:194-215).
+ * use_sqrt_out[ncones] receives use_sqrt_hess_cones.  used_fallback names the link of the chain that produced the
+ * factorization: 0 Cholesky, 1 Bunch-Kaufman with rook pivoting (symm_fact!, dense.jl:164-165) after a failed
+ * Cholesky, 2 increase_diag! (dense.jl:106-113) + Bunch-Kaufman after that found an exactly singular pivot.
+ * info = 0, or LAPACK's info of the last link (issuccess(fact) = info == 0). */
 int hyp_sys_update_lhs_fact(hyp_sys* sys, int* use_sqrt_out, int* info, int* used_fallback);
 /* the two halves of update_lhs_fact, for the multi-GPU path: each process assembles the Schur sum over
  * ITS cones (qrchol.jl:214-246), the partial n x n matrices are summed across processes (RCCL
