@@ -66,6 +66,7 @@ SIGNATURES = {
     "hyp_sys_step_directions": [c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int, c_dbl, c_dbl, c_vp, c_vp, P(c_int), P(c_int), P(c_int), P(c_int), c_vp],
     "hyp_sys_set_comm": [c_vp, c_vp, c_vp, c_vp, ctypes.c_long],
     "hyp_sys_last_update_lhs_seconds": [c_vp, P(c_dbl)],
+    "hyp_sys_bench_gemv": [c_vp, c_int, c_vp],
     "hyp_sys_search_alpha": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_dbl, c_dbl, c_int, c_dbl, c_vp,
                              P(c_int), P(c_dbl), P(c_int), P(c_int), P(c_dbl)],
     "hyp_sys_check_cone_points": [c_vp, c_vp, c_dbl, c_dbl, c_int, c_dbl, P(c_int), P(c_dbl), P(c_int), P(c_dbl)],

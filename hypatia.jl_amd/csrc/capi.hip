@@ -1,5 +1,6 @@
 // extern "C" boundary of libhypatia_hip.so (include/hypatia_hip.h).  Stages host buffers, forwards to
 // the device objects, converts exceptions to status codes.
+#include <unistd.h>
 #include "../../include/hypatia_hip.h"
 #include "syssolver.hpp"
 #include <chrono>
@@ -471,6 +472,36 @@ int hyp_sys_last_update_lhs_seconds(hyp_sys* sys, double* out) {
   *out = sys->s->last_update_lhs_s;
   API_END(sys->ctx)
 }
+int hyp_sys_bench_gemv(hyp_sys* sys, int reps, double* ms_out4) {
+  API_BEGIN
+  SysSolver* s = sys->s;
+  Ctx& c = sys->ctx->c;
+  const int q = s->q, n = s->n;
+  HYP_REQUIRE(reps >= 1 && q >= 1 && n >= 1, "bench_gemv: sizes");
+  DBuf xq((size_t)2 * q * 8), xn((size_t)2 * n * 8);
+  c.zero(xq.p, (size_t)2 * q * 8);
+  c.zero(xn.p, (size_t)2 * n * 8);
+  hipEvent_t e0, e1;
+  HYP_CHECK(hipEventCreate(&e0)); HYP_CHECK(hipEventCreate(&e1));
+  for (int v = 0; v < 4; ++v) {   // G' X (2 columns), G X (2 columns), G' x, G x
+    const bool trans = (v % 2 == 0);
+    const int nr = (v < 2) ? 2 : 1;
+    auto run = [&] {
+      if (trans) gemv_multi(c, true, q, n, nr, 1.0, s->G.d(), q, xq.d(), q, 0.0, xn.d(), n);
+      else gemv_multi(c, false, q, n, nr, 1.0, s->G.d(), q, xn.d(), n, 0.0, xq.d(), q);
+    };
+    run();
+    HYP_CHECK(hipEventRecord(e0, c.stream));
+    for (int r = 0; r < reps; ++r) run();
+    HYP_CHECK(hipEventRecord(e1, c.stream));
+    HYP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    HYP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    ms_out4[v] = ms / reps;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  API_END(sys->ctx)
+}
 int hyp_sys_search_alpha(hyp_sys* sys, const double* point_ztsk, const double* dir_cent, const double* dir_pred, const double* dir_centadj,
                          const double* dir_predadj, int unadj_only, int cent_only, const double* alpha_sched, int nsched, int start,
                          double min_prox, double prox_bound, int use_max_prox, double nup1, double* cand_ztsk, int* accepted_index,
@@ -606,12 +637,45 @@ int hyp_bench_syrk(hyp_ctx* ctx, int N, int K, int reps, double* ms_out) {
   c.sync();
   hipEvent_t e0, e1;
   HYP_CHECK(hipEventCreate(&e0)); HYP_CHECK(hipEventCreate(&e1));
-  HYP_CHECK(hipEventRecord(e0, c.stream));
-  for (int r = 0; r < reps; ++r) gemm(c, true, g);
-  HYP_CHECK(hipEventRecord(e1, c.stream));
-  HYP_CHECK(hipEventSynchronize(e1));
   float ms = 0;
-  HYP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  const char* gap = getenv("HYP_BENCH_SYRK_GAP_US");   // idle time before every timed launch (clock-ramp experiments)
+  if (gap && atoi(gap) > 0) {
+    for (int r = 0; r < reps; ++r) {
+      c.sync();
+      usleep(atoi(gap));
+      HYP_CHECK(hipEventRecord(e0, c.stream));
+      gemm(c, true, g);
+      HYP_CHECK(hipEventRecord(e1, c.stream));
+      const char* burst = getenv("HYP_BENCH_SYRK_BURST");   // further back-to-back launches after the timed one, each timed and printed
+      const int nb = burst ? std::min(atoi(burst), 8) : 0;
+      hipEvent_t eb[9];
+      for (int b = 0; b < nb; ++b) {
+        gemm(c, true, g);
+        HYP_CHECK(hipEventCreate(&eb[b]));
+        HYP_CHECK(hipEventRecord(eb[b], c.stream));
+      }
+      HYP_CHECK(hipEventSynchronize(nb ? eb[nb - 1] : e1));
+      float t = 0;
+      HYP_CHECK(hipEventElapsedTime(&t, e0, e1));
+      ms += t;
+      if (nb) {
+        fprintf(stderr, "burst after %s us idle: %.3f", gap, t);
+        for (int b = 0; b < nb; ++b) {
+          float tb = 0;
+          HYP_CHECK(hipEventElapsedTime(&tb, b ? eb[b - 1] : e1, eb[b]));
+          fprintf(stderr, " %.3f", tb);
+        }
+        fprintf(stderr, " ms\n");
+        for (int b = 0; b < nb; ++b) (void)hipEventDestroy(eb[b]);
+      }
+    }
+  } else {
+    HYP_CHECK(hipEventRecord(e0, c.stream));
+    for (int r = 0; r < reps; ++r) gemm(c, true, g);
+    HYP_CHECK(hipEventRecord(e1, c.stream));
+    HYP_CHECK(hipEventSynchronize(e1));
+    HYP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  }
   *ms_out = ms / std::max(reps, 1);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   API_END(ctx)

@@ -13,56 +13,68 @@ namespace hyp {
 constexpr int MR = 2;   // right-hand sides per pass
 
 // ---- Y[:, r] = alpha A' X[:, r] + beta Y[:, r]: one workgroup per column of A, A read once --------------
-template <int NR>
-__global__ __launch_bounds__(256) void gemv_t_multi_kernel(int m, double alpha, const double* __restrict__ A, long lda,
+// TPB threads, U independent 16-byte loads of the column in flight per thread (256 x 2, 256 x 4, 512 x 2, 512 x 4,
+// 1024 x 1, 1024 x 2 all measure 4.0-4.2 TB/s at q = 20100, n = 5000: the two X vectors re-read from L2 by every
+// workgroup cost as much as the column itself; one right-hand side reaches 4.8 TB/s).
+template <int NR, int TPB, int U>
+__global__ __launch_bounds__(TPB) void gemv_t_multi_kernel(int m, double alpha, const double* __restrict__ A, long lda,
                                                            const double* __restrict__ X, long ldx, double beta, double* __restrict__ Y,
                                                            long ldy) {
-  __shared__ double red[NR][4];
+  constexpr int NW = TPB / 64;
+  __shared__ double red[NR][NW];
   const int col = blockIdx.x;
   const double* a = A + (long)col * lda;
-  double s[NR][4];
+  double s[NR][2 * U];
 #pragma unroll
-  for (int r = 0; r < NR; ++r) s[r][0] = s[r][1] = s[r][2] = s[r][3] = 0.0;
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int u = 0; u < 2 * U; ++u) s[r][u] = 0.0;
   int i = 0;
   typedef double d2_t __attribute__((ext_vector_type(2)));
   const bool wide = (((uintptr_t)a | (uintptr_t)X | ((uintptr_t)ldx * sizeof(double))) & 15) == 0;   // 16-byte pairs everywhere
-  if (wide) {   // two pairs (4 doubles) in flight per thread and iteration
-    const int nfull = m / 1024;       // whole 1024-row blocks: thread t takes the pairs at 2 t and 2 t + 512 of each
+  if (wide) {
+    constexpr int BLK = 2 * TPB * U;    // rows per iteration: thread t takes the pairs at 2 t + 2 TPB u
+    const int nfull = m / BLK;
     for (int b = 0; b < nfull; ++b) {
-      const int j = 1024 * b + 2 * threadIdx.x;
-      const d2_t a0 = *reinterpret_cast<const d2_t*>(a + j), a1 = *reinterpret_cast<const d2_t*>(a + j + 512);
+      const int j = BLK * b + 2 * threadIdx.x;
+      d2_t av[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) av[u] = *reinterpret_cast<const d2_t*>(a + j + 2 * TPB * u);
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
-        const d2_t x0 = *reinterpret_cast<const d2_t*>(X + (long)r * ldx + j), x1 = *reinterpret_cast<const d2_t*>(X + (long)r * ldx + j + 512);
-        s[r][0] += a0.x * x0.x;
-        s[r][1] += a0.y * x0.y;
-        s[r][2] += a1.x * x1.x;
-        s[r][3] += a1.y * x1.y;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const d2_t xv = *reinterpret_cast<const d2_t*>(X + (long)r * ldx + j + 2 * TPB * u);
+          s[r][2 * u] += av[u].x * xv.x;
+          s[r][2 * u + 1] += av[u].y * xv.y;
+        }
       }
     }
-    i = 1024 * nfull + threadIdx.x;   // the tail below is element-wise
+    i = BLK * nfull + threadIdx.x;   // the tail below is element-wise
   } else {
     i = threadIdx.x;
-    for (; i + 768 < m; i += 1024) {   // four independent column loads in flight per thread
-      const double a0 = a[i], a1 = a[i + 256], a2 = a[i + 512], a3 = a[i + 768];
+    for (; i + (2 * U - 1) * TPB < m; i += 2 * U * TPB) {   // 2 U independent column loads in flight per thread
+      double av[2 * U];
+#pragma unroll
+      for (int u = 0; u < 2 * U; ++u) av[u] = a[i + u * TPB];
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         const double* x = X + (long)r * ldx + i;
-        s[r][0] += a0 * x[0];
-        s[r][1] += a1 * x[256];
-        s[r][2] += a2 * x[512];
-        s[r][3] += a3 * x[768];
+#pragma unroll
+        for (int u = 0; u < 2 * U; ++u) s[r][u] += av[u] * x[u * TPB];
       }
     }
   }
-  for (; i < m; i += 256) {
+  for (; i < m; i += TPB) {
     const double a0 = a[i];
 #pragma unroll
     for (int r = 0; r < NR; ++r) s[r][0] += a0 * X[(long)r * ldx + i];
   }
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
-    double t = (s[r][0] + s[r][1]) + (s[r][2] + s[r][3]);
+    double t = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) t += s[r][2 * u] + s[r][2 * u + 1];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
     if ((threadIdx.x & 63) == 0) red[r][threadIdx.x >> 6] = t;
@@ -70,7 +82,9 @@ __global__ __launch_bounds__(256) void gemv_t_multi_kernel(int m, double alpha, 
   __syncthreads();
   if (threadIdx.x < NR) {
     const int r = threadIdx.x;
-    const double t = (red[r][0] + red[r][1]) + (red[r][2] + red[r][3]);
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += red[r][w];
     double* y = Y + (long)r * ldy + col;
     *y = alpha * t + (beta != 0.0 ? beta * (*y) : 0.0);
   }
@@ -131,7 +145,7 @@ void gemv_multi(Ctx& c, bool trans, int m, int n, int nr, double alpha, const do
   HYP_REQUIRE(nr == MR, "gemv_multi: 1 or 2 right-hand sides");
   if (trans) {
     if (n <= 0) return;
-    hipLaunchKernelGGL((gemv_t_multi_kernel<MR>), dim3(n), dim3(256), 0, c.stream, m, alpha, A, lda, X, ldx, beta, Y, ldy);
+    hipLaunchKernelGGL((gemv_t_multi_kernel<MR, 256, 2>), dim3(n), dim3(256), 0, c.stream, m, alpha, A, lda, X, ldx, beta, Y, ldy);
   } else {
     if (m <= 0) return;
     const int nchunks = (n + GM_CHUNK - 1) / GM_CHUNK;

@@ -153,6 +153,10 @@ int hyp_sys_step_directions(hyp_sys* sys, const double* point_vec, const double*
 int hyp_sys_set_comm(hyp_sys* sys, int (*allreduce)(void* user, long count, int op), void* user, void* device_staging, long capacity_doubles);
 /* wall seconds the update_lhs part (solver.time_upsys) took inside the last hyp_sys_step_directions call */
 int hyp_sys_last_update_lhs_seconds(hyp_sys* sys, double* out);
+/* Measurement helper: HIP-event time (ms, averaged over reps back-to-back launches) of the four passes over the resident
+ * G (q x n) that a KKT solve is made of (qrchol.jl:51-53, 71-73): out4 = {G' X on 2 columns, G X on 2 columns, G' x, G x}.
+ * Algorithmic bytes of each pass: q*n*8. */
+int hyp_sys_bench_gemv(hyp_sys* sys, int reps, double* ms_out4);
 /* search_alpha (steppers/search.jl:46-69) for one stepper mode: forms each candidate exactly as update_stepper_points
  * (steppers/combined.jl:124-170) does -- all vectors are `ztsk` views [z(q); tau; s(q); kap] of the current point and of the
  * four directions -- and runs check_cone_points on it, from alpha_sched[start] on.  accepted_index = 0-based index of the first
