@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 # one metric for every N (weak scaling: one PosSemidefTri block per GPU, n shared).  At N = 1 a block-iteration IS an
 # IPM iteration of BASELINE.json's headline instance (configs[1]).
 METRIC = "IPM block-iterations/sec: dense n=%d, one PosSemidefTri(%d) block per GPU (Float64, QRCholDense + CombinedStepper)"
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix spec; measured 77.8 with tools/probe_mfma.hip (profiles/)
 
 
@@ -124,10 +125,15 @@ def main_multi(args, world, rank, local_rank):
         setattr(solver, "time_" + f, 0.0)
     comm.barrier()
     torch.cuda.synchronize()
+    n_coll0 = comm.n_collectives          # (setup -- the LSQR initial point, rescaling -- and warmup are not counted)
+    if comm.hist is not None:
+        comm.hist.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
+    n_coll = comm.n_collectives - n_coll0
+    coll_hist = dict(comm.hist) if comm.hist is not None else None
     comm.barrier()
     el = np.array([time.perf_counter() - t0])
     blas_cap.__exit__(None, None, None)
@@ -153,9 +159,12 @@ def main_multi(args, world, rank, local_rank):
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                          "launch_ms": syrk_ms, "flops_per_launch": syrk_flops},
             "kkt_solves_per_step": (solver.n_solves - n_solves0) / args.steps,
-            "collectives_per_step": comm.n_collectives / max(args.steps + args.warmup, 1),
+            "collectives_per_step": n_coll / max(args.steps, 1),
             "setup_s": t_setup,
         }
+        if coll_hist is not None:   # HYP_PROFILE=1: where the collectives of the timed region come from
+            for key, cnt in sorted(coll_hist.items(), key=lambda kv: -kv[1]):
+                print("collectives %-40s %8d doubles op %-5s : %.1f per step" % (key[0], key[1], key[2], cnt / max(args.steps, 1)), file=sys.stderr)
         print(json.dumps(out))
     dist.destroy_process_group()
 
@@ -254,6 +263,20 @@ def main():
         "search_trials_per_step": n_trials / args.steps,
         "setup_s": t_setup,
     }
+
+    # the HBM-bound part of the path: the passes over the resident G that every KKT solve is made of
+    # (qrchol.jl:51-53, 71-73), timed with HIP events after the timed region; algorithmic bytes per pass = q * n * 8
+    try:
+        g4 = np.zeros(4)
+        L = H._lib
+        L.check(lib.hyp_sys_bench_gemv(solver.syssolver._h, 20, L.vec_ptr(g4)), "bench_gemv")
+        gb = q * args.n * 8.0
+        out["roofline_solve"] = {"bound": "hbm", "kernel": "gemv_t_multi_kernel<2> (G' X, two right-hand sides per pass over G)",
+                                 "achieved": gb / g4[0] / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / g4[0] / 1e6 / HBM_PEAK_GBS,
+                                 "bytes_per_launch": gb, "launch_ms": g4[0],
+                                 "other_passes_GBs": {"G X (2 rhs)": gb / g4[1] / 1e6, "G' x": gb / g4[2] / 1e6, "G x": gb / g4[3] / 1e6}}
+    except Exception as e:   # measurement extra: never fails the bench line
+        print("roofline_solve skipped: %r" % (e,), file=sys.stderr)
 
     if args.cpu_iters > 0:
         # CPU baseline: the oracle restatement ("port") on the host cores, a bounded number of iterations

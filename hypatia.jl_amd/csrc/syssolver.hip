@@ -469,12 +469,10 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
     const double rel = szk[k] / (mu * nu_k);
     if (rel < min_prox || nu_k * (rel - 1.0) * (rel - 1.0) > proxsqr_bound) ok = false;
   }
-  if (dist()) {
-    double v = ok ? 0.0 : 1.0;
-    allreduce_host(&v, 1, 0);
-    ok = (v < 0.5);
-  }
-  if (!ok) return false;
+  // (sharded: a rank whose cones fail this test does not leave alone -- it skips its cone work below and reports
+  //  the failure in the trial's closing all-reduce, so the ranks stay in step without a collective of their own here)
+  if (!ok && !dist()) return false;
+  const bool local_reject = !ok;
   const double irtmu = 1.0 / std::sqrt(mu);
   *irtmu_out = irtmu;
   cand_d.ensure((size_t)(2 * q + 2) * sizeof(double));
@@ -487,7 +485,7 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
   // order and stops at the first failure, which only the points loaded beyond it could tell apart -- and nothing
   // reads those before the next candidate reloads them.
   std::vector<char> launched(nc, 0);
-  if (nc > 1) {
+  if (nc > 1 && !local_reject) {
     for (size_t k = 0; k < nc; ++k) {
       Cone* ck = cones[k];
       ck->load_point((ck->use_dual_barrier ? dz : dsv) + offs[k], irtmu);
@@ -503,7 +501,7 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
       if (launched[k]) cones[k]->prefetch_finish((int)k);
     *n_loaded = (int)nc;
   }
-  for (size_t k = 0; k < nc; ++k) {                                                   // :118-136
+  for (size_t k = 0; k < nc && !local_reject; ++k) {                                  // :118-136
     Cone* ck = cones[k];
     if (nc == 1) {
       ck->load_point((ck->use_dual_barrier ? dz : dsv) + offs[k], irtmu);

@@ -12,6 +12,8 @@ the CPU tests.  The local numerical back end is injected (`local_backend`): the 
 cones here, the numpy oracle in tests/test_distributed_gloo.py (there is no CPU fallback in the
 product: the default back end needs the GPU).
 """
+import sys
+
 import numpy as np
 
 from . import _lib as L
@@ -33,6 +35,16 @@ class Comm:
         self.device = device or ("cuda" if dist.get_backend() == "nccl" else "cpu")
         self._ops = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}
         self.n_collectives = 0
+        self.hist = None     # HYP_PROFILE=1: {(origin, payload doubles, op): calls}
+        import os
+        if os.environ.get("HYP_PROFILE", "0") not in ("", "0"):
+            import collections
+            self.hist = collections.Counter()
+
+    def _count(self, origin, count, op):
+        self.n_collectives += 1
+        if self.hist is not None:
+            self.hist[(origin, int(count), str(op))] += 1
 
     def _to(self, arr):
         t = self.torch.from_numpy(np.ascontiguousarray(arr))
@@ -43,14 +55,14 @@ class Comm:
         t = self._to(arr)
         self.dist.all_reduce(t, op=self._ops[op])
         arr[...] = t.cpu().numpy().reshape(arr.shape)
-        self.n_collectives += 1
+        self._count("host:" + (sys._getframe(1).f_code.co_name if self.hist is not None else ""), arr.size, op)
         return arr
 
     def bcast(self, arr, src):
         t = self._to(arr)
         self.dist.broadcast(t, src=src)
         arr[...] = t.cpu().numpy().reshape(arr.shape)
-        self.n_collectives += 1
+        self._count("host:bcast", arr.size, "bcast")
         return arr
 
     def bcast_scalar(self, value, src):
@@ -324,7 +336,7 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
             try:
                 dist.all_reduce(stage[:count], op=ops[op])
                 torch.cuda.synchronize()
-                comm.n_collectives += 1
+                comm._count("library", count, op)
                 return 0
             except Exception as e:   # never let an exception cross the C boundary
                 print("all-reduce callback failed:", e)
