@@ -108,6 +108,13 @@ int hyp_cone_create_wsosinterpnonnegative(hyp_ctx* ctx, int U, int K, const int*
   ctx->c.sync();
   API_END(ctx)
 }
+int hyp_cone_create_linmatrixineq(hyp_ctx* ctx, int dim, int side, const double* As, int use_dual, hyp_cone** out) {
+  API_BEGIN
+  HYP_CHECK(hipSetDevice(ctx->c.device));
+  *out = new hyp_cone{ctx, new LmiCone(ctx->c, dim, side, As, use_dual != 0)};
+  ctx->c.sync();
+  API_END(ctx)
+}
 int hyp_cone_update_use_hess_prod_slow(hyp_cone* cone, int* out) {
   API_BEGIN
   GenericHessCone* g = dynamic_cast<GenericHessCone*>(cone->cone);

@@ -13,7 +13,7 @@ bool psd_two_sided_fused_ok(int side);
 void psd_two_sided_fused(Ctx& c, int side, int ncols, const double* R, int rstruct /* 0 full, 1 upper, 2 lower */, const double* arr,
                          long lda, double* prod, long ldp, double* zws /* ncols * side^2 */);
 
-enum ConeKind { CONE_NONNEG = 0, CONE_PSD = 1, CONE_EPINORMSPECTRAL = 2, CONE_WSOS = 3 };
+enum ConeKind { CONE_NONNEG = 0, CONE_PSD = 1, CONE_EPINORMSPECTRAL = 2, CONE_WSOS = 3, CONE_LMI = 4 };
 
 struct Cone {
   Ctx& ctx;
@@ -174,6 +174,19 @@ struct WsosCone : GenericHessCone {   // src/Cones/wsosinterpnonnegative.jl (rea
   void hess_prod_slow(double* prod, long ldp, const double* arr, long lda, int ncols) override;   // :152-175
   const double* dder3(const double* d_dir) override;                                               // :177-188
   void partial_lambda(int k, const double* d_dir);                                                 // :190-200 -> LU[k]
+};
+
+struct LmiCone : GenericHessCone {   // src/Cones/linmatrixineq.jl (real dense symmetric members)
+  int side;
+  DBuf Amat;      // side^2 x dim: column i = A_i (col-major side x side)
+  DBuf sumA, fact, fdinv, Rinv, T, Mmat, dirmat, Zm, infos, Jm;   // Mmat: side^2 x dim, column i = L^-1 A_i L^-T
+  LmiCone(Ctx& c, int dim, int side, const double* hAs, bool use_dual);
+  bool update_feas() override;                                                                      // :87-96
+  void update_grad() override;                                                                      // :98-109
+  void update_hess() override;                                                                      // :111-123
+  void set_initial_point(double* h_out) override;                                                   // :74-81
+  void hess_prod_slow(double* prod, long ldp, const double* arr, long lda, int ncols) override;    // :125-144
+  const double* dder3(const double* d_dir) override;                                                // :146-159
 };
 
 struct EpiNormSpectralCone : GenericHessCone {   // src/Cones/epinormspectral.jl (real)

@@ -278,4 +278,110 @@ const double* WsosCone::dder3(const double* d_dir) {   // :177-188
   return dder3v.d();
 }
 
+// ---------------------------------------------------------------------------------------------
+// LinMatrixIneq (linmatrixineq.jl:9-159), real dense symmetric members: barrier -logdet(sum_i w_i A_i).
+// With sumA = U'U (the reference keeps L = U'), M_i = L^-1 A_i L^-T = R' A_i R for R = U^-1: the two-sided
+// product of the PSD cone, batched over the members; everything else is a product with the
+// side^2 x dim matrix Mmat = [vec M_1 ... vec M_dim]: gradient = -traces, Hessian = Mmat' Mmat (a syrk),
+// the slow Hessian product and the third-order term = Mmat' (.) of a side x side matrix.
+// ---------------------------------------------------------------------------------------------
+__global__ void lmi_neg_trace_kernel(int side, int dim, const double* __restrict__ M, double* __restrict__ grad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= dim) return;
+  const double* m = M + (long)i * side * side;
+  double t = 0.0;
+  for (int k = 0; k < side; ++k) t += m[(long)k * side + k];
+  grad[i] = -t;
+}
+
+LmiCone::LmiCone(Ctx& c, int dim_, int side_, const double* hAs, bool use_dual) : GenericHessCone(c, CONE_LMI) {
+  HYP_REQUIRE(dim_ > 1 && side_ >= 1 && (long)side_ * (side_ + 1) / 2 >= dim_, "LinMatrixIneq: 1 < dim <= side (side + 1) / 2");   // :42, :56
+  dim = dim_; side = side_;
+  use_dual_barrier = use_dual;
+  nu = side;                                                                                          // :72
+  alloc_common();
+  alloc_generic();
+  const size_t s2 = (size_t)side * side * sizeof(double);
+  Amat.alloc(s2 * dim); Mmat.alloc(s2 * dim); T.alloc(s2 * dim);
+  sumA.alloc(s2); fact.alloc(s2); Rinv.alloc(s2); dirmat.alloc(s2); Zm.alloc(s2);
+  fdinv.alloc(dinv_elems(side) * sizeof(double));
+  infos.alloc(64);
+  ctx.h2d(Amat.p, hAs, s2 * dim);
+  ctx.sync();
+}
+
+void LmiCone::set_initial_point(double* h) {   // :74-81
+  for (int i = 0; i < dim; ++i) h[i] = 0.0;
+  h[0] = 1.0;
+}
+
+bool LmiCone::update_feas() {   // :87-96
+  const int s2 = side * side;
+  gemv(ctx, false, s2, dim, 1.0, Amat.d(), s2, point.d(), 0.0, sumA.d());        // sumA = sum_i w_i A_i
+  ctx.d2d(fact.p, sumA.p, (size_t)s2 * sizeof(double));
+  potrf_upper_batched(ctx, side, fact.d(), side, 0, 1, fdinv.d(), infos.i());
+  is_feas_ = (read_info(ctx, infos.i()) == 0);
+  feas_updated = true;
+  return is_feas_;
+}
+
+void LmiCone::update_grad() {   // :98-109
+  const long s2 = (long)side * side;
+  trtri_upper_batched(ctx, side, fact.d(), side, 0, fdinv.d(), 0, Rinv.d(), side, 0, 1);   // R = U^-1
+  GemmArgs a{};   // T_i = A_i R
+  a.M = side; a.N = side; a.K = side; a.A = Amat.d(); a.lda = side; a.strideA = s2; a.B = Rinv.d(); a.ldb = side; a.strideB = 0;
+  a.C = T.d(); a.ldc = side; a.strideC = s2; a.alpha = 1; a.beta = 0; a.batch = dim;
+  gemm(ctx, false, a);
+  GemmArgs b{};   // M_i = R' T_i
+  b.M = side; b.N = side; b.K = side; b.A = Rinv.d(); b.lda = side; b.strideA = 0; b.B = T.d(); b.ldb = side; b.strideB = s2;
+  b.C = Mmat.d(); b.ldc = side; b.strideC = s2; b.alpha = 1; b.beta = 0; b.batch = dim;
+  gemm(ctx, true, b);
+  dev_symmetrize_from_upper(ctx, side, Mmat.d(), side, dim, s2);                             // Hermitian(., :U)
+  hipLaunchKernelGGL(lmi_neg_trace_kernel, dim3((dim + 255) / 256), dim3(256), 0, ctx.stream, side, dim, Mmat.d(), grad.d());
+  HYP_CHECK(hipGetLastError());
+  grad_updated = true;
+}
+
+void LmiCone::update_hess() {   // :111-123: H[i, j] = <M_i, M_j>
+  ensure_hess_storage(false);
+  get_grad();
+  const int s2 = side * side;
+  GemmArgs g{};
+  g.M = dim; g.N = dim; g.K = s2; g.A = Mmat.d(); g.lda = s2; g.B = Mmat.d(); g.ldb = s2; g.C = H.d(); g.ldc = dim;
+  g.alpha = 1; g.beta = 0; g.tri = GEMM_UPPER; g.batch = 1;
+  gemm(ctx, true, g);
+  dev_symmetrize_from_upper(ctx, dim, H.d(), dim, 1, 0);
+  hess_updated = true;
+}
+
+void LmiCone::hess_prod_slow(double* prod, long ldp, const double* arr, long lda, int ncols) {   // :125-144
+  if (!use_hess_prod_slow_updated) update_use_hess_prod_slow();
+  if (!use_hess_prod_slow) {
+    hess_prod(prod, ldp, arr, lda, ncols);
+    return;
+  }
+  if (ncols <= 0) return;
+  const int s2 = side * side;
+  Jm.ensure((size_t)s2 * ncols * sizeof(double));
+  GemmArgs a{};   // j_mat = sum_i arr[i, j] M_i, all columns j at once
+  a.M = s2; a.N = ncols; a.K = dim; a.A = Mmat.d(); a.lda = s2; a.B = arr; a.ldb = lda; a.C = Jm.d(); a.ldc = s2;
+  a.alpha = 1; a.beta = 0; a.batch = 1;
+  gemm(ctx, false, a);
+  GemmArgs b{};   // prod[i, j] = <j_mat, M_i>
+  b.M = dim; b.N = ncols; b.K = s2; b.A = Mmat.d(); b.lda = s2; b.B = Jm.d(); b.ldb = s2; b.C = prod; b.ldc = ldp;
+  b.alpha = 1; b.beta = 0; b.batch = 1;
+  gemm(ctx, true, b);
+}
+
+const double* LmiCone::dder3(const double* d_dir) {   // :146-159
+  const int s2 = side * side;
+  gemv(ctx, false, s2, dim, 1.0, Mmat.d(), s2, d_dir, 0.0, dirmat.d());           // dir_mat = sum_i d_i M_i (symmetric)
+  GemmArgs z{};   // Z = dir_mat dir_mat'
+  z.M = side; z.N = side; z.K = side; z.A = dirmat.d(); z.lda = side; z.B = dirmat.d(); z.ldb = side; z.C = Zm.d(); z.ldc = side;
+  z.alpha = 1; z.beta = 0; z.batch = 1;
+  gemm(ctx, true, z);
+  gemv(ctx, true, s2, dim, 1.0, Mmat.d(), s2, Zm.d(), 0.0, dder3v.d());           // dder3_i = <Z, M_i>
+  return dder3v.d();
+}
+
 }  // namespace hyp

@@ -45,6 +45,10 @@ int hyp_cone_create_epinormspectral(hyp_ctx* ctx, int d1, int d2, int use_dual, 
 /* Cones.WSOSInterpNonnegative{Float64,Float64}(U, Ps; use_dual) (wsosinterpnonnegative.jl:49-63):
  * Ps[k] is U x Ls[k], column-major; the matrices are copied to the device */
 int hyp_cone_create_wsosinterpnonnegative(hyp_ctx* ctx, int U, int K, const int* Ls, const double* const* Ps, int use_dual, hyp_cone** out);
+/* Cones.LinMatrixIneq{Float64}(As; use_dual) (linmatrixineq.jl:36-65), real dense symmetric members: As holds the
+ * dim matrices one after the other, each side x side column-major (A_1 positive definite, dim <= side (side + 1) / 2);
+ * copied to the device.  nu = side. */
+int hyp_cone_create_linmatrixineq(hyp_ctx* ctx, int dim, int side, const double* As, int use_dual, hyp_cone** out);
 int hyp_cone_destroy(hyp_cone* cone);
 int hyp_cone_dimension(hyp_cone* cone, int* out);            /* Cones.jl:34 */
 int hyp_cone_get_nu(hyp_cone* cone, double* out);            /* Cones.jl:41 */

@@ -688,3 +688,87 @@ class WSOSInterpNonnegative(Cone):
             LU = self._partial_lambda(dir, self.LamFLP[k])
             self.dder3_ += np.sum(LU ** 2, axis=0)
         return self.dder3_
+
+
+# ----------------------------------------------------------------------------------------------
+class LinMatrixIneq(Cone):
+    """linmatrixineq.jl:9-159, real dense symmetric `As` (the reference also accepts sparse, Diagonal,
+    UniformScaling and complex Hermitian members: converted to dense real by the caller / out of scope).
+    Barrier -logdet(sum_i w_i A_i); the explicit Hessian and the generic fallbacks of Cones.jl do the rest."""
+
+    def __init__(self, As, use_dual=False):
+        As = [np.array(A, dtype=np.float64) for A in As]
+        self.dim = len(As)
+        assert self.dim > 1                                    # :42
+        self.side = As[0].shape[0]
+        for A in As:
+            assert A.shape == (self.side, self.side) and np.array_equal(A, A.T)   # :44-53
+        assert self.side * (self.side + 1) // 2 >= self.dim    # :56
+        assert np.all(np.linalg.eigvalsh(As[0]) > 0)           # :57 isposdef(first(As))
+        self.use_dual_barrier_ = bool(use_dual)
+        self.As = As
+        self.nu = self.side                                    # :72
+
+    def reset_data(self):   # :68-70
+        self.feas_updated = self.grad_updated = self.hess_updated = self.inv_hess_updated = False
+        self.hess_fact_updated = False
+        self.use_hess_prod_slow = self.use_hess_prod_slow_updated = False
+
+    def set_initial_point(self, arr):   # :74-81
+        arr[:] = 0.0
+        arr[0] = 1.0
+        return arr
+
+    def update_feas(self):   # :87-96
+        assert not self.feas_updated
+        sumA = sum(w * A for w, A in zip(self.point, self.As))
+        c, info = lapack.dpotrf(np.asfortranarray(sumA), lower=1, clean=1)
+        self.fact_L = c
+        self.is_feas_ = (info == 0)
+        self.feas_updated = True
+        return self.is_feas_
+
+    def update_grad(self):   # :98-109
+        assert self.is_feas_
+        Lf = self.fact_L
+        self.sumAinvAs = []
+        for i, A in enumerate(self.As):
+            T = blas.dtrsm(1.0, Lf, np.asfortranarray(A), side=0, lower=1, trans_a=0, diag=0)        # L \ A_i
+            M = blas.dtrsm(1.0, Lf, np.asfortranarray(T.T), side=0, lower=1, trans_a=0, diag=0)      # L \ (L \ A_i)'
+            M = np.triu(M) + np.triu(M, 1).T                                                          # Hermitian(., :U)
+            self.sumAinvAs.append(M)
+            self.grad[i] = -np.trace(M)
+        self.grad_updated = True
+        return self.grad
+
+    def update_hess(self):   # :111-123 (upper triangle)
+        assert self.grad_updated
+        H = np.zeros((self.dim, self.dim))
+        for i in range(self.dim):
+            for j in range(i, self.dim):
+                H[i, j] = np.sum(self.sumAinvAs[i] * self.sumAinvAs[j])
+        self.hess_ = H
+        self.hess_updated = True
+        return self.hess_
+
+    def hess_prod_slow(self, prod, arr):   # :125-144
+        if not self.use_hess_prod_slow_updated:
+            self.update_use_hess_prod_slow()
+        assert self.hess_updated
+        if not self.use_hess_prod_slow:
+            return self.hess_prod(prod, arr)
+        assert self.grad_updated
+        P, A = _cols(prod), _cols(arr)
+        for j in range(A.shape[1]):
+            j_mat = sum(A[i, j] * self.sumAinvAs[i] for i in range(self.dim))
+            for i in range(self.dim):
+                P[i, j] = np.sum(j_mat * self.sumAinvAs[i])
+        return prod
+
+    def dder3(self, dir):   # :146-159
+        assert self.grad_updated
+        dir_mat = sum(d * M for d, M in zip(dir, self.sumAinvAs))
+        Z = dir_mat @ dir_mat.T
+        for i in range(self.dim):
+            self.dder3_[i] = np.sum(Z * self.sumAinvAs[i])
+        return self.dder3_

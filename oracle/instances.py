@@ -155,6 +155,42 @@ def wsosinterpnonnegative3():   # :2326-2343
             [("wsosinterpnonnegative", U, Ps, True)], dict(status="Optimal", primal_obj=0.0))
 
 
+def linmatrixineq1(side, seed=1):   # :696-719 (real case; property-based: objective = 2 / largest eigenvalue of A_1)
+    rng = np.random.default_rng(seed)
+    Ah = rng.random((side, side))
+    A1 = Ah @ Ah.T + 2 * np.eye(side)
+    A1 = 0.5 * (A1 + A1.T)
+    vals, vecs = np.linalg.eigh(A1)
+    v1 = vecs[:, -1]
+    A2 = -np.outer(v1, v1)
+    A2 = 0.5 * (A2 + A2.T)
+    G = np.zeros((2, 1))
+    G[0, 0] = -1.0
+    return (np.array([1.0]), np.zeros((0, 1)), np.zeros(0), G, np.array([0.0, 2.0]), [("linmatrixineq", [A1, A2], False)],
+            dict(status="Optimal", primal_obj=2 / vals[-1], s=[2 / vals[-1], 2.0]))
+
+
+def linmatrixineq2(seed=1):   # :721-745 (the all-real member [T, T] of the list; only primal_obj < 0 is asserted)
+    rng = np.random.default_rng(seed)
+    As = []
+    for _ in range(2):
+        Ah = rng.random((3, 3))
+        M = Ah @ Ah.T
+        As.append(0.5 * (M + M.T))
+    As[0] = As[0] + np.eye(3)
+    G = np.vstack([np.zeros((1, 1)), -np.eye(1)])
+    return (np.ones(1), np.zeros((0, 1)), np.zeros(0), G, np.array([1.0, 0.0]), [("linmatrixineq", As, False)],
+            dict(status="Optimal", primal_obj_negative=True))
+
+
+def linmatrixineq3():   # :747-789 (dense members; the sparse / Diagonal / I variants are the same matrices)
+    As = [np.array([[1.0, 0.0], [0.0, 1.0]]), np.array([[1.0, 0.0], [0.0, -1.0]])]
+    G = np.zeros((2, 1))
+    G[0, 0] = -1.0
+    return (np.array([1.0]), np.zeros((0, 1)), np.zeros(0), G, np.array([0.0, -1.0]), [("linmatrixineq", As, False)],
+            dict(status="Optimal", primal_obj=1.0, s=[1.0, -1.0]))
+
+
 KNOWN_ANSWER = {
     "dimension1": dimension1, "primalinfeas1": primalinfeas1, "nonnegative4": nonnegative4,
     "possemideftri1": possemideftri1, "possemideftri2": possemideftri2, "possemideftri3": possemideftri3,
@@ -165,6 +201,8 @@ KNOWN_ANSWER = {
     "epinormspectral4_primal": lambda: epinormspectral4(False), "epinormspectral4_dual": lambda: epinormspectral4(True),
     "wsosinterpnonnegative1": wsosinterpnonnegative1, "wsosinterpnonnegative2": wsosinterpnonnegative2,
     "wsosinterpnonnegative3": wsosinterpnonnegative3,
+    "linmatrixineq1_side2": lambda: linmatrixineq1(2), "linmatrixineq1_side4": lambda: linmatrixineq1(4),
+    "linmatrixineq2": linmatrixineq2, "linmatrixineq3": linmatrixineq3,
 }
 
 

@@ -35,6 +35,23 @@ CONE_CASES = {
 }
 
 
+def _lmi_members(side, count, seed):   # test/cone.jl:280-289 (rand_herms, real members)
+    rng = np.random.default_rng(seed)
+    Ah = rng.standard_normal((side, side))
+    As = [Ah @ Ah.T + np.eye(side)]
+    for _ in range(count - 1):
+        M = rng.standard_normal((side, side))
+        As.append(np.triu(M) + np.triu(M, 1).T)
+    return [0.5 * (A + A.T) for A in As]
+
+
+CONE_CASES["linmatrixineq_side4_dim5"] = ("linmatrixineq", _lmi_members(4, 5, 7), False)
+
+# seeds of the oracle points: fixed per case, so that adding a case leaves the committed vectors of the others unchanged
+SEEDS = {"epinormspectral_2x4_dual": 100, "epinormspectral_3x5": 101, "nonnegative_6": 102, "possemideftri_side19": 103,
+         "possemideftri_side5": 104, "wsos_2var_halfdeg3": 105, "wsos_2var_halfdeg3_dual": 106, "linmatrixineq_side4_dim5": 107}
+
+
 def wsos_spec(use_dual):
     rng = np.random.default_rng(5)
     U, pts, Ps = pu.interpolate_box([-1.0, -1.0], [1.0, 1.0], 3, rng=rng, sample_factor=10)
@@ -96,8 +113,8 @@ def main():
     specs = {k: v for k, v in cases.items()}
     specs["wsos_2var_halfdeg3"] = wsos_spec(False)
     specs["wsos_2var_halfdeg3_dual"] = wsos_spec(True)
-    for i, (name, spec) in enumerate(sorted(specs.items())):
-        vec = cone_vectors(spec, seed=100 + i)
+    for name, spec in sorted(specs.items()):
+        vec = cone_vectors(spec, seed=SEEDS[name])
         for k, v in vec.items():
             flat[name + "/" + k] = v
     np.savez_compressed(os.path.join(HERE, "cone_vectors.npz"), **flat)

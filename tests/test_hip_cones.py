@@ -202,3 +202,73 @@ def test_epinormspectral_dual_feasibility_nuclear_norm():
         for margin, expect in ((1e-6, True), (-1e-6, False)):
             c.load_dual_point(np.concatenate([[nn * (1 + margin)], Wm.reshape(-1, order="F")]))
             assert c.is_dual_feas() == expect, (d1, d2, margin)
+
+
+# ---------------------------------------------------------------------------------------------
+# LinMatrixIneq (a PSD-family neighbour built from the same kernels)
+# ---------------------------------------------------------------------------------------------
+def _rand_syms(side, count, rng):   # test/cone.jl:280-289 (rand_herms, real members)
+    Ah = rng.standard_normal((side, side))
+    As = [Ah @ Ah.T + np.eye(side)]
+    for _ in range(count - 1):
+        M = rng.standard_normal((side, side))
+        As.append(np.triu(M) + np.triu(M, 1).T)
+    return [0.5 * (A + A.T) for A in As]
+
+
+@pytest.mark.parametrize("side,count", [(2, 2), (3, 2), (4, 2), (3, 3), (4, 3)])
+def test_linmatrixineq_identities(side, count):   # test/cone.jl:423-429
+    import hypatia_jl_amd as H
+    rng = np.random.default_rng(side * 10 + count)
+    run_test_oracles(H.LinMatrixIneq(_rand_syms(side, count, rng)), noise=1e-2, init_tol=np.inf)
+
+
+@pytest.mark.parametrize("side,count", [(3, 2), (12, 30), (150, 400)])
+def test_linmatrixineq_vs_oracle(side, count):
+    """every oracle against the CPU restatement at a random interior point, including the forced slow Hessian product"""
+    import hypatia_jl_amd as H
+    from oracle import cones as oc
+    rng = np.random.default_rng(side + count)
+    As = _rand_syms(side, count, rng)
+    for A in As[1:]:
+        A *= 1.0 / np.sqrt(side)
+    hc, occ = H.LinMatrixIneq(As), oc.LinMatrixIneq(As)
+    dim = count
+    assert hc.dimension() == occ.dimension() == dim and hc.get_nu() == occ.get_nu() == side
+    pt = np.zeros(dim)
+    occ.set_initial_point(pt)
+    pt2 = np.ones(dim)
+    hc.set_initial_point(pt2)
+    assert np.array_equal(pt, pt2)
+    pt = pt + 0.05 / np.sqrt(dim) * (2 * rng.random(dim) - 1)
+    dual = -pt + 0.01 * rng.random(dim)
+    for c in (hc, occ):
+        c.setup_data()
+        c.reset_data()
+        c.load_point(pt, 0.9)
+        c.load_dual_point(dual)
+        assert c.is_feas()
+        assert c.is_dual_feas()
+    g_h, g_o = np.array(hc.get_grad()), np.array(occ.get_grad())
+    assert rel(g_h, g_o) < 1e-11
+    V = np.asfortranarray(rng.standard_normal((dim, 3)))
+    for name in ("hess_prod", "inv_hess_prod", "hess_prod_slow"):
+        Ph, Po = np.zeros((dim, 3), order="F"), np.zeros((dim, 3), order="F")
+        getattr(hc, name)(Ph, V)
+        getattr(occ, name)(Po, V)
+        assert rel(Ph, Po) < 1e-8, name
+    d3h, d3o = np.array(hc.dder3(V[:, 0].copy() * 0.01)), np.array(occ.dder3(V[:, 0].copy() * 0.01))
+    assert rel(d3h, d3o) < 1e-10
+    assert hc.check_numerics() == occ.check_numerics()
+    ph, po = hc.get_proxsqr(0.9, True), occ.get_proxsqr(0.9, True)
+    assert abs(ph - po) <= 1e-7 * max(1.0, abs(po))
+    for c in (hc, occ):
+        c.use_hess_prod_slow = True
+        c.use_hess_prod_slow_updated = True
+    Ph, Po = np.zeros((dim, 3), order="F"), np.zeros((dim, 3), order="F")
+    hc.hess_prod_slow(Ph, V)
+    occ.hess_prod_slow(Po, V)
+    assert rel(Ph, Po) < 1e-10
+    Pf = np.zeros((dim, 3), order="F")
+    hc.hess_prod(Pf, V)
+    assert rel(Ph, Pf) < 1e-9          # the operator form agrees with the explicit Hessian

@@ -79,3 +79,24 @@ def test_svec_roundtrip_and_order():
     b = np.random.default_rng(0).standard_normal((4, 4)); b = b + b.T
     vb = np.zeros(10); au.smat_to_svec(vb, b)
     assert np.isclose(v @ vb, np.trace(m @ b))
+
+
+def _rand_syms(side, count, rng):   # test/cone.jl:280-289 (rand_herms, real members)
+    Ah = rng.standard_normal((side, side))
+    As = [Ah @ Ah.T + np.eye(side)]
+    for _ in range(count - 1):
+        M = rng.standard_normal((side, side))
+        As.append(np.triu(M) + np.triu(M, 1).T)
+    return [0.5 * (A + A.T) for A in As]
+
+
+@pytest.mark.parametrize("side,count", [(2, 2), (3, 2), (4, 2), (3, 3), (4, 3)])
+def test_linmatrixineq_oracles(side, count):   # test/cone.jl:423-429
+    rng = np.random.default_rng(side * 10 + count)
+    run_test_oracles(oc.LinMatrixIneq(_rand_syms(side, count, rng)), noise=1e-2, init_tol=np.inf)
+
+
+def test_linmatrixineq_barrier():   # test/cone.jl:431-436
+    rng = np.random.default_rng(1)
+    Ps = _rand_syms(2, 2, rng)
+    run_test_barrier(oc.LinMatrixIneq(Ps), lambda s: -np.linalg.slogdet(sum(s[i] * Ps[i] for i in range(len(Ps))))[1])
