@@ -15,6 +15,8 @@ def make_cone(spec):
         return hc.WSOSInterpNonnegative(spec[1], spec[2], use_dual=spec[3])
     if kind == "linmatrixineq":
         return hc.LinMatrixIneq(spec[1], use_dual=spec[2])
+    if kind == "doublynonnegativetri":
+        return hc.DoublyNonnegativeTri(spec[1], use_dual=spec[2])
     raise NotImplementedError("no HIP cone for %r yet (and there is no CPU fallback)" % (kind,))
 
 

@@ -273,3 +273,14 @@ class LinMatrixIneq(_GenericHessMixin, Cone):
         L.check(L.lib().hyp_cone_create_linmatrixineq(L.ctx(), dim, side, stacked.ctypes.data_as(c_vp), int(bool(use_dual)), ctypes.byref(h)),
                 "hyp_cone_create_linmatrixineq")
         super().__init__(h)
+
+
+class DoublyNonnegativeTri(_GenericHessMixin, Cone):
+    """Cones.DoublyNonnegativeTri{Float64}(dim; use_dual)  (doublynonnegativetri.jl:9-52)."""
+
+    def __init__(self, dim, use_dual=False):
+        self._slow = False
+        h = c_vp()
+        L.check(L.lib().hyp_cone_create_doublynonnegativetri(L.ctx(), int(dim), int(bool(use_dual)), ctypes.byref(h)),
+                "hyp_cone_create_doublynonnegativetri")
+        super().__init__(h)

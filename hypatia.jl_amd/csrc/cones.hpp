@@ -13,7 +13,7 @@ bool psd_two_sided_fused_ok(int side);
 void psd_two_sided_fused(Ctx& c, int side, int ncols, const double* R, int rstruct /* 0 full, 1 upper, 2 lower */, const double* arr,
                          long lda, double* prod, long ldp, double* zws /* ncols * side^2 */);
 
-enum ConeKind { CONE_NONNEG = 0, CONE_PSD = 1, CONE_EPINORMSPECTRAL = 2, CONE_WSOS = 3, CONE_LMI = 4 };
+enum ConeKind { CONE_NONNEG = 0, CONE_PSD = 1, CONE_EPINORMSPECTRAL = 2, CONE_WSOS = 3, CONE_LMI = 4, CONE_DNN = 5 };
 
 struct Cone {
   Ctx& ctx;
@@ -187,6 +187,22 @@ struct LmiCone : GenericHessCone {   // src/Cones/linmatrixineq.jl (real dense s
   void set_initial_point(double* h_out) override;                                                   // :74-81
   void hess_prod_slow(double* prod, long ldp, const double* arr, long lda, int ncols) override;    // :125-144
   const double* dder3(const double* d_dir) override;                                                // :146-159
+};
+
+struct DnnCone : GenericHessCone {   // src/Cones/doublynonnegativetri.jl: PSD and entrywise nonnegative, svec format
+  PsdCone psd;     // the -logdet part: same point, same kernels
+  DBuf cnt;
+  DnnCone(Ctx& c, int dim, bool use_dual);
+  void reset_data() override {
+    GenericHessCone::reset_data();
+    psd.reset_data();
+  }
+  bool update_feas() override;                                                                      // :130-143
+  void update_grad() override;                                                                      // :145-156
+  void update_hess() override;                                                                      // :158-171
+  void set_initial_point(double* h_out) override;                                                   // :71-128
+  void hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;         // :173-192
+  const double* dder3(const double* d_dir) override;                                                // :194-205
 };
 
 struct EpiNormSpectralCone : GenericHessCone {   // src/Cones/epinormspectral.jl (real)

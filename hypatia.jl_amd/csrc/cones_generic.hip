@@ -384,4 +384,153 @@ const double* LmiCone::dder3(const double* d_dir) {   // :146-159
   return dder3v.d();
 }
 
+// ---------------------------------------------------------------------------------------------
+// DoublyNonnegativeTri (doublynonnegativetri.jl:9-205): barrier -logdet(smat(s)) - sum over the off-diagonal svec
+// entries of log(s_k).  The -logdet part IS the PosSemidefTri cone at the same point (its kernels are reused through
+// an inner PsdCone); the entrywise part adds a diagonal term to the gradient, Hessian and third-order oracle.  The
+// inverse Hessian has no closed form: explicit Hessian + factorization, the generic path of Cones.jl:101-118, 239-259.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool svec_is_diag(long k) {   // svec position k holds (i, j) with j(j+1)/2 + i = k, i <= j
+  long j = (long)((sqrt(8.0 * (double)k + 1.0) - 1.0) * 0.5);
+  while (j * (j + 1) / 2 > k) --j;
+  while ((j + 1) * (j + 2) / 2 <= k) ++j;
+  return k == j * (j + 1) / 2 + j;
+}
+__global__ void dnn_count_small_kernel(int dim, const double* __restrict__ pt, double thresh, int* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < dim && !(pt[k] > thresh)) atomicAdd(out, 1);
+}
+// mode 0: out[k] -= 1 / p_k;  mode 1: out[k, c] += arr[k, c] / p_k / p_k;  mode 2: out[k] += (arr[k] / p_k)^2 / p_k   (off-diagonal k only)
+__global__ void dnn_offdiag_kernel(int dim, int ncols, int mode, const double* __restrict__ pt, const double* __restrict__ arr, long lda,
+                                   double* __restrict__ out, long ldo) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= dim || svec_is_diag(k)) return;
+  const double p = pt[k];
+  if (mode == 0) {
+    out[k] -= 1.0 / p;
+  } else if (mode == 1) {
+    for (int c = blockIdx.y; c < ncols; c += gridDim.y) out[(long)c * ldo + k] += arr[(long)c * lda + k] / p / p;
+  } else {
+    const double t = arr[k] / p;
+    out[k] += t * t / p;
+  }
+}
+
+DnnCone::DnnCone(Ctx& c, int dim_, bool use_dual) : GenericHessCone(c, CONE_DNN), psd(c, dim_) {
+  dim = dim_;
+  use_dual_barrier = use_dual;
+  nu = dim;                                                                                           // :69
+  alloc_common();
+  alloc_generic();
+  cnt.alloc(64);
+}
+
+// real roots of a y^3 + b y^2 + c y + d (a != 0), polished by Newton steps
+static int cubic_real_roots(double a, double b, double c, double d, double* r) {
+  const double PI = 3.14159265358979323846;
+  const double p = (3 * a * c - b * b) / (3 * a * a), q = (2 * b * b * b - 9 * a * b * c + 27 * a * a * d) / (27 * a * a * a);
+  const double sh = -b / (3 * a);
+  int n = 0;
+  const double disc = q * q / 4 + p * p * p / 27;
+  if (disc > 0) {
+    const double sq = sqrt(disc);
+    r[n++] = cbrt(-q / 2 + sq) + cbrt(-q / 2 - sq) + sh;
+  } else if (p == 0) {
+    r[n++] = sh;
+  } else {
+    const double m = 2 * sqrt(-p / 3);
+    double arg = 3 * q / (p * m);
+    arg = arg > 1 ? 1 : (arg < -1 ? -1 : arg);
+    const double th = acos(arg) / 3;
+    for (int k = 0; k < 3; ++k) r[n++] = m * cos(th - 2 * PI * k / 3) + sh;
+  }
+  for (int i = 0; i < n; ++i)
+    for (int it = 0; it < 4; ++it) {
+      const double y = r[i], f = ((a * y + b) * y + c) * y + d, fp = (3 * a * y + 2 * b) * y + c;
+      if (fp != 0) r[i] = y - f / fp;
+    }
+  return n;
+}
+
+void DnnCone::set_initial_point(double* h) {   // :71-128
+  const int side = psd.side;
+  const double rt2 = sqrt(2.0), n = side, d = dim, tol = sqrt(EPS);
+  auto approx = [&](double x, double y) { return fabs(x - y) <= tol * fmax(fabs(x), fabs(y)); };   // Julia's isapprox default
+  double on_diag, off_diag;
+  if (side == 1) {
+    on_diag = off_diag = 1.0;
+  } else if (side == 2) {
+    on_diag = sqrt(5.0) / 2; off_diag = 1.0 / rt2;
+  } else {
+    // the off-diagonal is a root of -n-1 + (n^2+n+7) x^2 - (2n^2+8) x^4 + n^2 x^6: a cubic in y = x^2
+    on_diag = n + 1; off_diag = 1.0;
+    double r[3];
+    const int nr = cubic_real_roots(n * n, -(2 * n * n + 8), n * n + n + 7, -(n + 1), r);
+    for (int i = 0; i < nr; ++i) {
+      if (!(r[i] > 0)) continue;
+      const double offd = sqrt(r[i]);
+      const double temp = d - (d - n) * offd * offd;
+      if (!(temp > tol)) continue;
+      const double ond = sqrt(temp / n);
+      const double denom = ond * ond + (n - 2) / rt2 * ond * offd - (n - 1) * offd * offd / 2;
+      if (approx(ond * rt2 + (n - 2) * offd, ond * denom * rt2) && approx(denom, offd * offd * (denom + 1))) {   // s = -g(s)
+        on_diag = ond; off_diag = offd;
+        break;
+      }
+    }
+  }
+  for (int k = 0; k < dim; ++k) h[k] = off_diag;
+  long k = 0;
+  for (int i = 1; i <= side; ++i) { h[k] = on_diag; k += i + 1; }
+}
+
+bool DnnCone::update_feas() {   // :130-143: every svec entry > eps, then the Cholesky of smat(point)
+  ctx.zero(cnt.p, sizeof(int));
+  hipLaunchKernelGGL(dnn_count_small_kernel, dim3((dim + 255) / 256), dim3(256), 0, ctx.stream, dim, point.d(), EPS, cnt.i());
+  HYP_CHECK(hipGetLastError());
+  is_feas_ = (read_info(ctx, cnt.i()) == 0);
+  if (is_feas_) {
+    psd.load_point(point.d(), 1.0);
+    psd.reset_data();
+    is_feas_ = psd.is_feas();
+  }
+  feas_updated = true;
+  return is_feas_;
+}
+
+void DnnCone::update_grad() {   // :145-156
+  ctx.d2d(grad.p, psd.get_grad(), (size_t)dim * sizeof(double));
+  hipLaunchKernelGGL(dnn_offdiag_kernel, dim3((dim + 255) / 256), dim3(256), 0, ctx.stream, dim, 1, 0, point.d(), nullptr, 0L, grad.d(), 0L);
+  HYP_CHECK(hipGetLastError());
+  grad_updated = true;
+}
+
+void DnnCone::hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) {   // :173-192
+  HYP_REQUIRE(prod != arr, "DoublyNonnegativeTri hess_prod: in-place call");
+  if (ncols <= 0) return;
+  if (!feas_updated) update_feas();
+  psd.hess_prod(prod, ldp, arr, lda, ncols);
+  hipLaunchKernelGGL(dnn_offdiag_kernel, dim3((dim + 255) / 256, std::min(ncols, 1024)), dim3(256), 0, ctx.stream, dim, ncols, 1, point.d(), arr,
+                     lda, prod, ldp);
+  HYP_CHECK(hipGetLastError());
+}
+
+void DnnCone::update_hess() {   // :158-171: symm_kron(inv(X)) + diag(1 / s_off^2) = hess_prod applied to the identity
+  ensure_hess_storage(false);
+  get_grad();
+  DBuf eye((size_t)dim * dim * sizeof(double));
+  dev_fill_identity(ctx, dim, eye.d(), dim);
+  hess_prod(H.d(), dim, eye.d(), dim, dim);
+  dev_symmetrize_from_upper(ctx, dim, H.d(), dim, 1, 0);
+  ctx.sync();   // (eye is released on return)
+  hess_updated = true;
+}
+
+const double* DnnCone::dder3(const double* d_dir) {   // :194-205
+  ctx.d2d(dder3v.p, psd.dder3(d_dir), (size_t)dim * sizeof(double));
+  hipLaunchKernelGGL(dnn_offdiag_kernel, dim3((dim + 255) / 256), dim3(256), 0, ctx.stream, dim, 1, 2, point.d(), d_dir, 0L, dder3v.d(), 0L);
+  HYP_CHECK(hipGetLastError());
+  return dder3v.d();
+}
+
 }  // namespace hyp

@@ -15,7 +15,7 @@
 
 namespace hyp {
 
-void gemm(Ctx& c, bool transa, GemmArgs a) { HYP_CHECK(gemm_f64_launch(c.stream, transa, a)); }
+void gemm(Ctx& c, bool transa, GemmArgs a) { HYP_CHECK(gemm_f64_launch(c.stream, transa, a, &c.gemm_scratch)); }
 
 // potrf_diag.hip: diagonal-block factor / inverse kernels and the substitution panel solve
 void potrf_diag_launch(hipStream_t st, bool factor, bool invert, int batch, int nblocks, double* A, long lda, long strideA, int n, int k0,
@@ -810,6 +810,7 @@ Ctx::~Ctx() {
   for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
   for (hipEvent_t e : aux)
     if (e) (void)hipEventDestroy(e);
+  gemm_scratch.release();
   if (stream2) (void)hipStreamDestroy(stream2);
   if (stream) (void)hipStreamDestroy(stream);
 }

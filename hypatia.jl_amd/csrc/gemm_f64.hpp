@@ -67,7 +67,22 @@ struct GemmArgs {
   const int* tile_map;   // optional (tm, tn) per blockIdx.x: XCD-aware tile order (set by the launcher)
 };
 
+// Launcher state that belongs to the caller's context (one per hyp_ctx, i.e. per device and stream pair): the split-K
+// partial-sum workspace and the cached XCD-aware tile order of the Schur syrk.  Without it (nullptr) the launcher
+// uses neither split-K nor a tile map.  Not shared between contexts; released by its owner.
+struct GemmScratch {
+  double* splitk_ws = nullptr;
+  size_t splitk_ws_bytes = 0;
+  int* tile_map = nullptr;
+  int tile_map_T = -1;
+  void release() {
+    if (splitk_ws) (void)hipFree(splitk_ws);
+    if (tile_map) (void)hipFree(tile_map);
+    splitk_ws = nullptr; splitk_ws_bytes = 0; tile_map = nullptr; tile_map_T = -1;
+  }
+};
+
 // launch on `st`; returns the HIP launch status
-hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a);
+hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch* scratch = nullptr);
 
 }  // namespace hyp

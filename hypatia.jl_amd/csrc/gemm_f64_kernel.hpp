@@ -280,17 +280,12 @@ __global__ void splitk_reduce_kernel(int M, int N, int upper, int tri_off, int S
   *cp = alpha * s + (beta != 0.0 ? beta * (*cp) : 0.0);
 }
 
-static double* g_splitk_ws = nullptr;
-static size_t g_splitk_ws_bytes = 0;
-
 // XCD-aware order of the upper tiles of a T x T grid.  Hardware workgroup b runs on XCD b % 8 (observed,
 // used for speed only): give every XCD a contiguous run of a super-tile-major enumeration (8 x 8 tiles
 // per super-tile), so that the ~64 tiles resident on one XCD at a time share 16 operand panels in its
 // private L2 instead of touching up to 128 different ones.
-static int* g_tile_map = nullptr;
-static int g_tile_map_T = -1;
-static const int* upper_tile_map(int T, long nblk) {
-  if (g_tile_map_T == T) return g_tile_map;
+static const int* upper_tile_map(GemmScratch& gs, int T, long nblk) {
+  if (gs.tile_map_T == T) return gs.tile_map;
   std::vector<int> logical;
   logical.reserve(2 * nblk);
   const int ST = 8, nst = (T + ST - 1) / ST;
@@ -310,14 +305,15 @@ static const int* upper_tile_map(int T, long nblk) {
     hw[2 * b] = logical[2 * L];
     hw[2 * b + 1] = logical[2 * L + 1];
   }
-  if (g_tile_map) (void)hipFree(g_tile_map);
-  if (hipMalloc((void**)&g_tile_map, hw.size() * sizeof(int)) != hipSuccess) { g_tile_map = nullptr; g_tile_map_T = -1; return nullptr; }
-  if (hipMemcpy(g_tile_map, hw.data(), hw.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-  g_tile_map_T = T;
-  return g_tile_map;
+  if (gs.tile_map) (void)hipFree(gs.tile_map);
+  gs.tile_map = nullptr; gs.tile_map_T = -1;
+  if (hipMalloc((void**)&gs.tile_map, hw.size() * sizeof(int)) != hipSuccess) { gs.tile_map = nullptr; return nullptr; }
+  if (hipMemcpy(gs.tile_map, hw.data(), hw.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  gs.tile_map_T = T;
+  return gs.tile_map;
 }
 
-hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a) {
+hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch* gs) {
   if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return hipSuccess;
   // Schur syrk with a thin last tile column (n = 5000 = 39 x 128 + 8): the 128-wide edge workgroup tiles
   // would do full work for r / 128 useful output (10 % of all tiles at n = 5000).  The r <= 32 edge
@@ -327,7 +323,7 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a) {
     const int r = a.N % 128, N0 = a.N - r;
     GemmArgs m = a;
     m.M = m.N = N0;
-    hipError_t e = gemm_f64_launch(st, transa, m);
+    hipError_t e = gemm_f64_launch(st, transa, m, gs);
     if (e != hipSuccess) return e;
     GemmArgs s = a;                      // C[0:N, N0:N], rows <= columns
     s.tag = 0; s.M = a.N; s.N = r;
@@ -335,7 +331,7 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a) {
     s.C = a.C + (long)N0 * a.ldc;
     s.tri = GEMM_UPPER_RECT; s.tri_off = N0;
     s.tile_hint = 64; s.splitk_req = 8;
-    return gemm_f64_launch(st, transa, s);
+    return gemm_f64_launch(st, transa, s, gs);
   }
   // tile choice: the 128 x 128 tile unless the product is too small to fill the chip with it
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
@@ -353,7 +349,7 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a) {
   // split-K for the tall Schur syrk: pick the slice count that minimises the number of rounds of
   // 512 resident workgroups (2 per CU) per unit of work, so the last round is not mostly empty
   a.splitk = 1;
-  if (a.tag == 1 && !small && a.batch == 1 && a.epi == 0 && a.krange == KR_ALL && a.K >= 4096) {
+  if (gs && a.tag == 1 && !small && a.batch == 1 && a.epi == 0 && a.krange == KR_ALL && a.K >= 4096) {
     // cost in units of one full-K round of 512 workgroups: rounds(S) / S, plus the partial-sum traffic of S
     // slices (N^2 / 2 doubles written and read back per slice at ~3.5 TB/s against 2.6e-7 K s per round;
     // measured at n = 5000, q = 20100: S = 3 -> 8.71 ms, S = 5 -> 8.42 ms, S = 7 -> 8.45 ms)
@@ -367,24 +363,25 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a) {
     static const int s_env = [] { const char* e = getenv("HYP_SYRK_S"); return e ? atoi(e) : 0; }();
     if (s_env > 0 && a.K / s_env >= 512) a.splitk = s_env;
   }
-  if (a.splitk_req > 1 && a.batch == 1 && a.epi == 0 && a.krange == KR_ALL && a.cm_blk == 0 && a.K / a.splitk_req >= 256) a.splitk = a.splitk_req;
+  if (gs && a.splitk_req > 1 && a.batch == 1 && a.epi == 0 && a.krange == KR_ALL && a.cm_blk == 0 && a.K / a.splitk_req >= 256) a.splitk = a.splitk_req;
   if (a.splitk > 1) {
     a.kchunk = (((a.K + a.splitk - 1) / a.splitk) + BK - 1) / BK * BK;
     a.part_ld = a.M;
     a.part_stride = (long)a.M * a.N;
     const size_t need = (size_t)a.splitk * a.part_stride * sizeof(double);
-    if (need > g_splitk_ws_bytes) {
-      if (g_splitk_ws) (void)hipFree(g_splitk_ws);
-      hipError_t e = hipMalloc((void**)&g_splitk_ws, need);
+    if (need > gs->splitk_ws_bytes) {
+      if (gs->splitk_ws) (void)hipFree(gs->splitk_ws);
+      gs->splitk_ws = nullptr; gs->splitk_ws_bytes = 0;
+      hipError_t e = hipMalloc((void**)&gs->splitk_ws, need);
       if (e != hipSuccess) return e;
-      g_splitk_ws_bytes = need;
+      gs->splitk_ws_bytes = need;
     }
-    a.part = g_splitk_ws;
+    a.part = gs->splitk_ws;
   }
   a.vec2 = (transa && ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.B % 16 == 0) && (a.lda % 2 == 0) && (a.ldb % 2 == 0) &&
             (a.strideA % 2 == 0) && (a.strideB % 2 == 0) && a.krange != KR_GE_M && a.krange != KR_GE_N) ? 1 : 0;
   a.tile_map = nullptr;
-  if (a.tag == 1 && a.tri == GEMM_UPPER && !small && a.batch == 1 && nblk >= 64) a.tile_map = upper_tile_map(a.tiles_n, nblk);
+  if (gs && a.tag == 1 && a.tri == GEMM_UPPER && !small && a.batch == 1 && nblk >= 64) a.tile_map = upper_tile_map(*gs, a.tiles_n, nblk);
   dim3 grid((unsigned)nblk, (unsigned)a.batch, (unsigned)a.splitk);
   if (a.tag == 1 && transa && !small) {
     hipLaunchKernelGGL((gemm_f64_kernel<true, 4, 1>), grid, dim3(GEMM_THREADS), 0, st, a);

@@ -73,6 +73,7 @@ struct Ctx {
   hipEvent_t pool_event(size_t i);
   hipEvent_t aux[4] = {nullptr, nullptr, nullptr, nullptr};   // fork / join events of the two-stream sections (not the look-ahead pool)
   hipEvent_t aux_event(int i);
+  GemmScratch gemm_scratch;   // split-K workspace + syrk tile order of the GEMM launcher (per context, never shared)
   DBuf scratch;       // general device scratch (gemv partial sums)
   DBuf dscal;         // 64 device doubles for scalar results (dots, counts)
   DBuf stage_a, stage_b;   // device staging for host-pointer entry points

@@ -49,6 +49,9 @@ int hyp_cone_create_wsosinterpnonnegative(hyp_ctx* ctx, int U, int K, const int*
  * dim matrices one after the other, each side x side column-major (A_1 positive definite, dim <= side (side + 1) / 2);
  * copied to the device.  nu = side. */
 int hyp_cone_create_linmatrixineq(hyp_ctx* ctx, int dim, int side, const double* As, int use_dual, hyp_cone** out);
+/* Cones.DoublyNonnegativeTri{Float64}(dim; use_dual) (doublynonnegativetri.jl:38-52): svec format, dim = side (side + 1) / 2;
+ * nu = dim */
+int hyp_cone_create_doublynonnegativetri(hyp_ctx* ctx, int dim, int use_dual, hyp_cone** out);
 int hyp_cone_destroy(hyp_cone* cone);
 int hyp_cone_dimension(hyp_cone* cone, int* out);            /* Cones.jl:34 */
 int hyp_cone_get_nu(hyp_cone* cone, double* out);            /* Cones.jl:41 */

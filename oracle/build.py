@@ -15,6 +15,8 @@ def make_cone(spec):
         return oc.WSOSInterpNonnegative(spec[1], spec[2], use_dual=spec[3])
     if kind == "linmatrixineq":
         return oc.LinMatrixIneq(spec[1], use_dual=spec[2])
+    if kind == "doublynonnegativetri":
+        return oc.DoublyNonnegativeTri(spec[1], use_dual=spec[2])
     raise ValueError(kind)
 
 

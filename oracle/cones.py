@@ -772,3 +772,102 @@ class LinMatrixIneq(Cone):
         for i in range(self.dim):
             self.dder3_[i] = np.sum(Z * self.sumAinvAs[i])
         return self.dder3_
+
+
+# ----------------------------------------------------------------------------------------------
+class DoublyNonnegativeTri(PosSemidefTri):
+    """doublynonnegativetri.jl:9-205: positive semidefinite AND entrywise nonnegative, svec format; barrier
+    -logdet(smat(s)) - sum_offdiag log(s_ij).  The PSD oracles plus a diagonal term on the off-diagonal entries; the
+    inverse Hessian has no closed form, so it goes through the explicit Hessian and the generic fallbacks."""
+
+    def __init__(self, dim, use_dual=False):
+        PosSemidefTri.__init__(self, dim)
+        self.use_dual_barrier_ = bool(use_dual)
+        # :45-46 (0-based): the svec positions of the strictly-upper entries
+        self.offdiag_idxs = np.array([i * (i + 1) // 2 + k for i in range(1, self.side) for k in range(i)], dtype=np.int64)
+
+    def use_sqrt_hess_oracles(self, arr_dim):   # generic rule (Cones.jl:189-195), not the PSD shortcut
+        return Cone.use_sqrt_hess_oracles(self, arr_dim)
+
+    def get_nu(self):   # :69
+        return self.dim
+
+    def is_dual_feas(self):   # generic default (Cones.jl:59)
+        return True
+
+    def set_initial_point(self, arr):   # :71-128
+        side, n, d = self.side, float(self.side), float(self.dim)
+        if side == 1:
+            on_diag = off_diag = 1.0
+        elif side == 2:
+            on_diag, off_diag = np.sqrt(5.0) / 2, 1 / self.rt2
+        else:
+            p1 = [-n - 1, 0, n ** 2 + n + 7, 0, -2 * n ** 2 - 8, 0, n ** 2]     # increasing powers (PolynomialRoots.roots)
+            on_diag, off_diag = n + 1, 1.0
+            for r in np.roots(p1[::-1]):
+                offd = float(np.real(r))
+                if offd > 0:
+                    temp = d - (d - n) * offd ** 2
+                    if temp > np.sqrt(EPS):
+                        ond = np.sqrt(temp / n)
+                        denom = ond ** 2 + (n - 2) / self.rt2 * ond * offd - (n - 1) * offd ** 2 / 2
+                        if np.isclose(ond * self.rt2 + (n - 2) * offd, ond * denom * self.rt2, rtol=np.sqrt(EPS), atol=0) and \
+                                np.isclose(denom, offd ** 2 * (denom + 1), rtol=np.sqrt(EPS), atol=0):
+                            on_diag, off_diag = ond, offd
+                            break
+        arr[:] = off_diag
+        k = 0
+        for i in range(1, side + 1):
+            arr[k] = on_diag
+            k += i + 1
+        return arr
+
+    def update_feas(self):   # :130-143
+        assert not self.feas_updated
+        if np.all(self.point > EPS):
+            au.svec_to_smat(self.mat, self.point, self.rt2)
+            self.fact_mat = la.chol_upper(self.mat)
+            self.is_feas_ = self.fact_mat.success
+        else:
+            self.is_feas_ = False
+        self.feas_updated = True
+        return self.is_feas_
+
+    def update_grad(self):   # :145-156
+        PosSemidefTri.update_grad(self)
+        self.inv_vec = 1.0 / self.point[self.offdiag_idxs]
+        self.grad[self.offdiag_idxs] -= self.inv_vec
+        return self.grad
+
+    def update_hess(self):   # :158-171
+        PosSemidefTri.update_hess(self)
+        od = self.offdiag_idxs
+        self.hess_[od, od] += self.inv_vec ** 2
+        return self.hess_
+
+    def update_inv_hess(self):   # generic (Cones.jl:253-259)
+        return Cone.update_inv_hess(self)
+
+    def hess_prod(self, prod, arr):   # :173-192
+        PosSemidefTri.hess_prod(self, prod, arr)
+        P, A = _cols(prod), _cols(arr)
+        od = self.offdiag_idxs
+        s_off = self.point[od]
+        P[od, :] += A[od, :] / s_off[:, None] / s_off[:, None]
+        return prod
+
+    def inv_hess_prod(self, prod, arr):   # generic (Cones.jl:113-118)
+        return Cone.inv_hess_prod(self, prod, arr)
+
+    def sqrt_hess_prod(self, prod, arr):   # generic (Cones.jl:198-206)
+        return Cone.sqrt_hess_prod(self, prod, arr)
+
+    def inv_sqrt_hess_prod(self, prod, arr):   # generic (Cones.jl:209-218)
+        return Cone.inv_sqrt_hess_prod(self, prod, arr)
+
+    def dder3(self, dir):   # :194-205
+        PosSemidefTri.dder3(self, dir)
+        od = self.offdiag_idxs
+        s_off = self.point[od]
+        self.dder3_[od] += (dir[od] / s_off) ** 2 / s_off
+        return self.dder3_

@@ -191,6 +191,18 @@ def linmatrixineq3():   # :747-789 (dense members; the sparse / Diagonal / I var
             dict(status="Optimal", primal_obj=1.0, s=[1.0, -1.0]))
 
 
+def doublynonnegativetri1():   # :493-511 (the loop body resets use_dual = false: only the primal-barrier case runs)
+    G = -np.eye(3)
+    return (np.array([0.0, 1.0, 0.0]), np.array([[1.0, 0, 0], [0, 0, 1.0]]), np.ones(2), G, np.zeros(3),
+            [("doublynonnegativetri", 3, False)], dict(status="Optimal", primal_obj=0.0, x=[1.0, 0.0, 1.0], s=[1.0, 0.0, 1.0]))
+
+
+def doublynonnegativetri2():   # :513-526
+    G = -np.eye(3)
+    return (np.array([0.0, -1.0, 0.0]), np.array([[1.0, 0, 0], [0, 0, 1.0]]), np.array([1.0, 1.5]), G, np.array([-0.5, 0.0, -0.5]),
+            [("doublynonnegativetri", 3, False)], dict(status="Optimal", primal_obj=-1.0, x_at={1: 1.0}))
+
+
 KNOWN_ANSWER = {
     "dimension1": dimension1, "primalinfeas1": primalinfeas1, "nonnegative4": nonnegative4,
     "possemideftri1": possemideftri1, "possemideftri2": possemideftri2, "possemideftri3": possemideftri3,
@@ -203,6 +215,7 @@ KNOWN_ANSWER = {
     "wsosinterpnonnegative3": wsosinterpnonnegative3,
     "linmatrixineq1_side2": lambda: linmatrixineq1(2), "linmatrixineq1_side4": lambda: linmatrixineq1(4),
     "linmatrixineq2": linmatrixineq2, "linmatrixineq3": linmatrixineq3,
+    "doublynonnegativetri1": doublynonnegativetri1, "doublynonnegativetri2": doublynonnegativetri2,
 }
 
 

@@ -272,3 +272,69 @@ def test_linmatrixineq_vs_oracle(side, count):
     Pf = np.zeros((dim, 3), order="F")
     hc.hess_prod(Pf, V)
     assert rel(Ph, Pf) < 1e-9          # the operator form agrees with the explicit Hessian
+
+
+# ---------------------------------------------------------------------------------------------
+# DoublyNonnegativeTri: the PSD kernels plus the entrywise log terms, generic inverse Hessian
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("side", [1, 2, 5])
+def test_doublynonnegativetri_identities(side):   # test/cone.jl:353-361
+    import hypatia_jl_amd as H
+    run_test_oracles(H.DoublyNonnegativeTri(side * (side + 1) // 2), init_tol=np.sqrt(np.finfo(float).eps))
+
+
+@pytest.mark.parametrize("side", [10, 20])
+def test_doublynonnegativetri_initial_point(side):
+    import hypatia_jl_amd as H
+    from oracle import cones as oc
+    dim = side * (side + 1) // 2
+    run_test_oracles(H.DoublyNonnegativeTri(dim), init_tol=np.sqrt(np.finfo(float).eps), init_only=True)
+    a, b = np.zeros(dim), np.zeros(dim)
+    H.DoublyNonnegativeTri(dim).set_initial_point(a)
+    oc.DoublyNonnegativeTri(dim).set_initial_point(b)
+    assert np.allclose(a, b, rtol=1e-12, atol=0)      # cubic solved in closed form here, by numpy.roots in the oracle
+
+
+@pytest.mark.parametrize("side", [3, 12, 40])
+def test_doublynonnegativetri_vs_oracle(side):
+    import hypatia_jl_amd as H
+    from oracle import cones as oc
+    dim = side * (side + 1) // 2
+    hc, occ = H.DoublyNonnegativeTri(dim), oc.DoublyNonnegativeTri(dim)
+    assert hc.get_nu() == occ.get_nu() == dim
+    rng = np.random.default_rng(side)
+    pt = np.zeros(dim)
+    occ.set_initial_point(pt)
+    pt = pt * (1 + 0.1 * (2 * rng.random(dim) - 1))
+    dual = pt * (1 + 0.05 * (2 * rng.random(dim) - 1))
+    for c in (hc, occ):
+        c.setup_data()
+        c.reset_data()
+        c.load_point(pt, 0.8)
+        c.load_dual_point(dual)
+        assert c.is_feas() and c.is_dual_feas()
+    assert rel(np.array(hc.get_grad()), np.array(occ.get_grad())) < 1e-11
+    V = np.asfortranarray(rng.standard_normal((dim, 3)))
+    for name in ("hess_prod", "inv_hess_prod", "hess_prod_slow"):
+        Ph, Po = np.zeros((dim, 3), order="F"), np.zeros((dim, 3), order="F")
+        getattr(hc, name)(Ph, V)
+        getattr(occ, name)(Po, V)
+        assert rel(Ph, Po) < 1e-9, name
+    assert hc.use_sqrt_hess_oracles(dim) == occ.use_sqrt_hess_oracles(dim) == True
+    for name in ("sqrt_hess_prod", "inv_sqrt_hess_prod"):
+        Ph, Po = np.zeros((dim, 3), order="F"), np.zeros((dim, 3), order="F")
+        getattr(hc, name)(Ph, V)
+        getattr(occ, name)(Po, V)
+        assert rel(Ph, Po) < 1e-8, name
+    d = V[:, 0].copy() * 0.05
+    assert rel(np.array(hc.dder3(d)), np.array(occ.dder3(d))) < 1e-10
+    assert hc.check_numerics() == occ.check_numerics()
+    ph, po = hc.get_proxsqr(0.9, True), occ.get_proxsqr(0.9, True)
+    assert abs(ph - po) <= 1e-7 * max(1.0, abs(po))
+    # a point with a non-positive entry is infeasible before any factorization (:132)
+    bad = pt.copy()
+    bad[1] = 0.0
+    for c in (hc, occ):
+        c.reset_data()
+        c.load_point(bad, 1.0)
+        assert not c.is_feas()

@@ -100,3 +100,20 @@ def test_linmatrixineq_barrier():   # test/cone.jl:431-436
     rng = np.random.default_rng(1)
     Ps = _rand_syms(2, 2, rng)
     run_test_barrier(oc.LinMatrixIneq(Ps), lambda s: -np.linalg.slogdet(sum(s[i] * Ps[i] for i in range(len(Ps))))[1])
+
+
+@pytest.mark.parametrize("side", [1, 2, 5])
+def test_doublynonnegativetri_oracles(side):   # test/cone.jl:353-361
+    run_test_oracles(oc.DoublyNonnegativeTri(au.svec_length(side)), init_tol=np.sqrt(np.finfo(float).eps))
+
+
+@pytest.mark.parametrize("side", [10, 20])
+def test_doublynonnegativetri_initial_point(side):
+    run_test_oracles(oc.DoublyNonnegativeTri(au.svec_length(side)), init_tol=np.sqrt(np.finfo(float).eps), init_only=True)
+
+
+def test_doublynonnegativetri_barrier():   # test/cone.jl:363-371
+    side = 3
+    cone = oc.DoublyNonnegativeTri(au.svec_length(side))
+    od = cone.offdiag_idxs
+    run_test_barrier(cone, lambda s: -np.linalg.slogdet(_smat_full(s, side))[1] - np.sum(np.log(s[od])))
