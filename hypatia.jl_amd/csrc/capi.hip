@@ -634,6 +634,42 @@ int hyp_dense_gemv(hyp_ctx* ctx, int trans, int m, int n, double alpha, const do
   c.sync();
   API_END(ctx)
 }
+int hyp_bench_potrf(hyp_ctx* ctx, int n, int reps, double* ms_out) {
+  API_BEGIN
+  Ctx& c = ctx->c;
+  HYP_REQUIRE(n >= 1 && reps >= 1, "bench_potrf: sizes");
+  DBuf dA((size_t)n * n * 8), dW((size_t)n * n * 8), dinv(dinv_elems(n) * 8), dinfo(64);
+  // SPD test matrix: n I + a small symmetric perturbation (deterministic)
+  std::vector<double> h((size_t)n * n);
+  uint64_t s = 88172645463325252ULL;
+  for (long j = 0; j < n; ++j)
+    for (long i = 0; i <= j; ++i) {
+      s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+      const double v = (double)(s >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+      h[j * n + i] = h[i * n + j] = (i == j) ? (double)n : v;
+    }
+  c.h2d(dA.p, h.data(), h.size() * 8);
+  c.sync();
+  hipEvent_t e0, e1;
+  HYP_CHECK(hipEventCreate(&e0)); HYP_CHECK(hipEventCreate(&e1));
+  float total = 0;
+  for (int r = 0; r <= reps; ++r) {   // (first pass untimed)
+    c.d2d(dW.p, dA.p, (size_t)n * n * 8);
+    HYP_CHECK(hipEventRecord(e0, c.stream));
+    potrf_upper_batched(c, n, dW.d(), n, 0, 1, dinv.d(), dinfo.i());
+    HYP_CHECK(hipEventRecord(e1, c.stream));
+    HYP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    HYP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0) total += ms;
+  }
+  *ms_out = total / reps;
+  c.d2h(c.h_info, dinfo.p, sizeof(int));
+  c.sync();
+  HYP_REQUIRE(c.h_info[0] == 0, "bench_potrf: factorization failed");
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  API_END(ctx)
+}
 int hyp_bench_syrk(hyp_ctx* ctx, int N, int K, int reps, double* ms_out) {
   API_BEGIN
   Ctx& c = ctx->c;

@@ -19,7 +19,8 @@ void gemm(Ctx& c, bool transa, GemmArgs a) { HYP_CHECK(gemm_f64_launch(c.stream,
 
 // potrf_diag.hip: diagonal-block factor / inverse kernels and the substitution panel solve
 void potrf_diag_launch(hipStream_t st, bool factor, bool invert, int batch, int nblocks, double* A, long lda, long strideA, int n, int k0,
-                       double* dinv, long strideD, int* info);
+                       double* dinv, long strideD, int* info, int own_cu_lds = 0);
+int potrf_diag_own_cu_lds();
 void potrf_panel_solve_launch(hipStream_t st, int batch, double* A, long lda, long strideA, int k0, int mcols);
 
 static void potrf_step_gemms(Ctx& c, hipStream_t st, int nb, int M, int N, const double* U12a, const double* U12b, long lda, long strideA,
@@ -57,12 +58,19 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
   // update runs on the helper stream underneath the next diagonal-block kernel, which is pure latency.
   static const int la_env = [] { const char* e = getenv("HYP_POTRF_LOOKAHEAD"); return e ? atoi(e) : 1; }();
   const bool lookahead = (la_env != 0 && batch == 1 && nblk >= 6);
+  // with look-ahead the diagonal-block kernel shares the chip with the helper stream's GEMM: it takes a CU of its own
+  static const int own_env = [] { const char* e = getenv("HYP_POTRF_OWN_CU"); return e ? atoi(e) : 1; }();
+  int own_cu_lds = 0;
+  if (lookahead && own_env != 0) {
+    if (c.diag_own_cu_lds < 0) c.diag_own_cu_lds = potrf_diag_own_cu_lds();
+    own_cu_lds = c.diag_own_cu_lds;
+  }
   for (int kb = 0; kb < nblk; ++kb) {
     const int k0 = kb * NB;
     const int nb = std::min(NB, n - k0);
     const int m = n - k0 - nb;
     // factor only: the inverses of all diagonal blocks are produced by ONE launch after the loop
-    potrf_diag_launch(c.stream, true, false, batch, 1, A, lda, strideA, n, k0, dinv, strideD, d_info);
+    potrf_diag_launch(c.stream, true, false, batch, 1, A, lda, strideA, n, k0, dinv, strideD, d_info, own_cu_lds);
     if (m <= 0) break;
     double* A12 = A + (long)(k0 + nb) * lda + k0;
     double* A22 = A + (long)(k0 + nb) * lda + (k0 + nb);

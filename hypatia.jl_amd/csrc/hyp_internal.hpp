@@ -78,6 +78,7 @@ struct Ctx {
   DBuf dscal;         // 64 device doubles for scalar results (dots, counts)
   DBuf stage_a, stage_b;   // device staging for host-pointer entry points
   DBuf work_tri;           // workspace of trtri_upper_batched
+  int diag_own_cu_lds = -1;   // dynamic LDS that gives the critical-path diagonal-block kernel a CU of its own (-1: not asked yet, 0: refused)
   int trsv_sb = 1024;      // super-block of the one-right-hand-side triangular solves (HYP_TRSV_SB; 0 = per-128-block path)
   int* h_info = nullptr;    // pinned host word(s)
   double* h_pinned = nullptr;   // pinned host staging (small vectors / scalars)

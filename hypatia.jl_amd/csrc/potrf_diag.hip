@@ -239,13 +239,28 @@ template __global__ void potrf_diag_kernel_t<true, true>(double*, long, long, in
 template __global__ void potrf_diag_kernel_t<true, false>(double*, long, long, int, int, double*, long, int*);
 template __global__ void potrf_diag_kernel_t<false, true>(double*, long, long, int, int, double*, long, int*);
 
+// own_cu_lds > 0 (factor-only launches on the critical path of the look-ahead Cholesky): the single workgroup asks for
+// that much dynamic LDS on top of its own, so that no GEMM workgroup of the concurrent trailing update (36 / 72 KB of
+// LDS each) fits beside it and the CU's four SIMDs are its own -- 47 us instead of 62-79 us per diagonal block when the
+// helper stream's GEMM covers the chip (profiles/r01_cholesky_timeline.txt).  The other 255 CUs keep the GEMM.
 void potrf_diag_launch(hipStream_t st, bool factor, bool invert, int batch, int nblocks, double* A, long lda, long strideA, int n, int k0,
-                       double* dinv, long strideD, int* info) {
+                       double* dinv, long strideD, int* info, int own_cu_lds) {
   const dim3 grid(batch, nblocks), blk(256);
   if (factor && invert) hipLaunchKernelGGL((potrf_diag_kernel_t<true, true>), grid, blk, 0, st, A, lda, strideA, n, k0, dinv, strideD, info);
-  else if (factor) hipLaunchKernelGGL((potrf_diag_kernel_t<true, false>), grid, blk, 0, st, A, lda, strideA, n, k0, dinv, strideD, info);
+  else if (factor) hipLaunchKernelGGL((potrf_diag_kernel_t<true, false>), grid, blk, own_cu_lds > 0 ? own_cu_lds : 0, st, A, lda, strideA, n, k0, dinv, strideD, info);
   else hipLaunchKernelGGL((potrf_diag_kernel_t<false, true>), grid, blk, 0, st, A, lda, strideA, n, k0, dinv, strideD, info);
   HYP_CHECK(hipGetLastError());
+}
+// dynamic LDS (bytes) that leaves less than the smallest GEMM workgroup's 36 KB free on a 160 KB CU; 0 when the device
+// refuses the opt-in
+int potrf_diag_own_cu_lds() {
+  const int want = 124 * 1024;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_diag_kernel_t<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return want;
 }
 
 // =============================================================================================

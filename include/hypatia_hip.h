@@ -196,6 +196,9 @@ int hyp_dense_sysv_rook(hyp_ctx* ctx, int n, double* A, int lda, double* x, int 
                         double* d, double* e);
 int hyp_dense_gemv(hyp_ctx* ctx, int trans, int m, int n, double alpha, const double* A, int lda, const double* x, double beta,
                    double* y);
+/* Measurement helper: HIP-event time (ms, mean of reps) of the blocked upper Cholesky of an n x n positive definite matrix
+ * resident in HBM (posdef_fact_copy!'s first link, src/linearalgebra/dense.jl:194-200). */
+int hyp_bench_potrf(hyp_ctx* ctx, int n, int reps, double* ms_out);
 /* time `reps` launches of the syrk C = A'A (A is K x N) with HIP events on the library stream; ms per launch */
 int hyp_bench_syrk(hyp_ctx* ctx, int N, int K, int reps, double* ms_out);
 
