@@ -72,9 +72,14 @@ __global__ __launch_bounds__(TPB) void gemv_t_multi_kernel(int m, double alpha, 
   }
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
-    double t = 0.0;
+    double pu[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) t += s[r][2 * u] + s[r][2 * u + 1];
+    for (int u = 0; u < U; ++u) pu[u] = s[r][2 * u] + s[r][2 * u + 1];
+#pragma unroll
+    for (int step = 1; step < U; step *= 2)
+#pragma unroll
+      for (int u = 0; u + step < U; u += 2 * step) pu[u] += pu[u + step];
+    double t = pu[0];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
     if ((threadIdx.x & 63) == 0) red[r][threadIdx.x >> 6] = t;
@@ -82,9 +87,14 @@ __global__ __launch_bounds__(TPB) void gemv_t_multi_kernel(int m, double alpha, 
   __syncthreads();
   if (threadIdx.x < NR) {
     const int r = threadIdx.x;
-    double t = 0.0;
+    double pr[NW];   // fixed pairwise tree over the wavefronts' partial sums
 #pragma unroll
-    for (int w = 0; w < NW; ++w) t += red[r][w];
+    for (int w = 0; w < NW; ++w) pr[w] = red[r][w];
+#pragma unroll
+    for (int step = 1; step < NW; step *= 2)
+#pragma unroll
+      for (int w = 0; w + step < NW; w += 2 * step) pr[w] += pr[w + step];
+    const double t = pr[0];
     double* y = Y + (long)r * ldy + col;
     *y = alpha * t + (beta != 0.0 ? beta * (*y) : 0.0);
   }
