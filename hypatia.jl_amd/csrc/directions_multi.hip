@@ -100,6 +100,78 @@ __global__ __launch_bounds__(TPB) void gemv_t_multi_kernel(int m, double alpha, 
   }
 }
 
+// The same product with CB columns of A per workgroup: the X values of a row block are loaded once and serve all CB
+// columns (with one column per workgroup every workgroup streams both X vectors from L2, twice the traffic of the column
+// itself).  Per-thread row assignment, partial sums and reduction tree are those of gemv_t_multi_kernel<NR, 256, 2>, so
+// the results are bitwise the same.  Requires 16-byte aligned columns and X (the launcher checks).
+template <int NR, int CB>
+__global__ __launch_bounds__(256) void gemv_t_multi_cb_kernel(int m, int n, double alpha, const double* __restrict__ A, long lda,
+                                                              const double* __restrict__ X, long ldx, double beta, double* __restrict__ Y,
+                                                              long ldy) {
+  __shared__ double red[CB][NR][4];
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  const int col0 = blockIdx.x * CB;
+  const int ncol = min(CB, n - col0);
+  const double* a[CB];
+#pragma unroll
+  for (int c = 0; c < CB; ++c) a[c] = A + (long)(col0 + (c < ncol ? c : 0)) * lda;   // (surplus columns re-read column 0, results dropped)
+  double s[CB][NR][4];
+#pragma unroll
+  for (int c = 0; c < CB; ++c)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) s[c][r][0] = s[c][r][1] = s[c][r][2] = s[c][r][3] = 0.0;
+  const int nfull = m / 1024;
+  for (int b = 0; b < nfull; ++b) {
+    const int j = 1024 * b + 2 * threadIdx.x;
+    d2_t av[CB][2];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+      av[c][0] = *reinterpret_cast<const d2_t*>(a[c] + j);
+      av[c][1] = *reinterpret_cast<const d2_t*>(a[c] + j + 512);
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const d2_t x0 = *reinterpret_cast<const d2_t*>(X + (long)r * ldx + j), x1 = *reinterpret_cast<const d2_t*>(X + (long)r * ldx + j + 512);
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        s[c][r][0] += av[c][0].x * x0.x;
+        s[c][r][1] += av[c][0].y * x0.y;
+        s[c][r][2] += av[c][1].x * x1.x;
+        s[c][r][3] += av[c][1].y * x1.y;
+      }
+    }
+  }
+  for (int i = 1024 * nfull + threadIdx.x; i < m; i += 256) {   // element-wise tail
+    double xv[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) xv[r] = X[(long)r * ldx + i];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+      const double a0 = a[c][i];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) s[c][r][0] += a0 * xv[r];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CB; ++c)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      double t = (s[c][r][0] + s[c][r][1]) + (s[c][r][2] + s[c][r][3]);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+      if ((threadIdx.x & 63) == 0) red[c][r][threadIdx.x >> 6] = t;
+    }
+  __syncthreads();
+  if (threadIdx.x < CB * NR) {
+    const int c = threadIdx.x / NR, r = threadIdx.x % NR;
+    if (c < ncol) {
+      const double t = (red[c][r][0] + red[c][r][1]) + (red[c][r][2] + red[c][r][3]);
+      double* y = Y + (long)r * ldy + col0 + c;
+      *y = alpha * t + (beta != 0.0 ? beta * (*y) : 0.0);
+    }
+  }
+}
+
 // ---- Y[:, r] = alpha A X[:, r] + beta Y[:, r]: partial sums over 256-column chunks, then an ordered reduce
 constexpr int GM_CHUNK = 256;
 template <int NR>
@@ -155,7 +227,17 @@ void gemv_multi(Ctx& c, bool trans, int m, int n, int nr, double alpha, const do
   HYP_REQUIRE(nr == MR, "gemv_multi: 1 or 2 right-hand sides");
   if (trans) {
     if (n <= 0) return;
-    hipLaunchKernelGGL((gemv_t_multi_kernel<MR, 256, 2>), dim3(n), dim3(256), 0, c.stream, m, alpha, A, lda, X, ldx, beta, Y, ldy);
+    static const int cb_env = [] { const char* e = getenv("HYP_GEMVT_CB"); return e ? atoi(e) : 4; }();
+    const bool wide = ((((uintptr_t)A | (uintptr_t)X) & 15) == 0) && (lda % 2 == 0) && (ldx % 2 == 0);
+    if (wide && cb_env == 4) {
+      hipLaunchKernelGGL((gemv_t_multi_cb_kernel<MR, 4>), dim3((n + 3) / 4), dim3(256), 0, c.stream, m, n, alpha, A, lda, X, ldx, beta, Y, ldy);
+    } else if (wide && cb_env == 2) {
+      hipLaunchKernelGGL((gemv_t_multi_cb_kernel<MR, 2>), dim3((n + 1) / 2), dim3(256), 0, c.stream, m, n, alpha, A, lda, X, ldx, beta, Y, ldy);
+    } else if (wide && cb_env == 8) {
+      hipLaunchKernelGGL((gemv_t_multi_cb_kernel<MR, 8>), dim3((n + 7) / 8), dim3(256), 0, c.stream, m, n, alpha, A, lda, X, ldx, beta, Y, ldy);
+    } else {
+      hipLaunchKernelGGL((gemv_t_multi_kernel<MR, 256, 2>), dim3(n), dim3(256), 0, c.stream, m, alpha, A, lda, X, ldx, beta, Y, ldy);
+    }
   } else {
     if (m <= 0) return;
     const int nchunks = (n + GM_CHUNK - 1) / GM_CHUNK;
