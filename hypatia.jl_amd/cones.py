@@ -284,3 +284,14 @@ class DoublyNonnegativeTri(_GenericHessMixin, Cone):
         L.check(L.lib().hyp_cone_create_doublynonnegativetri(L.ctx(), int(dim), int(bool(use_dual)), ctypes.byref(h)),
                 "hyp_cone_create_doublynonnegativetri")
         super().__init__(h)
+
+
+class HypoRootdetTri(_GenericHessMixin, Cone):
+    """Cones.HypoRootdetTri{Float64, Float64}(dim; use_dual)  (hyporootdettri.jl:9-59)."""
+
+    def __init__(self, dim, use_dual=False):
+        self._slow = False
+        h = c_vp()
+        L.check(L.lib().hyp_cone_create_hyporootdettri(L.ctx(), int(dim), int(bool(use_dual)), ctypes.byref(h)),
+                "hyp_cone_create_hyporootdettri")
+        super().__init__(h)

@@ -122,6 +122,13 @@ int hyp_cone_create_doublynonnegativetri(hyp_ctx* ctx, int dim, int use_dual, hy
   ctx->c.sync();
   API_END(ctx)
 }
+int hyp_cone_create_hyporootdettri(hyp_ctx* ctx, int dim, int use_dual, hyp_cone** out) {
+  API_BEGIN
+  HYP_CHECK(hipSetDevice(ctx->c.device));
+  *out = new hyp_cone{ctx, new HypoRootdetTriCone(ctx->c, dim, use_dual != 0)};
+  ctx->c.sync();
+  API_END(ctx)
+}
 int hyp_cone_update_use_hess_prod_slow(hyp_cone* cone, int* out) {
   API_BEGIN
   GenericHessCone* g = dynamic_cast<GenericHessCone*>(cone->cone);

@@ -13,7 +13,7 @@ bool psd_two_sided_fused_ok(int side);
 void psd_two_sided_fused(Ctx& c, int side, int ncols, const double* R, int rstruct /* 0 full, 1 upper, 2 lower */, const double* arr,
                          long lda, double* prod, long ldp, double* zws /* ncols * side^2 */);
 
-enum ConeKind { CONE_NONNEG = 0, CONE_PSD = 1, CONE_EPINORMSPECTRAL = 2, CONE_WSOS = 3, CONE_LMI = 4, CONE_DNN = 5 };
+enum ConeKind { CONE_NONNEG = 0, CONE_PSD = 1, CONE_EPINORMSPECTRAL = 2, CONE_WSOS = 3, CONE_LMI = 4, CONE_DNN = 5, CONE_HYPOROOTDET = 6 };
 
 struct Cone {
   Ctx& ctx;
@@ -203,6 +203,29 @@ struct DnnCone : GenericHessCone {   // src/Cones/doublynonnegativetri.jl: PSD a
   void set_initial_point(double* h_out) override;                                                   // :71-128
   void hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;         // :173-192
   const double* dder3(const double* d_dir) override;                                                // :194-205
+};
+
+struct HypoRootdetTriCone : GenericHessCone {   // src/Cones/hyporootdettri.jl (real): (u, w), u <= det(smat(w))^(1/d)
+  int d;
+  PsdCone psd;      // the W part of the point: Cholesky, W^-1, the two-sided products
+  PsdCone psdd;     // the W part of the DUAL point (is_dual_feas needs its Cholesky and log-determinant)
+  double di = 0, u = 0, phi = 0, zeta = 0, phizidi = 0;
+  DBuf Wi_vec, dots, tmpw, ld;
+  HypoRootdetTriCone(Ctx& c, int dim, bool use_dual);
+  void reset_data() override {
+    GenericHessCone::reset_data();
+    psd.reset_data();
+  }
+  bool update_feas() override;                                                                      // :101-115
+  bool is_dual_feas() override;                                                                     // :117-127
+  void update_grad() override;                                                                      // :129-141
+  void update_hess() override;                                                                      // :143-170
+  void set_initial_point(double* h_out) override;                                                   // :82-99
+  void hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;         // :172-203
+  void inv_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;     // :235-272
+  bool inv_hess_ready() override { return true; }                                                   // closed form
+  const double* dder3(const double* d_dir) override;                                                // :274-324
+  double logdet_of(PsdCone& k);
 };
 
 struct EpiNormSpectralCone : GenericHessCone {   // src/Cones/epinormspectral.jl (real)

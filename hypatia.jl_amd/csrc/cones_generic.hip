@@ -533,4 +533,192 @@ const double* DnnCone::dder3(const double* d_dir) {   // :194-205
   return dder3v.d();
 }
 
+// ---------------------------------------------------------------------------------------------
+// HypoRootdetTri (hyporootdettri.jl:9-324, real): barrier -log(rootdet(W) - u) - logdet(W), W = smat(w).
+// Every W-block of the reference's oracles is U^-1 (a S^2 + b S + c I) U^-T with S = U^-T R U^-1, i.e. a combination of
+// the PosSemidefTri oracles at W -- W^-1 R W^-1 R W^-1 (dder3), W^-1 R W^-1 (hess_prod), W R W (inv_hess_prod) -- and of
+// svec(W^-1) or w, with coefficients that depend on the column only through p = arr[1] and one inner product
+// (tr S = <svec W^-1, r>, or <w, r>).  So: one batched PSD product through the inner cone, one pass of column inner
+// products, one combine kernel.  The explicit Hessian (only the generic sqrt oracles need it) = hess_prod of I.
+// ---------------------------------------------------------------------------------------------
+__global__ void logdet_diag_kernel(int side, const double* __restrict__ U, long ld, double* __restrict__ out) {   // log det(U'U)
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < side; i += 256) s += log(U[(long)i * ld + i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = 2.0 * ((red[0] + red[1]) + (red[2] + red[3]));
+}
+struct RootdetScal { double zeta, phi, di, phizidi; };
+// mode 0 hess_prod (:172-203): vec = svec(W^-1), t = <vec, r>;  mode 1 inv_hess_prod (:235-272): vec = w, t = <w, r>.
+// out[0, j] and out[1:, j] = a P[:, j] + b_j vec, with P already in out[1:, j]
+__global__ void rootdet_combine_kernel(int dw, int ncols, int mode, RootdetScal sc, const double* __restrict__ arr, long lda,
+                                       const double* __restrict__ dots, const double* __restrict__ vec, double* __restrict__ out, long ldo) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int j = blockIdx.y; j < ncols; j += gridDim.y) {
+    const double p = arr[(long)j * lda], t = dots[j];
+    double a, b, o0;
+    if (mode == 0) {
+      const double c0 = sc.phizidi * t;
+      const double c1 = c0 - p / sc.zeta;
+      b = sc.phizidi * c1 - sc.di * c0;
+      a = sc.phizidi + 1.0;
+      o0 = c1 / -sc.zeta;
+    } else {
+      const double phidi = sc.phi * sc.di;
+      a = 1.0 / (sc.phizidi + 1.0);
+      const double c3 = a / sc.zeta * sc.di;
+      const double c4 = sc.zeta * sc.zeta + phidi * sc.phi;
+      b = phidi * (c3 * t + p);
+      o0 = phidi * t + c4 * p;
+    }
+    if (i < dw) {
+      double* o = out + (long)j * ldo + 1 + i;
+      *o = a * (*o) + b * vec[i];
+    }
+    if (i == 0) out[(long)j * ldo] = o0;
+  }
+}
+// out[0] = o0; out[1 + i] = c9 D3[i] + c8 P1[i] + c7 vec[i]
+__global__ void rootdet_dder3_kernel(int dw, double o0, double c9, double c8, double c7, const double* __restrict__ D3, const double* __restrict__ P1,
+                                     const double* __restrict__ vec, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < dw) out[1 + i] = c9 * D3[i] + c8 * P1[i] + c7 * vec[i];
+  if (i == 0) out[0] = o0;
+}
+__global__ void scale_into_kernel(int n, double a, const double* __restrict__ x, double* __restrict__ y, double y0, int write_y0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[1 + i] = a * x[i];
+  if (i == 0 && write_y0) y[0] = y0;
+}
+
+HypoRootdetTriCone::HypoRootdetTriCone(Ctx& c, int dim_, bool use_dual)
+    : GenericHessCone(c, CONE_HYPOROOTDET), psd(c, dim_ - 1), psdd(c, dim_ - 1) {
+  HYP_REQUIRE(dim_ >= 2, "HypoRootdetTri: dim >= 2");
+  dim = dim_;
+  d = psd.side;
+  di = 1.0 / d;
+  use_dual_barrier = use_dual;
+  nu = 1 + d;                                                                                         // :80
+  alloc_common();
+  alloc_generic();
+  Wi_vec.alloc((size_t)(dim - 1) * sizeof(double));
+  tmpw.alloc((size_t)(dim - 1) * sizeof(double));
+  ld.alloc(64);
+}
+
+void HypoRootdetTriCone::set_initial_point(double* h) {   // :82-99
+  for (int i = 0; i < dim; ++i) h[i] = 0.0;
+  const double dd = d;
+  const double c1 = sqrt(5 * dd * dd + 2 * dd + 1);
+  const double c2 = h[0] = -sqrt((3 * dd + 1 - c1) / (2 * dd + 2));
+  const double c3 = -c2 * (dd + 1 + c1) / (2 * dd);
+  long k = 1;
+  for (int i = 1; i <= d; ++i) { h[k] = c3; k += i + 1; }
+}
+
+double HypoRootdetTriCone::logdet_of(PsdCone& k) {
+  hipLaunchKernelGGL(logdet_diag_kernel, dim3(1), dim3(256), 0, ctx.stream, k.side, k.U.d(), (long)k.side, ld.d());
+  HYP_CHECK(hipGetLastError());
+  ctx.d2h(ctx.h_pinned, ld.p, sizeof(double));
+  ctx.sync();
+  return ctx.h_pinned[0];
+}
+
+bool HypoRootdetTriCone::update_feas() {   // :101-115
+  ctx.d2h(ctx.h_pinned + 1, point.p, sizeof(double));
+  psd.load_point(point.d() + 1, 1.0);
+  psd.reset_data();
+  is_feas_ = psd.is_feas();        // (synchronises: the u read above has arrived)
+  u = ctx.h_pinned[1];
+  if (is_feas_) {
+    phi = exp(logdet_of(psd) / d);
+    zeta = phi - u;
+    is_feas_ = (zeta > EPS);
+  }
+  feas_updated = true;
+  return is_feas_;
+}
+
+bool HypoRootdetTriCone::is_dual_feas() {   // :117-127
+  ctx.d2h(ctx.h_pinned + 1, dual_point.p, sizeof(double));
+  ctx.sync();
+  const double ud = ctx.h_pinned[1];
+  if (!(ud < -EPS)) return false;
+  psdd.load_point(dual_point.d() + 1, 1.0);
+  psdd.reset_data();
+  if (!psdd.is_feas()) return false;
+  return logdet_of(psdd) - d * log(-ud / d) > EPS;
+}
+
+void HypoRootdetTriCone::update_grad() {   // :129-141
+  phizidi = phi / zeta * di;
+  const int dw = dim - 1;
+  dev_scale_copy(ctx, dw, -1.0, psd.get_grad(), Wi_vec.d());                // svec(W^-1) = -grad of the PSD barrier
+  hipLaunchKernelGGL(scale_into_kernel, dim3((dw + 255) / 256), dim3(256), 0, ctx.stream, dw, -phizidi - 1.0, Wi_vec.d(), grad.d(), 1.0 / zeta, 1);
+  HYP_CHECK(hipGetLastError());
+  grad_updated = true;
+}
+
+void HypoRootdetTriCone::hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) {   // :172-203
+  HYP_REQUIRE(prod != arr, "HypoRootdetTri hess_prod: in-place call");
+  if (ncols <= 0) return;
+  get_grad();
+  const int dw = dim - 1;
+  dots.ensure((size_t)ncols * sizeof(double));
+  gemv(ctx, true, dw, ncols, 1.0, arr + 1, lda, Wi_vec.d(), 0.0, dots.d());      // tr(U^-T R U^-1) = <svec W^-1, r>
+  psd.hess_prod(prod + 1, ldp, arr + 1, lda, ncols);                              // svec(W^-1 R W^-1)
+  hipLaunchKernelGGL(rootdet_combine_kernel, dim3((dw + 255) / 256, std::min(ncols, 1024)), dim3(256), 0, ctx.stream, dw, ncols, 0,
+                     RootdetScal{zeta, phi, di, phizidi}, arr, lda, dots.d(), Wi_vec.d(), prod, ldp);
+  HYP_CHECK(hipGetLastError());
+}
+
+void HypoRootdetTriCone::inv_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) {   // :235-272
+  HYP_REQUIRE(prod != arr, "HypoRootdetTri inv_hess_prod: in-place call");
+  if (ncols <= 0) return;
+  get_grad();
+  const int dw = dim - 1;
+  dots.ensure((size_t)ncols * sizeof(double));
+  gemv(ctx, true, dw, ncols, 1.0, arr + 1, lda, point.d() + 1, 0.0, dots.d());   // <w, r>
+  psd.inv_hess_prod(prod + 1, ldp, arr + 1, lda, ncols);                          // svec(W R W)
+  hipLaunchKernelGGL(rootdet_combine_kernel, dim3((dw + 255) / 256, std::min(ncols, 1024)), dim3(256), 0, ctx.stream, dw, ncols, 1,
+                     RootdetScal{zeta, phi, di, phizidi}, arr, lda, dots.d(), point.d() + 1, prod, ldp);
+  HYP_CHECK(hipGetLastError());
+}
+
+void HypoRootdetTriCone::update_hess() {   // :143-170
+  ensure_hess_storage(false);
+  get_grad();
+  DBuf eye((size_t)dim * dim * sizeof(double));
+  dev_fill_identity(ctx, dim, eye.d(), dim);
+  hess_prod(H.d(), dim, eye.d(), dim, dim);
+  dev_symmetrize_from_upper(ctx, dim, H.d(), dim, 1, 0);
+  ctx.sync();
+  hess_updated = true;
+}
+
+const double* HypoRootdetTriCone::dder3(const double* d_dir) {   // :274-324
+  get_grad();
+  const int dw = dim - 1;
+  const double* r = d_dir + 1;
+  ctx.d2h(ctx.h_pinned + 2, d_dir, sizeof(double));
+  psd.hess_prod(tmpw.d(), dw, r, dw, 1);                       // P1 = svec(W^-1 R W^-1)
+  const double* D3 = psd.dder3(r);                             // svec(W^-1 R W^-1 R W^-1)
+  const double trS = dot_host(dw, Wi_vec.d(), r);              // tr S, S = U^-T R U^-1
+  const double frS = dot_host(dw, r, tmpw.d());                // ||S||_F^2 = <R, W^-1 R W^-1>
+  const double p = ctx.h_pinned[2];
+  const double c0 = trS * di, c6 = frS * di;
+  const double zichi = (p - phi * c0) / zeta;
+  const double c1 = zichi * zichi + phi / zeta * (c6 - c0 * c0) / 2;
+  const double c7 = phizidi * (c1 - c6 / 2 + c0 * (zichi + c0 / 2));
+  const double c8 = -phizidi * (zichi + c0);
+  const double c9 = phizidi + 1;
+  hipLaunchKernelGGL(rootdet_dder3_kernel, dim3((dw + 255) / 256), dim3(256), 0, ctx.stream, dw, c1 / -zeta, c9, c8, c7, D3, tmpw.d(), Wi_vec.d(),
+                     dder3v.d());
+  HYP_CHECK(hipGetLastError());
+  return dder3v.d();
+}
+
 }  // namespace hyp

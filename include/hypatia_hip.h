@@ -52,6 +52,9 @@ int hyp_cone_create_linmatrixineq(hyp_ctx* ctx, int dim, int side, const double*
 /* Cones.DoublyNonnegativeTri{Float64}(dim; use_dual) (doublynonnegativetri.jl:38-52): svec format, dim = side (side + 1) / 2;
  * nu = dim */
 int hyp_cone_create_doublynonnegativetri(hyp_ctx* ctx, int dim, int use_dual, hyp_cone** out);
+/* Cones.HypoRootdetTri{Float64, Float64}(dim; use_dual) (hyporootdettri.jl:44-59): (u, svec(W)), dim = 1 + side (side + 1) / 2;
+ * nu = 1 + side */
+int hyp_cone_create_hyporootdettri(hyp_ctx* ctx, int dim, int use_dual, hyp_cone** out);
 int hyp_cone_destroy(hyp_cone* cone);
 int hyp_cone_dimension(hyp_cone* cone, int* out);            /* Cones.jl:34 */
 int hyp_cone_get_nu(hyp_cone* cone, double* out);            /* Cones.jl:41 */

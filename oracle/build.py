@@ -17,6 +17,8 @@ def make_cone(spec):
         return oc.LinMatrixIneq(spec[1], use_dual=spec[2])
     if kind == "doublynonnegativetri":
         return oc.DoublyNonnegativeTri(spec[1], use_dual=spec[2])
+    if kind == "hyporootdettri":
+        return oc.HypoRootdetTri(spec[1], use_dual=spec[2])
     raise ValueError(kind)
 
 

@@ -871,3 +871,188 @@ class DoublyNonnegativeTri(PosSemidefTri):
         s_off = self.point[od]
         self.dder3_[od] += (dir[od] / s_off) ** 2 / s_off
         return self.dder3_
+
+
+# ----------------------------------------------------------------------------------------------
+class HypoRootdetTri(Cone):
+    """hyporootdettri.jl:9-324 (real symmetric case): (u, w) with u <= det(smat(w))^(1/d); barrier
+    -log(rootdet(W) - u) - logdet(W).  Closed-form Hessian and inverse-Hessian products."""
+
+    def __init__(self, dim, use_dual=False):
+        assert dim >= 2
+        self.use_dual_barrier_ = bool(use_dual)
+        self.dim = dim
+        self.rt2 = au.RT2
+        self.d = au.svec_side(dim - 1)
+        self.di = 1.0 / self.d
+
+    def reset_data(self):   # :61-62
+        self.feas_updated = self.grad_updated = self.hess_updated = self.inv_hess_updated = False
+        self.hess_fact_updated = False
+
+    def setup_extra_data(self):   # :64-78
+        d = self.d
+        self.mat = np.zeros((d, d), order="F")
+        self.Wi = np.zeros((d, d), order="F")
+        self.Wi_vec = np.zeros(self.dim - 1)
+
+    def get_nu(self):   # :80
+        return 1 + self.d
+
+    def set_initial_point(self, arr):   # :82-99
+        d = self.d
+        arr[:] = 0
+        c1 = np.sqrt(5.0 * d * d + 2 * d + 1)
+        c2 = arr[0] = -np.sqrt((3 * d + 1 - c1) / (2.0 * d + 2))
+        c3 = -c2 * (d + 1 + c1) / (2 * d)
+        k = 1
+        for i in range(1, d + 1):
+            arr[k] = c3
+            k += i + 1
+        return arr
+
+    def _smat_full(self, v):
+        m = np.zeros((self.d, self.d), order="F")
+        au.svec_to_smat(m, v, self.rt2)
+        au.copytri_upper(m)
+        return m
+
+    def update_feas(self):   # :101-115
+        assert not self.feas_updated
+        au.svec_to_smat(self.mat, self.point[1:], self.rt2)
+        self.fact_W = la.chol_upper(self.mat)
+        if self.fact_W.success:
+            logdet = 2 * np.sum(np.log(np.diag(self.fact_W.factors)))
+            self.phi = np.exp(logdet / self.d)
+            self.zeta = self.phi - self.point[0]
+            self.is_feas_ = self.zeta > EPS
+        else:
+            self.is_feas_ = False
+        self.feas_updated = True
+        return self.is_feas_
+
+    def is_dual_feas(self):   # :117-127
+        u = self.dual_point[0]
+        if u < -EPS:
+            m = np.zeros((self.d, self.d), order="F")
+            au.svec_to_smat(m, self.dual_point[1:], self.rt2)
+            f = la.chol_upper(m)
+            if f.success:
+                logdet = 2 * np.sum(np.log(np.diag(f.factors)))
+                return logdet - self.d * np.log(-u / self.d) > EPS
+        return False
+
+    def update_grad(self):   # :129-141
+        assert self.is_feas_
+        self.phizidi = self.phi / self.zeta * self.di
+        self.grad[0] = 1.0 / self.zeta
+        self.Wi[:] = la.inv_fact_chol(self.fact_W)
+        au.smat_to_svec(self.Wi_vec, self.Wi, self.rt2)
+        self.grad[1:] = (-self.phizidi - 1) * self.Wi_vec
+        self.grad_updated = True
+        return self.grad
+
+    def update_hess(self):   # :143-170 (upper triangle)
+        assert self.grad_updated
+        H = np.zeros((self.dim, self.dim))
+        Wi_vec, zeta, pz = self.Wi_vec, self.zeta, self.phizidi
+        c1 = -pz / zeta
+        c2 = pz * (pz - self.di)
+        H[0, 0] = zeta ** -2
+        H[0, 1:] = c1 * Wi_vec
+        au.copytri_upper(self.Wi)
+        K = np.zeros((self.dim - 1, self.dim - 1))
+        au.symm_kron(K, self.Wi, self.rt2)
+        H[1:, 1:] = np.triu((pz + 1) * K + c2 * np.outer(Wi_vec, Wi_vec))
+        self.hess_ = H
+        self.hess_updated = True
+        return self.hess_
+
+    def _two_sided_chol(self, R):
+        """U'^-1 R U^-1 (rdiv!(R, U); ldiv!(U', R))"""
+        F = self.fact_W.factors
+        T = blas.dtrsm(1.0, F, np.asfortranarray(R), side=1, lower=0, trans_a=0, diag=0)
+        return blas.dtrsm(1.0, F, T, side=0, lower=0, trans_a=1, diag=0)
+
+    def _two_sided_chol_back(self, S):
+        """U^-1 S U'^-1 (rdiv!(S, U'); ldiv!(U, S))"""
+        F = self.fact_W.factors
+        T = blas.dtrsm(1.0, F, np.asfortranarray(S), side=1, lower=0, trans_a=1, diag=0)
+        return blas.dtrsm(1.0, F, T, side=0, lower=0, trans_a=0, diag=0)
+
+    def hess_prod(self, prod, arr):   # :172-203
+        assert self.grad_updated
+        P, A = _cols(prod), _cols(arr)
+        di, zeta, pz = self.di, self.zeta, self.phizidi
+        for j in range(A.shape[1]):
+            p = A[0, j]
+            S = self._two_sided_chol(self._smat_full(A[1:, j]))
+            c0 = pz * np.trace(S)
+            c1 = c0 - p / zeta
+            c2 = pz * c1 - di * c0
+            S = (pz + 1) * S
+            S[np.diag_indices(self.d)] += c2
+            W = self._two_sided_chol_back(S)
+            P[0, j] = c1 / -zeta
+            au.smat_to_svec(P[1:, j], W, self.rt2)
+        return prod
+
+    def update_inv_hess(self):   # :205-233
+        assert self.grad_updated
+        w = self.point[1:]
+        W = self._smat_full(w)
+        zeta, phi, di = self.zeta, self.phi, self.di
+        phidi = phi * di
+        c2 = 1.0 / (self.phizidi + 1)
+        c3 = phidi * c2 / zeta * di
+        Hi = np.zeros((self.dim, self.dim))
+        Hi[0, 0] = zeta ** 2 + phidi * phi
+        Hi[0, 1:] = phidi * w
+        K = np.zeros((self.dim - 1, self.dim - 1))
+        au.symm_kron(K, W, self.rt2)
+        Hi[1:, 1:] = np.triu(c2 * K + c3 * np.outer(w, w))
+        self.inv_hess_ = Hi
+        self.inv_hess_updated = True
+        return self.inv_hess_
+
+    def inv_hess_prod(self, prod, arr):   # :235-272
+        assert self.grad_updated
+        P, A = _cols(prod), _cols(arr)
+        w = self.point[1:]
+        W = self._smat_full(w)
+        zeta, phi, di = self.zeta, self.phi, self.di
+        phidi = phi * di
+        c2 = 1.0 / (self.phizidi + 1)
+        c3 = c2 / zeta * di
+        c4 = zeta ** 2 + phidi * phi
+        for j in range(A.shape[1]):
+            p = A[0, j]
+            r = A[1:, j].copy()
+            R = self._smat_full(r)
+            c5 = w @ r
+            c6 = phidi * (c3 * c5 + p)
+            P[0, j] = phidi * c5 + c4 * p
+            M = W @ (R @ W)
+            pw = np.zeros(self.dim - 1)
+            au.smat_to_svec(pw, M, self.rt2)
+            P[1:, j] = c6 * w + c2 * pw
+        return prod
+
+    def dder3(self, dir):   # :274-324
+        assert self.grad_updated
+        p, r = dir[0], dir[1:]
+        zeta, phi, di, pz = self.zeta, self.phi, self.di, self.phizidi
+        rwi = self._two_sided_chol(self._smat_full(r))
+        c0 = np.trace(rwi) * di
+        c6 = np.sum(rwi ** 2) * di
+        zichi = (p - phi * c0) / zeta
+        c1 = zichi ** 2 + phi / zeta * (c6 - c0 ** 2) / 2
+        c7 = pz * (c1 - c6 / 2 + c0 * (zichi + c0 / 2))
+        c8 = -pz * (zichi + c0)
+        c9 = pz + 1
+        self.dder3_[0] = c1 / -zeta
+        aux2 = c9 * rwi + c8 * np.eye(self.d)
+        M = rwi @ aux2
+        M[np.diag_indices(self.d)] += c7
+        au.smat_to_svec(self.dder3_[1:], self._two_sided_chol_back(M), self.rt2)
+        return self.dder3_

@@ -10,6 +10,7 @@ from the same description, and `expect` holds the pinned answers.
 import numpy as np
 
 from . import polyutils as pu
+from . import arrayutil as au
 
 RT2 = np.sqrt(2.0)
 RT3 = np.sqrt(3.0)
@@ -203,6 +204,64 @@ def doublynonnegativetri2():   # :513-526
             [("doublynonnegativetri", 3, False)], dict(status="Optimal", primal_obj=-1.0, x_at={1: 1.0}))
 
 
+def _rand_psd_svec(side, seed, scale=1.0, rank=None):
+    rng = np.random.default_rng(seed)
+    Mh = scale * rng.random((side, rank or side))
+    M = Mh @ Mh.T
+    v = np.zeros(side * (side + 1) // 2)
+    au.smat_to_svec(v, np.asfortranarray(0.5 * (M + M.T)), au.RT2)
+    return v
+
+
+def _rootdet(v, side):
+    m = np.zeros((side, side), order="F")
+    au.svec_to_smat(m, np.asarray(v, dtype=float), au.RT2)
+    m = np.triu(m) + np.triu(m, 1).T
+    return np.linalg.det(m) ** (1.0 / side)
+
+
+def hyporootdettri1(seed=1):   # :1569-1598 (real case; property-based: u = rootdet(W) at the optimum, primal and dual)
+    side = 3
+    dim = 1 + side * (side + 1) // 2
+    G = np.zeros((dim, 1))
+    G[0, 0] = -1.0
+    h = np.zeros(dim)
+    h[1:] = _rand_psd_svec(side, seed)
+
+    def check(sv, approx):
+        assert approx(sv.get_x()[0], -sv.get_primal_obj())
+        s, z = sv.get_s(), sv.get_z()
+        assert approx(_rootdet(s[1:], side), s[0])
+        assert approx(_rootdet(z[1:] * side, side), -z[0])
+    return (np.array([-1.0]), np.zeros((0, 1)), np.zeros(0), G, h, [("hyporootdettri", dim, False)], dict(status="Optimal", check=check))
+
+
+def hyporootdettri2(seed=1):   # :1600-1629 (real case, dual cone)
+    side = 4
+    dim = 1 + side * (side + 1) // 2
+    G = np.zeros((dim, 1))
+    G[0, 0] = -1.0
+    h = np.zeros(dim)
+    h[1:] = _rand_psd_svec(side, seed)
+
+    def check(sv, approx):
+        assert approx(sv.get_x()[0], sv.get_primal_obj())
+        s, z = sv.get_s(), sv.get_z()
+        assert approx(_rootdet(s[1:] * side, side), -s[0])
+        assert approx(_rootdet(z[1:], side), z[0])
+    return (np.array([1.0]), np.zeros((0, 1)), np.zeros(0), G, h, [("hyporootdettri", dim, True)], dict(status="Optimal", check=check))
+
+
+def hyporootdettri4():   # :1657-1674
+    G = np.zeros((6, 4))
+    G[0, 0] = G[1, 1] = G[3, 3] = -1.0
+    G[2, 2] = -au.RT2
+    G[4, 1] = G[5, 3] = 1.0
+    return (np.array([-1.0, 0, 0, 0]), np.zeros((0, 4)), np.zeros(0), G, np.array([0.0, 0, 0, 0, 1, 1]),
+            [("hyporootdettri", 4, False), ("nonnegative", 2)],
+            dict(status="Optimal", primal_obj=-1.0, x=[1.0, 1, 0, 1], z=[-1.0, 0.5, 0, 0.5, 0.5, 0.5]))
+
+
 KNOWN_ANSWER = {
     "dimension1": dimension1, "primalinfeas1": primalinfeas1, "nonnegative4": nonnegative4,
     "possemideftri1": possemideftri1, "possemideftri2": possemideftri2, "possemideftri3": possemideftri3,
@@ -216,6 +275,7 @@ KNOWN_ANSWER = {
     "linmatrixineq1_side2": lambda: linmatrixineq1(2), "linmatrixineq1_side4": lambda: linmatrixineq1(4),
     "linmatrixineq2": linmatrixineq2, "linmatrixineq3": linmatrixineq3,
     "doublynonnegativetri1": doublynonnegativetri1, "doublynonnegativetri2": doublynonnegativetri2,
+    "hyporootdettri1": hyporootdettri1, "hyporootdettri2": hyporootdettri2, "hyporootdettri4": hyporootdettri4,
 }
 
 

@@ -35,6 +35,8 @@ def build_solve_check(solver, model, inst, tol=TEST_TOL):
         assert approx(G.T @ z, -A.T @ y, rt_tol)
     if "primal_obj" in expect:
         assert approx(p_obj, expect["primal_obj"], tol), (p_obj, expect["primal_obj"])
+    if "check" in expect:   # property-based expectations of the reference's test (a callable of the solver)
+        expect["check"](solver, lambda a, b: approx(a, b, tol))
     if expect.get("primal_obj_negative"):
         assert p_obj < 0, p_obj
     if "x" in expect:

@@ -117,3 +117,17 @@ def test_doublynonnegativetri_barrier():   # test/cone.jl:363-371
     cone = oc.DoublyNonnegativeTri(au.svec_length(side))
     od = cone.offdiag_idxs
     run_test_barrier(cone, lambda s: -np.linalg.slogdet(_smat_full(s, side))[1] - np.sum(np.log(s[od])))
+
+
+@pytest.mark.parametrize("side", [1, 2, 4])
+def test_hyporootdettri_oracles(side):   # test/cone.jl:606-610
+    run_test_oracles(oc.HypoRootdetTri(1 + au.svec_length(side)))
+
+
+def test_hyporootdettri_barrier():   # test/cone.jl:612-620
+    side = 3
+
+    def barrier(s):
+        logdet = np.linalg.slogdet(_smat_full(s[1:], side))[1]
+        return -np.log(np.exp(logdet / side) - s[0]) - logdet
+    run_test_barrier(oc.HypoRootdetTri(1 + au.svec_length(side)), barrier)
