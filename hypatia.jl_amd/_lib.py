@@ -34,6 +34,7 @@ SIGNATURES = {
     "hyp_cone_create_linmatrixineq": [c_vp, c_int, c_int, c_vp, c_int, P(c_vp)],
     "hyp_cone_create_doublynonnegativetri": [c_vp, c_int, c_int, P(c_vp)],
     "hyp_cone_create_hyporootdettri": [c_vp, c_int, c_int, P(c_vp)],
+    "hyp_cone_create_hypoperlogdettri": [c_vp, c_int, c_int, P(c_vp)],
     "hyp_cone_update_use_hess_prod_slow": [c_vp, P(c_int)],
     "hyp_cone_set_use_hess_prod_slow": [c_vp, c_int],
     "hyp_cone_destroy": [c_vp],

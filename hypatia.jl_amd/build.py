@@ -19,6 +19,8 @@ def make_cone(spec):
         return hc.DoublyNonnegativeTri(spec[1], use_dual=spec[2])
     if kind == "hyporootdettri":
         return hc.HypoRootdetTri(spec[1], use_dual=spec[2])
+    if kind == "hypoperlogdettri":
+        return hc.HypoPerLogdetTri(spec[1], use_dual=spec[2])
     raise NotImplementedError("no HIP cone for %r yet (and there is no CPU fallback)" % (kind,))
 
 

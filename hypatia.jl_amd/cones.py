@@ -295,3 +295,14 @@ class HypoRootdetTri(_GenericHessMixin, Cone):
         L.check(L.lib().hyp_cone_create_hyporootdettri(L.ctx(), int(dim), int(bool(use_dual)), ctypes.byref(h)),
                 "hyp_cone_create_hyporootdettri")
         super().__init__(h)
+
+
+class HypoPerLogdetTri(_GenericHessMixin, Cone):
+    """Cones.HypoPerLogdetTri{Float64, Float64}(dim; use_dual)  (hypoperlogdettri.jl:9-58)."""
+
+    def __init__(self, dim, use_dual=False):
+        self._slow = False
+        h = c_vp()
+        L.check(L.lib().hyp_cone_create_hypoperlogdettri(L.ctx(), int(dim), int(bool(use_dual)), ctypes.byref(h)),
+                "hyp_cone_create_hypoperlogdettri")
+        super().__init__(h)

@@ -129,6 +129,13 @@ int hyp_cone_create_hyporootdettri(hyp_ctx* ctx, int dim, int use_dual, hyp_cone
   ctx->c.sync();
   API_END(ctx)
 }
+int hyp_cone_create_hypoperlogdettri(hyp_ctx* ctx, int dim, int use_dual, hyp_cone** out) {
+  API_BEGIN
+  HYP_CHECK(hipSetDevice(ctx->c.device));
+  *out = new hyp_cone{ctx, new HypoPerLogdetTriCone(ctx->c, dim, use_dual != 0)};
+  ctx->c.sync();
+  API_END(ctx)
+}
 int hyp_cone_update_use_hess_prod_slow(hyp_cone* cone, int* out) {
   API_BEGIN
   GenericHessCone* g = dynamic_cast<GenericHessCone*>(cone->cone);

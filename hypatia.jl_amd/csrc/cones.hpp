@@ -13,7 +13,7 @@ bool psd_two_sided_fused_ok(int side);
 void psd_two_sided_fused(Ctx& c, int side, int ncols, const double* R, int rstruct /* 0 full, 1 upper, 2 lower */, const double* arr,
                          long lda, double* prod, long ldp, double* zws /* ncols * side^2 */);
 
-enum ConeKind { CONE_NONNEG = 0, CONE_PSD = 1, CONE_EPINORMSPECTRAL = 2, CONE_WSOS = 3, CONE_LMI = 4, CONE_DNN = 5, CONE_HYPOROOTDET = 6 };
+enum ConeKind { CONE_NONNEG = 0, CONE_PSD = 1, CONE_EPINORMSPECTRAL = 2, CONE_WSOS = 3, CONE_LMI = 4, CONE_DNN = 5, CONE_HYPOROOTDET = 6, CONE_HYPOPERLOGDET = 7 };
 
 struct Cone {
   Ctx& ctx;
@@ -225,6 +225,29 @@ struct HypoRootdetTriCone : GenericHessCone {   // src/Cones/hyporootdettri.jl (
   void inv_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;     // :235-272
   bool inv_hess_ready() override { return true; }                                                   // closed form
   const double* dder3(const double* d_dir) override;                                                // :274-324
+  double logdet_of(PsdCone& k);
+};
+
+struct HypoPerLogdetTriCone : GenericHessCone {   // src/Cones/hypoperlogdettri.jl (real): (u, v, w), u <= v logdet(smat(w) / v)
+  int d;
+  PsdCone psd;      // the W part of the point
+  PsdCone psdd;     // the W part of the dual point
+  double u = 0, v = 0, phi = 0, zeta = 0;
+  DBuf Wi_vec, dots, tmpw, ld;
+  HypoPerLogdetTriCone(Ctx& c, int dim, bool use_dual);
+  void reset_data() override {
+    GenericHessCone::reset_data();
+    psd.reset_data();
+  }
+  bool update_feas() override;                                                                      // :97-118
+  bool is_dual_feas() override;                                                                     // :120-131
+  void update_grad() override;                                                                      // :133-150
+  void update_hess() override;                                                                      // :152-193
+  void set_initial_point(double* h_out) override;                                                   // :80-95
+  void hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;         // :195-236
+  void inv_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;     // :271-316
+  bool inv_hess_ready() override { return true; }
+  const double* dder3(const double* d_dir) override;                                                // :318-368
   double logdet_of(PsdCone& k);
 };
 

@@ -721,4 +721,216 @@ const double* HypoRootdetTriCone::dder3(const double* d_dir) {   // :274-324
   return dder3v.d();
 }
 
+// ---------------------------------------------------------------------------------------------
+// HypoPerLogdetTri (hypoperlogdettri.jl:9-368, real): barrier -log(v logdet(W / v) - u) - log(v) - logdet(W).  Same
+// structure as HypoRootdetTri above with two leading scalars (u, v): per column p = arr[1], q = arr[2] and one inner
+// product; the W-blocks are combinations of the PSD oracles at W and of svec(W^-1) or w.
+// ---------------------------------------------------------------------------------------------
+struct PerLogdetScal { double v, d, zeta, phi; };
+__global__ void perlogdet_combine_kernel(int dw, int ncols, int mode, PerLogdetScal sc, const double* __restrict__ arr, long lda,
+                                         const double* __restrict__ dots, const double* __restrict__ vec, double* __restrict__ out, long ldo) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const double v = sc.v, d = sc.d, zeta = sc.zeta, phi = sc.phi;
+  for (int j = blockIdx.y; j < ncols; j += gridDim.y) {
+    const double p = arr[(long)j * lda], q = arr[(long)j * lda + 1], t = dots[j];
+    double a, b, o0, o1;
+    if (mode == 0) {   // hess_prod (:195-236): t = <svec W^-1, r>
+      const double sigma = phi - d;
+      const double qzi = q / zeta;
+      const double c0 = t / zeta;
+      const double c1 = (v * c0 - p / zeta + sigma * qzi) / zeta;
+      b = c1 * v - qzi;
+      a = v / zeta + 1.0;
+      o0 = -c1;
+      o1 = c1 * sigma - c0 + (qzi * d + q / v) / v;
+    } else {           // inv_hess_prod (:271-316): t = <w, r>
+      const double zv = zeta + v;
+      const double zzvi = zeta / zv;
+      const double c3 = v / (zv + d * v);
+      const double c0 = phi - d * zzvi;
+      const double c4 = v * c3 * zv;
+      const double vphi = v * phi, zvp = zeta + v * phi;
+      const double c6 = vphi * vphi + zeta * (zeta + d * v) - d * zvp * zvp * c3;
+      const double c7 = c4 * c0;
+      const double c8 = c7 + v * zeta;
+      const double c1 = t / zv;
+      const double c5 = c0 * p + q + c1;
+      b = v * (zzvi * p + c3 * c5);
+      a = zzvi;
+      o0 = c6 * p + c7 * q + c8 * c1;
+      o1 = c4 * c5;
+    }
+    if (i < dw) {
+      double* o = out + (long)j * ldo + 2 + i;
+      *o = a * (*o) + b * vec[i];
+    }
+    if (i == 0) {
+      out[(long)j * ldo] = o0;
+      out[(long)j * ldo + 1] = o1;
+    }
+  }
+}
+__global__ void perlogdet_dder3_kernel(int dw, double o0, double o1, double ca, double cb, double cc, const double* __restrict__ D3,
+                                       const double* __restrict__ P1, const double* __restrict__ vec, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < dw) out[2 + i] = ca * D3[i] + cb * P1[i] + cc * vec[i];
+  if (i == 0) { out[0] = o0; out[1] = o1; }
+}
+__global__ void perlogdet_grad_kernel(int dw, double g0, double g1, double a, const double* __restrict__ x, double* __restrict__ g) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < dw) g[2 + i] = a * x[i];
+  if (i == 0) { g[0] = g0; g[1] = g1; }
+}
+
+HypoPerLogdetTriCone::HypoPerLogdetTriCone(Ctx& c, int dim_, bool use_dual)
+    : GenericHessCone(c, CONE_HYPOPERLOGDET), psd(c, dim_ - 2), psdd(c, dim_ - 2) {
+  HYP_REQUIRE(dim_ >= 3, "HypoPerLogdetTri: dim >= 3");
+  dim = dim_;
+  d = psd.side;
+  use_dual_barrier = use_dual;
+  nu = 2 + d;                                                                                         // :78
+  alloc_common();
+  alloc_generic();
+  Wi_vec.alloc((size_t)(dim - 2) * sizeof(double));
+  tmpw.alloc((size_t)(dim - 2) * sizeof(double));
+  ld.alloc(64);
+}
+
+// hypoperlog.jl:289-319: central ray of the hypograph-of-perspective-of-sum-log cone (looked up for d <= 10, fitted beyond)
+static void central_ray_hypoperlog(int d, double* uvw) {
+  static const double tab[10][3] = {
+      {-0.827838387, 0.805102007, 1.290927686}, {-0.689607388, 0.724605082, 1.224617936}, {-0.584372665, 0.68128058, 1.182421942},
+      {-0.503499342, 0.65448622, 1.153053152},  {-0.440285893, 0.636444224, 1.131466926}, {-0.389979809, 0.623569352, 1.114979519},
+      {-0.349255921, 0.613978276, 1.102013921}, {-0.315769104, 0.606589839, 1.091577908}, {-0.287837744, 0.600745284, 1.083013},
+      {-0.264242734, 0.596019009, 1.075868782}};
+  if (d <= 10) {
+    for (int k = 0; k < 3; ++k) uvw[k] = tab[d - 1][k];
+    return;
+  }
+  const double x = 1.0 / d;
+  if (d <= 70) {
+    uvw[0] = 4.657876 * x * x - 3.116192 * x + 0.000647; uvw[1] = 0.424682 * x + 0.553392; uvw[2] = 0.760412 * x + 1.001795;
+  } else {
+    uvw[0] = -3.011166 * x - 0.000122; uvw[1] = 0.395308 * x + 0.553955; uvw[2] = 0.837545 * x + 1.000024;
+  }
+}
+
+void HypoPerLogdetTriCone::set_initial_point(double* h) {   // :80-95
+  for (int i = 0; i < dim; ++i) h[i] = 0.0;
+  double uvw[3];
+  central_ray_hypoperlog(d, uvw);
+  h[0] = uvw[0]; h[1] = uvw[1];
+  long k = 2;
+  for (int i = 1; i <= d; ++i) { h[k] = uvw[2]; k += i + 1; }
+}
+
+double HypoPerLogdetTriCone::logdet_of(PsdCone& k) {
+  hipLaunchKernelGGL(logdet_diag_kernel, dim3(1), dim3(256), 0, ctx.stream, k.side, k.U.d(), (long)k.side, ld.d());
+  HYP_CHECK(hipGetLastError());
+  ctx.d2h(ctx.h_pinned, ld.p, sizeof(double));
+  ctx.sync();
+  return ctx.h_pinned[0];
+}
+
+bool HypoPerLogdetTriCone::update_feas() {   // :97-118
+  ctx.d2h(ctx.h_pinned + 1, point.p, 2 * sizeof(double));
+  ctx.sync();
+  u = ctx.h_pinned[1];
+  v = ctx.h_pinned[2];
+  is_feas_ = false;
+  if (v > EPS) {
+    psd.load_point(point.d() + 2, 1.0);
+    psd.reset_data();
+    if (psd.is_feas()) {
+      phi = logdet_of(psd) - d * log(v);
+      zeta = v * phi - u;
+      is_feas_ = (zeta > EPS);
+    }
+  }
+  feas_updated = true;
+  return is_feas_;
+}
+
+bool HypoPerLogdetTriCone::is_dual_feas() {   // :120-131
+  ctx.d2h(ctx.h_pinned + 1, dual_point.p, 2 * sizeof(double));
+  ctx.sync();
+  const double ud = ctx.h_pinned[1], vd = ctx.h_pinned[2];
+  if (!(ud < -EPS)) return false;
+  psdd.load_point(dual_point.d() + 2, 1.0);
+  psdd.reset_data();
+  if (!psdd.is_feas()) return false;
+  return vd - ud * (logdet_of(psdd) + d * (1.0 - log(-ud))) > EPS;
+}
+
+void HypoPerLogdetTriCone::update_grad() {   // :133-150
+  const int dw = dim - 2;
+  dev_scale_copy(ctx, dw, -1.0, psd.get_grad(), Wi_vec.d());                // svec(W^-1)
+  hipLaunchKernelGGL(perlogdet_grad_kernel, dim3((dw + 255) / 256), dim3(256), 0, ctx.stream, dw, 1.0 / zeta, -1.0 / v - (phi - d) / zeta,
+                     -1.0 - v / zeta, Wi_vec.d(), grad.d());
+  HYP_CHECK(hipGetLastError());
+  grad_updated = true;
+}
+
+void HypoPerLogdetTriCone::hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) {   // :195-236
+  HYP_REQUIRE(prod != arr, "HypoPerLogdetTri hess_prod: in-place call");
+  if (ncols <= 0) return;
+  get_grad();
+  const int dw = dim - 2;
+  dots.ensure((size_t)ncols * sizeof(double));
+  gemv(ctx, true, dw, ncols, 1.0, arr + 2, lda, Wi_vec.d(), 0.0, dots.d());      // tr(U^-T R U^-1)
+  psd.hess_prod(prod + 2, ldp, arr + 2, lda, ncols);                              // svec(W^-1 R W^-1)
+  hipLaunchKernelGGL(perlogdet_combine_kernel, dim3((dw + 255) / 256, std::min(ncols, 1024)), dim3(256), 0, ctx.stream, dw, ncols, 0,
+                     PerLogdetScal{v, (double)d, zeta, phi}, arr, lda, dots.d(), Wi_vec.d(), prod, ldp);
+  HYP_CHECK(hipGetLastError());
+}
+
+void HypoPerLogdetTriCone::inv_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) {   // :271-316
+  HYP_REQUIRE(prod != arr, "HypoPerLogdetTri inv_hess_prod: in-place call");
+  if (ncols <= 0) return;
+  get_grad();
+  const int dw = dim - 2;
+  dots.ensure((size_t)ncols * sizeof(double));
+  gemv(ctx, true, dw, ncols, 1.0, arr + 2, lda, point.d() + 2, 0.0, dots.d());   // <w, r>
+  psd.inv_hess_prod(prod + 2, ldp, arr + 2, lda, ncols);                          // svec(W R W)
+  hipLaunchKernelGGL(perlogdet_combine_kernel, dim3((dw + 255) / 256, std::min(ncols, 1024)), dim3(256), 0, ctx.stream, dw, ncols, 1,
+                     PerLogdetScal{v, (double)d, zeta, phi}, arr, lda, dots.d(), point.d() + 2, prod, ldp);
+  HYP_CHECK(hipGetLastError());
+}
+
+void HypoPerLogdetTriCone::update_hess() {   // :152-193
+  ensure_hess_storage(false);
+  get_grad();
+  DBuf eye((size_t)dim * dim * sizeof(double));
+  dev_fill_identity(ctx, dim, eye.d(), dim);
+  hess_prod(H.d(), dim, eye.d(), dim, dim);
+  dev_symmetrize_from_upper(ctx, dim, H.d(), dim, 1, 0);
+  ctx.sync();
+  hess_updated = true;
+}
+
+const double* HypoPerLogdetTriCone::dder3(const double* d_dir) {   // :318-368
+  get_grad();
+  const int dw = dim - 2;
+  const double* r = d_dir + 2;
+  ctx.d2h(ctx.h_pinned + 2, d_dir, 2 * sizeof(double));
+  psd.hess_prod(tmpw.d(), dw, r, dw, 1);                       // P1 = svec(W^-1 R W^-1)
+  const double* D3 = psd.dder3(r);                             // svec(W^-1 R W^-1 R W^-1)
+  const double c0 = dot_host(dw, Wi_vec.d(), r);               // tr S
+  const double c7 = dot_host(dw, r, tmpw.d());                 // ||S||_F^2
+  const double p = ctx.h_pinned[2], q = ctx.h_pinned[3];
+  const double sigma = phi - d;
+  const double viq = q / v, viq2 = viq * viq, vzi = v / zeta, vzi1 = vzi + 1;
+  const double zichi = (-p + sigma * q + c0 * v) / zeta;
+  const double c4 = (viq * (-viq * d + 2 * c0) - c7) / zeta / 2;
+  const double c1 = (zichi * zichi - v * c4) / zeta;
+  const double c3 = -(zichi + viq) / zeta;
+  const double c5 = c3 * q + vzi * viq2;
+  const double c6 = -2 * vzi * viq - c3 * v;
+  const double c8 = c5 + c1 * v;
+  hipLaunchKernelGGL(perlogdet_dder3_kernel, dim3((dw + 255) / 256), dim3(256), 0, ctx.stream, dw, -c1,
+                     c1 * sigma + (viq2 - (d * c5 + c6 * c0 + vzi * c7)) / v - c4, vzi1, c6, c8, D3, tmpw.d(), Wi_vec.d(), dder3v.d());
+  HYP_CHECK(hipGetLastError());
+  return dder3v.d();
+}
+
 }  // namespace hyp

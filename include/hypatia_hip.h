@@ -55,6 +55,9 @@ int hyp_cone_create_doublynonnegativetri(hyp_ctx* ctx, int dim, int use_dual, hy
 /* Cones.HypoRootdetTri{Float64, Float64}(dim; use_dual) (hyporootdettri.jl:44-59): (u, svec(W)), dim = 1 + side (side + 1) / 2;
  * nu = 1 + side */
 int hyp_cone_create_hyporootdettri(hyp_ctx* ctx, int dim, int use_dual, hyp_cone** out);
+/* Cones.HypoPerLogdetTri{Float64, Float64}(dim; use_dual) (hypoperlogdettri.jl:43-58): (u, v, svec(W)),
+ * dim = 2 + side (side + 1) / 2; nu = 2 + side */
+int hyp_cone_create_hypoperlogdettri(hyp_ctx* ctx, int dim, int use_dual, hyp_cone** out);
 int hyp_cone_destroy(hyp_cone* cone);
 int hyp_cone_dimension(hyp_cone* cone, int* out);            /* Cones.jl:34 */
 int hyp_cone_get_nu(hyp_cone* cone, double* out);            /* Cones.jl:41 */

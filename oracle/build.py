@@ -19,6 +19,8 @@ def make_cone(spec):
         return oc.DoublyNonnegativeTri(spec[1], use_dual=spec[2])
     if kind == "hyporootdettri":
         return oc.HypoRootdetTri(spec[1], use_dual=spec[2])
+    if kind == "hypoperlogdettri":
+        return oc.HypoPerLogdetTri(spec[1], use_dual=spec[2])
     raise ValueError(kind)
 
 

@@ -1056,3 +1056,213 @@ class HypoRootdetTri(Cone):
         M[np.diag_indices(self.d)] += c7
         au.smat_to_svec(self.dder3_[1:], self._two_sided_chol_back(M), self.rt2)
         return self.dder3_
+
+
+# ----------------------------------------------------------------------------------------------
+# hypoperlog.jl:289-319: central ray (u, v, w) of the hypograph-of-perspective-of-sum-log cone, shared by HypoPerLogdetTri
+_CENTRAL_RAYS_HYPOPERLOG = np.array([
+    [-0.827838387, 0.805102007, 1.290927686], [-0.689607388, 0.724605082, 1.224617936], [-0.584372665, 0.68128058, 1.182421942],
+    [-0.503499342, 0.65448622, 1.153053152], [-0.440285893, 0.636444224, 1.131466926], [-0.389979809, 0.623569352, 1.114979519],
+    [-0.349255921, 0.613978276, 1.102013921], [-0.315769104, 0.606589839, 1.091577908], [-0.287837744, 0.600745284, 1.083013],
+    [-0.264242734, 0.596019009, 1.075868782]])
+
+
+def get_central_ray_hypoperlog(d):
+    if d <= 10:
+        return _CENTRAL_RAYS_HYPOPERLOG[d - 1]
+    x = 1.0 / d
+    if d <= 70:
+        return np.array([4.657876 * x ** 2 - 3.116192 * x + 0.000647, 0.424682 * x + 0.553392, 0.760412 * x + 1.001795])
+    return np.array([-3.011166 * x - 0.000122, 0.395308 * x + 0.553955, 0.837545 * x + 1.000024])
+
+
+class HypoPerLogdetTri(HypoRootdetTri):
+    """hypoperlogdettri.jl:9-368 (real symmetric case): (u, v, w) with u <= v logdet(smat(w) / v); barrier
+    -log(v logdet(W / v) - u) - log(v) - logdet(W).  (Subclass only to share the small matrix helpers.)"""
+
+    def __init__(self, dim, use_dual=False):
+        assert dim >= 3
+        self.use_dual_barrier_ = bool(use_dual)
+        self.dim = dim
+        self.rt2 = au.RT2
+        self.d = au.svec_side(dim - 2)
+
+    def setup_extra_data(self):   # :62-76
+        d = self.d
+        self.mat = np.zeros((d, d), order="F")
+        self.Wi = np.zeros((d, d), order="F")
+        self.Wi_vec = np.zeros(self.dim - 2)
+
+    def get_nu(self):   # :78
+        return 2 + self.d
+
+    def set_initial_point(self, arr):   # :80-95
+        arr[:] = 0
+        arr[0], arr[1], w = get_central_ray_hypoperlog(self.d)
+        k = 2
+        for i in range(1, self.d + 1):
+            arr[k] = w
+            k += i + 1
+        return arr
+
+    def update_feas(self):   # :97-118
+        assert not self.feas_updated
+        v = self.point[1]
+        self.is_feas_ = False
+        if v > EPS:
+            u = self.point[0]
+            au.svec_to_smat(self.mat, self.point[2:], self.rt2)
+            self.fact_W = la.chol_upper(self.mat)
+            if self.fact_W.success:
+                logdet = 2 * np.sum(np.log(np.diag(self.fact_W.factors)))
+                self.phi = logdet - self.d * np.log(v)
+                self.zeta = v * self.phi - u
+                self.is_feas_ = self.zeta > EPS
+        self.feas_updated = True
+        return self.is_feas_
+
+    def is_dual_feas(self):   # :120-131
+        u = self.dual_point[0]
+        if u < -EPS:
+            v = self.dual_point[1]
+            m = np.zeros((self.d, self.d), order="F")
+            au.svec_to_smat(m, self.dual_point[2:], self.rt2)
+            f = la.chol_upper(m)
+            if f.success:
+                logdet = 2 * np.sum(np.log(np.diag(f.factors)))
+                return v - u * (logdet + self.d * (1 - np.log(-u))) > EPS
+        return False
+
+    def update_grad(self):   # :133-150
+        assert self.is_feas_
+        v, zeta = self.point[1], self.zeta
+        self.grad[0] = 1.0 / zeta
+        self.grad[1] = -1.0 / v - (self.phi - self.d) / zeta
+        self.Wi[:] = la.inv_fact_chol(self.fact_W)
+        au.smat_to_svec(self.Wi_vec, self.Wi, self.rt2)
+        self.grad[2:] = (-1 - v / zeta) * self.Wi_vec
+        self.grad_updated = True
+        return self.grad
+
+    def update_hess(self):   # :152-193 (upper triangle)
+        assert self.grad_updated
+        v, d, zeta = self.point[1], self.d, self.zeta
+        zi = 1.0 / zeta
+        sigma = self.phi - d
+        Wi_vec = self.Wi_vec
+        zisig = sigma / zeta
+        vzi = v / zeta
+        H = np.zeros((self.dim, self.dim))
+        H[0, 0] = zi ** 2
+        H[0, 1] = -zi * zisig
+        H[1, 1] = v ** -2 + zisig ** 2 + d / (v * zeta)
+        H[0, 2:] = (-vzi / zeta) * Wi_vec
+        H[1, 2:] = ((sigma * vzi - 1) / zeta) * Wi_vec
+        au.copytri_upper(self.Wi)
+        K = np.zeros((self.dim - 2, self.dim - 2))
+        au.symm_kron(K, self.Wi, self.rt2)
+        Wv = vzi * Wi_vec
+        H[2:, 2:] = np.triu((1 + vzi) * K + np.outer(Wv, Wv))
+        self.hess_ = H
+        self.hess_updated = True
+        return self.hess_
+
+    def hess_prod(self, prod, arr):   # :195-236
+        assert self.grad_updated
+        P, A = _cols(prod), _cols(arr)
+        v, d, zeta = self.point[1], self.d, self.zeta
+        sigma = self.phi - d
+        vzi1 = v / zeta + 1
+        for j in range(A.shape[1]):
+            p, q = A[0, j], A[1, j]
+            S = self._two_sided_chol(self._smat_full(A[2:, j]))
+            qzi = q / zeta
+            c0 = np.trace(S) / zeta
+            c1 = (v * c0 - p / zeta + sigma * qzi) / zeta
+            c3 = c1 * v - qzi
+            P[0, j] = -c1
+            P[1, j] = c1 * sigma - c0 + (qzi * d + q / v) / v
+            S = vzi1 * S
+            S[np.diag_indices(d)] += c3
+            au.smat_to_svec(P[2:, j], self._two_sided_chol_back(S), self.rt2)
+        return prod
+
+    def _inv_consts(self):
+        v, d, zeta, phi = self.point[1], self.d, self.zeta, self.phi
+        zv = zeta + v
+        zzvi = zeta / zv
+        c3 = v / (zv + d * v)
+        c0 = phi - d * zzvi
+        return v, d, zeta, phi, zv, zzvi, c3, c0
+
+    def update_inv_hess(self):   # :238-269
+        assert self.grad_updated
+        v, d, zeta, phi, zv, zzvi, c3, c0 = self._inv_consts()
+        w = self.point[2:]
+        W = self._smat_full(w)
+        c2 = v * c3
+        c4 = c2 * zv
+        c1 = v * zzvi + c0 * c2
+        Hi = np.zeros((self.dim, self.dim))
+        Hi[0, 0] = (v * phi) ** 2 + zeta * (zeta + d * v) - d * (zeta + v * phi) ** 2 * c3
+        Hi[0, 1] = c0 * c4
+        Hi[1, 1] = c4
+        Hi[0, 2:] = c1 * w
+        Hi[1, 2:] = c2 * w
+        K = np.zeros((self.dim - 2, self.dim - 2))
+        au.symm_kron(K, W, self.rt2)
+        Hi[2:, 2:] = np.triu(zzvi * K + (c2 / zv) * np.outer(w, w))
+        self.inv_hess_ = Hi
+        self.inv_hess_updated = True
+        return self.inv_hess_
+
+    def inv_hess_prod(self, prod, arr):   # :271-316
+        assert self.grad_updated
+        P, A = _cols(prod), _cols(arr)
+        v, d, zeta, phi, zv, zzvi, c3, c0 = self._inv_consts()
+        w = self.point[2:]
+        W = self._smat_full(w)
+        c4 = v * c3 * zv
+        c6 = (v * phi) ** 2 + zeta * (zeta + d * v) - d * (zeta + v * phi) ** 2 * c3
+        c7 = c4 * c0
+        c8 = c7 + v * zeta
+        for j in range(A.shape[1]):
+            p, q = A[0, j], A[1, j]
+            r = A[2:, j].copy()
+            R = self._smat_full(r)
+            c1 = (w @ r) / zv
+            c5 = c0 * p + q + c1
+            c2 = v * (zzvi * p + c3 * c5)
+            P[0, j] = c6 * p + c7 * q + c8 * c1
+            P[1, j] = c4 * c5
+            pw = np.zeros(self.dim - 2)
+            au.smat_to_svec(pw, W @ (R @ W), self.rt2)
+            P[2:, j] = c2 * w + zzvi * pw
+        return prod
+
+    def dder3(self, dir):   # :318-368
+        assert self.grad_updated
+        v, d, zeta = self.point[1], self.d, self.zeta
+        p, q, r = dir[0], dir[1], dir[2:]
+        sigma = self.phi - d
+        viq = q / v
+        viq2 = viq ** 2
+        vzi = v / zeta
+        vzi1 = vzi + 1
+        rwi = self._two_sided_chol(self._smat_full(r))
+        c0 = np.trace(rwi)
+        c7 = np.sum(rwi ** 2)
+        zichi = (-p + sigma * q + c0 * v) / zeta
+        c4 = (viq * (-viq * d + 2 * c0) - c7) / zeta / 2
+        c1 = (zichi ** 2 - v * c4) / zeta
+        c3 = -(zichi + viq) / zeta
+        c5 = c3 * q + vzi * viq2
+        c6 = -2 * vzi * viq - c3 * v
+        c8 = c5 + c1 * v
+        self.dder3_[0] = -c1
+        self.dder3_[1] = c1 * sigma + (viq2 - (d * c5 + c6 * c0 + vzi * c7)) / v - c4
+        aux2 = vzi1 * rwi + c6 * np.eye(d)
+        M = rwi @ aux2
+        M[np.diag_indices(d)] += c8
+        au.smat_to_svec(self.dder3_[2:], self._two_sided_chol_back(M), self.rt2)
+        return self.dder3_

@@ -262,6 +262,77 @@ def hyporootdettri4():   # :1657-1674
             dict(status="Optimal", primal_obj=-1.0, x=[1.0, 1, 0, 1], z=[-1.0, 0.5, 0, 0.5, 0.5, 0.5]))
 
 
+def _logdet(v, side):
+    m = np.zeros((side, side), order="F")
+    au.svec_to_smat(m, np.asarray(v, dtype=float), au.RT2)
+    m = np.triu(m) + np.triu(m, 1).T
+    return np.linalg.slogdet(m)[1]
+
+
+def hypoperlogdettri1(seed=1):   # :1797-1827 (real case; property-based)
+    side = 4
+    dim = 2 + side * (side + 1) // 2
+    G = np.zeros((dim, 2))
+    G[0, 0] = G[1, 1] = -1.0
+    h = np.zeros(dim)
+    rng = np.random.default_rng(seed)
+    Mh = rng.random((side, side))
+    M = Mh @ Mh.T + np.eye(side)
+    au.smat_to_svec(h[2:], np.asfortranarray(0.5 * (M + M.T)), au.RT2)
+
+    def check(sv, approx):
+        x, s, z = sv.get_x(), sv.get_s(), sv.get_z()
+        assert approx(x[0], -sv.get_primal_obj()) and approx(x[1], 1.0)
+        assert approx(s[1] * _logdet(s[2:] / s[1], side), s[0])
+        assert approx(z[0] * (_logdet(-z[2:] / z[0], side) + side), z[1])
+    return (np.array([-1.0, 0.0]), np.array([[0.0, 1.0]]), np.array([1.0]), G, h, [("hypoperlogdettri", dim, False)],
+            dict(status="Optimal", check=check))
+
+
+def hypoperlogdettri2(seed=1):   # :1829-1859 (real case, dual cone)
+    side = 2
+    dim = 2 + side * (side + 1) // 2
+    G = np.zeros((dim, 2))
+    G[0, 0] = G[1, 1] = -1.0
+    h = np.zeros(dim)
+    h[2:] = _rand_psd_svec(side, seed)
+
+    def check(sv, approx):
+        x, s, z = sv.get_x(), sv.get_s(), sv.get_z()
+        assert approx(x[1], sv.get_primal_obj()) and approx(x[0], -1.0)
+        assert approx(s[0] * (_logdet(-s[2:] / s[0], side) + side), s[1])
+        assert approx(z[1] * _logdet(z[2:] / z[1], side), z[0])
+    return (np.array([0.0, 1.0]), np.array([[1.0, 0.0]]), np.array([-1.0]), G, h, [("hypoperlogdettri", dim, True)],
+            dict(status="Optimal", check=check))
+
+
+def hypoperlogdettri3(seed=1):   # :1861-1884 (real case)
+    side = 3
+    dim = 2 + side * (side + 1) // 2
+    G = np.zeros((dim, 2))
+    G[0, 0] = G[1, 1] = -1.0
+    h = np.zeros(dim)
+    h[2:] = _rand_psd_svec(side, seed)
+
+    def check(sv, approx):
+        x = sv.get_x()
+        assert approx(x[0], -sv.get_primal_obj()) and approx(np.linalg.norm(x), 0.0)
+    return (np.array([-1.0, 0.0]), np.array([[0.0, 1.0]]), np.array([0.0]), G, h, [("hypoperlogdettri", dim, False)],
+            dict(status="Optimal", check=check))
+
+
+def hypoperlogdettri4():   # :1886-1907
+    A = np.zeros((1, 5))
+    A[0, 1] = 1.0
+    G = np.zeros((7, 5))
+    G[0, 0] = G[1, 1] = G[2, 2] = G[4, 4] = -1.0
+    G[3, 3] = -au.RT2
+    G[5, 2] = G[6, 4] = 1.0
+    return (np.array([-1.0, 0, 0, 0, 0]), A, np.array([1.0]), G, np.array([0.0, 0, 0, 0, 0, 1, 1]),
+            [("hypoperlogdettri", 5, False), ("nonnegative", 2)],
+            dict(status="Optimal", primal_obj=0.0, x=[0.0, 1, 1, 0, 1], y=[-2.0], z=[-1.0, -2, 1, 0, 1, 1, 1]))
+
+
 KNOWN_ANSWER = {
     "dimension1": dimension1, "primalinfeas1": primalinfeas1, "nonnegative4": nonnegative4,
     "possemideftri1": possemideftri1, "possemideftri2": possemideftri2, "possemideftri3": possemideftri3,
@@ -276,6 +347,8 @@ KNOWN_ANSWER = {
     "linmatrixineq2": linmatrixineq2, "linmatrixineq3": linmatrixineq3,
     "doublynonnegativetri1": doublynonnegativetri1, "doublynonnegativetri2": doublynonnegativetri2,
     "hyporootdettri1": hyporootdettri1, "hyporootdettri2": hyporootdettri2, "hyporootdettri4": hyporootdettri4,
+    "hypoperlogdettri1": hypoperlogdettri1, "hypoperlogdettri2": hypoperlogdettri2, "hypoperlogdettri3": hypoperlogdettri3,
+    "hypoperlogdettri4": hypoperlogdettri4,
 }
 
 

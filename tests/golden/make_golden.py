@@ -48,11 +48,13 @@ def _lmi_members(side, count, seed):   # test/cone.jl:280-289 (rand_herms, real 
 CONE_CASES["linmatrixineq_side4_dim5"] = ("linmatrixineq", _lmi_members(4, 5, 7), False)
 CONE_CASES["doublynonnegativetri_side6"] = ("doublynonnegativetri", 21, False)
 CONE_CASES["hyporootdettri_side5"] = ("hyporootdettri", 16, False)
+CONE_CASES["hypoperlogdettri_side5_dual"] = ("hypoperlogdettri", 17, True)
 
 # seeds of the oracle points: fixed per case, so that adding a case leaves the committed vectors of the others unchanged
 SEEDS = {"epinormspectral_2x4_dual": 100, "epinormspectral_3x5": 101, "nonnegative_6": 102, "possemideftri_side19": 103,
          "possemideftri_side5": 104, "wsos_2var_halfdeg3": 105, "wsos_2var_halfdeg3_dual": 106, "linmatrixineq_side4_dim5": 107,
-         "doublynonnegativetri_side6": 108, "hyporootdettri_side5": 109}
+         "doublynonnegativetri_side6": 108, "hyporootdettri_side5": 109,
+         "hypoperlogdettri_side5_dual": 110}
 
 
 def wsos_spec(use_dual):

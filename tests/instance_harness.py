@@ -46,6 +46,8 @@ def build_solve_check(solver, model, inst, tol=TEST_TOL):
             assert approx(x[i], v, tol)
     if "x_norm" in expect:
         assert approx(np.linalg.norm(x), expect["x_norm"], tol)
+    if "y" in expect:
+        assert approx(y, expect["y"], tol), y
     if "s" in expect:
         assert approx(s, expect["s"], tol), s
     if "z" in expect:

@@ -410,3 +410,79 @@ def test_hyporootdettri_vs_oracle(side, use_dual):
         c.load_dual_point(bdual)
         assert not c.is_feas()
         assert not c.is_dual_feas()
+
+
+# ---------------------------------------------------------------------------------------------
+# HypoPerLogdetTri
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("side", [1, 2, 4])
+def test_hypoperlogdettri_identities(side):   # test/cone.jl:648-651
+    import hypatia_jl_amd as H
+    run_test_oracles(H.HypoPerLogdetTri(2 + side * (side + 1) // 2), init_tol=1e-4)
+
+
+@pytest.mark.parametrize("side", [8, 12])
+def test_hypoperlogdettri_initial_point(side):   # test/cone.jl:652-654
+    import hypatia_jl_amd as H
+    run_test_oracles(H.HypoPerLogdetTri(2 + side * (side + 1) // 2), init_tol=1e-1, init_only=True)
+
+
+@pytest.mark.parametrize("side,use_dual", [(2, False), (9, False), (9, True), (60, False)])
+def test_hypoperlogdettri_vs_oracle(side, use_dual):
+    import hypatia_jl_amd as H
+    from oracle import cones as oc
+    dim = 2 + side * (side + 1) // 2
+    hc, occ = H.HypoPerLogdetTri(dim, use_dual=use_dual), oc.HypoPerLogdetTri(dim, use_dual=use_dual)
+    assert hc.get_nu() == occ.get_nu() == 2 + side and hc.use_dual_barrier() == occ.use_dual_barrier() == use_dual
+    rng = np.random.default_rng(side)
+    pt, pt2 = np.zeros(dim), np.ones(dim)
+    occ.set_initial_point(pt)
+    hc.set_initial_point(pt2)
+    assert np.array_equal(pt, pt2)
+    for c in (hc, occ):
+        c.setup_data()
+        c.reset_data()
+        c.load_point(pt, 1.0)
+        assert c.is_feas()
+    dual = -np.array(occ.get_grad())
+    pt = pt + 0.05 / side * (2 * rng.random(dim) - 1)
+    dual = dual + 0.02 / side * (2 * rng.random(dim) - 1)
+    for c in (hc, occ):
+        c.reset_data()
+        c.load_point(pt, 0.9)
+        c.load_dual_point(dual)
+        assert c.is_feas() and c.is_dual_feas()
+    assert rel(np.array(hc.get_grad()), np.array(occ.get_grad())) < 1e-11
+    for ncols in (1, 6):
+        V = np.asfortranarray(rng.standard_normal((dim, ncols)))
+        for name in ("hess_prod", "inv_hess_prod", "hess_prod_slow"):
+            Ph, Po = np.zeros((dim, ncols), order="F"), np.zeros((dim, ncols), order="F")
+            getattr(hc, name)(Ph, V)
+            getattr(occ, name)(Po, V)
+            assert rel(Ph, Po) < 1e-10, (name, ncols)
+    T, R = np.zeros((dim, 3), order="F"), np.zeros((dim, 3), order="F")
+    V = np.asfortranarray(rng.standard_normal((dim, 3)))
+    hc.hess_prod(T, V)
+    hc.inv_hess_prod(R, T)
+    assert rel(R, V) < 1e-9
+    assert hc.use_sqrt_hess_oracles(dim) == occ.use_sqrt_hess_oracles(dim) == True
+    for name in ("sqrt_hess_prod", "inv_sqrt_hess_prod"):
+        Ph, Po = np.zeros((dim, 3), order="F"), np.zeros((dim, 3), order="F")
+        getattr(hc, name)(Ph, V)
+        getattr(occ, name)(Po, V)
+        assert rel(Ph, Po) < 1e-8, name
+    dv = V[:, 0].copy() * 0.05
+    assert rel(np.array(hc.dder3(dv)), np.array(occ.dder3(dv))) < 1e-10
+    assert hc.check_numerics() == occ.check_numerics()
+    ph, po = hc.get_proxsqr(0.9, True), occ.get_proxsqr(0.9, True)
+    assert abs(ph - po) <= 1e-7 * max(1.0, abs(po))
+    for bad_idx, bad_val, bdual0 in ((0, 100.0, 0.5), (1, -1.0, 0.0)):   # u too large / v negative; dual u >= 0
+        bad, bdual = pt.copy(), dual.copy()
+        bad[bad_idx] = bad_val
+        bdual[0] = bdual0
+        for c in (hc, occ):
+            c.reset_data()
+            c.load_point(bad, 1.0)
+            c.load_dual_point(bdual)
+            assert not c.is_feas()
+            assert not c.is_dual_feas()

@@ -131,3 +131,23 @@ def test_hyporootdettri_barrier():   # test/cone.jl:612-620
         logdet = np.linalg.slogdet(_smat_full(s[1:], side))[1]
         return -np.log(np.exp(logdet / side) - s[0]) - logdet
     run_test_barrier(oc.HypoRootdetTri(1 + au.svec_length(side)), barrier)
+
+
+@pytest.mark.parametrize("side", [1, 2, 4])
+def test_hypoperlogdettri_oracles(side):   # test/cone.jl:648-655
+    run_test_oracles(oc.HypoPerLogdetTri(2 + au.svec_length(side)), init_tol=1e-4)
+
+
+@pytest.mark.parametrize("side", [8, 12])
+def test_hypoperlogdettri_initial_point(side):
+    run_test_oracles(oc.HypoPerLogdetTri(2 + au.svec_length(side)), init_tol=1e-1, init_only=True)
+
+
+def test_hypoperlogdettri_barrier():   # test/cone.jl:657-665
+    side = 3
+
+    def barrier(s):
+        u, v = s[0], s[1]
+        W = _smat_full(s[2:], side)
+        return -np.log(v * np.linalg.slogdet(W / v)[1] - u) - np.log(v) - np.linalg.slogdet(W)[1]
+    run_test_barrier(oc.HypoPerLogdetTri(2 + au.svec_length(side)), barrier)
