@@ -11,6 +11,6 @@ without the HIP library and a GPU raises.
 from . import _lib            # noqa: F401
 from .cones import Nonnegative, PosSemidefTri, EpiNormSpectral, WSOSInterpNonnegative, LinMatrixIneq, DoublyNonnegativeTri, HypoRootdetTri, HypoPerLogdetTri, Cone   # noqa: F401
 from .models import Model                                    # noqa: F401
-from .systemsolvers import QRCholDenseSystemSolver           # noqa: F401
+from .systemsolvers import QRCholDenseSystemSolver, SymIndefDenseSystemSolver   # noqa: F401
 from .solvers import Solver, CombinedStepper, StepSearcher, Point   # noqa: F401
 from .build import make_cone, make_model                     # noqa: F401

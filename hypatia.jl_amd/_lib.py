@@ -64,6 +64,13 @@ SIGNATURES = {
     "hyp_sys_create": [c_vp, c_int, c_int, c_int, P(c_vp), c_int, P(c_vp)],
     "hyp_sys_destroy": [c_vp],
     "hyp_sys_load": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "hyp_symindef_create": [c_vp, c_int, c_int, c_int, P(c_vp), c_int, P(c_vp)],
+    "hyp_symindef_destroy": [c_vp],
+    "hyp_symindef_load": [c_vp, c_vp, c_vp],
+    "hyp_symindef_update_lhs": [c_vp, P(c_int), P(c_int)],
+    "hyp_symindef_solve3": [c_vp, c_vp, c_vp],
+    "hyp_symindef_mul_G": [c_vp, c_int, c_dbl, c_vp, c_dbl, c_vp],
+    "hyp_symindef_get_lhs": [c_vp, c_vp],
     "hyp_sys_update_lhs_fact": [c_vp, P(c_int), P(c_int), P(c_int)],
     "hyp_sys_solve3": [c_vp, c_vp, c_vp],
     "hyp_sys_get_directions2": [c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int, c_dbl, c_dbl, P(c_dbl), P(c_int)],

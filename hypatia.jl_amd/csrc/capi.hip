@@ -11,6 +11,7 @@ using namespace hyp;
 struct hyp_ctx { Ctx c; hyp_ctx(int d) : c(d) {} };
 struct hyp_cone { hyp_ctx* ctx; Cone* cone; };
 struct hyp_sys { hyp_ctx* ctx; SysSolver* s; };
+struct hyp_symindef { hyp_ctx* ctx; SymIndefSys* s; };
 
 static thread_local std::string g_last_error;
 
@@ -328,6 +329,64 @@ int hyp_sys_destroy(hyp_sys* sys) {
     delete sys;
   }
   API_END(ctx)
+}
+int hyp_symindef_create(hyp_ctx* ctx, int n, int p, int q, hyp_cone* const* cones, int ncones, hyp_symindef** out) {
+  API_BEGIN
+  std::vector<Cone*> cs;
+  for (int k = 0; k < ncones; ++k) {
+    HYP_REQUIRE(cones[k] && cones[k]->ctx == ctx, "symindef: cone belongs to another context");
+    cs.push_back(cones[k]->cone);
+  }
+  *out = new hyp_symindef{ctx, new SymIndefSys(ctx->c, n, p, q, cs)};
+  ctx->c.sync();
+  API_END(ctx)
+}
+int hyp_symindef_destroy(hyp_symindef* sys) {
+  hyp_ctx* ctx = sys ? sys->ctx : nullptr;
+  API_BEGIN
+  if (sys) {
+    ctx->c.sync();
+    delete sys->s;
+    delete sys;
+  }
+  API_END(ctx)
+}
+int hyp_symindef_load(hyp_symindef* sys, const double* A, const double* G) {
+  API_BEGIN
+  sys->s->load(A, G);
+  API_END(sys->ctx)
+}
+int hyp_symindef_update_lhs(hyp_symindef* sys, int* info, int* used_fallback) {
+  API_BEGIN
+  sys->s->update_lhs(info, used_fallback);
+  API_END(sys->ctx)
+}
+int hyp_symindef_solve3(hyp_symindef* sys, double* sol_vec, const double* rhs_vec) {
+  API_BEGIN
+  sys->s->solve3(sol_vec, rhs_vec);
+  API_END(sys->ctx)
+}
+int hyp_symindef_mul_G(hyp_symindef* sys, int trans, double alpha, const double* x, double beta, double* y) {
+  API_BEGIN
+  Ctx& c = sys->ctx->c;
+  SymIndefSys* s = sys->s;
+  const int nx = trans ? s->q : s->n, ny = trans ? s->n : s->q;
+  double* dx = stage_in(c, c.stage_a, x, nx);
+  c.stage_b.ensure(std::max<size_t>(ny, 1) * sizeof(double));
+  if (beta != 0.0) c.h2d(c.stage_b.p, y, (size_t)ny * sizeof(double));
+  // G' sits in the x-rows / z-columns block of the left-hand side (n x q, leading dimension npq): op(G) = op'(G')
+  const double* Gt = s->lhs.d() + (long)(s->n + s->p) * s->npq;
+  gemv(c, trans == 0, s->n, s->q, alpha, Gt, s->npq, dx, beta, c.stage_b.d());
+  c.d2h(y, c.stage_b.p, (size_t)ny * sizeof(double));
+  c.sync();
+  API_END(sys->ctx)
+}
+int hyp_symindef_get_lhs(hyp_symindef* sys, double* out) {
+  API_BEGIN
+  Ctx& c = sys->ctx->c;
+  c.d2h(out, sys->s->lhs.p, (size_t)sys->s->npq * sys->s->npq * sizeof(double));
+  c.sync();
+  API_END(sys->ctx)
 }
 int hyp_sys_load(hyp_sys* sys, const double* G, const double* GQ1, const double* GQ2, const double* Q, const double* R) {
   API_BEGIN

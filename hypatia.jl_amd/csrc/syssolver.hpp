@@ -110,4 +110,21 @@ struct SysSolver {
                         double min_impr_tol, int* n_solves);
 };
 
+// Device-resident SymIndefDenseSystemSolver (symindef.jl:203-271): see symindef.hip
+struct SymIndefSys {
+  Ctx& ctx;
+  int n, p, q, npq;
+  std::vector<Cone*> cones;
+  std::vector<int> offs;
+  DBuf lhs;      // npq x npq, upper triangle: [0 A' G'; . 0 0; . . -M]
+  DBuf fact, dinv, xb;
+  BKFact bk;
+  TriSolvePlan tri;
+  bool fact_ok = false;
+  SymIndefSys(Ctx& c, int n_, int p_, int q_, const std::vector<Cone*>& cs);
+  void load(const double* hA, const double* hG);                 // :222-240 (host pointers, col-major p x n and q x n)
+  void update_lhs(int* info, int* used_fallback);                // :242-262 without the constant-column solve
+  void solve3(double* h_sol, const double* h_rhs);               // :264-271
+};
+
 }  // namespace hyp

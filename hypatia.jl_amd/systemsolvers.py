@@ -274,3 +274,92 @@ class QRCholDenseSystemSolver:
         out = np.zeros((nmp, nmp), order="F")
         L.check(L.lib().hyp_sys_get_lhs(self._h, out.ctypes.data_as(c_vp)), "hyp_sys_get_lhs")
         return out
+
+
+class SymIndefDenseSystemSolver:
+    """SymIndefDenseSystemSolver on the MI355X (symindef.jl:1-56, 203-271): the 3x3 symmetric indefinite form of the Newton
+    system, Bunch-Kaufman (rook) on the device.  `load`, `update_lhs`, `solve_subsystem3` forward to hyp_symindef_*; the
+    right-hand side set-up and the shared 6 -> 4 -> 3 reductions stay on the host as in the reference.  Use with
+    `Solver(reduce=False, ...)` (the reference's option sets for it, test/runnativetests.jl:80-86, 101-118)."""
+
+    native_directions = False     # directions / line search are composed on the host from the per-call entry points
+
+    def __init__(self):
+        self._h = None
+
+    def __del__(self):
+        try:
+            if self._h is not None and L._lib is not None:
+                L._lib.hyp_symindef_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def load(self, solver):   # :222-240
+        model = solver.model
+        n, p, q = model.n, model.p, model.q
+        lib = L.lib()
+        if self._h is not None:
+            lib.hyp_symindef_destroy(self._h)
+            self._h = None
+        handles = (c_vp * len(model.cones))(*[cone._h for cone in model.cones])
+        h = c_vp()
+        L.check(lib.hyp_symindef_create(L.ctx(), n, p, q, handles, len(model.cones), ctypes.byref(h)), "hyp_symindef_create")
+        self._h = h
+        self.n, self.p, self.q = n, p, q
+        A = np.asfortranarray(model.A, dtype=np.float64) if p > 0 else None
+        G = np.asfortranarray(model.G, dtype=np.float64)
+        L.check(lib.hyp_symindef_load(h, A.ctypes.data_as(c_vp) if A is not None else None, G.ctypes.data_as(c_vp)), "hyp_symindef_load")
+        # setup_point_sub (common.jl:184-208)
+        self.sol_sub = SubPoint(model)
+        self.rhs_sub = SubPoint(model)
+        self.rhs_const = SubPoint(model)
+        self.sol_const = SubPoint(model)
+        self.rhs_const.x[:] = -model.c
+        self.rhs_const.y[:] = model.b
+        self.rhs_const.z[:] = model.h
+        self.last_info, self.used_fallback = 0, False
+        return self
+
+    def mul_G(self, trans, x, alpha=1.0, beta=0.0, y=None):
+        xx = np.ascontiguousarray(x, dtype=np.float64)
+        ny = self.n if trans else self.q
+        if y is None:
+            y = np.zeros(ny)
+        L.check(L.lib().hyp_symindef_mul_G(self._h, int(trans), float(alpha), L.vec_ptr(xx), float(beta), L.vec_ptr(y)), "hyp_symindef_mul_G")
+        return y
+
+    def update_lhs(self, solver):   # :242-262
+        info, fb = c_int(0), c_int(0)
+        t0 = time.perf_counter()
+        L.check(L.lib().hyp_symindef_update_lhs(self._h, ctypes.byref(info), ctypes.byref(fb)), "hyp_symindef_update_lhs")
+        solver.time_upfact += time.perf_counter() - t0
+        self.last_info, self.used_fallback = info.value, bool(fb.value)
+        if info.value != 0:
+            print("symmetric linear system factorization failed")
+        self.solve_subsystem3(solver, self.sol_const, self.rhs_const)
+        return self
+
+    def solve_subsystem3(self, solver, sol, rhs):   # :264-271
+        L.check(L.lib().hyp_symindef_solve3(self._h, L.vec_ptr(sol.vec), L.vec_ptr(rhs.vec)), "hyp_symindef_solve3")
+        return sol
+
+    def setup_rhs3(self, model, rhs, sol, rhs_sub):   # :33-56
+        for k, cone_k in enumerate(model.cones):
+            rhs_z_k = rhs.z_views[k]
+            rhs_s_k = rhs.s_views[k]
+            rhs_sub_z_k = rhs_sub.z_views[k]
+            if cone_k.use_dual_barrier():
+                rhs_sub_z_k[:] = -rhs_z_k - rhs_s_k
+            else:
+                cone_k.inv_hess_prod(rhs_sub_z_k, rhs_s_k)
+                rhs_sub_z_k[:] = -rhs_z_k - rhs_sub_z_k
+
+    solve_system = QRCholDenseSystemSolver.solve_system              # common.jl:129-144
+    solve_subsystem4 = QRCholDenseSystemSolver.solve_subsystem4      # common.jl:146-182
+
+    def get_lhs(self):
+        npq = self.n + self.p + self.q
+        out = np.zeros((npq, npq), order="F")
+        L.check(L.lib().hyp_symindef_get_lhs(self._h, out.ctypes.data_as(c_vp)), "hyp_symindef_get_lhs")
+        return out

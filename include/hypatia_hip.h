@@ -96,6 +96,26 @@ int hyp_cone_inv_hess(hyp_cone* cone, double* out_dimxdim);
 /* cones[k] occupies rows sum(dim[0..k-1]) .. of z / s (Models.jl:54-66 cone_idxs) */
 int hyp_sys_create(hyp_ctx* ctx, int n, int p, int q, hyp_cone* const* cones, int ncones, hyp_sys** out);
 int hyp_sys_destroy(hyp_sys* sys);
+
+/* ---- SymIndefDenseSystemSolver (src/Solvers/systemsolvers/symindef.jl:203-271): the 3x3 symmetric indefinite form
+ * [0 A' G'; A 0 0; G 0 -M], M_k = inv_hess(cone_k) for a primal-barrier cone and hess(cone_k) for a dual-barrier one (at
+ * the cones' currently loaded, scaled points: :247-252), factored by Bunch-Kaufman with rook pivoting (symm_fact_copy!,
+ * src/linearalgebra/dense.jl:170-184).  No preprocessing of A is needed.  The Julia subtype keeps setup_rhs3
+ * (symindef.jl:33-56) and the shared 6 -> 4 -> 3 reductions on the host and calls: */
+typedef struct hyp_symindef hyp_symindef;
+int hyp_symindef_create(hyp_ctx* ctx, int n, int p, int q, hyp_cone* const* cones, int ncones, hyp_symindef** out);
+int hyp_symindef_destroy(hyp_symindef* sys);
+/* load (:222-240): A is p x n (NULL when p == 0), G is q x n, both column-major; copied to the device */
+int hyp_symindef_load(hyp_symindef* sys, const double* A, const double* G);
+/* update_lhs (:242-257) without the constant-column solve: z-blocks from the cones, then symm_fact_copy!.
+ * used_fallback = 1 when the first factorization met an exactly singular pivot and increase_diag! was applied;
+ * info = 0 <=> issuccess(fact) */
+int hyp_symindef_update_lhs(hyp_symindef* sys, int* info, int* used_fallback);
+/* solve_subsystem3 (:264-271): sol.vec = fact \ rhs.vec, vectors [x(n); y(p); z(q)] */
+int hyp_symindef_solve3(hyp_symindef* sys, double* sol_vec, const double* rhs_vec);
+/* y = alpha * op(G) x + beta * y on the device-resident G (trans != 0: op(G) = G'), for the residuals the driver computes */
+int hyp_symindef_mul_G(hyp_symindef* sys, int trans, double alpha, const double* x, double beta, double* y);
+int hyp_symindef_get_lhs(hyp_symindef* sys, double* out_npqxnpq);   /* upper triangle meaningful (tests) */
 /* load (qrchol.jl:138-179): G = model.G (q x n).  When p == 0 pass NULL for GQ1, GQ2, Q, R (GQ2 = G,
  * Ap_Q = I).  Otherwise GQ1 = (G*Ap_Q)[:, 1:p], GQ2 = (G*Ap_Q)[:, p+1:n], Q = Ap_Q (n x n), R = Ap_R (p x p). */
 int hyp_sys_load(hyp_sys* sys, const double* G, const double* GQ1, const double* GQ2, const double* Q, const double* R);

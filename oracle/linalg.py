@@ -281,6 +281,17 @@ def posdef_fact_copy(mat, try_shift=True):
     return fact
 
 
+def symm_fact_copy(mat):
+    """dense.jl:170-184: Bunch-Kaufman (rook) of Symmetric(mat, :U); on failure increase_diag! and again."""
+    full = np.triu(mat) + np.triu(mat, 1).T
+    fact = bk_rook(full)
+    if not fact.success:
+        full = np.triu(mat) + np.triu(mat, 1).T
+        increase_diag(full)
+        fact = bk_rook(full)
+    return fact
+
+
 def inv_fact_chol(fact):
     """inv_fact!(mat, fact::Cholesky) = potri: upper triangle of the inverse (dense.jl:15-22)."""
     inv, info = lapack.dpotri(fact.factors, lower=0)

@@ -124,7 +124,96 @@ def block_hess_prod(prod_k, arr_k, cone_k):   # qrchol.jl:87-98
         cone_k.hess_prod(prod_k, arr_k)
 
 
-class QRCholDenseSystemSolver:
+class _SystemSolverCommon:
+    """systemsolvers/common.jl:129-208: the 6 -> 4 -> 3 reductions shared by the system solvers."""
+
+    def setup_point_sub(self, model):   # common.jl:184-208
+        self.sol_sub = SubPoint(model)
+        self.rhs_sub = SubPoint(model)
+        self.rhs_const = SubPoint(model)
+        self.sol_const = SubPoint(model)
+        self.rhs_const.x[:] = -model.c
+        self.rhs_const.y[:] = model.b
+        self.rhs_const.z[:] = model.h
+
+    def solve_system(self, solver, sol, rhs):   # common.jl:129-144
+        model = solver.model
+        self.solve_subsystem4(solver, sol, rhs)
+        tau = sol.tau
+        sol.s[:] = model.h * tau - rhs.z - model.G @ sol.x
+        taubar = solver.point.tau
+        sol.kap = -solver.mu / taubar / taubar * tau + rhs.kap
+        return sol
+
+    def solve_subsystem4(self, solver, sol, rhs):   # common.jl:146-182
+        model = solver.model
+        rhs_sub, sol_sub = self.rhs_sub, self.sol_sub
+        rhs_sub.x[:] = rhs.x
+        rhs_sub.y[:] = -rhs.y
+        self.setup_rhs3(model, rhs, sol, rhs_sub)
+        self.solve_subsystem3(solver, sol_sub, rhs_sub)
+        sol_const = self.sol_const
+        tau_num = rhs.tau + rhs.kap + dot_obj(model, sol_sub)
+        taubar = solver.point.tau
+        tau_denom = solver.mu / taubar / taubar - dot_obj(model, sol_const)
+        sol_tau = tau_num / tau_denom
+        dim3 = sol_sub.vec.shape[0]
+        sol.vec[:dim3] = sol_sub.vec + sol_tau * sol_const.vec
+        sol.tau = sol_tau
+        return sol
+
+
+class SymIndefDenseSystemSolver(_SystemSolverCommon):
+    """symindef.jl:1-56 (the 3x3 symmetric indefinite form and its right-hand side) and :203-271 (dense):
+    [0 A' G'; A 0 0; G 0 -M] with M_k = (mu H_k)^-1 for a primal barrier and mu H_k for a dual one,
+    factored by Bunch-Kaufman (symm_fact_copy!, dense.jl:170-184)."""
+
+    def load(self, solver):   # :222-240
+        model = solver.model
+        n, p, q = model.n, model.p, model.q
+        npq = n + p + q
+        lhs = np.zeros((npq, npq), order="F")
+        lhs[:n, n:n + p] = model.A.T        # (the reference fills the lower triangle; stored upper here)
+        lhs[:n, n + p:] = model.G.T
+        self.lhs_sub = lhs
+        self.fact = None
+        self.setup_point_sub(model)
+        return self
+
+    def update_lhs(self, solver):   # :242-262
+        model = solver.model
+        z0 = model.n + model.p
+        lhs = self.lhs_sub
+        for cone_k, idxs in zip(model.cones, model.cone_idxs):
+            H = cone_k.hess() if cone_k.use_dual_barrier() else cone_k.inv_hess()
+            Hs = np.triu(H) + np.triu(H, 1).T
+            rows = slice(z0 + idxs.start, z0 + idxs.stop)
+            lhs[rows, rows] = -Hs
+        t0 = time.perf_counter()
+        self.fact = la.symm_fact_copy(lhs)
+        solver.time_upfact += time.perf_counter() - t0
+        if not self.fact.success:
+            print("symmetric linear system factorization failed")
+        self.solve_subsystem3(solver, self.sol_const, self.rhs_const)
+        return self
+
+    def setup_rhs3(self, model, rhs, sol, rhs_sub):   # :33-56
+        for k, cone_k in enumerate(model.cones):
+            rhs_z_k = rhs.z_views[k]
+            rhs_s_k = rhs.s_views[k]
+            rhs_sub_z_k = rhs_sub.z_views[k]
+            if cone_k.use_dual_barrier():
+                rhs_sub_z_k[:] = -rhs_z_k - rhs_s_k
+            else:
+                cone_k.inv_hess_prod(rhs_sub_z_k, rhs_s_k)
+                rhs_sub_z_k[:] = -rhs_z_k - rhs_sub_z_k
+
+    def solve_subsystem3(self, solver, sol, rhs):   # :264-271
+        sol.vec[:] = self.fact.solve(rhs.vec)
+        return sol
+
+
+class QRCholDenseSystemSolver(_SystemSolverCommon):
     """qrchol.jl:104-257."""
 
     def load(self, solver):   # :138-179
@@ -253,33 +342,6 @@ class QRCholDenseSystemSolver:
         if p != 0:
             y[:] = self.Q1pbxGHbz - self.GQ1.T @ self.HGx
             y[:] = sla.solve_triangular(solver.Ap_R, y, lower=False)
-        return sol
-
-    # ---- systemsolvers/common.jl:129-182 (shared 6 -> 4 -> 3 reductions)
-    def solve_system(self, solver, sol, rhs):
-        model = solver.model
-        self.solve_subsystem4(solver, sol, rhs)
-        tau = sol.tau
-        sol.s[:] = model.h * tau - rhs.z - model.G @ sol.x
-        taubar = solver.point.tau
-        sol.kap = -solver.mu / taubar / taubar * tau + rhs.kap
-        return sol
-
-    def solve_subsystem4(self, solver, sol, rhs):
-        model = solver.model
-        rhs_sub, sol_sub = self.rhs_sub, self.sol_sub
-        rhs_sub.x[:] = rhs.x
-        rhs_sub.y[:] = -rhs.y
-        self.setup_rhs3(model, rhs, sol, rhs_sub)
-        self.solve_subsystem3(solver, sol_sub, rhs_sub)
-        sol_const = self.sol_const
-        tau_num = rhs.tau + rhs.kap + dot_obj(model, sol_sub)
-        taubar = solver.point.tau
-        tau_denom = solver.mu / taubar / taubar - dot_obj(model, sol_const)
-        sol_tau = tau_num / tau_denom
-        dim3 = sol_sub.vec.shape[0]
-        sol.vec[:dim3] = sol_sub.vec + sol_tau * sol_const.vec
-        sol.tau = sol_tau
         return sol
 
 

@@ -255,3 +255,43 @@ def test_native_search_alpha_matches_host_walk():
             break
     assert a_native == a_host and a_native > 0
     assert abs(prox_native - st.searcher.prox) <= 1e-9 * (1 + prox_native)
+
+
+# ---------------------------------------------------------------------------------------------
+# SymIndefDenseSystemSolver: the 3x3 symmetric indefinite form, Bunch-Kaufman on the device
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(_instances()))
+@pytest.mark.parametrize("preprocess", [True, False])
+def test_known_answer_hip_symindef(name, preprocess):
+    """the reference's option sets for this solver: test/runnativetests.jl:80-86 (no preprocessing) and :101-118
+    (reduce = false)"""
+    import hypatia_jl_amd as H
+    from oracle import instances as I
+    if not preprocess and name in ("dimension1",):
+        pytest.skip("needs preprocessing (dependent equalities)")
+    inst = I.KNOWN_ANSWER[name]()
+    solver = H.Solver(default_tol_relax=10, reduce=False, preprocess=preprocess, syssolver=H.SymIndefDenseSystemSolver())
+    build_solve_check(solver, H.make_model(inst), inst)
+
+
+def test_symindef_matches_oracle_and_qrchol():
+    """left-hand side and first iterate against the oracle's SymIndefDense; same optimum as the QRChol path"""
+    import hypatia_jl_amd as H
+    from oracle import instances as I
+    from oracle.build import make_model as omodel
+    from oracle.solvers import Solver as OSolver, SymIndefDenseSystemSolver as OSym
+    inst = I.psd_blocks(40, [9, 6], seed=5)
+    hs = H.Solver(iter_limit=1, reduce=False, syssolver=H.SymIndefDenseSystemSolver())
+    hs.load(H.make_model(inst)); hs.solve()
+    os_ = OSolver(iter_limit=1, reduce=False, syssolver=OSym())
+    os_.load(omodel(inst)); os_.solve()
+    Lh, Lo = np.triu(hs.syssolver.get_lhs()), np.triu(os_.syssolver.lhs_sub)
+    assert np.linalg.norm(Lh - Lo) / np.linalg.norm(Lo) < 1e-11
+    assert np.linalg.norm(hs.point.vec - os_.point.vec) / np.linalg.norm(os_.point.vec) < 1e-8
+    full = H.Solver(reduce=False, syssolver=H.SymIndefDenseSystemSolver())
+    full.load(H.make_model(inst)); full.solve()
+    ref = H.Solver()
+    ref.load(H.make_model(inst)); ref.solve()
+    assert full.status == ref.status == "Optimal"
+    assert abs(full.primal_obj - ref.primal_obj) <= 1e-7 * (1 + abs(ref.primal_obj))
+    assert np.allclose(full.get_x(), ref.get_x(), rtol=1e-5, atol=1e-7)

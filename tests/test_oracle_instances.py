@@ -18,6 +18,20 @@ def test_known_answer(name, reduce):
     build_solve_check(solver, make_model(inst), inst)
 
 
+@pytest.mark.parametrize("name", sorted(inst_mod.KNOWN_ANSWER))
+@pytest.mark.parametrize("preprocess", [True, False])
+def test_known_answer_symindef(name, preprocess):
+    """SymIndefDenseSystemSolver (symindef.jl:203-271) with the option sets of test/runnativetests.jl:80-86 (no
+    preprocessing) and :101-118 (reduce = false): an independent factorization (Bunch-Kaufman of the 3x3 system) of the
+    same Newton systems."""
+    from oracle.solvers import SymIndefDenseSystemSolver
+    inst = inst_mod.KNOWN_ANSWER[name]()
+    if not preprocess and name in ("dimension1",):
+        pytest.skip("needs preprocessing (dependent equalities, test/runnativetests.jl inst_preproc)")
+    solver = Solver(default_tol_relax=10, reduce=False, preprocess=preprocess, syssolver=SymIndefDenseSystemSolver())
+    build_solve_check(solver, make_model(inst), inst)
+
+
 def test_linearopt_config1():
     inst = inst_mod.linearopt(50, 100, seed=1)
     s = build_solve_check(Solver(default_tol_relax=10), make_model(inst), inst)
