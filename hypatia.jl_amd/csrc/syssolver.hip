@@ -47,10 +47,23 @@ void SysSolver::load(const double* hG, const double* hGQ1, const double* hGQ2, c
   const size_t d = sizeof(double);
   ctx.h2d(G.p, hG, (size_t)q * n * d);
   if (p > 0) {
-    HYP_REQUIRE(hGQ1 && hGQ2 && hQ && hR, "sys: GQ1, GQ2, Q, R are required when p > 0");
-    ctx.h2d(GQ1.p, hGQ1, (size_t)q * p * d);
-    ctx.h2d(GQ2s.p, hGQ2, (size_t)q * nmp * d);
+    HYP_REQUIRE(hQ && hR, "sys: Q, R are required when p > 0");
+    HYP_REQUIRE((hGQ1 == nullptr) == (hGQ2 == nullptr), "sys: pass both GQ1 and GQ2, or neither");
     ctx.h2d(Qm.p, hQ, (size_t)n * n * d);
+    if (hGQ1) {
+      ctx.h2d(GQ1.p, hGQ1, (size_t)q * p * d);
+      ctx.h2d(GQ2s.p, hGQ2, (size_t)q * nmp * d);
+    } else {   // GQ = G * Ap_Q on the device (qrchol.jl:154), split into its first p and last n - p columns
+      GemmArgs g1{};
+      g1.M = q; g1.N = p; g1.K = n; g1.A = G.d(); g1.lda = q; g1.B = Qm.d(); g1.ldb = n; g1.C = GQ1.d(); g1.ldc = q;
+      g1.alpha = 1; g1.beta = 0; g1.batch = 1;
+      gemm(ctx, false, g1);
+      if (nmp > 0) {
+        GemmArgs g2 = g1;
+        g2.N = nmp; g2.B = Qm.d() + (long)p * n; g2.C = GQ2s.d();
+        gemm(ctx, false, g2);
+      }
+    }
     // inverse of the p x p upper triangular Ap_R, once per solve (setup, not on the iteration path)
     std::vector<double> ri((size_t)p * p, 0.0);
     for (int j = 0; j < p; ++j) {

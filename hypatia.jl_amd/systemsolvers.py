@@ -62,13 +62,9 @@ class QRCholDenseSystemSolver:
         if p == 0:
             L.check(lib.hyp_sys_load(h, G.ctypes.data_as(c_vp), None, None, None, None), "hyp_sys_load")
         else:
-            GQ = model.G @ solver.Ap_Q            # qrchol.jl:154 (once per solve, host)
-            GQ1 = np.asfortranarray(GQ[:, :p])
-            GQ2 = np.asfortranarray(GQ[:, p:])
-            Q = np.asfortranarray(solver.Ap_Q)
+            Q = np.asfortranarray(solver.Ap_Q)    # G * Ap_Q (qrchol.jl:154) is formed on the device
             R = np.asfortranarray(solver.Ap_R)
-            L.check(lib.hyp_sys_load(h, G.ctypes.data_as(c_vp), GQ1.ctypes.data_as(c_vp), GQ2.ctypes.data_as(c_vp),
-                                     Q.ctypes.data_as(c_vp), R.ctypes.data_as(c_vp)), "hyp_sys_load")
+            L.check(lib.hyp_sys_load(h, G.ctypes.data_as(c_vp), None, None, Q.ctypes.data_as(c_vp), R.ctypes.data_as(c_vp)), "hyp_sys_load")
         self.use_sqrt_hess_cones = [False] * len(model.cones)
         # setup_point_sub (common.jl:184-208)
         self.sol_sub = SubPoint(model)

@@ -117,7 +117,8 @@ int hyp_symindef_solve3(hyp_symindef* sys, double* sol_vec, const double* rhs_ve
 int hyp_symindef_mul_G(hyp_symindef* sys, int trans, double alpha, const double* x, double beta, double* y);
 int hyp_symindef_get_lhs(hyp_symindef* sys, double* out_npqxnpq);   /* upper triangle meaningful (tests) */
 /* load (qrchol.jl:138-179): G = model.G (q x n).  When p == 0 pass NULL for GQ1, GQ2, Q, R (GQ2 = G,
- * Ap_Q = I).  Otherwise GQ1 = (G*Ap_Q)[:, 1:p], GQ2 = (G*Ap_Q)[:, p+1:n], Q = Ap_Q (n x n), R = Ap_R (p x p). */
+ * Ap_Q = I).  Otherwise Q = Ap_Q (n x n), R = Ap_R (p x p), and either GQ1 = (G*Ap_Q)[:, 1:p], GQ2 = (G*Ap_Q)[:, p+1:n]
+ * or NULL for both: the product G*Ap_Q of qrchol.jl:154 is then formed on the device. */
 int hyp_sys_load(hyp_sys* sys, const double* G, const double* GQ1, const double* GQ2, const double* Q, const double* R);
 /* update_lhs_fact (qrchol.jl:201-257): Schur assembly + posdef_fact_copy! (src/linearalgebra/dense.jl:194-215).
  * use_sqrt_out[ncones] receives use_sqrt_hess_cones.  used_fallback names the link of the chain that produced the
