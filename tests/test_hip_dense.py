@@ -127,3 +127,32 @@ def test_syrk_schur_path_with_splitk(hip, N, K):
     C2 = np.full((N, N), 3.0, order="F")
     L.check(lib.hyp_dense_syrk(ctx, N, K, fp(A), K, fp(C2), N), "syrk")
     assert np.array_equal(C, C2)
+
+
+def test_two_contexts_are_independent(hip):
+    """distinct contexts must be independent.  Two contexts on the same device run the split-K Schur syrk and
+    the rook solve alternately (each owns its split-K workspace, tile order and streams) and agree with numpy."""
+    lib, ctx1, L = hip
+    h2 = c_vp()
+    assert lib.hyp_ctx_create(0, ctypes.byref(h2)) == 0
+    try:
+        rng = np.random.default_rng(11)
+        n, q = 1100, 4200
+        A1 = np.asfortranarray(rng.standard_normal((q, n)))
+        A2 = np.asfortranarray(rng.standard_normal((q, n)))
+        C1, C2 = np.zeros((n, n), order="F"), np.zeros((n, n), order="F")
+        for _ in range(2):
+            L.check(lib.hyp_dense_syrk(ctx1, n, q, fp(A1), q, fp(C1), n), "syrk ctx1")
+            L.check(lib.hyp_dense_syrk(h2, n, q, fp(A2), q, fp(C2), n), "syrk ctx2")
+        iu = np.triu_indices(n)
+        assert np.allclose(C1[iu], (A1.T @ A1)[iu], rtol=1e-12, atol=1e-10)
+        assert np.allclose(C2[iu], (A2.T @ A2)[iu], rtol=1e-12, atol=1e-10)
+        M = rng.standard_normal((300, 300))
+        S = np.asfortranarray(M + M.T)
+        b = rng.standard_normal(300)
+        for c in (ctx1, h2):
+            Sd, x, info = S.copy(order="F"), b.copy(), c_int(-1)
+            L.check(lib.hyp_dense_sysv_rook(c, 300, fp(Sd), 300, fp(x), 1, 300, ctypes.byref(info), None, None, None, None), "sysv")
+            assert info.value == 0 and np.linalg.norm(S @ x - b) <= 1e-10 * np.linalg.norm(b) * np.linalg.cond(S)
+    finally:
+        assert lib.hyp_ctx_destroy(h2) == 0
