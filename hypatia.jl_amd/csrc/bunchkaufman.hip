@@ -9,17 +9,25 @@
 //
 //     P A P' = U' D U,   U unit upper triangular,  D block diagonal,
 //
-// eliminating forwards (k = 0, 1, ...) on the upper triangle in place, so that the existing blocked
+// eliminating forwards (k = 0, 1, ...) and leaving U in the upper triangle, so that the existing blocked
 // triangular solves (trsv_upper / trsm_upper_left / TriSolvePlan: U'^-1 then U^-1) are reused unchanged,
 // with a gather by P before, a block-diagonal solve between and a scatter after.
 //
-// Shape of the computation.  A pivot step is inherently sequential (search -> interchange -> eliminate), so
-// each step is two launches with no host involvement: a one-workgroup kernel that does the whole rook
-// search, the interchanges and the scaling of the pivot row(s) (all decisions on the device; the step's
-// column index lives in device memory because a 2x2 pivot advances it by two), and a many-workgroup
-// rank-1 / rank-2 update of the trailing upper triangle, which is the HBM-bound part:
-// sum_k (n-k)^2/2 * 16 B = 8 n^3 / 3 B (3.3e11 B at n = 5000).  This is the fallback of a failed Cholesky,
-// reached on a few late iterations of badly conditioned instances, not the steady-state factorization.
+// Storage during the factorization: the TRANSPOSE of the upper triangle (element (i, j), i <= j, at B[i * ld + j]), so that
+// "row k right of the diagonal" -- the pivot column of the symmetric matrix, read by the search, scaled by the
+// elimination -- is contiguous.  On the upper triangle itself those were 5000 accesses 40 KB apart per pass (one cache line
+// and one page each): 30 us per pivot step against 8 us now.  factor() transposes in and out.
+//
+// Shape of the computation.  A pivot step is inherently sequential (search -> interchange -> eliminate), so the host
+// enqueues pairs of launches with no involvement of its own: a one-workgroup kernel that does the whole rook search,
+// the interchanges and the scaling of the pivot row(s) -- all decisions on the device; the step's column index lives in
+// device memory because a 2x2 pivot advances it by two -- and a many-workgroup update of the trailing triangle, the
+// HBM-bound part (16 B per element and pass).  Updates are DELAYED: a step that takes its diagonal entry as a 1x1 pivot
+// without interchange (the usual case for the nearly positive definite matrices a failed Cholesky hands over) needs only
+// its own row up to date, which the pivot kernel does itself from the pending (l, w) vectors; the trailing matrix is
+// updated once per BK_M such steps (rank-BK_M, one pass) instead of once per step, and the update launches in between
+// return at once.  A step that needs the rook search first has the pending eliminations applied (one extra launch pair),
+// then runs on current data and is applied immediately, as in the unblocked algorithm.
 #include "hyp_internal.hpp"
 #include <limits.h>
 
@@ -28,6 +36,7 @@ namespace {
 
 constexpr int BK_T = 1024;   // threads of the pivot kernel
 constexpr int BK_TILE = 64;  // trailing update tile
+constexpr int BK_M = 8;      // pending eliminations (pairs of vectors l, w) a trailing update applies at once
 
 struct BkState {
   int knext;   // first column not yet eliminated
@@ -36,6 +45,9 @@ struct BkState {
   int skip;    // 1: exactly singular column, nothing to eliminate (LAPACK sets info and moves on)
   int info;    // 0 or 1-based index of the first exactly singular pivot
   int n2x2;    // number of 2x2 pivots (diagnostics)
+  int npend;   // eliminations whose trailing update is still pending (their l / w vectors sit in slots 0 .. npend - 1)
+  int flush;   // 1: the update launch that follows applies the pending eliminations to rows >= base (and the next pivot launch starts with none)
+  int base;    // first row the flush applies to
 };
 
 // max |.| with the SMALLEST index among equal maxima (idamax returns the first one); every thread returns the result
@@ -66,24 +78,25 @@ __device__ __forceinline__ void bk_argmax(double& v, int& ix, double* s_v, int* 
   ix = s_i[16];
 }
 
-// symmetric interchange of indices a < b on the upper-stored matrix, all rows (the rows above the active
-// block hold U, which the rook variant permutes too, so that ONE permutation describes the factorization)
-__device__ __forceinline__ void bk_swap(int n, double* __restrict__ A, long lda, int a, int b, int* __restrict__ perm) {
+// symmetric interchange of indices a < b, all rows (the rows above the active block hold U, which the rook variant
+// permutes too, so that ONE permutation describes the factorization).  E(i, j), i <= j, is B[i * ld + j].
+__device__ __forceinline__ void bk_swap(int n, double* __restrict__ B, long ld, int a, int b, int* __restrict__ perm) {
   const int t = threadIdx.x;
-  double* ca = A + (long)a * lda;
-  double* cb = A + (long)b * lda;
-  for (int i = t; i < a; i += BK_T) { const double x = ca[i]; ca[i] = cb[i]; cb[i] = x; }
-  for (int i = a + 1 + t; i < b; i += BK_T) {   // row a right of the diagonal <-> column b above it
-    double* pr = A + (long)i * lda + a;
-    const double x = *pr; *pr = cb[i]; cb[i] = x;
+  double* ra = B + (long)a * ld;   // E(a, .)
+  double* rb = B + (long)b * ld;   // E(b, .)
+  for (int i = t; i < a; i += BK_T) {   // E(i, a) <-> E(i, b)
+    double* pi = B + (long)i * ld;
+    const double x = pi[a]; pi[a] = pi[b]; pi[b] = x;
   }
-  for (int i = b + 1 + t; i < n; i += BK_T) {
-    double* pa = A + (long)i * lda + a;
-    double* pb = A + (long)i * lda + b;
-    const double x = *pa; *pa = *pb; *pb = x;
+  for (int i = a + 1 + t; i < b; i += BK_T) {   // E(a, i) <-> E(i, b)
+    double* pc = B + (long)i * ld + b;
+    const double x = ra[i]; ra[i] = *pc; *pc = x;
+  }
+  for (int i = b + 1 + t; i < n; i += BK_T) {   // E(a, i) <-> E(b, i)
+    const double x = ra[i]; ra[i] = rb[i]; rb[i] = x;
   }
   if (t == 0) {
-    const double x = ca[a]; ca[a] = cb[b]; cb[b] = x;
+    const double x = ra[a]; ra[a] = rb[b]; rb[b] = x;
     const int pi = perm[a]; perm[a] = perm[b]; perm[b] = pi;
   }
   __syncthreads();
@@ -96,52 +109,73 @@ __global__ __launch_bounds__(BK_T) void bk_pivot_kernel(int n, double* __restric
                                                         int* __restrict__ perm, double* __restrict__ wl) {
   __shared__ double s_v[17];
   __shared__ int s_i[17];
+  __shared__ double s_lk[BK_M];
   const int t = threadIdx.x;
   const int k = st->knext;
   if (k >= n) {
-    if (t == 0) st->k = n;
+    if (t == 0) { st->k = n; st->flush = 0; }
     return;
   }
   const double alpha = 0.6403882032022076;   // (1 + sqrt(17)) / 8
-  double* w1 = wl;
-  double* l1 = wl + n;
-  double* w2 = wl + 2L * n;
-  double* l2 = wl + 3L * n;
+  double* PW = wl;                     // slot p: w_p at PW + p n
+  double* PL = wl + (long)BK_M * n;    //         l_p at PL + p n
+  const int m = st->flush ? 0 : st->npend;   // (a flush ran since the last pivot launch: nothing is pending any more)
 
-  const double absakk = fabs(A[(long)k * lda + k]);
+  double* rk = A + (long)k * lda;   // E(k, .): the pivot column of the symmetric matrix, contiguous
+  if (m > 0) {   // bring row k up to date: E(k, j) -= sum_p l_p[k] w_p[j]
+    if (t < m) s_lk[t] = PL[(long)t * n + k];
+    __syncthreads();
+    for (int j = k + t; j < n; j += BK_T) {
+      double v = rk[j];
+      for (int p = 0; p < m; ++p) v -= s_lk[p] * PW[(long)p * n + j];
+      rk[j] = v;
+    }
+    __syncthreads();
+  }
+  const double absakk = fabs(rk[k]);
   double colmax = -1.0;
   int imax = INT_MAX;
   for (int j = k + 1 + t; j < n; j += BK_T) {
-    const double a = fabs(A[(long)j * lda + k]);
+    const double a = fabs(rk[j]);
     if (a > colmax) { colmax = a; imax = j; }
   }
   bk_argmax(colmax, imax, s_v, s_i);
   if (colmax < 0.0) colmax = 0.0;
 
   int kstep = 1, kp = k, p = k;
-  bool skip = false;
+  bool skip = false, searched = false;
   if (fmax(absakk, colmax) == 0.0 || absakk != absakk) {
     skip = true;
   } else if (!(absakk < alpha * colmax)) {
     kp = k;
   } else {
+    if (m > 0) {   // the rook search reads other rows: have the pending eliminations applied first, then come back to step k
+      if (t == 0) {   // (row k itself is already up to date: the flush starts below it)
+        st->k = n;
+        st->npend = m;
+        st->flush = 1;
+        st->base = k + 1;
+      }
+      return;
+    }
+    searched = true;
     for (;;) {
-      // largest off-diagonal of row/column imax inside the active block: (j, imax) for k <= j < imax down
-      // the stored column, (imax, j) for j > imax along the stored row
+      // largest off-diagonal of row/column imax inside the active block: E(j, imax) for k <= j < imax (strided),
+      // E(imax, j) for j > imax (contiguous)
       double rowmax = -1.0;
       int jmax = INT_MAX;
-      const double* ci = A + (long)imax * lda;
+      const double* ri = A + (long)imax * lda;
       for (int j = k + t; j < imax; j += BK_T) {
-        const double a = fabs(ci[j]);
+        const double a = fabs(A[(long)j * lda + imax]);
         if (a > rowmax) { rowmax = a; jmax = j; }
       }
       for (int j = imax + 1 + t; j < n; j += BK_T) {
-        const double a = fabs(A[(long)j * lda + imax]);
+        const double a = fabs(ri[j]);
         if (a > rowmax) { rowmax = a; jmax = j; }
       }
       bk_argmax(rowmax, jmax, s_v, s_i);
       if (rowmax < 0.0) rowmax = 0.0;
-      if (!(fabs(ci[imax]) < alpha * rowmax)) {
+      if (!(fabs(ri[imax]) < alpha * rowmax)) {
         kp = imax; kstep = 1;
         break;
       } else if (p == jmax || rowmax <= colmax) {
@@ -157,96 +191,110 @@ __global__ __launch_bounds__(BK_T) void bk_pivot_kernel(int n, double* __restric
   const int kk = k + kstep - 1;
   if (kp != kk) bk_swap(n, A, lda, kk, kp, perm);
 
+  double* w1 = PW + (long)m * n;
+  double* l1 = PL + (long)m * n;
   if (skip) {
     if (t == 0) {
-      dd[k] = A[(long)k * lda + k];
+      dd[k] = rk[k];
       de[k] = 0.0;
       blk[k] = 0;
-      A[(long)k * lda + k] = 1.0;
+      rk[k] = 1.0;
       if (st->info == 0) st->info = k + 1;
     }
   } else if (kstep == 1) {
-    const double d = A[(long)k * lda + k];
+    const double d = rk[k];
     __syncthreads();
     for (int j = k + 1 + t; j < n; j += BK_T) {
-      double* pe = A + (long)j * lda + k;
-      const double w = *pe;
+      const double w = rk[j];
       const double l = w / d;
       w1[j] = w; l1[j] = l;
-      *pe = l;
+      rk[j] = l;
     }
     if (t == 0) {
       dd[k] = d; de[k] = 0.0; blk[k] = 0;
-      A[(long)k * lda + k] = 1.0;
+      rk[k] = 1.0;
     }
   } else {
-    const double d11 = A[(long)k * lda + k];
-    const double d12 = A[(long)(k + 1) * lda + k];
-    const double d22 = A[(long)(k + 1) * lda + k + 1];
+    double* w2 = PW + (long)(m + 1) * n;
+    double* l2 = PL + (long)(m + 1) * n;
+    const double d11 = rk[k];
+    double* rk1 = A + (long)(k + 1) * lda;   // E(k + 1, .)
+    const double d12 = rk[k + 1];
+    const double d22 = rk1[k + 1];
     __syncthreads();
     // [l1 l2] = [w1 w2] D^-1 with the scaling of dsytf2_rook (everything divided by the large off-diagonal)
     const double D11 = d22 / d12, D22 = d11 / d12;
     const double T = 1.0 / (D11 * D22 - 1.0);
     for (int j = k + 2 + t; j < n; j += BK_T) {
-      double* pe = A + (long)j * lda + k;
-      const double a = pe[0], b = pe[1];
+      const double a = rk[j], b = rk1[j];
       const double la = T * (D11 * a - b) / d12;
       const double lb = T * (D22 * b - a) / d12;
       w1[j] = a; w2[j] = b; l1[j] = la; l2[j] = lb;
-      pe[0] = la; pe[1] = lb;
+      rk[j] = la; rk1[j] = lb;
     }
     if (t == 0) {
       dd[k] = d11; dd[k + 1] = d22; de[k] = d12; de[k + 1] = 0.0;
       blk[k] = 1; blk[k + 1] = 2;
-      A[(long)k * lda + k] = 1.0;
-      A[(long)(k + 1) * lda + k] = 0.0;
-      A[(long)(k + 1) * lda + k + 1] = 1.0;
+      rk[k] = 1.0;
+      rk[k + 1] = 0.0;
+      rk1[k + 1] = 1.0;
       st->n2x2 += 1;
     }
   }
   if (t == 0) {
+    const int np = m + (skip ? 0 : kstep);
     st->k = k;
     st->kstep = kstep;
     st->skip = skip ? 1 : 0;
     st->knext = k + kstep;
+    st->npend = np;
+    st->base = k + kstep;
+    // apply at once after a searched step (the next one most likely searches too and must see current data), or when
+    // the slots could not take a 2x2 pivot any more
+    st->flush = (np > 0 && (searched || np > BK_M - 2)) ? 1 : 0;
   }
 }
 
-// trailing update A[i, j] -= l1[i] w1[j] (+ l2[i] w2[j]) on the upper triangle i <= j of the block that starts
-// after the pivot; tiles are numbered along the upper triangle of the tile grid (host launches for the
-// largest block the step can have, surplus workgroups leave)
+// flush: E(i, j) -= sum_p l_p[i] w_p[j] for base <= i <= j over the npend pending eliminations (E(i, j) at B[i * ld + j]:
+// lanes run along j); tiles are numbered along the triangle of the tile grid (the host launches for the largest block the
+// flush can have, surplus workgroups leave; without the flush flag every workgroup leaves at once)
 __global__ __launch_bounds__(256) void bk_update_kernel(int n, double* __restrict__ A, long lda, const BkState* __restrict__ st,
                                                         const double* __restrict__ wl) {
-  const int k = st->k;
-  if (k >= n || st->skip) return;
-  const int ks = st->kstep;
-  const int base = k + ks;
+  if (!st->flush) return;
+  const int m = st->npend;
+  const int base = st->base;
   const int rem = n - base;
-  if (rem <= 0) return;
+  if (rem <= 0 || m <= 0) return;
   const int nt = (rem + BK_TILE - 1) / BK_TILE;
   const long idx = blockIdx.x;
   if (idx >= (long)nt * (nt + 1) / 2) return;
   int bj = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
   while ((long)bj * (bj + 1) / 2 > idx) --bj;
   while ((long)(bj + 1) * (bj + 2) / 2 <= idx) ++bj;
-  const int bi = (int)(idx - (long)bj * (bj + 1) / 2);
+  const int bi = (int)(idx - (long)bj * (bj + 1) / 2);   // bi <= bj: tile rows i, tile columns j
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int i = base + bi * BK_TILE + tx;
-  const int j0 = base + bj * BK_TILE;
-  if (i >= n) return;
-  const double* w1 = wl;
-  const double* l1 = wl + n;
-  const double* w2 = wl + 2L * n;
-  const double* l2 = wl + 3L * n;
-  const double a1 = l1[i];
-  const double a2 = (ks == 2) ? l2[i] : 0.0;
-#pragma unroll 4
+  const int j = base + bj * BK_TILE + tx;
+  const int i0 = base + bi * BK_TILE;
+  const double* PW = wl;
+  const double* PL = wl + (long)BK_M * n;
+  __shared__ double s_l[BK_M][BK_TILE];
+  for (int e = threadIdx.x; e < BK_M * BK_TILE; e += 256) {
+    const int p = e / BK_TILE, c = e % BK_TILE;
+    s_l[p][c] = (p < m && i0 + c < n) ? PL[(long)p * n + i0 + c] : 0.0;
+  }
+  __syncthreads();
+  if (j >= n) return;
+  double a[BK_M];
+#pragma unroll
+  for (int p = 0; p < BK_M; ++p) a[p] = (p < m) ? PW[(long)p * n + j] : 0.0;
+#pragma unroll 2
   for (int c = ty; c < BK_TILE; c += 4) {
-    const int j = j0 + c;
-    if (j < n && i <= j) {
-      double* pe = A + (long)j * lda + i;
-      double v = *pe - a1 * w1[j];
-      if (ks == 2) v -= a2 * w2[j];
+    const int i = i0 + c;
+    if (i < n && i <= j) {
+      double* pe = A + (long)i * lda + j;
+      double v = *pe;
+#pragma unroll
+      for (int p = 0; p < BK_M; ++p) v -= s_l[p][c] * a[p];
       *pe = v;
     }
   }
@@ -255,7 +303,7 @@ __global__ __launch_bounds__(256) void bk_update_kernel(int n, double* __restric
 __global__ void bk_init_kernel(int n, BkState* st, int* perm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) perm[i] = i;
-  if (i == 0) { st->knext = 0; st->k = 0; st->kstep = 1; st->skip = 0; st->info = 0; st->n2x2 = 0; }
+  if (i == 0) { st->knext = 0; st->k = 0; st->kstep = 1; st->skip = 0; st->info = 0; st->n2x2 = 0; st->npend = 0; st->flush = 0; st->base = 0; }
 }
 
 __global__ void bk_gather_kernel(int n, int nr, const int* __restrict__ perm, const double* __restrict__ x, long ldx,
@@ -304,18 +352,33 @@ int BKFact::factor(Ctx& c, int n_, double* A, long lda, double* dinv) {
   de.ensure((size_t)n * d);
   blk.ensure((size_t)n * sizeof(int));
   perm.ensure((size_t)n * sizeof(int));
-  wl.ensure((size_t)4 * n * d);
+  wl.ensure((size_t)2 * BK_M * n * d);
   state.ensure(64);
+  tr.ensure((size_t)n * n * d);
+  double* B = tr.d();
+  dev_transpose(c, n, n, A, lda, B, n, 1, 0, 0);   // B[i * n + j] = A(i, j): the upper triangle, transposed
   BkState* st = (BkState*)state.p;
   hipLaunchKernelGGL(bk_init_kernel, dim3((n + 255) / 256), dim3(256), 0, c.stream, n, st, perm.i());
-  for (int s = 0; s < n; ++s) {
-    hipLaunchKernelGGL(bk_pivot_kernel, dim3(1), dim3(BK_T), 0, c.stream, n, A, lda, st, dd.d(), de.d(), blk.i(), perm.i(), wl.d());
-    const int rem = n - s - 1;   // the step's column is >= s, so its trailing block has at most n - s - 1 rows
-    if (rem > 0) {
-      const long nt = (rem + BK_TILE - 1) / BK_TILE;
-      hipLaunchKernelGGL(bk_update_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, c.stream, n, A, lda, st, wl.d());
+  // Launch pairs are enqueued in chunks; after each chunk the host reads how far the device got.  A pair either completes
+  // a step or only requests a flush (always followed by a pair that completes one), so after q further pairs the next
+  // column is at least known + q / 2: that bounds the trailing block an update launch can meet.
+  const int CH = std::min(128, 2 * n + 2);
+  int known = 0;
+  for (int chunk = 0; chunk < 4 * n / CH + 8 && known < n; ++chunk) {
+    for (int q = 0; q < CH; ++q) {
+      hipLaunchKernelGGL(bk_pivot_kernel, dim3(1), dim3(BK_T), 0, c.stream, n, B, (long)n, st, dd.d(), de.d(), blk.i(), perm.i(), wl.d());
+      const int rem = n - 1 - (known + q / 2);
+      if (rem > 0) {
+        const long nt = (rem + BK_TILE - 1) / BK_TILE;
+        hipLaunchKernelGGL(bk_update_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, c.stream, n, B, (long)n, st, wl.d());
+      }
     }
+    c.d2h(c.h_info, st, sizeof(BkState));
+    c.sync();
+    known = ((const BkState*)c.h_info)->knext;
   }
+  HYP_REQUIRE(known >= n, "Bunch-Kaufman: the factorization did not finish (internal)");
+  dev_transpose(c, n, n, B, n, A, lda, 1, 0, 0);   // U back into the upper triangle of A (its lower triangle gets its old content back)
   if (dinv) potrf_invert_diag_blocks(c, n, A, lda, 0, 1, dinv);
   c.d2h(c.h_info, st, sizeof(BkState));
   c.sync();

@@ -151,7 +151,7 @@ struct BKFact {
   int n = 0;
   int n_2x2 = 0;                  // number of 2x2 pivot blocks of the last factorization
   DBuf dd, de, blk, perm;         // diagonal / off-diagonal of D, block marks (0: 1x1, 1 / 2: rows of a 2x2), P as a gather map
-  DBuf state, wl, tmp;
+  DBuf state, wl, tmp, tr;        // tr: n x n work matrix (the factorization runs on the transposed triangle)
   // A: upper triangle in, U out.  dinv (dinv_elems(n) doubles, may be null) receives the inverted diagonal
   // blocks for trsv_upper / trsm_upper_left / TriSolvePlan.  Returns LAPACK's info: 0 or the 1-based index of the
   // first exactly singular pivot (issuccess(fact) = info == 0).  Synchronizes.
