@@ -370,7 +370,11 @@ def psd_blocks(n, sides, seed=1, dtype=np.float64):
     rng = np.random.default_rng(seed)
     dims = [s * (s + 1) // 2 for s in sides]
     q = sum(dims)
-    G = np.asfortranarray(rng.standard_normal((q, n)) / np.sqrt(n))
+    if dtype == np.float32:   # (draws in single precision, stored in double: half the generation time of the 8.3 GB of config 4)
+        G = np.asfortranarray(rng.standard_normal((q, n), dtype=np.float32), dtype=np.float64)
+        G /= np.sqrt(n)
+    else:
+        G = np.asfortranarray(rng.standard_normal((q, n)) / np.sqrt(n))
     x0 = rng.standard_normal(n)
     e = np.concatenate([svec_identity(s) for s in sides])
     h = G @ x0 + e
