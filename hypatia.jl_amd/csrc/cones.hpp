@@ -141,6 +141,7 @@ struct GenericHessCone : Cone {
   bool hess_fact_ok = false;   // issuccess(hess_fact)
   bool hess_fact_bk = false;   // hess_fact is the Bunch-Kaufman fallback of a failed Cholesky (posdef_fact_copy!(.., false), Cones.jl:247)
   BKFact Hbk;
+  TriSolvePlan Hplan;          // super-block plan for one-vector solves with a large factor (built on first use per factorization)
   bool use_hess_prod_slow = false, use_hess_prod_slow_updated = false;
   GenericHessCone(Ctx& c, int kind) : Cone(c, kind) {}
   void alloc_generic();

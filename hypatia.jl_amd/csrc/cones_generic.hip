@@ -90,6 +90,7 @@ bool GenericHessCone::update_hess_fact() {   // Cones.jl:239-251: posdef_fact_co
     hess_fact_ok = (Hbk.factor(ctx, dim, Hfact.d(), dim, Hdinv.d()) == 0);
   }
   hess_fact_updated = true;
+  Hplan.invalidate();
   return hess_fact_ok;
 }
 
@@ -120,7 +121,16 @@ void GenericHessCone::inv_hess_prod(double* prod, long ldp, const double* arr, l
   if (ncols <= 0) return;
   if (prod != arr) HYP_CHECK(hipMemcpy2DAsync(prod, ldp * sizeof(double), arr, lda * sizeof(double), (size_t)dim * sizeof(double), ncols,
                                               hipMemcpyDeviceToDevice, ctx.stream));
-  if (hess_fact_bk) {   // ldiv!(::BunchKaufman, .)
+  if (ncols == 1 && ctx.trsv_sb > 0 && dim >= 2 * ctx.trsv_sb) {
+    // one vector against a large factor (check_numerics / get_proxsqr of every line-search trial): the super-block solves
+    // of the system solver (76 dependent block steps otherwise); Bunch-Kaufman factor: P before, D^-1 between, P' after
+    if (!Hplan.ready(dim)) Hplan.build(ctx, dim, Hfact.d(), dim, Hdinv.d());
+    double* y = hess_fact_bk ? Hbk.gather(ctx, prod, ldp, 1) : prod;
+    Hplan.solve(ctx, Hfact.d(), dim, true, y);
+    if (hess_fact_bk) Hbk.dsolve(ctx, y, dim, 1);
+    Hplan.solve(ctx, Hfact.d(), dim, false, y);
+    if (hess_fact_bk) Hbk.scatter(ctx, y, prod, ldp, 1);
+  } else if (hess_fact_bk) {   // ldiv!(::BunchKaufman, .)
     Hbk.solve(ctx, Hfact.d(), dim, Hdinv.d(), prod, ldp, ncols, trsm_work);
   } else if (ncols == 1) {
     trsv_upper(ctx, dim, Hfact.d(), dim, Hdinv.d(), true, prod);
