@@ -21,6 +21,8 @@ def make_cone(spec):
         return hc.HypoRootdetTri(spec[1], use_dual=spec[2])
     if kind == "hypoperlogdettri":
         return hc.HypoPerLogdetTri(spec[1], use_dual=spec[2])
+    if kind == "wsosinterppossemideftri":
+        return hc.WSOSInterpPosSemidefTri(spec[1], spec[2], spec[3], use_dual=spec[4])
     raise NotImplementedError("no HIP cone for %r yet (and there is no CPU fallback)" % (kind,))
 
 

@@ -306,3 +306,20 @@ class HypoPerLogdetTri(_GenericHessMixin, Cone):
         L.check(L.lib().hyp_cone_create_hypoperlogdettri(L.ctx(), int(dim), int(bool(use_dual)), ctypes.byref(h)),
                 "hyp_cone_create_hypoperlogdettri")
         super().__init__(h)
+
+
+class WSOSInterpPosSemidefTri(_GenericHessMixin, Cone):
+    """Cones.WSOSInterpPosSemidefTri{Float64}(R, U, Ps; use_dual)  (wsosinterppossemideftri.jl:9-69)."""
+
+    def __init__(self, R, U, Ps, use_dual=False):
+        self._slow = False
+        Ps = [np.asfortranarray(P, dtype=np.float64) for P in Ps]
+        for P in Ps:
+            assert P.shape[0] == U
+        K = len(Ps)
+        Ls = (c_int * K)(*[P.shape[1] for P in Ps])
+        ptrs = (c_vp * K)(*[P.ctypes.data_as(c_vp) for P in Ps])
+        h = c_vp()
+        L.check(L.lib().hyp_cone_create_wsosinterppossemideftri(L.ctx(), int(R), int(U), K, Ls, ptrs, int(bool(use_dual)), ctypes.byref(h)),
+                "hyp_cone_create_wsosinterppossemideftri")
+        super().__init__(h)

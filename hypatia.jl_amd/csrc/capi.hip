@@ -137,6 +137,14 @@ int hyp_cone_create_hypoperlogdettri(hyp_ctx* ctx, int dim, int use_dual, hyp_co
   ctx->c.sync();
   API_END(ctx)
 }
+int hyp_cone_create_wsosinterppossemideftri(hyp_ctx* ctx, int R, int U, int K, const int* Ls, const double* const* Ps, int use_dual,
+                                            hyp_cone** out) {
+  API_BEGIN
+  HYP_CHECK(hipSetDevice(ctx->c.device));
+  *out = new hyp_cone{ctx, new WsosPsdCone(ctx->c, R, U, K, Ls, Ps, use_dual != 0)};
+  ctx->c.sync();
+  API_END(ctx)
+}
 int hyp_cone_update_use_hess_prod_slow(hyp_cone* cone, int* out) {
   API_BEGIN
   GenericHessCone* g = dynamic_cast<GenericHessCone*>(cone->cone);

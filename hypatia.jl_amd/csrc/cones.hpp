@@ -13,7 +13,7 @@ bool psd_two_sided_fused_ok(int side);
 void psd_two_sided_fused(Ctx& c, int side, int ncols, const double* R, int rstruct /* 0 full, 1 upper, 2 lower */, const double* arr,
                          long lda, double* prod, long ldp, double* zws /* ncols * side^2 */);
 
-enum ConeKind { CONE_NONNEG = 0, CONE_PSD = 1, CONE_EPINORMSPECTRAL = 2, CONE_WSOS = 3, CONE_LMI = 4, CONE_DNN = 5, CONE_HYPOROOTDET = 6, CONE_HYPOPERLOGDET = 7 };
+enum ConeKind { CONE_NONNEG = 0, CONE_PSD = 1, CONE_EPINORMSPECTRAL = 2, CONE_WSOS = 3, CONE_LMI = 4, CONE_DNN = 5, CONE_HYPOROOTDET = 6, CONE_HYPOPERLOGDET = 7, CONE_WSOSPSD = 8 };
 
 struct Cone {
   Ctx& ctx;
@@ -250,6 +250,22 @@ struct HypoPerLogdetTriCone : GenericHessCone {   // src/Cones/hypoperlogdettri.
   bool inv_hess_ready() override { return true; }
   const double* dder3(const double* d_dir) override;                                                // :318-368
   double logdet_of(PsdCone& k);
+};
+
+struct WsosPsdCone : GenericHessCone {   // src/Cones/wsosinterppossemideftri.jl: R x R matrices of interpolant-basis polynomials
+  int R, U, K, nblk;            // nblk = R (R + 1) / 2 svec blocks of length U
+  std::vector<int> Ls;
+  std::vector<DBuf> P, SP, Lam, LamDinv, FLP, Mk, Tk, LRUR;   // per basis k
+  DBuf PLiP, tU, infos;
+  WsosPsdCone(Ctx& c, int R, int U, int K, const int* Ls, const double* const* hPs, bool use_dual);
+  bool update_feas() override;                                                                      // :110-140
+  void update_grad() override;                                                                      // :142-186
+  void update_hess() override;                                                                      // :188-236
+  void set_initial_point(double* h_out) override;                                                   // :100-108
+  void hess_prod_slow(double* prod, long ldp, const double* arr, long lda, int ncols) override;    // :238-247
+  const double* dder3(const double* d_dir) override;                                                // :249-252
+  void block_matrix(int k, const double* d_vec, double* M);                                         // :122-130, 300-307 (upper blocks)
+  void partial_prod(double* prod, long ldp, const double* arr, long lda, int ncols, bool use_symm_prod);   // :288-321
 };
 
 struct EpiNormSpectralCone : GenericHessCone {   // src/Cones/epinormspectral.jl (real)

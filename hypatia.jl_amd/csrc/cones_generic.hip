@@ -943,4 +943,210 @@ const double* HypoPerLogdetTriCone::dder3(const double* d_dir) {   // :318-368
   return dder3v.d();
 }
 
+// ---------------------------------------------------------------------------------------------
+// WSOSInterpPosSemidefTri (wsosinterppossemideftri.jl:9-321).  The barrier is for the DUAL cone (use_dual_barrier =
+// !use_dual, :61): -sum_k logdet Lambda_k with Lambda_k the (L_k R) x (L_k R) matrix of blocks P_k' diag(s_pq) P_k
+// (off-diagonal blocks scaled by 1 / sqrt 2).  Lambda_k = U_k' U_k (the reference keeps L_k = U_k');
+// FLP_k = L_k^-1 kron(I_R, P_k') by ONE triangular solve with R U right-hand sides (the reference substitutes block by
+// block; the result is the same block lower triangular matrix).  Gradient, slow Hessian product and dder3 are diagonals
+// of U x U blocks of products with FLP_k; the explicit Hessian combines U x U blocks of FLP_k' FLP_k elementwise.
+// ---------------------------------------------------------------------------------------------
+// out[b(j, i) U + u] (+)= sign * <m1[:, i U + u], m2[:, j U + u]> * (i == j ? 1 : sqrt 2), i <= j   (:264-286); one wavefront per entry
+__global__ __launch_bounds__(256) void wsospsd_bdp_kernel(int rows, int U, int R, const double* __restrict__ m1, long ld1,
+                                                          const double* __restrict__ m2, long ld2, double sign, int accumulate,
+                                                          double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long e = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long total = (long)U * (R * (R + 1) / 2);
+  if (e >= total) return;
+  const int b = (int)(e / U), u = (int)(e % U);
+  int j = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
+  while (j * (j + 1) / 2 > b) --j;
+  while ((j + 1) * (j + 2) / 2 <= b) ++j;
+  const int i = b - j * (j + 1) / 2;
+  const double* a = m1 + ((long)i * U + u) * ld1;
+  const double* c = m2 + ((long)j * U + u) * ld2;
+  double s = 0.0;
+  for (int r = lane; r < rows; r += 64) s += a[r] * c[r];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if (lane == 0) out[e] = (accumulate ? out[e] : 0.0) + sign * s * (i == j ? 1.0 : 1.4142135623730951);
+}
+// H[b1 U + u, b2 U + v] (+)= PLiP[p, p2] .* PLiP[q, q2] * scal (+ PLiP[p, q2] .* PLiP[q, p2] when p != q and p2 != q2), b1 <= b2   (:207-232)
+__global__ void wsospsd_hess_kernel(int U, int R, const double* __restrict__ G, long ldg, int accumulate, double* __restrict__ H, long ldh) {
+  const int nb = R * (R + 1) / 2;
+  int pr = blockIdx.z;   // pair index over b1 <= b2
+  int b2 = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
+  while (b2 * (b2 + 1) / 2 > pr) --b2;
+  while ((b2 + 1) * (b2 + 2) / 2 <= pr) ++b2;
+  const int b1 = pr - b2 * (b2 + 1) / 2;
+  if (b2 >= nb) return;
+  auto rc = [](int b, int& row, int& col) {
+    row = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
+    while (row * (row + 1) / 2 > b) --row;
+    while ((row + 1) * (row + 2) / 2 <= b) ++row;
+    col = b - row * (row + 1) / 2;
+  };
+  int p, q, p2, q2;
+  rc(b1, p, q);
+  rc(b2, p2, q2);
+  const int u = blockIdx.x * 16 + (threadIdx.x & 15), v = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (u >= U || v >= U) return;
+  auto Gb = [&](int a, int b) { return G[((long)b * U + v) * ldg + (long)a * U + u]; };
+  const double scal = ((p == q) != (p2 == q2)) ? 1.4142135623730951 : 1.0;
+  double val = Gb(p, p2) * Gb(q, q2) * scal;
+  if (p != q && p2 != q2) val += Gb(p, q2) * Gb(q, p2);
+  double* h = H + ((long)b2 * U + v) * ldh + (long)b1 * U + u;
+  *h = (accumulate ? *h : 0.0) + val;
+}
+
+WsosPsdCone::WsosPsdCone(Ctx& c, int R_, int U_, int K_, const int* Ls_, const double* const* hPs, bool use_dual)
+    : GenericHessCone(c, CONE_WSOSPSD) {
+  HYP_REQUIRE(R_ >= 1 && U_ >= 1 && K_ >= 1, "WSOSInterpPosSemidefTri: sizes");
+  R = R_; U = U_; K = K_;
+  nblk = R * (R + 1) / 2;
+  dim = U * nblk;
+  use_dual_barrier = !use_dual;                                                                       // :61
+  nu = 0;
+  for (int k = 0; k < K; ++k) {
+    HYP_REQUIRE(Ls_[k] >= 1 && Ls_[k] <= U, "WSOSInterpPosSemidefTri: 1 <= L_k <= U");
+    Ls.push_back(Ls_[k]);
+    nu += (double)R * Ls_[k];                                                                         // :66
+  }
+  alloc_common();
+  alloc_generic();
+  infos.alloc(64);
+  tU.alloc((size_t)U * sizeof(double));
+  PLiP.alloc((size_t)R * U * R * U * sizeof(double));
+  for (int k = 0; k < K; ++k) {
+    const long Lk = Ls[k], LR = Lk * R;
+    const size_t pb = (size_t)U * Lk * sizeof(double);
+    P.emplace_back(pb); SP.emplace_back(pb);
+    Lam.emplace_back((size_t)LR * LR * sizeof(double));
+    Mk.emplace_back((size_t)LR * LR * sizeof(double));
+    Tk.emplace_back((size_t)LR * LR * sizeof(double));
+    LamDinv.emplace_back(dinv_elems((int)LR) * sizeof(double));
+    FLP.emplace_back((size_t)LR * R * U * sizeof(double));
+    LRUR.emplace_back((size_t)LR * R * U * sizeof(double));
+    ctx.h2d(P[k].p, hPs[k], pb);
+  }
+  ctx.sync();
+}
+
+void WsosPsdCone::set_initial_point(double* h) {   // :100-108
+  for (int i = 0; i < dim; ++i) h[i] = 0.0;
+  for (int r = 0; r < R; ++r) {
+    const long b = (long)r * (r + 1) / 2 + r;
+    for (int u = 0; u < U; ++u) h[b * U + u] = 1.0;
+  }
+}
+
+// M (L R x L R, ld L R): upper blocks (q, p), q <= p, = P_k' diag(vec_pq * (p == q ? 1 : 1 / sqrt 2)) P_k
+void WsosPsdCone::block_matrix(int k, const double* d_vec, double* M) {
+  const int Lk = Ls[k];
+  const long LR = (long)Lk * R;
+  for (int p = 0; p < R; ++p)
+    for (int q = 0; q <= p; ++q) {
+      const long b = (long)p * (p + 1) / 2 + q;
+      dev_scale_copy(ctx, U, p == q ? 1.0 : 0.7071067811865476, d_vec + b * U, tU.d());
+      row_scale(ctx, U, Lk, tU.d(), P[k].d(), U, SP[k].d(), U);
+      GemmArgs g{};
+      g.M = Lk; g.N = Lk; g.K = U; g.A = SP[k].d(); g.lda = U; g.B = P[k].d(); g.ldb = U;
+      g.C = M + (long)q * Lk + (long)p * Lk * LR; g.ldc = LR;
+      g.alpha = 1; g.beta = 0; g.tri = (p == q) ? GEMM_UPPER : GEMM_FULL; g.batch = 1;
+      gemm(ctx, true, g);
+    }
+}
+
+bool WsosPsdCone::update_feas() {   // :110-140
+  is_feas_ = true;
+  for (int k = 0; k < K && is_feas_; ++k) {
+    const int LR = Ls[k] * R;
+    block_matrix(k, point.d(), Lam[k].d());
+    potrf_upper_batched(ctx, LR, Lam[k].d(), LR, 0, 1, LamDinv[k].d(), infos.i());
+    if (read_info(ctx, infos.i()) != 0) is_feas_ = false;
+  }
+  feas_updated = true;
+  return is_feas_;
+}
+
+void WsosPsdCone::update_grad() {   // :142-186
+  for (int k = 0; k < K; ++k) {
+    const int Lk = Ls[k];
+    const long LR = (long)Lk * R, RU = (long)R * U;
+    // kron(I_R, P_k'): block (r, r) = P_k' (L x U)
+    ctx.zero(FLP[k].p, (size_t)LR * RU * sizeof(double));
+    for (int r = 0; r < R; ++r) dev_transpose(ctx, U, Lk, P[k].d(), U, FLP[k].d() + (long)r * Lk + (long)r * U * LR, LR, 1, 0, 0);
+    trsm_work.ensure((size_t)NB * RU * sizeof(double));
+    trsm_upper_left(ctx, (int)LR, (int)RU, Lam[k].d(), LR, LamDinv[k].d(), true, FLP[k].d(), LR, trsm_work.d());   // U'^-1 (.)
+    const long total = (long)U * nblk;
+    hipLaunchKernelGGL(wsospsd_bdp_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, ctx.stream, (int)LR, U, R, FLP[k].d(), LR, FLP[k].d(), LR,
+                       -1.0, k > 0 ? 1 : 0, grad.d());
+    HYP_CHECK(hipGetLastError());
+  }
+  grad_updated = true;
+}
+
+void WsosPsdCone::update_hess() {   // :188-236
+  ensure_hess_storage(false);
+  get_grad();
+  const long RU = (long)R * U;
+  const int npairs = nblk * (nblk + 1) / 2;
+  for (int k = 0; k < K; ++k) {
+    const long LR = (long)Ls[k] * R;
+    GemmArgs g{};   // P Lambda^-1 P = FLP' FLP (R U x R U)
+    g.M = (int)RU; g.N = (int)RU; g.K = (int)LR; g.A = FLP[k].d(); g.lda = LR; g.B = FLP[k].d(); g.ldb = LR; g.C = PLiP.d(); g.ldc = RU;
+    g.alpha = 1; g.beta = 0; g.tri = GEMM_UPPER; g.batch = 1;
+    gemm(ctx, true, g);
+    dev_symmetrize_from_upper(ctx, (int)RU, PLiP.d(), RU, 1, 0);
+    hipLaunchKernelGGL(wsospsd_hess_kernel, dim3((U + 15) / 16, (U + 15) / 16, npairs), dim3(256), 0, ctx.stream, U, R, PLiP.d(), RU, k > 0 ? 1 : 0,
+                       H.d(), (long)dim);
+    HYP_CHECK(hipGetLastError());
+  }
+  dev_symmetrize_from_upper(ctx, dim, H.d(), dim, 1, 0);
+  hess_updated = true;
+}
+
+void WsosPsdCone::partial_prod(double* prod, long ldp, const double* arr, long lda, int ncols, bool use_symm_prod) {   // :288-321
+  get_grad();
+  const long RU = (long)R * U;
+  const long total = (long)U * nblk;
+  for (int j = 0; j < ncols; ++j) {
+    for (int k = 0; k < K; ++k) {
+      const int LR = Ls[k] * R;
+      double* M = Mk[k].d();
+      double* T = Tk[k].d();
+      block_matrix(k, arr + (long)j * lda, M);
+      dev_symmetrize_from_upper(ctx, LR, M, LR, 1, 0);
+      // W = L^-1 M L^-T = U^-T M U^-1: left solve, transpose, left solve (W is symmetric)
+      trsm_work.ensure((size_t)NB * std::max<long>(LR, RU) * sizeof(double));
+      trsm_upper_left(ctx, LR, LR, Lam[k].d(), LR, LamDinv[k].d(), true, M, LR, trsm_work.d());
+      dev_transpose(ctx, LR, LR, M, LR, T, LR, 1, 0, 0);
+      trsm_upper_left(ctx, LR, LR, Lam[k].d(), LR, LamDinv[k].d(), true, T, LR, trsm_work.d());
+      dev_symmetrize_from_upper(ctx, LR, T, LR, 1, 0);                                    // Symmetric(., :U)
+      GemmArgs g{};   // LRUR = W FLP
+      g.M = LR; g.N = (int)RU; g.K = LR; g.A = T; g.lda = LR; g.B = FLP[k].d(); g.ldb = LR; g.C = LRUR[k].d(); g.ldc = LR;
+      g.alpha = 1; g.beta = 0; g.batch = 1;
+      gemm(ctx, true, g);
+      hipLaunchKernelGGL(wsospsd_bdp_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, ctx.stream, LR, U, R,
+                         use_symm_prod ? LRUR[k].d() : FLP[k].d(), (long)LR, LRUR[k].d(), (long)LR, 1.0, k > 0 ? 1 : 0, prod + (long)j * ldp);
+      HYP_CHECK(hipGetLastError());
+    }
+  }
+}
+
+void WsosPsdCone::hess_prod_slow(double* prod, long ldp, const double* arr, long lda, int ncols) {   // :238-247
+  if (!use_hess_prod_slow_updated) update_use_hess_prod_slow();
+  if (!use_hess_prod_slow) {
+    hess_prod(prod, ldp, arr, lda, ncols);
+    return;
+  }
+  partial_prod(prod, ldp, arr, lda, ncols, false);
+}
+
+const double* WsosPsdCone::dder3(const double* d_dir) {   // :249-252
+  partial_prod(dder3v.d(), dim, d_dir, dim, 1, true);
+  return dder3v.d();
+}
+
 }  // namespace hyp

@@ -58,6 +58,11 @@ int hyp_cone_create_hyporootdettri(hyp_ctx* ctx, int dim, int use_dual, hyp_cone
 /* Cones.HypoPerLogdetTri{Float64, Float64}(dim; use_dual) (hypoperlogdettri.jl:43-58): (u, v, svec(W)),
  * dim = 2 + side (side + 1) / 2; nu = 2 + side */
 int hyp_cone_create_hypoperlogdettri(hyp_ctx* ctx, int dim, int use_dual, hyp_cone** out);
+/* Cones.WSOSInterpPosSemidefTri{Float64}(R, U, Ps; use_dual) (wsosinterppossemideftri.jl:46-69): R x R symmetric matrices of
+ * polynomials given by U interpolant values each (svec order by blocks of length U), dim = U R (R + 1) / 2; Ps[k] is U x Ls[k],
+ * column-major, copied to the device; nu = R sum_k Ls[k] */
+int hyp_cone_create_wsosinterppossemideftri(hyp_ctx* ctx, int R, int U, int K, const int* Ls, const double* const* Ps, int use_dual,
+                                            hyp_cone** out);
 int hyp_cone_destroy(hyp_cone* cone);
 int hyp_cone_dimension(hyp_cone* cone, int* out);            /* Cones.jl:34 */
 int hyp_cone_get_nu(hyp_cone* cone, double* out);            /* Cones.jl:41 */

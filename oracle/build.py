@@ -21,6 +21,8 @@ def make_cone(spec):
         return oc.HypoRootdetTri(spec[1], use_dual=spec[2])
     if kind == "hypoperlogdettri":
         return oc.HypoPerLogdetTri(spec[1], use_dual=spec[2])
+    if kind == "wsosinterppossemideftri":
+        return oc.WSOSInterpPosSemidefTri(spec[1], spec[2], spec[3], use_dual=spec[4])
     raise ValueError(kind)
 
 

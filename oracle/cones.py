@@ -1266,3 +1266,135 @@ class HypoPerLogdetTri(HypoRootdetTri):
         M[np.diag_indices(d)] += c8
         au.smat_to_svec(self.dder3_[2:], self._two_sided_chol_back(M), self.rt2)
         return self.dder3_
+
+
+# ----------------------------------------------------------------------------------------------
+class WSOSInterpPosSemidefTri(Cone):
+    """wsosinterppossemideftri.jl:9-321: R x R symmetric matrices of polynomials (U interpolant values each, svec order by
+    blocks of length U) that are weighted-SOS positive semidefinite.  The barrier is for the DUAL cone
+    (use_dual_barrier = !use_dual, :61): -sum_k logdet Lambda_k, Lambda_k the LR x LR block matrix with blocks
+    P_k' diag(s_pq) P_k (off-diagonal blocks scaled by 1/sqrt 2).  Explicit Hessian + the generic fallbacks."""
+
+    def __init__(self, R, U, Ps, use_dual=False):
+        for Pk in Ps:
+            assert Pk.shape[0] == U
+        self.use_dual_barrier_ = not use_dual
+        self.R, self.U = R, U
+        self.dim = U * (R * (R + 1) // 2)
+        self.Ps = [np.asfortranarray(Pk) for Pk in Ps]
+        self.nu = R * sum(Pk.shape[1] for Pk in Ps)
+        self.rt2 = au.RT2
+        self.rt2i = 1.0 / au.RT2
+
+    def reset_data(self):   # :70-73
+        self.feas_updated = self.grad_updated = self.hess_updated = self.inv_hess_updated = False
+        self.hess_fact_updated = False
+        self.use_hess_prod_slow = self.use_hess_prod_slow_updated = False
+
+    def _blk(self, row, col):   # 0-based block of svec_idx(row, col), row >= col
+        b = row * (row + 1) // 2 + col
+        return slice(self.U * b, self.U * (b + 1))
+
+    def set_initial_point(self, arr):   # :100-108
+        arr[:] = 0
+        for i in range(self.R):
+            arr[self._blk(i, i)] = 1.0
+        return arr
+
+    def _block_matrix(self, vec, Pk):
+        """LR x LR symmetric matrix with blocks P_k' diag(vec_pq) P_k, off-diagonal blocks scaled by 1/sqrt(2) (:122-130, 300-307)"""
+        R, L = self.R, Pk.shape[1]
+        M = np.zeros((L * R, L * R))
+        for p in range(R):
+            for q in range(p + 1):
+                t = vec[self._blk(p, q)] * (1.0 if p == q else self.rt2i)
+                B = (Pk.T * t[None, :]) @ Pk
+                M[L * p:L * (p + 1), L * q:L * (q + 1)] = B
+                if p != q:
+                    M[L * q:L * (q + 1), L * p:L * (p + 1)] = B.T
+        return M
+
+    def update_feas(self):   # :110-140
+        assert not self.feas_updated
+        self.is_feas_ = True
+        self.LamFL = [None] * len(self.Ps)
+        for k, Pk in enumerate(self.Ps):
+            c, info = lapack.dpotrf(self._block_matrix(self.point, Pk), lower=1, clean=1)
+            self.LamFL[k] = c
+            if info != 0:
+                self.is_feas_ = False
+                break
+        self.feas_updated = True
+        return self.is_feas_
+
+    def _block_diag_prod(self, vect, mat1, mat2):   # :264-286: diagonal of every (i, j) U x U block of mat1' mat2
+        U = self.U
+        for j in range(self.R):
+            for i in range(j + 1):
+                d = np.einsum("lu,lu->u", mat1[:, U * i:U * (i + 1)], mat2[:, U * j:U * (j + 1)])
+                vect[self._blk(j, i)] += d * (1.0 if i == j else self.rt2)
+
+    def update_grad(self):   # :142-186
+        assert self.is_feas_
+        self.grad[:] = 0
+        self.LamFLP = []
+        for k, Pk in enumerate(self.Ps):
+            KP = np.kron(np.eye(self.R), Pk.T)                                    # kron(I, P'): LR x UR
+            FLP = blas.dtrsm(1.0, self.LamFL[k], np.asfortranarray(KP), side=0, lower=1, trans_a=0, diag=0)
+            self.LamFLP.append(FLP)
+            self._block_diag_prod(self.grad, FLP, FLP)
+        self.grad *= -1
+        self.grad_updated = True
+        return self.grad
+
+    def update_hess(self):   # :188-236 (upper triangle)
+        assert self.grad_updated
+        R, U = self.R, self.U
+        H = np.zeros((self.dim, self.dim))
+        for FLP in self.LamFLP:
+            PLiP = FLP.T @ FLP
+            blkU = lambda a, b: PLiP[U * a:U * (a + 1), U * b:U * (b + 1)]
+            for p in range(R):
+                for q in range(p + 1):
+                    b1 = p * (p + 1) // 2 + q
+                    for p2 in range(R):
+                        for q2 in range(p2 + 1):
+                            b2 = p2 * (p2 + 1) // 2 + q2
+                            if b2 < b1:
+                                continue
+                            scal = self.rt2 if ((p == q) != (p2 == q2)) else 1.0
+                            Hv = blkU(p, p2) * blkU(q, q2) * scal
+                            if p != q and p2 != q2:
+                                Hv = Hv + blkU(p, q2) * blkU(q, p2)
+                            H[U * b1:U * (b1 + 1), U * b2:U * (b2 + 1)] += Hv
+        self.hess_ = np.triu(H)
+        self.hess_updated = True
+        return self.hess_
+
+    def _partial_prod(self, prod, arr, use_symm_prod):   # :288-321
+        assert self.grad_updated
+        P, A = _cols(prod), _cols(arr)
+        P[:] = 0
+        for k, Pk in enumerate(self.Ps):
+            Lf, FLP = self.LamFL[k], self.LamFLP[k]
+            for j in range(A.shape[1]):
+                M = self._block_matrix(A[:, j], Pk)
+                M = blas.dtrsm(1.0, Lf, np.asfortranarray(M), side=0, lower=1, trans_a=0, diag=0)      # L \ M
+                M = blas.dtrsm(1.0, Lf, M, side=1, lower=1, trans_a=1, diag=0)                          # (.) / L'
+                M = np.triu(M) + np.triu(M, 1).T                                                        # Symmetric(., :U)
+                LRUR = M @ FLP
+                self._block_diag_prod(P[:, j], LRUR if use_symm_prod else FLP, LRUR)
+        return prod
+
+    def hess_prod_slow(self, prod, arr):   # :238-247
+        if not self.use_hess_prod_slow_updated:
+            self.update_use_hess_prod_slow()
+        assert self.hess_updated
+        if not self.use_hess_prod_slow:
+            return self.hess_prod(prod, arr)
+        return self._partial_prod(prod, arr, False)
+
+    def dder3(self, dir):   # :249-252
+        assert self.grad_updated
+        self._partial_prod(self.dder3_, dir, True)
+        return self.dder3_

@@ -333,6 +333,14 @@ def hypoperlogdettri4():   # :1886-1907
             dict(status="Optimal", primal_obj=0.0, x=[0.0, 1, 1, 0, 1], y=[-2.0], z=[-1.0, -2, 1, 0, 1, 1, 1]))
 
 
+def wsosinterppossemideftri1():   # :2385-2405: convexity parameter of (x + 1)^2 (x - 1)^2 on [-1, 1]
+    U, pts, Ps = pu.interpolate_box([-1.0], [1.0], 1)
+    x = pts[:, 0]
+    h = 12 * x ** 2 - 4                      # second derivative of (x^2 - 1)^2
+    return (np.array([-1.0]), np.zeros((0, 1)), np.zeros(0), np.ones((U, 1)), h,
+            [("wsosinterppossemideftri", 1, U, Ps, False)], dict(status="Optimal", primal_obj=4.0, x=[-4.0]))
+
+
 KNOWN_ANSWER = {
     "dimension1": dimension1, "primalinfeas1": primalinfeas1, "nonnegative4": nonnegative4,
     "possemideftri1": possemideftri1, "possemideftri2": possemideftri2, "possemideftri3": possemideftri3,
@@ -349,6 +357,7 @@ KNOWN_ANSWER = {
     "hyporootdettri1": hyporootdettri1, "hyporootdettri2": hyporootdettri2, "hyporootdettri4": hyporootdettri4,
     "hypoperlogdettri1": hypoperlogdettri1, "hypoperlogdettri2": hypoperlogdettri2, "hypoperlogdettri3": hypoperlogdettri3,
     "hypoperlogdettri4": hypoperlogdettri4,
+    "wsosinterppossemideftri1": wsosinterppossemideftri1,
 }
 
 

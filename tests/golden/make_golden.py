@@ -54,13 +54,18 @@ CONE_CASES["hypoperlogdettri_side5_dual"] = ("hypoperlogdettri", 17, True)
 SEEDS = {"epinormspectral_2x4_dual": 100, "epinormspectral_3x5": 101, "nonnegative_6": 102, "possemideftri_side19": 103,
          "possemideftri_side5": 104, "wsos_2var_halfdeg3": 105, "wsos_2var_halfdeg3_dual": 106, "linmatrixineq_side4_dim5": 107,
          "doublynonnegativetri_side6": 108, "hyporootdettri_side5": 109,
-         "hypoperlogdettri_side5_dual": 110}
+         "hypoperlogdettri_side5_dual": 110, "wsospsd_2var_halfdeg2_R2": 111}
 
 
 def wsos_spec(use_dual):
     rng = np.random.default_rng(5)
     U, pts, Ps = pu.interpolate_box([-1.0, -1.0], [1.0, 1.0], 3, rng=rng, sample_factor=10)
     return ("wsosinterpnonnegative", U, Ps, use_dual)
+
+
+def wsospsd_spec():
+    U, pts, Ps = pu.interpolate_box([-1.0, -1.0], [1.0, 1.0], 2, sample=False)
+    return ("wsosinterppossemideftri", 2, U, Ps, False)
 
 
 def cone_vectors(spec, seed):
@@ -118,6 +123,7 @@ def main():
     specs = {k: v for k, v in cases.items()}
     specs["wsos_2var_halfdeg3"] = wsos_spec(False)
     specs["wsos_2var_halfdeg3_dual"] = wsos_spec(True)
+    specs["wsospsd_2var_halfdeg2_R2"] = wsospsd_spec()
     for name, spec in sorted(specs.items()):
         vec = cone_vectors(spec, seed=SEEDS[name])
         for k, v in vec.items():

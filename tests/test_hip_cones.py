@@ -486,3 +486,60 @@ def test_hypoperlogdettri_vs_oracle(side, use_dual):
             c.load_dual_point(bdual)
             assert not c.is_feas()
             assert not c.is_dual_feas()
+
+
+# ---------------------------------------------------------------------------------------------
+# WSOSInterpPosSemidefTri
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nvars,halfdeg,R", [(1, 1, 1), (1, 1, 4), (2, 2, 1), (3, 1, 2)])
+def test_wsosinterppossemideftri_identities(nvars, halfdeg, R):   # test/cone.jl:775-780
+    import hypatia_jl_amd as H
+    from oracle import polyutils as pu
+    U, _, Ps = pu.interpolate_box([-1.0] * nvars, [1.0] * nvars, halfdeg, sample=False)
+    run_test_oracles(H.WSOSInterpPosSemidefTri(R, U, Ps), init_tol=np.inf)
+
+
+@pytest.mark.parametrize("nvars,halfdeg,R", [(1, 2, 2), (2, 3, 3), (3, 3, 2)])
+def test_wsosinterppossemideftri_vs_oracle(nvars, halfdeg, R):
+    import hypatia_jl_amd as H
+    from oracle import cones as oc
+    from oracle import polyutils as pu
+    U, _, Ps = pu.interpolate_box([-1.0] * nvars, [1.0] * nvars, halfdeg, sample=(None if nvars < 3 else False), rng=np.random.default_rng(5))
+    hc, occ = H.WSOSInterpPosSemidefTri(R, U, Ps), oc.WSOSInterpPosSemidefTri(R, U, Ps)
+    dim = hc.dimension()
+    assert dim == occ.dimension() == U * R * (R + 1) // 2 and hc.get_nu() == occ.get_nu()
+    assert hc.use_dual_barrier() == occ.use_dual_barrier() == True
+    rng = np.random.default_rng(dim)
+    pt, pt2 = np.zeros(dim), np.ones(dim)
+    occ.set_initial_point(pt)
+    hc.set_initial_point(pt2)
+    assert np.array_equal(pt, pt2)
+    pt = pt + 0.1 / R * (2 * rng.random(dim) - 1)
+    dual = pt + 0.03 * (2 * rng.random(dim) - 1)
+    for c in (hc, occ):
+        c.setup_data()
+        c.reset_data()
+        c.load_point(pt, 0.8)
+        c.load_dual_point(dual)
+        assert c.is_feas() and c.is_dual_feas()
+    assert rel(np.array(hc.get_grad()), np.array(occ.get_grad())) < 1e-10
+    V = np.asfortranarray(rng.standard_normal((dim, 3)))
+    for name in ("hess_prod", "inv_hess_prod", "hess_prod_slow"):
+        Ph, Po = np.zeros((dim, 3), order="F"), np.zeros((dim, 3), order="F")
+        getattr(hc, name)(Ph, V)
+        getattr(occ, name)(Po, V)
+        assert rel(Ph, Po) < 1e-8, name
+    assert rel(np.triu(hc.hess()), np.triu(occ.hess())) < 1e-10
+    dv = V[:, 0].copy() * 0.05
+    assert rel(np.array(hc.dder3(dv)), np.array(occ.dder3(dv))) < 1e-9
+    assert hc.check_numerics() == occ.check_numerics()
+    ph, po = hc.get_proxsqr(0.9, True), occ.get_proxsqr(0.9, True)
+    assert abs(ph - po) <= 1e-7 * max(1.0, abs(po))
+    for c in (hc, occ):          # the operator form of the Hessian product (:238-247, forced)
+        c.use_hess_prod_slow = True
+        c.use_hess_prod_slow_updated = True
+    Ph, Po, Pf = (np.zeros((dim, 3), order="F") for _ in range(3))
+    hc.hess_prod_slow(Ph, V)
+    occ.hess_prod_slow(Po, V)
+    hc.hess_prod(Pf, V)
+    assert rel(Ph, Po) < 1e-9 and rel(Ph, Pf) < 1e-8

@@ -7,7 +7,7 @@ from instance_harness import build_solve_check
 
 pytestmark = pytest.mark.gpu
 
-HIP_KINDS = ("nonnegative", "possemideftri", "epinormspectral", "wsosinterpnonnegative", "linmatrixineq", "doublynonnegativetri", "hyporootdettri", "hypoperlogdettri")
+HIP_KINDS = ("nonnegative", "possemideftri", "epinormspectral", "wsosinterpnonnegative", "linmatrixineq", "doublynonnegativetri", "hyporootdettri", "hypoperlogdettri", "wsosinterppossemideftri")
 
 
 def _hip_ok(inst):

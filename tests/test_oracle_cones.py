@@ -151,3 +151,19 @@ def test_hypoperlogdettri_barrier():   # test/cone.jl:657-665
         W = _smat_full(s[2:], side)
         return -np.log(v * np.linalg.slogdet(W / v)[1] - u) - np.log(v) - np.linalg.slogdet(W)[1]
     run_test_barrier(oc.HypoPerLogdetTri(2 + au.svec_length(side)), barrier)
+
+
+@pytest.mark.parametrize("nvars,halfdeg,R", [(1, 1, 1), (1, 1, 4), (2, 2, 1), (3, 1, 2)])
+def test_wsosinterppossemideftri_oracles(nvars, halfdeg, R):   # test/cone.jl:775-780
+    U, _, Ps = pu.interpolate_box([-1.0] * nvars, [1.0] * nvars, halfdeg, sample=False)
+    run_test_oracles(oc.WSOSInterpPosSemidefTri(R, U, Ps), init_tol=np.inf)
+
+
+def test_wsosinterppossemideftri_barrier():   # test/cone.jl:782-803
+    U, _, Ps = pu.interpolate_box([-1.0], [1.0], 1, sample=False)
+    R = 3
+    cone = oc.WSOSInterpPosSemidefTri(R, U, Ps)
+
+    def barrier(s):
+        return -sum(np.linalg.slogdet(cone._block_matrix(s, Pk))[1] for Pk in Ps)
+    run_test_barrier(cone, barrier)
