@@ -104,9 +104,12 @@ def main_multi(args, world, rank, local_rank):
     cones = [D.ShardedCone(comm, r, H.PosSemidefTri(dim) if r == rank else None, dim, side) for r in range(world)]
     model = D.DistModel(comm, c, h, G_r, cones, owners)
     t_setup = time.perf_counter()
-    solver = H.Solver(verbose=args.verbose and rank == 0, syssolver=D.DistQRCholDenseSystemSolver(comm))
-    solver.load(model)
-    solver.setup()
+    from threadpoolctl import threadpool_limits
+    host_threads = max(1, min(args.cpu_threads, (os.cpu_count() or 8) // world))   # untimed host set-up: the ranks share the host cores
+    with threadpool_limits(limits=host_threads, user_api="blas"):
+        solver = H.Solver(verbose=args.verbose and rank == 0, syssolver=D.DistQRCholDenseSystemSolver(comm))
+        solver.load(model)
+        solver.setup()
     t_setup = time.perf_counter() - t_setup
     lib, ctx = H._lib.lib(), H._lib.ctx()
 
