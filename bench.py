@@ -265,6 +265,13 @@ def main():
         "ms_per_kkt_solve": solver.time_getdir / max(n_solves, 1) * 1e3,
         "search_trials_per_step": n_trials / args.steps,
         "setup_s": t_setup,
+        # the reference's ten timers (Solvers.jl:86-96): set-up ones for the whole solve set-up, the others per timed step
+        "hypatia_timers_s": {"rescale": getattr(solver, "time_rescale", 0.0), "initx": getattr(solver, "time_initx", 0.0),
+                             "inity": getattr(solver, "time_inity", 0.0), "unproc": getattr(solver, "time_unproc", 0.0),
+                             "loadsys": getattr(solver, "time_loadsys", 0.0),
+                             "upsys_per_step": solver.time_upsys / args.steps, "upfact_per_step": solver.time_upfact / args.steps,
+                             "uprhs_per_step": solver.time_uprhs / args.steps, "getdir_per_step": solver.time_getdir / args.steps,
+                             "search_per_step": solver.time_search / args.steps},
     }
 
     # the HBM-bound part of the path: the passes over the resident G that every KKT solve is made of

@@ -703,6 +703,74 @@ int hyp_dense_sysv_rook(hyp_ctx* ctx, int n, double* A, int lda, double* x, int 
   c.sync();
   API_END(ctx)
 }
+// Least squares x = argmin || A x - b || for a tall dense A (m x n) known to be well conditioned: Cholesky of A'A on the
+// device, one step of corrected semi-normal equations (x += (R'R)^-1 A'(b - A x)) and an estimate of
+// sigma_min(A) / sigma_max(A) from power iterations with the factor, so that the caller can decide whether to trust it.
+int hyp_dense_lstsq_normal(hyp_ctx* ctx, int m, int n, const double* A, int lda, const double* b, double* x, double* rcond_est, int* info) {
+  API_BEGIN
+  Ctx& c = ctx->c;
+  HYP_REQUIRE(m >= n && n >= 1 && lda >= m, "lstsq_normal: m >= n >= 1");
+  const size_t d = sizeof(double);
+  DBuf dA((size_t)lda * n * d), dC((size_t)n * n * d), dF((size_t)n * n * d), dinv(dinv_elems(n) * d), dinfo(64);
+  DBuf db((size_t)m * d), dr((size_t)m * d), dx((size_t)n * d), dg((size_t)n * d), dv((size_t)n * d);
+  c.h2d(dA.p, A, (size_t)lda * n * d);
+  c.h2d(db.p, b, (size_t)m * d);
+  GemmArgs g{};   // C = A'A (upper)
+  g.M = n; g.N = n; g.K = m; g.A = dA.d(); g.lda = lda; g.B = dA.d(); g.ldb = lda; g.C = dC.d(); g.ldc = n;
+  g.alpha = 1; g.beta = 0; g.tri = GEMM_UPPER; g.krange = KR_ALL; g.batch = 1; g.tag = 1;
+  gemm(c, true, g);
+  c.d2d(dF.p, dC.p, (size_t)n * n * d);
+  potrf_upper_batched(c, n, dF.d(), n, 0, 1, dinv.d(), dinfo.i());
+  c.d2h(c.h_info, dinfo.p, sizeof(int));
+  c.sync();
+  *info = c.h_info[0];
+  *rcond_est = 0.0;
+  if (*info == 0) {
+    TriSolvePlan tri;
+    const bool plan = (c.trsv_sb > 0 && n >= 2 * c.trsv_sb);
+    if (plan) tri.build(c, n, dF.d(), n, dinv.d());
+    auto solve = [&](double* v) {
+      for (int pass = 0; pass < 2; ++pass) {
+        if (plan) tri.solve(c, dF.d(), n, pass == 0, v);
+        else trsv_upper(c, n, dF.d(), n, dinv.d(), pass == 0, v);
+      }
+    };
+    gemv(c, true, m, n, 1.0, dA.d(), lda, db.d(), 0.0, dx.d());           // x = (R'R)^-1 A'b
+    solve(dx.d());
+    c.d2d(dr.p, db.p, (size_t)m * d);                                     // r = b - A x
+    gemv(c, false, m, n, -1.0, dA.d(), lda, dx.d(), 1.0, dr.d());
+    gemv(c, true, m, n, 1.0, dA.d(), lda, dr.d(), 0.0, dg.d());           // x += (R'R)^-1 A'r
+    solve(dg.d());
+    dev_axpby(c, n, 1.0, dg.d(), 1.0, dx.d());
+    // extreme eigenvalues of A'A: power iteration with C (completed to both triangles) and inverse iteration with the factor
+    dev_symmetrize_from_upper(c, n, dC.d(), n, 1, 0);
+    std::vector<double> h(n);
+    for (int i = 0; i < n; ++i) h[i] = 1.0 + 0.5 * ((i * 2654435761u) % 1000) / 1000.0;
+    double lmax = 0.0, lmin_inv = 0.0;
+    for (int which = 0; which < 2; ++which) {
+      c.h2d(dv.p, h.data(), (size_t)n * d);
+      double lam = 0.0;
+      for (int it = 0; it < 8; ++it) {
+        dev_dot(c, n, dv.d(), dv.d(), c.dscal.d());
+        c.d2h(c.h_pinned, c.dscal.p, d);
+        c.sync();
+        const double nv = std::sqrt(c.h_pinned[0]);
+        dev_scale_copy(c, n, 1.0 / nv, dv.d(), dg.d());
+        if (which == 0) gemv(c, false, n, n, 1.0, dC.d(), n, dg.d(), 0.0, dv.d());
+        else { c.d2d(dv.p, dg.p, (size_t)n * d); solve(dv.d()); }
+        dev_dot(c, n, dg.d(), dv.d(), c.dscal.d());                       // Rayleigh quotient
+        c.d2h(c.h_pinned, c.dscal.p, d);
+        c.sync();
+        lam = c.h_pinned[0];
+      }
+      if (which == 0) lmax = lam; else lmin_inv = lam;
+    }
+    if (lmax > 0 && lmin_inv > 0) *rcond_est = std::sqrt(1.0 / (lmin_inv * lmax));
+    c.d2h(x, dx.p, (size_t)n * d);
+    c.sync();
+  }
+  API_END(ctx)
+}
 int hyp_dense_gemv(hyp_ctx* ctx, int trans, int m, int n, double alpha, const double* A, int lda, const double* x, double beta,
                    double* y) {
   API_BEGIN

@@ -226,6 +226,12 @@ int hyp_dense_posv(hyp_ctx* ctx, int n, double* A, int lda, double* x, int* info
  * info = 0, or the 1-based position of the first exactly singular pivot (LAPACK dsytrf_rook). */
 int hyp_dense_sysv_rook(hyp_ctx* ctx, int n, double* A, int lda, double* x, int nrhs, int ldx, int* info, int* perm, int* blk,
                         double* d, double* e);
+/* Set-up helper for find_initial_x (src/Solvers/process.jl:64-178): least squares x = argmin ||A x - b|| for a tall, dense,
+ * well-conditioned A (m x n col-major, host pointers) by the Cholesky factorization of A'A on the device with one step of
+ * corrected semi-normal equations; rcond_est ~ sigma_min(A) / sigma_max(A) from power iterations, info = dpotrf's.  The
+ * reference uses a column-pivoted QR there (also to detect dependent columns): the caller takes this x only when info = 0
+ * and rcond_est is far from the rank-decision threshold, and otherwise runs the reference's pivoted QR on the host. */
+int hyp_dense_lstsq_normal(hyp_ctx* ctx, int m, int n, const double* A, int lda, const double* b, double* x, double* rcond_est, int* info);
 int hyp_dense_gemv(hyp_ctx* ctx, int trans, int m, int n, double alpha, const double* A, int lda, const double* x, double beta,
                    double* y);
 /* Measurement helper: HIP-event time (ms, mean of reps) of the blocked upper Cholesky of an n x n positive definite matrix

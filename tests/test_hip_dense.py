@@ -156,3 +156,24 @@ def test_two_contexts_are_independent(hip):
             assert info.value == 0 and np.linalg.norm(S @ x - b) <= 1e-10 * np.linalg.norm(b) * np.linalg.cond(S)
     finally:
         assert lib.hyp_ctx_destroy(h2) == 0
+
+
+@pytest.mark.parametrize("m,n", [(2500, 600), (9000, 2100)])
+def test_lstsq_normal_matches_qr_and_estimates_conditioning(hip, m, n):
+    """set-up helper of find_initial_x: Cholesky of A'A + one corrected semi-normal-equations step on the device"""
+    lib, ctx, L = hip
+    rng = np.random.default_rng(m)
+    A = np.asfortranarray(rng.standard_normal((m, n)) / np.sqrt(n))
+    b = rng.standard_normal(m)
+    x, rc, info = np.zeros(n), ctypes.c_double(0), c_int(-1)
+    L.check(lib.hyp_dense_lstsq_normal(ctx, m, n, fp(A), m, fp(b), fp(x), ctypes.byref(rc), ctypes.byref(info)), "lstsq_normal")
+    xref = np.linalg.lstsq(A, b, rcond=None)[0]
+    sv = np.linalg.svd(A, compute_uv=False)
+    assert info.value == 0
+    assert np.linalg.norm(x - xref) <= 1e-12 * np.linalg.norm(xref)
+    assert 0.5 * sv[-1] / sv[0] <= rc.value <= 1.5 * sv[-1] / sv[0]
+    # nearly dependent columns: the estimate says so (the caller then takes the reference's pivoted QR)
+    A2 = A.copy(order="F")
+    A2[:, -1] = A2[:, 0] + 1e-7 * A2[:, 1]
+    L.check(lib.hyp_dense_lstsq_normal(ctx, m, n, fp(A2), m, fp(b), fp(x), ctypes.byref(rc), ctypes.byref(info)), "lstsq_normal")
+    assert info.value != 0 or rc.value < 1e-5
