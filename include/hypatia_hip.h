@@ -120,6 +120,8 @@ int hyp_symindef_update_lhs(hyp_symindef* sys, int* info, int* used_fallback);
 int hyp_symindef_solve3(hyp_symindef* sys, double* sol_vec, const double* rhs_vec);
 /* y = alpha * op(G) x + beta * y on the device-resident G (trans != 0: op(G) = G'), for the residuals the driver computes */
 int hyp_symindef_mul_G(hyp_symindef* sys, int trans, double alpha, const double* x, double beta, double* y);
+/* y = alpha * op(G) x + beta * y on the device-resident G (trans != 0: op(G) = G'), for the residuals the driver computes */
+int hyp_symindef_mul_G(hyp_symindef* sys, int trans, double alpha, const double* x, double beta, double* y);
 int hyp_symindef_get_lhs(hyp_symindef* sys, double* out_npqxnpq);   /* upper triangle meaningful (tests) */
 /* load (qrchol.jl:138-179): G = model.G (q x n).  When p == 0 pass NULL for GQ1, GQ2, Q, R (GQ2 = G,
  * Ap_Q = I).  Otherwise Q = Ap_Q (n x n), R = Ap_R (p x p), and either GQ1 = (G*Ap_Q)[:, 1:p], GQ2 = (G*Ap_Q)[:, p+1:n]

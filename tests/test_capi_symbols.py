@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     txt = open(os.path.join(ROOT, "include", "hypatia_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(hyp_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(hyp_[A-Za-z0-9_]+)\s*\(", txt)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -49,3 +49,36 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+
+
+def _declared_prototypes():
+    """{name: number of parameters} parsed from include/hypatia_hip.h"""
+    txt = open(os.path.join(ROOT, "include", "hypatia_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(hyp_[A-Za-z0-9_]+)\s*\(", txt):
+        name, i, depth = m.group(1), m.end(), 1
+        j = i
+        while depth:                       # matching parenthesis of the parameter list (function-pointer parameters nest)
+            depth += {"(": 1, ")": -1}.get(txt[j], 0)
+            j += 1
+        params = txt[i:j - 1].strip()
+        if params in ("", "void"):
+            out[name] = 0
+            continue
+        n, depth = 1, 0
+        for ch in params:
+            depth += {"(": 1, ")": -1}.get(ch, 0)
+            if ch == "," and depth == 0:
+                n += 1
+        out[name] = n
+    return out
+
+
+def test_ctypes_signatures_match_the_header():
+    """the ctypes table of the Python mirror declares as many parameters as the C prototypes (ABI drift guard)"""
+    import hypatia_jl_amd as H
+    protos = _declared_prototypes()
+    for name, argtypes in H._lib.SIGNATURES.items():
+        assert name in protos, name + " is bound but not declared in include/hypatia_hip.h"
+        assert len(argtypes) == protos[name], (name, len(argtypes), protos[name])
