@@ -52,6 +52,19 @@ double Cone::get_proxsqr(double irtmu, bool) {   // Cones.jl:294-310
   return fabs(prox_sqr);
 }
 
+bool Cone::prox_launch(double irtmu, double* d_out3) {   // the device work of check_numerics + get_proxsqr, no host round trip
+  const double* g = get_grad();
+  dev_dot(ctx, dim, g, point.d(), d_out3);
+  if (!inv_hess_ready()) return false;
+  inv_hess_prod(vec1.d(), dim, g, dim, 1);
+  dev_dot(ctx, dim, vec1.d(), g, d_out3 + 1);
+  ctx.d2d(vec1.p, g, (size_t)dim * sizeof(double));
+  dev_axpby(ctx, dim, irtmu, dual_point.d(), 1.0, vec1.d());
+  inv_hess_prod(vec2.d(), dim, vec1.d(), dim, 1);
+  dev_dot(ctx, dim, vec2.d(), vec1.d(), d_out3 + 2);
+  return true;
+}
+
 void Cone::hess_explicit(double* d_out, long ld) {
   DBuf eye((size_t)dim * dim * sizeof(double));
   dev_fill_identity(ctx, dim, eye.d(), dim);

@@ -70,6 +70,11 @@ struct Cone {
   // Cones.jl:273-310 (generic; Nonnegative overrides get_proxsqr)
   virtual bool check_numerics();
   virtual double get_proxsqr(double irtmu, bool use_max_prox);
+  // The three scalar products those two tests consist of -- <g, point>, <H^-1 g, g>, <H^-1 v, v> with v = irtmu dual + g --
+  // queued into d_out3 (device) without a synchronisation, so that a sweep over many cones reads them all back at once;
+  // false: no usable inverse Hessian (the caller counts the cone as failed).  Cones with their own get_proxsqr opt out.
+  virtual bool prox_batchable() { return true; }
+  bool prox_launch(double irtmu, double* d_out3);
   // false when inv_hess_prod has no usable factorization at this point (generic cones whose explicit
   // Hessian fails both its Cholesky and its Bunch-Kaufman factorization, Cones.jl:239-251: the
   // reference's ldiv! throws a SingularException there; here the trial point is rejected)
@@ -91,6 +96,7 @@ struct NonnegCone : Cone {   // src/Cones/nonnegative.jl
   void inv_sqrt_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;
   const double* dder3(const double* d_dir) override;
   double get_proxsqr(double irtmu, bool use_max_prox) override;
+  bool prox_batchable() override { return false; }
 };
 
 struct PsdCone : Cone {   // src/Cones/possemideftri.jl (real symmetric)

@@ -514,7 +514,39 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
       if (launched[k]) cones[k]->prefetch_finish((int)k);
     *n_loaded = (int)nc;
   }
-  for (size_t k = 0; k < nc && !local_reject; ++k) {                                  // :118-136
+  // several cones, all with the generic proximity test: after the batched feasibility flags, the scalar products of
+  // check_numerics / get_proxsqr are queued for a chunk of cones and read back with one synchronisation (three per cone
+  // otherwise); the tests are then evaluated in the reference's order.  Same decision: a trial is rejected iff some cone fails.
+  bool batched_prox = (nc > 1 && !local_reject);
+  for (size_t k = 0; k < nc && batched_prox; ++k) batched_prox = cones[k]->prox_batchable();
+  if (batched_prox) {
+    for (size_t k = 0; k < nc && ok; ++k)
+      if (!(cones[k]->is_feas() && cones[k]->is_dual_feas())) ok = false;          // (answered by the prefetch above)
+    if (ok) {
+      // in chunks of 8 cones: most rejected trials fail the proximity bound at one of the first cones, and the
+      // reference's sweep stops there -- a chunk bounds the work queued beyond that point
+      const size_t CHK = 8;
+      prox_scal.ensure(3 * CHK * sizeof(double));
+      const double gtol = std::sqrt(std::sqrt(EPS)), Htol = 10 * std::sqrt(gtol), negtol = std::sqrt(EPS);
+      for (size_t k0 = 0; k0 < nc && ok; k0 += CHK) {
+        const size_t k1 = std::min(nc, k0 + CHK);
+        for (size_t k = k0; k < k1 && ok; ++k)
+          if (!cones[k]->prox_launch(irtmu, prox_scal.d() + 3 * (k - k0))) ok = false;
+        if (!ok) break;
+        ctx.d2h(ctx.h_pinned, prox_scal.p, 3 * (k1 - k0) * sizeof(double));
+        ctx.sync();
+        for (size_t k = k0; k < k1; ++k) {
+          const double dk = cones[k]->dim, nuk = cones[k]->nu;
+          const double* hp = ctx.h_pinned + 3 * (k - k0);
+          if (std::fabs(1 + hp[0] / nuk) > gtol * dk || std::fabs(1 - hp[1] / nuk) > Htol * dk) { ok = false; break; }   // Cones.jl:273-290
+          const double pk = (hp[2] < -negtol * dk) ? INFINITY : std::fabs(hp[2]);                                        // Cones.jl:294-310
+          agg = use_max_prox ? std::max(agg, pk) : agg + pk;
+          if (!dist() && !(agg < proxsqr_bound)) { ok = false; break; }
+        }
+      }
+    }
+  }
+  for (size_t k = 0; k < nc && !local_reject && !batched_prox; ++k) {                 // :118-136
     Cone* ck = cones[k];
     if (nc == 1) {
       ck->load_point((ck->use_dual_barrier ? dz : dsv) + offs[k], irtmu);

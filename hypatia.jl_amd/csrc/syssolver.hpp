@@ -26,6 +26,7 @@ struct SysSolver {
   DBuf QpbxGHbz, Gx, HGx, GQ1x, HGQ1x, tmpn, sol, rhs, tmpq;
   std::vector<int> use_sqrt;
   bool fact_ok = false;
+  DBuf prox_scal;         // 3 scalars per cone of the batched proximity test of check_cone_points
   BKFact bk;              // the factorization after a failed Cholesky (posdef_fact_copy!, dense.jl:194-215)
   bool use_bk = false;    // lhs_fact holds U of P lhs P' = U' D U instead of the Cholesky factor
   DBuf bk_work;
