@@ -4,6 +4,7 @@
 // Python glue only forwards calls.  All array arguments are DEVICE pointers; the C-ABI wrappers in
 // capi.hip stage host buffers.
 #pragma once
+#include <memory>
 #include "hyp_internal.hpp"
 
 namespace hyp {
@@ -112,6 +113,10 @@ struct PsdCone : Cone {   // src/Cones/possemideftri.jl (real symmetric)
   DBuf tmpmat, tmpmat2, d_info;
   DBuf ws1, ws2; // batched workspaces (chunk * side^2)
   bool inv_ready = false;   // Uinv / UinvT / Xinv computed for the current point
+  // A run of equal cones of one model keeps X, U, U', U^-1, U^-T, X^-1 and the inverted diagonal blocks of all its members
+  // in one arena (member g at offset g * side^2), so that the group's inverses are ONE batched launch sequence
+  // (SysSolver::group_inverses); the cones hold the arena alive.
+  std::shared_ptr<DBuf> group_arena;
   bool dual_cached = false, dual_feas_ = false;   // is_dual_feas() answered ahead of time by prefetch_feas()
   PsdCone(Ctx& c, int dim);
   void reset_data() override {

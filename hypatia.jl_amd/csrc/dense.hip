@@ -98,9 +98,9 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
   if (dinv) potrf_invert_diag_blocks(c, n, A, lda, strideA, batch, dinv);
 }
 
-void potrf_invert_diag_blocks(Ctx& c, int n, double* A, long lda, long strideA, int batch, double* dinv) {
+void potrf_invert_diag_blocks(Ctx& c, int n, double* A, long lda, long strideA, int batch, double* dinv, long strideD) {
   const int nblk = (n + NB - 1) / NB;
-  potrf_diag_launch(c.stream, false, true, batch, nblk, A, lda, strideA, n, 0, dinv, (long)dinv_elems(n), nullptr);
+  potrf_diag_launch(c.stream, false, true, batch, nblk, A, lda, strideA, n, 0, dinv, strideD > 0 ? strideD : (long)dinv_elems(n), nullptr);
 }
 
 // ---- diagonal block solve of the blocked substitution -----------------------------------------

@@ -32,9 +32,10 @@ struct HipError : std::runtime_error {
 struct DBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  bool owned = true;   // false: a view into storage owned elsewhere (a group arena), never freed or regrown here
   DBuf() {}
   explicit DBuf(size_t nbytes) { alloc(nbytes); }
-  DBuf(DBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DBuf(DBuf&& o) noexcept : p(o.p), bytes(o.bytes), owned(o.owned) { o.p = nullptr; o.bytes = 0; o.owned = true; }
   DBuf(const DBuf&) = delete;
   DBuf& operator=(const DBuf&) = delete;
   ~DBuf() { release(); }
@@ -48,9 +49,16 @@ struct DBuf {
     if (nbytes > bytes) alloc(nbytes);
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && owned) (void)hipFree(p);
     p = nullptr;
     bytes = 0;
+    owned = true;
+  }
+  void view(void* ptr, size_t nbytes) {   // drop the own allocation and look at [ptr, ptr + nbytes) instead
+    release();
+    p = ptr;
+    bytes = nbytes;
+    owned = false;
   }
   double* d() const { return (double*)p; }
   int* i() const { return (int*)p; }
@@ -120,7 +128,8 @@ struct StreamSwap {
 // d_info[b] = 0 or the 1-based index of the first non-positive pivot (LAPACK dpotrf convention).
 // dinv == nullptr: factor only (feasibility checks); potrf_invert_diag_blocks produces the block inverses later.
 void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int batch, double* dinv, int* d_info);
-void potrf_invert_diag_blocks(Ctx& c, int n, double* A /* factored */, long lda, long strideA, int batch, double* dinv);
+void potrf_invert_diag_blocks(Ctx& c, int n, double* A /* factored */, long lda, long strideA, int batch, double* dinv,
+                              long strideD = 0 /* doubles between the batch members' dinv; 0: dinv_elems(n) */);
 constexpr long DINV_BLK = 2L * NB * NB;
 inline size_t dinv_elems(int n) { return (size_t)((n + NB - 1) / NB) * DINV_BLK; }
 

@@ -19,6 +19,7 @@ SysSolver::SysSolver(Ctx& c, int n_, int p_, int q_, const std::vector<Cone*>& c
   for (size_t k = 0; k < cones.size(); ++k) offs[k + 1] = offs[k] + cones[k]->dim;
   HYP_REQUIRE(offs.back() == q, "sys: cone dimensions do not sum to q");
   use_sqrt.assign(cones.size(), 0);
+  make_psd_runs();
   const size_t d = sizeof(double);
   G.alloc((size_t)q * n * d);
   if (p > 0) {
@@ -41,6 +42,73 @@ SysSolver::SysSolver(Ctx& c, int n_, int p_, int q_, const std::vector<Cone*>& c
   tmpq.alloc((size_t)std::max(q, 1) * d);
   sol.alloc((size_t)(n + p + q + 1) * d);
   rhs.alloc((size_t)(n + p + q + 1) * d);
+}
+
+// Runs of equal PSD cones: one arena per run, the members' matrices become views into it (see PsdCone::group_arena).
+void SysSolver::make_psd_runs() {
+  static const bool on = [] { const char* e = getenv("HYP_PSD_GROUP"); return !(e && e[0] == '0'); }();
+  if (!on) return;
+  size_t k = 0;
+  while (k < cones.size()) {
+    PsdCone* pk = (cones[k]->kind == CONE_PSD) ? static_cast<PsdCone*>(cones[k]) : nullptr;
+    size_t e = k + 1;
+    if (pk)
+      while (e < cones.size() && cones[e]->kind == CONE_PSD && static_cast<PsdCone*>(cones[e])->side == pk->side) ++e;
+    const int cnt = (int)(e - k);
+    if (pk && cnt >= 4) {
+      const long s2 = (long)pk->side * pk->side;
+      const long dv = 2 * (long)dinv_elems(pk->side);
+      auto arena = std::make_shared<DBuf>((size_t)cnt * (6 * s2 + dv) * sizeof(double));
+      ctx.zero(arena->p, arena->bytes);
+      double* base = arena->d();
+      PsdRun r{(int)k, cnt, pk->side, base, base + cnt * s2, base + 2 * cnt * s2, base + 3 * cnt * s2, base + 4 * cnt * s2, base + 5 * cnt * s2,
+               base + 6 * cnt * s2};
+      for (int g = 0; g < cnt; ++g) {   // the members' matrices move into the arena with their contents (cached factor, inverses)
+        PsdCone* c = static_cast<PsdCone*>(cones[k + g]);
+        auto move_in = [&](DBuf& b, double* dst, long count) {
+          ctx.d2d(dst, b.p, (size_t)count * sizeof(double));
+          ctx.sync();   // (the old allocation is released right below)
+          b.view(dst, (size_t)count * sizeof(double));
+        };
+        move_in(c->X, r.X + g * s2, s2);
+        move_in(c->U, r.U + g * s2, s2);
+        move_in(c->UT, r.UT + g * s2, s2);
+        move_in(c->Uinv, r.Uinv + g * s2, s2);
+        move_in(c->UinvT, r.UinvT + g * s2, s2);
+        move_in(c->Xinv, r.Xinv + g * s2, s2);
+        move_in(c->dinvb, r.dinvb + g * dv, dv);
+        c->group_arena = arena;   // (a previous arena, if any, is released with its last member)
+      }
+      psd_runs.push_back(r);
+    }
+    k = e;
+  }
+}
+
+// PsdCone::ensure_inverses (possemideftri.jl:97-107, 126-177 need U^-1, X^-1) for whole runs at once: the same seven launches
+// as for one cone, with batch = members.  Runs with an infeasible, not yet factored or already inverted member are left
+// to the per-cone path.
+void SysSolver::group_inverses() {
+  for (const PsdRun& r : psd_runs) {
+    bool all = true;
+    for (int g = 0; g < r.count && all; ++g) {
+      PsdCone* c = static_cast<PsdCone*>(cones[r.k0 + g]);
+      all = c->feas_updated && c->is_feas_ && !c->inv_ready && c->U.p == (void*)(r.U + (long)g * r.side * r.side);
+    }
+    if (!all) continue;
+    const int s = r.side, B = r.count;
+    const long s2 = (long)s * s, dv = 2 * (long)dinv_elems(s);
+    dev_zero_strict_lower(ctx, s, r.U, s, B, s2);
+    potrf_invert_diag_blocks(ctx, s, r.U, s, s2, B, r.dinvb, dv);
+    trtri_upper_batched(ctx, s, r.U, s, s2, r.dinvb, dv, r.Uinv, s, s2, B);
+    dev_transpose(ctx, s, s, r.Uinv, s, r.UinvT, s, B, s2, s2);
+    dev_transpose(ctx, s, s, r.U, s, r.UT, s, B, s2, s2);
+    GemmArgs g{};   // Xinv = Uinv Uinv'
+    g.M = s; g.N = s; g.K = s; g.A = r.Uinv; g.lda = s; g.strideA = s2; g.B = r.UinvT; g.ldb = s; g.strideB = s2;
+    g.C = r.Xinv; g.ldc = s; g.strideC = s2; g.alpha = 1; g.beta = 0; g.tri = GEMM_FULL; g.krange = KR_GE_M; g.batch = B;
+    gemm(ctx, false, g);
+    for (int gi = 0; gi < B; ++gi) static_cast<PsdCone*>(cones[r.k0 + gi])->inv_ready = true;
+  }
 }
 
 void SysSolver::load(const double* hG, const double* hGQ1, const double* hGQ2, const double* hQ, const double* hR) {
@@ -114,7 +182,8 @@ void SysSolver::update_lhs_fact(int* info, int* used_fallback) {   // qrchol.jl:
   factor_lhs(info, used_fallback);
 }
 
-void SysSolver::assemble_lhs() {   // qrchol.jl:214-246 (this process's cones only; the multi-GPU glue sums the result)
+void SysSolver::assemble_lhs() {
+  group_inverses();   // qrchol.jl:214-246 (this process's cones only; the multi-GPU glue sums the result)
   if (nmp == 0) return;
   const double* gq2 = GQ2();
   for (size_t k = 0; k < cones.size(); ++k) use_sqrt[k] = cones[k]->use_sqrt_hess_oracles(nmp) ? 1 : 0;   // :214-216
@@ -523,6 +592,7 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
     for (size_t k = 0; k < nc && ok; ++k)
       if (!(cones[k]->is_feas() && cones[k]->is_dual_feas())) ok = false;          // (answered by the prefetch above)
     if (ok) {
+      group_inverses();   // runs of equal PSD cones: U^-1, X^-1 of all members in one batched launch sequence
       // in chunks of 8 cones: most rejected trials fail the proximity bound at one of the first cones, and the
       // reference's sweep stops there -- a chunk bounds the work queued beyond that point
       const size_t CHK = 8;

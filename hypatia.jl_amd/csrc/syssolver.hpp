@@ -26,6 +26,11 @@ struct SysSolver {
   DBuf QpbxGHbz, Gx, HGx, GQ1x, HGQ1x, tmpn, sol, rhs, tmpq;
   std::vector<int> use_sqrt;
   bool fact_ok = false;
+  // runs of >= 4 consecutive PosSemidefTri cones of equal side (config 4: 64 x side 80): group-owned storage, batched inverses
+  struct PsdRun { int k0, count, side; double *X, *U, *UT, *Uinv, *UinvT, *Xinv, *dinvb; };
+  std::vector<PsdRun> psd_runs;
+  void make_psd_runs();
+  void group_inverses();   // ensure_inverses() of every run whose members are all feasible and not yet inverted, batched
   DBuf prox_scal;         // 3 scalars per cone of the batched proximity test of check_cone_points
   BKFact bk;              // the factorization after a failed Cholesky (posdef_fact_copy!, dense.jl:194-215)
   bool use_bk = false;    // lhs_fact holds U of P lhs P' = U' D U instead of the Cholesky factor

@@ -44,7 +44,8 @@ def _trajectory(solver_cls, model, **opts):
     return s, np.array(rows)
 
 
-@pytest.mark.parametrize("n,sides,seed", [(30, [6, 4], 1), (60, [10, 8, 3], 2), (150, [24, 17], 3)])
+@pytest.mark.parametrize("n,sides,seed", [(30, [6, 4], 1), (60, [10, 8, 3], 2), (150, [24, 17], 3),
+                                          (50, [7, 7, 7, 7, 7], 4), (60, [5, 8, 8, 8, 8, 3], 5)])   # (runs of equal cones: group arena, batched inverses)
 def test_trajectory_parity_psd(n, sides, seed):
     """Iterate-by-iterate parity with the CPU oracle.  Bar: identical status, iteration count and
     line-search step sizes; objective / mu / tau / residual norms agree to 1e-10 relative while the
