@@ -361,6 +361,7 @@ void SysSolver::solve3_multi(double* sol, const double* rhs, int nr) {
   gemv_multi(ctx, false, q, n, nr, 1.0, G.d(), q, sol, ld3, 0.0, m_Gx.d(), q);
   for (size_t k = 0; k < cones.size(); ++k) {
     Cone* ck = cones[k];
+    if (const int used = run_hess_prod(k, m_HGx.d() + offs[k], q, m_Gx.d() + offs[k], q, nr)) { k += used - 1; continue; }
     if (ck->use_dual_barrier) ck->inv_hess_prod(m_HGx.d() + offs[k], q, m_Gx.d() + offs[k], q, nr);
     else ck->hess_prod(m_HGx.d() + offs[k], q, m_Gx.d() + offs[k], q, nr);
   }
@@ -435,6 +436,9 @@ void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double
         dev_axpby(ctx, dk, -1.0, rhs + (long)r * dv + os + o, 1.0, tmp);
       }
       ck->inv_hess_prod(sr + oz + o, ld3, ss + oz + o, ld3, MR);
+    } else if (const int used = run_hess_prod(k, sr + oz + o, ld3, rhs + oz + o, dv, MR)) {
+      for (int r = 0; r < MR; ++r) dev_axpby(ctx, offs[k + used] - o, -1.0, rhs + (long)r * dv + os + o, -1.0, sr + r * ld3 + oz + o);
+      k += used - 1;
     } else {
       ck->hess_prod(sr + oz + o, ld3, rhs + oz + o, dv, MR);
       for (int r = 0; r < MR; ++r) dev_axpby(ctx, dk, -1.0, rhs + (long)r * dv + os + o, -1.0, sr + r * ld3 + oz + o);
@@ -495,6 +499,11 @@ void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double
       Cone* ck = cones[k];
       const int o = offs[k], dk = ck->dim;
       const int po = ck->use_dual_barrier ? oz + o : os + o, du = ck->use_dual_barrier ? os + o : oz + o;
+      if (const int used = run_hess_prod(k, res + os + o, dv, dir + po, dv, MR)) {   // (PosSemidefTri: hess_prod_slow! = hess_prod!)
+        for (int r = 0; r < MR; ++r) dev_axpby(ctx, offs[k + used] - o, 1.0, dir + (long)r * dv + du, 1.0, res + (long)r * dv + os + o);
+        k += used - 1;
+        continue;
+      }
       ck->hess_prod_slow(res + os + o, dv, dir + po, dv, MR);
       for (int r = 0; r < MR; ++r) dev_axpby(ctx, dk, 1.0, dir + (long)r * dv + du, 1.0, res + (long)r * dv + os + o);
     }

@@ -58,11 +58,12 @@ void SysSolver::make_psd_runs() {
     if (pk && cnt >= 4) {
       const long s2 = (long)pk->side * pk->side;
       const long dv = 2 * (long)dinv_elems(pk->side);
-      auto arena = std::make_shared<DBuf>((size_t)cnt * (6 * s2 + dv) * sizeof(double));
+      const long dm = pk->dim;
+      auto arena = std::make_shared<DBuf>((size_t)cnt * (6 * s2 + dv + 2 * dm) * sizeof(double));
       ctx.zero(arena->p, arena->bytes);
       double* base = arena->d();
       PsdRun r{(int)k, cnt, pk->side, base, base + cnt * s2, base + 2 * cnt * s2, base + 3 * cnt * s2, base + 4 * cnt * s2, base + 5 * cnt * s2,
-               base + 6 * cnt * s2};
+               base + 6 * cnt * s2, base + 6 * cnt * s2 + cnt * dv, base + 6 * cnt * s2 + cnt * dv + cnt * dm};
       for (int g = 0; g < cnt; ++g) {   // the members' matrices move into the arena with their contents (cached factor, inverses)
         PsdCone* c = static_cast<PsdCone*>(cones[k + g]);
         auto move_in = [&](DBuf& b, double* dst, long count) {
@@ -77,6 +78,8 @@ void SysSolver::make_psd_runs() {
         move_in(c->UinvT, r.UinvT + g * s2, s2);
         move_in(c->Xinv, r.Xinv + g * s2, s2);
         move_in(c->dinvb, r.dinvb + g * dv, dv);
+        move_in(c->point, r.point + g * dm, dm);
+        move_in(c->dual_point, r.dual + g * dm, dm);
         c->group_arena = arena;   // (a previous arena, if any, is released with its last member)
       }
       psd_runs.push_back(r);
@@ -109,6 +112,91 @@ void SysSolver::group_inverses() {
     gemm(ctx, false, g);
     for (int gi = 0; gi < B; ++gi) static_cast<PsdCone*>(cones[r.k0 + gi])->inv_ready = true;
   }
+}
+
+// out[3 g + off] = <a_g, b_g> over the members' consecutive segments of length len; one wavefront per member
+__global__ __launch_bounds__(256) void seg_dot3_kernel(int B, int len, const double* __restrict__ a, const double* __restrict__ b, int off,
+                                                       double* __restrict__ out) {
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (g >= B) return;
+  const double* x = a + (long)g * len;
+  const double* y = b + (long)g * len;
+  double s0 = 0.0, s1 = 0.0;
+  int i = lane;
+  for (; i + 64 < len; i += 128) { s0 += x[i] * y[i]; s1 += x[i + 64] * y[i + 64]; }
+  if (i < len) s0 += x[i] * y[i];
+  double s = s0 + s1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if (lane == 0) out[3 * g + off] = s;
+}
+
+void SysSolver::run_prox_launch(const PsdRun& r, double irtmu, double* d_out) {
+  const int s = r.side, B = r.count, dm = cones[r.k0]->dim;
+  const long s2 = (long)s * s, tot = (long)B * dm;
+  for (DBuf* b : {&run_ws1, &run_ws2}) b->ensure((size_t)B * s2 * sizeof(double));
+  for (DBuf* b : {&run_g, &run_v, &run_h}) b->ensure((size_t)tot * sizeof(double));
+  double* W1 = run_ws1.d();
+  double* W2 = run_ws2.d();
+  auto xvx = [&](const double* v, double* out) {   // PsdCone::inv_hess_prod (possemideftri.jl:144-159) for every member: svec(X smat(v) X)
+    svec_unpack(ctx, s, B, v, dm, W1);
+    GemmArgs a{};
+    a.M = s; a.N = s; a.K = s; a.A = W1; a.lda = s; a.strideA = s2; a.B = r.X; a.ldb = s; a.strideB = s2; a.C = W2; a.ldc = s; a.strideC = s2;
+    a.alpha = 1; a.beta = 0; a.tri = GEMM_FULL; a.krange = KR_ALL; a.batch = B;
+    gemm(ctx, true, a);
+    GemmArgs b{};
+    b.M = s; b.N = s; b.K = s; b.A = r.X; b.lda = s; b.strideA = s2; b.B = W2; b.ldb = s; b.strideB = s2; b.C = W1; b.ldc = s; b.strideC = s2;
+    b.alpha = 1; b.beta = 0; b.tri = GEMM_FULL; b.krange = KR_ALL; b.batch = B;
+    gemm(ctx, true, b);
+    svec_pack(ctx, s, B, W1, out, dm, 1.0);
+  };
+  const dim3 grid((B + 3) / 4), blk(256);
+  svec_pack(ctx, s, B, r.Xinv, run_g.d(), dm, -1.0);                                   // g = -svec(X^-1)  (possemideftri.jl:97-107)
+  hipLaunchKernelGGL(seg_dot3_kernel, grid, blk, 0, ctx.stream, B, dm, run_g.d(), r.point, 0, d_out);      // <g, point>
+  xvx(run_g.d(), run_h.d());
+  hipLaunchKernelGGL(seg_dot3_kernel, grid, blk, 0, ctx.stream, B, dm, run_h.d(), run_g.d(), 1, d_out);    // <H^-1 g, g>
+  ctx.d2d(run_v.p, run_g.p, (size_t)tot * sizeof(double));                             // v = irtmu dual + g
+  dev_axpby(ctx, (int)tot, irtmu, r.dual, 1.0, run_v.d());
+  xvx(run_v.d(), run_h.d());
+  hipLaunchKernelGGL(seg_dot3_kernel, grid, blk, 0, ctx.stream, B, dm, run_h.d(), run_v.d(), 2, d_out);    // <H^-1 v, v>
+  HYP_CHECK(hipGetLastError());
+}
+
+int SysSolver::run_hess_prod(size_t k, double* prod, long ldp, const double* arr, long lda, int ncols) {
+  if (psd_runs.empty() || ncols < 1 || ncols > 3) return 0;
+  for (const PsdRun& r : psd_runs) {
+    if ((size_t)r.k0 != k) continue;
+    const int s = r.side, B = r.count, dimk = cones[k]->dim;
+    const long s2 = (long)s * s;
+    group_inverses();
+    for (int g = 0; g < B; ++g) {
+      PsdCone* c = static_cast<PsdCone*>(cones[k + g]);
+      if (c->use_dual_barrier || c->U.p != (void*)(r.U + g * s2)) return 0;
+      c->ensure_inverses();   // (no-op after the batched pass; covers a member that was handled alone)
+    }
+    run_ws1.ensure((size_t)B * s2 * sizeof(double));
+    run_ws2.ensure((size_t)B * s2 * sizeof(double));
+    double* W1 = run_ws1.d();
+    double* W2 = run_ws2.d();
+    auto two_sided = [&](const double* R, int kr2, int kr3) {   // W1_g <- R_g' W1_g R_g for every member g
+      GemmArgs a{};
+      a.M = s; a.N = s; a.K = s; a.A = W1; a.lda = s; a.strideA = s2; a.B = R; a.ldb = s; a.strideB = s2; a.C = W2; a.ldc = s; a.strideC = s2;
+      a.alpha = 1; a.beta = 0; a.tri = GEMM_FULL; a.krange = kr2; a.batch = B;
+      gemm(ctx, true, a);
+      GemmArgs b{};
+      b.M = s; b.N = s; b.K = s; b.A = R; b.lda = s; b.strideA = s2; b.B = W2; b.ldb = s; b.strideB = s2; b.C = W1; b.ldc = s; b.strideC = s2;
+      b.alpha = 1; b.beta = 0; b.tri = GEMM_FULL; b.krange = kr3; b.batch = B;
+      gemm(ctx, true, b);
+    };
+    for (int col = 0; col < ncols; ++col) {
+      svec_unpack(ctx, s, B, arr + (long)col * lda, dimk, W1);        // the members' slices are consecutive columns of length dim
+      two_sided(r.Uinv, KR_LE_N, KR_LE_M);                            // U^-T V U^-1   (possemideftri.jl:126-142, as PsdCone::hess_prod)
+      two_sided(r.UinvT, KR_GE_N, KR_GE_M);                           // U^-1 (.) U^-T
+      svec_pack(ctx, s, B, W1, prod + (long)col * ldp, dimk, 1.0);
+    }
+    return B;
+  }
+  return 0;
 }
 
 void SysSolver::load(const double* hG, const double* hGQ1, const double* hGQ2, const double* hQ, const double* hR) {
@@ -169,6 +257,7 @@ void SysSolver::allreduce_host(double* h_buf, int count, int op) {
 void SysSolver::block_hess_prod_vec(double* d_out, const double* d_in) {   // qrchol.jl:87-98
   for (size_t k = 0; k < cones.size(); ++k) {
     Cone* ck = cones[k];
+    if (const int used = run_hess_prod(k, d_out + offs[k], q, d_in + offs[k], q, 1)) { k += used - 1; continue; }
     if (ck->use_dual_barrier) ck->inv_hess_prod(d_out + offs[k], q, d_in + offs[k], q, 1);
     else ck->hess_prod(d_out + offs[k], q, d_in + offs[k], q, 1);
   }
@@ -421,6 +510,9 @@ SysSolver::Scal SysSolver::solve_system(double* sol, const double* rhs, Scal rs,
       dev_scale_copy(ctx, dk, -1.0, rhs + oz + o, tmp);
       dev_axpby(ctx, dk, -1.0, rhs + os + o, 1.0, tmp);
       ck->inv_hess_prod(sr + oz + o, q, tmp, q, 1);
+    } else if (const int used = run_hess_prod(k, sr + oz + o, q, rhs + oz + o, q, 1)) {
+      dev_axpby(ctx, offs[k + used] - o, -1.0, rhs + os + o, -1.0, sr + oz + o);
+      k += used - 1;
     } else {
       ck->hess_prod(sr + oz + o, q, rhs + oz + o, q, 1);
       dev_axpby(ctx, dk, -1.0, rhs + os + o, -1.0, sr + oz + o);
@@ -484,6 +576,11 @@ SysSolver::Scal SysSolver::apply_lhs(double* res, const double* dir, Scal ds_, d
     const int o = offs[k], dk = ck->dim;
     const double* prim = ck->use_dual_barrier ? dir + oz + o : dir + os + o;
     const double* dual = ck->use_dual_barrier ? dir + os + o : dir + oz + o;
+    if (const int used = run_hess_prod(k, res + os + o, q, prim, q, 1)) {   // (PosSemidefTri: hess_prod_slow! = hess_prod!)
+      dev_axpby(ctx, offs[k + used] - o, 1.0, dual, 1.0, res + os + o);
+      k += used - 1;
+      continue;
+    }
     ck->hess_prod_slow(res + os + o, q, prim, q, 1);
     dev_axpby(ctx, dk, 1.0, dual, 1.0, res + os + o);
   }
@@ -567,7 +664,46 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
   // order and stops at the first failure, which only the points loaded beyond it could tell apart -- and nothing
   // reads those before the next candidate reloads them.
   std::vector<char> launched(nc, 0);
-  if (nc > 1 && !local_reject) {
+  bool run_feas = false;
+  if (nc > 1 && !local_reject && psd_runs.size() == 1 && psd_runs[0].k0 == 0 && (size_t)psd_runs[0].count == nc) {
+    // one run of equal PSD cones is the whole model (config 4): load_point / load_dual_point of all members are two copies
+    // over the arena, the 2 x nc feasibility Choleskys two batched factorizations, their infos one read-back
+    const PsdRun& r = psd_runs[0];
+    bool usable = true;
+    for (size_t k = 0; k < nc && usable; ++k) {
+      PsdCone* c = static_cast<PsdCone*>(cones[k]);
+      usable = !c->use_dual_barrier && c->U.p == (void*)(r.U + (long)k * r.side * r.side) && c->point.p == (void*)(r.point + (long)k * c->dim);
+    }
+    if (usable) {
+      const int sd = r.side, B = r.count, dm = cones[0]->dim;
+      const long s2 = (long)sd * sd, tot = (long)B * dm;
+      if (irtmu == 1.0) ctx.d2d(r.point, dsv, (size_t)tot * sizeof(double));          // Cone::load_point (Cones.jl:157-166)
+      else dev_scale_copy(ctx, (int)tot, irtmu, dsv, r.point);
+      ctx.d2d(r.dual, dz, (size_t)tot * sizeof(double));                               // Cone::load_dual_point
+      run_ws1.ensure((size_t)B * s2 * sizeof(double));
+      run_info.ensure((size_t)2 * B * sizeof(int));
+      svec_unpack(ctx, sd, B, r.point, dm, r.X);                                       // PsdCone::update_feas (possemideftri.jl:80-90)
+      ctx.d2d(r.U, r.X, (size_t)B * s2 * sizeof(double));
+      potrf_upper_batched(ctx, sd, r.U, sd, s2, B, nullptr, run_info.i());
+      svec_unpack(ctx, sd, B, r.dual, dm, run_ws1.d());                                // PsdCone::is_dual_feas (:92-95)
+      potrf_upper_batched(ctx, sd, run_ws1.d(), sd, s2, B, nullptr, run_info.i() + B);
+      HYP_REQUIRE(64 + 2 * (size_t)B < 8192, "check_cone_points: too many cones for the pinned info words");
+      ctx.d2h(ctx.h_info + 64, run_info.p, (size_t)2 * B * sizeof(int));
+      ctx.sync();
+      for (int g = 0; g < B; ++g) {
+        PsdCone* c = static_cast<PsdCone*>(cones[g]);
+        c->reset_data();
+        c->is_feas_ = (ctx.h_info[64 + g] == 0);
+        c->dual_feas_ = (ctx.h_info[64 + B + g] == 0);
+        c->feas_updated = true;
+        c->dual_cached = true;
+        c->inv_ready = false;
+      }
+      *n_loaded = (int)nc;
+      run_feas = true;
+    }
+  }
+  if (nc > 1 && !local_reject && !run_feas) {
     for (size_t k = 0; k < nc; ++k) {
       Cone* ck = cones[k];
       ck->load_point((ck->use_dual_barrier ? dz : dsv) + offs[k], irtmu);
@@ -593,12 +729,38 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
       if (!(cones[k]->is_feas() && cones[k]->is_dual_feas())) ok = false;          // (answered by the prefetch above)
     if (ok) {
       group_inverses();   // runs of equal PSD cones: U^-1, X^-1 of all members in one batched launch sequence
+      const double gtol = std::sqrt(std::sqrt(EPS)), Htol = 10 * std::sqrt(gtol), negtol = std::sqrt(EPS);
+      bool run_done = false;
+      if (psd_runs.size() == 1 && psd_runs[0].k0 == 0 && (size_t)psd_runs[0].count == nc) {
+        // one run is the whole model (config 4): its members' scalar products in ~16 launches and one read-back
+        const PsdRun& r = psd_runs[0];
+        bool usable = true;
+        for (size_t k = 0; k < nc && usable; ++k) {
+          PsdCone* c = static_cast<PsdCone*>(cones[k]);
+          usable = c->inv_ready && c->U.p == (void*)(r.U + (long)k * r.side * r.side);
+        }
+        if (usable) {
+          prox_scal.ensure(3 * nc * sizeof(double));
+          HYP_REQUIRE(3 * nc <= ctx.h_pinned_n, "check_cone_points: too many cones for the pinned staging buffer");
+          run_prox_launch(r, irtmu, prox_scal.d());
+          ctx.d2h(ctx.h_pinned, prox_scal.p, 3 * nc * sizeof(double));
+          ctx.sync();
+          for (size_t k = 0; k < nc; ++k) {
+            const double dk = cones[k]->dim, nuk = cones[k]->nu;
+            const double* hp = ctx.h_pinned + 3 * k;
+            if (std::fabs(1 + hp[0] / nuk) > gtol * dk || std::fabs(1 - hp[1] / nuk) > Htol * dk) { ok = false; break; }   // Cones.jl:273-290
+            const double pk = (hp[2] < -negtol * dk) ? INFINITY : std::fabs(hp[2]);                                        // Cones.jl:294-310
+            agg = use_max_prox ? std::max(agg, pk) : agg + pk;
+            if (!dist() && !(agg < proxsqr_bound)) { ok = false; break; }
+          }
+          run_done = true;
+        }
+      }
       // in chunks of 8 cones: most rejected trials fail the proximity bound at one of the first cones, and the
       // reference's sweep stops there -- a chunk bounds the work queued beyond that point
       const size_t CHK = 8;
-      prox_scal.ensure(3 * CHK * sizeof(double));
-      const double gtol = std::sqrt(std::sqrt(EPS)), Htol = 10 * std::sqrt(gtol), negtol = std::sqrt(EPS);
-      for (size_t k0 = 0; k0 < nc && ok; k0 += CHK) {
+      prox_scal.ensure(3 * std::max(CHK, nc) * sizeof(double));
+      for (size_t k0 = 0; k0 < nc && ok && !run_done; k0 += CHK) {
         const size_t k1 = std::min(nc, k0 + CHK);
         for (size_t k = k0; k < k1 && ok; ++k)
           if (!cones[k]->prox_launch(irtmu, prox_scal.d() + 3 * (k - k0))) ok = false;

@@ -27,10 +27,17 @@ struct SysSolver {
   std::vector<int> use_sqrt;
   bool fact_ok = false;
   // runs of >= 4 consecutive PosSemidefTri cones of equal side (config 4: 64 x side 80): group-owned storage, batched inverses
-  struct PsdRun { int k0, count, side; double *X, *U, *UT, *Uinv, *UinvT, *Xinv, *dinvb; };
+  struct PsdRun { int k0, count, side; double *X, *U, *UT, *Uinv, *UinvT, *Xinv, *dinvb, *point, *dual; };
   std::vector<PsdRun> psd_runs;
   void make_psd_runs();
   void group_inverses();   // ensure_inverses() of every run whose members are all feasible and not yet inverted, batched
+  // hess_prod! of ALL members of the run that starts at cone k on ncols <= 3 columns (prod / arr point at cone k's rows; the
+  // members' rows follow): per column one unpack, four batched GEMMs, one pack.  Returns the number of cones done (0: cone k
+  // does not start a usable run -- the caller takes the per-cone path).
+  int run_hess_prod(size_t k, double* prod, long ldp, const double* arr, long lda, int ncols);
+  DBuf run_ws1, run_ws2, run_g, run_v, run_h, run_info;
+  // the three scalar products of check_numerics / get_proxsqr (Cones.jl:273-310) of every member of run r, 3 per member
+  void run_prox_launch(const PsdRun& r, double irtmu, double* d_out);
   DBuf prox_scal;         // 3 scalars per cone of the batched proximity test of check_cone_points
   BKFact bk;              // the factorization after a failed Cholesky (posdef_fact_copy!, dense.jl:194-215)
   bool use_bk = false;    // lhs_fact holds U of P lhs P' = U' D U instead of the Cholesky factor
