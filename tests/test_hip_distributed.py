@@ -13,6 +13,14 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.timeout(600)
+def test_sharded_hip_solve_with_runs_of_equal_cones(monkeypatch):
+    """8 equal PSD cones, 4 per rank: each rank's cones form a run (group arena, batched feasibility / inverses / products /
+    proximity scalars) inside the native sharded step"""
+    monkeypatch.setenv("HYP_DIST_NATIVE", "1")
+    _run_sharded("1", inst_args=(90, [6] * 8, 3))
+
+
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("native", ["1", "0"])
 def test_sharded_hip_solve_matches_oracle(native, monkeypatch):
     """native = 1: every rank runs the fused device routines on its rows / cones and the library calls back for the
@@ -21,12 +29,11 @@ def test_sharded_hip_solve_matches_oracle(native, monkeypatch):
     _run_sharded(native)
 
 
-def _run_sharded(native):
+def _run_sharded(native, inst_args=(120, [20, 12, 16, 9], 4)):
     import dist_worker
     from oracle import instances as I
     from oracle.build import make_model
     from oracle.solvers import Solver as OSolver
-    inst_args = (120, [20, 12, 16, 9], 4)
     port = _free_port()
     out = os.path.join(tempfile.mkdtemp(), "dist_hip.npz")
     ctx = mp.get_context("spawn")
