@@ -722,7 +722,17 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
   // several cones, all with the generic proximity test: after the batched feasibility flags, the scalar products of
   // check_numerics / get_proxsqr are queued for a chunk of cones and read back with one synchronisation (three per cone
   // otherwise); the tests are then evaluated in the reference's order.  Same decision: a trial is rejected iff some cone fails.
-  bool batched_prox = (nc > 1 && !local_reject);
+  bool single_loaded = false;
+  if (nc == 1 && !local_reject && cones[0]->prox_batchable()) {   // one cone: load it here, so that its scalars also come back in one read
+    Cone* ck = cones[0];
+    ck->load_point((ck->use_dual_barrier ? dz : dsv), irtmu);
+    ck->load_dual_point((ck->use_dual_barrier ? dsv : dz));
+    ck->reset_data();
+    ck->prefetch_feas();
+    *n_loaded = 1;
+    single_loaded = true;
+  }
+  bool batched_prox = ((nc > 1 || single_loaded) && !local_reject);
   for (size_t k = 0; k < nc && batched_prox; ++k) batched_prox = cones[k]->prox_batchable();
   if (batched_prox) {
     for (size_t k = 0; k < nc && ok; ++k)
@@ -780,7 +790,7 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
   }
   for (size_t k = 0; k < nc && !local_reject && !batched_prox; ++k) {                 // :118-136
     Cone* ck = cones[k];
-    if (nc == 1) {
+    if (nc == 1 && !single_loaded) {
       ck->load_point((ck->use_dual_barrier ? dz : dsv) + offs[k], irtmu);
       ck->load_dual_point((ck->use_dual_barrier ? dsv : dz) + offs[k]);
       ck->reset_data();
