@@ -10,6 +10,7 @@
 
 namespace hyp {
 
+void seg_dots(Ctx& c, int B, int len, const double* a, const double* b, int off, int stride, double* out);   // syssolver.hip
 constexpr int MR = 2;   // right-hand sides per pass
 
 // ---- Y[:, r] = alpha A' X[:, r] + beta Y[:, r]: one workgroup per column of A, A read once --------------
@@ -564,6 +565,16 @@ void SysSolver::build_rhs_pair(int stage, double* rhs2, const double* pt, double
     const double rtmu = std::sqrt(mu);
     ctx.d2d(c1, s_resid.d(), (size_t)n * d);                       // pred: x, z residuals (:7-24); cent: zeros (:63-84)
     ctx.d2d(c1 + oz, s_resid.d() + n + p, (size_t)q * d);
+    if (const PsdRun* r = whole_model_run()) {   // one run of equal PSD cones: the same three vector operations over all of them
+      run_g.ensure((size_t)q * d);
+      run_grad(*r, run_g.d());
+      dev_scale_copy(ctx, q, -1.0, pt + oz, c0 + os);
+      dev_axpby(ctx, q, -rtmu, run_g.d(), 1.0, c0 + os);
+      dev_scale_copy(ctx, q, -1.0, pt + oz, c1 + os);
+      rs[0] = Scal{0.0, -kap + mu / tau};
+      rs[1] = Scal{tau_residual, -kap};
+      return;
+    }
     for (size_t k = 0; k < cones.size(); ++k) {
       Cone* ck = cones[k];
       const int o = offs[k], dk = ck->dim;
@@ -586,7 +597,19 @@ void SysSolver::build_rhs_pair(int stage, double* rhs2, const double* pt, double
   const size_t nc = cones.size();
   s_dots.ensure(std::max<size_t>(4 * nc, 4) * d);
   double* dots = s_dots.d();
-  for (size_t k = 0; k < nc; ++k) {
+  const PsdRun* wr = whole_model_run();
+  if (wr) {   // one run of equal PSD cones: scaled directions, H products, dder3 and the four scalar products per cone, batched
+    for (int r = 0; r < MR; ++r) {
+      const double* prim = dirs2 + (long)r * dv + os;
+      dev_scale_copy(ctx, q, irtrtmu, prim, scal + (long)r * q);
+      const int used = run_hess_prod(0, Hq + (long)r * q, q, r == 0 ? scal : prim, q, 1);
+      HYP_REQUIRE(used == (int)nc, "build_rhs_pair: run product");
+      run_dder3(*wr, scal + (long)r * q, D3 + (long)r * q);
+      seg_dots(ctx, (int)nc, cones[0]->dim, D3 + (long)r * q, wr->point, 2 * r, 4, dots);
+      seg_dots(ctx, (int)nc, cones[0]->dim, scal + (long)r * q, Hq + (long)r * q, 2 * r + 1, 4, dots);
+    }
+  }
+  for (size_t k = 0; k < nc && !wr; ++k) {
     Cone* ck = cones[k];
     if (!ck->use_dder3()) continue;
     const int o = offs[k], dk = ck->dim;
@@ -601,7 +624,7 @@ void SysSolver::build_rhs_pair(int stage, double* rhs2, const double* pt, double
       ctx.d2d(D3 + (long)r * q + o, d3, (size_t)dk * d);
     }
   }
-  for (size_t k = 0; k < nc; ++k) {   // (after all cone calls: they use ctx.dscal themselves)
+  for (size_t k = 0; k < nc && !wr; ++k) {   // (after all cone calls: they use ctx.dscal themselves)
     Cone* ck = cones[k];
     if (!ck->use_dder3()) continue;
     const int o = offs[k], dk = ck->dim;

@@ -116,7 +116,7 @@ void SysSolver::group_inverses() {
 
 // out[3 g + off] = <a_g, b_g> over the members' consecutive segments of length len; one wavefront per member
 __global__ __launch_bounds__(256) void seg_dot3_kernel(int B, int len, const double* __restrict__ a, const double* __restrict__ b, int off,
-                                                       double* __restrict__ out) {
+                                                       double* __restrict__ out, int stride = 3) {
   const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (g >= B) return;
   const double* x = a + (long)g * len;
@@ -128,7 +128,10 @@ __global__ __launch_bounds__(256) void seg_dot3_kernel(int B, int len, const dou
   double s = s0 + s1;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-  if (lane == 0) out[3 * g + off] = s;
+  if (lane == 0) out[stride * g + off] = s;
+}
+void seg_dots(Ctx& c, int B, int len, const double* a, const double* b, int off, int stride, double* out) {
+  hipLaunchKernelGGL(seg_dot3_kernel, dim3((B + 3) / 4), dim3(256), 0, c.stream, B, len, a, b, off, out, stride);
 }
 
 void SysSolver::run_prox_launch(const PsdRun& r, double irtmu, double* d_out) {
@@ -160,6 +163,46 @@ void SysSolver::run_prox_launch(const PsdRun& r, double irtmu, double* d_out) {
   xvx(run_v.d(), run_h.d());
   hipLaunchKernelGGL(seg_dot3_kernel, grid, blk, 0, ctx.stream, B, dm, run_h.d(), run_v.d(), 2, d_out);    // <H^-1 v, v>
   HYP_CHECK(hipGetLastError());
+}
+
+const SysSolver::PsdRun* SysSolver::whole_model_run() {
+  if (psd_runs.size() != 1 || psd_runs[0].k0 != 0 || (size_t)psd_runs[0].count != cones.size()) return nullptr;
+  const PsdRun& r = psd_runs[0];
+  for (size_t k = 0; k < cones.size(); ++k) {
+    PsdCone* c = static_cast<PsdCone*>(cones[k]);
+    if (c->use_dual_barrier || c->U.p != (void*)(r.U + (long)k * r.side * r.side) || c->point.p != (void*)(r.point + (long)k * c->dim)) return nullptr;
+  }
+  return &r;
+}
+
+void SysSolver::run_grad(const PsdRun& r, double* d_out) {
+  group_inverses();
+  for (int g = 0; g < r.count; ++g) static_cast<PsdCone*>(cones[r.k0 + g])->ensure_inverses();
+  svec_pack(ctx, r.side, r.count, r.Xinv, d_out, cones[r.k0]->dim, -1.0);
+}
+
+void SysSolver::run_dder3(const PsdRun& r, const double* d_dir, double* d_out) {   // PsdCone::dder3 with batch = members
+  group_inverses();
+  const int s = r.side, B = r.count, dm = cones[r.k0]->dim;
+  const long s2 = (long)s * s;
+  for (int g = 0; g < B; ++g) static_cast<PsdCone*>(cones[r.k0 + g])->ensure_inverses();
+  for (DBuf* b : {&run_ws1, &run_ws2, &run_ws3}) b->ensure((size_t)B * s2 * sizeof(double));
+  double* W1 = run_ws1.d();
+  double* W2 = run_ws2.d();
+  double* W3 = run_ws3.d();
+  auto bgemm = [&](const double* A, const double* Bm, double* C, int kr) {   // C_g = A_g' B_g
+    GemmArgs a{};
+    a.M = s; a.N = s; a.K = s; a.A = A; a.lda = s; a.strideA = s2; a.B = Bm; a.ldb = s; a.strideB = s2; a.C = C; a.ldc = s; a.strideC = s2;
+    a.alpha = 1; a.beta = 0; a.tri = GEMM_FULL; a.krange = kr; a.batch = B;
+    gemm(ctx, true, a);
+  };
+  svec_unpack(ctx, s, B, d_dir, dm, W1);
+  bgemm(W1, r.Uinv, W2, KR_LE_N);        // P = U^-T D U^-1
+  bgemm(r.Uinv, W2, W1, KR_LE_M);
+  bgemm(W1, W1, W3, KR_ALL);             // Q = P' P
+  bgemm(W3, r.UinvT, W2, KR_GE_N);       // U^-1 Q U^-T
+  bgemm(r.UinvT, W2, W1, KR_GE_M);
+  svec_pack(ctx, s, B, W1, d_out, dm, 1.0);
 }
 
 int SysSolver::run_hess_prod(size_t k, double* prod, long ldp, const double* arr, long lda, int ncols) {

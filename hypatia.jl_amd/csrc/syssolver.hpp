@@ -35,7 +35,10 @@ struct SysSolver {
   // members' rows follow): per column one unpack, four batched GEMMs, one pack.  Returns the number of cones done (0: cone k
   // does not start a usable run -- the caller takes the per-cone path).
   int run_hess_prod(size_t k, double* prod, long ldp, const double* arr, long lda, int ncols);
-  DBuf run_ws1, run_ws2, run_g, run_v, run_h, run_info;
+  DBuf run_ws1, run_ws2, run_ws3, run_g, run_v, run_h, run_info;
+  const PsdRun* whole_model_run();                                   // the run, if one run of primal-barrier cones is the whole model and still owns the members' storage
+  void run_grad(const PsdRun& r, double* d_out);                     // -svec(X^-1) of every member (possemideftri.jl:97-107)
+  void run_dder3(const PsdRun& r, const double* d_dir, double* d_out);   // svec(X^-1 D X^-1 D X^-1) of every member (:197-207)
   // the three scalar products of check_numerics / get_proxsqr (Cones.jl:273-310) of every member of run r, 3 per member
   void run_prox_launch(const PsdRun& r, double irtmu, double* d_out);
   DBuf prox_scal;         // 3 scalars per cone of the batched proximity test of check_cone_points
