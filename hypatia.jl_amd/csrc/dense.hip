@@ -11,6 +11,7 @@
 // (gemm_f64.hpp) against the inverted diagonal block.  Triangular solves with one right-hand side
 // run block by block against the same inverted diagonal blocks (one fused launch per block).
 // All reductions have a fixed order: results are bitwise reproducible run to run.
+#include <malloc.h>
 #include "hyp_internal.hpp"
 
 namespace hyp {
@@ -32,6 +33,35 @@ static void potrf_step_gemms(Ctx& c, hipStream_t st, int nb, int M, int N, const
   s.C = C; s.ldc = lda; s.strideC = strideA;
   s.alpha = -1.0; s.beta = 1.0; s.tri = tri; s.krange = KR_ALL; s.batch = batch;
   HYP_CHECK(gemm_f64_launch(st, true, s));
+}
+
+// When the host allocator returns pages to the kernel (munmap of a freed multi-MB temporary, heap trimming) while the driver
+// has host ranges of the process mapped, the driver's MMU notifier evicts the process's GPU queues and restores them ~25 ms
+// later: at config 4 the first device call after every iteration stalled that long (profiles/README "host allocator").  glibc
+// is told to keep freed pages (arrays up to 32 MB come from the heap, the heap is not trimmed); HYP_HOST_MALLOPT=0 leaves
+// the allocator alone.
+static void host_allocator_keep_pages() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  const char* e = getenv("HYP_HOST_MALLOPT");
+  if (e && atoi(e) == 0) return;
+  (void)mallopt(M_MMAP_THRESHOLD, 32 << 20);
+  (void)mallopt(M_TRIM_THRESHOLD, 2147483647);
+  (void)mallopt(M_TOP_PAD, 64 << 20);
+}
+
+// Large caller-owned (pageable) vectors travel through pinned memory of the library: a pageable hipMemcpyAsync of a
+// 1.7 MB vector the host has just rewritten took 17-28 ms at config 4 (q = 207 360), 1.7 ms from pinned memory.
+double* Ctx::stage_host(size_t n_doubles) {
+  if (n_doubles > h_stage_n) {
+    if (h_stage) (void)hipHostFree(h_stage);
+    h_stage = nullptr; h_stage_n = 0;
+    const size_t want = std::max<size_t>(n_doubles, 1 << 18);
+    HYP_CHECK(hipHostMalloc((void**)&h_stage, want * sizeof(double), hipHostMallocDefault));
+    h_stage_n = want;
+  }
+  return h_stage;
 }
 
 hipEvent_t Ctx::aux_event(int i) {
@@ -806,6 +836,7 @@ Ctx::Ctx(int dev) : device(dev) {
   scratch.alloc(1 << 20);
   dscal.alloc(64 * sizeof(double));
   for (int i = 0; i < 6; ++i) HYP_CHECK(hipEventCreate(&ev[i]));
+  host_allocator_keep_pages();
   HYP_CHECK(hipHostMalloc((void**)&h_info, 8192 * sizeof(int), hipHostMallocDefault));   // [0..63] general; [64 + 2 k, 64 + 2 k + 1] cone k of a batched feasibility sweep
   h_pinned_n = 1 << 16;
   HYP_CHECK(hipHostMalloc((void**)&h_pinned, h_pinned_n * sizeof(double), hipHostMallocDefault));
@@ -815,6 +846,7 @@ Ctx::~Ctx() {
     if (ev[i]) (void)hipEventDestroy(ev[i]);
   if (h_info) (void)hipHostFree(h_info);
   if (h_pinned) (void)hipHostFree(h_pinned);
+  if (h_stage) (void)hipHostFree(h_stage);
   for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
   for (hipEvent_t e : aux)
     if (e) (void)hipEventDestroy(e);

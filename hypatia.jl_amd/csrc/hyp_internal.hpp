@@ -91,6 +91,9 @@ struct Ctx {
   int* h_info = nullptr;    // pinned host word(s)
   double* h_pinned = nullptr;   // pinned host staging (small vectors / scalars)
   size_t h_pinned_n = 0;
+  double* h_stage = nullptr;    // growable pinned staging for large caller-owned vectors (see stage_host)
+  size_t h_stage_n = 0;
+  double* stage_host(size_t n_doubles);
   Ctx(int dev);
   ~Ctx();
   void sync() { HYP_CHECK(hipStreamSynchronize(stream)); }
