@@ -433,3 +433,40 @@ def matrixcompletion(d1, d2, seed=1, known_frac=0.8):
     c = np.zeros(nvar)
     c[0] = 1
     return (c, np.zeros((0, nvar)), np.zeros(0), G, h, [("epinormspectral", d1, d2, False)], dict(status="Optimal"))
+
+
+# ---- complex Hermitian PosSemidefTri (SURVEY 8(f) rank 3 "complex Hermitian variants"): oracle-only so far, kept out of
+# KNOWN_ANSWER (whose members all run through the device path and have golden fixtures)
+def _svec_c(m):
+    from .cones_complex import smat_to_svec_c
+    return smat_to_svec_c(np.zeros(m.shape[0] ** 2), m, RT2)
+
+
+def _rand_herm_c(side, rng):   # Hermitian(rand(Complex, side, side), :U): entries in the unit square, real diagonal
+    m = rng.random((side, side)) + 1j * rng.random((side, side))
+    u = np.triu(m, 1)
+    return np.diag(np.diag(m).real) + u + u.conj().T
+
+
+def possemideftri5():   # :382-397
+    return (np.array([1.0, 0, 0, 1]), np.array([[0.0, 0, 1, 0]]), np.array([1.0]), -np.eye(4), np.zeros(4),
+            [("possemideftri_complex", 4)], dict(status="Optimal", primal_obj=RT2, x=[1 / RT2, 0, 1, 1 / RT2]))
+
+
+def possemideftri6(seed=1):   # :399-416 (objective = largest eigenvalue of a random Hermitian matrix)
+    m = _rand_herm_c(2, np.random.default_rng(seed))
+    eig_max = float(np.max(np.linalg.eigvalsh(m)))
+    return (np.array([1.0]), np.zeros((0, 1)), np.zeros(0), np.array([[-1.0], [0], [0], [-1]]), -_svec_c(m),
+            [("possemideftri_complex", 4)], dict(status="Optimal", primal_obj=eig_max, x=[eig_max]))
+
+
+def possemideftri7(seed=1):   # :418-437
+    side = 3
+    m = _rand_herm_c(side, np.random.default_rng(seed))
+    dim = side * side
+    eig_max = float(np.max(np.linalg.eigvalsh(m)))
+    return (-_svec_c(m), _svec_c(np.eye(side, dtype=complex)).reshape(1, dim), np.array([1.0]), -np.eye(dim), np.zeros(dim),
+            [("possemideftri_complex", dim)], dict(status="Optimal", primal_obj=-eig_max))
+
+
+KNOWN_ANSWER_COMPLEX = {"possemideftri5": possemideftri5, "possemideftri6": possemideftri6, "possemideftri7": possemideftri7}

@@ -1,0 +1,80 @@
+"""CPU: the complex Hermitian PosSemidefTri oracle (oracle/cones_complex.py) against the reference's own cone tests
+(test/cone.jl:335-346: test_oracles for sides 1, 2, 3, 5 and test_barrier with -logdet) and the defining identities of the
+complex vectorisation (arrayutilities.jl): round trip, inner products, the Kronecker matrix as the operator D -> M D M."""
+import numpy as np
+import pytest
+
+from oracle import arrayutil as au
+from oracle import cones_complex as occ
+from cone_harness import run_test_oracles, run_test_barrier
+
+
+def _rand_herm(side, rng):
+    a = rng.standard_normal((side, side)) + 1j * rng.standard_normal((side, side))
+    return a + a.conj().T
+
+
+def _full(s, side):
+    m = np.zeros((side, side), dtype=complex)
+    occ.svec_to_smat_c(m, s)
+    return occ.herm_from_upper(m)
+
+
+@pytest.mark.parametrize("side", [1, 2, 3, 5])
+def test_possemideftri_complex_oracles(side):   # test/cone.jl:336-340
+    run_test_oracles(occ.PosSemidefTriComplex(occ.svec_length_c(side)))
+
+
+def test_possemideftri_complex_barrier():   # test/cone.jl:342-346
+    side = 3
+    run_test_barrier(occ.PosSemidefTriComplex(occ.svec_length_c(side)), lambda s: -np.linalg.slogdet(_full(s, side))[1])
+
+
+@pytest.mark.parametrize("side", [1, 2, 4])
+def test_complex_svec_roundtrip_and_inner_product(side):
+    rng = np.random.default_rng(side)
+    A, B = _rand_herm(side, rng), _rand_herm(side, rng)
+    a, b = np.zeros(side * side), np.zeros(side * side)
+    occ.smat_to_svec_c(a, A)
+    occ.smat_to_svec_c(b, B)
+    assert np.allclose(_full(a, side), A, atol=1e-14)
+    assert abs(a @ b - np.trace(A @ B).real) < 1e-12 * max(1.0, abs(a @ b))   # the scaling makes svec an isometry
+    # (re, -im) of the upper-triangle entry: the second entry of column 1 is -sqrt(2) * imag(A[0, 1])
+    if side >= 2:
+        assert abs(a[1] - au.RT2 * A[0, 1].real) < 1e-14 and abs(a[2] + au.RT2 * A[0, 1].imag) < 1e-14
+
+
+@pytest.mark.parametrize("side", [1, 2, 3, 4])
+def test_complex_symm_kron_is_the_two_sided_product(side):
+    rng = np.random.default_rng(10 + side)
+    M = _rand_herm(side, rng)
+    dim = side * side
+    K = np.zeros((dim, dim))
+    occ.symm_kron_c(K, M)
+    assert np.allclose(K, K.T)
+    for _ in range(3):
+        D = _rand_herm(side, rng)
+        d, out = np.zeros(dim), np.zeros(dim)
+        occ.smat_to_svec_c(d, D)
+        occ.smat_to_svec_c(out, M @ D @ M)
+        assert np.allclose(K @ d, out, rtol=1e-12, atol=1e-12)
+
+
+def test_complex_initial_point_is_identity():
+    side = 4
+    c = occ.PosSemidefTriComplex(side * side)
+    c.setup_data()
+    p = np.zeros(side * side)
+    c.set_initial_point(p)
+    assert np.allclose(_full(p, side), np.eye(side))
+
+
+@pytest.mark.parametrize("name", ["possemideftri5", "possemideftri6", "possemideftri7"])
+@pytest.mark.parametrize("reduce", [True, False])
+def test_complex_known_answer(name, reduce):   # test/nativeinstances.jl:382-437 through the oracle's solver
+    from oracle import instances as I
+    from oracle.build import make_model
+    from oracle.solvers import Solver
+    from instance_harness import build_solve_check
+    inst = I.KNOWN_ANSWER_COMPLEX[name]()
+    build_solve_check(Solver(default_tol_relax=10, reduce=reduce), make_model(inst), inst)
