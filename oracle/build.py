@@ -26,6 +26,9 @@ def make_cone(spec):
     if kind == "possemideftri_complex":   # oracle-only so far
         from .cones_complex import PosSemidefTriComplex
         return PosSemidefTriComplex(spec[1])
+    if kind == "epinormspectral_complex":
+        from .cones_complex import EpiNormSpectralComplex
+        return EpiNormSpectralComplex(spec[1], spec[2], use_dual=spec[3])
     raise ValueError(kind)
 
 

@@ -221,3 +221,175 @@ class PosSemidefTriComplex(Cone):
         S = sla.solve_triangular(U, S.conj().T, trans="C", lower=False).conj().T   # (.) U^-1
         smat_to_svec_c(self.dder3_, S @ S.conj().T, self.rt2)
         return self.dder3_
+
+
+# ----------------------------------------------------------------------------------------------
+def cvec_to_rvec(rvec, cmat):   # arrayutilities.jl:30-45 (vec_copyto!, complex -> real): (re, im) pairs in column-major order
+    flat = np.asarray(cmat).reshape(-1, order="F")
+    rvec[0::2] = flat.real
+    rvec[1::2] = flat.imag
+    return rvec
+
+
+def rvec_to_cmat(rvec, d1, d2):   # arrayutilities.jl:47-60 (vec_copyto!, real -> complex)
+    return np.asfortranarray((rvec[0::2] + 1j * rvec[1::2]).reshape(d1, d2, order="F"))
+
+
+class EpiNormSpectralComplex(Cone):
+    """epinormspectral.jl:13-294 with R = Complex{Float64}: (u, W), u >= sigma_1(W), W complex d1 x d2 (d1 <= d2) held as
+    interleaved (re, im) pairs; barrier -logdet(u^2 I - W W^H) + (d1 - 1) log u."""
+
+    def __init__(self, d1, d2, use_dual=False):
+        assert 1 <= d1 <= d2
+        self.use_dual_barrier_ = use_dual
+        self.d1, self.d2 = d1, d2
+        self.dim = 1 + 2 * d1 * d2
+
+    def reset_data(self):   # :70-72
+        self.feas_updated = self.grad_updated = self.hess_updated = self.inv_hess_updated = False
+        self.hess_aux_updated = self.hess_fact_updated = False
+
+    def setup_extra_data(self):   # :75-95
+        self.W = self.tau = self.Zi = self.U = None
+
+    def get_nu(self):   # :97
+        return self.d1 + 1
+
+    def set_initial_point(self, arr):   # :99-105
+        arr[:] = 0
+        arr[0] = np.sqrt(self.get_nu())
+        return arr
+
+    def _solve(self, M):   # ldiv!(fact_Z, M)
+        return sla.cho_solve((self.U, False), M)
+
+    def update_feas(self):   # :107-123
+        assert not self.feas_updated
+        u = self.point[0]
+        self.is_feas_ = False
+        if u > np.finfo(float).eps:
+            self.W = rvec_to_cmat(self.point[1:], self.d1, self.d2)
+            Z = u * u * np.eye(self.d1) - self.W @ self.W.conj().T
+            try:
+                self.U = sla.cholesky((Z + Z.conj().T) / 2, lower=False)
+                self.is_feas_ = True
+            except sla.LinAlgError:
+                self.is_feas_ = False
+        self.feas_updated = True
+        return self.is_feas_
+
+    def is_dual_feas(self):   # :125-132
+        u = self.dual_point[0]
+        if u > np.finfo(float).eps:
+            W = rvec_to_cmat(self.dual_point[1:], self.d1, self.d2)
+            return bool(u - np.sum(sla.svdvals(W)) > np.finfo(float).eps)
+        return False
+
+    def update_grad(self):   # :134-150
+        assert self.is_feas_
+        u = self.point[0]
+        self.tau = self._solve(self.W)
+        self.Zi = self._solve(np.eye(self.d1, dtype=complex))
+        self.grad[0] = -u * np.trace(self.Zi).real
+        cvec_to_rvec(self.grad[1:], self.tau)
+        self.grad *= 2
+        self.grad[0] += (self.d1 - 1) / u
+        self.grad_updated = True
+        return self.grad
+
+    def update_hess_aux(self):   # :152-170
+        assert self.grad_updated
+        u = self.point[0]
+        self.Zitau = self._solve(self.tau)
+        self.HuW = -4 * u * self.Zitau
+        self.trZi2 = float(np.sum(np.abs(self.Zi) ** 2))
+        self.Huu = 4 * u * u * self.trZi2 + (self.grad[0] - 2 * (self.d1 - 1) / u) / u
+        self.WtauI = np.eye(self.d2) + self.W.conj().T @ self.tau
+        self.hess_aux_updated = True
+
+    def update_hess(self):   # :172-209 (upper triangle, 2 x 2 real blocks of spectral_kron_element!, arrayutilities.jl:366-383)
+        if not self.hess_aux_updated:
+            self.update_hess_aux()
+        d1, d2 = self.d1, self.d2
+        Zi, tau, WtauI = self.Zi, self.tau, self.WtauI
+        H = np.zeros((self.dim, self.dim))
+        r = 1
+        for i in range(d2):
+            for j in range(d1):
+                c = r
+                for k in range(i, d2):
+                    for l in range(j if i == k else 0, d1):
+                        a = Zi[l, j] * WtauI[i, k]
+                        b = tau[l, i] * tau[j, k]
+                        apb, amb = a + b, a - b
+                        H[r, c] = apb.real
+                        H[r + 1, c] = -amb.imag
+                        H[r, c + 1] = apb.imag
+                        H[r + 1, c + 1] = amb.real
+                        c += 2
+                r += 2
+        H *= 2
+        cvec_to_rvec(H[0, 1:], self.HuW)
+        H[0, 0] = self.Huu
+        self.hess_ = np.triu(H)
+        self.hess_updated = True
+        return self.hess_
+
+    def hess_prod(self, prod, arr):   # :211-239
+        if not self.hess_aux_updated:
+            self.update_hess_aux()
+        u = self.point[0]
+        W = self.W
+        P, A = _cols(prod), _cols(arr)
+        for j in range(A.shape[1]):
+            a1 = A[0, j]
+            AW = rvec_to_cmat(A[1:, j], self.d1, self.d2)
+            P[0, j] = self.Huu * a1 + np.vdot(self.HuW, AW).real
+            T = AW @ W.conj().T
+            T = T + T.conj().T
+            T[np.diag_indices(self.d1)] -= 2 * u * a1
+            R = self._solve(2 * (T @ self.tau) + 2 * AW)
+            cvec_to_rvec(P[1:, j], R)
+        return prod
+
+    def dder3(self, dir):   # :241-294
+        assert self.hess_aux_updated
+        u = self.point[0]
+        W = self.W
+        u_dir = dir[0]
+        W_dir = rvec_to_cmat(dir[1:], self.d1, self.d2)
+        Zi, tau, Zitau, WtauI = self.Zi, self.tau, self.Zitau, self.WtauI
+        H = lambda M: M.conj().T
+
+        d2d2b = H(W_dir) @ tau
+        d1d2d = self._solve(W_dir)
+        d1d2b = d1d2d @ WtauI
+        d1d2c = d1d2d @ H(d2d2b)
+        d1d1 = d1d2d @ H(W)
+        d2d2 = d2d2b @ d2d2b
+
+        d2d2 = d2d2 + H(W_dir) @ d1d2b
+        d1d2d = tau @ d2d2
+        d1d2d = d1d2d + d1d2c @ WtauI
+        d1d2d = d1d2d + d1d2b @ d2d2b
+
+        d1d2b = self._solve(d1d2b)
+        d1d2b = d1d2b + Zitau @ d2d2b
+
+        d1d1 = d1d1 + tau @ H(W_dir)
+        d1d2b = d1d2b + d1d1 @ Zitau
+        d1d2b = d1d2b * (-2 * u)
+
+        const1 = 4 * u * u_dir * u
+        d1d2c = self._solve(const1 * Zitau - u_dir * tau)
+        d1d2b = d1d2b + d1d2c
+
+        d1d2d = -2 * u_dir * d1d2b - 2 * d1d2d
+        cvec_to_rvec(self.dder3_[1:], d1d2d)
+
+        LiZi = sla.solve_triangular(self.U, Zi, trans="C", lower=False)   # fact_Z.L \ Zi with Z = U^H U
+        trZi3 = float(np.sum(np.abs(LiZi) ** 2))
+        d1d2b = d1d2b + 3 * d1d2c
+        self.dder3_[0] = (-np.vdot(W_dir, d1d2b).real - u * u_dir * (6 * self.trZi2 - 8 * u * trZi3 * u) * u_dir
+                          - (self.d1 - 1) * (u_dir / u) ** 2 / u)
+        return self.dder3_

@@ -469,4 +469,59 @@ def possemideftri7(seed=1):   # :418-437
             [("possemideftri_complex", dim)], dict(status="Optimal", primal_obj=-eig_max))
 
 
-KNOWN_ANSWER_COMPLEX = {"possemideftri5": possemideftri5, "possemideftri6": possemideftri6, "possemideftri7": possemideftri7}
+def _rvec_c(m):
+    from .cones_complex import cvec_to_rvec
+    return cvec_to_rvec(np.zeros(2 * m.size), m)
+
+
+def epinormspectral1_complex(use_dual, seed=1):   # :1038-1072, complex member (property-based on the singular values of s and z)
+    from .cones_complex import rvec_to_cmat
+    rng = np.random.default_rng(seed)
+    Xn, Xm = 3, 4
+    dim = 2 * Xn * Xm
+    c = np.concatenate([[1.0], np.zeros(dim)])
+    A = np.hstack([np.zeros((dim, 1)), np.eye(dim)])
+    b = rng.random(dim)
+    h = np.concatenate([[0.0], rng.random(dim)])
+
+    def check(solver, approx):
+        s, z = solver.get_s(), solver.get_z()
+        psv = np.linalg.svd(rvec_to_cmat(s[1:], Xn, Xm), compute_uv=False)
+        dsv = np.linalg.svd(rvec_to_cmat(z[1:], Xn, Xm), compute_uv=False)
+        if use_dual:
+            assert approx(np.sum(psv), s[0]) and approx(dsv[0], z[0])
+        else:
+            assert approx(psv[0], s[0]) and approx(np.sum(dsv), z[0])
+    return (c, A, b, -np.eye(dim + 1), h, [("epinormspectral_complex", Xn, Xm, use_dual)], dict(status="Optimal", check=check))
+
+
+def epinormspectral2_complex(use_dual, seed=1):   # :1074-1103, complex member
+    rng = np.random.default_rng(seed)
+    Xn, Xm = 3, 4
+    dim = 2 * Xn * Xm
+    mat = rng.random((Xn, Xm)) + 1j * rng.random((Xn, Xm))
+    sv = np.linalg.svd(mat, compute_uv=False)
+    obj = -sv[0] if use_dual else -np.sum(sv)
+    return (-_rvec_c(mat), np.zeros((0, dim)), np.zeros(0), np.vstack([np.zeros((1, dim)), -np.eye(dim)]),
+            np.concatenate([[1.0], np.zeros(dim)]), [("epinormspectral_complex", Xn, Xm, use_dual)],
+            dict(status="Optimal", primal_obj=float(obj)))
+
+
+def epinormspectral3_complex(Xn, Xm, use_dual):   # :1105-1125, complex members
+    dim = 2 * Xn * Xm
+    return (-np.ones(dim), np.zeros((0, dim)), np.zeros(0), np.vstack([np.zeros((1, dim)), -np.eye(dim)]),
+            np.zeros(dim + 1), [("epinormspectral_complex", Xn, Xm, use_dual)],
+            dict(status="Optimal", primal_obj=0.0, x_norm=0.0))
+
+
+KNOWN_ANSWER_COMPLEX = {
+    "possemideftri5": possemideftri5, "possemideftri6": possemideftri6, "possemideftri7": possemideftri7,
+    "epinormspectral1_complex_primal": lambda: epinormspectral1_complex(False),
+    "epinormspectral1_complex_dual": lambda: epinormspectral1_complex(True),
+    "epinormspectral2_complex_primal": lambda: epinormspectral2_complex(False),
+    "epinormspectral2_complex_dual": lambda: epinormspectral2_complex(True),
+    "epinormspectral3_complex_1x1": lambda: epinormspectral3_complex(1, 1, False),
+    "epinormspectral3_complex_1x3_dual": lambda: epinormspectral3_complex(1, 3, True),
+    "epinormspectral3_complex_2x2": lambda: epinormspectral3_complex(2, 2, False),
+    "epinormspectral3_complex_3x4_dual": lambda: epinormspectral3_complex(3, 4, True),
+}

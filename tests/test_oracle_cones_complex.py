@@ -69,12 +69,33 @@ def test_complex_initial_point_is_identity():
     assert np.allclose(_full(p, side), np.eye(side))
 
 
-@pytest.mark.parametrize("name", ["possemideftri5", "possemideftri6", "possemideftri7"])
+def _complex_names():
+    from oracle import instances as I
+    return sorted(I.KNOWN_ANSWER_COMPLEX)
+
+
+@pytest.mark.parametrize("name", _complex_names())
 @pytest.mark.parametrize("reduce", [True, False])
-def test_complex_known_answer(name, reduce):   # test/nativeinstances.jl:382-437 through the oracle's solver
+def test_complex_known_answer(name, reduce):   # test/nativeinstances.jl:382-437, :1038-1125 (complex members) through the oracle's solver
     from oracle import instances as I
     from oracle.build import make_model
     from oracle.solvers import Solver
     from instance_harness import build_solve_check
     inst = I.KNOWN_ANSWER_COMPLEX[name]()
     build_solve_check(Solver(default_tol_relax=10, reduce=reduce), make_model(inst), inst)
+
+
+@pytest.mark.parametrize("d1,d2", [(1, 1), (1, 2), (2, 2), (2, 4), (3, 4)])
+def test_epinormspectral_complex_oracles(d1, d2):   # test/cone.jl (EpiNormSpectral{T, R} test_oracles: the same dimension pairs)
+    run_test_oracles(occ.EpiNormSpectralComplex(d1, d2))
+
+
+def test_epinormspectral_complex_barrier():
+    d1, d2 = 2, 3
+
+    def barrier(s):
+        u = s[0]
+        W = occ.rvec_to_cmat(s[1:], d1, d2)
+        return -np.linalg.slogdet(u * u * np.eye(d1) - W @ W.conj().T)[1] + (d1 - 1) * np.log(u)
+
+    run_test_barrier(occ.EpiNormSpectralComplex(d1, d2), barrier)
