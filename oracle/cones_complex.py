@@ -1,6 +1,7 @@
-"""TEST INFRASTRUCTURE (CPU oracle), not the product: complex Hermitian variant of PosSemidefTri, the first item of
+"""TEST INFRASTRUCTURE (CPU oracle), not the product: complex variants of PosSemidefTri and EpiNormSpectral, the item of
 SURVEY 8(f) rank 3 that the device path does not cover yet ("complex Hermitian variants").  Restates
-reference src/Cones/possemideftri.jl:9-207 for R = Complex{Float64} and the complex vectorisation helpers of
+reference src/Cones/possemideftri.jl:9-207 and src/Cones/epinormspectral.jl:13-294 for R = Complex{Float64} and the complex
+vectorisation helpers of
 src/Cones/arrayutilities.jl:13,81,103-108 (lengths), :188-210 (smat_to_svec!), :240-262 (svec_to_smat!), :308-352 (symm_kron!),
 :366-383 (spectral_kron_element!).  Parity pinned by the reference's own oracle identities (test/cone.jl: logdet barrier finite
 differences, H*point = -grad, H^-1 H = I, dder3 against the second-order difference) in tests/test_oracle_cones_complex.py; the
