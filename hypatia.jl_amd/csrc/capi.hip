@@ -374,19 +374,39 @@ int hyp_symindef_solve3(hyp_symindef* sys, double* sol_vec, const double* rhs_ve
   sys->s->solve3(sol_vec, rhs_vec);
   API_END(sys->ctx)
 }
+// y = alpha op(A) x + beta y with caller-owned host vectors x (nx) and y (ny): both travel through the library's pinned
+// staging (Ctx::stage_host), one stream synchronisation at the end
+static void gemv_host(Ctx& c, bool trans, int m, int n, double alpha, const double* A, long lda, const double* x, int nx, double beta,
+                      double* y, int ny) {
+  // x and y go through the library's pinned staging (Ctx::stage_host): [x | y]
+  double* hs = c.stage_host((size_t)nx + ny);
+  memcpy(hs, x, (size_t)nx * sizeof(double));
+  if (beta != 0.0) memcpy(hs + nx, y, (size_t)ny * sizeof(double));
+  c.stage_a.ensure(std::max<size_t>(nx, 1) * sizeof(double));
+  c.stage_b.ensure(std::max<size_t>(ny, 1) * sizeof(double));
+  static const bool trace = getenv("HYP_MULG_TRACE") != nullptr;   // diagnosis: host-timed phases with a stream sync between them
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = trace ? now() : 0.0;
+  c.h2d(c.stage_a.p, hs, (size_t)nx * sizeof(double));
+  if (beta != 0.0) c.h2d(c.stage_b.p, hs + nx, (size_t)ny * sizeof(double));
+  if (trace) c.sync();
+  const double t1 = trace ? now() : 0.0;
+  gemv(c, trans, m, n, alpha, A, lda, c.stage_a.d(), beta, c.stage_b.d());
+  if (trace) c.sync();
+  const double t2 = trace ? now() : 0.0;
+  c.d2h(hs + nx, c.stage_b.p, (size_t)ny * sizeof(double));
+  c.sync();
+  if (trace) fprintf(stderr, "[gemv_host trans=%d] h2d %.2f ms, gemv %.2f ms, d2h %.2f ms\n", (int)trans, t1 - t0, t2 - t1, now() - t2);
+  memcpy(y, hs + nx, (size_t)ny * sizeof(double));
+}
 int hyp_symindef_mul_G(hyp_symindef* sys, int trans, double alpha, const double* x, double beta, double* y) {
   API_BEGIN
   Ctx& c = sys->ctx->c;
   SymIndefSys* s = sys->s;
   const int nx = trans ? s->q : s->n, ny = trans ? s->n : s->q;
-  double* dx = stage_in(c, c.stage_a, x, nx);
-  c.stage_b.ensure(std::max<size_t>(ny, 1) * sizeof(double));
-  if (beta != 0.0) c.h2d(c.stage_b.p, y, (size_t)ny * sizeof(double));
   // G' sits in the x-rows / z-columns block of the left-hand side (n x q, leading dimension npq): op(G) = op'(G')
   const double* Gt = s->lhs.d() + (long)(s->n + s->p) * s->npq;
-  gemv(c, trans == 0, s->n, s->q, alpha, Gt, s->npq, dx, beta, c.stage_b.d());
-  c.d2h(y, c.stage_b.p, (size_t)ny * sizeof(double));
-  c.sync();
+  gemv_host(c, trans == 0, s->n, s->q, alpha, Gt, s->npq, x, nx, beta, y, ny);
   API_END(sys->ctx)
 }
 int hyp_symindef_get_lhs(hyp_symindef* sys, double* out) {
@@ -490,26 +510,7 @@ int hyp_sys_mul_G(hyp_sys* sys, int trans, double alpha, const double* x, double
   Ctx& c = sys->ctx->c;
   SysSolver* s = sys->s;
   const int nx = trans ? s->q : s->n, ny = trans ? s->n : s->q;
-  // x and y go through the library's pinned staging (Ctx::stage_host): [x | y]
-  double* hs = c.stage_host((size_t)nx + ny);
-  memcpy(hs, x, (size_t)nx * sizeof(double));
-  if (beta != 0.0) memcpy(hs + nx, y, (size_t)ny * sizeof(double));
-  c.stage_a.ensure(std::max<size_t>(nx, 1) * sizeof(double));
-  c.stage_b.ensure(std::max<size_t>(ny, 1) * sizeof(double));
-  static const bool trace = getenv("HYP_MULG_TRACE") != nullptr;   // diagnosis: host-timed phases with a stream sync between them
-  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double t0 = trace ? now() : 0.0;
-  c.h2d(c.stage_a.p, hs, (size_t)nx * sizeof(double));
-  if (beta != 0.0) c.h2d(c.stage_b.p, hs + nx, (size_t)ny * sizeof(double));
-  if (trace) c.sync();
-  const double t1 = trace ? now() : 0.0;
-  gemv(c, trans != 0, s->q, s->n, alpha, s->G.d(), s->q, c.stage_a.d(), beta, c.stage_b.d());
-  if (trace) c.sync();
-  const double t2 = trace ? now() : 0.0;
-  c.d2h(hs + nx, c.stage_b.p, (size_t)ny * sizeof(double));
-  c.sync();
-  if (trace) fprintf(stderr, "[mul_G trans=%d] h2d %.2f ms, gemv %.2f ms, d2h %.2f ms\n", trans, t1 - t0, t2 - t1, now() - t2);
-  memcpy(y, hs + nx, (size_t)ny * sizeof(double));
+  gemv_host(c, trans != 0, s->q, s->n, alpha, s->G.d(), s->q, x, nx, beta, y, ny);
   API_END(sys->ctx)
 }
 int hyp_sys_load_model(hyp_sys* sys, const double* c, const double* b, const double* h, const double* A) {
