@@ -1,6 +1,6 @@
-"""TEST INFRASTRUCTURE (CPU oracle), not the product: complex variants of PosSemidefTri and EpiNormSpectral, the item of
+"""TEST INFRASTRUCTURE (CPU oracle), not the product: complex variants of PosSemidefTri, EpiNormSpectral and LinMatrixIneq, the item of
 SURVEY 8(f) rank 3 that the device path does not cover yet ("complex Hermitian variants").  Restates
-reference src/Cones/possemideftri.jl:9-207 and src/Cones/epinormspectral.jl:13-294 for R = Complex{Float64} and the complex
+reference src/Cones/possemideftri.jl:9-207, src/Cones/epinormspectral.jl:13-294 (R = Complex{Float64}), src/Cones/linmatrixineq.jl:9-159 (Hermitian members) and the complex
 vectorisation helpers of
 src/Cones/arrayutilities.jl:13,81,103-108 (lengths), :188-210 (smat_to_svec!), :240-262 (svec_to_smat!), :308-352 (symm_kron!),
 :366-383 (spectral_kron_element!).  Parity pinned by the reference's own oracle identities (test/cone.jl: logdet barrier finite
@@ -393,4 +393,90 @@ class EpiNormSpectralComplex(Cone):
         d1d2b = d1d2b + 3 * d1d2c
         self.dder3_[0] = (-np.vdot(W_dir, d1d2b).real - u * u_dir * (6 * self.trZi2 - 8 * u * trZi3 * u) * u_dir
                           - (self.d1 - 1) * (u_dir / u) ** 2 / u)
+        return self.dder3_
+
+
+# ----------------------------------------------------------------------------------------------
+class LinMatrixIneqComplex(Cone):
+    """linmatrixineq.jl:9-159 with complex Hermitian (or mixed real / complex) members `As`: the cone vector stays real
+    (one weight per matrix); barrier -logdet(sum_i w_i A_i)."""
+
+    def __init__(self, As, use_dual=False):
+        As = [np.array(A, dtype=complex) for A in As]
+        self.dim = len(As)
+        assert self.dim > 1                                    # :42
+        self.side = As[0].shape[0]
+        for A in As:
+            assert A.shape == (self.side, self.side) and np.allclose(A, A.conj().T, rtol=0, atol=0)   # :44-53 ishermitian
+        assert self.side * self.side >= self.dim
+        assert np.all(np.linalg.eigvalsh(As[0]) > 0)           # :57
+        self.use_dual_barrier_ = bool(use_dual)
+        self.As = As
+        self.nu = self.side                                    # :72
+
+    def reset_data(self):   # :68-70
+        self.feas_updated = self.grad_updated = self.hess_updated = self.inv_hess_updated = False
+        self.hess_fact_updated = False
+        self.use_hess_prod_slow = self.use_hess_prod_slow_updated = False
+
+    def get_nu(self):
+        return self.nu
+
+    def set_initial_point(self, arr):   # :74-81
+        arr[:] = 0.0
+        arr[0] = 1.0
+        return arr
+
+    def update_feas(self):   # :87-96
+        assert not self.feas_updated
+        sumA = sum(w * A for w, A in zip(self.point, self.As))
+        try:
+            self.L = sla.cholesky(sumA, lower=True)
+            self.is_feas_ = True
+        except sla.LinAlgError:
+            self.is_feas_ = False
+        self.feas_updated = True
+        return self.is_feas_
+
+    def update_grad(self):   # :98-109   Hermitian(L \ (L \ A_i)', :U)
+        assert self.is_feas_
+        self.sumAinvAs = []
+        for i, A in enumerate(self.As):
+            T = sla.solve_triangular(self.L, A, lower=True)
+            M = sla.solve_triangular(self.L, T.conj().T, lower=True)
+            self.sumAinvAs.append(herm_from_upper(M))
+            self.grad[i] = -np.trace(self.sumAinvAs[-1]).real
+        self.grad_updated = True
+        return self.grad
+
+    def update_hess(self):   # :111-123 (upper triangle): real(dot(M_i, M_j')) = Re tr(M_i M_j)
+        assert self.grad_updated
+        H = np.zeros((self.dim, self.dim))
+        for i in range(self.dim):
+            for j in range(i, self.dim):
+                H[i, j] = np.vdot(self.sumAinvAs[i], self.sumAinvAs[j].conj().T).real
+        self.hess_ = H
+        self.hess_updated = True
+        return self.hess_
+
+    def hess_prod_slow(self, prod, arr):   # :125-144
+        if not self.use_hess_prod_slow_updated:
+            self.update_use_hess_prod_slow()
+        assert self.hess_updated
+        if not self.use_hess_prod_slow:
+            return self.hess_prod(prod, arr)
+        assert self.grad_updated
+        P, A = _cols(prod), _cols(arr)
+        for j in range(A.shape[1]):
+            j_mat = sum(A[i, j] * self.sumAinvAs[i] for i in range(self.dim))
+            for i in range(self.dim):
+                P[i, j] = np.vdot(j_mat, self.sumAinvAs[i]).real
+        return prod
+
+    def dder3(self, dir):   # :146-159
+        assert self.grad_updated
+        dir_mat = sum(d * M for d, M in zip(dir, self.sumAinvAs))
+        Z = dir_mat @ dir_mat.conj().T
+        for i in range(self.dim):
+            self.dder3_[i] = np.vdot(Z, self.sumAinvAs[i]).real
         return self.dder3_

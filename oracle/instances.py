@@ -514,7 +514,47 @@ def epinormspectral3_complex(Xn, Xm, use_dual):   # :1105-1125, complex members
             dict(status="Optimal", primal_obj=0.0, x_norm=0.0))
 
 
+def _rand_c(rng, shape, is_complex):
+    m = rng.random(shape)
+    return m + 1j * rng.random(shape) if is_complex else m.astype(complex)
+
+
+def linmatrixineq1_complex(side, seed=1):   # :696-719, complex members (objective = 2 / largest eigenvalue of A_1)
+    rng = np.random.default_rng(seed)
+    Ah = _rand_c(rng, (side, side), True)
+    A1 = Ah @ Ah.conj().T + 2 * np.eye(side)
+    A1 = 0.5 * (A1 + A1.conj().T)
+    vals, vecs = np.linalg.eigh(A1)
+    v1 = vecs[:, -1]
+    A2 = -np.outer(v1, v1.conj())
+    A2 = 0.5 * (A2 + A2.conj().T)
+    G = np.zeros((2, 1))
+    G[0, 0] = -1.0
+    return (np.array([1.0]), np.zeros((0, 1)), np.zeros(0), G, np.array([0.0, 2.0]), [("linmatrixineq_complex", [A1, A2], False)],
+            dict(status="Optimal", primal_obj=2 / vals[-1], s=[2 / vals[-1], 2.0]))
+
+
+def linmatrixineq2_complex(kinds, seed=1):   # :721-745, the members with complex matrices (kinds: True = complex)
+    rng = np.random.default_rng(seed)
+    dim = len(kinds)
+    As = []
+    for is_c in kinds:
+        Ah = _rand_c(rng, (3, 3), is_c)
+        M = Ah @ Ah.conj().T
+        As.append(0.5 * (M + M.conj().T))
+    As[0] = As[0] + np.eye(3)
+    G = np.vstack([np.zeros((1, dim - 1)), -np.eye(dim - 1)])
+    h = np.zeros(dim)
+    h[0] = 1.0
+    return (np.ones(dim - 1), np.zeros((0, dim - 1)), np.zeros(0), G, h, [("linmatrixineq_complex", As, False)],
+            dict(status="Optimal", primal_obj_negative=True))
+
+
 KNOWN_ANSWER_COMPLEX = {
+    "linmatrixineq1_complex_side2": lambda: linmatrixineq1_complex(2), "linmatrixineq1_complex_side4": lambda: linmatrixineq1_complex(4),
+    "linmatrixineq2_complex_cc": lambda: linmatrixineq2_complex([True, True]),
+    "linmatrixineq2_complex_rcr": lambda: linmatrixineq2_complex([False, True, False]),
+    "linmatrixineq2_complex_crr": lambda: linmatrixineq2_complex([True, False, False]),
     "possemideftri5": possemideftri5, "possemideftri6": possemideftri6, "possemideftri7": possemideftri7,
     "epinormspectral1_complex_primal": lambda: epinormspectral1_complex(False),
     "epinormspectral1_complex_dual": lambda: epinormspectral1_complex(True),

@@ -99,3 +99,23 @@ def test_epinormspectral_complex_barrier():
         return -np.linalg.slogdet(u * u * np.eye(d1) - W @ W.conj().T)[1] + (d1 - 1) * np.log(u)
 
     run_test_barrier(occ.EpiNormSpectralComplex(d1, d2), barrier)
+
+
+def _rand_herms(side, count, rng):   # test/cone.jl:280-289 (rand_herms, complex members)
+    Ah = rng.standard_normal((side, side)) + 1j * rng.standard_normal((side, side))
+    As = [Ah @ Ah.conj().T + np.eye(side)]
+    for _ in range(count - 1):
+        As.append(_rand_herm(side, rng))
+    return [0.5 * (A + A.conj().T) for A in As]
+
+
+@pytest.mark.parametrize("side,count", [(2, 2), (3, 2), (4, 2), (3, 3), (4, 3)])
+def test_linmatrixineq_complex_oracles(side, count):   # test/cone.jl:423-429, complex Hermitian members
+    rng = np.random.default_rng(side * 10 + count)
+    run_test_oracles(occ.LinMatrixIneqComplex(_rand_herms(side, count, rng)), noise=1e-2, init_tol=np.inf)
+
+
+def test_linmatrixineq_complex_barrier():   # test/cone.jl:431-436
+    rng = np.random.default_rng(1)
+    Ps = _rand_herms(2, 2, rng)
+    run_test_barrier(occ.LinMatrixIneqComplex(Ps), lambda s: -np.linalg.slogdet(sum(s[i] * Ps[i] for i in range(len(Ps))))[1])
