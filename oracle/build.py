@@ -32,6 +32,10 @@ def make_cone(spec):
     if kind == "linmatrixineq_complex":
         from .cones_complex import LinMatrixIneqComplex
         return LinMatrixIneqComplex(spec[1], use_dual=spec[2])
+    if kind == "hyporootdettri_complex":
+        from .cones_complex import HypoRootdetTriComplex
+        c = HypoRootdetTriComplex(spec[1], use_dual=spec[2])
+        return c
     raise ValueError(kind)
 
 

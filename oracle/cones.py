@@ -883,7 +883,7 @@ class HypoRootdetTri(Cone):
         self.use_dual_barrier_ = bool(use_dual)
         self.dim = dim
         self.rt2 = au.RT2
-        self.d = au.svec_side(dim - 1)
+        self.d = self._side_of(dim - 1)
         self.di = 1.0 / self.d
 
     def reset_data(self):   # :61-62
@@ -908,8 +908,15 @@ class HypoRootdetTri(Cone):
         k = 1
         for i in range(1, d + 1):
             arr[k] = c3
-            k += i + 1
+            k += self._diag_step(i)
         return arr
+
+    # ---- representation hooks (real symmetric here; oracle/cones_complex.py overrides them for the Hermitian variant)
+    def _side_of(self, length):
+        return au.svec_side(length)
+
+    def _diag_step(self, i):   # distance from the i-th diagonal entry (1-based) to the next one in the svec
+        return i + 1
 
     def _smat_full(self, v):
         m = np.zeros((self.d, self.d), order="F")
@@ -917,12 +924,42 @@ class HypoRootdetTri(Cone):
         au.copytri_upper(m)
         return m
 
+    @staticmethod
+    def _full(upper):
+        m = np.array(upper, order="F")
+        au.copytri_upper(m)
+        return m
+
+    def _to_svec(self, out, mat):
+        return au.smat_to_svec(out, mat, self.rt2)
+
+    def _kron(self, out, mat):
+        return au.symm_kron(out, mat, self.rt2)
+
+    def _chol(self, v):
+        """Cholesky of smat(v): (factor object or None, logdet)"""
+        m = np.zeros((self.d, self.d), order="F")
+        au.svec_to_smat(m, v, self.rt2)
+        f = la.chol_upper(m)
+        if not f.success:
+            return None, 0.0
+        return f, 2 * np.sum(np.log(np.diag(f.factors)))
+
+    def _inv_from_chol(self, f):
+        return la.inv_fact_chol(f)
+
+    @staticmethod
+    def _tr(m):
+        return np.trace(m)
+
+    @staticmethod
+    def _fro2(m):
+        return np.sum(m ** 2)
+
     def update_feas(self):   # :101-115
         assert not self.feas_updated
-        au.svec_to_smat(self.mat, self.point[1:], self.rt2)
-        self.fact_W = la.chol_upper(self.mat)
-        if self.fact_W.success:
-            logdet = 2 * np.sum(np.log(np.diag(self.fact_W.factors)))
+        self.fact_W, logdet = self._chol(self.point[1:])
+        if self.fact_W is not None:
             self.phi = np.exp(logdet / self.d)
             self.zeta = self.phi - self.point[0]
             self.is_feas_ = self.zeta > EPS
@@ -934,11 +971,8 @@ class HypoRootdetTri(Cone):
     def is_dual_feas(self):   # :117-127
         u = self.dual_point[0]
         if u < -EPS:
-            m = np.zeros((self.d, self.d), order="F")
-            au.svec_to_smat(m, self.dual_point[1:], self.rt2)
-            f = la.chol_upper(m)
-            if f.success:
-                logdet = 2 * np.sum(np.log(np.diag(f.factors)))
+            f, logdet = self._chol(self.dual_point[1:])
+            if f is not None:
                 return logdet - self.d * np.log(-u / self.d) > EPS
         return False
 
@@ -946,8 +980,8 @@ class HypoRootdetTri(Cone):
         assert self.is_feas_
         self.phizidi = self.phi / self.zeta * self.di
         self.grad[0] = 1.0 / self.zeta
-        self.Wi[:] = la.inv_fact_chol(self.fact_W)
-        au.smat_to_svec(self.Wi_vec, self.Wi, self.rt2)
+        self.Wi = self._inv_from_chol(self.fact_W)
+        self._to_svec(self.Wi_vec, self.Wi)
         self.grad[1:] = (-self.phizidi - 1) * self.Wi_vec
         self.grad_updated = True
         return self.grad
@@ -960,9 +994,8 @@ class HypoRootdetTri(Cone):
         c2 = pz * (pz - self.di)
         H[0, 0] = zeta ** -2
         H[0, 1:] = c1 * Wi_vec
-        au.copytri_upper(self.Wi)
         K = np.zeros((self.dim - 1, self.dim - 1))
-        au.symm_kron(K, self.Wi, self.rt2)
+        self._kron(K, self._full(self.Wi))
         H[1:, 1:] = np.triu((pz + 1) * K + c2 * np.outer(Wi_vec, Wi_vec))
         self.hess_ = H
         self.hess_updated = True
@@ -987,14 +1020,14 @@ class HypoRootdetTri(Cone):
         for j in range(A.shape[1]):
             p = A[0, j]
             S = self._two_sided_chol(self._smat_full(A[1:, j]))
-            c0 = pz * np.trace(S)
+            c0 = pz * self._tr(S)
             c1 = c0 - p / zeta
             c2 = pz * c1 - di * c0
             S = (pz + 1) * S
             S[np.diag_indices(self.d)] += c2
             W = self._two_sided_chol_back(S)
             P[0, j] = c1 / -zeta
-            au.smat_to_svec(P[1:, j], W, self.rt2)
+            self._to_svec(P[1:, j], W)
         return prod
 
     def update_inv_hess(self):   # :205-233
@@ -1009,7 +1042,7 @@ class HypoRootdetTri(Cone):
         Hi[0, 0] = zeta ** 2 + phidi * phi
         Hi[0, 1:] = phidi * w
         K = np.zeros((self.dim - 1, self.dim - 1))
-        au.symm_kron(K, W, self.rt2)
+        self._kron(K, W)
         Hi[1:, 1:] = np.triu(c2 * K + c3 * np.outer(w, w))
         self.inv_hess_ = Hi
         self.inv_hess_updated = True
@@ -1034,7 +1067,7 @@ class HypoRootdetTri(Cone):
             P[0, j] = phidi * c5 + c4 * p
             M = W @ (R @ W)
             pw = np.zeros(self.dim - 1)
-            au.smat_to_svec(pw, M, self.rt2)
+            self._to_svec(pw, M)
             P[1:, j] = c6 * w + c2 * pw
         return prod
 
@@ -1043,8 +1076,8 @@ class HypoRootdetTri(Cone):
         p, r = dir[0], dir[1:]
         zeta, phi, di, pz = self.zeta, self.phi, self.di, self.phizidi
         rwi = self._two_sided_chol(self._smat_full(r))
-        c0 = np.trace(rwi) * di
-        c6 = np.sum(rwi ** 2) * di
+        c0 = self._tr(rwi) * di
+        c6 = self._fro2(rwi) * di
         zichi = (p - phi * c0) / zeta
         c1 = zichi ** 2 + phi / zeta * (c6 - c0 ** 2) / 2
         c7 = pz * (c1 - c6 / 2 + c0 * (zichi + c0 / 2))
@@ -1054,7 +1087,7 @@ class HypoRootdetTri(Cone):
         aux2 = c9 * rwi + c8 * np.eye(self.d)
         M = rwi @ aux2
         M[np.diag_indices(self.d)] += c7
-        au.smat_to_svec(self.dder3_[1:], self._two_sided_chol_back(M), self.rt2)
+        self._to_svec(self.dder3_[1:], self._two_sided_chol_back(M))
         return self.dder3_
 
 

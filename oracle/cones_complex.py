@@ -480,3 +480,84 @@ class LinMatrixIneqComplex(Cone):
         for i in range(self.dim):
             self.dder3_[i] = np.vdot(Z, self.sumAinvAs[i]).real
         return self.dder3_
+
+
+# ----------------------------------------------------------------------------------------------
+class _CholC:
+    """upper Cholesky factor of a Hermitian matrix (fact.U)"""
+    def __init__(self, U):
+        self.factors = U
+
+
+def _hermitian_hooks(cls_name, base, doc):
+    """complex Hermitian variant of a PSD-family oracle cone whose matrix handling goes through the representation hooks
+    (oracle/cones.py HypoRootdetTri: _side_of, _diag_step, _smat_full, _full, _to_svec, _kron, _chol, _inv_from_chol, _tr, _fro2,
+    _two_sided_chol, _two_sided_chol_back)"""
+
+    class _C(base):
+        def _side_of(self, length):
+            return svec_side_c(length)
+
+        def _diag_step(self, i):
+            return 2 * i + 1
+
+        def setup_extra_data(self):
+            base.setup_extra_data(self)
+            d = self.d
+            self.mat = np.zeros((d, d), dtype=complex, order="F")
+            self.Wi = np.zeros((d, d), dtype=complex, order="F")
+
+        def _smat_full(self, v):
+            m = np.zeros((self.d, self.d), dtype=complex, order="F")
+            svec_to_smat_c(m, v, self.rt2)
+            return herm_from_upper(m)
+
+        @staticmethod
+        def _full(upper):
+            return herm_from_upper(np.asarray(upper))
+
+        def _to_svec(self, out, mat):
+            return smat_to_svec_c(out, mat, self.rt2)
+
+        def _kron(self, out, mat):
+            return symm_kron_c(out, mat, self.rt2)
+
+        def _chol(self, v):
+            try:
+                U = sla.cholesky(self._smat_full(v), lower=False)
+            except sla.LinAlgError:
+                return None, 0.0
+            return _CholC(U), 2 * np.sum(np.log(np.diag(U).real))
+
+        def _inv_from_chol(self, f):
+            Ui = sla.solve_triangular(f.factors, np.eye(self.d), lower=False)
+            return np.asfortranarray(Ui @ Ui.conj().T)
+
+        @staticmethod
+        def _tr(m):
+            return np.trace(m).real
+
+        @staticmethod
+        def _fro2(m):
+            return float(np.sum(np.abs(m) ** 2))
+
+        def _two_sided_chol(self, R):   # U^-H R U^-1
+            U = self.fact_W.factors
+            T = sla.solve_triangular(U, np.asarray(R).conj().T, trans="C", lower=False).conj().T
+            return sla.solve_triangular(U, T, trans="C", lower=False)
+
+        def _two_sided_chol_back(self, S):   # U^-1 S U^-H
+            U = self.fact_W.factors
+            T = sla.solve_triangular(U, np.asarray(S).conj().T, lower=False).conj().T
+            return sla.solve_triangular(U, T, lower=False)
+
+    _C.__name__ = _C.__qualname__ = cls_name
+    _C.__doc__ = doc
+    return _C
+
+
+from .cones import HypoRootdetTri as _HypoRootdetTri   # noqa: E402
+
+HypoRootdetTriComplex = _hermitian_hooks(
+    "HypoRootdetTriComplex", _HypoRootdetTri,
+    "hyporootdettri.jl:9-324 with R = Complex{Float64}: (u, w), u <= det(smat(w))^(1/d), w the complex svec of a Hermitian matrix.")

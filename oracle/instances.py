@@ -550,7 +550,56 @@ def linmatrixineq2_complex(kinds, seed=1):   # :721-745, the members with comple
             dict(status="Optimal", primal_obj_negative=True))
 
 
+def _rootdet_c(v, side):
+    from .cones_complex import svec_to_smat_c, herm_from_upper
+    m = np.zeros((side, side), dtype=complex)
+    svec_to_smat_c(m, np.asarray(v, dtype=float), RT2)
+    return float(np.linalg.det(herm_from_upper(m)).real ** (1.0 / side))
+
+
+def _rand_psd_svec_c(side, seed, scale=1.0, rank=None):
+    rng = np.random.default_rng(seed)
+    Mh = scale * _rand_c(rng, (side, rank or side), True)
+    M = Mh @ Mh.conj().T
+    return _svec_c(0.5 * (M + M.conj().T))
+
+
+def hyporootdettri1_complex(seed=1):   # :1569-1598, complex member
+    side = 3
+    dim = 1 + side * side
+    G = np.zeros((dim, 1))
+    G[0, 0] = -1.0
+    h = np.zeros(dim)
+    h[1:] = _rand_psd_svec_c(side, seed)
+
+    def check(sv, approx):
+        assert approx(sv.get_x()[0], -sv.get_primal_obj())
+        s, z = sv.get_s(), sv.get_z()
+        assert approx(_rootdet_c(s[1:], side), s[0])
+        assert approx(_rootdet_c(z[1:] * side, side), -z[0])
+    return (np.array([-1.0]), np.zeros((0, 1)), np.zeros(0), G, h, [("hyporootdettri_complex", dim, False)],
+            dict(status="Optimal", check=check))
+
+
+def hyporootdettri2_complex(seed=1):   # :1600-1629, complex member (dual cone)
+    side = 4
+    dim = 1 + side * side
+    G = np.zeros((dim, 1))
+    G[0, 0] = -1.0
+    h = np.zeros(dim)
+    h[1:] = _rand_psd_svec_c(side, seed)
+
+    def check(sv, approx):
+        assert approx(sv.get_x()[0], sv.get_primal_obj())
+        s, z = sv.get_s(), sv.get_z()
+        assert approx(_rootdet_c(s[1:] * side, side), -s[0])
+        assert approx(_rootdet_c(z[1:], side), z[0])
+    return (np.array([1.0]), np.zeros((0, 1)), np.zeros(0), G, h, [("hyporootdettri_complex", dim, True)],
+            dict(status="Optimal", check=check))
+
+
 KNOWN_ANSWER_COMPLEX = {
+    "hyporootdettri1_complex": hyporootdettri1_complex, "hyporootdettri2_complex": hyporootdettri2_complex,
     "linmatrixineq1_complex_side2": lambda: linmatrixineq1_complex(2), "linmatrixineq1_complex_side4": lambda: linmatrixineq1_complex(4),
     "linmatrixineq2_complex_cc": lambda: linmatrixineq2_complex([True, True]),
     "linmatrixineq2_complex_rcr": lambda: linmatrixineq2_complex([False, True, False]),

@@ -119,3 +119,18 @@ def test_linmatrixineq_complex_barrier():   # test/cone.jl:431-436
     rng = np.random.default_rng(1)
     Ps = _rand_herms(2, 2, rng)
     run_test_barrier(occ.LinMatrixIneqComplex(Ps), lambda s: -np.linalg.slogdet(sum(s[i] * Ps[i] for i in range(len(Ps))))[1])
+
+
+@pytest.mark.parametrize("side", [1, 2, 4])
+def test_hyporootdettri_complex_oracles(side):   # test/cone.jl:606-610, complex members
+    run_test_oracles(occ.HypoRootdetTriComplex(1 + side * side))
+
+
+def test_hyporootdettri_complex_barrier():   # test/cone.jl:612-620
+    side = 3
+
+    def barrier(s):
+        sign, logdet = np.linalg.slogdet(_full(s[1:], side))
+        return -np.log(np.exp(logdet / side) - s[0]) - logdet
+
+    run_test_barrier(occ.HypoRootdetTriComplex(1 + side * side), barrier)
