@@ -36,6 +36,9 @@ def make_cone(spec):
         from .cones_complex import HypoRootdetTriComplex
         c = HypoRootdetTriComplex(spec[1], use_dual=spec[2])
         return c
+    if kind == "hypoperlogdettri_complex":
+        from .cones_complex import HypoPerLogdetTriComplex
+        return HypoPerLogdetTriComplex(spec[1], use_dual=spec[2])
     raise ValueError(kind)
 
 

@@ -1118,7 +1118,7 @@ class HypoPerLogdetTri(HypoRootdetTri):
         self.use_dual_barrier_ = bool(use_dual)
         self.dim = dim
         self.rt2 = au.RT2
-        self.d = au.svec_side(dim - 2)
+        self.d = self._side_of(dim - 2)
 
     def setup_extra_data(self):   # :62-76
         d = self.d
@@ -1135,7 +1135,7 @@ class HypoPerLogdetTri(HypoRootdetTri):
         k = 2
         for i in range(1, self.d + 1):
             arr[k] = w
-            k += i + 1
+            k += self._diag_step(i)
         return arr
 
     def update_feas(self):   # :97-118
@@ -1144,10 +1144,8 @@ class HypoPerLogdetTri(HypoRootdetTri):
         self.is_feas_ = False
         if v > EPS:
             u = self.point[0]
-            au.svec_to_smat(self.mat, self.point[2:], self.rt2)
-            self.fact_W = la.chol_upper(self.mat)
-            if self.fact_W.success:
-                logdet = 2 * np.sum(np.log(np.diag(self.fact_W.factors)))
+            self.fact_W, logdet = self._chol(self.point[2:])
+            if self.fact_W is not None:
                 self.phi = logdet - self.d * np.log(v)
                 self.zeta = v * self.phi - u
                 self.is_feas_ = self.zeta > EPS
@@ -1158,11 +1156,8 @@ class HypoPerLogdetTri(HypoRootdetTri):
         u = self.dual_point[0]
         if u < -EPS:
             v = self.dual_point[1]
-            m = np.zeros((self.d, self.d), order="F")
-            au.svec_to_smat(m, self.dual_point[2:], self.rt2)
-            f = la.chol_upper(m)
-            if f.success:
-                logdet = 2 * np.sum(np.log(np.diag(f.factors)))
+            f, logdet = self._chol(self.dual_point[2:])
+            if f is not None:
                 return v - u * (logdet + self.d * (1 - np.log(-u))) > EPS
         return False
 
@@ -1171,8 +1166,8 @@ class HypoPerLogdetTri(HypoRootdetTri):
         v, zeta = self.point[1], self.zeta
         self.grad[0] = 1.0 / zeta
         self.grad[1] = -1.0 / v - (self.phi - self.d) / zeta
-        self.Wi[:] = la.inv_fact_chol(self.fact_W)
-        au.smat_to_svec(self.Wi_vec, self.Wi, self.rt2)
+        self.Wi = self._inv_from_chol(self.fact_W)
+        self._to_svec(self.Wi_vec, self.Wi)
         self.grad[2:] = (-1 - v / zeta) * self.Wi_vec
         self.grad_updated = True
         return self.grad
@@ -1191,9 +1186,8 @@ class HypoPerLogdetTri(HypoRootdetTri):
         H[1, 1] = v ** -2 + zisig ** 2 + d / (v * zeta)
         H[0, 2:] = (-vzi / zeta) * Wi_vec
         H[1, 2:] = ((sigma * vzi - 1) / zeta) * Wi_vec
-        au.copytri_upper(self.Wi)
         K = np.zeros((self.dim - 2, self.dim - 2))
-        au.symm_kron(K, self.Wi, self.rt2)
+        self._kron(K, self._full(self.Wi))
         Wv = vzi * Wi_vec
         H[2:, 2:] = np.triu((1 + vzi) * K + np.outer(Wv, Wv))
         self.hess_ = H
@@ -1210,14 +1204,14 @@ class HypoPerLogdetTri(HypoRootdetTri):
             p, q = A[0, j], A[1, j]
             S = self._two_sided_chol(self._smat_full(A[2:, j]))
             qzi = q / zeta
-            c0 = np.trace(S) / zeta
+            c0 = self._tr(S) / zeta
             c1 = (v * c0 - p / zeta + sigma * qzi) / zeta
             c3 = c1 * v - qzi
             P[0, j] = -c1
             P[1, j] = c1 * sigma - c0 + (qzi * d + q / v) / v
             S = vzi1 * S
             S[np.diag_indices(d)] += c3
-            au.smat_to_svec(P[2:, j], self._two_sided_chol_back(S), self.rt2)
+            self._to_svec(P[2:, j], self._two_sided_chol_back(S))
         return prod
 
     def _inv_consts(self):
@@ -1243,7 +1237,7 @@ class HypoPerLogdetTri(HypoRootdetTri):
         Hi[0, 2:] = c1 * w
         Hi[1, 2:] = c2 * w
         K = np.zeros((self.dim - 2, self.dim - 2))
-        au.symm_kron(K, W, self.rt2)
+        self._kron(K, W)
         Hi[2:, 2:] = np.triu(zzvi * K + (c2 / zv) * np.outer(w, w))
         self.inv_hess_ = Hi
         self.inv_hess_updated = True
@@ -1269,7 +1263,7 @@ class HypoPerLogdetTri(HypoRootdetTri):
             P[0, j] = c6 * p + c7 * q + c8 * c1
             P[1, j] = c4 * c5
             pw = np.zeros(self.dim - 2)
-            au.smat_to_svec(pw, W @ (R @ W), self.rt2)
+            self._to_svec(pw, W @ (R @ W))
             P[2:, j] = c2 * w + zzvi * pw
         return prod
 
@@ -1283,8 +1277,8 @@ class HypoPerLogdetTri(HypoRootdetTri):
         vzi = v / zeta
         vzi1 = vzi + 1
         rwi = self._two_sided_chol(self._smat_full(r))
-        c0 = np.trace(rwi)
-        c7 = np.sum(rwi ** 2)
+        c0 = self._tr(rwi)
+        c7 = self._fro2(rwi)
         zichi = (-p + sigma * q + c0 * v) / zeta
         c4 = (viq * (-viq * d + 2 * c0) - c7) / zeta / 2
         c1 = (zichi ** 2 - v * c4) / zeta
@@ -1297,7 +1291,7 @@ class HypoPerLogdetTri(HypoRootdetTri):
         aux2 = vzi1 * rwi + c6 * np.eye(d)
         M = rwi @ aux2
         M[np.diag_indices(d)] += c8
-        au.smat_to_svec(self.dder3_[2:], self._two_sided_chol_back(M), self.rt2)
+        self._to_svec(self.dder3_[2:], self._two_sided_chol_back(M))
         return self.dder3_
 
 

@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE (CPU oracle), not the product: complex variants of PosSemidefTri, EpiNormSpectral and LinMatrixIneq, the item of
+"""TEST INFRASTRUCTURE (CPU oracle), not the product: complex variants of PosSemidefTri, EpiNormSpectral, LinMatrixIneq, HypoRootdetTri and HypoPerLogdetTri, the item of
 SURVEY 8(f) rank 3 that the device path does not cover yet ("complex Hermitian variants").  Restates
 reference src/Cones/possemideftri.jl:9-207, src/Cones/epinormspectral.jl:13-294 (R = Complex{Float64}), src/Cones/linmatrixineq.jl:9-159 (Hermitian members) and the complex
 vectorisation helpers of
@@ -561,3 +561,9 @@ from .cones import HypoRootdetTri as _HypoRootdetTri   # noqa: E402
 HypoRootdetTriComplex = _hermitian_hooks(
     "HypoRootdetTriComplex", _HypoRootdetTri,
     "hyporootdettri.jl:9-324 with R = Complex{Float64}: (u, w), u <= det(smat(w))^(1/d), w the complex svec of a Hermitian matrix.")
+
+from .cones import HypoPerLogdetTri as _HypoPerLogdetTri   # noqa: E402
+
+HypoPerLogdetTriComplex = _hermitian_hooks(
+    "HypoPerLogdetTriComplex", _HypoPerLogdetTri,
+    "hypoperlogdettri.jl:9-368 with R = Complex{Float64}: (u, v, w), u <= v logdet(smat(w) / v), w the complex svec of a Hermitian matrix.")

@@ -598,7 +598,68 @@ def hyporootdettri2_complex(seed=1):   # :1600-1629, complex member (dual cone)
             dict(status="Optimal", check=check))
 
 
+def _logdet_c(v, side):
+    from .cones_complex import svec_to_smat_c, herm_from_upper
+    m = np.zeros((side, side), dtype=complex)
+    svec_to_smat_c(m, np.asarray(v, dtype=float), RT2)
+    return float(np.linalg.slogdet(herm_from_upper(m))[1])
+
+
+def hypoperlogdettri1_complex(seed=1):   # :1797-1827, complex member
+    side = 4
+    dim = 2 + side * side
+    G = np.zeros((dim, 2))
+    G[0, 0] = G[1, 1] = -1.0
+    h = np.zeros(dim)
+    rng = np.random.default_rng(seed)
+    Mh = _rand_c(rng, (side, side), True)
+    M = Mh @ Mh.conj().T + np.eye(side)
+    h[2:] = _svec_c(0.5 * (M + M.conj().T))
+
+    def check(sv, approx):
+        x, s, z = sv.get_x(), sv.get_s(), sv.get_z()
+        assert approx(x[0], -sv.get_primal_obj()) and approx(x[1], 1.0)
+        assert approx(s[1] * _logdet_c(s[2:] / s[1], side), s[0])
+        assert approx(z[0] * (_logdet_c(-z[2:] / z[0], side) + side), z[1])
+    return (np.array([-1.0, 0.0]), np.array([[0.0, 1.0]]), np.array([1.0]), G, h, [("hypoperlogdettri_complex", dim, False)],
+            dict(status="Optimal", check=check))
+
+
+def hypoperlogdettri2_complex(seed=1):   # :1829-1859, complex member (dual cone)
+    side = 2
+    dim = 2 + side * side
+    G = np.zeros((dim, 2))
+    G[0, 0] = G[1, 1] = -1.0
+    h = np.zeros(dim)
+    h[2:] = _rand_psd_svec_c(side, seed)
+
+    def check(sv, approx):
+        x, s, z = sv.get_x(), sv.get_s(), sv.get_z()
+        assert approx(x[1], sv.get_primal_obj()) and approx(x[0], -1.0)
+        assert approx(s[0] * (_logdet_c(-s[2:] / s[0], side) + side), s[1])
+        assert approx(z[1] * _logdet_c(z[2:] / z[1], side), z[0])
+    return (np.array([0.0, 1.0]), np.array([[1.0, 0.0]]), np.array([-1.0]), G, h, [("hypoperlogdettri_complex", dim, True)],
+            dict(status="Optimal", check=check))
+
+
+def hypoperlogdettri3_complex(seed=1):   # :1861-1884, complex member
+    side = 3
+    dim = 2 + side * side
+    G = np.zeros((dim, 2))
+    G[0, 0] = G[1, 1] = -1.0
+    h = np.zeros(dim)
+    h[2:] = _rand_psd_svec_c(side, seed)
+
+    def check(sv, approx):
+        x = sv.get_x()
+        assert approx(x[0], -sv.get_primal_obj()) and approx(np.linalg.norm(x), 0.0)
+    return (np.array([-1.0, 0.0]), np.array([[0.0, 1.0]]), np.array([0.0]), G, h, [("hypoperlogdettri_complex", dim, False)],
+            dict(status="Optimal", check=check))
+
+
 KNOWN_ANSWER_COMPLEX = {
+    "hypoperlogdettri1_complex": hypoperlogdettri1_complex, "hypoperlogdettri2_complex": hypoperlogdettri2_complex,
+    "hypoperlogdettri3_complex": hypoperlogdettri3_complex,
     "hyporootdettri1_complex": hyporootdettri1_complex, "hyporootdettri2_complex": hyporootdettri2_complex,
     "linmatrixineq1_complex_side2": lambda: linmatrixineq1_complex(2), "linmatrixineq1_complex_side4": lambda: linmatrixineq1_complex(4),
     "linmatrixineq2_complex_cc": lambda: linmatrixineq2_complex([True, True]),

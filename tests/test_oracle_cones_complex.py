@@ -134,3 +134,19 @@ def test_hyporootdettri_complex_barrier():   # test/cone.jl:612-620
         return -np.log(np.exp(logdet / side) - s[0]) - logdet
 
     run_test_barrier(occ.HypoRootdetTriComplex(1 + side * side), barrier)
+
+
+@pytest.mark.parametrize("side", [1, 2, 4])
+def test_hypoperlogdettri_complex_oracles(side):   # test/cone.jl:648-655, complex members
+    run_test_oracles(occ.HypoPerLogdetTriComplex(2 + side * side), init_tol=1e-4)   # the central-ray table is a fit
+
+
+def test_hypoperlogdettri_complex_barrier():   # test/cone.jl:657-665
+    side = 3
+
+    def barrier(s):
+        u, v = s[0], s[1]
+        W = _full(s[2:], side)
+        return -np.log(v * np.linalg.slogdet(W / v)[1] - u) - np.log(v) - np.linalg.slogdet(W)[1]
+
+    run_test_barrier(occ.HypoPerLogdetTriComplex(2 + side * side), barrier)
