@@ -22,13 +22,13 @@ class Cone:
         self._h = handle
         lib = L.lib()
         d = c_int(0)
-        lib.hyp_cone_dimension(self._h, ctypes.byref(d))
+        L.check(lib.hyp_cone_dimension(self._h, ctypes.byref(d)), "hyp_cone_dimension")
         self.dim = d.value
         nu = c_dbl(0)
-        lib.hyp_cone_get_nu(self._h, ctypes.byref(nu))
+        L.check(lib.hyp_cone_get_nu(self._h, ctypes.byref(nu)), "hyp_cone_get_nu")
         self.nu = nu.value
         udb = c_int(0)
-        lib.hyp_cone_use_dual_barrier(self._h, ctypes.byref(udb))
+        L.check(lib.hyp_cone_use_dual_barrier(self._h, ctypes.byref(udb)), "hyp_cone_use_dual_barrier")
         self._use_dual_barrier = bool(udb.value)
         self.setup_data()
 
@@ -208,8 +208,8 @@ class _GenericHessMixin:
     @use_hess_prod_slow.setter
     def use_hess_prod_slow(self, v):
         self._slow = bool(v)
-        if getattr(self, "_h", None) is not None and v:
-            L.check(L.lib().hyp_cone_set_use_hess_prod_slow(self._h, 1), "set_use_hess_prod_slow")
+        if getattr(self, "_h", None) is not None:   # both values reach the device: host and device never disagree on the path
+            L.check(L.lib().hyp_cone_set_use_hess_prod_slow(self._h, int(bool(v))), "set_use_hess_prod_slow")
 
     def update_use_hess_prod_slow(self):
         out = c_int(0)

@@ -28,6 +28,7 @@ static thread_local std::string g_last_error;
     return -2;                                                                \
   } catch (...) {                                                             \
     g_last_error = "unknown error";                                           \
+    if (ctxp) (ctxp)->c.last_error = g_last_error;                            \
     return -3;                                                                \
   }
 
@@ -56,7 +57,9 @@ int hyp_ctx_destroy(hyp_ctx* ctx) {
   delete ctx;
   API_END(none)
 }
-const char* hyp_last_error(hyp_ctx* ctx) { return ctx ? ctx->c.last_error.c_str() : g_last_error.c_str(); }
+// the message of the most recent failing call of this thread (every catch branch writes it); the context's copy only
+// serves callers on another thread
+const char* hyp_last_error(hyp_ctx* ctx) { return (!g_last_error.empty() || !ctx) ? g_last_error.c_str() : ctx->c.last_error.c_str(); }
 int hyp_ctx_synchronize(hyp_ctx* ctx) {
   API_BEGIN
   HYP_CHECK(hipSetDevice(ctx->c.device));

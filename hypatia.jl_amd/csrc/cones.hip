@@ -20,7 +20,10 @@ void Cone::load_point(const double* d_pt, double scal) {   // Cones.jl:157-166
   if (scal == 1.0) ctx.d2d(point.p, d_pt, (size_t)dim * sizeof(double));
   else dev_scale_copy(ctx, dim, scal, d_pt, point.d());
 }
-void Cone::load_dual_point(const double* d_pt) { ctx.d2d(dual_point.p, d_pt, (size_t)dim * sizeof(double)); }   // :168-171
+void Cone::load_dual_point(const double* d_pt) {   // :168-171
+  ctx.d2d(dual_point.p, d_pt, (size_t)dim * sizeof(double));
+  dual_cached = false;
+}
 
 double Cone::dot_host(int n, const double* dx, const double* dy) {
   dev_dot(ctx, n, dx, dy, ctx.dscal.d());

@@ -25,6 +25,10 @@ struct Cone {
   DBuf point, dual_point, grad, dder3v, vec1, vec2;
   bool feas_updated = false, grad_updated = false, hess_updated = false, inv_hess_updated = false,
        hess_fact_updated = false, is_feas_ = false;
+  // is_dual_feas() answered ahead of time by prefetch_feas() / the batched line-search sweep (PsdCone); cleared by every
+  // load_dual_point, so that a caller following the reference's protocol (load_dual_point, then is_dual_feas, with no
+  // reset_data in between: Solvers.jl initialize_cone_point) never sees the previous candidate's answer
+  bool dual_cached = false, dual_feas_ = false;
 
   Cone(Ctx& c, int k) : ctx(c), kind(k) {}
   virtual ~Cone() {}
@@ -117,7 +121,6 @@ struct PsdCone : Cone {   // src/Cones/possemideftri.jl (real symmetric)
   // in one arena (member g at offset g * side^2), so that the group's inverses are ONE batched launch sequence
   // (SysSolver::group_inverses); the cones hold the arena alive.
   std::shared_ptr<DBuf> group_arena;
-  bool dual_cached = false, dual_feas_ = false;   // is_dual_feas() answered ahead of time by prefetch_feas()
   PsdCone(Ctx& c, int dim);
   void reset_data() override {
     Cone::reset_data();

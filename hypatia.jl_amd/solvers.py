@@ -432,10 +432,12 @@ class CombinedStepper:
             up = sysv.last_update_lhs_seconds() if hasattr(sysv, "last_update_lhs_seconds") else 0.0
             solver.time_upsys += up
             solver.time_getdir += dt - up
-            if not ok:   # factorization failed: leave the decision to the unfused path (reference behaviour)
-                fused = False
+            if not ok:
+                return self._factorization_failed(solver)
         if not fused:
             t0 = T(); solver.syssolver.update_lhs(solver); solver.time_upsys += T() - t0
+            if getattr(sysv, "last_info", 0) != 0:
+                return self._factorization_failed(solver)
 
         if fused:
             pass
@@ -490,6 +492,15 @@ class CombinedStepper:
             point.ztsk[:] = self.temp.ztsk   # exactly the accepted candidate the cones were loaded with (formed natively)
         self.prev_alpha = alpha
         return True
+
+    def _factorization_failed(self, solver):
+        """Every link of posdef_fact_copy! failed (Cholesky, Bunch-Kaufman, shifted Bunch-Kaufman: dense.jl:194-215).  The
+        reference warns (qrchol.jl:253-255) and carries on with the unusable factorization: its directions are not finite, no
+        step of the schedule passes check_cone_points and step() ends in NumericalFailure (combined.jl:97-117).  The device keeps
+        no failed factorization to solve with, so the same outcome is reported directly -- without re-running the assembly."""
+        solver.status = "NumericalFailure"
+        self.prev_alpha = 0.0
+        return False
 
     def _pair(self, solver, dir_a, dir_b):
         (ra, rb), ns = solver.syssolver.get_directions2_native(solver, self.dir2, self.rhs2)

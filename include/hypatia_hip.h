@@ -120,9 +120,9 @@ int hyp_symindef_update_lhs(hyp_symindef* sys, int* info, int* used_fallback);
 int hyp_symindef_solve3(hyp_symindef* sys, double* sol_vec, const double* rhs_vec);
 /* y = alpha * op(G) x + beta * y on the device-resident G (trans != 0: op(G) = G'), for the residuals the driver computes */
 int hyp_symindef_mul_G(hyp_symindef* sys, int trans, double alpha, const double* x, double beta, double* y);
-/* y = alpha * op(G) x + beta * y on the device-resident G (trans != 0: op(G) = G'), for the residuals the driver computes */
-int hyp_symindef_mul_G(hyp_symindef* sys, int trans, double alpha, const double* x, double beta, double* y);
 int hyp_symindef_get_lhs(hyp_symindef* sys, double* out_npqxnpq);   /* upper triangle meaningful (tests) */
+
+/* ---- QRCholDenseSystemSolver, continued ------------------------------------------------------- */
 /* load (qrchol.jl:138-179): G = model.G (q x n).  When p == 0 pass NULL for GQ1, GQ2, Q, R (GQ2 = G,
  * Ap_Q = I).  Otherwise Q = Ap_Q (n x n), R = Ap_R (p x p), and either GQ1 = (G*Ap_Q)[:, 1:p], GQ2 = (G*Ap_Q)[:, p+1:n]
  * or NULL for both: the product G*Ap_Q of qrchol.jl:154 is then formed on the device. */
@@ -219,7 +219,6 @@ int hyp_dense_syrk(hyp_ctx* ctx, int N, int K, const double* A, int lda, double*
 int hyp_dense_potrf(hyp_ctx* ctx, int n, double* A, int lda, int* info);
 /* dposv 'U': A (upper triangle read) is overwritten by its Cholesky factor U, x (in: b) by A^-1 b */
 int hyp_dense_posv(hyp_ctx* ctx, int n, double* A, int lda, double* x, int* info);
-/* y = alpha * op(A) x + beta * y */
 /* Symmetric indefinite solve through the rook-pivoted factorization P A P' = U' D U (the reference's
  * bunchkaufman!(Symmetric(A, :U), true, check = false) + ldiv!: symm_fact!, src/linearalgebra/dense.jl:164-165).
  * A: upper triangle in, U (unit upper, diagonal explicit) out.  perm / blk / d / e (length n, each may be NULL)
@@ -234,6 +233,7 @@ int hyp_dense_sysv_rook(hyp_ctx* ctx, int n, double* A, int lda, double* x, int 
  * reference uses a column-pivoted QR there (also to detect dependent columns): the caller takes this x only when info = 0
  * and rcond_est is far from the rank-decision threshold, and otherwise runs the reference's pivoted QR on the host. */
 int hyp_dense_lstsq_normal(hyp_ctx* ctx, int m, int n, const double* A, int lda, const double* b, double* x, double* rcond_est, int* info);
+/* y = alpha * op(A) x + beta * y (A is m x n col-major; trans != 0: op(A) = A') */
 int hyp_dense_gemv(hyp_ctx* ctx, int trans, int m, int n, double alpha, const double* A, int lda, const double* x, double beta,
                    double* y);
 /* Measurement helper: HIP-event time (ms, mean of reps) of the blocked upper Cholesky of an n x n positive definite matrix

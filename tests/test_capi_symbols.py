@@ -28,6 +28,16 @@ def test_library_exports_every_declared_symbol():
     assert set(syms) <= bound, sorted(set(syms) - bound)
 
 
+def test_header_declares_every_function_once():
+    """no duplicated prototypes, and every prototype directly follows its own doc block or a sibling prototype"""
+    txt = open(os.path.join(ROOT, "include", "hypatia_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = re.findall(r"^\s*(?:int|const char\*)\s+(hyp_[A-Za-z0-9_]+)\s*\(", txt, flags=re.M)
+    dups = sorted({n for n in names if names.count(n) > 1})
+    assert not dups, "declared more than once: %s" % dups
+    assert len(names) == len(_declared_symbols())
+
+
 def test_no_cpu_fallback_without_gpu():
     import hypatia_jl_amd as H
     import ctypes
