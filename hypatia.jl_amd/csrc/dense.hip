@@ -23,6 +23,10 @@ void potrf_diag_launch(hipStream_t st, bool factor, bool invert, int batch, int 
                        double* dinv, long strideD, int* info, int own_cu_lds = 0);
 int potrf_diag_own_cu_lds();
 void potrf_panel_solve_launch(hipStream_t st, int batch, double* A, long lda, long strideA, int k0, int mcols);
+// potrf_mfma.hip: the same two steps cut into 16 x 16 MFMA tiles (default; HYP_POTRF_MFMA=0 restores the first generation)
+void potrf_diag_mfma_launch(hipStream_t st, int batch, double* A, long lda, long strideA, int n, int k0, int* info, int own_cu_lds);
+int potrf_diag_mfma_own_cu_lds();
+void potrf_panel_mfma_launch(hipStream_t st, int batch, double* A, long lda, long strideA, int k0, int mcols);
 
 static void potrf_step_gemms(Ctx& c, hipStream_t st, int nb, int M, int N, const double* U12a, const double* U12b, long lda, long strideA,
                              double* C, int tri, int batch) {
@@ -90,9 +94,11 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
   const bool lookahead = (la_env != 0 && batch == 1 && nblk >= 6);
   // with look-ahead the diagonal-block kernel shares the chip with the helper stream's GEMM: it takes a CU of its own
   static const int own_env = [] { const char* e = getenv("HYP_POTRF_OWN_CU"); return e ? atoi(e) : 1; }();
+  static const int mfma_env = [] { const char* e = getenv("HYP_POTRF_MFMA"); return e ? atoi(e) : 1; }();
+  const bool tiles = (mfma_env != 0);
   int own_cu_lds = 0;
   if (lookahead && own_env != 0) {
-    if (c.diag_own_cu_lds < 0) c.diag_own_cu_lds = potrf_diag_own_cu_lds();
+    if (c.diag_own_cu_lds < 0) c.diag_own_cu_lds = tiles ? potrf_diag_mfma_own_cu_lds() : potrf_diag_own_cu_lds();
     own_cu_lds = c.diag_own_cu_lds;
   }
   for (int kb = 0; kb < nblk; ++kb) {
@@ -100,11 +106,13 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
     const int nb = std::min(NB, n - k0);
     const int m = n - k0 - nb;
     // factor only: the inverses of all diagonal blocks are produced by ONE launch after the loop
-    potrf_diag_launch(c.stream, true, false, batch, 1, A, lda, strideA, n, k0, dinv, strideD, d_info, own_cu_lds);
+    if (tiles) potrf_diag_mfma_launch(c.stream, batch, A, lda, strideA, n, k0, d_info, own_cu_lds);
+    else potrf_diag_launch(c.stream, true, false, batch, 1, A, lda, strideA, n, k0, dinv, strideD, d_info, own_cu_lds);
     if (m <= 0) break;
     double* A12 = A + (long)(k0 + nb) * lda + k0;
     double* A22 = A + (long)(k0 + nb) * lda + (k0 + nb);
-    potrf_panel_solve_launch(c.stream, batch, A, lda, strideA, k0, m);   // A12 <- U11^-T A12 (substitution)
+    if (tiles) potrf_panel_mfma_launch(c.stream, batch, A, lda, strideA, k0, m);
+    else potrf_panel_solve_launch(c.stream, batch, A, lda, strideA, k0, m);   // A12 <- U11^-T A12 (substitution)
     if (!lookahead) {
       potrf_step_gemms(c, c.stream, nb, m, m, A12, A12, lda, strideA, A22, GEMM_UPPER, batch);   // A22 -= A12' A12 (upper)
       continue;

@@ -1,0 +1,497 @@
+// Critical-path kernels of the blocked Cholesky (dense.hip: potrf_upper_batched), second generation: the 128 x 128
+// diagonal block factor and the 128 x m panel solve, both cut into 16 x 16 MFMA tiles.
+//   dpotrf 'U' of the reference: /root/reference/src/linearalgebra/dense.jl:189-200 (posdef_fact!), called from
+//   src/Solvers/systemsolvers/qrchol.jl:249-250 and src/Cones/possemideftri.jl:85,94.
+//
+// Why: the first generation (potrf_diag.hip) advanced one COLUMN per workgroup barrier (128 barriers + LDS round trips per
+// diagonal block, 43 us) and one column per DPP step in the panel (26 us); 39 such pairs in a row are 2.7 of the 3.8 ms the
+// n = 5000 factorization took (profiles/r01_cholesky_timeline.txt).  Here a block advances 16 rows per step:
+//   * the 16 x 16 diagonal tile is factored inside ONE wavefront (column per lane, pivot row broadcast with v_readlane:
+//     no barrier, no LDS round trip per column),
+//   * the row panel right of it is solved by forward SUBSTITUTION against that tile (dtrsm's rounding; no inverse),
+//     column per lane with the tile's rows broadcast from LDS,
+//   * everything below is a rank-16 update on v_mfma_f64_16x16x4_f64, accumulators resident in registers for the whole
+//     kernel (the block never round-trips through memory between steps).
+// Tile register layout = the MFMA C/D layout: lane (q = lane >> 4, n = lane & 15), register r holds row q + 4 r of column n.
+// With the panel tile of block step jb used as the MFMA's second operand, its register r IS k-chunk r of the operand (rows
+// 4 r .. 4 r + 3 over q), so solved tiles feed the rank-16 update with no data movement; the first operand (the tile of U
+// left of the diagonal, transposed by the MFMA's own operand convention) comes from LDS, tiles stored [k][m] with a row
+// stride of 17 doubles (conflict-free for the column writes and for the operand reads).
+// Deterministic: fixed tile ownership and summation order.
+#include "hyp_internal.hpp"
+#include <utility>
+
+namespace hyp {
+
+#ifdef HYP_PROBE   // tools/probe_potrf.hip: s_memtime stamps of the phases (lane 0 of wavefront 0 of workgroup 0)
+__device__ long long g_stamps[64];
+#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_stamps[i] = clock64(); } while (0)
+__device__ long long g_wstamps[8][16];
+#define WSTAMP(cond, i) do { if ((cond) && (threadIdx.x & 63) == 0 && blockIdx.x == 0) g_wstamps[threadIdx.x >> 6][i] = clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#define WSTAMP(cond, i) do { } while (0)
+#endif
+
+namespace {
+
+// two doubles stored together where the address is only known to be 8-byte aligned (lda and k0 are arbitrary)
+struct __attribute__((packed, aligned(8))) d2_t { double a, b; };
+constexpr int TS = 17;          // row stride of a 16 x 16 tile in LDS
+constexpr int TL = 16 * TS;     // doubles per tile in LDS
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL store of the
+// wavefront (s_waitcnt vmcnt(0)), which would put the write-back of finished tiles on the critical path of every step
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ d4_t mfma4(double a, double b, d4_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+// value of lane L of each 16-lane row (DPP row_newbcast): the four rows of a wavefront hold identical copies wherever this is used
+template <int L>
+__device__ __forceinline__ double bcast16(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + L, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + L, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// C/D layout -> every lane holds all 16 rows of its column (the four lanes of a column end up with identical copies)
+__device__ __forceinline__ void tile_gather(const d4_t& c, int n, double (&x)[16]) {
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[4 * r + qq] = __shfl(c[r], qq * 16 + n, 64);
+}
+__device__ __forceinline__ void tile_scatter(const double (&x)[16], int q, d4_t& c) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    // (three selects; the empty asm keeps the compiler from turning them into a scratch array indexed by q)
+    double v = x[4 * r];
+    v = (q == 1) ? x[4 * r + 1] : v;
+    asm volatile("" : "+v"(v));
+    v = (q == 2) ? x[4 * r + 2] : v;
+    asm volatile("" : "+v"(v));
+    v = (q == 3) ? x[4 * r + 3] : v;
+    c[r] = v;
+  }
+}
+
+// x <- T^-T x for the upper triangular tile T (LDS, [j * TS + i]) by forward substitution, rinv[j] = 1 / T[j][j].
+// The tile's rows are wave-uniform LDS reads (broadcast); row j + 1 is fetched while row j is applied -- written out by
+// hand because the compiler otherwise waits for every single read in front of its FMA (136 serial LDS round trips).
+__device__ __forceinline__ void tile_subst(double (&x)[16], const double* __restrict__ T, const double* __restrict__ rinv) {
+  double rv[16], row[2][16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) rv[j] = rinv[j];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) row[0][i] = T[i];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (j + 1 < 15) {
+#pragma unroll
+      for (int i = j + 2; i < 16; ++i) row[(j + 1) & 1][i] = T[(j + 1) * TS + i];
+    }
+    x[j] *= rv[j];
+#pragma unroll
+    for (int i = j + 1; i < 16; ++i) x[i] = fma(-row[j & 1][i], x[j], x[i]);
+  }
+}
+
+// the same for two columns per lane at once: one read of the tile's row serves both, and the two dependent chains fill each
+// other's 32-cycle latency shadows
+__device__ __forceinline__ void tile_subst2(double (&x)[16], double (&y)[16], const double* __restrict__ T, const double* __restrict__ rinv) {
+  double rv[16], row[2][16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) rv[j] = rinv[j];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) row[0][i] = T[i];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (j + 1 < 15) {
+#pragma unroll
+      for (int i = j + 2; i < 16; ++i) row[(j + 1) & 1][i] = T[(j + 1) * TS + i];
+    }
+    x[j] *= rv[j];
+    y[j] *= rv[j];
+#pragma unroll
+    for (int i = j + 1; i < 16; ++i) {
+      x[i] = fma(-row[j & 1][i], x[j], x[i]);
+      y[i] = fma(-row[j & 1][i], y[j], y[i]);
+    }
+  }
+}
+
+// the rows 4 q .. 4 q + 3 of a lane's column, for 32-byte contiguous stores (the four lanes of a column cover its 128 bytes)
+__device__ __forceinline__ void tile_rows4(const double (&x)[16], int q, double (&v)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    double t = x[i];
+    t = (q == 1) ? x[4 + i] : t;
+    asm volatile("" : "+v"(t));
+    t = (q == 2) ? x[8 + i] : t;
+    asm volatile("" : "+v"(t));
+    t = (q == 3) ? x[12 + i] : t;
+    v[i] = t;
+  }
+}
+
+// 1 / sqrt(d) and sqrt(d) to an ulp or two without the division / square-root expansions: v_rsq_f64 + two Newton
+// steps, one correction of s (off the critical path: 16 independent chains interleave)
+__device__ __forceinline__ void rsqrt_sqrt(double d, double& r, double& s) {
+  r = __builtin_amdgcn_rsq(d);
+  const double h = 0.5 * d;
+  double e = fma(-h * r, r, 0.5);
+  r = fma(r, e, r);
+  e = fma(-h * r, r, 0.5);
+  r = fma(r, e, r);
+  s = d * r;
+  const double t = fma(-s, s, d);
+  s = fma(0.5 * r, t, s);
+}
+
+// Upper Cholesky of one 16 x 16 tile inside a wavefront.  Lane n (every 16-lane row holds a copy) owns column n, rows
+// 0 .. n meaningful.  A dependent v_fma_f64 costs 32 cycles on gfx950 (tools/probe_potrf.hip), so what matters is the
+// number of double-precision operations between one pivot and the next.  The elimination therefore runs on UNSCALED rows
+// (the L D L' form): step j broadcasts the raw pivot d_j (DPP), refines 1 / d_j from v_rcp_f64 with one cubic step
+// (e = 1 - d r; r += r (e + e^2): three operations), forms the lane's multiplier f = w_jn / d_j and applies
+// a_in -= w_ji f with the raw row broadcast by DPP ahead of time -- six operations from pivot to pivot.  The rows are scaled
+// by 1 / sqrt(d_j) afterwards, all sixteen chains side by side.  fail = 0 or the 1-based index of the first non-positive
+// pivot; after a failure the remaining arithmetic runs on meaningless numbers (dpotrf stops there; callers only read info).
+template <int J, int... Is>
+__device__ __forceinline__ void tile_potrf_updates(double (&x)[16], double f, std::integer_sequence<int, Is...>) {
+  ((x[J + 1 + Is] = fma(-bcast16<J + 1 + Is>(x[J]), f, x[J + 1 + Is])), ...);
+}
+template <int J>
+__device__ __forceinline__ void tile_potrf_step(double (&x)[16], double (&piv)[16]) {
+  const double d = bcast16<J>(x[J]);
+  piv[J] = d;
+  double r = __builtin_amdgcn_rcp(d);
+  const double e = fma(-d, r, 1.0);
+  const double p = fma(e, e, e);
+  r = fma(r, p, r);
+  const double f = x[J] * r;
+  tile_potrf_updates<J>(x, f, std::make_integer_sequence<int, 15 - J>{});
+}
+template <int... Js>
+__device__ __forceinline__ void tile_potrf_all(double (&x)[16], double (&piv)[16], std::integer_sequence<int, Js...>) {
+  (tile_potrf_step<Js>(x, piv), ...);
+}
+__device__ __forceinline__ int tile_potrf(double (&x)[16], int n, double (&ri)[16]) {
+  double piv[16];
+  tile_potrf_all(x, piv, std::make_integer_sequence<int, 16>{});
+  int fail = 0;
+#pragma unroll
+  for (int j = 15; j >= 0; --j) fail = !(piv[j] > 0.0) ? j + 1 : fail;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    double r, sq;
+    rsqrt_sqrt(piv[j], r, sq);
+    ri[j] = r;
+    x[j] = (n == j) ? sq : x[j] * r;
+  }
+  return fail;
+}
+
+}  // namespace
+
+// =============================================================================================
+// Diagonal block: A[k0 : k0 + nb, k0 : k0 + nb] (upper) <- its Cholesky factor, nb <= 128.  One workgroup of EIGHT
+// wavefronts (two per SIMD); wavefront w owns tile column w (tiles (a, w), a <= w).  Block step jb:
+//   1. wavefront jb factors the diagonal tile in registers and publishes it (LDS);           -- barrier --
+//   2. wavefronts w > jb solve their tile (jb, w) against it, store it (final) and publish it; -- barrier --
+//   3. wavefronts w > jb apply the rank-16 update to their tiles (a, w), jb < a <= w.
+// Wavefront jb + 1 has ONE tile to update before it factors the next diagonal tile, so the critical path of a step is
+// factor + one solve + one update; the other wavefronts' updates run underneath the next factorization.
+// =============================================================================================
+// the code of wavefront W, fully specialised (tile ownership, loop bounds and register indices are compile-time: with a
+// run-time wavefront index every MFMA sat in its own exec-masked block behind a waited LDS read, ~500 cycles apiece).
+// Wavefront W owns tile columns W and 7 - W (9 tiles each way).
+template <int W>
+__device__ __forceinline__ void potrf_diag_wave(double* __restrict__ Ab, long lda, int nb, int nbt, int lane, double* Dt, double* rinv, double* Pt,
+                                                int* sfail) {
+  constexpr int C0 = W, C1 = 7 - W;
+  const int q = lane >> 4, nn = lane & 15;
+  const int l0 = 16 * C0 + nn, l1 = 16 * C1 + nn;   // this lane's two columns of the block
+  double* colp0 = Ab + (long)min(l0, nb - 1) * lda;
+  double* colp1 = Ab + (long)min(l1, nb - 1) * lda;
+  d4_t acc0[8], acc1[8];
+  // loads: unconditional on clamped addresses (a predicated load is waited for individually), identity padding applied after
+#pragma unroll
+  for (int a = 0; a <= C0; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc0[a][r] = colp0[min(16 * a + q + 4 * r, nb - 1)];
+#pragma unroll
+  for (int a = 0; a <= C1; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc1[a][r] = colp1[min(16 * a + q + 4 * r, nb - 1)];
+#pragma unroll
+  for (int a = 0; a <= C0; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * a + q + 4 * r;
+      acc0[a][r] = (i < nb && l0 < nb && i <= l0) ? acc0[a][r] : (i == l0 ? 1.0 : 0.0);
+    }
+#pragma unroll
+  for (int a = 0; a <= C1; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * a + q + 4 * r;
+      acc1[a][r] = (i < nb && l1 < nb && i <= l1) ? acc1[a][r] : (i == l1 ? 1.0 : 0.0);
+    }
+  if (W == 0 && lane == 0) *sfail = 0;   // (wavefront 0 also owns block step 0; later owners write after barriers)
+  STAMP(0);
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) {
+    if (jb >= nbt) break;   // (identity padding needs no elimination)
+    if (jb == 1) STAMP(4);
+    WSTAMP(jb == 2, 0);
+    // ---- 1. the owner of tile column jb factors the diagonal tile and publishes it
+    const bool own0 = (C0 == jb), own1 = (C1 == jb);
+    double xd[16];
+    if (own0 || own1) {
+      double ri[16];
+      tile_gather(own0 ? acc0[jb] : acc1[jb], nn, xd);
+      const int f = tile_potrf(xd, nn, ri);
+      if (q == 0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) Dt[j * TS + nn] = xd[j];
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) rinv[j] = ri[j];
+        if (f && *sfail == 0) *sfail = 16 * jb + f;
+      }
+    }
+    WSTAMP(jb == 2, 3);
+    lds_barrier();
+    WSTAMP(jb == 2, 4);
+    if (jb == 0) STAMP(1);
+    if (own0 || own1) {   // upper triangle of the diagonal tile -> memory (off the critical path: the others are solving)
+      const int l = own0 ? l0 : l1;
+      double* colp = own0 ? colp0 : colp1;
+      if (q == 0 && l < nb) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (j <= nn) colp[16 * jb + j] = xd[j];
+      }
+    }
+    // ---- 2. row panel: the owned tiles (jb, C0), (jb, C1) right of the diagonal are solved against it and published
+    const bool m0 = (C0 > jb) && (16 * C0 < nb), m1 = (C1 > jb) && (16 * C1 < nb);
+    double x0[16], x1[16];
+    if (m0 && m1) {
+      tile_gather(acc0[jb], nn, x0);
+      tile_gather(acc1[jb], nn, x1);
+      tile_subst2(x0, x1, Dt, rinv);
+    } else if (m0) {
+      tile_gather(acc0[jb], nn, x0);
+      tile_subst(x0, Dt, rinv);
+    } else if (m1) {
+      tile_gather(acc1[jb], nn, x1);
+      tile_subst(x1, Dt, rinv);
+    }
+    if (m0) {
+      tile_scatter(x0, q, acc0[jb]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Pt[C0 * TL + (4 * r + q) * TS + nn] = acc0[jb][r];
+    }
+    if (m1) {
+      tile_scatter(x1, q, acc1[jb]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Pt[C1 * TL + (4 * r + q) * TS + nn] = acc1[jb][r];
+    }
+    WSTAMP(jb == 2, 8);
+    lds_barrier();
+    WSTAMP(jb == 2, 9);
+    if (jb == 0) STAMP(2);
+    // ---- 3. rank-16 update of the owned tiles (a, C), jb < a <= C: k-chunks outside, tiles inside (independent accumulators
+    //         back to back; a dependent MFMA waits for its predecessor).  The own column's diagonal tile needs no LDS: its
+    //         registers ARE the first operand -- and it goes first: it is the next diagonal tile when C = jb + 1.
+    if (m0 || m1) {
+      constexpr int AMAX = (C0 > C1) ? C0 : C1;
+      double op[4][8];
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+        for (int a = jb + 1; a <= AMAX; ++a) op[kc][a] = Pt[a * TL + (4 * kc + q) * TS + nn];
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+        if (m0) acc0[C0] = mfma4(acc0[jb][kc], -acc0[jb][kc], acc0[C0]);
+        if (m1) acc1[C1] = mfma4(acc1[jb][kc], -acc1[jb][kc], acc1[C1]);
+#pragma unroll
+        for (int a = jb + 1; a <= AMAX; ++a) {
+          if (m0 && a < C0) acc0[a] = mfma4(op[kc][a], -acc0[jb][kc], acc0[a]);
+          if (m1 && a < C1) acc1[a] = mfma4(op[kc][a], -acc1[jb][kc], acc1[a]);
+        }
+      }
+    }
+    // the solved rows are final: 32 contiguous bytes per lane
+    if (m0 && l0 < nb) {
+      double v[4];
+      tile_rows4(x0, q, v);
+      double* dst = colp0 + 16 * jb + 4 * q;
+      *reinterpret_cast<d2_t*>(dst) = (d2_t){v[0], v[1]};
+      *reinterpret_cast<d2_t*>(dst + 2) = (d2_t){v[2], v[3]};
+    }
+    if (m1 && l1 < nb) {
+      double v[4];
+      tile_rows4(x1, q, v);
+      double* dst = colp1 + 16 * jb + 4 * q;
+      *reinterpret_cast<d2_t*>(dst) = (d2_t){v[0], v[1]};
+      *reinterpret_cast<d2_t*>(dst + 2) = (d2_t){v[2], v[3]};
+    }
+    WSTAMP(jb == 2, 10);
+  }
+  STAMP(5);
+}
+
+__global__ __launch_bounds__(256) void potrf_diag_mfma_kernel(double* __restrict__ A, long lda, long strideA, int n, int k0, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double pm_lds[];
+  double* Dt = pm_lds;              // factor of the current diagonal tile
+  double* rinv = pm_lds + TL;       // 1 / its diagonal
+  double* Pt = pm_lds + TL + 16;    // solved row panel of the current block step: tile b at Pt + b * TL, [k][m]
+  int* sfail = reinterpret_cast<int*>(pm_lds + TL + 16 + 8 * TL);   // first failed pivot of the block (1-based), 0 = none
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nb = min(NB, n - k0);
+  const int nbt = (nb + 15) >> 4;
+  double* Ab = A + (long)blockIdx.x * strideA + (long)k0 * lda + k0;
+  switch (w) {
+    case 0: potrf_diag_wave<0>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail); break;
+    case 1: potrf_diag_wave<1>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail); break;
+    case 2: potrf_diag_wave<2>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail); break;
+    default: potrf_diag_wave<3>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail); break;
+  }
+  lds_barrier();
+  if (tid == 0 && *sfail && *sfail <= nb) atomicCAS(&info[blockIdx.x], 0, k0 + *sfail);
+  STAMP(6);
+}
+
+// =============================================================================================
+// Panel solve: A12 <- U11^-T A12 (dtrsm 'L','U','T','N'), U11 = the factored 128 x 128 diagonal block, A12 128 x mcols.
+// One wavefront per 16 columns, WAVES wavefronts per workgroup share U11 in LDS (36 upper tiles, 77 KB).
+// =============================================================================================
+__device__ __forceinline__ constexpr int tix(int a, int b) { return a * 8 - a * (a - 1) / 2 + (b - a); }
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void potrf_panel_mfma_kernel(double* __restrict__ A, long lda, long strideA, int k0, int mcols) {
+  extern __shared__ __attribute__((aligned(16))) double pm_lds[];
+  double* Ut = pm_lds;               // 36 tiles
+  double* rinv = pm_lds + 36 * TL;   // 128
+  constexpr int THREADS = 64 * WAVES;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, q = lane >> 4, nn = lane & 15;
+  double* Ab = A + (long)blockIdx.y * strideA;
+  const double* U11 = Ab + (long)k0 * lda + k0;
+  double* A12 = Ab + (long)(k0 + NB) * lda + k0;
+  const int c0 = (blockIdx.x * WAVES + wv) * 16;
+  const bool active = c0 < mcols;
+  double* colp = A12 + (long)min(c0 + nn, mcols - 1) * lda;
+
+  // this wavefront's 128 x 16 slab first (the longest latency), then U11 -> LDS: ALL loads of a half are issued before
+  // the first LDS store waits for one (a load-store pair per tile row serialises on the memory latency)
+  STAMP(10);
+  d4_t acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[i][r] = colp[16 * i + q + 4 * r];
+  {
+    constexpr int PER = 256 / THREADS;   // elements of a tile per thread
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      double v[18][PER];
+#pragma unroll
+      for (int t = 0; t < 18; ++t) {
+        const int ti = 18 * half + t;
+        // tile index -> (a, b), row-major over the upper triangle
+        int a = 0, rem = ti;
+#pragma unroll
+        for (int aa = 0; aa < 8; ++aa)
+          if (rem >= 8 - aa && a == aa) { rem -= 8 - aa; a = aa + 1; }
+        const int b = a + rem;
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+          const int e = tid + THREADS * p, k = e & 15, m = e >> 4;
+          v[t][p] = U11[(long)(16 * b + m) * lda + 16 * a + k];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 18; ++t) {
+        const int ti = 18 * half + t;
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+          const int e = tid + THREADS * p, k = e & 15, m = e >> 4;
+          Ut[ti * TL + k * TS + m] = v[t][p];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  STAMP(11);
+  for (int t = tid; t < NB; t += THREADS) rinv[t] = 1.0 / Ut[tix(t >> 4, t >> 4) * TL + (t & 15) * TS + (t & 15)];
+  __syncthreads();
+  if (!active) return;
+  STAMP(12);
+
+  const bool inb = c0 + nn < mcols;
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) {
+    if (jb == 1) STAMP(13);
+    double x[16];
+    tile_gather(acc[jb], nn, x);
+    tile_subst(x, Ut + tix(jb, jb) * TL, rinv + 16 * jb);
+    tile_scatter(x, q, acc[jb]);
+    if (inb) {   // rows 16 jb .. 16 jb + 15 of this column are final: 32 contiguous bytes per lane
+      double v[4];
+      tile_rows4(x, q, v);
+      double* dst = colp + 16 * jb + 4 * q;
+      *reinterpret_cast<d2_t*>(dst) = (d2_t){v[0], v[1]};
+      *reinterpret_cast<d2_t*>(dst + 2) = (d2_t){v[2], v[3]};
+    }
+    const d4_t c = acc[jb];
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+      for (int i = jb + 1; i < 8; ++i) acc[i] = mfma4(Ut[tix(jb, i) * TL + (4 * kc + q) * TS + nn], -c[kc], acc[i]);
+  }
+  STAMP(14);
+  STAMP(15);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers (same contracts as potrf_diag_launch(factor only) / potrf_panel_solve_launch of potrf_diag.hip)
+// ---------------------------------------------------------------------------------------------
+void potrf_diag_mfma_launch(hipStream_t st, int batch, double* A, long lda, long strideA, int n, int k0, int* info, int own_cu_lds) {
+  const size_t lds = (size_t)(TL + 16 + 8 * TL + 2) * sizeof(double);
+  const size_t want = own_cu_lds > 0 ? std::max<size_t>(lds, (size_t)own_cu_lds) : lds;
+  hipLaunchKernelGGL(potrf_diag_mfma_kernel, dim3(batch), dim3(256), want, st, A, lda, strideA, n, k0, info);
+  HYP_CHECK(hipGetLastError());
+}
+int potrf_diag_mfma_own_cu_lds() {
+  const int want = 124 * 1024;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_diag_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return want;
+}
+
+void potrf_panel_mfma_launch(hipStream_t st, int batch, double* A, long lda, long strideA, int k0, int mcols) {
+  if (mcols <= 0) return;
+  const size_t lds = (size_t)(36 * TL + NB) * sizeof(double);
+  static const int waves = [] { const char* e = getenv("HYP_PANEL_WAVES"); const int v = e ? atoi(e) : 2; return (v == 1 || v == 2 || v == 4) ? v : 2; }();
+  static bool attr_set = false;
+  if (!attr_set) {
+    HYP_CHECK(hipFuncSetAttribute((const void*)potrf_panel_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HYP_CHECK(hipFuncSetAttribute((const void*)potrf_panel_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HYP_CHECK(hipFuncSetAttribute((const void*)potrf_panel_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const dim3 grid((mcols + 16 * waves - 1) / (16 * waves), batch);
+  if (waves == 1) hipLaunchKernelGGL(potrf_panel_mfma_kernel<1>, grid, dim3(64), lds, st, A, lda, strideA, k0, mcols);
+  else if (waves == 2) hipLaunchKernelGGL(potrf_panel_mfma_kernel<2>, grid, dim3(128), lds, st, A, lda, strideA, k0, mcols);
+  else hipLaunchKernelGGL(potrf_panel_mfma_kernel<4>, grid, dim3(256), lds, st, A, lda, strideA, k0, mcols);
+  HYP_CHECK(hipGetLastError());
+}
+
+}  // namespace hyp
