@@ -2,6 +2,9 @@
  * `ccall` glue makes.  PosSemidefTri(side 3) at a perturbed interior point: feasibility, gradient,
  * H^-1 H v = v, <g, point> = -nu; then a QRChol system solver over a random G: Schur assembly + factorization, one
  * solve_subsystem3, and the identity  lhs x = rhs_x + G'(H rhs_z-part ...)  checked through lhs itself.
+ * Then the two other cones of the north star, created and driven from C as well: EpiNormSpectral(2, 3) and
+ * WSOSInterpNonnegative (U = 3, two basis matrices passed as an array of pointers), their use_dual_barrier flags
+ * (WSOS inverts use_dual: wsosinterpnonnegative.jl:58), identities, and a system solver over both.
  * Exit code 0 on success; prints the failing check otherwise.  Built and run by tests/test_c_abi.py. */
 #include <math.h>
 #include <stdio.h>
@@ -85,6 +88,109 @@ int main(void) {
   }
   CHECK(hyp_sys_destroy(sys));
   CHECK(hyp_cone_destroy(cone));
+
+  /* ---- EpiNormSpectral(d1 = 2, d2 = 3): dim 7, nu = d1 + 1 (epinormspectral.jl:53-66, 97) */
+  enum { D1 = 2, D2 = 3, EDIM = 1 + D1 * D2, U = 3, K = 2, Q2 = EDIM + U, N2 = 3 };
+  hyp_cone* ens = NULL;
+  CHECK(hyp_cone_create_epinormspectral(ctx, D1, D2, 0, &ens));
+  int udb = -1;
+  CHECK(hyp_cone_dimension(ens, &dim));
+  CHECK(hyp_cone_get_nu(ens, &nu));
+  CHECK(hyp_cone_use_dual_barrier(ens, &udb));
+  REQUIRE(dim == EDIM && nu == D1 + 1 && udb == 0);
+  double ept[EDIM], eg[EDIM], ev[EDIM] = {0.2, -0.1, 0.3, 0.05, -0.2, 0.15, 0.1}, ehv[EDIM], ew[EDIM];
+  CHECK(hyp_cone_set_initial_point(ens, ept));            /* (sqrt(nu), 0) */
+  REQUIRE(fabs(ept[0] - sqrt(3.0)) < 1e-15);
+  ept[1] += 0.3; ept[4] -= 0.2; ept[6] += 0.1;            /* sigma_1(W) well below u */
+  CHECK(hyp_cone_load_point(ens, ept, 1.0));
+  CHECK(hyp_cone_reset_data(ens));
+  CHECK(hyp_cone_is_feas(ens, &feas));
+  REQUIRE(feas == 1);
+  CHECK(hyp_cone_grad(ens, eg));
+  gp = 0;
+  for (int i = 0; i < EDIM; ++i) gp += eg[i] * ept[i];
+  REQUIRE(fabs(gp + nu) < 1e-12);
+  CHECK(hyp_cone_hess_prod(ens, ehv, EDIM, ev, EDIM, 1));
+  CHECK(hyp_cone_inv_hess_prod(ens, ew, EDIM, ehv, EDIM, 1));
+  for (int i = 0; i < EDIM; ++i) REQUIRE(fabs(ew[i] - ev[i]) < 1e-10);
+  /* dual feasibility = nuclear norm test (epinormspectral.jl:125-132): u = 10 dominates any sum of singular values here */
+  double edual[EDIM] = {10.0, 0.5, -0.5, 0.25, 1.0, -1.0, 0.75};
+  CHECK(hyp_cone_load_dual_point(ens, edual));
+  CHECK(hyp_cone_is_dual_feas(ens, &feas));
+  REQUIRE(feas == 1);
+  edual[0] = 0.1;
+  CHECK(hyp_cone_load_dual_point(ens, edual));
+  CHECK(hyp_cone_is_dual_feas(ens, &feas));
+  REQUIRE(feas == 0);
+
+  /* ---- WSOSInterpNonnegative(U = 3, Ps = [P0 (3 x 2), P1 (3 x 1)]): univariate, half-degree 1 on [-1, 1] at the points
+   *      -1, 0, 1 with the monomial basis (wsosinterpnonnegative.jl:49-63); Ps as an array of K column-major matrices */
+  static const double P0[U * 2] = {1.0, 1.0, 1.0, -1.0, 0.0, 1.0};   /* columns: 1, x */
+  static const double P1[U * 1] = {0.0, 1.0, 0.0};                  /* sqrt(1 - x^2) * 1 */
+  const double* Ps[K] = {P0, P1};
+  const int Ls[K] = {2, 1};
+  hyp_cone* wsos = NULL;
+  CHECK(hyp_cone_create_wsosinterpnonnegative(ctx, U, K, Ls, Ps, 0, &wsos));
+  CHECK(hyp_cone_dimension(wsos, &dim));
+  CHECK(hyp_cone_get_nu(wsos, &nu));
+  CHECK(hyp_cone_use_dual_barrier(wsos, &udb));
+  REQUIRE(dim == U && nu == 3.0 && udb == 1);            /* use_dual = false -> the barrier is for the dual cone (:58) */
+  double wpt[U], wg[U], wv[U] = {0.3, -0.2, 0.1}, whv[U], ww[U];
+  CHECK(hyp_cone_set_initial_point(wsos, wpt));
+  for (int i = 0; i < U; ++i) REQUIRE(wpt[i] == 1.0);
+  wpt[0] = 0.8; wpt[1] = 1.3; wpt[2] = 1.1;
+  CHECK(hyp_cone_load_point(wsos, wpt, 1.0));
+  CHECK(hyp_cone_reset_data(wsos));
+  CHECK(hyp_cone_is_feas(wsos, &feas));
+  REQUIRE(feas == 1);
+  CHECK(hyp_cone_grad(wsos, wg));
+  gp = 0;
+  for (int i = 0; i < U; ++i) gp += wg[i] * wpt[i];
+  REQUIRE(fabs(gp + nu) < 1e-12);
+  CHECK(hyp_cone_hess_prod(wsos, whv, U, wv, U, 1));
+  CHECK(hyp_cone_inv_hess_prod(wsos, ww, U, whv, U, 1));
+  for (int i = 0; i < U; ++i) REQUIRE(fabs(ww[i] - wv[i]) < 1e-10);
+  double wneg[U] = {1.0, -0.5, 1.0};                      /* Lambda_1 = P1' diag(pt) P1 = pt[1] < 0 */
+  CHECK(hyp_cone_load_point(wsos, wneg, 1.0));
+  CHECK(hyp_cone_reset_data(wsos));
+  CHECK(hyp_cone_is_feas(wsos, &feas));
+  REQUIRE(feas == 0);
+  CHECK(hyp_cone_load_point(wsos, wpt, 1.0));
+  CHECK(hyp_cone_reset_data(wsos));
+  CHECK(hyp_cone_is_feas(wsos, &feas));
+  REQUIRE(feas == 1);
+
+  /* ---- a system solver over both: lhs = G1' H1 G1 + G2' H2^-1 G2 (primal- / dual-barrier cone: qrchol.jl:219-246) */
+  double G2[Q2 * N2];
+  for (int i = 0; i < Q2 * N2; ++i) { s = s * 1664525u + 1013904223u; G2[i] = ((double)(s >> 8) / 16777216.0) - 0.5; }
+  hyp_cone* cones2[2] = {ens, wsos};
+  CHECK(hyp_sys_create(ctx, N2, 0, Q2, cones2, 2, &sys));
+  CHECK(hyp_sys_load(sys, G2, NULL, NULL, NULL, NULL));
+  int use_sqrt2[2] = {0, 0};
+  CHECK(hyp_sys_update_lhs_fact(sys, use_sqrt2, &info, &fb));
+  REQUIRE(info == 0);
+  double lhs2[N2 * N2], col1[EDIM], col2[U], Hc1[EDIM], Hc2[U];
+  CHECK(hyp_sys_get_lhs(sys, lhs2));
+  for (int i = 0; i < EDIM; ++i) col1[i] = G2[i];        /* column 0 of G, rows of each cone */
+  for (int i = 0; i < U; ++i) col2[i] = G2[EDIM + i];
+  CHECK(hyp_cone_hess_prod(ens, Hc1, EDIM, col1, EDIM, 1));
+  CHECK(hyp_cone_inv_hess_prod(wsos, Hc2, U, col2, U, 1));
+  for (int j = 0; j < N2; ++j) {
+    double r = 0;
+    for (int i = 0; i < EDIM; ++i) r += G2[j * Q2 + i] * Hc1[i];
+    for (int i = 0; i < U; ++i) r += G2[j * Q2 + EDIM + i] * Hc2[i];
+    REQUIRE(fabs(r - lhs2[j * N2 + 0]) < 1e-10 * (1 + fabs(r)));
+  }
+  double rhs2[N2 + Q2] = {1.0, -2.0, 0.5}, sol2[N2 + Q2];
+  CHECK(hyp_sys_solve3(sys, sol2, rhs2));
+  for (int i = 0; i < N2; ++i) {
+    double r = 0;
+    for (int j = 0; j < N2; ++j) r += (i <= j ? lhs2[j * N2 + i] : lhs2[i * N2 + j]) * sol2[j];
+    REQUIRE(fabs(r - rhs2[i]) < 1e-9);
+  }
+  CHECK(hyp_sys_destroy(sys));
+  CHECK(hyp_cone_destroy(ens));
+  CHECK(hyp_cone_destroy(wsos));
   CHECK(hyp_ctx_destroy(ctx));
   printf("c abi smoke ok\n");
   return 0;
