@@ -77,6 +77,12 @@ SIGNATURES = {
     "hyp_sys_get_directions2": [c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int, c_dbl, c_dbl, P(c_dbl), P(c_int)],
     "hyp_sys_step_directions": [c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int, c_dbl, c_dbl, c_vp, c_vp, P(c_int), P(c_int), P(c_int), P(c_int), c_vp],
     "hyp_sys_set_comm": [c_vp, c_vp, c_vp, c_vp, ctypes.c_long],
+    "hyp_comm_unique_id": [c_vp],
+    "hyp_comm_init_rank": [c_vp, c_int, c_int, c_vp, P(c_vp)],
+    "hyp_comm_destroy": [c_vp],
+    "hyp_comm_allreduce": [c_vp, c_vp, ctypes.c_long, c_int],
+    "hyp_sys_set_comm_rccl": [c_vp, c_vp],
+    "hyp_sys_comm_stats": [c_vp, c_vp],
     "hyp_sys_last_update_lhs_seconds": [c_vp, P(c_dbl)],
     "hyp_sys_bench_gemv": [c_vp, c_int, c_vp],
     "hyp_sys_search_alpha": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_dbl, c_dbl, c_int, c_dbl, c_vp,

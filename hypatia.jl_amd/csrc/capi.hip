@@ -12,6 +12,14 @@ struct hyp_ctx { Ctx c; hyp_ctx(int d) : c(d) {} };
 struct hyp_cone { hyp_ctx* ctx; Cone* cone; };
 struct hyp_sys { hyp_ctx* ctx; SysSolver* s; };
 struct hyp_symindef { hyp_ctx* ctx; SymIndefSys* s; };
+struct hyp_comm { hyp_ctx* ctx; void* nccl; int nranks, rank; };
+
+namespace hyp {   // rccl_comm.hip
+void rccl_allreduce_inplace(void* comm, double* d_buf, long count, int op, hipStream_t st);
+void rccl_unique_id(char* out128);
+void* rccl_init_rank(int device, int nranks, int rank, const char* id128);
+void rccl_destroy(void* comm);
+}
 
 static thread_local std::string g_last_error;
 
@@ -578,6 +586,53 @@ int hyp_sys_set_comm(hyp_sys* sys, int (*allreduce)(void* user, long count, int 
   s->comm_user = user;
   s->comm_stage = (double*)device_staging;
   s->comm_cap = capacity_doubles;
+  API_END(sys->ctx)
+}
+int hyp_comm_unique_id(char* out128) {
+  hyp_ctx* none = nullptr;
+  API_BEGIN
+  rccl_unique_id(out128);
+  API_END(none)
+}
+int hyp_comm_init_rank(hyp_ctx* ctx, int nranks, int rank, const char* id128, hyp_comm** out) {
+  API_BEGIN
+  hyp_comm* c = new hyp_comm{ctx, nullptr, nranks, rank};
+  try {
+    c->nccl = rccl_init_rank(ctx->c.device, nranks, rank, id128);
+  } catch (...) {
+    delete c;
+    throw;
+  }
+  *out = c;
+  API_END(ctx)
+}
+int hyp_comm_destroy(hyp_comm* comm) {
+  hyp_ctx* ctx = comm ? comm->ctx : nullptr;
+  API_BEGIN
+  if (comm) {
+    ctx->c.sync();
+    rccl_destroy(comm->nccl);
+    delete comm;
+  }
+  API_END(ctx)
+}
+int hyp_comm_allreduce(hyp_comm* comm, void* device_buf, long count, int op) {
+  API_BEGIN
+  HYP_REQUIRE(comm && comm->nccl && device_buf && count >= 0 && op >= 0 && op <= 2, "hyp_comm_allreduce: arguments");
+  if (count > 0) rccl_allreduce_inplace(comm->nccl, (double*)device_buf, count, op, comm->ctx->c.stream);
+  comm->ctx->c.sync();
+  API_END(comm->ctx)
+}
+int hyp_sys_set_comm_rccl(hyp_sys* sys, hyp_comm* comm) {
+  API_BEGIN
+  HYP_REQUIRE(comm == nullptr || comm->ctx == sys->ctx, "set_comm_rccl: the communicator belongs to another context");
+  sys->s->rccl_comm = comm ? comm->nccl : nullptr;
+  API_END(sys->ctx)
+}
+int hyp_sys_comm_stats(hyp_sys* sys, double* out2) {
+  API_BEGIN
+  out2[0] = (double)sys->s->comm_calls;
+  out2[1] = sys->s->comm_doubles;
   API_END(sys->ctx)
 }
 int hyp_sys_last_update_lhs_seconds(hyp_sys* sys, double* out) {

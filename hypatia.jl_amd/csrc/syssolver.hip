@@ -279,8 +279,17 @@ void SysSolver::load(const double* hG, const double* hGQ1, const double* hGQ2, c
   ctx.sync();
 }
 
+// rccl_comm.hip
+void rccl_allreduce_inplace(void* comm, double* d_buf, long count, int op, hipStream_t st);
+
 void SysSolver::allreduce_dev(double* d_buf, long count, int op) {
-  if (!comm_fn || count <= 0) return;
+  if (!dist() || count <= 0) return;
+  comm_calls += 1;
+  comm_doubles += (double)count;
+  if (rccl_comm) {   // in place, on the library stream: the consumers of d_buf are queued behind it
+    rccl_allreduce_inplace(rccl_comm, d_buf, count, op, ctx.stream);
+    return;
+  }
   HYP_REQUIRE(count <= comm_cap, "sys: all-reduce payload exceeds the registered staging buffer");
   ctx.d2d(comm_stage, d_buf, (size_t)count * sizeof(double));
   ctx.sync();
@@ -288,7 +297,18 @@ void SysSolver::allreduce_dev(double* d_buf, long count, int op) {
   ctx.d2d(d_buf, comm_stage, (size_t)count * sizeof(double));
 }
 void SysSolver::allreduce_host(double* h_buf, int count, int op) {
-  if (!comm_fn || count <= 0) return;
+  if (!dist() || count <= 0) return;
+  comm_calls += 1;
+  comm_doubles += (double)count;
+  if (rccl_comm) {   // scalars: through the context's device scalar buffer (64 doubles)
+    HYP_REQUIRE(count <= 32, "sys: host all-reduce payload");
+    double* d = ctx.dscal.d() + 32;
+    ctx.h2d(d, h_buf, (size_t)count * sizeof(double));
+    rccl_allreduce_inplace(rccl_comm, d, count, op, ctx.stream);
+    ctx.d2h(h_buf, d, (size_t)count * sizeof(double));
+    ctx.sync();
+    return;
+  }
   HYP_REQUIRE(count <= comm_cap, "sys: all-reduce payload exceeds the registered staging buffer");
   ctx.h2d(comm_stage, h_buf, (size_t)count * sizeof(double));
   ctx.sync();

@@ -67,7 +67,12 @@ struct SysSolver {
   void* comm_user = nullptr;
   double* comm_stage = nullptr;
   long comm_cap = 0;
-  bool dist() const { return comm_fn != nullptr; }
+  // The same exchanges through RCCL inside the library (hyp_sys_set_comm_rccl): ncclAllReduce in place on the library's own
+  // stream -- no staging copy, no host callback, and no host synchronisation for device payloads (stream order).
+  void* rccl_comm = nullptr;     // ncclComm_t
+  long comm_calls = 0;           // exchanges issued since creation (hyp_sys_comm_stats)
+  double comm_doubles = 0;
+  bool dist() const { return comm_fn != nullptr || rccl_comm != nullptr; }
   void allreduce_dev(double* d_buf, long count, int op);
   void allreduce_host(double* h_buf, int count, int op);
 

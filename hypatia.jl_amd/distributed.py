@@ -344,8 +344,24 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
 
         self._cb = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_int)(_allreduce)
         lib, h = L.lib(), self.local._h
-        L.check(lib.hyp_sys_set_comm(h, ctypes.cast(self._cb, ctypes.c_void_p), None, ctypes.c_void_p(stage.data_ptr()), int(stage.numel())),
-                "hyp_sys_set_comm")
+        self.rccl_in_library = False
+        if dist.get_backend() == "nccl" and os.environ.get("HYP_DIST_RCCL", "1") not in ("0",):
+            # RCCL inside the library: rank 0 creates the unique id, torch.distributed only carries its 128 bytes; from
+            # here on the exchanges of the fused routines are ncclAllReduce calls on the library's own stream
+            uid = ctypes.create_string_buffer(128)
+            if self.comm.rank == 0:
+                L.check(lib.hyp_comm_unique_id(uid), "hyp_comm_unique_id")
+            box = [uid.raw]
+            dist.broadcast_object_list(box, src=0)
+            uid = ctypes.create_string_buffer(box[0], 128)
+            hc = ctypes.c_void_p()
+            L.check(lib.hyp_comm_init_rank(L.ctx(), self.comm.world, self.comm.rank, uid, ctypes.byref(hc)), "hyp_comm_init_rank")
+            self._hyp_comm = hc
+            L.check(lib.hyp_sys_set_comm_rccl(h, hc), "hyp_sys_set_comm_rccl")
+            self.rccl_in_library = True
+        else:
+            L.check(lib.hyp_sys_set_comm(h, ctypes.cast(self._cb, ctypes.c_void_p), None, ctypes.c_void_p(stage.data_ptr()), int(stage.numel())),
+                    "hyp_sys_set_comm")
         cc = np.ascontiguousarray(model.c, dtype=np.float64)
         hl = np.ascontiguousarray(model.h[self.rows], dtype=np.float64)
         bb = np.zeros(1)

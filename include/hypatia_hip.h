@@ -192,6 +192,20 @@ int hyp_sys_step_directions(hyp_sys* sys, const double* point_vec, const double*
  * all-reduce the first `count` doubles of that buffer IN PLACE over all ranks (RCCL) and return 0.  Every rank issues the
  * same sequence of calls.  allreduce = NULL restores single-GPU behaviour.  (qrchol.jl:219-246, search.jl:118-134) */
 int hyp_sys_set_comm(hyp_sys* sys, int (*allreduce)(void* user, long count, int op), void* user, void* device_staging, long capacity_doubles);
+/* The same exchanges through RCCL INSIDE the library (one process per GPU, xGMI): the library owns the communicator and
+ * issues ncclAllReduce(sum | max | min, double) in place on its own stream -- no staging copy, no host callback, no host
+ * synchronisation for device payloads.  Rank 0 creates the 128-byte id (ncclUniqueId) and distributes it out of band
+ * (torch.distributed / MPI / a file); every rank then joins with hyp_comm_init_rank on its context's device. */
+typedef struct hyp_comm hyp_comm;
+int hyp_comm_unique_id(char* out128);
+int hyp_comm_init_rank(hyp_ctx* ctx, int nranks, int rank, const char* id128, hyp_comm** out);
+int hyp_comm_destroy(hyp_comm* comm);
+/* in-place all-reduce of count doubles at a DEVICE pointer (op 0 sum, 1 max, 2 min); returns when it is complete */
+int hyp_comm_allreduce(hyp_comm* comm, void* device_buf, long count, int op);
+/* route the exchange points of hyp_sys_set_comm's description through the communicator (NULL: back to single GPU / callback) */
+int hyp_sys_set_comm_rccl(hyp_sys* sys, hyp_comm* comm);
+/* out2 = {exchanges issued by this solver since its creation, doubles moved by them} */
+int hyp_sys_comm_stats(hyp_sys* sys, double* out2);
 /* wall seconds the update_lhs part (solver.time_upsys) took inside the last hyp_sys_step_directions call */
 int hyp_sys_last_update_lhs_seconds(hyp_sys* sys, double* out);
 /* Measurement helper: HIP-event time (ms, averaged over reps back-to-back launches) of the four passes over the resident

@@ -55,11 +55,23 @@ class OracleLocalSys:
         return out_local
 
 
-def run(rank, world, port, inst_args, out_path, backend="oracle"):
+def _lib_exchanges(solver):
+    try:
+        import hypatia_jl_amd as H
+        cs = np.zeros(2)
+        H._lib.check(H._lib.lib().hyp_sys_comm_stats(solver.syssolver.local._h, H._lib.vec_ptr(cs)), "hyp_sys_comm_stats")
+        return cs
+    except Exception:
+        return np.zeros(2)
+
+
+def run(rank, world, port, inst_args, out_path, backend="oracle", transport="gloo"):
     if backend == "hip":
         import torch   # noqa: F401  (first: one HIP runtime per process)
+        if transport == "nccl":
+            torch.cuda.set_device(0)
     import torch.distributed as dist
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    dist.init_process_group(transport, init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     try:
         import hypatia_jl_amd as H
         from hypatia_jl_amd import distributed as D
@@ -88,6 +100,7 @@ def run(rank, world, port, inst_args, out_path, backend="oracle"):
         if rank == 0:
             np.savez(out_path, status=solver.status, iters=solver.num_iters, p_obj=solver.primal_obj, d_obj=solver.dual_obj,
                      x=solver.get_x(), s=solver.get_s(), z=solver.get_z(), ncoll=comm.n_collectives,
-                     hooked=bool(getattr(solver.syssolver, "_hooked", False)), worst_dir_res=solver.worst_dir_res)
+                     hooked=bool(getattr(solver.syssolver, "_hooked", False)), worst_dir_res=solver.worst_dir_res,
+                     rccl_in_library=bool(getattr(solver.syssolver, "rccl_in_library", False)), lib_exchanges=_lib_exchanges(solver))
     finally:
         dist.destroy_process_group()

@@ -29,7 +29,36 @@ def test_sharded_hip_solve_matches_oracle(native, monkeypatch):
     _run_sharded(native)
 
 
-def _run_sharded(native, inst_args=(120, [20, 12, 16, 9], 4)):
+@pytest.mark.timeout(600)
+def test_library_rccl_exchanges_one_rank(monkeypatch):
+    """RCCL inside the library (hyp_comm_init_rank + hyp_sys_set_comm_rccl): the test box has ONE GPU and RCCL wants one device
+    per rank, so the communicator has a single rank -- every exchange point of the fused sharded step still goes through
+    ncclAllReduce on the library stream (the multi-rank data flow is covered by the gloo tests with the callback)."""
+    monkeypatch.setenv("HYP_DIST_NATIVE", "1")
+    res = _run_sharded("1", world=1, transport="nccl")
+    assert bool(res["rccl_in_library"])
+    assert res["lib_exchanges"][0] > 50 and res["lib_exchanges"][1] >= 120 * 120
+
+
+def test_library_rccl_allreduce_on_a_device_buffer():
+    import ctypes
+    import torch
+    import hypatia_jl_amd as H
+    L = H._lib
+    lib = L.lib()
+    uid = ctypes.create_string_buffer(128)
+    L.check(lib.hyp_comm_unique_id(uid), "hyp_comm_unique_id")
+    assert any(b != 0 for b in uid.raw)
+    hc = ctypes.c_void_p()
+    L.check(lib.hyp_comm_init_rank(L.ctx(), 1, 0, uid, ctypes.byref(hc)), "hyp_comm_init_rank")
+    t = torch.arange(1000, dtype=torch.float64, device="cuda")
+    for op in (0, 1, 2):
+        L.check(lib.hyp_comm_allreduce(hc, ctypes.c_void_p(t.data_ptr()), 1000, op), "hyp_comm_allreduce")
+    assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float64))
+    L.check(lib.hyp_comm_destroy(hc), "hyp_comm_destroy")
+
+
+def _run_sharded(native, inst_args=(120, [20, 12, 16, 9], 4), world=2, transport="gloo"):
     import dist_worker
     from oracle import instances as I
     from oracle.build import make_model
@@ -37,7 +66,7 @@ def _run_sharded(native, inst_args=(120, [20, 12, 16, 9], 4)):
     port = _free_port()
     out = os.path.join(tempfile.mkdtemp(), "dist_hip.npz")
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=dist_worker.run, args=(r, 2, port, inst_args, out, "hip")) for r in range(2)]
+    procs = [ctx.Process(target=dist_worker.run, args=(r, world, port, inst_args, out, "hip", transport)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -52,3 +81,4 @@ def _run_sharded(native, inst_args=(120, [20, 12, 16, 9], 4)):
     assert abs(int(res["iters"]) - ref.num_iters) <= 1
     assert abs(float(res["p_obj"]) - ref.primal_obj) <= 1e-7 * (1 + abs(ref.primal_obj))
     assert np.allclose(res["x"], ref.get_x(), rtol=1e-5, atol=1e-7)
+    return res

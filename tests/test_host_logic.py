@@ -39,3 +39,16 @@ def test_step_reports_numerical_failure_when_the_factorization_chain_fails():
     assert solver.status == "NumericalFailure"
     assert sysv.calls == 1            # the failed assembly + factorizations are not run a second time
     assert st.prev_alpha == 0.0
+
+
+def test_bench_blocks_do_not_depend_on_the_number_of_ranks():
+    """bench.py --config 4: every cone's rows of G come from their own stream (seed, k), so that the N-rank run and the
+    single-GPU run of the strong-scaling workload are the SAME instance"""
+    import bench
+    a = bench.gen_block(40, 6, 3, 1)
+    b = bench.gen_block(40, 6, 3, 1)
+    c = bench.gen_block(40, 6, 4, 1)
+    assert a.shape == (21, 40) and a.flags.f_contiguous and np.array_equal(a, b) and not np.array_equal(a, c)
+    assert abs(np.std(a) * np.sqrt(40) - 1.0) < 0.15
+    e = bench.svec_identity(3)
+    assert np.array_equal(e, np.array([1.0, 0, 1, 0, 0, 1]))

@@ -1,8 +1,9 @@
-python -m pytest tests/test_hip_dense.py tests/test_hip_cones.py -q -x -m gpu 2>&1 | tail -3
-for v in 1 0; do
-HYP_POTRF_MFMA=$v python bench.py --steps 30 --warmup 3 --cpu-iters 0 2>/dev/null | python -c "
-import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('MFMA=$v', 'ms/step', round(d['ms_per_step'],3), d['phases_ms_per_step'])
-"
-done
+python -m pytest tests/test_hip_distributed.py tests/test_c_abi.py -q -x -m gpu 2>&1 | tail -5
+(time python bench.py --config 4 > gpurun_out/r02_bench_cfg4_1gpu.json 2> gpurun_out/r02_bench_cfg4_1gpu.err) 2>&1 | grep real
+tail -2 gpurun_out/r02_bench_cfg4_1gpu.err; cat gpurun_out/r02_bench_cfg4_1gpu.json
+export MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0
+(time HYP_FORCE_DIST=1 python bench.py --config 4 --steps 10 > gpurun_out/r02_bench_cfg4_rccl1.json 2> gpurun_out/r02_bench_cfg4_rccl1.err) 2>&1 | grep real
+tail -3 gpurun_out/r02_bench_cfg4_rccl1.err; cat gpurun_out/r02_bench_cfg4_rccl1.json
+unset MASTER_ADDR MASTER_PORT RANK WORLD_SIZE LOCAL_RANK
+(time python bench.py > gpurun_out/r02_bench1.json 2> gpurun_out/r02_bench1.err) 2>&1 | grep real
+tail -2 gpurun_out/r02_bench1.err; cat gpurun_out/r02_bench1.json
