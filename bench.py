@@ -14,11 +14,15 @@ bound of the same iteration on all host cores).
 
 Workloads (--config; default "2" at N = 1, "4" at N > 1):
   2   configs[1], the headline: ONE PosSemidefTri cone of side 200 (q = 20100), dense random G (q x n,
-      n = 5000), p = 0.  Single GPU only (one cone: its oracles do not shard).
+      n = 5000), p = 0.  With N > 1 ("strong"): one cone's oracles, factorization and solves do not shard, so
+      the model is replicated and the ranks split the K dimension of the Schur product (one all-reduce of
+      the n x n partial sums per iteration) -- Amdahl-bound, DESIGN section 6.
   4   configs[3]: 64 x PosSemidefTri(side 80), q = 207 360, n = 5000 -- the FIXED instance at every N
       ("strong" scaling): the cones, with their rows of G / h / z / s, are partitioned over the ranks
       (64 / N per rank), each rank assembles the Schur sum over ITS cones, one RCCL all-reduce (sum, f64,
-      n x n) per iteration inside the library, replicated factorization.  value = IPM iterations/s.
+      n x n) per iteration inside the library, replicated factorization.  value = IPM iterations/s.  The
+      same line carries "same_workload_1gpu" (the committed single-GPU figure of THIS instance: the driver's
+      own N = 1 run is the headline config 2) and "headline_config2_kshard" (config 2 on the same ranks).
   2w  the round-1 multi-GPU workload (one PosSemidefTri(200) block per rank, "weak" scaling), kept for
       comparison.
 """
@@ -257,42 +261,41 @@ def main_multi(args, world, rank, local_rank):
         if coll_hist is not None:   # HYP_PROFILE=1: where the collectives of the timed region come from
             for key, cnt in sorted(coll_hist.items(), key=lambda kv: -kv[1]):
                 print("collectives %-40s %8d doubles op %-5s : %.1f per step" % (key[0], key[1], key[2], cnt / max(args.steps, 1)), file=sys.stderr)
+    else:
+        out = None
+    if strong and not args.no_secondary:
+        # secondary record of the same job: the HEADLINE workload (config 2, the one the N = 1 bench line is quoted on) on the
+        # same ranks -- one cone, model replicated, K-panel shard of the Schur product
+        import copy
+        solver = model = cones = G_r = None
+        a2 = copy.copy(args)
+        a2.config, a2.steps, a2.warmup, a2.cpu_iters = "2", args.secondary_steps, 3, 0
+        sec = run_headline(a2, world, rank, local_rank, True, comm=comm)
+        if rank == 0:
+            out["headline_config2_kshard"] = {k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "scaling", "config", "roofline",
+                                                                 "phases_ms_per_step", "kkt_solves_per_step", "ms_per_kkt_solve")}
+    if rank == 0:
         print(json.dumps(out))
     dist.destroy_process_group()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed IPM iterations (default: 220 at config 2 = ~5 s of timed region; 30 at config 4)")
-    ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", default=None, help="2 (headline, N = 1 default) | 4 (64 x PSD(80), strong scaling, N > 1 default) | 2w (one PSD block per rank)")
-    ap.add_argument("--nvars", dest="n", type=int, default=5000)
-    ap.add_argument("--psd-side", dest="side", type=int, default=200)
-    ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--cpu-iters", type=int, default=2, help="oracle iterations timed for cpu_baseline (0 = skip)")
-    ap.add_argument("--cpu-threads", type=int, default=8, help="host BLAS threads for the cpu_baseline leg and the host-side setup")
-    ap.add_argument("--verbose", action="store_true")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    multi = world > 1 or bool(os.environ.get("HYP_FORCE_DIST"))   # HYP_FORCE_DIST=1: exercise the RCCL path with a single rank
-    if args.config is None:
-        args.config = "4" if multi else "2"
-    if args.config not in ("2", "4", "2w"):
-        raise SystemExit("--config must be 2, 4 or 2w")
-    if multi and args.config == "2":
-        raise SystemExit("config 2 is ONE cone: its oracles, factorization and solves do not shard (DESIGN.md section 6); use --config 4 (strong) or 2w (weak)")
-    if args.steps is None:
-        args.steps = 220 if args.config == "2" else 30
-    if args.warmup is None:
-        args.warmup = 5 if args.config == "2" else 2
-    if multi:
-        return main_multi(args, world, rank, local_rank)
-
+def run_headline(args, world, rank, local_rank, multi, comm=None):
+    """the headline workload (config 2; --config 4 on one GPU): measure and return the JSON record; with several ranks the model is
+    replicated and the Schur product K-sharded (KShardQRCholDenseSystemSolver)"""
+    own_group = False
+    if multi and comm is None:   # config 2 on N GPUs: ONE cone -- the model is replicated, the ranks split the K dimension of the Schur product
+        import torch                      # before the HIP library: one HIP runtime per process (torch's)
+        import torch.distributed as dist
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        dist.init_process_group(backend=os.environ.get("HYP_DIST_BACKEND", "nccl"))
+        own_group = True
     import hypatia_jl_amd as H
+    if multi:
+        from hypatia_jl_amd import distributed as D
+        if comm is None:
+            comm = D.Comm(device="cuda")
+        args.cpu_iters = 0
 
     t_setup = time.perf_counter()
     from threadpoolctl import threadpool_limits
@@ -311,7 +314,8 @@ def main():
         inst = gen_instance(args.n, [args.side], args.seed)
     q = inst[3].shape[0]
     with threadpool_limits(limits=args.cpu_threads, user_api="blas"):   # host preprocessing (rescale, QR for the initial x): untimed setup
-        solver = H.Solver(verbose=args.verbose, init_use_indirect=(args.config == "4"))
+        solver = H.Solver(verbose=args.verbose and rank == 0, init_use_indirect=(args.config == "4"),
+                          syssolver=(D.KShardQRCholDenseSystemSolver(comm) if comm is not None else None))
         solver.load(H.make_model(inst))
         solver.setup()
     t_setup = time.perf_counter() - t_setup
@@ -334,11 +338,21 @@ def main():
     for f in ("upsys", "upfact", "uprhs", "getdir", "search"):
         setattr(solver, "time_" + f, 0.0)
     lib.hyp_ctx_synchronize(ctx)      # (every C-ABI call is synchronous; this is the device-wide fence)
+    if comm is not None:
+        comm.barrier()
+        comm.torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     lib.hyp_ctx_synchronize(ctx)
+    if comm is not None:
+        comm.torch.cuda.synchronize()
+        comm.barrier()
     elapsed = time.perf_counter() - t0
+    if comm is not None:
+        el = np.array([elapsed])
+        comm.allreduce(el, "max")
+        elapsed = float(el[0])
     blas_cap.__exit__(None, None, None)   # (the CPU baseline below runs with the full host BLAS pool)
 
     ks = (ctypes.c_double * 8)()
@@ -346,6 +360,9 @@ def main():
     syrk_ms = ks[1] / max(ks[4], 1)
     nmp = solver.model.n - solver.model.p
     syrk_flops = float(nmp) * nmp * q                     # algorithmic: n^2 q
+    if comm is not None:
+        r0, r1 = D.kshard_range(q, rank, world)
+        syrk_flops = float(nmp) * nmp * (r1 - r0)         # this rank's K panel
     achieved = syrk_flops / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
     ms_per_step = elapsed / args.steps * 1e3
     n_solves = solver.n_solves - n_solves0
@@ -356,18 +373,20 @@ def main():
         "value": args.steps / elapsed,
         "unit": "iterations/s",
         "iterations_per_s": args.steps / elapsed,
-        "n_gpus": 1,
+        "n_gpus": world if comm is not None else 1,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "strong" if args.config == "4" else "weak",
+        "scaling": "strong" if (args.config == "4" or comm is not None) else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": ("configs[1]: single PosSemidefTri side=%d (q=%d), dense random G q x n, n=%d, p=0" % (args.side, q, args.n)) if args.config == "2"
                                else ("configs[3]: 64 x PosSemidefTri side=80 (q=%d), dense random G q x n, n=%d, p=0, all cones on one GPU" % (q, args.n)),
-                   "n": args.n, "q": q, "seed": args.seed},
+                   "n": args.n, "q": q, "seed": args.seed,
+                   **({"parallelism": "K-panel shard of the Schur product x%d, model replicated; one RCCL all-reduce (sum, f64, n x n) per iteration" % world}
+                      if comm is not None else {})},
         "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<true, 4, 1> (Schur syrk, upper)", "achieved": achieved,
                      "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                      "traffic": pmc_traffic(args.n, q), "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 PMC, profiles/r01_pmc_summary.json)",
@@ -434,7 +453,48 @@ def main():
     if hasattr(lib, "report"):
         print(lib.report(), file=sys.stderr)
         print("host wall in timed region: %.1f ms/step" % ms_per_step, file=sys.stderr)
-    print(json.dumps(out))
+    solver = None   # (release the device memory before a following workload)
+    if own_group:
+        if rank == 0:
+            print(json.dumps(out))
+        comm.dist.destroy_process_group()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed IPM iterations (default: 220 at config 2 = ~5 s of timed region; 30 at config 4)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default=None, help="2 (headline, N = 1 default) | 4 (64 x PSD(80), strong scaling, N > 1 default) | 2w (one PSD block per rank)")
+    ap.add_argument("--nvars", dest="n", type=int, default=5000)
+    ap.add_argument("--psd-side", dest="side", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cpu-iters", type=int, default=2, help="oracle iterations timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=8, help="host BLAS threads for the cpu_baseline leg and the host-side setup")
+    ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="N > 1, config 4: skip the secondary record (config 2, K-panel shard)")
+    ap.add_argument("--secondary-steps", type=int, default=100)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    multi = world > 1 or bool(os.environ.get("HYP_FORCE_DIST"))   # HYP_FORCE_DIST=1: exercise the RCCL path with a single rank
+    if args.config is None:
+        args.config = "4" if multi else "2"
+    if args.config not in ("2", "4", "2w"):
+        raise SystemExit("--config must be 2, 4 or 2w")
+    if args.steps is None:
+        args.steps = 220 if args.config == "2" else 30
+    if args.warmup is None:
+        args.warmup = 5 if args.config == "2" else 2
+    if multi and args.config != "2":
+        return main_multi(args, world, rank, local_rank)
+    out = run_headline(args, world, rank, local_rank, multi)
+    if not multi:
+        print(json.dumps(out))
+
 
 
 if __name__ == "__main__":

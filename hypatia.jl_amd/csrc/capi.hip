@@ -629,6 +629,13 @@ int hyp_sys_set_comm_rccl(hyp_sys* sys, hyp_comm* comm) {
   sys->s->rccl_comm = comm ? comm->nccl : nullptr;
   API_END(sys->ctx)
 }
+int hyp_sys_set_kshard(hyp_sys* sys, int rank, int world) {
+  API_BEGIN
+  HYP_REQUIRE(world >= 1 && rank >= 0 && rank < world, "set_kshard: rank / world");
+  sys->s->ks_rank = rank;
+  sys->s->ks_world = world;
+  API_END(sys->ctx)
+}
 int hyp_sys_comm_stats(hyp_sys* sys, double* out2) {
   API_BEGIN
   out2[0] = (double)sys->s->comm_calls;

@@ -282,6 +282,20 @@ void SysSolver::load(const double* hG, const double* hGQ1, const double* hGQ2, c
 // rccl_comm.hip
 void rccl_allreduce_inplace(void* comm, double* d_buf, long count, int op, hipStream_t st);
 
+void SysSolver::allreduce_lhs() {
+  const bool have = (comm_fn != nullptr || rccl_comm != nullptr);
+  if (!have || (ks_world <= 1 && !dist())) return;
+  const int kw = ks_world;
+  ks_world = 1;   // (allreduce_dev is the cone-sharded mode's entry point: borrow it)
+  try {
+    allreduce_dev(lhs.d(), (long)nmp * nmp, 0);
+  } catch (...) {
+    ks_world = kw;
+    throw;
+  }
+  ks_world = kw;
+}
+
 void SysSolver::allreduce_dev(double* d_buf, long count, int op) {
   if (!dist() || count <= 0) return;
   comm_calls += 1;
@@ -355,7 +369,13 @@ void SysSolver::assemble_lhs() {
     }
     HYP_CHECK(hipEventRecord(ctx.ev[1], ctx.stream));
     GemmArgs s{};   // lhs = HGQ2[1:idx, :]' HGQ2[1:idx, :]  (outer_prod!, dense.jl:80-86)
-    s.M = nmp; s.N = nmp; s.K = idx; s.A = HGQ2.d(); s.lda = q; s.B = HGQ2.d(); s.ldb = q; s.C = lhs.d(); s.ldc = nmp;
+    long r0 = 0, r1 = idx;
+    if (ks_world > 1) {   // this rank's K panel (16-row granularity keeps the aligned fast loader); the sum over ranks follows
+      const long per = (((long)idx + ks_world - 1) / ks_world + 15) / 16 * 16;
+      r0 = std::min<long>((long)idx, per * ks_rank);
+      r1 = std::min<long>((long)idx, r0 + per);
+    }
+    s.M = nmp; s.N = nmp; s.K = (int)(r1 - r0); s.A = HGQ2.d() + r0; s.lda = q; s.B = HGQ2.d() + r0; s.ldb = q; s.C = lhs.d(); s.ldc = nmp;
     s.alpha = 1; s.beta = 0; s.tri = GEMM_UPPER; s.krange = KR_ALL; s.batch = 1; s.tag = 1;
     gemm(ctx, true, s);
     HYP_CHECK(hipEventRecord(ctx.ev[2], ctx.stream));
@@ -374,7 +394,11 @@ void SysSolver::assemble_lhs() {
     g.alpha = 1; g.beta = 1; g.tri = GEMM_UPPER; g.krange = KR_ALL; g.batch = 1;
     gemm(ctx, true, g);
   }
-  if (dist()) allreduce_dev(lhs.d(), (long)nmp * nmp, 0);   // the one large exchange: sum of the ranks' Schur contributions
+  if (ks_world > 1) {
+    for (size_t k = 0; k < cones.size(); ++k)
+      HYP_REQUIRE(use_sqrt[k], "K-panel sharding covers the sqrt-Hessian branch of the Schur assembly (qrchol.jl:219-234) only");
+  }
+  allreduce_lhs();   // the one large exchange: sum of the ranks' Schur contributions (cones or K panels)
 }
 
 void SysSolver::factor_lhs(int* info, int* used_fallback) {   // qrchol.jl:249-250

@@ -72,7 +72,13 @@ struct SysSolver {
   void* rccl_comm = nullptr;     // ncclComm_t
   long comm_calls = 0;           // exchanges issued since creation (hyp_sys_comm_stats)
   double comm_doubles = 0;
-  bool dist() const { return comm_fn != nullptr || rccl_comm != nullptr; }
+  // K-panel sharding of ONE model over several GPUs (third bullet: configs 2 / 3, a single cone): model, cones,
+  // point and every solve are REPLICATED on all ranks; only the Schur product lhs = HGQ2' HGQ2 is cut along its K dimension
+  // (rank r sums rows [q r / N, q (r + 1) / N) of HGQ2) and the partial n x n matrices are all-reduced.  Everything a rank
+  // computes afterwards is bitwise the same on every rank (the all-reduce hands every rank the same sum).
+  int ks_rank = 0, ks_world = 1;
+  bool dist() const { return (comm_fn != nullptr || rccl_comm != nullptr) && ks_world <= 1; }
+  void allreduce_lhs();   // the n x n exchange of either sharding mode
   void allreduce_dev(double* d_buf, long count, int op);
   void allreduce_host(double* h_buf, int count, int op);
 

@@ -706,3 +706,66 @@ def find_initial_x_dist(solver, init_s):
     model = solver.model
     solver.x_keep_idxs = np.arange(model.n)
     return lsqr(_GOnly(model), model.h - init_s)
+
+
+# ---------------------------------------------------------------------------------------------------
+# K-panel sharding of ONE replicated model (third bullet: a single cone -- configs[1] / [2])
+# ---------------------------------------------------------------------------------------------------
+def kshard_range(nrows, rank, world):
+    """rows [r0, r1) of the sqrt-Hessian product that rank `rank` sums into the Schur matrix (the K dimension of outer_prod!,
+    qrchol.jl:234); 16-row granularity, the same rule as SysSolver::assemble_lhs"""
+    per = ((nrows + world - 1) // world + 15) // 16 * 16
+    r0 = min(nrows, per * rank)
+    return r0, min(nrows, r0 + per)
+
+
+class KShardQRCholDenseSystemSolver(QRCholDenseSystemSolver):
+    """QRCholDenseSystemSolver on a model that every rank holds in full (one cone: its oracles, the factorization and the
+    solves do not shard): the ranks split the K dimension of the Schur product and all-reduce the n x n partial sums
+    (hyp_sys_set_kshard).  Everything else is replicated and bitwise identical on all ranks, so the plain driver runs unchanged
+    on every rank with no further exchange."""
+
+    def __init__(self, comm):
+        super().__init__()
+        self.comm = comm
+
+    def load(self, solver):
+        import ctypes
+        import os
+        super().load(solver)
+        lib, h, comm = L.lib(), self._h, self.comm
+        dist, torch = comm.dist, comm.torch
+        self.rccl_in_library = False
+        if dist.get_backend() == "nccl" and os.environ.get("HYP_DIST_RCCL", "1") not in ("0",):
+            uid = ctypes.create_string_buffer(128)
+            if comm.rank == 0:
+                L.check(lib.hyp_comm_unique_id(uid), "hyp_comm_unique_id")
+            box = [uid.raw]
+            dist.broadcast_object_list(box, src=0)
+            uid = ctypes.create_string_buffer(box[0], 128)
+            hc = ctypes.c_void_p()
+            L.check(lib.hyp_comm_init_rank(L.ctx(), comm.world, comm.rank, uid, ctypes.byref(hc)), "hyp_comm_init_rank")
+            self._hyp_comm = hc
+            L.check(lib.hyp_sys_set_comm_rccl(h, hc), "hyp_sys_set_comm_rccl")
+            self.rccl_in_library = True
+        else:
+            nmp = self.n - self.p
+            self._stage = torch.empty(max(nmp * nmp, 1024), dtype=torch.float64, device="cuda")
+            stage = self._stage
+            ops = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MAX, 2: dist.ReduceOp.MIN}
+
+            def _allreduce(user, count, op):
+                try:
+                    dist.all_reduce(stage[:count], op=ops[op])
+                    torch.cuda.synchronize()
+                    comm._count("library", count, op)
+                    return 0
+                except Exception as e:   # never let an exception cross the C boundary
+                    print("all-reduce callback failed:", e)
+                    return 1
+
+            self._cb = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_int)(_allreduce)
+            L.check(lib.hyp_sys_set_comm(h, ctypes.cast(self._cb, ctypes.c_void_p), None, ctypes.c_void_p(stage.data_ptr()), int(stage.numel())),
+                    "hyp_sys_set_comm")
+        L.check(lib.hyp_sys_set_kshard(h, comm.rank, comm.world), "hyp_sys_set_kshard")
+        return self

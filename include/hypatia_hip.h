@@ -204,6 +204,11 @@ int hyp_comm_destroy(hyp_comm* comm);
 int hyp_comm_allreduce(hyp_comm* comm, void* device_buf, long count, int op);
 /* route the exchange points of hyp_sys_set_comm's description through the communicator (NULL: back to single GPU / callback) */
 int hyp_sys_set_comm_rccl(hyp_sys* sys, hyp_comm* comm);
+/* K-panel sharding of ONE replicated model (a single cone: configs[1] / [2]): with a communicator (or callback) installed
+ * and world > 1, hyp_sys_update_lhs / _assemble_lhs sum only rows [q rank / world, q (rank + 1) / world) of the sqrt-Hessian
+ * product into the Schur matrix (the K dimension of outer_prod!, qrchol.jl:234) and all-reduce the n x n result; model,
+ * cones, points and solves stay replicated, so no other exchange exists.  world = 1 switches it off. */
+int hyp_sys_set_kshard(hyp_sys* sys, int rank, int world);
 /* out2 = {exchanges issued by this solver since its creation, doubles moved by them} */
 int hyp_sys_comm_stats(hyp_sys* sys, double* out2);
 /* wall seconds the update_lhs part (solver.time_upsys) took inside the last hyp_sys_step_directions call */

@@ -104,3 +104,73 @@ def run(rank, world, port, inst_args, out_path, backend="oracle", transport="glo
                      rccl_in_library=bool(getattr(solver.syssolver, "rccl_in_library", False)), lib_exchanges=_lib_exchanges(solver))
     finally:
         dist.destroy_process_group()
+
+
+def run_kshard(rank, world, port, inst_args, out_path, backend="oracle"):
+    """K-panel sharding of ONE replicated model (hypatia.jl_amd.distributed.kshard_range / KShardQRCholDenseSystemSolver).
+    oracle: the partition rule on the CPU -- each rank sums its rows of the oracle's sqrt-Hessian product into the Schur
+    matrix, one all-reduce, compared by the parent with the oracle's full assembly.  hip: the whole solve on the GPU."""
+    if backend == "hip":
+        import torch   # noqa: F401
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        import hypatia_jl_amd as H
+        from hypatia_jl_amd import distributed as D
+        from oracle import instances as I
+        inst = I.psd_blocks(*inst_args)
+        if backend == "hip":
+            comm = D.Comm(device="cuda")
+            solver = H.Solver(verbose=False, syssolver=D.KShardQRCholDenseSystemSolver(comm))
+            solver.load(H.make_model(inst))
+            solver.solve()
+            cs = _lib_exchanges_plain(solver)
+            if rank == 0:
+                np.savez(out_path, status=solver.status, iters=solver.num_iters, p_obj=solver.primal_obj, x=solver.get_x(), exchanges=cs,
+                         ncoll=comm.n_collectives)
+            return
+        from oracle.build import make_cone
+        comm = D.Comm()
+        c, A, b, G, h, specs = inst[:6]
+        assert len(specs) == 1
+        cone = make_cone(specs[0]).setup_data()
+        pt = np.zeros(cone.dimension())
+        cone.set_initial_point(pt)
+        pt += 0.05 * np.random.default_rng(7).standard_normal(pt.shape) / np.sqrt(pt.shape[0])
+        cone.load_point(pt, 0.9)
+        assert cone.is_feas()
+        HG = np.zeros(G.shape, order="F")
+        cone.sqrt_hess_prod(HG, np.asfortranarray(G))
+        r0, r1 = D.kshard_range(G.shape[0], rank, world)
+        part = HG[r0:r1].T @ HG[r0:r1]
+        comm.allreduce(part)
+        if rank == 0:
+            np.savez(out_path, lhs=part, full=HG.T @ HG, ranges=np.array([D.kshard_range(G.shape[0], r, world) for r in range(world)]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _lib_exchanges_plain(solver):
+    import hypatia_jl_amd as H
+    cs = np.zeros(2)
+    H._lib.check(H._lib.lib().hyp_sys_comm_stats(solver.syssolver._h, H._lib.vec_ptr(cs)), "hyp_sys_comm_stats")
+    return cs
+
+
+def run_comm_selftest():
+    import ctypes
+    import torch
+    torch.cuda.set_device(0)
+    t = torch.arange(1000, dtype=torch.float64, device="cuda")
+    import hypatia_jl_amd as H
+    L = H._lib
+    lib = L.lib()
+    uid = ctypes.create_string_buffer(128)
+    L.check(lib.hyp_comm_unique_id(uid), "hyp_comm_unique_id")
+    assert any(b != 0 for b in uid.raw)
+    hc = ctypes.c_void_p()
+    L.check(lib.hyp_comm_init_rank(L.ctx(), 1, 0, uid, ctypes.byref(hc)), "hyp_comm_init_rank")
+    for op in (0, 1, 2):
+        L.check(lib.hyp_comm_allreduce(hc, ctypes.c_void_p(t.data_ptr()), 1000, op), "hyp_comm_allreduce")
+    assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float64))
+    L.check(lib.hyp_comm_destroy(hc), "hyp_comm_destroy")

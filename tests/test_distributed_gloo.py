@@ -49,3 +49,32 @@ def test_sharded_solve_matches_single_process(world):
     assert np.allclose(res["x"], ref.get_x(), rtol=1e-5, atol=1e-7)
     assert np.allclose(res["s"], ref.get_s(), rtol=1e-4, atol=1e-6)
     assert int(res["ncoll"]) > 0
+
+
+def test_kshard_ranges_tile_the_rows():
+    from hypatia_jl_amd.distributed import kshard_range
+    for nrows in (1, 15, 16, 17, 210, 20100, 250001):
+        for world in (1, 2, 3, 8):
+            rs = [kshard_range(nrows, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == nrows
+            assert all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+            assert all((r0 % 16 == 0 or r0 == nrows) and r0 <= r1 for r0, r1 in rs)
+
+
+@pytest.mark.timeout(300)
+def test_kshard_schur_sum_matches_full_assembly():
+    """world-2 gloo: the K-panel split of outer_prod! (qrchol.jl:234) for a single-cone model -- partial Gram matrices over
+    kshard_range rows, one all-reduce -- against the oracle's full sqrt-Hessian assembly"""
+    import dist_worker
+    port = _free_port()
+    out = os.path.join(tempfile.mkdtemp(), "kshard.npz")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=dist_worker.run_kshard, args=(r, 2, port, (30, [9], 5), out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(280)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    res = np.load(out)
+    assert np.allclose(res["lhs"], res["full"], rtol=1e-13, atol=1e-13)
+    assert res["ranges"].tolist() == [[0, 32], [32, 45]]

@@ -41,21 +41,14 @@ def test_library_rccl_exchanges_one_rank(monkeypatch):
 
 
 def test_library_rccl_allreduce_on_a_device_buffer():
-    import ctypes
-    import torch
-    import hypatia_jl_amd as H
-    L = H._lib
-    lib = L.lib()
-    uid = ctypes.create_string_buffer(128)
-    L.check(lib.hyp_comm_unique_id(uid), "hyp_comm_unique_id")
-    assert any(b != 0 for b in uid.raw)
-    hc = ctypes.c_void_p()
-    L.check(lib.hyp_comm_init_rank(L.ctx(), 1, 0, uid, ctypes.byref(hc)), "hyp_comm_init_rank")
-    t = torch.arange(1000, dtype=torch.float64, device="cuda")
-    for op in (0, 1, 2):
-        L.check(lib.hyp_comm_allreduce(hc, ctypes.c_void_p(t.data_ptr()), 1000, op), "hyp_comm_allreduce")
-    assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float64))
-    L.check(lib.hyp_comm_destroy(hc), "hyp_comm_destroy")
+    """hyp_comm_unique_id / _init_rank / _allreduce / _destroy on a device buffer (one rank; in a fresh process, torch first:
+    one HIP runtime per process)"""
+    import dist_worker
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=dist_worker.run_comm_selftest)
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
 
 
 def _run_sharded(native, inst_args=(120, [20, 12, 16, 9], 4), world=2, transport="gloo"):
@@ -82,3 +75,35 @@ def _run_sharded(native, inst_args=(120, [20, 12, 16, 9], 4), world=2, transport
     assert abs(float(res["p_obj"]) - ref.primal_obj) <= 1e-7 * (1 + abs(ref.primal_obj))
     assert np.allclose(res["x"], ref.get_x(), rtol=1e-5, atol=1e-7)
     return res
+
+
+@pytest.mark.timeout(600)
+def test_kshard_single_cone_solve_matches_oracle():
+    """ONE PosSemidefTri cone, model replicated on 2 ranks (sharing the GPU, gloo callback): the Schur product is split along K,
+    the partial matrices are all-reduced, everything else runs replicated -- same solve as the oracle, one exchange per
+    update_lhs and no other"""
+    import dist_worker
+    from oracle import instances as I
+    from oracle.build import make_model
+    from oracle.solvers import Solver as OSolver
+    inst_args = (150, [30], 2)
+    port = _free_port()
+    out = os.path.join(tempfile.mkdtemp(), "kshard_hip.npz")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=dist_worker.run_kshard, args=(r, 2, port, inst_args, out, "hip")) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(500)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    res = np.load(out)
+    ref = OSolver(verbose=False)
+    ref.load(make_model(I.psd_blocks(*inst_args)))
+    ref.solve()
+    assert str(res["status"]) == ref.status == "Optimal"
+    assert abs(int(res["iters"]) - ref.num_iters) <= 1
+    assert abs(float(res["p_obj"]) - ref.primal_obj) <= 1e-7 * (1 + abs(ref.primal_obj))
+    assert np.allclose(res["x"], ref.get_x(), rtol=1e-5, atol=1e-7)
+    # one n x n exchange per Schur assembly (one per iteration), nothing else
+    assert int(res["iters"]) <= res["exchanges"][0] <= int(res["iters"]) + 3
+    assert res["exchanges"][1] == res["exchanges"][0] * 150 * 150
