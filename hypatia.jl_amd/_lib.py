@@ -29,6 +29,7 @@ SIGNATURES = {
     "hyp_get_kernel_stats": [c_vp, c_vp],
     "hyp_cone_create_nonnegative": [c_vp, c_int, P(c_vp)],
     "hyp_cone_create_possemideftri": [c_vp, c_int, P(c_vp)],
+    "hyp_cone_create_possemideftri_complex": [c_vp, c_int, P(c_vp)],
     "hyp_cone_create_epinormspectral": [c_vp, c_int, c_int, c_int, P(c_vp)],
     "hyp_cone_create_wsosinterpnonnegative": [c_vp, c_int, c_int, P(c_int), P(c_vp), c_int, P(c_vp)],
     "hyp_cone_create_wsosinterppossemideftri": [c_vp, c_int, c_int, c_int, P(c_int), P(c_vp), c_int, P(c_vp)],

@@ -9,6 +9,8 @@ def make_cone(spec):
         return hc.Nonnegative(spec[1])
     if kind == "possemideftri":
         return hc.PosSemidefTri(spec[1])
+    if kind == "possemideftri_complex":
+        return hc.PosSemidefTriComplex(spec[1])
     if kind == "epinormspectral":
         return hc.EpiNormSpectral(spec[1], spec[2], use_dual=spec[3])
     if kind == "wsosinterpnonnegative":

@@ -198,6 +198,16 @@ class PosSemidefTri(Cone):
         self.side = int(round((np.sqrt(1 + 8 * dim) - 1) / 2))
 
 
+class PosSemidefTriComplex(Cone):
+    """Cones.PosSemidefTri{Float64, ComplexF64}(dim)  (possemideftri.jl:9-46 with R = Complex{T}; dim = side^2)."""
+
+    def __init__(self, dim):
+        h = c_vp()
+        L.check(L.lib().hyp_cone_create_possemideftri_complex(L.ctx(), int(dim), ctypes.byref(h)), "hyp_cone_create_possemideftri_complex")
+        super().__init__(h)
+        self.side = int(round(np.sqrt(dim)))
+
+
 class _GenericHessMixin:
     """cones that carry Hypatia's `use_hess_prod_slow` switch (Cones.jl:222-237)"""
 

@@ -106,6 +106,13 @@ int hyp_cone_create_possemideftri(hyp_ctx* ctx, int dim, hyp_cone** out) {
   ctx->c.sync();
   API_END(ctx)
 }
+int hyp_cone_create_possemideftri_complex(hyp_ctx* ctx, int dim, hyp_cone** out) {
+  API_BEGIN
+  HYP_CHECK(hipSetDevice(ctx->c.device));
+  *out = new hyp_cone{ctx, new CplxPsdCone(ctx->c, dim)};
+  ctx->c.sync();
+  API_END(ctx)
+}
 int hyp_cone_create_epinormspectral(hyp_ctx* ctx, int d1, int d2, int use_dual, hyp_cone** out) {
   API_BEGIN
   HYP_CHECK(hipSetDevice(ctx->c.device));

@@ -14,7 +14,7 @@ bool psd_two_sided_fused_ok(int side);
 void psd_two_sided_fused(Ctx& c, int side, int ncols, const double* R, int rstruct /* 0 full, 1 upper, 2 lower */, const double* arr,
                          long lda, double* prod, long ldp, double* zws /* ncols * side^2 */);
 
-enum ConeKind { CONE_NONNEG = 0, CONE_PSD = 1, CONE_EPINORMSPECTRAL = 2, CONE_WSOS = 3, CONE_LMI = 4, CONE_DNN = 5, CONE_HYPOROOTDET = 6, CONE_HYPOPERLOGDET = 7, CONE_WSOSPSD = 8 };
+enum ConeKind { CONE_NONNEG = 0, CONE_PSD = 1, CONE_EPINORMSPECTRAL = 2, CONE_WSOS = 3, CONE_LMI = 4, CONE_DNN = 5, CONE_HYPOROOTDET = 6, CONE_HYPOPERLOGDET = 7, CONE_WSOSPSD = 8, CONE_PSD_COMPLEX = 9 };
 
 struct Cone {
   Ctx& ctx;
@@ -144,6 +144,40 @@ struct PsdCone : Cone {   // src/Cones/possemideftri.jl (real symmetric)
   void sqrt_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;
   void inv_sqrt_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;
   const double* dder3(const double* d_dir) override;
+};
+
+// PosSemidefTri{T, Complex{T}} (src/Cones/possemideftri.jl:9-207 with R = Complex{T}; complex vectorisation of
+// src/Cones/arrayutilities.jl:188-210, 240-262): Hermitian positive definite matrices of side s, dim = s^2.
+// Device form: the INTERLEAVED real embedding phi(a + i b) = [[a, -b], [b, a]] (rows 2 i, 2 i + 1; columns 2 j, 2 j + 1) maps
+// Hermitian matrices of side s onto real symmetric matrices of side 2 s, multiplicatively (phi(X Y) = phi(X) phi(Y),
+// phi(X^H) = phi(X)') -- and, because the 2 x 2 diagonal blocks of phi(U) are diagonal, the complex Cholesky factor onto the
+// REAL Cholesky factor of phi(X).  Every oracle of the complex cone is therefore the real PosSemidefTri oracle of side 2 s on
+// embedded vectors (same square root included), and the complex svec <-> embedded real svec maps are signed copies without
+// rescaling (both carry sqrt(2) on off-diagonals).  Twice the arithmetic of native complex kernels, all of it on the tuned
+// real path (MFMA two-sided products, blocked Cholesky).
+struct CplxPsdCone : Cone {
+  int side;            // complex side s
+  long edim;           // s (2 s + 1): svec length of the embedded matrix
+  PsdCone inner;       // real PosSemidefTri of side 2 s
+  DBuf ea, eb;         // embedded column workspaces
+  CplxPsdCone(Ctx& c, int dim);
+  void reset_data() override {
+    Cone::reset_data();
+    inner.reset_data();
+  }
+  bool update_feas() override;
+  bool is_dual_feas() override;
+  void update_grad() override;
+  void set_initial_point(double* h_out) override;
+  void hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;
+  void inv_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;
+  bool use_sqrt_hess_oracles(int) override { return true; }   // possemideftri.jl:54
+  void sqrt_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;
+  void inv_sqrt_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;
+  const double* dder3(const double* d_dir) override;
+  void embed(const double* cvec, long ldc, double* evec, int ncols);     // E: complex svec columns -> embedded real svec columns
+  void extract(const double* evec, double* cvec, long ldc, int ncols);   // the projection back (mean of the two copies)
+  template <class F> void through(F f, double* prod, long ldp, const double* arr, long lda, int ncols);
 };
 
 // Cones whose Hessian is formed explicitly and factored (the generic fallbacks of Cones.jl:101-118,

@@ -40,6 +40,9 @@ int hyp_get_kernel_stats(hyp_ctx* ctx, double* out8);
 /* ---- cone lifecycle: constructors of src/Cones/nonnegative.jl:27-33, possemideftri.jl:36-46 --- */
 int hyp_cone_create_nonnegative(hyp_ctx* ctx, int dim, hyp_cone** out);
 int hyp_cone_create_possemideftri(hyp_ctx* ctx, int dim, hyp_cone** out);
+/* Cones.PosSemidefTri{Float64, ComplexF64}(dim) (possemideftri.jl:9-46 with R = Complex{T}): Hermitian matrices of side s in the
+ * complex svec format of arrayutilities.jl:188-210, dim = s^2; nu = s */
+int hyp_cone_create_possemideftri_complex(hyp_ctx* ctx, int dim, hyp_cone** out);
 /* Cones.EpiNormSpectral{Float64,Float64}(d1, d2; use_dual) (epinormspectral.jl:53-66): dim = 1 + d1*d2 */
 int hyp_cone_create_epinormspectral(hyp_ctx* ctx, int d1, int d2, int use_dual, hyp_cone** out);
 /* Cones.WSOSInterpNonnegative{Float64,Float64}(U, Ps; use_dual) (wsosinterpnonnegative.jl:49-63):

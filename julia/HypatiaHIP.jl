@@ -100,6 +100,7 @@ end
 
 @hipcone Nonnegative                # Cones.Nonnegative{Float64}                       nonnegative.jl:8-33
 @hipcone PosSemidefTri              # Cones.PosSemidefTri{Float64, Float64}            possemideftri.jl:9-46
+@hipcone PosSemidefTriComplex       # Cones.PosSemidefTri{Float64, ComplexF64}         possemideftri.jl:9-46 (dim = side^2)
 @hipcone EpiNormSpectral            # Cones.EpiNormSpectral{Float64, Float64}          epinormspectral.jl:13-66
 @hipcone WSOSInterpNonnegative      # Cones.WSOSInterpNonnegative{Float64, Float64}    wsosinterpnonnegative.jl:16-63
 @hipcone LinMatrixIneq              # Cones.LinMatrixIneq{Float64} (real dense members) linmatrixineq.jl:9-65
@@ -122,6 +123,13 @@ function PosSemidefTri(dim::Int)
     h = new_handle()
     check(ccall((:hyp_cone_create_possemideftri, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Ptr{Cvoid}}), CTX[], dim, h), "hyp_cone_create_possemideftri")
     return PosSemidefTri(h[])
+end
+
+function PosSemidefTriComplex(dim::Int)
+    h = new_handle()
+    check(ccall((:hyp_cone_create_possemideftri_complex, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Ptr{Cvoid}}), CTX[], dim, h),
+        "hyp_cone_create_possemideftri_complex")
+    return PosSemidefTriComplex(h[])
 end
 
 function EpiNormSpectral(d1::Int, d2::Int; use_dual::Bool = false)

@@ -543,3 +543,62 @@ def test_wsosinterppossemideftri_vs_oracle(nvars, halfdeg, R):
     occ.hess_prod_slow(Po, V)
     hc.hess_prod(Pf, V)
     assert rel(Ph, Po) < 1e-9 and rel(Ph, Pf) < 1e-8
+
+
+# ---------------------------------------------------------------------------------------------
+# PosSemidefTri{T, Complex{T}} (complex Hermitian variant) through the interleaved real embedding
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("side", [1, 2, 3, 5, 12])
+def test_possemideftri_complex_identities(side):   # test/cone.jl:336-340 (R = Complex)
+    import hypatia_jl_amd as H
+    run_test_oracles(H.PosSemidefTriComplex(side * side), tol=1e4 * np.finfo(float).eps)
+
+
+@pytest.mark.parametrize("side", [40, 100])
+def test_possemideftri_complex_identities_matrix_free(side):
+    import hypatia_jl_amd as H
+    run_test_oracles(H.PosSemidefTriComplex(side * side), explicit_hess=False, tol=1e-9, noise=0.5 / side)
+
+
+@pytest.mark.parametrize("side", [1, 2, 7, 33, 100])
+def test_complex_psd_oracle_vs_hip(side):
+    import hypatia_jl_amd as H
+    from oracle import cones_complex as occ
+    dim = side * side
+    hc, oc = H.PosSemidefTriComplex(dim), occ.PosSemidefTriComplex(dim)
+    assert hc.dimension() == oc.dimension() == dim and hc.get_nu() == oc.get_nu() == side
+    rng = np.random.default_rng(dim)
+    for c in (hc, oc):
+        c.setup_data()
+    pt, pt2 = np.zeros(dim), np.zeros(dim)
+    oc.set_initial_point(pt)
+    hc.set_initial_point(pt2)
+    assert np.array_equal(pt, pt2)
+    pt += 0.2 * (2 * rng.random(dim) - 1) / side
+    dual = pt + 0.1 * (2 * rng.random(dim) - 1) / side
+    for c in (hc, oc):
+        c.reset_data()
+        c.load_point(pt, 1.3)
+        c.load_dual_point(dual)
+        assert c.is_feas()
+        assert c.is_dual_feas()
+    assert rel(hc.get_grad(), oc.get_grad()) < TOL
+    V = np.asfortranarray(rng.standard_normal((dim, 3)))
+    for name in ("hess_prod", "inv_hess_prod", "sqrt_hess_prod", "inv_sqrt_hess_prod"):
+        Ph, Po = np.zeros((dim, 3), order="F"), np.zeros((dim, 3), order="F")
+        getattr(hc, name)(Ph, V)
+        getattr(oc, name)(Po, V)
+        assert rel(Ph, Po) < TOL * 10, name     # (the SAME square root as the reference's complex Cholesky, not just some S'S = H)
+    assert rel(hc.dder3(V[:, 0].copy()), oc.dder3(V[:, 0].copy())) < TOL * 10
+    assert hc.check_numerics() == oc.check_numerics()
+    assert abs(hc.get_proxsqr(0.9, True) - oc.get_proxsqr(0.9, True)) <= 1e-9 * max(1.0, abs(oc.get_proxsqr(0.9, True)))
+    # an indefinite Hermitian matrix: [[1, 2i], [-2i, 1]] in the top-left corner
+    if side >= 2:
+        bad = np.zeros(dim)
+        oc.set_initial_point(bad)
+        bad[2] = 2.0 * np.sqrt(2)    # -im part of sqrt(2) * mat[0, 1]
+        for c in (hc, oc):
+            c.reset_data()
+            c.load_point(bad)
+        assert not oc.is_feas()
+        assert not hc.is_feas()

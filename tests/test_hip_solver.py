@@ -34,6 +34,17 @@ def test_known_answer_hip(name, reduce):
     build_solve_check(solver, H.make_model(inst), inst)
 
 
+@pytest.mark.parametrize("name", ["possemideftri5", "possemideftri6", "possemideftri7"])
+@pytest.mark.parametrize("reduce", [True, False])
+def test_known_answer_hip_complex_psd(name, reduce):
+    """the reference's complex Hermitian PosSemidefTri instances (test/nativeinstances.jl:382-437) through the HIP path"""
+    import hypatia_jl_amd as H
+    from oracle import instances as I
+    inst = I.KNOWN_ANSWER_COMPLEX[name]()
+    solver = H.Solver(default_tol_relax=10, reduce=reduce)
+    build_solve_check(solver, H.make_model(inst), inst)
+
+
 def _trajectory(solver_cls, model, **opts):
     rows = []
     s = solver_cls(**opts)
