@@ -84,6 +84,10 @@ SIGNATURES = {
     "hyp_comm_allreduce": [c_vp, c_vp, ctypes.c_long, c_int],
     "hyp_sys_set_comm_rccl": [c_vp, c_vp],
     "hyp_sys_comm_stats": [c_vp, c_vp],
+    "hyp_qrcp_factor": [c_vp, c_int, c_int, c_vp, c_int, c_vp, P(c_vp)],
+    "hyp_qrcp_get": [c_vp, c_vp, c_vp, c_vp, c_vp],
+    "hyp_qrcp_apply_q": [c_vp, c_int, c_vp],
+    "hyp_qrcp_destroy": [c_vp],
     "hyp_sys_set_kshard": [c_vp, c_int, c_int],
     "hyp_sys_last_update_lhs_seconds": [c_vp, P(c_dbl)],
     "hyp_sys_bench_gemv": [c_vp, c_int, c_vp],

@@ -13,6 +13,14 @@ struct hyp_cone { hyp_ctx* ctx; Cone* cone; };
 struct hyp_sys { hyp_ctx* ctx; SysSolver* s; };
 struct hyp_symindef { hyp_ctx* ctx; SymIndefSys* s; };
 struct hyp_comm { hyp_ctx* ctx; void* nccl; int nranks, rank; };
+namespace hyp {   // qrcp.hip
+struct QrcpFact;
+QrcpFact* qrcp_create(Ctx& c, int m, int n, const double* hA, int lda, const double* hb);
+void qrcp_get(QrcpFact* f, int* jpvt, double* R, double* rdiag, double* qtb);
+void qrcp_apply_q(QrcpFact* f, bool trans, double* hx);
+void qrcp_destroy(QrcpFact* f);
+}
+struct hyp_qrcp { hyp_ctx* ctx; hyp::QrcpFact* f; };
 
 namespace hyp {   // rccl_comm.hip
 void rccl_allreduce_inplace(void* comm, double* d_buf, long count, int op, hipStream_t st);
@@ -793,6 +801,32 @@ int hyp_dense_sysv_rook(hyp_ctx* ctx, int n, double* A, int lda, double* x, int 
 // Least squares x = argmin || A x - b || for a tall dense A (m x n) known to be well conditioned: Cholesky of A'A on the
 // device, one step of corrected semi-normal equations (x += (R'R)^-1 A'(b - A x)) and an estimate of
 // sigma_min(A) / sigma_max(A) from power iterations with the factor, so that the caller can decide whether to trust it.
+int hyp_qrcp_factor(hyp_ctx* ctx, int m, int n, const double* A, int lda, const double* rhs, hyp_qrcp** out) {
+  API_BEGIN
+  HYP_CHECK(hipSetDevice(ctx->c.device));
+  *out = new hyp_qrcp{ctx, qrcp_create(ctx->c, m, n, A, lda, rhs)};
+  API_END(ctx)
+}
+int hyp_qrcp_get(hyp_qrcp* q, int* jpvt, double* R, double* rdiag, double* qtb) {
+  API_BEGIN
+  qrcp_get(q->f, jpvt, R, rdiag, qtb);
+  API_END(q->ctx)
+}
+int hyp_qrcp_apply_q(hyp_qrcp* q, int trans, double* vec) {
+  API_BEGIN
+  qrcp_apply_q(q->f, trans != 0, vec);
+  API_END(q->ctx)
+}
+int hyp_qrcp_destroy(hyp_qrcp* q) {
+  hyp_ctx* ctx = q ? q->ctx : nullptr;
+  API_BEGIN
+  if (q) {
+    ctx->c.sync();
+    qrcp_destroy(q->f);
+    delete q;
+  }
+  API_END(ctx)
+}
 int hyp_dense_lstsq_normal(hyp_ctx* ctx, int m, int n, const double* A, int lda, const double* b, double* x, double* rcond_est, int* info) {
   API_BEGIN
   Ctx& c = ctx->c;

@@ -926,11 +926,20 @@ def find_initial_x(solver, init_s):   # process.jl:64-178
         op.model.n = n
         return lsqr(op, rhs)
     AG = G.copy() if p == 0 else np.vstack([A, G])
+    # Large [A; G]: the reference's own algorithm on the device -- column-pivoted Householder QR with dgeqp3's semantics
+    # (hyp_qrcp_factor: pivots, R and the rank decision as LAPACK's, which is what Julia's qr!(AG, ColumnNorm()) calls); the
+    # right-hand side rides along as an extra column, so Q' rhs comes with the factorization.  HYP_INITX_DEVICE=0: host LAPACK;
+    # HYP_INITX_DEVICE=normal: the conditioning-gated normal-equations shortcut of round 1 (a different algorithm, opt-in).
+    mode = os.environ.get("HYP_INITX_DEVICE", "1")
+    if (p + q) * n * n >= 2e9 and mode not in ("0", "normal"):
+        init_x = _find_initial_x_device_qr(solver, model, AG, rhs)
+        if init_x is not None:
+            return init_x
     # Large, clearly full-rank [A; G]: the least-squares x from the device (Cholesky of AG'AG + one corrected
     # semi-normal-equations step) instead of the host's pivoted QR, which is 2 (p + q) n^2 flops (11 s of 12 at config 2).
     # Taken only when the estimated sigma_min / sigma_max is far above the rank-decision threshold of get_rank_est, where
     # the pivoted QR would report full rank too and return the same x up to rounding; otherwise the reference's path below.
-    if (p + q) * n * n >= 2e10 and solver.preprocess and os.environ.get("HYP_INITX_DEVICE", "1") not in ("0",):
+    if (p + q) * n * n >= 2e10 and solver.preprocess and mode == "normal":
         from . import _lib as L
         import ctypes
         AGf = np.asfortranarray(AG)
@@ -968,6 +977,77 @@ def find_initial_x(solver, init_s):   # process.jl:64-178
     temp = Qf.T @ np.concatenate([model.b, model.h - init_s])
     init_x = sla.solve_triangular(AG_R, temp[:model.n], lower=False)
     return init_x
+
+
+class DeviceQRCP:
+    """column-pivoted QR of a tall dense matrix on the device (hyp_qrcp_*): LAPACK dgeqp3's pivots / R / reflectors"""
+
+    def __init__(self, M, rhs=None):
+        from . import _lib as L
+        import ctypes
+        self.L, self.ct = L, ctypes
+        Mf = np.asfortranarray(M, dtype=np.float64)
+        self.m, self.n = Mf.shape
+        h = ctypes.c_void_p()
+        rp = L.vec_ptr(np.ascontiguousarray(rhs, dtype=np.float64)) if rhs is not None else None
+        L.check(L.lib().hyp_qrcp_factor(L.ctx(), self.m, self.n, Mf.ctypes.data_as(ctypes.c_void_p), self.m, rp, ctypes.byref(h)), "hyp_qrcp_factor")
+        self._h = h
+        self.has_rhs = rhs is not None
+
+    def get(self, want_R=True):
+        L, ct = self.L, self.ct
+        r = min(self.m, self.n)
+        piv = np.zeros(self.n, dtype=np.int32)
+        R = np.zeros((r, self.n), order="F") if want_R else None
+        rdiag = np.zeros(r)
+        qtb = np.zeros(self.m) if self.has_rhs else None
+        L.check(L.lib().hyp_qrcp_get(self._h, piv.ctypes.data_as(ct.c_void_p), R.ctypes.data_as(ct.c_void_p) if want_R else None,
+                                     L.vec_ptr(rdiag), L.vec_ptr(qtb) if qtb is not None else None), "hyp_qrcp_get")
+        return piv.astype(int), (np.triu(R) if want_R else None), rdiag, qtb
+
+    def apply_q(self, vec, trans):
+        v = np.ascontiguousarray(vec, dtype=np.float64).copy()
+        self.L.check(self.L.lib().hyp_qrcp_apply_q(self._h, int(bool(trans)), self.L.vec_ptr(v)), "hyp_qrcp_apply_q")
+        return v
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self.L._lib is not None:
+                self.L._lib.hyp_qrcp_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def _find_initial_x_device_qr(solver, model, AG, rhs):   # process.jl:64-178 with the factorization on the device
+    n, p = model.n, model.p
+    A, G = model.A, model.G
+    fact = DeviceQRCP(AG, rhs)
+    piv, R, rdiag, qtb = fact.get(want_R=True)
+    AG_rank = int(np.sum(np.abs(rdiag) > solver.init_tol_qr))          # get_rank_est (process.jl:373-382)
+    if (not solver.preprocess) or AG_rank == n:
+        r = min(AG_rank, n)
+        xs = np.zeros(n)
+        xs[:r] = sla.solve_triangular(R[:r, :r], qtb[:r], lower=False)
+        init_x = np.zeros(n)
+        init_x[piv] = xs
+        return init_x
+    x_keep_idxs = piv[:AG_rank]
+    AG_R = R[:AG_rank, :AG_rank]
+    c_sub = model.c[x_keep_idxs]
+    w = np.zeros(AG.shape[0])
+    w[:AG_rank] = sla.solve_triangular(AG_R, c_sub, trans="T", lower=False)
+    yz_sub = fact.apply_q(w, trans=False)                                 # Q[:, 1:rank] (R1' \ c_sub)
+    residual = _norm_inf(A.T @ yz_sub[:p] + G.T @ yz_sub[p:] - model.c)
+    if residual > solver.init_tol_qr:
+        solver.status = "DualInconsistent"
+        return np.zeros(0)
+    model.c = c_sub
+    model.A = A[:, x_keep_idxs]
+    model.G = np.ascontiguousarray(G[:, x_keep_idxs])
+    model.n = AG_rank
+    solver.x_keep_idxs = x_keep_idxs
+    return sla.solve_triangular(AG_R, qtb[:AG_rank], lower=False)
 
 
 def find_initial_y(solver, init_z, reduce):   # process.jl:182-365

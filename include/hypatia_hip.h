@@ -249,6 +249,17 @@ int hyp_dense_posv(hyp_ctx* ctx, int n, double* A, int lda, double* x, int* info
  * info = 0, or the 1-based position of the first exactly singular pivot (LAPACK dsytrf_rook). */
 int hyp_dense_sysv_rook(hyp_ctx* ctx, int n, double* A, int lda, double* x, int nrhs, int ldx, int* info, int* perm, int* blk,
                         double* d, double* e);
+/* Column-pivoted Householder QR on the device with LAPACK dgeqp3's semantics (= Julia's qr!(AG, ColumnNorm()) of
+ * find_initial_x, src/Solvers/process.jl:64-178; the rank decision of :373-382 reads the diagonal of R).  A is m x n column-major
+ * (host, copied); rhs (m entries, may be NULL) rides along as an extra column: after the factorization it holds Q' rhs.
+ * hyp_qrcp_get: jpvt (n, 0-based: column jpvt[i] of A is column i of A P), R (min(m, n) x n column-major with leading dimension
+ * min(m, n), upper triangle meaningful), rdiag (min(m, n)), qtb (m) -- any of them may be NULL.
+ * hyp_qrcp_apply_q: vec (m, host, in place) <- Q' vec (trans != 0) or Q vec. */
+typedef struct hyp_qrcp hyp_qrcp;
+int hyp_qrcp_factor(hyp_ctx* ctx, int m, int n, const double* A, int lda, const double* rhs, hyp_qrcp** out);
+int hyp_qrcp_get(hyp_qrcp* q, int* jpvt, double* R, double* rdiag, double* qtb);
+int hyp_qrcp_apply_q(hyp_qrcp* q, int trans, double* vec);
+int hyp_qrcp_destroy(hyp_qrcp* q);
 /* Set-up helper for find_initial_x (src/Solvers/process.jl:64-178): least squares x = argmin ||A x - b|| for a tall, dense,
  * well-conditioned A (m x n col-major, host pointers) by the Cholesky factorization of A'A on the device with one step of
  * corrected semi-normal equations; rcond_est ~ sigma_min(A) / sigma_max(A) from power iterations, info = dpotrf's.  The

@@ -513,4 +513,24 @@ function mul_G!(y::Vector{Float64}, sys::HIPQRCholDenseSystemSolver, trans::Bool
     return y
 end
 
+# =============================================================================================
+# preprocessing: column-pivoted QR of [A; G] on the device (find_initial_x, src/Solvers/process.jl:64-178)
+# =============================================================================================
+# dgeqp3's semantics (what qr!(AG, ColumnNorm()) calls): returns (p, R, qtb) with AG[:, p] = Q R and qtb = Q' rhs, so that the
+# body of find_initial_x reads  AG_rank = count(abs(R[i, i]) > tol);  init_x[p] = R \ qtb[1:n]  unchanged.
+function qr_pivoted_device(AG::Matrix{Float64}, rhs::Vector{Float64})
+    (m, n) = size(AG)
+    h = new_handle()
+    check(ccall((:hyp_qrcp_factor, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Ptr{Cvoid}}),
+        CTX[], m, n, AG, m, rhs, h), "hyp_qrcp_factor")
+    r = min(m, n)
+    jpvt = zeros(Cint, n)
+    R = zeros(r, n)
+    qtb = zeros(m)
+    check(ccall((:hyp_qrcp_get, lib), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        h[], jpvt, R, C_NULL, qtb), "hyp_qrcp_get")
+    check(ccall((:hyp_qrcp_destroy, lib), Cint, (Ptr{Cvoid},), h[]), "hyp_qrcp_destroy")
+    return (Int.(jpvt) .+ 1, UpperTriangular(R[:, 1:r]), qtb)
+end
+
 end # module
