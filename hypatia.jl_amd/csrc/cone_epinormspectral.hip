@@ -121,6 +121,133 @@ __global__ __launch_bounds__(256) void jacobi_round_kernel(int len, int m, int m
   }
 }
 
+// the same round with the rotations accumulated: columns p, q of J (m x m) get the rotation applied to columns p, q of V, so
+// that V_final = V_initial J with J orthogonal
+__global__ __launch_bounds__(256) void jacobi_round_vec_kernel(int len, int m, int mm, int t, double* __restrict__ V, long ldv, double* __restrict__ J,
+                                                               int* __restrict__ flag) {
+  __shared__ double red[3][256];
+  const int i = blockIdx.x;
+  int p, q;
+  if (i == 0) { p = mm - 1; q = t; }
+  else { p = (t + i) % (mm - 1); q = (t - i + (mm - 1)) % (mm - 1); }
+  if (p >= m || q >= m) return;
+  double* vp = V + (long)p * ldv;
+  double* vq = V + (long)q * ldv;
+  double a = 0.0, b = 0.0, g = 0.0;
+  for (int r = threadIdx.x; r < len; r += 256) {
+    const double x = vp[r], y = vq[r];
+    a += x * x; b += y * y; g += x * y;
+  }
+  red[0][threadIdx.x] = a; red[1][threadIdx.x] = b; red[2][threadIdx.x] = g;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + off];
+      red[1][threadIdx.x] += red[1][threadIdx.x + off];
+      red[2][threadIdx.x] += red[2][threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  a = red[0][0]; b = red[1][0]; g = red[2][0];
+  if (fabs(g) <= 1e-15 * sqrt(a * b) || g == 0.0) return;
+  if (threadIdx.x == 0) atomicAdd(flag, 1);
+  const double zeta = (b - a) / (2.0 * g);
+  const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+  const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+  for (int r = threadIdx.x; r < len; r += 256) {
+    const double x = vp[r], y = vq[r];
+    vp[r] = cs * x - sn * y;
+    vq[r] = sn * x + cs * y;
+  }
+  double* jp = J + (long)p * m;
+  double* jq = J + (long)q * m;
+  for (int r = threadIdx.x; r < m; r += 256) {
+    const double x = jp[r], y = jq[r];
+    jp[r] = cs * x - sn * y;
+    jq[r] = sn * x + cs * y;
+  }
+}
+
+// column i of B (len x m): sigma_i = its norm, V1[:, i] = B[:, i] / sigma_i; counts exact zeros into flag
+__global__ __launch_bounds__(256) void svd_finish_kernel(int len, const double* __restrict__ B, double* __restrict__ V1, double* __restrict__ sig,
+                                                         int* __restrict__ flag) {
+  __shared__ double red[256];
+  const int i = blockIdx.x;
+  const double* b = B + (long)i * len;
+  double s = 0.0;
+  for (int r = threadIdx.x; r < len; r += 256) s += b[r] * b[r];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  const double nr = sqrt(red[0]);
+  if (threadIdx.x == 0) {
+    sig[i] = nr;
+    if (!(nr > 0.0)) atomicAdd(flag, 1);
+  }
+  const double inv = (nr > 0.0) ? 1.0 / nr : 0.0;
+  for (int r = threadIdx.x; r < len; r += 256) V1[(long)i * len + r] = b[r] * inv;
+}
+
+// the d1 x d1 block of the closed-form inverse (one workgroup): R1 = U' R V1, r_u -> A1, a
+//   pairs i != j : A1_ij = z_i z_j / 2 * (u^2 R1_ij - s_i s_j R1_ji) / (u^4 - s_i^2 s_j^2)
+//   arrow        : c_i = 4 u s_i / z_i^2, d_i = 2 (u^2 + s_i^2) / z_i^2;
+//                  a = (r_u + sum c_i R1_ii / d_i) / (Huu - sum c_i^2 / d_i); A1_ii = (R1_ii + c_i a) / d_i
+__global__ __launch_bounds__(256) void ens_closed_block_kernel(int d1, double u, double Huu, const double* __restrict__ sig, const double* __restrict__ R1,
+                                                               const double* __restrict__ ru, double* __restrict__ A1, double* __restrict__ a_out) {
+  __shared__ double red[2][256];
+  __shared__ double a_sh;
+  const double u2 = u * u;
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = threadIdx.x; i < d1; i += 256) {
+    const double si = sig[i], zi = u2 - si * si;
+    const double ci = 4.0 * u * si / (zi * zi), di = 2.0 * (u2 + si * si) / (zi * zi);
+    s0 += ci * R1[(long)i * d1 + i] / di;
+    s1 += ci * ci / di;
+  }
+  red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) { red[0][threadIdx.x] += red[0][threadIdx.x + off]; red[1][threadIdx.x] += red[1][threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    a_sh = (ru[0] + red[0][0]) / (Huu - red[1][0]);
+    a_out[0] = a_sh;
+  }
+  __syncthreads();
+  const double a = a_sh;
+  for (long e = threadIdx.x; e < (long)d1 * d1; e += 256) {
+    const int i = (int)(e % d1), j = (int)(e / d1);
+    const double si = sig[i], sj = sig[j], zi = u2 - si * si, zj = u2 - sj * sj;
+    double v;
+    if (i == j) {
+      const double ci = 4.0 * u * si / (zi * zi), di = 2.0 * (u2 + si * si) / (zi * zi);
+      v = (R1[e] + ci * a) / di;
+    } else {
+      const double ss = si * sj;
+      v = 0.5 * zi * zj * (u2 * R1[(long)j * d1 + i] - ss * R1[(long)i * d1 + j]) / (u2 * u2 - ss * ss);
+    }
+    A1[e] = v;
+  }
+}
+// T (d1 x d2) <- z_i / 2 * (Rt - P)_ij : the part of the rotated right-hand side orthogonal to V1
+__global__ void ens_closed_perp_kernel(int d1, int d2, double u, const double* __restrict__ sig, const double* __restrict__ Rt, const double* __restrict__ P,
+                                       double* __restrict__ T) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)d1 * d2) return;
+  const int i = (int)(e % d1);
+  const double si = sig[i];
+  T[e] = 0.5 * (u * u - si * si) * (Rt[e] - P[e]);
+}
+__global__ void ens_identity_bases_kernel(int d1, int d2, double* __restrict__ U, double* __restrict__ V1) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < (long)d1 * d1) U[e] = ((e % d1) == (e / d1)) ? 1.0 : 0.0;
+  if (e < (long)d2 * d1) V1[e] = ((e % d2) == (e / d2)) ? 1.0 : 0.0;
+}
+
 static void mm(Ctx& c, bool transa, int M, int N, int K, const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                double alpha, double beta, int batch = 1, long sA = 0, long sB = 0, long sC = 0) {
   GemmArgs g{};
@@ -326,6 +453,83 @@ const double* EpiNormSpectralCone::dder3(const double* d_dir) {   // :241-294
   ctx.h2d(dder3v.p, &d0, sizeof(double));
   ctx.sync();
   return dder3v.d();
+}
+
+// ---------------------------------------------------------------------------------------------
+// closed-form inverse Hessian (see cones.hpp).  Derivation, in the coordinates At = U' A [V1 V2], W = U S V1', z_i = u^2 - s_i^2,
+// from hess_prod! (epinormspectral.jl:211-239: T = A W' + W A' - 2 u a I, out_W = 2 Z^-1 (T Z^-1 W + A), out_u = Huu a + <HuW, A>):
+//   V2 part       out_ij = 2 At_ij / z_i
+//   i != j < d1   [out_ij; out_ji] = 2 / (z_i z_j) [[u^2, s_i s_j], [s_i s_j, u^2]] [At_ij; At_ji]
+//   diagonal, u   out_ii = d_i At_ii - c_i a,  out_u = Huu a - sum_i c_i At_ii,  c_i = 4 u s_i / z_i^2, d_i = 2 (u^2 + s_i^2) / z_i^2
+// each of which inverts in closed form (the 2 x 2 determinant u^4 - s_i^2 s_j^2 and the arrow's Schur complement are positive in
+// the interior of the cone).  U, s, V1 come from a one-sided Jacobi SVD of W' with accumulated rotations.
+// ---------------------------------------------------------------------------------------------
+bool EpiNormSpectralCone::update_svd() {
+  if (svd_updated) return svd_ok;
+  const size_t b11 = (size_t)d1 * d1 * 8, b21 = (size_t)d2 * d1 * 8;
+  Usvd.ensure(b11); Jm.ensure(b11); V1.ensure(b21); V1T.ensure(b21); Bj.ensure(b21); sig.ensure((size_t)d1 * 8);
+  ctx.d2d(Bj.p, WT.p, b21);                                   // W' (d2 x d1): its columns are the rows of W
+  dev_fill_identity(ctx, d1, Jm.d(), d1);
+  const int m = d1, mm2 = (m % 2 == 0) ? m : m + 1;
+  if (m > 1) {
+    for (int sweep = 0; sweep < 60; ++sweep) {
+      ctx.zero(Zinfo.p, sizeof(int));
+      for (int t = 0; t < mm2 - 1; ++t)
+        hipLaunchKernelGGL(jacobi_round_vec_kernel, dim3(mm2 / 2), dim3(256), 0, ctx.stream, d2, m, mm2, t, Bj.d(), (long)d2, Jm.d(), Zinfo.i());
+      if (read_info(ctx, Zinfo.i()) == 0) break;
+    }
+  }
+  ctx.zero(Zinfo.p, sizeof(int));
+  hipLaunchKernelGGL(svd_finish_kernel, dim3(d1), dim3(256), 0, ctx.stream, d2, Bj.d(), V1.d(), sig.d(), Zinfo.i());
+  const int nzero = read_info(ctx, Zinfo.i());
+  ctx.d2d(Usvd.p, Jm.p, b11);
+  svd_ok = true;
+  if (nzero == d1) {   // W = 0 (the initial point): any orthonormal bases do
+    const long tot = std::max((long)d1 * d1, (long)d2 * d1);
+    hipLaunchKernelGGL(ens_identity_bases_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx.stream, d1, d2, Usvd.d(), V1.d());
+  } else if (nzero > 0) {
+    svd_ok = false;    // some, not all, singular values vanish exactly: the generic path handles the point
+  }
+  dev_transpose(ctx, d2, d1, V1.d(), d2, V1T.d(), d1, 1, 0, 0);
+  svd_updated = true;
+  return svd_ok;
+}
+
+bool EpiNormSpectralCone::inv_hess_ready() {
+  static const bool on = [] { const char* e = getenv("HYP_ENS_CLOSED_INV"); return !(e && e[0] == '0'); }();
+  closed_inv = on;
+  if (closed_inv && update_svd()) return true;
+  return GenericHessCone::inv_hess_ready();
+}
+
+void EpiNormSpectralCone::inv_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) {
+  static const bool on = [] { const char* e = getenv("HYP_ENS_CLOSED_INV"); return !(e && e[0] == '0'); }();
+  closed_inv = on;
+  if (!closed_inv || hess_fact_updated || !update_svd()) {   // (a factorization that exists already is used: same operator)
+    GenericHessCone::inv_hess_prod(prod, ldp, arr, lda, ncols);
+    return;
+  }
+  if (!hess_aux_updated) update_hess_aux();
+  const int dw = d1 * d2;
+  const size_t b11 = (size_t)d1 * d1 * 8, b12 = (size_t)dw * 8;
+  cw1.ensure(b12); cw2.ensure(b11); cw3.ensure(b12); cw4.ensure(b11); cw5.ensure(b12);
+  for (int j = 0; j < ncols; ++j) {
+    const double* a = arr + (long)j * lda;
+    double* p = prod + (long)j * ldp;
+    double* Rt = cw1.d();      // U' R              (d1 x d2)
+    double* R1 = cw2.d();      // Rt V1             (d1 x d1)
+    double* P = cw3.d();       // R1 V1'            (d1 x d2)
+    double* A1 = cw4.d();      // closed-form block (d1 x d1)
+    double* T = cw5.d();       // z / 2 * (Rt - P), then + A1 V1' = At
+    mm(ctx, true, d1, d2, d1, Usvd.d(), d1, a + 1, d1, Rt, d1, 1.0, 0.0);
+    mm(ctx, false, d1, d1, d2, Rt, d1, V1.d(), d2, R1, d1, 1.0, 0.0);
+    mm(ctx, false, d1, d2, d1, R1, d1, V1T.d(), d1, P, d1, 1.0, 0.0);
+    hipLaunchKernelGGL(ens_closed_block_kernel, dim3(1), dim3(256), 0, ctx.stream, d1, u, Huu, sig.d(), R1, a, A1, p);
+    hipLaunchKernelGGL(ens_closed_perp_kernel, dim3((unsigned)((dw + 255) / 256)), dim3(256), 0, ctx.stream, d1, d2, u, sig.d(), Rt, P, T);
+    mm(ctx, false, d1, d2, d1, A1, d1, V1T.d(), d1, T, d1, 1.0, 1.0);
+    mm(ctx, false, d1, d2, d1, Usvd.d(), d1, T, d1, p + 1, d1, 1.0, 0.0);
+  }
+  HYP_CHECK(hipGetLastError());
 }
 
 }  // namespace hyp

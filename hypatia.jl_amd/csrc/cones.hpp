@@ -326,6 +326,7 @@ struct EpiNormSpectralCone : GenericHessCone {   // src/Cones/epinormspectral.jl
   void reset_data() override {
     GenericHessCone::reset_data();
     hess_aux_updated = false;
+    svd_updated = false;
   }
   bool update_feas() override;
   bool is_dual_feas() override;
@@ -337,6 +338,16 @@ struct EpiNormSpectralCone : GenericHessCone {   // src/Cones/epinormspectral.jl
   const double* dder3(const double* d_dir) override;                                          // :241-294
   void zsolve(double* X, long ldx, int nrhs);    // X <- Z^-1 X
   double nuclear_norm(const double* d_mat /* d1 x d2 col-major */);
+  // Closed-form inverse Hessian (NOT in this Hypatia version, whose inv_hess_prod! is the generic explicit-Hessian
+  // Cholesky of Cones.jl:113-118): with W = U S V1' the Hessian of epinormspectral.jl:211-239 decouples in the rotated
+  // coordinates U' A [V1 V2] into 2 x 2 blocks over the index pairs (i, j), (j, i), a diagonal scaling on the V2 part and an
+  // arrow system coupling u with the diagonal -- see cone_epinormspectral.hip.  HYP_ENS_CLOSED_INV=0 restores the generic path.
+  bool closed_inv = true, svd_updated = false, svd_ok = false;
+  DBuf Usvd, V1, V1T, sig, Bj, Jm, cw1, cw2, cw3, cw4, cw5;
+  void reset_svd() { svd_updated = false; }
+  bool update_svd();
+  void inv_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;
+  bool inv_hess_ready() override;
 };
 
 }  // namespace hyp

@@ -166,7 +166,11 @@ def test_generic_oracle_vs_hip(kind, args):
         getattr(hc, name)(Ph, V)
         getattr(oc, name)(Po, V)
         assert rel(Ph, Po) < 1e-8, name
-    assert hc.use_sqrt_hess_oracles(dim - 1) == oc.use_sqrt_hess_oracles(dim - 1) == True   # factor exists after inv_hess_prod
+    if kind == "ens":   # closed-form inverse Hessian on the device: inv_hess_prod leaves no factorization behind, so a small array
+        assert oc.use_sqrt_hess_oracles(dim - 1) and not hc.use_sqrt_hess_oracles(dim - 1)   # does not take the sqrt path (deviation, DESIGN)
+        assert hc.use_sqrt_hess_oracles(dim) and oc.use_sqrt_hess_oracles(dim)               # a full-size one factors the explicit Hessian
+    else:
+        assert hc.use_sqrt_hess_oracles(dim - 1) == oc.use_sqrt_hess_oracles(dim - 1) == True   # factor exists after inv_hess_prod
     for name in ("sqrt_hess_prod", "inv_sqrt_hess_prod"):
         Ph = np.zeros((dim, 3), order="F")
         Po = np.zeros((dim, 3), order="F")
@@ -602,3 +606,70 @@ def test_complex_psd_oracle_vs_hip(side):
             c.load_point(bad)
         assert not oc.is_feas()
         assert not hc.is_feas()
+
+
+# ---------------------------------------------------------------------------------------------
+# EpiNormSpectral: closed-form inverse Hessian against the oracle's generic inverse (explicit Hessian + Cholesky,
+# Cones.jl:113-118, 239-251 -- what this Hypatia version does)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d1,d2", [(1, 1), (1, 5), (2, 2), (3, 4), (7, 7), (20, 33), (50, 100)])
+def test_epinormspectral_closed_form_inverse_hessian(d1, d2):
+    import hypatia_jl_amd as H
+    from oracle import cones as oc
+    hc, o = H.EpiNormSpectral(d1, d2), oc.EpiNormSpectral(d1, d2)
+    dim = 1 + d1 * d2
+    rng = np.random.default_rng(100 * d1 + d2)
+    for c in (hc, o):
+        c.setup_data()
+    Wm = rng.standard_normal((d1, d2))
+    Wm *= 0.8 / np.linalg.norm(Wm, 2)                      # sigma_1 = 0.8 u: well inside, but far from the central ray
+    pt = np.concatenate([[1.0], Wm.reshape(-1, order="F")])
+    for c in (hc, o):
+        c.reset_data()
+        c.load_point(pt, 1.1)
+        assert c.is_feas()
+        c.get_grad()
+    V = np.asfortranarray(rng.standard_normal((dim, 3)))
+    Ph, Po = np.zeros((dim, 3), order="F"), np.zeros((dim, 3), order="F")
+    hc.inv_hess_prod(Ph, V)                                 # closed form (no explicit Hessian is ever formed)
+    o.inv_hess_prod(Po, V)
+    assert rel(Ph, Po) <= 1e-9, rel(Ph, Po)
+    # H (H^-1 v) = v through the closed-form hess_prod!
+    back = np.zeros((dim, 3), order="F")
+    hc.hess_prod(back, Ph)
+    assert rel(back, V) <= 1e-10
+    g = np.array(hc.get_grad())
+    Hg = np.zeros(dim)
+    hc.inv_hess_prod(Hg, g)
+    assert abs(Hg @ g - hc.get_nu()) <= 1e-10 * hc.get_nu()
+    assert rel(Hg, -np.array(hc.point)) <= 1e-9           # H^-1 g = -point (logarithmic homogeneity)
+
+
+def test_epinormspectral_closed_form_inverse_at_the_initial_point_and_500x500():
+    import hypatia_jl_amd as H
+    c = H.EpiNormSpectral(3, 5)                              # W = 0: every singular value vanishes
+    pt = np.zeros(16)
+    c.set_initial_point(pt)
+    c.load_point(pt)
+    c.reset_data()
+    assert c.is_feas()
+    v = np.arange(1.0, 17.0)
+    hv, w = np.zeros(16), np.zeros(16)
+    c.hess_prod(hv, v)
+    c.inv_hess_prod(w, hv)
+    assert rel(w, v) <= 1e-12
+    # configs[2] size: dim 250 001, the inverse Hessian applied without any dim x dim object
+    d = 500
+    big = H.EpiNormSpectral(d, d)
+    rng = np.random.default_rng(1)
+    Wm = rng.standard_normal((d, d))
+    Wm *= 0.5 / np.linalg.norm(Wm, 2)
+    big.load_point(np.concatenate([[1.0], Wm.reshape(-1, order="F")]))
+    big.reset_data()
+    assert big.is_feas()
+    v = rng.standard_normal(1 + d * d)
+    hv, w = np.zeros_like(v), np.zeros_like(v)
+    big.hess_prod(hv, v)
+    big.inv_hess_prod(w, hv)
+    assert rel(w, v) <= 1e-9
+    assert big.check_numerics()

@@ -180,7 +180,8 @@ def test_device_get_directions_matches_host_composition_and_oracle(name, reduce)
         OS.get_directions(os_.stepper, os_)
         d_orc = os_.stepper.dir.vec
         scale = np.linalg.norm(d_orc)
-        assert np.linalg.norm(d_dev - d_host) <= 1e-11 * scale, name
+        floor = 1e-15 * np.linalg.norm(hs.point.vec)     # (a nearly converged instance has directions of ~1e-6: rounding of the point itself)
+        assert np.linalg.norm(d_dev - d_host) <= 1e-11 * scale + floor, name
         assert np.linalg.norm(d_dev - d_orc) <= 1e-7 * scale, name
 
 

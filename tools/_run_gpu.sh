@@ -1,1 +1,1 @@
-python -m pytest tests/test_hip_qrcp.py -q -x -m gpu -s 2>&1 | tail -30 > gpurun_out/r02_qrcp.log; cat gpurun_out/r02_qrcp.log
+python -m pytest tests -q -x -m gpu > gpurun_out/r02_pytest_full2.log 2>&1; tail -5 gpurun_out/r02_pytest_full2.log
