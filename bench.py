@@ -25,6 +25,8 @@ Workloads (--config; default "2" at N = 1, "4" at N > 1):
       own N = 1 run is the headline config 2) and "headline_config2_kshard" (config 2 on the same ranks).
   2w  the round-1 multi-GPU workload (one PosSemidefTri(200) block per rank, "weak" scaling), kept for
       comparison.
+  3b | 5p | 5d  the other configurations (matrix completion / polymin primal / polymin dual) on one GPU: same schema,
+      a step = one IPM iteration of the full solve.
 """
 import argparse
 import ctypes
@@ -461,12 +463,79 @@ def run_headline(args, world, rank, local_rank, multi, comm=None):
     return out
 
 
+def main_other(args):
+    """--config 3b | 5p | 5d: the other BASELINE.json configurations on one GPU, same JSON schema.  A step is one IPM iteration
+    of the full solve of the instance (the solve is repeated until `steps` iterations have been timed).
+      3b  matrix completion, EpiNormSpectral 50 x 100 (dim 5001): the largest size the reference's algorithm admits
+      5p  polymin, WSOSInterpNonnegative, 4 variables, half-degree 8 (U = 4845), primal form (the cone uses the dual barrier)
+      5d  the same in dual form (n - p = 4844 unknowns in the Schur system, the "MFMA Hessian-product" form)
+    roofline: the blocked Cholesky of the cone's dim x dim Hessian (Cones.jl:239-251), the dominant kernel chain of every
+    accepted line-search trial, timed in isolation with HIP events (hyp_bench_potrf); 3b with the closed-form inverse has no
+    such factorization in its loop and reports the Schur-matrix Cholesky instead."""
+    import hypatia_jl_amd as H
+    from oracle import instances as I       # instance generators only (data)
+    from threadpoolctl import threadpool_limits
+    t_setup = time.perf_counter()
+    if args.config == "3b":
+        inst = I.matrixcompletion(50, 100, seed=args.seed)
+        work = "configs[2] at the largest size the reference admits: matrix completion, EpiNormSpectral 50 x 100 (dim 5001)"
+    else:
+        from oracle import polyutils as pu
+        rng = np.random.default_rng(args.seed)
+        U, pts, Ps = pu.interpolate_box([-1.0] * 4, [1.0] * 4, 8, rng=rng, sample_factor=2)
+        a = rng.uniform(-0.5, 0.5, 4)
+        vals = np.sum((pts - a) ** 2, axis=1) + (pts[:, 0] * pts[:, 1] - pts[:, 2] * pts[:, 3]) ** 2 + 0.3 * pts[:, 0] * pts[:, 2]
+        if args.config == "5p":
+            inst = (np.array([-1.0]), np.zeros((0, 1)), np.zeros(0), np.ones((U, 1)), vals, [("wsosinterpnonnegative", U, Ps, False)], {})
+        else:
+            inst = (vals, np.ones((1, U)), np.array([1.0]), -np.eye(U), np.zeros(U), [("wsosinterpnonnegative", U, Ps, True)], {})
+        work = "configs[4]: polymin, WSOSInterpNonnegative, 4 variables, half-degree 8 (U = %d), %s form" % (U, "primal" if args.config == "5p" else "dual")
+    t_setup = time.perf_counter() - t_setup
+    steps = args.steps if args.steps is not None else 40
+    lib, ctx = H._lib.lib(), H._lib.ctx()
+    iters, loop_s, solves, trials, nsolve_runs = 0, 0.0, 0, 0, 0
+    phases = dict(upsys=0.0, getdir=0.0, search=0.0)
+    status = None
+    with threadpool_limits(limits=args.cpu_threads, user_api="blas"):
+        warm = H.Solver(verbose=False, iter_limit=2)          # untimed: first-touch allocations, kernel loading
+        warm.load(H.make_model(inst)); warm.solve()
+        while iters < steps:
+            s = H.Solver(verbose=args.verbose)
+            s.load(H.make_model(inst))
+            s.solve()
+            iters += s.num_iters; loop_s += s.iter_time; solves += s.n_solves; trials += s.stepper.searcher.n_trials
+            for k in phases:
+                phases[k] += getattr(s, "time_" + k)
+            status = s.status
+            nsolve_runs += 1
+    n_fact = (s.model.n - s.model.p) if args.config in ("5d", "3b") else s.model.cones[0].dimension()
+    ms = ctypes.c_double(0)
+    lib.hyp_bench_potrf.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    lib.hyp_bench_potrf(ctx, int(n_fact), 5, ctypes.byref(ms))
+    flops = float(n_fact) ** 3 / 3.0
+    achieved = flops / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+    out = {
+        "metric": "IPM iterations/sec (+ ms per KKT solve): " + work + " (Float64, QRCholDense + CombinedStepper)",
+        "value": iters / loop_s, "unit": "iterations/s", "iterations_per_s": iters / loop_s, "n_gpus": 1, "steps": iters, "warmup": 2,
+        "ms_per_step": loop_s / iters * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": work, "n": int(s.model.n), "p": int(s.model.p), "q": int(s.model.q), "seed": args.seed, "solves_timed": nsolve_runs,
+                   "final_status": status},
+        "roofline": {"bound": "mfma", "kernel": "blocked upper Cholesky, n = %d (potrf_diag_mfma + potrf_panel_mfma + gemm_f64 trailing updates)" % n_fact,
+                     "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "launch_ms": ms.value, "flops_per_launch": flops},
+        "phases_ms_per_step": {k: v / iters * 1e3 for k, v in phases.items()},
+        "kkt_solves_per_step": solves / iters, "ms_per_kkt_solve": phases["getdir"] / max(solves, 1) * 1e3,
+        "search_trials_per_step": trials / iters, "setup_s": t_setup,
+    }
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed IPM iterations (default: 220 at config 2 = ~5 s of timed region; 30 at config 4)")
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", default=None, help="2 (headline, N = 1 default) | 4 (64 x PSD(80), strong scaling, N > 1 default) | 2w (one PSD block per rank)")
+    ap.add_argument("--config", default=None, help="2 (headline, N = 1 default) | 4 (64 x PSD(80), strong scaling, N > 1 default) | 2w (one PSD block per rank) | 3b | 5p | 5d")
     ap.add_argument("--nvars", dest="n", type=int, default=5000)
     ap.add_argument("--psd-side", dest="side", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
@@ -483,8 +552,12 @@ def main():
     multi = world > 1 or bool(os.environ.get("HYP_FORCE_DIST"))   # HYP_FORCE_DIST=1: exercise the RCCL path with a single rank
     if args.config is None:
         args.config = "4" if multi else "2"
+    if args.config in ("3b", "5p", "5d"):
+        if multi:
+            raise SystemExit("--config %s is a single-GPU line" % args.config)
+        return main_other(args)
     if args.config not in ("2", "4", "2w"):
-        raise SystemExit("--config must be 2, 4 or 2w")
+        raise SystemExit("--config must be 2, 4, 2w, 3b, 5p or 5d")
     if args.steps is None:
         args.steps = 220 if args.config == "2" else 30
     if args.warmup is None:

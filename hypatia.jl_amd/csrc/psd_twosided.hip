@@ -218,6 +218,151 @@ __global__ __launch_bounds__(TS_THREADS, (TS_BT <= 4 ? 4 : (TS_BT <= 5 ? 3 : 2))
   }
 }
 
+// =============================================================================================
+// Small sides (<= 96, i.e. T <= 6 tiles: config 4's side 80): the whole two-sided product of a matrix stays on one CU.
+// One workgroup of T wavefronts per matrix; R (shared by every column of the cone) is staged in LDS once per workgroup, which
+// then walks a contiguous range of columns: V_j gathered from the svec column into LDS (both triangles), wavefront w computes
+// tile row w of Z = V R in registers and writes it over ITS rows of V (nobody else reads those rows in this pass), then tile
+// row w of the upper triangle of W = Z' R, stored as the packed svec column.  No Z round trip through HBM (the two-pass
+// kernel moves 3 s^2 doubles per matrix for s^2 of input + output), no per-K-tile barrier: three barriers per matrix; the
+// next column's svec entries are in flight (registers) during the two passes.
+// Measured at config 4 (64 cones of side 80, 5000 columns each): 21.5 -> 12.2 ms per iteration.  Two variants were tried and
+// lost: four wavefronts with the T^2 tiles dealt out evenly and Z in a second LDS buffer (18.8 ms: every MFMA then needs two
+// LDS operand reads of its own, the tile-row form shares the V / Z fragment over a whole row of tiles), and run-time tile
+// coordinates instead of per-wavefront tile rows (31 ms: one basic block per MFMA).
+// LDS strides: [k][c] operands (R, and Z in pass 2) want consecutive rows 32 dwords apart modulo 64 (S = 16 mod 32 doubles);
+// the row-indexed operand V of pass 1 wants 2 S2 = 4 mod 32 dwords (S2 = 16 T + 2).
+// =============================================================================================
+template <int T>
+__global__ __launch_bounds__(64 * T) void psd_ts_small_kernel(TsArgs p, int cols_per_wg) {
+  constexpr int N = 16 * T;
+  constexpr int S = (N % 32 == 16) ? N : N + 16;
+  constexpr int S2 = N + 2;
+  constexpr int THREADS = 64 * T;
+  extern __shared__ __attribute__((aligned(16))) double ts_lds[];
+  double* Rs = ts_lds;             // [k][c], N x S
+  double* VZ = ts_lds + N * S;     // [m][k] (V), then Z over the same rows, N x S2
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, nn = lane & 15;
+  const int s = p.s;
+  const long d = (long)s * (s + 1) / 2;
+  for (int e = tid; e < N * N; e += THREADS) {   // R -> LDS (zero padding beyond s; a triangular R has its zeros in memory)
+    const int k = e % N, c = e / N;
+    Rs[k * S + c] = (k < s && c < s) ? p.R[(long)c * s + k] : 0.0;
+  }
+  for (int e = tid; e < N * S2; e += THREADS) VZ[e] = 0.0;
+  const long j0 = (long)blockIdx.x * cols_per_wg;
+  const long j1 = min((long)p.ncols, j0 + cols_per_wg);
+  constexpr int PER = (N * (N + 1) / 2 + THREADS - 1) / THREADS;   // upper-triangle entries per thread
+  int ei[PER], ej[PER];                                            // (i, j) of this thread's entries: the same for every matrix
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const long e = tid + (long)THREADS * u;
+    int j = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+    while ((long)(j + 1) * (j + 2) / 2 <= e) ++j;
+    while ((long)j * (j + 1) / 2 > e) --j;
+    ei[u] = (int)(e - (long)j * (j + 1) / 2);
+    ej[u] = (e < d) ? j : -1;
+  }
+  double vreg[PER];
+  if (j0 < j1) {
+    const double* __restrict__ col = p.A + j0 * p.lda;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) vreg[u] = col[min((long)tid + (long)THREADS * u, d - 1)];
+  }
+  __syncthreads();
+  for (long j = j0; j < j1; ++j) {
+    // ---- V_j -> LDS, both triangles, off-diagonals / sqrt(2) (arrayutilities.jl:231)
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      if (ej[u] >= 0) {
+        const double v = (ei[u] == ej[u]) ? vreg[u] : div_rt2(vreg[u]);
+        VZ[ei[u] * S2 + ej[u]] = v;
+        VZ[ej[u] * S2 + ei[u]] = v;
+      }
+    }
+    __syncthreads();
+    if (j + 1 < j1) {   // next column's entries: in flight during the two passes
+      const double* __restrict__ col = p.A + (j + 1) * p.lda;
+#pragma unroll
+      for (int u = 0; u < PER; ++u) vreg[u] = col[min((long)tid + (long)THREADS * u, d - 1)];
+    }
+    // ---- pass 1: tile row w of Z = V R (k-chunks outside, column tiles inside: consecutive MFMAs go to different accumulators)
+    d4_t acc[T];
+#pragma unroll
+    for (int ct = 0; ct < T; ++ct) acc[ct] = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kt = 0; kt < T; ++kt) {
+      double af[4];
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) af[kc] = VZ[(16 * w + nn) * S2 + 16 * kt + 4 * kc + q];
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+#pragma unroll
+        for (int ct = 0; ct < T; ++ct) {
+          if ((p.rstruct == 1 && kt > ct) || (p.rstruct == 2 && kt < ct)) continue;   // R[kt, ct] is a zero tile
+          acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kc], Rs[(16 * kt + 4 * kc + q) * S + 16 * ct + nn], acc[ct], 0, 0, 0);
+        }
+      }
+    }
+    // Z tile row w over this wavefront's own rows of V (lane (q, nn), register r: row q + 4 r, column nn of the tile)
+#pragma unroll
+    for (int ct = 0; ct < T; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) VZ[(16 * w + q + 4 * r) * S2 + 16 * ct + nn] = acc[ct][r];
+    __syncthreads();
+    // ---- pass 2: tile row w of the upper triangle of W = Z' R, computed transposed (D[c][m]) so that 16 lanes hold 16
+    //      consecutive ROWS of a column of W = 128 contiguous bytes of the packed column
+    double* __restrict__ out = p.C + j * p.ldc;
+#pragma unroll
+    for (int ct = 0; ct < T; ++ct) acc[ct] = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kt = 0; kt < T; ++kt) {
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+        const double zf = VZ[(16 * kt + 4 * kc + q) * S2 + 16 * w + nn];
+#pragma unroll
+        for (int ct = 0; ct < T; ++ct) {
+          if (ct < w) continue;
+          if ((p.rstruct == 1 && kt > ct) || (p.rstruct == 2 && kt < ct)) continue;
+          acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(Rs[(16 * kt + 4 * kc + q) * S + 16 * ct + nn], zf, acc[ct], 0, 0, 0);
+        }
+      }
+    }
+    const int m = 16 * w + nn;
+#pragma unroll
+    for (int ct = 0; ct < T; ++ct) {
+      if (ct < w) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 16 * ct + q + 4 * r;
+        if (m <= c && c < s) out[(long)c * (c + 1) / 2 + m] = (m == c) ? acc[ct][r] : acc[ct][r] * 1.4142135623730951;   // arrayutilities.jl:176
+      }
+    }
+    __syncthreads();   // (the next matrix overwrites VZ)
+  }
+}
+
+template <int T>
+static void ts_small_launch(Ctx& c, TsArgs a) {
+  constexpr int N = 16 * T;
+  constexpr int S = (N % 32 == 16) ? N : N + 16;
+  constexpr int S2 = N + 2;
+  const size_t lds = (size_t)(N * S + N * S2) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HYP_CHECK(hipFuncSetAttribute((const void*)psd_ts_small_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  // enough workgroups to fill the chip a few times over (R is re-staged per workgroup: keep the ranges long)
+  const int per_cu = std::max(1, (int)(160 * 1024 / lds));
+  const int want = 256 * per_cu * 2;
+  const int cols_per_wg = std::max(4, (a.ncols + want - 1) / want);
+  const int grid = (a.ncols + cols_per_wg - 1) / cols_per_wg;
+  hipLaunchKernelGGL(psd_ts_small_kernel<T>, dim3(grid), dim3(64 * T), lds, c.stream, a, cols_per_wg);
+}
+
 bool psd_two_sided_fused_ok(int side) { return side >= 1 && side <= 2048; }
 
 // prod[:, j] = svec(R' smat(arr[:, j]) R), j < ncols.  zws: ncols * side^2 doubles.  arr may alias prod.
@@ -240,6 +385,20 @@ void psd_two_sided_fused(Ctx& c, int side, int ncols, const double* R, int rstru
   static const int bt2 = [] { const char* e = getenv("HYP_TS_BT2"); return e ? atoi(e) : 3; }();   // pass 2 (upper triangle only): 48 x 48, finer triangular skipping and 5 resident workgroups
   TsArgs a{};
   a.s = side; a.T = (side + 15) / 16; a.rstruct = rstruct; a.R = R; a.ncols = ncols;
+  static const bool small_on = [] { const char* e = getenv("HYP_TS_SMALL"); return !(e && e[0] == '0'); }();
+  if (small_on && a.T <= 6) {   // one kernel, everything of a matrix on one CU
+    a.A = arr; a.lda = lda; a.C = prod; a.ldc = ldp;
+    switch (a.T) {
+      case 1: ts_small_launch<1>(c, a); break;
+      case 2: ts_small_launch<2>(c, a); break;
+      case 3: ts_small_launch<3>(c, a); break;
+      case 4: ts_small_launch<4>(c, a); break;
+      case 5: ts_small_launch<5>(c, a); break;
+      default: ts_small_launch<6>(c, a); break;
+    }
+    HYP_CHECK(hipGetLastError());
+    return;
+  }
   a.A = arr; a.lda = lda; a.C = zws; a.ldc = 0;
   ts_launch<1>(c, a, bt1);
   a.A = zws; a.lda = 0; a.C = prod; a.ldc = ldp;
