@@ -168,6 +168,95 @@ __global__ __launch_bounds__(256) void jacobi_round_vec_kernel(int len, int m, i
   }
 }
 
+// The whole one-sided Jacobi iteration of a SMALL matrix in one launch: B (len x m) and, optionally, the accumulated
+// rotations J (m x m) live in LDS, one workgroup sweeps the round-robin tournament (m - 1 rounds of m / 2 disjoint pairs, a
+// barrier per round) until a full sweep rotates nothing.  Same pairing, rotation formula and stopping rule as the
+// multi-launch rounds above, which took ~400 launches of 3 us per SVD at 50 x 100 (the line search of matrix completion
+// spent its time there once the explicit Hessian was gone); beyond the LDS the multi-launch form remains.
+// 16 lanes per pair: 16 pairs at a time per 256-thread workgroup.
+__global__ __launch_bounds__(256) void jacobi_lds_kernel(int len, int m, double* __restrict__ Vg, double* __restrict__ Jg, int max_sweeps) {
+  extern __shared__ __attribute__((aligned(16))) double jl_lds[];
+  const int ldv = len | 1;                       // odd stride: the 16 lanes of a pair walk down two columns
+  double* V = jl_lds;                            // m columns of length len
+  double* J = jl_lds + (long)m * ldv;            // m columns of length m (only if Jg)
+  const int ldj = m | 1;
+  __shared__ int rotated;
+  const int tid = threadIdx.x;
+  for (long e = tid; e < (long)len * m; e += 256) V[(e / len) * ldv + (e % len)] = Vg[e];
+  if (Jg) for (long e = tid; e < (long)m * m; e += 256) J[(e / m) * ldj + (e % m)] = ((e / m) == (e % m)) ? 1.0 : 0.0;
+  __syncthreads();
+  const int mm = (m % 2 == 0) ? m : m + 1;
+  const int sub = tid & 15, grp = tid >> 4;      // 16 groups of 16 lanes
+  for (int sweep = 0; sweep < max_sweeps && m > 1; ++sweep) {
+    if (tid == 0) rotated = 0;
+    __syncthreads();
+    for (int t = 0; t < mm - 1; ++t) {
+      for (int i = grp; i < mm / 2; i += 16) {
+        int p, q;
+        if (i == 0) { p = mm - 1; q = t; }
+        else { p = (t + i) % (mm - 1); q = (t - i + (mm - 1)) % (mm - 1); }
+        if (p >= m || q >= m) continue;          // dummy player of an odd tournament (uniform over the 16 lanes)
+        double* vp = V + (long)p * ldv;
+        double* vq = V + (long)q * ldv;
+        double a = 0.0, b = 0.0, g = 0.0;
+        for (int r = sub; r < len; r += 16) {
+          const double x = vp[r], y = vq[r];
+          a += x * x; b += y * y; g += x * y;
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {   // the 16 lanes of a group are one DPP row: xor-shuffles stay inside it
+          a += __shfl_xor(a, off, 16);
+          b += __shfl_xor(b, off, 16);
+          g += __shfl_xor(g, off, 16);
+        }
+        if (fabs(g) <= 1e-15 * sqrt(a * b) || g == 0.0) continue;
+        if (sub == 0) rotated = 1;
+        const double zeta = (b - a) / (2.0 * g);
+        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+        for (int r = sub; r < len; r += 16) {
+          const double x = vp[r], y = vq[r];
+          vp[r] = cs * x - sn * y;
+          vq[r] = sn * x + cs * y;
+        }
+        if (Jg) {
+          double* jp = J + (long)p * ldj;
+          double* jq = J + (long)q * ldj;
+          for (int r = sub; r < m; r += 16) {
+            const double x = jp[r], y = jq[r];
+            jp[r] = cs * x - sn * y;
+            jq[r] = sn * x + cs * y;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (rotated == 0) break;
+    __syncthreads();
+  }
+  __syncthreads();
+  for (long e = tid; e < (long)len * m; e += 256) Vg[e] = V[(e / len) * ldv + (e % len)];
+  if (Jg) for (long e = tid; e < (long)m * m; e += 256) Jg[e] = J[(e / m) * ldj + (e % m)];
+}
+// bytes of LDS the one-launch form needs; 0 = does not fit
+static size_t jacobi_lds_bytes(int len, int m, bool with_j) {
+  const size_t b = ((size_t)m * (len | 1) + (with_j ? (size_t)m * (m | 1) : 0)) * sizeof(double);
+  return b <= 150 * 1024 ? b : 0;
+}
+static bool jacobi_in_lds(Ctx& ctx, int len, int m, double* V, double* J) {
+  static const bool on = [] { const char* e = getenv("HYP_JACOBI_LDS"); return !(e && e[0] == '0'); }();
+  const size_t lds = jacobi_lds_bytes(len, m, J != nullptr);
+  if (!on || lds == 0) return false;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HYP_CHECK(hipFuncSetAttribute((const void*)jacobi_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(jacobi_lds_kernel, dim3(1), dim3(256), lds, ctx.stream, len, m, V, J, 60);
+  HYP_CHECK(hipGetLastError());
+  return true;
+}
+
 // column i of B (len x m): sigma_i = its norm, V1[:, i] = B[:, i] / sigma_i; counts exact zeros into flag
 __global__ __launch_bounds__(256) void svd_finish_kernel(int len, const double* __restrict__ B, double* __restrict__ V1, double* __restrict__ sig,
                                                          int* __restrict__ flag) {
@@ -317,7 +406,7 @@ double EpiNormSpectralCone::nuclear_norm(const double* d_mat) {
   double* V = t12a.d();
   dev_transpose(ctx, d1, d2, d_mat, d1, V, d2, 1, 0, 0);
   const int m = d1, mm = (m % 2 == 0) ? m : m + 1;
-  if (m > 1) {
+  if (m > 1 && !jacobi_in_lds(ctx, d2, m, V, nullptr)) {
     for (int sweep = 0; sweep < 40; ++sweep) {
       ctx.zero(Zinfo.p, sizeof(int));
       for (int t = 0; t < mm - 1; ++t)
@@ -471,7 +560,7 @@ bool EpiNormSpectralCone::update_svd() {
   ctx.d2d(Bj.p, WT.p, b21);                                   // W' (d2 x d1): its columns are the rows of W
   dev_fill_identity(ctx, d1, Jm.d(), d1);
   const int m = d1, mm2 = (m % 2 == 0) ? m : m + 1;
-  if (m > 1) {
+  if (m > 1 && !jacobi_in_lds(ctx, d2, m, Bj.d(), Jm.d())) {
     for (int sweep = 0; sweep < 60; ++sweep) {
       ctx.zero(Zinfo.p, sizeof(int));
       for (int t = 0; t < mm2 - 1; ++t)
