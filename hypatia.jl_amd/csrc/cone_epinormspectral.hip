@@ -173,48 +173,87 @@ __global__ __launch_bounds__(256) void jacobi_round_vec_kernel(int len, int m, i
 // barrier per round) until a full sweep rotates nothing.  Same pairing, rotation formula and stopping rule as the
 // multi-launch rounds above, which took ~400 launches of 3 us per SVD at 50 x 100 (the line search of matrix completion
 // spent its time there once the explicit Hessian was gone); beyond the LDS the multi-launch form remains.
-// 16 lanes per pair: 16 pairs at a time per 256-thread workgroup.
-__global__ __launch_bounds__(256) void jacobi_lds_kernel(int len, int m, double* __restrict__ Vg, double* __restrict__ Jg, int max_sweeps) {
+// 32 lanes per pair, 1024 threads: 32 pairs at a time.  What a pair costs is latency (a dependent FP64 operation is 32 cycles,
+// tools/probe_potrf.hip): row sums by DPP, and the rotation from v_rcp / v_rsq seeds with Newton steps instead of the
+// division / square-root expansions (three divisions and two roots were ~2.5k cycles per pair).
+template <int CTRL>
+__device__ __forceinline__ double jl_dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double jl_sum32(double v) {   // total over the 32 lanes of a half wavefront, in every lane
+  v += jl_dpp<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+  v += jl_dpp<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+  v += jl_dpp<0x141>(v);   // row_half_mirror
+  v += jl_dpp<0x140>(v);   // row_mirror
+  return v + __shfl_xor(v, 16, 32);
+}
+__device__ __forceinline__ double jl_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  const double e = fma(-x, r, 1.0);
+  return fma(r, fma(e, e, e), r);
+}
+__device__ __forceinline__ double jl_rsqrt(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  double e = fma(-h * r, r, 0.5);
+  r = fma(r, e, r);
+  e = fma(-h * r, r, 0.5);
+  return fma(r, e, r);
+}
+__global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double* __restrict__ Vg, double* __restrict__ Jg, int max_sweeps) {
   extern __shared__ __attribute__((aligned(16))) double jl_lds[];
-  const int ldv = len | 1;                       // odd stride: the 16 lanes of a pair walk down two columns
+  const int ldv = len | 1;                       // odd stride
   double* V = jl_lds;                            // m columns of length len
   double* J = jl_lds + (long)m * ldv;            // m columns of length m (only if Jg)
   const int ldj = m | 1;
   __shared__ int rotated;
   const int tid = threadIdx.x;
-  for (long e = tid; e < (long)len * m; e += 256) V[(e / len) * ldv + (e % len)] = Vg[e];
-  if (Jg) for (long e = tid; e < (long)m * m; e += 256) J[(e / m) * ldj + (e % m)] = ((e / m) == (e % m)) ? 1.0 : 0.0;
+  for (long e = tid; e < (long)len * m; e += 1024) V[(e / len) * ldv + (e % len)] = Vg[e];
+  if (Jg) for (long e = tid; e < (long)m * m; e += 1024) J[(e / m) * ldj + (e % m)] = ((e / m) == (e % m)) ? 1.0 : 0.0;
   __syncthreads();
   const int mm = (m % 2 == 0) ? m : m + 1;
-  const int sub = tid & 15, grp = tid >> 4;      // 16 groups of 16 lanes
+  const int sub = tid & 31, grp = tid >> 5;      // 32 groups of 32 lanes
   for (int sweep = 0; sweep < max_sweeps && m > 1; ++sweep) {
     if (tid == 0) rotated = 0;
     __syncthreads();
     for (int t = 0; t < mm - 1; ++t) {
-      for (int i = grp; i < mm / 2; i += 16) {
+      for (int i = grp; i < mm / 2; i += 32) {
         int p, q;
         if (i == 0) { p = mm - 1; q = t; }
         else { p = (t + i) % (mm - 1); q = (t - i + (mm - 1)) % (mm - 1); }
-        if (p >= m || q >= m) continue;          // dummy player of an odd tournament (uniform over the 16 lanes)
+        if (p >= m || q >= m) continue;          // dummy player of an odd tournament (uniform over the group)
         double* vp = V + (long)p * ldv;
         double* vq = V + (long)q * ldv;
         double a = 0.0, b = 0.0, g = 0.0;
-        for (int r = sub; r < len; r += 16) {
+        for (int r = sub; r < len; r += 32) {
           const double x = vp[r], y = vq[r];
-          a += x * x; b += y * y; g += x * y;
+          a = fma(x, x, a); b = fma(y, y, b); g = fma(x, y, g);
         }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {   // the 16 lanes of a group are one DPP row: xor-shuffles stay inside it
-          a += __shfl_xor(a, off, 16);
-          b += __shfl_xor(b, off, 16);
-          g += __shfl_xor(g, off, 16);
-        }
+        a = jl_sum32(a); b = jl_sum32(b); g = jl_sum32(g);
         if (fabs(g) <= 1e-15 * sqrt(a * b) || g == 0.0) continue;
+        // (outside the range where the seeds + Newton steps are safe -- g or zeta near the ends of the exponent range, which
+        //  happens when columns of W are ~1e-150 at the end of a solve with a zero optimum -- the plain expansions are used)
+        double cs, sn;
+        const double ag = fabs(g), az = fabs(b - a);
+        if (ag > 1e-140 && ag < 1e140 && az < 1e140 * ag) {
+          const double zeta = (b - a) * 0.5 * jl_rcp(g);
+          const double w1 = fma(zeta, zeta, 1.0);
+          const double hyp1 = w1 * jl_rsqrt(w1);                    // sqrt(1 + zeta^2)
+          const double tt = copysign(jl_rcp(fabs(zeta) + hyp1), zeta);
+          cs = jl_rsqrt(fma(tt, tt, 1.0));
+          sn = cs * tt;
+        } else {
+          const double zeta = (b - a) / (2.0 * g);
+          const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          cs = 1.0 / sqrt(1.0 + tt * tt);
+          sn = cs * tt;
+        }
+        if (!(cs == cs) || !(sn == sn)) continue;
         if (sub == 0) rotated = 1;
-        const double zeta = (b - a) / (2.0 * g);
-        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
-        for (int r = sub; r < len; r += 16) {
+        for (int r = sub; r < len; r += 32) {
           const double x = vp[r], y = vq[r];
           vp[r] = cs * x - sn * y;
           vq[r] = sn * x + cs * y;
@@ -222,7 +261,7 @@ __global__ __launch_bounds__(256) void jacobi_lds_kernel(int len, int m, double*
         if (Jg) {
           double* jp = J + (long)p * ldj;
           double* jq = J + (long)q * ldj;
-          for (int r = sub; r < m; r += 16) {
+          for (int r = sub; r < m; r += 32) {
             const double x = jp[r], y = jq[r];
             jp[r] = cs * x - sn * y;
             jq[r] = sn * x + cs * y;
@@ -235,8 +274,8 @@ __global__ __launch_bounds__(256) void jacobi_lds_kernel(int len, int m, double*
     __syncthreads();
   }
   __syncthreads();
-  for (long e = tid; e < (long)len * m; e += 256) Vg[e] = V[(e / len) * ldv + (e % len)];
-  if (Jg) for (long e = tid; e < (long)m * m; e += 256) Jg[e] = J[(e / m) * ldj + (e % m)];
+  for (long e = tid; e < (long)len * m; e += 1024) Vg[e] = V[(e / len) * ldv + (e % len)];
+  if (Jg) for (long e = tid; e < (long)m * m; e += 1024) Jg[e] = J[(e / m) * ldj + (e % m)];
 }
 // bytes of LDS the one-launch form needs; 0 = does not fit
 static size_t jacobi_lds_bytes(int len, int m, bool with_j) {
@@ -252,7 +291,7 @@ static bool jacobi_in_lds(Ctx& ctx, int len, int m, double* V, double* J) {
     HYP_CHECK(hipFuncSetAttribute((const void*)jacobi_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(jacobi_lds_kernel, dim3(1), dim3(256), lds, ctx.stream, len, m, V, J, 60);
+  hipLaunchKernelGGL(jacobi_lds_kernel, dim3(1), dim3(1024), lds, ctx.stream, len, m, V, J, 60);
   HYP_CHECK(hipGetLastError());
   return true;
 }
