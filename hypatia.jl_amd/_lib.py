@@ -115,6 +115,7 @@ SIGNATURES = {
     "hyp_dense_gemv": [c_vp, c_int, c_int, c_int, c_dbl, c_vp, c_int, c_vp, c_dbl, c_vp],
     "hyp_bench_syrk": [c_vp, c_int, c_int, c_int, P(c_dbl)],
     "hyp_bench_potrf": [c_vp, c_int, c_int, P(c_dbl)],
+    "hyp_bench_trsv": [c_vp, c_int, c_int, P(c_dbl), P(c_dbl)],
 }
 
 

@@ -940,6 +940,63 @@ int hyp_bench_potrf(hyp_ctx* ctx, int n, int reps, double* ms_out) {
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   API_END(ctx)
 }
+int hyp_bench_trsv(hyp_ctx* ctx, int n, int reps, double* ms_out3, double* x_out) {
+  API_BEGIN
+  Ctx& c = ctx->c;
+  HYP_REQUIRE(n >= 1 && reps >= 1, "bench_trsv: sizes");
+  DBuf dA((size_t)n * n * 8), dinv(dinv_elems(n) * 8), dinfo(64), dx((size_t)2 * n * 8), dx0((size_t)2 * n * 8);
+  std::vector<double> h((size_t)n * n), hx((size_t)2 * n);
+  uint64_t s = 88172645463325252ULL;
+  for (long j = 0; j < n; ++j)
+    for (long i = 0; i <= j; ++i) {
+      s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+      const double v = (double)(s >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+      h[j * n + i] = h[i * n + j] = (i == j) ? (double)n : v;
+    }
+  for (auto& v : hx) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (double)(s >> 11) * (1.0 / 9007199254740992.0) - 0.5; }
+  c.h2d(dA.p, h.data(), h.size() * 8);
+  c.h2d(dx0.p, hx.data(), hx.size() * 8);
+  potrf_upper_batched(c, n, dA.d(), n, 0, 1, dinv.d(), dinfo.i());
+  c.d2h(c.h_info, dinfo.p, sizeof(int));
+  c.sync();
+  HYP_REQUIRE(c.h_info[0] == 0, "bench_trsv: factorization failed");
+  hipEvent_t e0, e1;
+  HYP_CHECK(hipEventCreate(&e0)); HYP_CHECK(hipEventCreate(&e1));
+  TriSolvePlan tri;
+  float tb = 0, t1 = 0, t2 = 0;
+  for (int r = 0; r <= reps; ++r) {   // (first pass untimed)
+    float ms = 0;
+    tri.invalidate();
+    HYP_CHECK(hipEventRecord(e0, c.stream));
+    tri.build(c, n, dA.d(), n, dinv.d());
+    HYP_CHECK(hipEventRecord(e1, c.stream));
+    HYP_CHECK(hipEventSynchronize(e1));
+    HYP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0) tb += ms;
+    c.d2d(dx.p, dx0.p, (size_t)2 * n * 8);
+    HYP_CHECK(hipEventRecord(e0, c.stream));
+    tri.solve(c, dA.d(), n, true, dx.d());
+    tri.solve(c, dA.d(), n, false, dx.d());
+    HYP_CHECK(hipEventRecord(e1, c.stream));
+    HYP_CHECK(hipEventSynchronize(e1));
+    HYP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0) t1 += ms;
+    if (x_out && r == reps) c.d2h(x_out, dx.p, (size_t)n * 8);
+    c.d2d(dx.p, dx0.p, (size_t)2 * n * 8);
+    HYP_CHECK(hipEventRecord(e0, c.stream));
+    tri.solve_multi(c, dA.d(), n, true, dx.d(), n, 2);
+    tri.solve_multi(c, dA.d(), n, false, dx.d(), n, 2);
+    HYP_CHECK(hipEventRecord(e1, c.stream));
+    HYP_CHECK(hipEventSynchronize(e1));
+    HYP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0) t2 += ms;
+    if (x_out && r == reps) c.d2h(x_out + n, dx.p, (size_t)2 * n * 8);
+  }
+  c.sync();
+  ms_out3[0] = tb / reps; ms_out3[1] = t1 / reps; ms_out3[2] = t2 / reps;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  API_END(ctx)
+}
 int hyp_bench_syrk(hyp_ctx* ctx, int N, int K, int reps, double* ms_out) {
   API_BEGIN
   Ctx& c = ctx->c;

@@ -518,10 +518,62 @@ __global__ __launch_bounds__(256) void coldot_kernel(int m, int ncols, int mode,
   if (lane == 0) out[j] = (base ? base[j] : 0.0) + alpha * s;
 }
 
+// The same sums in the same order for m <= 1024, with ALL of a lane's loads issued before the first product: in the loop
+// above every group of four loads is waited for before the next group is issued, four dependent memory round trips per
+// launch -- and a triangular solve is a chain of ~30 such launches (4.4-6 us each, profiles/r02_iteration_timeline.txt).
+// Loads are unconditional on clamped addresses (a predicated load is waited for individually), validity decides only
+// whether the product is added.
+__global__ __launch_bounds__(256) void coldot_batched_kernel(int m, int ncols, int mode, const double* __restrict__ M, long ld,
+                                                             const double* __restrict__ v, const double* base, double alpha, double* out) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= ncols) return;
+  const int lane = threadIdx.x & 63;
+  int i0 = 0, i1 = m;
+  if (mode == 1) i1 = min(j + 1, m);
+  else if (mode == 2) i0 = min(j, m);
+  const double* a = M + (long)j * ld;
+  const int ilast = max(i1 - 1, 0);
+  double av[16], vv[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int i = min(i0 + lane + 64 * k, ilast);
+    av[k] = a[i];
+    vv[k] = v[i];
+  }
+  const double b = base ? base[j] : 0.0;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int i = i0 + lane + 256 * g;
+    if (i + 192 < i1) {
+      s0 += av[4 * g] * vv[4 * g];
+      s1 += av[4 * g + 1] * vv[4 * g + 1];
+      s2 += av[4 * g + 2] * vv[4 * g + 2];
+      s3 += av[4 * g + 3] * vv[4 * g + 3];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        if (i + 64 * t < i1) s0 += av[4 * g + t] * vv[4 * g + t];
+    }
+  }
+  double s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if (lane == 0) out[j] = b + alpha * s;
+}
+
+bool coldot_batched_on() {
+  static const bool on = [] { const char* e = getenv("HYP_COLDOT_BATCH"); return !(e && atoi(e) == 0); }();
+  return on;
+}
+
 static void coldot(Ctx& c, int m, int ncols, int mode, const double* M, long ld, const double* v, const double* base, double alpha,
                    double* out) {
   if (ncols <= 0) return;
-  hipLaunchKernelGGL(coldot_kernel, dim3((ncols + 3) / 4), dim3(256), 0, c.stream, m, ncols, mode, M, ld, v, base, alpha, out);
+  if (m <= 1024 && coldot_batched_on())
+    hipLaunchKernelGGL(coldot_batched_kernel, dim3((ncols + 3) / 4), dim3(256), 0, c.stream, m, ncols, mode, M, ld, v, base, alpha, out);
+  else
+    hipLaunchKernelGGL(coldot_kernel, dim3((ncols + 3) / 4), dim3(256), 0, c.stream, m, ncols, mode, M, ld, v, base, alpha, out);
 }
 
 void TriSolvePlan::build(Ctx& c, int n_, const double* U, long ldu, const double* dinv) {

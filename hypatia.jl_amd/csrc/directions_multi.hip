@@ -289,10 +289,60 @@ __global__ __launch_bounds__(256) void coldot2_kernel(int m, int ncols, int mode
     out[ldo + j] = (base ? base[ldb + j] : 0.0) + alpha * t;
   }
 }
+// the same sums in the same order for m <= 1024 with all loads of a lane in flight at once (see coldot_batched_kernel, dense.hip)
+__global__ __launch_bounds__(256) void coldot2_batched_kernel(int m, int ncols, int mode, const double* __restrict__ M, long ld,
+                                                              const double* __restrict__ v, long ldv, const double* base, long ldb, double alpha,
+                                                              double* out, long ldo) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= ncols) return;
+  const int lane = threadIdx.x & 63;
+  int i0 = 0, i1 = m;
+  if (mode == 1) i1 = min(j + 1, m);
+  else if (mode == 2) i0 = min(j, m);
+  const double* a = M + (long)j * ld;
+  const int ilast = max(i1 - 1, 0);
+  double av[16], v0[16], v1[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int i = min(i0 + lane + 64 * k, ilast);
+    av[k] = a[i];
+    v0[k] = v[i];
+    v1[k] = v[ldv + i];
+  }
+  const double b0 = base ? base[j] : 0.0, b1 = base ? base[ldb + j] : 0.0;
+  double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const int i = i0 + lane + 128 * g;
+    if (i + 64 < i1) {
+      s0 += av[2 * g] * v0[2 * g];
+      s1 += av[2 * g + 1] * v0[2 * g + 1];
+      t0 += av[2 * g] * v1[2 * g];
+      t1 += av[2 * g + 1] * v1[2 * g + 1];
+    } else if (i < i1) {
+      s0 += av[2 * g] * v0[2 * g];
+      t0 += av[2 * g] * v1[2 * g];
+    }
+  }
+  double s = s0 + s1, t = t0 + t1;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_down(s, off);
+    t += __shfl_down(t, off);
+  }
+  if (lane == 0) {
+    out[j] = b0 + alpha * s;
+    out[ldo + j] = b1 + alpha * t;
+  }
+}
+bool coldot_batched_on();   // dense.hip (HYP_COLDOT_BATCH)
 static void coldot2(Ctx& c, int m, int ncols, int mode, const double* M, long ld, const double* v, long ldv, const double* base, long ldb,
                     double alpha, double* out, long ldo) {
   if (ncols <= 0) return;
-  hipLaunchKernelGGL(coldot2_kernel, dim3((ncols + 3) / 4), dim3(256), 0, c.stream, m, ncols, mode, M, ld, v, ldv, base, ldb, alpha, out, ldo);
+  if (m <= 1024 && coldot_batched_on())
+    hipLaunchKernelGGL(coldot2_batched_kernel, dim3((ncols + 3) / 4), dim3(256), 0, c.stream, m, ncols, mode, M, ld, v, ldv, base, ldb, alpha, out, ldo);
+  else
+    hipLaunchKernelGGL(coldot2_kernel, dim3((ncols + 3) / 4), dim3(256), 0, c.stream, m, ncols, mode, M, ld, v, ldv, base, ldb, alpha, out, ldo);
 }
 
 void TriSolvePlan::solve_multi(Ctx& c, const double* U, long ldu, bool trans, double* x, long ldx, int nr) {

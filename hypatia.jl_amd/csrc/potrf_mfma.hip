@@ -367,6 +367,247 @@ __global__ __launch_bounds__(256) void potrf_diag_mfma_kernel(double* __restrict
 }
 
 // =============================================================================================
+// Third form of the diagonal-block kernel (default): up to NT <= 16 tile columns in one workgroup, with look-ahead INSIDE the
+// kernel.  Four wavefronts; tile column c belongs to wavefront c mod 4 (c mod 8 < 4) or 3 - c mod 4 (else), so each wavefront
+// owns columns W, 7 - W, 8 + W, 15 - W: a balanced share of the triangle.  Block step JB of a wavefront:
+//   A. (owner of column JB only) apply the previous step's rank-16 update to tile (JB, JB) -- both operands are its own
+//      registers --, factor it, publish it and raise the step's flag (an LDS word; no barrier);
+//   B. apply the previous step's update to the rest of the owned tiles, first operands from the row panel published in LDS;
+//   C. wait for the flag; solve the owned tiles of row JB by substitution against the published diagonal tile, publish them;
+//   -- ONE barrier --
+// so the 16 x 16 factorization (4.7 K cycles, tools/probe_potrf.hip) runs underneath the other wavefronts' updates instead of
+// in front of a barrier of its own.  The published row panel is double-buffered (a fast wavefront may publish step JB while a
+// slow one still reads step JB - 1); the diagonal tile is not (it is rewritten only after the barrier that ends its use).
+// Measured (tools/bench_potrf.py): n = 5000 3.62 -> 3.55 ms -- the per-step gain is smaller than the 4.7 K cycles moved off
+// the barrier path because the owner's own solve and the substitution of the others now bound the step.  The template also
+// takes NW = 8 wavefronts with NT = 16 tile columns (a whole matrix of side <= 256 in one launch); that form needs 17 tiles
+// plus the substitution temporaries in the 256 registers left at two wavefronts per SIMD, spills, and was no faster than the
+// blocked path (148 vs 150 us at side 200): not instantiated.
+// =============================================================================================
+// (NW = 8 wavefronts: column c belongs to wavefront c (c < 8) or 15 - c, two columns each -- the form for NT = 16, where four
+// wavefronts would hold up to 34 tiles each and spill)
+__device__ __forceinline__ constexpr int tile_owner(int NW, int c) { return NW == 4 ? ((c & 4) ? 3 - (c & 3) : (c & 3)) : ((c & 8) ? 7 - (c & 7) : (c & 7)); }
+__device__ __forceinline__ constexpr int own_col(int NW, int W, int k) {   // ascending in k; 99 = none
+  return NW == 4 ? (k == 0 ? W : k == 1 ? 7 - W : k == 2 ? 8 + W : 15 - W) : (k == 0 ? W : k == 1 ? 15 - W : 99);
+}
+__device__ __forceinline__ constexpr int own_idx(int NW, int c) { return NW == 4 ? (((c >> 3) << 1) | ((c >> 2) & 1)) : ((c >> 3) & 1); }
+__device__ __forceinline__ constexpr int own_cnt(int NW, int W, int NT) {
+  int n = 0;
+  for (int k = 0; k < 4; ++k) n += own_col(NW, W, k) < NT ? 1 : 0;
+  return n;
+}
+// first index k of W's columns with own_col(NW, W, k) > c (own_cnt if none)
+__device__ __forceinline__ constexpr int own_first_above(int NW, int W, int NT, int c) {
+  int k = 0;
+  while (k < own_cnt(NW, W, NT) && own_col(NW, W, k) <= c) ++k;
+  return k;
+}
+
+template <int NW, int W, int NT, int JB>
+__device__ __forceinline__ void potrf_tiles_step(d4_t (&acc)[4][NT], double* const (&colp)[4], const int (&lcol)[4], int nb, int lane, double* Dt,
+                                                 double* rinv, double* Pt, int* sfail, int* dflag) {
+  constexpr int NC = own_cnt(NW, W, NT);
+  constexpr bool OWNER = tile_owner(NW, JB) == W;
+  constexpr int KO = own_idx(NW, JB);
+  constexpr int P = JB - 1;
+  const int q = lane >> 4, nn = lane & 15;
+  double xd[16];
+  // ---- A. owner: the next diagonal tile
+  if constexpr (OWNER) {
+    if constexpr (JB > 0) {
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) acc[KO][JB] = mfma4(acc[KO][P][kc], -acc[KO][P][kc], acc[KO][JB]);
+    }
+    double ri[16];
+    tile_gather(acc[KO][JB], nn, xd);
+    const int f = tile_potrf(xd, nn, ri);
+    if (q == 0) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) Dt[j * TS + nn] = xd[j];
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) rinv[j] = ri[j];
+      if (f && *sfail == 0) *sfail = 16 * JB + f;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) *reinterpret_cast<volatile int*>(dflag) = JB + 1;
+  }
+  // ---- B. the previous step's rank-16 update of the other owned tiles (a, C), P < a <= C
+  if constexpr (JB > 0) {
+    constexpr int K0 = own_first_above(NW, W, NT, P);
+    if constexpr (K0 < NC) {
+      constexpr int AMAX = own_col(NW, W, NC - 1);
+      const double* Pp = Pt + (P & 1) * NT * TL;
+      bool m[4] = {false, false, false, false};
+      bool any = false;
+#pragma unroll
+      for (int k = K0; k < NC; ++k) {
+        m[k] = (16 * own_col(NW, W, k) < nb) && !(OWNER && k == KO);
+        any |= m[k];
+      }
+      if (any) {
+        double op[2][NT];
+#pragma unroll
+        for (int a = JB; a < AMAX; ++a) op[0][a] = Pp[a * TL + q * TS + nn];
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+          if (kc < 3) {
+#pragma unroll
+            for (int a = JB; a < AMAX; ++a) op[(kc + 1) & 1][a] = Pp[a * TL + (4 * (kc + 1) + q) * TS + nn];
+          }
+#pragma unroll
+          for (int k = K0; k < NC; ++k) {
+            constexpr int dummy = 0; (void)dummy;
+            const int C = own_col(NW, W, k);
+            if (m[k]) {
+              acc[k][C] = mfma4(acc[k][P][kc], -acc[k][P][kc], acc[k][C]);   // (own registers: goes first)
+#pragma unroll
+              for (int a = JB; a < NT; ++a)
+                if (a < C) acc[k][a] = mfma4(op[kc & 1][a], -acc[k][P][kc], acc[k][a]);
+            }
+          }
+        }
+      }
+    }
+  }
+  if constexpr (OWNER) {   // upper triangle of the diagonal tile -> memory
+    if (q == 0 && lcol[KO] < nb) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (j <= nn) colp[KO][16 * JB + j] = xd[j];
+    }
+  }
+  // ---- C. row panel of step JB: the owned tiles (JB, C), C > JB
+  constexpr int K1 = own_first_above(NW, W, NT, JB);
+  constexpr int NS = NC - K1;
+  if constexpr (NS > 0) {
+    int cnt = 0;
+#pragma unroll
+    for (int k = K1; k < NC; ++k) cnt += (16 * own_col(NW, W, k) < nb) ? 1 : 0;
+    if (cnt > 0) {
+      double x[NS][16];
+#pragma unroll
+      for (int i = 0; i < NS; ++i)
+        if (i < cnt) tile_gather(acc[K1 + i][JB], nn, x[i]);
+      if constexpr (!OWNER) {
+        while (*reinterpret_cast<volatile int*>(dflag) <= JB) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+      }
+      if constexpr (NS >= 2) {
+        if (cnt >= 2) tile_subst2(x[0], x[1], Dt, rinv);
+        else tile_subst(x[0], Dt, rinv);
+      } else {
+        tile_subst(x[0], Dt, rinv);
+      }
+      if constexpr (NS >= 4) {
+        if (cnt == 4) tile_subst2(x[2], x[3], Dt, rinv);
+      }
+      if constexpr (NS >= 3) {
+        if (cnt == 3) tile_subst(x[2], Dt, rinv);
+      }
+      double* Pc = Pt + (JB & 1) * NT * TL;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        if (i < cnt) {
+          const int C = own_col(NW, W, K1 + i);
+          tile_scatter(x[i], q, acc[K1 + i][JB]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Pc[C * TL + (4 * r + q) * TS + nn] = acc[K1 + i][JB][r];
+          if (lcol[K1 + i] < nb) {   // the solved rows are final: 32 contiguous bytes per lane
+            double v[4];
+            tile_rows4(x[i], q, v);
+            double* dst = colp[K1 + i] + 16 * JB + 4 * q;
+            *reinterpret_cast<d2_t*>(dst) = (d2_t){v[0], v[1]};
+            *reinterpret_cast<d2_t*>(dst + 2) = (d2_t){v[2], v[3]};
+          }
+        }
+      }
+    }
+  }
+  lds_barrier();
+}
+
+template <int NW, int W, int NT, int... JBs>
+__device__ __forceinline__ void potrf_tiles_steps(d4_t (&acc)[4][NT], double* const (&colp)[4], const int (&lcol)[4], int nb, int nbt, int lane,
+                                                  double* Dt, double* rinv, double* Pt, int* sfail, int* dflag, std::integer_sequence<int, JBs...>) {
+  ((JBs < nbt ? potrf_tiles_step<NW, W, NT, JBs>(acc, colp, lcol, nb, lane, Dt, rinv, Pt, sfail, dflag) : (void)0), ...);
+}
+
+template <int NW, int W, int NT>
+__device__ __forceinline__ void potrf_tiles_wave(double* __restrict__ Ab, long lda, int nb, int nbt, int lane, double* Dt, double* rinv, double* Pt,
+                                                 int* sfail, int* dflag) {
+  constexpr int NC = own_cnt(NW, W, NT);
+  const int q = lane >> 4, nn = lane & 15;
+  d4_t acc[4][NT];
+  double* colp[4];
+  int lcol[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    lcol[k] = 16 * own_col(NW, W, k) + nn;
+    colp[k] = Ab + (long)min(lcol[k], nb - 1) * lda;
+  }
+  // loads: unconditional on clamped addresses (a predicated load is waited for individually), identity padding applied after
+#pragma unroll
+  for (int k = 0; k < NC; ++k)
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+      if (a <= own_col(NW, W, k)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[k][a][r] = colp[k][min(16 * a + q + 4 * r, nb - 1)];
+      }
+#pragma unroll
+  for (int k = 0; k < NC; ++k)
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+      if (a <= own_col(NW, W, k)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * a + q + 4 * r;
+          acc[k][a][r] = (i < nb && lcol[k] < nb && i <= lcol[k]) ? acc[k][a][r] : (i == lcol[k] ? 1.0 : 0.0);
+        }
+      }
+  potrf_tiles_steps<NW, W, NT>(acc, colp, lcol, nb, nbt, lane, Dt, rinv, Pt, sfail, dflag, std::make_integer_sequence<int, NT>{});
+}
+
+template <int NW, int NT>
+__global__ __launch_bounds__(64 * NW) void potrf_tiles_kernel(double* __restrict__ A, long lda, long strideA, int n, int k0, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double pm_lds[];
+  double* Dt = pm_lds;              // factor of the current diagonal tile
+  double* rinv = pm_lds + TL;       // 1 / its diagonal
+  double* Pt = pm_lds + TL + 16;    // solved row panels of two consecutive block steps: tile b of step s at Pt + ((s & 1) NT + b) TL, [k][m]
+  int* sfail = reinterpret_cast<int*>(pm_lds + TL + 16 + 2 * NT * TL);   // first failed pivot of the block (1-based), 0 = none
+  int* dflag = sfail + 1;                                                // number of diagonal tiles published so far
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nb = min(16 * NT, n - k0);
+  const int nbt = (nb + 15) >> 4;
+  double* Ab = A + (long)blockIdx.x * strideA + (long)k0 * lda + k0;
+  if (tid == 0) { *sfail = 0; *dflag = 0; }
+  lds_barrier();
+  if constexpr (NW == 4) {
+    switch (w) {
+      case 0: potrf_tiles_wave<NW, 0, NT>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail, dflag); break;
+      case 1: potrf_tiles_wave<NW, 1, NT>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail, dflag); break;
+      case 2: potrf_tiles_wave<NW, 2, NT>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail, dflag); break;
+      default: potrf_tiles_wave<NW, 3, NT>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail, dflag); break;
+    }
+  } else {
+    switch (w) {
+      case 0: potrf_tiles_wave<NW, 0, NT>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail, dflag); break;
+      case 1: potrf_tiles_wave<NW, 1, NT>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail, dflag); break;
+      case 2: potrf_tiles_wave<NW, 2, NT>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail, dflag); break;
+      case 3: potrf_tiles_wave<NW, 3, NT>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail, dflag); break;
+      case 4: potrf_tiles_wave<NW, 4, NT>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail, dflag); break;
+      case 5: potrf_tiles_wave<NW, 5, NT>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail, dflag); break;
+      case 6: potrf_tiles_wave<NW, 6, NT>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail, dflag); break;
+      default: potrf_tiles_wave<NW, 7, NT>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail, dflag); break;
+    }
+  }
+  if (tid == 0 && *sfail && *sfail <= nb) atomicCAS(&info[blockIdx.x], 0, k0 + *sfail);
+}
+
+// =============================================================================================
 // Panel solve: A12 <- U11^-T A12 (dtrsm 'L','U','T','N'), U11 = the factored 128 x 128 diagonal block, A12 128 x mcols.
 // One wavefront per 16 columns, WAVES wavefronts per workgroup share U11 in LDS (36 upper tiles, 77 KB).
 // =============================================================================================
@@ -460,22 +701,32 @@ __global__ __launch_bounds__(64 * WAVES) void potrf_panel_mfma_kernel(double* __
 // ---------------------------------------------------------------------------------------------
 // launchers (same contracts as potrf_diag_launch(factor only) / potrf_panel_solve_launch of potrf_diag.hip)
 // ---------------------------------------------------------------------------------------------
+static bool potrf_la_on() {
+  static const bool on = [] { const char* e = getenv("HYP_POTRF_LA"); return !(e && atoi(e) == 0); }();
+  return on;
+}
 void potrf_diag_mfma_launch(hipStream_t st, int batch, double* A, long lda, long strideA, int n, int k0, int* info, int own_cu_lds) {
-  const size_t lds = (size_t)(TL + 16 + 8 * TL + 2) * sizeof(double);
-  const size_t want = own_cu_lds > 0 ? std::max<size_t>(lds, (size_t)own_cu_lds) : lds;
-  hipLaunchKernelGGL(potrf_diag_mfma_kernel, dim3(batch), dim3(256), want, st, A, lda, strideA, n, k0, info);
+  if (potrf_la_on()) {
+    const size_t lds = (size_t)(TL + 16 + 2 * 8 * TL + 2) * sizeof(double);
+    const size_t want = own_cu_lds > 0 ? std::max<size_t>(lds, (size_t)own_cu_lds) : lds;
+    hipLaunchKernelGGL((potrf_tiles_kernel<4, 8>), dim3(batch), dim3(256), want, st, A, lda, strideA, n, k0, info);
+  } else {
+    const size_t lds = (size_t)(TL + 16 + 8 * TL + 2) * sizeof(double);
+    const size_t want = own_cu_lds > 0 ? std::max<size_t>(lds, (size_t)own_cu_lds) : lds;
+    hipLaunchKernelGGL(potrf_diag_mfma_kernel, dim3(batch), dim3(256), want, st, A, lda, strideA, n, k0, info);
+  }
   HYP_CHECK(hipGetLastError());
 }
 int potrf_diag_mfma_own_cu_lds() {
   const int want = 124 * 1024;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_diag_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want);
+  hipError_t e = potrf_la_on() ? hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_tiles_kernel<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, want)
+                               : hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_diag_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
   return want;
 }
-
 void potrf_panel_mfma_launch(hipStream_t st, int batch, double* A, long lda, long strideA, int k0, int mcols) {
   if (mcols <= 0) return;
   const size_t lds = (size_t)(36 * TL + NB) * sizeof(double);

@@ -418,6 +418,11 @@ void SysSolver::factor_lhs(int* info, int* used_fallback) {   // qrchol.jl:249-2
     potrf_upper_batched(ctx, nmp, lhs_fact.d(), nmp, 0, 1, dinv.d(), d_info.i());
     HYP_CHECK(hipEventRecord(ctx.ev[4], ctx.stream));
     ctx.d2h(ctx.h_info, d_info.p, sizeof(int));
+    // the solve plan of the (almost always successful) factorization is queued BEFORE the host learns info: reading info
+    // first left the device idle for the round trip (~0.2 ms per iteration, profiles/r02_iteration_timeline.txt); after a
+    // failed Cholesky the plan's kernels ran on meaningless numbers and the plan is discarded below
+    tri.invalidate();
+    if (ctx.trsv_sb > 0 && nmp >= 2 * ctx.trsv_sb) tri.build(ctx, nmp, lhs_fact.d(), nmp, dinv.d());
     ctx.sync();
     *info = ctx.h_info[0];
     float ms = 0;
@@ -439,8 +444,8 @@ void SysSolver::factor_lhs(int* info, int* used_fallback) {   // qrchol.jl:249-2
     }
   }
   fact_ok = (*info == 0);
-  tri.invalidate();
-  if (fact_ok && ctx.trsv_sb > 0 && nmp >= 2 * ctx.trsv_sb) tri.build(ctx, nmp, lhs_fact.d(), nmp, dinv.d());
+  if (use_bk || !fact_ok) tri.invalidate();
+  if (fact_ok && !tri.ready(nmp) && ctx.trsv_sb > 0 && nmp >= 2 * ctx.trsv_sb) tri.build(ctx, nmp, lhs_fact.d(), nmp, dinv.d());
 }
 
 // x <- lhs^-1 x.  Cholesky: U'^-1 then U^-1.  Bunch-Kaufman: the same two sweeps with the unit factor, between a

@@ -272,6 +272,10 @@ int hyp_dense_gemv(hyp_ctx* ctx, int trans, int m, int n, double alpha, const do
 /* Measurement helper: HIP-event time (ms, mean of reps) of the blocked upper Cholesky of an n x n positive definite matrix
  * resident in HBM (posdef_fact_copy!'s first link, src/linearalgebra/dense.jl:194-200). */
 int hyp_bench_potrf(hyp_ctx* ctx, int n, int reps, double* ms_out);
+/* Measurement helper for the one- and two-right-hand-side potrs of qrchol.jl:68 on an n x n factor resident in HBM: HIP-event
+ * times (ms, mean of reps) of [0] building the super-block solve plan, [1] U'^-1 then U^-1 on one vector, [2] on two vectors.
+ * x_out (3 n doubles, may be NULL): the solutions of the last repetition (one vector, then the two), for A/B comparisons. */
+int hyp_bench_trsv(hyp_ctx* ctx, int n, int reps, double* ms_out3, double* x_out);
 /* time `reps` launches of the syrk C = A'A (A is K x N) with HIP events on the library stream; ms per launch */
 int hyp_bench_syrk(hyp_ctx* ctx, int N, int K, int reps, double* ms_out);
 

@@ -1,9 +1,7 @@
 export TMPDIR=/tmp
-for c in 5p 5d; do
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$c -o b -- python tools/run_config.py --config $c > gpurun_out/r02_cfg${c}_run.txt 2>&1
-DB=$(find gpurun_out/prof_$c -name "*.db" | head -1); python tools/rocpd_stats.py $DB gpurun_out/r02_cfg${c}_kernel_stats.csv > /dev/null
-rm -rf gpurun_out/prof_$c
-done
-HYP_PROFILE=1 python tools/run_config.py --config 5p > gpurun_out/r02_cfg5p_profile.txt 2>&1
-head -30 gpurun_out/r02_cfg5p_kernel_stats.csv | cut -c1-160
-tail -40 gpurun_out/r02_cfg5p_profile.txt
+python -m pytest tests -m gpu -q -x > gpurun_out/r02_pytest_full3.log 2>&1; tail -5 gpurun_out/r02_pytest_full3.log
+python bench.py --steps 60 > gpurun_out/bench_tmp.json 2>/dev/null; python - <<'PY'
+import json
+d=json.loads(open("gpurun_out/bench_tmp.json").read().strip().splitlines()[-1])
+print(d["ms_per_step"], d["phases_ms_per_step"], d["roofline"]["frac"])
+PY

@@ -7,7 +7,9 @@ import sys
 db = sqlite3.connect(sys.argv[1])
 rows = db.cursor().execute("select name,start,end from kernels order by start").fetchall()
 syrk = [i for i, r in enumerate(rows) if "gemm_f64_kernel<true, 4, 1>" in r[0]]
-a, b = syrk[-2], syrk[-1]
+import os
+back = int(os.environ.get("ITER_BACK", "1"))   # 1 = the last iteration of the trace, 2 = the one before, ...
+a, b = syrk[-1 - back], syrk[-back]
 t0, t1 = rows[a][1], rows[b][1]
 print("iteration window %.2f ms, %d kernels" % ((t1 - t0) / 1e6, b - a))
 busy, last_end, gaps, bykern = 0, t0, [], collections.Counter()
