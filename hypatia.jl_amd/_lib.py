@@ -196,6 +196,11 @@ def ctx():
     return _ctx
 
 
+def last_error():
+    """text of the calling thread's last library error ("" if none)"""
+    return _lib.hyp_last_error(_ctx).decode() if _lib is not None else ""
+
+
 def check(rc, what=""):
     if rc != 0:
         msg = _lib.hyp_last_error(_ctx).decode() if _lib is not None else ""

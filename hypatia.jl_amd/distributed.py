@@ -348,18 +348,31 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
         if dist.get_backend() == "nccl" and os.environ.get("HYP_DIST_RCCL", "1") not in ("0",):
             # RCCL inside the library: rank 0 creates the unique id, torch.distributed only carries its 128 bytes; from
             # here on the exchanges of the fused routines are ncclAllReduce calls on the library's own stream
+            # (every rank takes the same branch: a failure anywhere is agreed on through torch.distributed and all ranks
+            # fall back to the callback together)
+            def _all_ok(ok):
+                t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return bool(t.item())
             uid = ctypes.create_string_buffer(128)
+            ok = True
             if self.comm.rank == 0:
-                L.check(lib.hyp_comm_unique_id(uid), "hyp_comm_unique_id")
+                ok = lib.hyp_comm_unique_id(uid) == 0
             box = [uid.raw]
             dist.broadcast_object_list(box, src=0)
-            uid = ctypes.create_string_buffer(box[0], 128)
             hc = ctypes.c_void_p()
-            L.check(lib.hyp_comm_init_rank(L.ctx(), self.comm.world, self.comm.rank, uid, ctypes.byref(hc)), "hyp_comm_init_rank")
-            self._hyp_comm = hc
-            L.check(lib.hyp_sys_set_comm_rccl(h, hc), "hyp_sys_set_comm_rccl")
-            self.rccl_in_library = True
-        else:
+            if _all_ok(ok):
+                uid = ctypes.create_string_buffer(box[0], 128)
+                ok = lib.hyp_comm_init_rank(L.ctx(), self.comm.world, self.comm.rank, uid, ctypes.byref(hc)) == 0
+                if _all_ok(ok):
+                    self._hyp_comm = hc
+                    L.check(lib.hyp_sys_set_comm_rccl(h, hc), "hyp_sys_set_comm_rccl")
+                    self.rccl_in_library = True
+                elif ok:
+                    lib.hyp_comm_destroy(hc)
+            if not self.rccl_in_library and self.comm.rank == 0:
+                print("hypatia_jl_amd: RCCL inside the library is not available (%s); collectives go through torch.distributed" % L.last_error())
+        if not self.rccl_in_library:
             L.check(lib.hyp_sys_set_comm(h, ctypes.cast(self._cb, ctypes.c_void_p), None, ctypes.c_void_p(stage.data_ptr()), int(stage.numel())),
                     "hyp_sys_set_comm")
         cc = np.ascontiguousarray(model.c, dtype=np.float64)
