@@ -1,7 +1,5 @@
 export TMPDIR=/tmp
-for d in 0 1 2 3 4 7; do
-HYP_TS_DBG=$d rocprofv3 --kernel-trace --stats -d gpurun_out/prof_ts$d -o b -- python tools/bench_psd_ts.py 200 2500 3 > /dev/null 2>&1
-DB=$(find gpurun_out/prof_ts$d -name "*.db" | head -1); python tools/rocpd_stats.py $DB /tmp/ts$d.csv > /dev/null
-echo "dbg=$d"; grep psd_ts /tmp/ts$d.csv | cut -d, -f1-4 | cut -c1-90
-rm -rf gpurun_out/prof_ts$d
-done
+HYP_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python bench.py --steps 6 --warmup 1 --secondary-steps 10 2>/dev/null | tail -1 | cut -c1-200
+HYP_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29534 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python bench.py --config 2 --steps 6 --warmup 1 2>/dev/null | tail -1 | cut -c1-200
+python bench.py --steps 10 --cpu-iters 0 2>/dev/null | tail -1 | cut -c1-120
+python bench.py --config 3b 2>/dev/null | tail -1 | cut -c1-120
