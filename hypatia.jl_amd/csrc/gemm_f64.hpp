@@ -65,6 +65,10 @@ struct GemmArgs {
   int splitk; int kchunk; double* part; long part_ld; long part_stride;
   int vec2;        // set by the launcher: operands are 16-byte aligned with even leading dimensions
   const int* tile_map;   // optional (tm, tn) per blockIdx.x: XCD-aware tile order (set by the launcher)
+  // tail of the split-K launch (set by the launcher): the workgroups of the last, partly filled round -- slice splitk_base - 1
+  // of the tiles at launch positions >= tail_first -- are cut into tail_q sub-slices of tail_chunk k each, which run as the
+  // extra z layers splitk_base .. splitk - 1 (positions < tail_first leave at once there) and write partial slots of their own
+  int splitk_base, tail_q, tail_first, tail_chunk;
 };
 
 // Launcher state that belongs to the caller's context (one per hyp_ctx, i.e. per device and stream pair): the split-K
@@ -73,7 +77,7 @@ struct GemmArgs {
 struct GemmScratch {
   double* splitk_ws = nullptr;
   size_t splitk_ws_bytes = 0;
-  int* tile_map = nullptr;
+  int* tile_map = nullptr;     // (tm, tn) per launch position, then the inverse: launch position per tile tm + tn * T
   int tile_map_T = -1;
   void release() {
     if (splitk_ws) (void)hipFree(splitk_ws);

@@ -55,8 +55,22 @@ void gemm_f64_kernel(GemmArgs p) {
   // K range (split-K: this slice's chunk)
   int kbeg = 0, kend = p.K;
   if (p.splitk > 1) {
-    kbeg = blockIdx.z * p.kchunk;
+    int z = blockIdx.z, sub = -1;
+    if (p.tail_q > 1) {
+      if (z >= p.splitk_base) {
+        if ((int)blockIdx.x < p.tail_first) return;
+        sub = z - p.splitk_base + 1;
+        z = p.splitk_base - 1;
+      } else if (z == p.splitk_base - 1 && (int)blockIdx.x >= p.tail_first) {
+        sub = 0;
+      }
+    }
+    kbeg = z * p.kchunk;
     kend = min(p.K, kbeg + p.kchunk);
+    if (sub >= 0) {
+      kbeg += sub * p.tail_chunk;
+      kend = min(kend, kbeg + p.tail_chunk);
+    }
   }
   switch (p.krange) {
     case KR_LE_M: kend = min(p.K, m0 + BM); break;
@@ -268,14 +282,18 @@ void gemm_f64_kernel(GemmArgs p) {
   }
 }
 
-// C = alpha * (sum of the split-K slices, in slice order) + beta * C
+// C = alpha * (sum of the split-K slices, in slice order) + beta * C.  Tiles of the launch's tail (launch position >= tail_first,
+// tile_rank = launch position per 128 x 128 tile) have S_extra more partial slots, the sub-slices of their last slice.
 __global__ void splitk_reduce_kernel(int M, int N, int upper, int tri_off, int S, const double* __restrict__ part, long part_ld, long part_stride,
-                                     double alpha, double beta, double* __restrict__ C, long ldc) {
+                                     double alpha, double beta, double* __restrict__ C, long ldc, int S_extra, int tail_first,
+                                     const int* __restrict__ tile_rank, int T) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = blockIdx.y;
   if (m >= M || (upper && m > n + tri_off)) return;
   double s = 0.0;
   for (int z = 0; z < S; ++z) s += part[(long)z * part_stride + (long)n * part_ld + m];
+  if (S_extra > 0 && tile_rank[(m >> 7) + (n >> 7) * T] >= tail_first)
+    for (int z = S; z < S + S_extra; ++z) s += part[(long)z * part_stride + (long)n * part_ld + m];
   double* cp = C + (long)n * ldc + m;
   *cp = alpha * s + (beta != 0.0 ? beta * (*cp) : 0.0);
 }
@@ -296,7 +314,7 @@ static const int* upper_tile_map(GemmScratch& gs, int T, long nblk) {
           const int tm = I * ST + i, tn = J * ST + j;
           if (tm < T && tn < T && tm <= tn) { logical.push_back(tm); logical.push_back(tn); }
         }
-  std::vector<int> hw(2 * nblk);
+  std::vector<int> hw(2 * nblk + (size_t)T * T, -1);
   const long q = nblk / 8, r = nblk % 8;   // XCD x owns logical [start_x, start_x + q + (x < r))
   for (long b = 0; b < nblk; ++b) {
     const long x = b % 8, k = b / 8;
@@ -304,6 +322,7 @@ static const int* upper_tile_map(GemmScratch& gs, int T, long nblk) {
     const long L = start + k;
     hw[2 * b] = logical[2 * L];
     hw[2 * b + 1] = logical[2 * L + 1];
+    hw[2 * nblk + hw[2 * b] + (size_t)hw[2 * b + 1] * T] = (int)b;   // inverse: launch position of tile (tm, tn)
   }
   if (gs.tile_map) (void)hipFree(gs.tile_map);
   gs.tile_map = nullptr; gs.tile_map_T = -1;
@@ -364,8 +383,33 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch*
     if (s_env > 0 && a.K / s_env >= 512) a.splitk = s_env;
   }
   if (gs && a.splitk_req > 1 && a.batch == 1 && a.epi == 0 && a.krange == KR_ALL && a.cm_blk == 0 && a.K / a.splitk_req >= 256) a.splitk = a.splitk_req;
+  a.splitk_base = a.splitk; a.tail_q = 1; a.tail_first = 0; a.tail_chunk = 0;
   if (a.splitk > 1) {
     a.kchunk = (((a.K + a.splitk - 1) / a.splitk) + BK - 1) / BK * BK;
+    // The last round of 512 resident workgroups is only partly filled (config 2: 3900 = 7 x 512 + 316, so the launch takes 8
+    // workgroup times for 7.6 of work).  Its workgroups are cut into q sub-slices of K: 316 x 3 = 948 short ones fill two
+    // rounds of a third of the length -- 7.67 workgroup times.  Only for the Schur syrk with its tile order (the reduction
+    // needs the launch position of a tile).  Measured: 8.26 -> 8.18 ms back to back (q = 2: 8.29, 4: 8.17, 6: 8.18; cutting
+    // more than the last round's workgroups: slower) -- the workgroups do not run in lock-step rounds, most of the tail was
+    // already filled.
+    static const bool tail_on = [] { const char* e = getenv("HYP_SYRK_TAIL"); return !(e && atoi(e) == 0); }();
+    if (tail_on && gs && a.tag == 1 && transa && a.tri == GEMM_UPPER && !small && a.batch == 1 && nblk >= 64) {
+      const long rem = (nblk * a.splitk) % 512;
+      if (rem > 0 && rem <= nblk) {
+        int best_q = 1;
+        double best = 1.0;
+        for (int q = 2; q <= 4; ++q) {
+          const double t = (double)((rem * q + 511) / 512) / q;
+          if (t < best - 1e-9 && a.kchunk / q >= 256) { best = t; best_q = q; }
+        }
+        if (best_q > 1) {
+          a.tail_q = best_q;
+          a.tail_first = (int)(nblk - rem);
+          a.tail_chunk = ((a.kchunk + best_q - 1) / best_q + BK - 1) / BK * BK;
+          a.splitk = a.splitk_base + best_q - 1;
+        }
+      }
+    }
     a.part_ld = a.M;
     a.part_stride = (long)a.M * a.N;
     const size_t need = (size_t)a.splitk * a.part_stride * sizeof(double);
@@ -382,6 +426,7 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch*
             (a.strideA % 2 == 0) && (a.strideB % 2 == 0) && a.krange != KR_GE_M && a.krange != KR_GE_N) ? 1 : 0;
   a.tile_map = nullptr;
   if (gs && a.tag == 1 && a.tri == GEMM_UPPER && !small && a.batch == 1 && nblk >= 64) a.tile_map = upper_tile_map(*gs, a.tiles_n, nblk);
+  if (a.tail_q > 1 && !a.tile_map) { a.splitk = a.splitk_base; a.tail_q = 1; }
   dim3 grid((unsigned)nblk, (unsigned)a.batch, (unsigned)a.splitk);
   if (a.tag == 1 && transa && !small) {
     hipLaunchKernelGGL((gemm_f64_kernel<true, 4, 1>), grid, dim3(GEMM_THREADS), 0, st, a);
@@ -393,8 +438,9 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch*
     else hipLaunchKernelGGL((gemm_f64_kernel<false, 4, 0>), grid, dim3(GEMM_THREADS), 0, st, a);
   }
   if (a.splitk > 1)
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((a.M + 255) / 256, a.N), dim3(256), 0, st, a.M, a.N, a.tri != GEMM_FULL ? 1 : 0, a.tri_off, a.splitk,
-                       a.part, a.part_ld, a.part_stride, a.alpha, a.beta, a.C, a.ldc);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((a.M + 255) / 256, a.N), dim3(256), 0, st, a.M, a.N, a.tri != GEMM_FULL ? 1 : 0, a.tri_off,
+                       a.splitk_base, a.part, a.part_ld, a.part_stride, a.alpha, a.beta, a.C, a.ldc, a.tail_q - 1, a.tail_first,
+                       a.tile_map ? a.tile_map + 2 * nblk : nullptr, a.tiles_n);
   return hipGetLastError();
 }
 

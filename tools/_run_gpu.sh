@@ -1,5 +1,4 @@
 export TMPDIR=/tmp
-HYP_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python bench.py --steps 6 --warmup 1 --secondary-steps 10 2>/dev/null | tail -1 | cut -c1-200
-HYP_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29534 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python bench.py --config 2 --steps 6 --warmup 1 2>/dev/null | tail -1 | cut -c1-200
-python bench.py --steps 10 --cpu-iters 0 2>/dev/null | tail -1 | cut -c1-120
-python bench.py --config 3b 2>/dev/null | tail -1 | cut -c1-120
+for v in "0 0 0" "1 2 0" "1 3 0" "1 4 0" "1 6 0" "1 3 196" "1 2 464" "1 4 100"; do set -- $v
+echo "tail=$1 q=$2 extra=$3: $(HYP_SYRK_TAIL=$1 HYP_SYRK_TAIL_Q=$2 HYP_SYRK_TAIL_X=$3 python tools/bench_syrk.py 5000 20100 8 2>&1 | tail -1)"
+done
