@@ -282,13 +282,30 @@ void SysSolver::load(const double* hG, const double* hGQ1, const double* hGQ2, c
 // rccl_comm.hip
 void rccl_allreduce_inplace(void* comm, double* d_buf, long count, int op, hipStream_t st);
 
+// upper triangle of an n x n column-major matrix <-> packed columns (column j at j (j + 1) / 2): what the ranks exchange
+__global__ void tri_pack_kernel(int n, const double* __restrict__ A, long lda, double* __restrict__ P, int unpack) {
+  const int j = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > j) return;
+  if (unpack) const_cast<double*>(A)[(long)j * lda + i] = P[(long)j * (j + 1) / 2 + i];
+  else P[(long)j * (j + 1) / 2 + i] = A[(long)j * lda + i];
+}
+
 void SysSolver::allreduce_lhs() {
   const bool have = (comm_fn != nullptr || rccl_comm != nullptr);
   if (!have || (ks_world <= 1 && !dist())) return;
   const int kw = ks_world;
   ks_world = 1;   // (allreduce_dev is the cone-sharded mode's entry point: borrow it)
   try {
-    allreduce_dev(lhs.d(), (long)nmp * nmp, 0);
+    // only the upper triangle is meaningful (syrk 'U'): the ranks exchange its n (n + 1) / 2 entries, not the n^2 of the
+    // square buffer -- half the bytes over xGMI for two passes over the matrix in HBM
+    const long cnt = (long)nmp * (nmp + 1) / 2;
+    lhs_tri.ensure((size_t)cnt * sizeof(double));
+    const dim3 grid((nmp + 255) / 256, nmp);
+    hipLaunchKernelGGL(tri_pack_kernel, grid, dim3(256), 0, ctx.stream, nmp, lhs.d(), (long)nmp, lhs_tri.d(), 0);
+    allreduce_dev(lhs_tri.d(), cnt, 0);
+    hipLaunchKernelGGL(tri_pack_kernel, grid, dim3(256), 0, ctx.stream, nmp, lhs.d(), (long)nmp, lhs_tri.d(), 1);
+    HYP_CHECK(hipGetLastError());
   } catch (...) {
     ks_world = kw;
     throw;

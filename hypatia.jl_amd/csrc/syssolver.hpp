@@ -20,6 +20,7 @@ struct SysSolver {
   DBuf Rinv;    // p x p   inverse of Ap_R (upper), computed once at load
   DBuf HGQ2;    // q x nmp
   DBuf lhs;     // nmp x nmp (upper)
+  DBuf lhs_tri; // its packed upper triangle: the payload of the Schur all-reduce
   DBuf lhs_fact, dinv, d_info;
   TriSolvePlan tri;   // super-block inverses of lhs_fact for the one-RHS solves
   // vectors

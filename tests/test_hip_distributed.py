@@ -37,7 +37,7 @@ def test_library_rccl_exchanges_one_rank(monkeypatch):
     monkeypatch.setenv("HYP_DIST_NATIVE", "1")
     res = _run_sharded("1", world=1, transport="nccl")
     assert bool(res["rccl_in_library"])
-    assert res["lib_exchanges"][0] > 50 and res["lib_exchanges"][1] >= 120 * 120
+    assert res["lib_exchanges"][0] > 50 and res["lib_exchanges"][1] >= 120 * 121 // 2
 
 
 def test_library_rccl_allreduce_on_a_device_buffer():
@@ -104,6 +104,6 @@ def test_kshard_single_cone_solve_matches_oracle():
     assert abs(int(res["iters"]) - ref.num_iters) <= 1
     assert abs(float(res["p_obj"]) - ref.primal_obj) <= 1e-7 * (1 + abs(ref.primal_obj))
     assert np.allclose(res["x"], ref.get_x(), rtol=1e-5, atol=1e-7)
-    # one n x n exchange per Schur assembly (one per iteration), nothing else
+    # one exchange of the Schur matrix's packed upper triangle per assembly (one per iteration), nothing else
     assert int(res["iters"]) <= res["exchanges"][0] <= int(res["iters"]) + 3
-    assert res["exchanges"][1] == res["exchanges"][0] * 150 * 150
+    assert res["exchanges"][1] == res["exchanges"][0] * (150 * 151 // 2)
