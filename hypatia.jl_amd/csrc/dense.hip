@@ -29,8 +29,9 @@ int potrf_diag_mfma_own_cu_lds();
 void potrf_panel_mfma_launch(hipStream_t st, int batch, double* A, long lda, long strideA, int k0, int mcols);
 
 static void potrf_step_gemms(Ctx& c, hipStream_t st, int nb, int M, int N, const double* U12a, const double* U12b, long lda, long strideA,
-                             double* C, int tri, int batch) {
+                             double* C, int tri, int batch, int tile_hint = 0) {
   GemmArgs s{};   // C <- C - U12a' U12b
+  s.tile_hint = tile_hint;
   s.M = M; s.N = N; s.K = nb;
   s.A = U12a; s.lda = lda; s.strideA = strideA;
   s.B = U12b; s.ldb = lda; s.strideB = strideA;
@@ -121,14 +122,16 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
     const int mr = m - nb1;                // rows beyond it
     hipEvent_t Tk = c.pool_event(2 * kb), Rk = c.pool_event(2 * kb + 1);
     if (kb >= 1) HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(2 * (kb - 1) + 1), 0));   // rest(k-1) touched block row k+1 too
-    potrf_step_gemms(c, c.stream, nb, nb1, m, A12, A12, lda, strideA, A22, GEMM_UPPER_RECT, 1);   // block row k+1: diagonal block (upper) + its row panel
+    static const int look_tile = [] { const char* e = getenv("HYP_POTRF_LOOK_TILE"); return e ? atoi(e) : 0; }();
+    potrf_step_gemms(c, c.stream, nb, nb1, m, A12, A12, lda, strideA, A22, GEMM_UPPER_RECT, 1, look_tile);   // block row k+1: diagonal block (upper) + its row panel
     // the big remainder starts only after the main stream's small updates are queued: it then runs
     // underneath the next diagonal-block kernel + panel solve instead of competing with them
     HYP_CHECK(hipEventRecord(Tk, c.stream));
     if (mr > 0) {
       HYP_CHECK(hipStreamWaitEvent(c.stream2, Tk, 0));
+      static const int trail_tile = [] { const char* e = getenv("HYP_POTRF_TRAIL_TILE"); return e ? atoi(e) : 64; }();
       potrf_step_gemms(c, c.stream2, nb, mr, mr, A12 + (long)nb1 * lda, A12 + (long)nb1 * lda, lda, strideA,
-                       A22 + (long)nb1 * lda + nb1, GEMM_UPPER, 1);                                            // everything below, on the helper stream
+                       A22 + (long)nb1 * lda + nb1, GEMM_UPPER, 1, trail_tile);                                // everything below, on the helper stream
     }
     HYP_CHECK(hipEventRecord(Rk, c.stream2));
   }

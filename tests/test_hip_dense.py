@@ -82,6 +82,22 @@ def test_posv_superblock_solves(hip, n, cond):
     assert np.linalg.norm(x - xref) <= 1e-12 * cond * np.linalg.norm(xref)
 
 
+def test_superblock_solve_kernels_same_sums_with_and_without_batched_loads(tmp_path):
+    """the dot-product kernels of the super-block solves exist in two forms (all loads of a lane issued at once, or four at a
+    time: HYP_COLDOT_BATCH); the switch is read once per process, so each form runs in a process of its own -- bitwise equal"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("0", "1"):
+        out = str(tmp_path / ("trsv%s.npz" % flag))
+        env = dict(os.environ, HYP_COLDOT_BATCH=flag)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_trsv.py"), "2300", "--dump", out], cwd=root, env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out)["x2300"])
+    assert np.all(np.isfinite(outs[0])) and np.array_equal(outs[0], outs[1])
+
+
 def test_potrf_reports_failed_minor(hip):
     lib, ctx, L = hip
     n = 200

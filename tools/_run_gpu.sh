@@ -1,2 +1,8 @@
 export TMPDIR=/tmp
-python -m pytest tests/test_hip_distributed.py -q -x 2>&1 | tail -3
+python -m pytest tests -m gpu -q -x > gpurun_out/r02_pytest_full4.log 2>&1; tail -4 gpurun_out/r02_pytest_full4.log
+python bench.py > gpurun_out/r02_bench_cfg2_1gpu.json 2> gpurun_out/r02_bench_cfg2_1gpu.err
+python - <<'PY'
+import json
+d=json.loads(open("gpurun_out/r02_bench_cfg2_1gpu.json").read().strip().splitlines()[-1])
+print(d["ms_per_step"], d["value"], d["phases_ms_per_step"], d["roofline"]["frac"], d["setup_s"])
+PY
