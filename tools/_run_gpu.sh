@@ -1,8 +1,3 @@
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -q -x > gpurun_out/r02_pytest_full4.log 2>&1; tail -4 gpurun_out/r02_pytest_full4.log
-python bench.py > gpurun_out/r02_bench_cfg2_1gpu.json 2> gpurun_out/r02_bench_cfg2_1gpu.err
-python - <<'PY'
-import json
-d=json.loads(open("gpurun_out/r02_bench_cfg2_1gpu.json").read().strip().splitlines()[-1])
-print(d["ms_per_step"], d["value"], d["phases_ms_per_step"], d["roofline"]["frac"], d["setup_s"])
-PY
+for w in 1 2 4; do echo "panel waves $w: $(HYP_PANEL_WAVES=$w python tools/bench_potrf.py 5000 2>&1 | tail -1)"; done
+for w in 2 4; do echo "panel waves $w own_cu 0: $(HYP_POTRF_OWN_CU=0 HYP_PANEL_WAVES=$w python tools/bench_potrf.py 5000 2>&1 | tail -1)"; done
