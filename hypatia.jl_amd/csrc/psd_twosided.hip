@@ -33,6 +33,8 @@ constexpr int TS_LDK = 18;                    // LDS row stride (16 k + 2): conf
 // BT = MFMA tiles per workgroup-tile edge (template parameter).  Smaller tiles re-read operands from L2 more often but
 // leave room for 3 - 4 resident workgroups per CU, which hides the staging / barrier latency of this short-K kernel:
 // measured on 3000 matrices of side 200 (pass 1 / pass 2, us): BT 7: 1233 / 1103, BT 5: 1271 / 824, BT 4: 1100 / 977, BT 3: 1085 / 700.
+// (round 2: K loop reordered -- store block kt + 1, request block kt + 2, multiply block kt, LDS-only barrier: 2500 matrices
+//  960 / 588 -> 876 / 568 us; the same order in the big GEMM kernel, whose K steps are four times longer, lost 4 %)
 
 struct TsArgs {
   int s, T, rstruct;          // side, ceil(side / 16), 0 full / 1 upper / 2 lower triangular R
@@ -179,16 +181,20 @@ __global__ __launch_bounds__(TS_THREADS, (TS_BT <= 4 ? 4 : (TS_BT <= 5 ? 3 : 2))
       }
   };
 
+  // K loop.  Step kt: the operands of block kt + 1 (requested a whole step ago) go to the other LDS buffer, block kt + 2 is
+  // requested, block kt is multiplied; the barrier at the end orders LDS traffic only (__syncthreads() would also wait for
+  // the loads just requested: s_waitcnt vmcnt(0)).
   if (kt_hi > kt_lo) {
     load_tiles(kt_lo);
     store_tiles(0, kt_lo);
-    __syncthreads();
+    if (kt_lo + 1 < kt_hi) load_tiles(kt_lo + 1);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     for (int kt = kt_lo; kt < kt_hi; ++kt) {
       const int buf = (kt - kt_lo) & 1;
-      if (kt + 1 < kt_hi) load_tiles(kt + 1);
-      compute(kt, buf);
       if (kt + 1 < kt_hi) store_tiles(buf ^ 1, kt + 1);
-      __syncthreads();
+      if (kt + 2 < kt_hi) load_tiles(kt + 2);
+      compute(kt, buf);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
   }
 

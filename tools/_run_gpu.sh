@@ -1,3 +1,5 @@
 export TMPDIR=/tmp
-for w in 1 2 4; do echo "panel waves $w: $(HYP_PANEL_WAVES=$w python tools/bench_potrf.py 5000 2>&1 | tail -1)"; done
-for w in 2 4; do echo "panel waves $w own_cu 0: $(HYP_POTRF_OWN_CU=0 HYP_PANEL_WAVES=$w python tools/bench_potrf.py 5000 2>&1 | tail -1)"; done
+python tools/bench_syrk.py 5000 20100 8 | tail -1
+python tools/bench_potrf.py 5000 4845 1000 | tail -3
+python tools/bench_trsv.py 5000 | tail -1
+python -m pytest tests/test_hip_dense.py -q -x 2>&1 | tail -2
