@@ -34,6 +34,7 @@ SIGNATURES = {
     "hyp_cone_create_wsosinterpnonnegative": [c_vp, c_int, c_int, P(c_int), P(c_vp), c_int, P(c_vp)],
     "hyp_cone_create_wsosinterppossemideftri": [c_vp, c_int, c_int, c_int, P(c_int), P(c_vp), c_int, P(c_vp)],
     "hyp_cone_create_linmatrixineq": [c_vp, c_int, c_int, c_vp, c_int, P(c_vp)],
+    "hyp_cone_create_linmatrixineq_complex": [c_vp, c_int, c_int, c_vp, c_int, P(c_vp)],
     "hyp_cone_create_doublynonnegativetri": [c_vp, c_int, c_int, P(c_vp)],
     "hyp_cone_create_hyporootdettri": [c_vp, c_int, c_int, P(c_vp)],
     "hyp_cone_create_hypoperlogdettri": [c_vp, c_int, c_int, P(c_vp)],

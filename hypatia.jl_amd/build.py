@@ -15,7 +15,7 @@ def make_cone(spec):
         return hc.EpiNormSpectral(spec[1], spec[2], use_dual=spec[3])
     if kind == "wsosinterpnonnegative":
         return hc.WSOSInterpNonnegative(spec[1], spec[2], use_dual=spec[3])
-    if kind == "linmatrixineq":
+    if kind in ("linmatrixineq", "linmatrixineq_complex"):   # (complex Hermitian members are recognised by their dtype)
         return hc.LinMatrixIneq(spec[1], use_dual=spec[2])
     if kind == "doublynonnegativetri":
         return hc.DoublyNonnegativeTri(spec[1], use_dual=spec[2])

@@ -266,20 +266,32 @@ class WSOSInterpNonnegative(_GenericHessMixin, Cone):
 
 
 class LinMatrixIneq(_GenericHessMixin, Cone):
-    """Cones.LinMatrixIneq{Float64}(As; use_dual)  (linmatrixineq.jl:9-65), real dense symmetric members
+    """Cones.LinMatrixIneq{Float64}(As; use_dual)  (linmatrixineq.jl:9-65), dense real symmetric or complex Hermitian members
     (sparse / Diagonal members are densified here; `I` is not accepted, pass np.eye(side))."""
 
     def __init__(self, As, use_dual=False):
         self._slow = False
-        As = [np.asarray(A.toarray() if hasattr(A, "toarray") else A, dtype=np.float64) for A in As]
+        As = [np.asarray(A.toarray() if hasattr(A, "toarray") else A) for A in As]
         dim, side = len(As), As[0].shape[0]
         assert dim > 1                                                        # :42
+        h = c_vp()
+        if any(np.iscomplexobj(A) for A in As):   # complex Hermitian members (the cone vector stays real)
+            As = [np.asarray(A, dtype=np.complex128) for A in As]
+            for A in As:
+                assert A.shape == (side, side) and np.array_equal(A, A.conj().T)  # :44-53 ishermitian
+            assert side * (side + 1) // 2 >= dim                              # :56
+            assert np.all(np.linalg.eigvalsh(As[0]) > 0)                      # :57
+            stacked = np.ascontiguousarray(np.stack([A.T for A in As]))       # C order of A.T = column-major A, (re, im) interleaved
+            L.check(L.lib().hyp_cone_create_linmatrixineq_complex(L.ctx(), dim, side, stacked.ctypes.data_as(c_vp), int(bool(use_dual)),
+                                                                  ctypes.byref(h)), "hyp_cone_create_linmatrixineq_complex")
+            super().__init__(h)
+            return
+        As = [np.asarray(A, dtype=np.float64) for A in As]
         for A in As:
             assert A.shape == (side, side) and np.array_equal(A, A.T)         # :44-53
         assert side * (side + 1) // 2 >= dim                                  # :56
         assert np.all(np.linalg.eigvalsh(As[0]) > 0)                          # :57
         stacked = np.ascontiguousarray(np.stack(As))                          # symmetric: row- and column-major coincide
-        h = c_vp()
         L.check(L.lib().hyp_cone_create_linmatrixineq(L.ctx(), dim, side, stacked.ctypes.data_as(c_vp), int(bool(use_dual)), ctypes.byref(h)),
                 "hyp_cone_create_linmatrixineq")
         super().__init__(h)

@@ -142,6 +142,13 @@ int hyp_cone_create_linmatrixineq(hyp_ctx* ctx, int dim, int side, const double*
   ctx->c.sync();
   API_END(ctx)
 }
+int hyp_cone_create_linmatrixineq_complex(hyp_ctx* ctx, int dim, int side, const double* As, int use_dual, hyp_cone** out) {
+  API_BEGIN
+  HYP_CHECK(hipSetDevice(ctx->c.device));
+  *out = new hyp_cone{ctx, new LmiCone(ctx->c, dim, side, As, use_dual != 0, true)};
+  ctx->c.sync();
+  API_END(ctx)
+}
 int hyp_cone_create_doublynonnegativetri(hyp_ctx* ctx, int dim, int use_dual, hyp_cone** out) {
   API_BEGIN
   HYP_CHECK(hipSetDevice(ctx->c.device));

@@ -225,11 +225,16 @@ struct WsosCone : GenericHessCone {   // src/Cones/wsosinterpnonnegative.jl (rea
   void partial_lambda(int k, const double* d_dir);                                                 // :190-200 -> LU[k]
 };
 
-struct LmiCone : GenericHessCone {   // src/Cones/linmatrixineq.jl (real dense symmetric members)
+struct LmiCone : GenericHessCone {   // src/Cones/linmatrixineq.jl (real dense symmetric members; complex Hermitian members embedded)
   int side;
+  // Complex Hermitian members (side s) are held as their real embeddings phi(a + ib) = [[a, -b], [b, a]] of side 2 s: phi is a
+  // ring homomorphism with det phi(M) = |det M|^2, so -logdet(sum w_i A_i) = bscale * (-logdet(sum w_i phi(A_i))) with
+  // bscale = 1/2 -- the same function of w, hence every oracle of the complex cone is bscale times the real one's on the
+  // embedded members (gradient, Hessian, third-order term), and nu = s.
+  double bscale = 1.0;
   DBuf Amat;      // side^2 x dim: column i = A_i (col-major side x side)
   DBuf sumA, fact, fdinv, Rinv, T, Mmat, dirmat, Zm, infos, Jm;   // Mmat: side^2 x dim, column i = L^-1 A_i L^-T
-  LmiCone(Ctx& c, int dim, int side, const double* hAs, bool use_dual);
+  LmiCone(Ctx& c, int dim, int side, const double* hAs, bool use_dual, bool complex_members = false);
   bool update_feas() override;                                                                      // :87-96
   void update_grad() override;                                                                      // :98-109
   void update_hess() override;                                                                      // :111-123

@@ -304,11 +304,14 @@ __global__ void lmi_neg_trace_kernel(int side, int dim, const double* __restrict
   grad[i] = -t;
 }
 
-LmiCone::LmiCone(Ctx& c, int dim_, int side_, const double* hAs, bool use_dual) : GenericHessCone(c, CONE_LMI) {
+LmiCone::LmiCone(Ctx& c, int dim_, int side_, const double* hAs, bool use_dual, bool complex_members) : GenericHessCone(c, CONE_LMI) {
+  // (side_ is the side of the members as the caller sees them: complex side s -> embedded side 2 s; the bound of
+  //  linmatrixineq.jl:56, svec_length(side) >= dim, is the same for real and complex members)
   HYP_REQUIRE(dim_ > 1 && side_ >= 1 && (long)side_ * (side_ + 1) / 2 >= dim_, "LinMatrixIneq: 1 < dim <= side (side + 1) / 2");   // :42, :56
-  dim = dim_; side = side_;
+  dim = dim_; side = complex_members ? 2 * side_ : side_;
   use_dual_barrier = use_dual;
-  nu = side;                                                                                          // :72
+  nu = side_;                                                                                         // :72
+  bscale = complex_members ? 0.5 : 1.0;
   alloc_common();
   alloc_generic();
   const size_t s2 = (size_t)side * side * sizeof(double);
@@ -316,8 +319,25 @@ LmiCone::LmiCone(Ctx& c, int dim_, int side_, const double* hAs, bool use_dual) 
   sumA.alloc(s2); fact.alloc(s2); Rinv.alloc(s2); dirmat.alloc(s2); Zm.alloc(s2);
   fdinv.alloc(dinv_elems(side) * sizeof(double));
   infos.alloc(64);
-  ctx.h2d(Amat.p, hAs, s2 * dim);
-  ctx.sync();
+  if (complex_members) {   // hAs: dim matrices of side_ x side_ complex numbers (re, im interleaved), column-major
+    std::vector<double> emb((size_t)side * side * dim);
+    const long cs = side_;
+    for (long m = 0; m < dim; ++m) {
+      const double* a = hAs + 2 * cs * cs * m;
+      double* e = emb.data() + (size_t)side * side * m;
+      for (long j = 0; j < cs; ++j)
+        for (long i = 0; i < cs; ++i) {
+          const double re = a[2 * (j * cs + i)], im = a[2 * (j * cs + i) + 1];
+          e[(2 * j) * side + 2 * i] = re;          e[(2 * j + 1) * side + 2 * i + 1] = re;
+          e[(2 * j + 1) * side + 2 * i] = -im;     e[(2 * j) * side + 2 * i + 1] = im;      // [[a, -b], [b, a]]
+        }
+    }
+    ctx.h2d(Amat.p, emb.data(), s2 * dim);
+    ctx.sync();
+  } else {
+    ctx.h2d(Amat.p, hAs, s2 * dim);
+    ctx.sync();
+  }
 }
 
 void LmiCone::set_initial_point(double* h) {   // :74-81
@@ -349,6 +369,7 @@ void LmiCone::update_grad() {   // :98-109
   dev_symmetrize_from_upper(ctx, side, Mmat.d(), side, dim, s2);                             // Hermitian(., :U)
   hipLaunchKernelGGL(lmi_neg_trace_kernel, dim3((dim + 255) / 256), dim3(256), 0, ctx.stream, side, dim, Mmat.d(), grad.d());
   HYP_CHECK(hipGetLastError());
+  if (bscale != 1.0) dev_scale_copy(ctx, dim, bscale, grad.d(), grad.d());
   grad_updated = true;
 }
 
@@ -358,7 +379,7 @@ void LmiCone::update_hess() {   // :111-123: H[i, j] = <M_i, M_j>
   const int s2 = side * side;
   GemmArgs g{};
   g.M = dim; g.N = dim; g.K = s2; g.A = Mmat.d(); g.lda = s2; g.B = Mmat.d(); g.ldb = s2; g.C = H.d(); g.ldc = dim;
-  g.alpha = 1; g.beta = 0; g.tri = GEMM_UPPER; g.batch = 1;
+  g.alpha = bscale; g.beta = 0; g.tri = GEMM_UPPER; g.batch = 1;
   gemm(ctx, true, g);
   dev_symmetrize_from_upper(ctx, dim, H.d(), dim, 1, 0);
   hess_updated = true;
@@ -379,7 +400,7 @@ void LmiCone::hess_prod_slow(double* prod, long ldp, const double* arr, long lda
   gemm(ctx, false, a);
   GemmArgs b{};   // prod[i, j] = <j_mat, M_i>
   b.M = dim; b.N = ncols; b.K = s2; b.A = Mmat.d(); b.lda = s2; b.B = Jm.d(); b.ldb = s2; b.C = prod; b.ldc = ldp;
-  b.alpha = 1; b.beta = 0; b.batch = 1;
+  b.alpha = bscale; b.beta = 0; b.batch = 1;
   gemm(ctx, true, b);
 }
 
@@ -390,7 +411,7 @@ const double* LmiCone::dder3(const double* d_dir) {   // :146-159
   z.M = side; z.N = side; z.K = side; z.A = dirmat.d(); z.lda = side; z.B = dirmat.d(); z.ldb = side; z.C = Zm.d(); z.ldc = side;
   z.alpha = 1; z.beta = 0; z.batch = 1;
   gemm(ctx, true, z);
-  gemv(ctx, true, s2, dim, 1.0, Mmat.d(), s2, Zm.d(), 0.0, dder3v.d());           // dder3_i = <Z, M_i>
+  gemv(ctx, true, s2, dim, bscale, Mmat.d(), s2, Zm.d(), 0.0, dder3v.d());        // dder3_i = <Z, M_i>
   return dder3v.d();
 }
 

@@ -52,6 +52,10 @@ int hyp_cone_create_wsosinterpnonnegative(hyp_ctx* ctx, int U, int K, const int*
  * dim matrices one after the other, each side x side column-major (A_1 positive definite, dim <= side (side + 1) / 2);
  * copied to the device.  nu = side. */
 int hyp_cone_create_linmatrixineq(hyp_ctx* ctx, int dim, int side, const double* As, int use_dual, hyp_cone** out);
+/* The same with complex Hermitian members (linmatrixineq.jl:44-53 accepts any Hermitian A_i): As holds the dim matrices one
+ * after the other, each side x side complex numbers (re, im interleaved = Matrix{ComplexF64}), column-major.  The cone vector
+ * stays real (one weight per member); nu = side. */
+int hyp_cone_create_linmatrixineq_complex(hyp_ctx* ctx, int dim, int side, const double* As, int use_dual, hyp_cone** out);
 /* Cones.DoublyNonnegativeTri{Float64}(dim; use_dual) (doublynonnegativetri.jl:38-52): svec format, dim = side (side + 1) / 2;
  * nu = dim */
 int hyp_cone_create_doublynonnegativetri(hyp_ctx* ctx, int dim, int use_dual, hyp_cone** out);

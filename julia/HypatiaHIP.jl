@@ -103,7 +103,7 @@ end
 @hipcone PosSemidefTriComplex       # Cones.PosSemidefTri{Float64, ComplexF64}         possemideftri.jl:9-46 (dim = side^2)
 @hipcone EpiNormSpectral            # Cones.EpiNormSpectral{Float64, Float64}          epinormspectral.jl:13-66
 @hipcone WSOSInterpNonnegative      # Cones.WSOSInterpNonnegative{Float64, Float64}    wsosinterpnonnegative.jl:16-63
-@hipcone LinMatrixIneq              # Cones.LinMatrixIneq{Float64} (real dense members) linmatrixineq.jl:9-65
+@hipcone LinMatrixIneq              # Cones.LinMatrixIneq{Float64} (dense real symmetric or complex Hermitian members) linmatrixineq.jl:9-65
 @hipcone DoublyNonnegativeTri       # Cones.DoublyNonnegativeTri{Float64}              doublynonnegativetri.jl:9-52
 @hipcone HypoRootdetTri             # Cones.HypoRootdetTri{Float64, Float64}           hyporootdettri.jl:9-59
 @hipcone HypoPerLogdetTri           # Cones.HypoPerLogdetTri{Float64, Float64}         hypoperlogdettri.jl:9-58
@@ -189,11 +189,20 @@ function LinMatrixIneq(As::Vector; use_dual::Bool = false)
     @assert side > 0
     @assert Cones.svec_length(side) >= dim
     @assert isposdef(first(As))
+    h = new_handle()
+    if any(A_i -> A_i isa AbstractMatrix && eltype(A_i) <: Complex, As)             # complex Hermitian members: the cone vector stays real
+        cstacked = zeros(ComplexF64, side, side, dim)                             # (re, im) interleaved, column-major
+        for (i, A_i) in enumerate(As)
+            cstacked[:, :, i] .= (A_i isa UniformScaling ? Matrix{ComplexF64}(A_i, side, side) : Matrix{ComplexF64}(A_i))
+        end
+        check(ccall((:hyp_cone_create_linmatrixineq_complex, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{ComplexF64}, Cint, Ptr{Ptr{Cvoid}}),
+            CTX[], dim, side, cstacked, use_dual, h), "hyp_cone_create_linmatrixineq_complex")
+        return LinMatrixIneq(h[])
+    end
     stacked = zeros(side, side, dim)                                              # member i at stacked[:, :, i], column-major
     for (i, A_i) in enumerate(As)
         stacked[:, :, i] .= (A_i isa UniformScaling ? Matrix{Float64}(A_i, side, side) : Matrix{Float64}(A_i))
     end
-    h = new_handle()
     check(ccall((:hyp_cone_create_linmatrixineq, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Cint, Ptr{Ptr{Cvoid}}),
         CTX[], dim, side, stacked, use_dual, h), "hyp_cone_create_linmatrixineq")
     return LinMatrixIneq(h[])

@@ -550,6 +550,73 @@ def test_wsosinterppossemideftri_vs_oracle(nvars, halfdeg, R):
 
 
 # ---------------------------------------------------------------------------------------------
+# LinMatrixIneq with complex Hermitian members: the real cone on the embedded members, barrier halved
+# ---------------------------------------------------------------------------------------------
+def _rand_herms_c(side, count, rng):   # test/cone.jl:280-289 (rand_herms, complex members)
+    Ah = rng.standard_normal((side, side)) + 1j * rng.standard_normal((side, side))
+    As = [Ah @ Ah.conj().T + np.eye(side)]
+    for _ in range(count - 1):
+        M = rng.standard_normal((side, side)) + 1j * rng.standard_normal((side, side))
+        As.append(M + M.conj().T)
+    return [0.5 * (A + A.conj().T) for A in As]
+
+
+@pytest.mark.parametrize("side,count", [(2, 2), (3, 2), (4, 2), (3, 3), (4, 3)])
+def test_linmatrixineq_complex_identities(side, count):   # test/cone.jl:423-429, complex Hermitian members
+    import hypatia_jl_amd as H
+    rng = np.random.default_rng(side * 10 + count)
+    run_test_oracles(H.LinMatrixIneq(_rand_herms_c(side, count, rng)), noise=1e-2, init_tol=np.inf)
+
+
+@pytest.mark.parametrize("side,count", [(3, 2), (12, 30), (60, 200)])
+def test_linmatrixineq_complex_vs_oracle(side, count):
+    """every oracle against the complex CPU restatement (oracle/cones_complex.py) at a random interior point; mixed real /
+    complex members as in the reference's linmatrixineq2 instance"""
+    import hypatia_jl_amd as H
+    from oracle import cones_complex as occ
+    rng = np.random.default_rng(side + count)
+    As = _rand_herms_c(side, count, rng)
+    As[-1] = As[-1].real + 0j          # (a real member among complex ones)
+    for A in As[1:]:
+        A *= 1.0 / np.sqrt(side)
+    hc, oc = H.LinMatrixIneq(As), occ.LinMatrixIneqComplex(As)
+    dim = count
+    assert hc.dimension() == oc.dimension() == dim and hc.get_nu() == oc.get_nu() == side
+    pt = np.zeros(dim)
+    oc.set_initial_point(pt)
+    pt2 = np.ones(dim)
+    hc.set_initial_point(pt2)
+    assert np.array_equal(pt, pt2)
+    pt = pt + 0.05 / np.sqrt(dim) * (2 * rng.random(dim) - 1)
+    dual = -pt + 0.01 * rng.random(dim)
+    for c in (hc, oc):
+        c.setup_data()
+        c.reset_data()
+        c.load_point(pt, 0.9)
+        c.load_dual_point(dual)
+        assert c.is_feas()
+        assert c.is_dual_feas()
+    assert rel(np.array(hc.get_grad()), np.array(oc.get_grad())) < 1e-11
+    V = np.asfortranarray(rng.standard_normal((dim, 3)))
+    for name in ("hess_prod", "inv_hess_prod", "hess_prod_slow"):
+        Ph, Po = np.zeros((dim, 3), order="F"), np.zeros((dim, 3), order="F")
+        getattr(hc, name)(Ph, V)
+        getattr(oc, name)(Po, V)
+        assert rel(Ph, Po) < 1e-8, name
+    d3h, d3o = np.array(hc.dder3(V[:, 0].copy() * 0.01)), np.array(oc.dder3(V[:, 0].copy() * 0.01))
+    assert rel(d3h, d3o) < 1e-10
+    ph, po = hc.get_proxsqr(0.9, True), oc.get_proxsqr(0.9, True)
+    assert abs(ph - po) <= 1e-7 * max(1.0, abs(po))
+    for c in (hc, oc):
+        c.use_hess_prod_slow = True
+        c.use_hess_prod_slow_updated = True
+    Ph, Po = np.zeros((dim, 3), order="F"), np.zeros((dim, 3), order="F")
+    hc.hess_prod_slow(Ph, V)
+    oc.hess_prod_slow(Po, V)
+    assert rel(Ph, Po) < 1e-10
+
+
+# ---------------------------------------------------------------------------------------------
 # PosSemidefTri{T, Complex{T}} (SURVEY 8f-3: complex Hermitian variant) through the interleaved real embedding
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("side", [1, 2, 3, 5, 12])

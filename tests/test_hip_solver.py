@@ -45,6 +45,18 @@ def test_known_answer_hip_complex_psd(name, reduce):
     build_solve_check(solver, H.make_model(inst), inst)
 
 
+@pytest.mark.parametrize("name", ["linmatrixineq1_complex_side2", "linmatrixineq1_complex_side4", "linmatrixineq2_complex_cc",
+                                  "linmatrixineq2_complex_rcr", "linmatrixineq2_complex_crr"])
+def test_known_answer_hip_complex_linmatrixineq(name):
+    """the complex members of the reference's linmatrixineq1 / linmatrixineq2 instances (test/nativeinstances.jl:696-745) through
+    the HIP path"""
+    import hypatia_jl_amd as H
+    from oracle import instances as I
+    inst = I.KNOWN_ANSWER_COMPLEX[name]()
+    solver = H.Solver(default_tol_relax=10)
+    build_solve_check(solver, H.make_model(inst), inst)
+
+
 def _trajectory(solver_cls, model, **opts):
     rows = []
     s = solver_cls(**opts)
