@@ -31,6 +31,7 @@ SIGNATURES = {
     "hyp_cone_create_possemideftri": [c_vp, c_int, P(c_vp)],
     "hyp_cone_create_possemideftri_complex": [c_vp, c_int, P(c_vp)],
     "hyp_cone_create_epinormspectral": [c_vp, c_int, c_int, c_int, P(c_vp)],
+    "hyp_cone_create_epinormspectral_complex": [c_vp, c_int, c_int, c_int, P(c_vp)],
     "hyp_cone_create_wsosinterpnonnegative": [c_vp, c_int, c_int, P(c_int), P(c_vp), c_int, P(c_vp)],
     "hyp_cone_create_wsosinterppossemideftri": [c_vp, c_int, c_int, c_int, P(c_int), P(c_vp), c_int, P(c_vp)],
     "hyp_cone_create_linmatrixineq": [c_vp, c_int, c_int, c_vp, c_int, P(c_vp)],
@@ -38,6 +39,8 @@ SIGNATURES = {
     "hyp_cone_create_doublynonnegativetri": [c_vp, c_int, c_int, P(c_vp)],
     "hyp_cone_create_hyporootdettri": [c_vp, c_int, c_int, P(c_vp)],
     "hyp_cone_create_hypoperlogdettri": [c_vp, c_int, c_int, P(c_vp)],
+    "hyp_cone_create_hyporootdettri_complex": [c_vp, c_int, c_int, P(c_vp)],
+    "hyp_cone_create_hypoperlogdettri_complex": [c_vp, c_int, c_int, P(c_vp)],
     "hyp_cone_update_use_hess_prod_slow": [c_vp, P(c_int)],
     "hyp_cone_set_use_hess_prod_slow": [c_vp, c_int],
     "hyp_cone_destroy": [c_vp],

@@ -13,6 +13,8 @@ def make_cone(spec):
         return hc.PosSemidefTriComplex(spec[1])
     if kind == "epinormspectral":
         return hc.EpiNormSpectral(spec[1], spec[2], use_dual=spec[3])
+    if kind == "epinormspectral_complex":
+        return hc.EpiNormSpectralComplex(spec[1], spec[2], use_dual=spec[3])
     if kind == "wsosinterpnonnegative":
         return hc.WSOSInterpNonnegative(spec[1], spec[2], use_dual=spec[3])
     if kind in ("linmatrixineq", "linmatrixineq_complex"):   # (complex Hermitian members are recognised by their dtype)
@@ -23,6 +25,10 @@ def make_cone(spec):
         return hc.HypoRootdetTri(spec[1], use_dual=spec[2])
     if kind == "hypoperlogdettri":
         return hc.HypoPerLogdetTri(spec[1], use_dual=spec[2])
+    if kind == "hyporootdettri_complex":
+        return hc.HypoRootdetTriComplex(spec[1], use_dual=spec[2])
+    if kind == "hypoperlogdettri_complex":
+        return hc.HypoPerLogdetTriComplex(spec[1], use_dual=spec[2])
     if kind == "wsosinterppossemideftri":
         return hc.WSOSInterpPosSemidefTri(spec[1], spec[2], spec[3], use_dual=spec[4])
     raise NotImplementedError("no HIP cone for %r yet (and there is no CPU fallback)" % (kind,))

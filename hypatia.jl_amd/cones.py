@@ -248,6 +248,18 @@ class EpiNormSpectral(_GenericHessMixin, Cone):
         super().__init__(h)
 
 
+class EpiNormSpectralComplex(Cone):
+    """Cones.EpiNormSpectral{Float64, ComplexF64}(d1, d2; use_dual)  (epinormspectral.jl:13-66 with R = Complex{T}): the cone
+    vector is (u, W), W complex d1 x d2 as (re, im) pairs in column-major order; dim = 1 + 2 d1 d2."""
+
+    def __init__(self, d1, d2, use_dual=False):
+        h = c_vp()
+        L.check(L.lib().hyp_cone_create_epinormspectral_complex(L.ctx(), int(d1), int(d2), int(bool(use_dual)), ctypes.byref(h)),
+                "hyp_cone_create_epinormspectral_complex")
+        self.d1, self.d2 = d1, d2
+        super().__init__(h)
+
+
 class WSOSInterpNonnegative(_GenericHessMixin, Cone):
     """Cones.WSOSInterpNonnegative{Float64, Float64}(U, Ps; use_dual)  (wsosinterpnonnegative.jl:16-63)."""
 
@@ -316,6 +328,28 @@ class HypoRootdetTri(_GenericHessMixin, Cone):
         h = c_vp()
         L.check(L.lib().hyp_cone_create_hyporootdettri(L.ctx(), int(dim), int(bool(use_dual)), ctypes.byref(h)),
                 "hyp_cone_create_hyporootdettri")
+        super().__init__(h)
+
+
+class HypoRootdetTriComplex(_GenericHessMixin, Cone):
+    """Cones.HypoRootdetTri{Float64, ComplexF64}(dim; use_dual)  (hyporootdettri.jl:9-59 with R = Complex{T}; dim = 1 + side^2)."""
+
+    def __init__(self, dim, use_dual=False):
+        self._slow = False
+        h = c_vp()
+        L.check(L.lib().hyp_cone_create_hyporootdettri_complex(L.ctx(), int(dim), int(bool(use_dual)), ctypes.byref(h)),
+                "hyp_cone_create_hyporootdettri_complex")
+        super().__init__(h)
+
+
+class HypoPerLogdetTriComplex(_GenericHessMixin, Cone):
+    """Cones.HypoPerLogdetTri{Float64, ComplexF64}(dim; use_dual)  (hypoperlogdettri.jl:9-58 with R = Complex{T}; dim = 2 + side^2)."""
+
+    def __init__(self, dim, use_dual=False):
+        self._slow = False
+        h = c_vp()
+        L.check(L.lib().hyp_cone_create_hypoperlogdettri_complex(L.ctx(), int(dim), int(bool(use_dual)), ctypes.byref(h)),
+                "hyp_cone_create_hypoperlogdettri_complex")
         super().__init__(h)
 
 

@@ -128,6 +128,13 @@ int hyp_cone_create_epinormspectral(hyp_ctx* ctx, int d1, int d2, int use_dual, 
   ctx->c.sync();
   API_END(ctx)
 }
+int hyp_cone_create_epinormspectral_complex(hyp_ctx* ctx, int d1, int d2, int use_dual, hyp_cone** out) {
+  API_BEGIN
+  HYP_CHECK(hipSetDevice(ctx->c.device));
+  *out = new hyp_cone{ctx, new CplxEnsCone(ctx->c, d1, d2, use_dual != 0)};
+  ctx->c.sync();
+  API_END(ctx)
+}
 int hyp_cone_create_wsosinterpnonnegative(hyp_ctx* ctx, int U, int K, const int* Ls, const double* const* Ps, int use_dual, hyp_cone** out) {
   API_BEGIN
   HYP_CHECK(hipSetDevice(ctx->c.device));
@@ -146,6 +153,20 @@ int hyp_cone_create_linmatrixineq_complex(hyp_ctx* ctx, int dim, int side, const
   API_BEGIN
   HYP_CHECK(hipSetDevice(ctx->c.device));
   *out = new hyp_cone{ctx, new LmiCone(ctx->c, dim, side, As, use_dual != 0, true)};
+  ctx->c.sync();
+  API_END(ctx)
+}
+int hyp_cone_create_hyporootdettri_complex(hyp_ctx* ctx, int dim, int use_dual, hyp_cone** out) {
+  API_BEGIN
+  HYP_CHECK(hipSetDevice(ctx->c.device));
+  *out = new hyp_cone{ctx, new CplxHypoCone(ctx->c, CONE_HYPOROOTDET_COMPLEX, dim, false, use_dual != 0)};
+  ctx->c.sync();
+  API_END(ctx)
+}
+int hyp_cone_create_hypoperlogdettri_complex(hyp_ctx* ctx, int dim, int use_dual, hyp_cone** out) {
+  API_BEGIN
+  HYP_CHECK(hipSetDevice(ctx->c.device));
+  *out = new hyp_cone{ctx, new CplxHypoCone(ctx->c, CONE_HYPOPERLOGDET_COMPLEX, dim, true, use_dual != 0)};
   ctx->c.sync();
   API_END(ctx)
 }

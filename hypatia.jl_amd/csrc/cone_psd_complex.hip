@@ -84,16 +84,16 @@ void CplxPsdCone::set_initial_point(double* h) {   // :69-78 (2 i + 1 between di
   }
 }
 
-void CplxPsdCone::embed(const double* cvec, long ldc, double* evec, int ncols) {
+void CplxPsdCone::embed(const double* cvec, long ldc, double* evec, int ncols, long lde) {
   const long npair = (long)side * (side + 1) / 2;
   hipLaunchKernelGGL(cpsd_embed_kernel, dim3((unsigned)((npair + 255) / 256), (unsigned)std::min(ncols, 1024)), dim3(256), 0, ctx.stream, side, ncols, cvec,
-                     ldc, evec, edim);
+                     ldc, evec, lde > 0 ? lde : edim);
   HYP_CHECK(hipGetLastError());
 }
-void CplxPsdCone::extract(const double* evec, double* cvec, long ldc, int ncols) {
+void CplxPsdCone::extract(const double* evec, double* cvec, long ldc, int ncols, long lde) {
   const long npair = (long)side * (side + 1) / 2;
   hipLaunchKernelGGL(cpsd_extract_kernel, dim3((unsigned)((npair + 255) / 256), (unsigned)std::min(ncols, 1024)), dim3(256), 0, ctx.stream, side, ncols, evec,
-                     edim, cvec, ldc);
+                     lde > 0 ? lde : edim, cvec, ldc);
   HYP_CHECK(hipGetLastError());
 }
 

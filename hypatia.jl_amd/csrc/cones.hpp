@@ -14,7 +14,7 @@ bool psd_two_sided_fused_ok(int side);
 void psd_two_sided_fused(Ctx& c, int side, int ncols, const double* R, int rstruct /* 0 full, 1 upper, 2 lower */, const double* arr,
                          long lda, double* prod, long ldp, double* zws /* ncols * side^2 */);
 
-enum ConeKind { CONE_NONNEG = 0, CONE_PSD = 1, CONE_EPINORMSPECTRAL = 2, CONE_WSOS = 3, CONE_LMI = 4, CONE_DNN = 5, CONE_HYPOROOTDET = 6, CONE_HYPOPERLOGDET = 7, CONE_WSOSPSD = 8, CONE_PSD_COMPLEX = 9 };
+enum ConeKind { CONE_NONNEG = 0, CONE_PSD = 1, CONE_EPINORMSPECTRAL = 2, CONE_WSOS = 3, CONE_LMI = 4, CONE_DNN = 5, CONE_HYPOROOTDET = 6, CONE_HYPOPERLOGDET = 7, CONE_WSOSPSD = 8, CONE_PSD_COMPLEX = 9, CONE_EPINORMSPECTRAL_COMPLEX = 10, CONE_HYPOROOTDET_COMPLEX = 11, CONE_HYPOPERLOGDET_COMPLEX = 12 };
 
 struct Cone {
   Ctx& ctx;
@@ -175,8 +175,8 @@ struct CplxPsdCone : Cone {
   void sqrt_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;
   void inv_sqrt_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;
   const double* dder3(const double* d_dir) override;
-  void embed(const double* cvec, long ldc, double* evec, int ncols);     // E: complex svec columns -> embedded real svec columns
-  void extract(const double* evec, double* cvec, long ldc, int ncols);   // the projection back (mean of the two copies)
+  void embed(const double* cvec, long ldc, double* evec, int ncols, long lde = 0);     // E: complex svec columns -> embedded real svec columns (stride lde, default edim)
+  void extract(const double* evec, double* cvec, long ldc, int ncols, long lde = 0);   // the projection back (mean of the two copies)
   template <class F> void through(F f, double* prod, long ldp, const double* arr, long lda, int ncols);
 };
 
@@ -353,6 +353,67 @@ struct EpiNormSpectralCone : GenericHessCone {   // src/Cones/epinormspectral.jl
   bool update_svd();
   void inv_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;
   bool inv_hess_ready() override;
+};
+
+// HypoRootdetTri / HypoPerLogdetTri with a complex Hermitian matrix part (cone_hypo_complex.hip): with phi the real embedding
+// of twice the side, logdet(phi(W)) = 2 logdet(W), so the complex barrier is the real cone's on the embedded point (leading
+// scalars rescaled) MINUS the complex PosSemidefTri barrier -logdet(W), which the real one counts twice.
+void central_ray_hypoperlog(int d, double* uvw);   // cones_generic.hip (hypoperlogdettri.jl:80-95)
+struct CplxHypoCone : GenericHessCone {
+  int d, nlead;              // complex side; leading scalars: 1 (u) for the root-determinant, 2 (u, v) for the perspective of logdet
+  double lead_scale[2];      // primal map of the leading scalars into the real cone
+  double dual_scale[2];      // and of the dual point's
+  long cdw, edw, edim;       // d^2, d (2 d + 1), nlead + edw
+  Cone* inner;               // real cone of side 2 d (owned)
+  CplxPsdCone psdc;          // -logdet(W) in complex svec coordinates
+  DBuf ea, eb, pw;
+  CplxHypoCone(Ctx& c, int kind, int dim, bool perlog, bool use_dual);
+  ~CplxHypoCone() override { delete inner; }
+  void reset_data() override {
+    GenericHessCone::reset_data();
+    inner->reset_data();
+    psdc.reset_data();
+  }
+  bool update_feas() override;
+  bool is_dual_feas() override;
+  void update_grad() override;
+  void update_hess() override;
+  void set_initial_point(double* h_out) override;
+  void hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;
+  const double* dder3(const double* d_dir) override;
+  void to_inner(const double* cvec, long ldc, double* evec, int ncols, const double* scale);      // T
+  void from_inner(const double* evec, double* cvec, long ldc, int ncols);                          // T'
+};
+
+// EpiNormSpectral{Float64, ComplexF64}: the real cone of twice the sides on the embedded matrix, barrier halved, plus the
+// univariate term the halving leaves over (cone_ens_complex.hip).
+struct CplxEnsCone : Cone {
+  int d1, d2;          // complex sides
+  long edim;           // 1 + 4 d1 d2: dimension of the embedded real cone
+  EpiNormSpectralCone inner;
+  DBuf ea, eb, xw, ainv;   // embedded workspaces; A^-1 columns in complex coordinates; a = A^-1 e_u
+  bool ainv_ready = false;
+  CplxEnsCone(Ctx& c, int d1, int d2, bool use_dual);
+  void reset_data() override {
+    Cone::reset_data();
+    inner.reset_data();
+    ainv_ready = false;
+  }
+  bool update_feas() override;
+  bool is_dual_feas() override;
+  void update_grad() override;
+  void set_initial_point(double* h_out) override;
+  void hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;
+  void inv_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;
+  bool use_sqrt_hess_oracles(int) override { return false; }   // (no factored Hessian: the assembly takes the hess_prod! branch, qrchol.jl:240-246)
+  void sqrt_hess_prod(double*, long, const double*, long, int) override { HYP_REQUIRE(false, "EpiNormSpectral (complex): no square-root oracle"); }
+  void inv_sqrt_hess_prod(double*, long, const double*, long, int) override { HYP_REQUIRE(false, "EpiNormSpectral (complex): no square-root oracle"); }
+  const double* dder3(const double* d_dir) override;
+  bool inv_hess_ready() override { return inner.inv_hess_ready(); }
+  void embed(const double* cvec, long ldc, double* evec, int ncols, double uscale);
+  void extract(const double* evec, double* cvec, long ldc, int ncols, double uscale);
+  void apply_ainv(double* xc, long ldx, const double* arr, long lda, int ncols);
+  void dev_axpby_scalar0(double v);
 };
 
 }  // namespace hyp

@@ -828,7 +828,7 @@ HypoPerLogdetTriCone::HypoPerLogdetTriCone(Ctx& c, int dim_, bool use_dual)
 }
 
 // hypoperlog.jl:289-319: central ray of the hypograph-of-perspective-of-sum-log cone (looked up for d <= 10, fitted beyond)
-static void central_ray_hypoperlog(int d, double* uvw) {
+void central_ray_hypoperlog(int d, double* uvw) {
   static const double tab[10][3] = {
       {-0.827838387, 0.805102007, 1.290927686}, {-0.689607388, 0.724605082, 1.224617936}, {-0.584372665, 0.68128058, 1.182421942},
       {-0.503499342, 0.65448622, 1.153053152},  {-0.440285893, 0.636444224, 1.131466926}, {-0.389979809, 0.623569352, 1.114979519},

@@ -45,6 +45,9 @@ int hyp_cone_create_possemideftri(hyp_ctx* ctx, int dim, hyp_cone** out);
 int hyp_cone_create_possemideftri_complex(hyp_ctx* ctx, int dim, hyp_cone** out);
 /* Cones.EpiNormSpectral{Float64,Float64}(d1, d2; use_dual) (epinormspectral.jl:53-66): dim = 1 + d1*d2 */
 int hyp_cone_create_epinormspectral(hyp_ctx* ctx, int d1, int d2, int use_dual, hyp_cone** out);
+/* Cones.EpiNormSpectral{Float64, ComplexF64}(d1, d2; use_dual): W complex d1 x d2, the cone vector is (u, W) with W as (re, im)
+ * pairs in column-major order (vec_copyto!, arrayutilities.jl:30-60): dim = 1 + 2 d1 d2, nu = d1 + 1 */
+int hyp_cone_create_epinormspectral_complex(hyp_ctx* ctx, int d1, int d2, int use_dual, hyp_cone** out);
 /* Cones.WSOSInterpNonnegative{Float64,Float64}(U, Ps; use_dual) (wsosinterpnonnegative.jl:49-63):
  * Ps[k] is U x Ls[k], column-major; the matrices are copied to the device */
 int hyp_cone_create_wsosinterpnonnegative(hyp_ctx* ctx, int U, int K, const int* Ls, const double* const* Ps, int use_dual, hyp_cone** out);
@@ -65,6 +68,11 @@ int hyp_cone_create_hyporootdettri(hyp_ctx* ctx, int dim, int use_dual, hyp_cone
 /* Cones.HypoPerLogdetTri{Float64, Float64}(dim; use_dual) (hypoperlogdettri.jl:43-58): (u, v, svec(W)),
  * dim = 2 + side (side + 1) / 2; nu = 2 + side */
 int hyp_cone_create_hypoperlogdettri(hyp_ctx* ctx, int dim, int use_dual, hyp_cone** out);
+/* The same two cones over complex Hermitian matrices, Cones.HypoRootdetTri{Float64, ComplexF64}(dim) and
+ * Cones.HypoPerLogdetTri{Float64, ComplexF64}(dim): the matrix part is the complex svec (side^2 reals), dim = 1 + side^2 resp.
+ * 2 + side^2; nu = 1 + side resp. 2 + side */
+int hyp_cone_create_hyporootdettri_complex(hyp_ctx* ctx, int dim, int use_dual, hyp_cone** out);
+int hyp_cone_create_hypoperlogdettri_complex(hyp_ctx* ctx, int dim, int use_dual, hyp_cone** out);
 /* Cones.WSOSInterpPosSemidefTri{Float64}(R, U, Ps; use_dual) (wsosinterppossemideftri.jl:46-69): R x R symmetric matrices of
  * polynomials given by U interpolant values each (svec order by blocks of length U), dim = U R (R + 1) / 2; Ps[k] is U x Ls[k],
  * column-major, copied to the device; nu = R sum_k Ls[k] */

@@ -102,11 +102,14 @@ end
 @hipcone PosSemidefTri              # Cones.PosSemidefTri{Float64, Float64}            possemideftri.jl:9-46
 @hipcone PosSemidefTriComplex       # Cones.PosSemidefTri{Float64, ComplexF64}         possemideftri.jl:9-46 (dim = side^2)
 @hipcone EpiNormSpectral            # Cones.EpiNormSpectral{Float64, Float64}          epinormspectral.jl:13-66
+@hipcone EpiNormSpectralComplex     # Cones.EpiNormSpectral{Float64, ComplexF64}       epinormspectral.jl:13-66 (dim = 1 + 2 d1 d2)
 @hipcone WSOSInterpNonnegative      # Cones.WSOSInterpNonnegative{Float64, Float64}    wsosinterpnonnegative.jl:16-63
 @hipcone LinMatrixIneq              # Cones.LinMatrixIneq{Float64} (dense real symmetric or complex Hermitian members) linmatrixineq.jl:9-65
 @hipcone DoublyNonnegativeTri       # Cones.DoublyNonnegativeTri{Float64}              doublynonnegativetri.jl:9-52
 @hipcone HypoRootdetTri             # Cones.HypoRootdetTri{Float64, Float64}           hyporootdettri.jl:9-59
 @hipcone HypoPerLogdetTri           # Cones.HypoPerLogdetTri{Float64, Float64}         hypoperlogdettri.jl:9-58
+@hipcone HypoRootdetTriComplex      # Cones.HypoRootdetTri{Float64, ComplexF64}        hyporootdettri.jl:9-59 (dim = 1 + side^2)
+@hipcone HypoPerLogdetTriComplex    # Cones.HypoPerLogdetTri{Float64, ComplexF64}      hypoperlogdettri.jl:9-58 (dim = 2 + side^2)
 @hipcone WSOSInterpPosSemidefTri    # Cones.WSOSInterpPosSemidefTri{Float64}           wsosinterppossemideftri.jl:9-69
 
 is_nonnegative(::Nonnegative) = true
@@ -138,6 +141,14 @@ function EpiNormSpectral(d1::Int, d2::Int; use_dual::Bool = false)
     check(ccall((:hyp_cone_create_epinormspectral, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Ptr{Cvoid}}),
         CTX[], d1, d2, use_dual, h), "hyp_cone_create_epinormspectral")
     return EpiNormSpectral(h[])
+end
+
+function EpiNormSpectralComplex(d1::Int, d2::Int; use_dual::Bool = false)
+    @assert 1 <= d1 <= d2                                                         # epinormspectral.jl:58
+    h = new_handle()
+    check(ccall((:hyp_cone_create_epinormspectral_complex, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Ptr{Cvoid}}),
+        CTX[], d1, d2, use_dual, h), "hyp_cone_create_epinormspectral_complex")
+    return EpiNormSpectralComplex(h[])
 end
 
 # Ps[k] is U x L_k, column-major: passed as an array of K pointers
@@ -210,7 +221,9 @@ end
 
 for (T, sym) in ((:DoublyNonnegativeTri, :hyp_cone_create_doublynonnegativetri),
                  (:HypoRootdetTri, :hyp_cone_create_hyporootdettri),
-                 (:HypoPerLogdetTri, :hyp_cone_create_hypoperlogdettri))
+                 (:HypoPerLogdetTri, :hyp_cone_create_hypoperlogdettri),
+                 (:HypoRootdetTriComplex, :hyp_cone_create_hyporootdettri_complex),
+                 (:HypoPerLogdetTriComplex, :hyp_cone_create_hypoperlogdettri_complex))
     @eval function $T(dim::Int; use_dual::Bool = false)
         h = new_handle()
         check(ccall(($(QuoteNode(sym)), lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Ptr{Cvoid}}), CTX[], dim, use_dual, h), $(string(sym)))

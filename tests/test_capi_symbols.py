@@ -113,7 +113,7 @@ def _header_prototypes():
 def test_julia_binding_matches_the_header():
     """julia/HypatiaHIP.jl (the reference-side binding; Julia is not installed here, so it cannot be run): every ccall names a
     declared symbol and passes as many arguments as the prototype has, the argument-type tuple and the argument list agree
-    in length, and all nine cones and both system solvers of the boundary are bound."""
+    in length, and all cone constructors and both system solvers of the boundary are bound."""
     src = open(os.path.join(ROOT, "julia", "HypatiaHIP.jl")).read()
     src = re.sub(r"#.*", "", src)
     protos = _header_prototypes()
@@ -152,12 +152,14 @@ def test_julia_binding_matches_the_header():
             seen.add(name)
     # the @eval-generated families
     for name in ("hyp_cone_hess_prod", "hyp_cone_inv_hess_prod", "hyp_cone_sqrt_hess_prod", "hyp_cone_inv_sqrt_hess_prod", "hyp_cone_hess_prod_slow",
-                 "hyp_cone_create_doublynonnegativetri", "hyp_cone_create_hyporootdettri", "hyp_cone_create_hypoperlogdettri"):
+                 "hyp_cone_create_doublynonnegativetri", "hyp_cone_create_hyporootdettri", "hyp_cone_create_hypoperlogdettri",
+                 "hyp_cone_create_hyporootdettri_complex", "hyp_cone_create_hypoperlogdettri_complex"):
         assert ":" + name in src and name in protos
         seen.add(name)
     must = {"hyp_cone_create_nonnegative", "hyp_cone_create_possemideftri", "hyp_cone_create_epinormspectral", "hyp_cone_create_wsosinterpnonnegative",
             "hyp_cone_create_linmatrixineq", "hyp_cone_create_doublynonnegativetri", "hyp_cone_create_hyporootdettri", "hyp_cone_create_hypoperlogdettri",
-            "hyp_cone_create_wsosinterppossemideftri", "hyp_cone_use_dual_barrier", "hyp_cone_get_nu", "hyp_cone_dimension", "hyp_sys_create",
+            "hyp_cone_create_wsosinterppossemideftri", "hyp_cone_create_possemideftri_complex", "hyp_cone_create_epinormspectral_complex",
+            "hyp_cone_create_linmatrixineq_complex", "hyp_cone_create_hyporootdettri_complex", "hyp_cone_create_hypoperlogdettri_complex", "hyp_cone_use_dual_barrier", "hyp_cone_get_nu", "hyp_cone_dimension", "hyp_sys_create",
             "hyp_sys_load", "hyp_sys_update_lhs_fact", "hyp_sys_solve3", "hyp_sys_block_hess_prod", "hyp_symindef_create", "hyp_symindef_load",
             "hyp_symindef_update_lhs", "hyp_symindef_solve3", "hyp_cone_update_use_hess_prod_slow", "hyp_cone_set_use_hess_prod_slow"}
     assert must <= seen, sorted(must - seen)

@@ -550,6 +550,136 @@ def test_wsosinterppossemideftri_vs_oracle(nvars, halfdeg, R):
 
 
 # ---------------------------------------------------------------------------------------------
+# HypoRootdetTri / HypoPerLogdetTri over complex Hermitian matrices: the real cone on the embedded point minus the
+# complex PosSemidefTri barrier it counts twice
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("side", [1, 2, 4])
+def test_hyporootdettri_complex_identities(side):   # test/cone.jl:606-610, complex members
+    import hypatia_jl_amd as H
+    run_test_oracles(H.HypoRootdetTriComplex(1 + side * side), tol=1e5 * np.finfo(float).eps)
+
+
+@pytest.mark.parametrize("side", [1, 2, 4])
+def test_hypoperlogdettri_complex_identities(side):   # test/cone.jl:648-655, complex members
+    import hypatia_jl_amd as H
+    run_test_oracles(H.HypoPerLogdetTriComplex(2 + side * side), init_tol=1e-4, tol=1e5 * np.finfo(float).eps)
+
+
+@pytest.mark.parametrize("kind,side,use_dual", [("root", 1, False), ("root", 3, False), ("root", 6, True), ("root", 17, False),
+                                                ("perlog", 1, False), ("perlog", 3, True), ("perlog", 6, False), ("perlog", 17, False)])
+def test_complex_hypograph_cones_vs_oracle(kind, side, use_dual):
+    """every oracle against the complex CPU restatement (oracle/cones_complex.py) at a random interior point"""
+    import hypatia_jl_amd as H
+    from oracle import cones_complex as occ
+    nlead = 1 if kind == "root" else 2
+    dim = nlead + side * side
+    if kind == "root":
+        hc, oc = H.HypoRootdetTriComplex(dim, use_dual=use_dual), occ.HypoRootdetTriComplex(dim, use_dual=use_dual)
+    else:
+        hc, oc = H.HypoPerLogdetTriComplex(dim, use_dual=use_dual), occ.HypoPerLogdetTriComplex(dim, use_dual=use_dual)
+    assert hc.get_nu() == oc.get_nu() == nlead + side and bool(hc.use_dual_barrier()) == bool(oc.use_dual_barrier()) == use_dual
+    rng = np.random.default_rng(10 * side + nlead)
+    pt, pt2 = np.zeros(dim), np.ones(dim)
+    oc.set_initial_point(pt)
+    hc.set_initial_point(pt2)
+    assert np.allclose(pt, pt2, rtol=1e-15, atol=0)
+    for c in (hc, oc):
+        c.setup_data()
+        c.reset_data()
+        c.load_point(pt, 1.0)
+        assert c.is_feas()
+    dual = -np.array(oc.get_grad())
+    pt = pt + 0.05 / side * (2 * rng.random(dim) - 1)
+    dual = dual + 0.02 / side * (2 * rng.random(dim) - 1)
+    for c in (hc, oc):
+        c.reset_data()
+        c.load_point(pt, 0.9)
+        c.load_dual_point(dual)
+        assert c.is_feas() and c.is_dual_feas()
+    assert rel(np.array(hc.get_grad()), np.array(oc.get_grad())) < 1e-10
+    for ncols in (1, 5):
+        V = np.asfortranarray(rng.standard_normal((dim, ncols)))
+        for name in ("hess_prod", "inv_hess_prod"):
+            Ph, Po = np.zeros((dim, ncols), order="F"), np.zeros((dim, ncols), order="F")
+            getattr(hc, name)(Ph, V)
+            getattr(oc, name)(Po, V)
+            assert rel(Ph, Po) < 1e-8, (name, ncols)
+    T, R = np.zeros((dim, 3), order="F"), np.zeros((dim, 3), order="F")
+    V = np.asfortranarray(rng.standard_normal((dim, 3)))
+    hc.hess_prod(T, V)
+    hc.inv_hess_prod(R, T)
+    assert rel(R, V) < 1e-8
+    dv = V[:, 0].copy() * 0.05
+    assert rel(np.array(hc.dder3(dv)), np.array(oc.dder3(dv))) < 1e-9
+    ph, po = hc.get_proxsqr(0.9, True), oc.get_proxsqr(0.9, True)
+    assert abs(ph - po) <= 1e-7 * max(1.0, abs(po))
+    # a dual point outside the dual cone
+    bad = dual.copy()
+    bad[0] = abs(bad[0]) + 1.0
+    hc.load_dual_point(bad)
+    oc.load_dual_point(bad)
+    assert hc.is_dual_feas() == oc.is_dual_feas() == False
+
+
+# ---------------------------------------------------------------------------------------------
+# EpiNormSpectral{T, Complex{T}} (SURVEY 8f-3): the real cone of twice the sides on the embedded matrix, barrier halved, and the
+# univariate term the halving leaves over
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d1,d2", [(1, 1), (1, 2), (2, 2), (2, 4), (3, 4)])
+def test_epinormspectral_complex_identities(d1, d2):   # test/cone.jl:305-315 (R = Complex)
+    import hypatia_jl_amd as H
+    run_test_oracles(H.EpiNormSpectralComplex(d1, d2), tol=1e5 * np.finfo(float).eps)
+
+
+@pytest.mark.parametrize("d1,d2,use_dual", [(1, 1, False), (2, 3, False), (4, 7, True), (12, 20, False)])
+def test_epinormspectral_complex_vs_oracle(d1, d2, use_dual):
+    """every oracle against the complex CPU restatement (oracle/cones_complex.py) at a random interior point"""
+    import hypatia_jl_amd as H
+    from oracle import cones_complex as occ
+    rng = np.random.default_rng(100 * d1 + d2)
+    hc, oc = H.EpiNormSpectralComplex(d1, d2, use_dual=use_dual), occ.EpiNormSpectralComplex(d1, d2, use_dual=use_dual)
+    dim = 1 + 2 * d1 * d2
+    assert hc.dimension() == oc.dimension() == dim and hc.get_nu() == oc.get_nu() == d1 + 1
+    assert bool(hc.use_dual_barrier()) == bool(oc.use_dual_barrier()) == use_dual
+    pt0, pt1 = np.zeros(dim), np.ones(dim)
+    oc.set_initial_point(pt0)
+    hc.set_initial_point(pt1)
+    assert np.array_equal(pt0, pt1)
+    W = (rng.standard_normal((d1, d2)) + 1j * rng.standard_normal((d1, d2))) / np.sqrt(d2)
+    pt = np.zeros(dim)
+    pt[0] = np.linalg.svd(W, compute_uv=False)[0] * 1.3 + 0.1
+    occ.cvec_to_rvec(pt[1:], W)
+    Wd = (rng.standard_normal((d1, d2)) + 1j * rng.standard_normal((d1, d2))) / np.sqrt(d2)
+    dual = np.zeros(dim)
+    dual[0] = np.linalg.svd(Wd, compute_uv=False).sum() * 1.2 + 0.1
+    occ.cvec_to_rvec(dual[1:], Wd)
+    for c in (hc, oc):
+        c.setup_data()
+        c.reset_data()
+        c.load_point(pt, 1.0)
+        c.load_dual_point(dual)
+        assert c.is_feas()
+        assert c.is_dual_feas()
+    assert rel(np.array(hc.get_grad()), np.array(oc.get_grad())) < 1e-11
+    V = np.asfortranarray(rng.standard_normal((dim, 3)))
+    for name in ("hess_prod", "inv_hess_prod"):
+        Ph, Po = np.zeros((dim, 3), order="F"), np.zeros((dim, 3), order="F")
+        getattr(hc, name)(Ph, V)
+        getattr(oc, name)(Po, V)
+        assert rel(Ph, Po) < 1e-8, name
+    d3h, d3o = np.array(hc.dder3(V[:, 0].copy() * 0.01)), np.array(oc.dder3(V[:, 0].copy() * 0.01))
+    assert rel(d3h, d3o) < 1e-9
+    ph, po = hc.get_proxsqr(0.9, True), oc.get_proxsqr(0.9, True)
+    assert abs(ph - po) <= 1e-7 * max(1.0, abs(po))
+    # the dual cone's boundary: u against the nuclear norm
+    for margin, expect in ((1e-6, True), (-1e-6, False)):
+        d2v = dual.copy()
+        d2v[0] = np.linalg.svd(Wd, compute_uv=False).sum() * (1 + margin)
+        hc.load_dual_point(d2v)
+        assert hc.is_dual_feas() == expect
+
+
+# ---------------------------------------------------------------------------------------------
 # LinMatrixIneq with complex Hermitian members (SURVEY 8f-3): the real cone on the embedded members, barrier halved
 # ---------------------------------------------------------------------------------------------
 def _rand_herms_c(side, count, rng):   # test/cone.jl:280-289 (rand_herms, complex members)

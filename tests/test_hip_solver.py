@@ -57,6 +57,34 @@ def test_known_answer_hip_complex_linmatrixineq(name):
     build_solve_check(solver, H.make_model(inst), inst)
 
 
+def _complex_ens_names():
+    from oracle import instances as I
+    return sorted(k for k in I.KNOWN_ANSWER_COMPLEX if k.startswith("epinormspectral"))
+
+
+@pytest.mark.parametrize("name", _complex_ens_names())
+def test_known_answer_hip_complex_epinormspectral(name):
+    """the complex members of the reference's epinormspectral1 / 2 / 3 instances (test/nativeinstances.jl:1038-1125) through the
+    HIP path"""
+    import hypatia_jl_amd as H
+    from oracle import instances as I
+    inst = I.KNOWN_ANSWER_COMPLEX[name]()
+    solver = H.Solver(default_tol_relax=10)
+    build_solve_check(solver, H.make_model(inst), inst)
+
+
+@pytest.mark.parametrize("name", ["hyporootdettri1_complex", "hyporootdettri2_complex", "hypoperlogdettri1_complex", "hypoperlogdettri2_complex",
+                                  "hypoperlogdettri3_complex"])
+def test_known_answer_hip_complex_hypograph_cones(name):
+    """the complex members of the reference's hyporootdettri1 / 2 and hypoperlogdettri1 / 2 / 3 instances
+    (test/nativeinstances.jl:1569-1760) through the HIP path"""
+    import hypatia_jl_amd as H
+    from oracle import instances as I
+    inst = I.KNOWN_ANSWER_COMPLEX[name]()
+    solver = H.Solver(default_tol_relax=10)
+    build_solve_check(solver, H.make_model(inst), inst)
+
+
 def _trajectory(solver_cls, model, **opts):
     rows = []
     s = solver_cls(**opts)
