@@ -23,7 +23,7 @@ def make_cone(spec):
         return oc.HypoPerLogdetTri(spec[1], use_dual=spec[2])
     if kind == "wsosinterppossemideftri":
         return oc.WSOSInterpPosSemidefTri(spec[1], spec[2], spec[3], use_dual=spec[4])
-    if kind == "possemideftri_complex":   # oracle-only so far
+    if kind == "possemideftri_complex":   # the complex Hermitian variants
         from .cones_complex import PosSemidefTriComplex
         return PosSemidefTriComplex(spec[1])
     if kind == "epinormspectral_complex":
