@@ -553,6 +553,8 @@ def main_other(args):
         "kkt_solves_per_step": solves / iters, "ms_per_kkt_solve": phases["getdir"] / max(solves, 1) * 1e3,
         "search_trials_per_step": trials / iters, "setup_s": t_setup,
     }
+    if hasattr(lib, "report"):   # HYP_PROFILE=1: wall time per C-ABI entry point
+        print(lib.report(), file=sys.stderr)
     emit_json_line(out)
 
 

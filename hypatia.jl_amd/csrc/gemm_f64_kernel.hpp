@@ -382,6 +382,15 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch*
     static const int s_env = [] { const char* e = getenv("HYP_SYRK_S"); return e ? atoi(e) : 0; }();
     if (s_env > 0 && a.K / s_env >= 512) a.splitk = s_env;
   }
+  // Gram-type products with a small result and a long K (the WSOS cone's L x L x U products of every feasibility check and
+  // third-order term: 495 x 495 x 4845 is 36 upper tiles, 303 K steps each -- 1.5 ms of latency on 36 CUs): split K so that
+  // about two workgroups per CU exist
+  static const bool auto_split = [] { const char* e = getenv("HYP_GEMM_AUTOSPLIT"); return !(e && atoi(e) == 0); }();
+  if (auto_split && gs && a.splitk_req <= 1 && a.tag != 1 && a.batch == 1 && a.epi == 0 && a.krange == KR_ALL && a.cm_blk == 0 && a.K >= 2048 &&
+      nblk < 128) {
+    const int S = (int)std::min<long>(std::min<long>(16, 512 / nblk), a.K / 256);
+    if (S > 1) a.splitk_req = S;
+  }
   if (gs && a.splitk_req > 1 && a.batch == 1 && a.epi == 0 && a.krange == KR_ALL && a.cm_blk == 0 && a.K / a.splitk_req >= 256) a.splitk = a.splitk_req;
   a.splitk_base = a.splitk; a.tail_q = 1; a.tail_first = 0; a.tail_chunk = 0;
   if (a.splitk > 1) {

@@ -1,9 +1,5 @@
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -q -x > gpurun_out/r02_pytest_full5.log 2>&1; tail -4 gpurun_out/r02_pytest_full5.log
-python bench.py > gpurun_out/r02_bench_cfg2_1gpu.json 2> gpurun_out/r02_bench_cfg2_1gpu.err
-python - <<'PY'
-import json
-d=json.loads(open("gpurun_out/r02_bench_cfg2_1gpu.json").read().strip().splitlines()[-1])
-print(d["ms_per_step"], d["value"], d["phases_ms_per_step"], d["roofline"]["frac"], d["roofline"]["launch_ms"])
-PY
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+python -m pytest tests -m gpu -q -x > gpurun_out/r02_pytest_full6.log 2>&1; tail -4 gpurun_out/r02_pytest_full6.log
+rm -f gpurun_out/r02_other_configs.jsonl
+for c in 3b 5p 5d; do python bench.py --config $c 2>/dev/null | tail -1 >> gpurun_out/r02_other_configs.jsonl; done
+cut -c1-60 gpurun_out/r02_other_configs.jsonl
