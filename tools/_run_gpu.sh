@@ -1,5 +1,5 @@
+# Scratch script for one gpurun call (`gpurun --timeout N -- 'bash tools/_run_gpu.sh'`): whatever is measured goes under
+# gpurun_out/, summaries worth keeping are copied to profiles/.  The round's standard batch:
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -q -x > gpurun_out/r02_pytest_full6.log 2>&1; tail -4 gpurun_out/r02_pytest_full6.log
-rm -f gpurun_out/r02_other_configs.jsonl
-for c in 3b 5p 5d; do python bench.py --config $c 2>/dev/null | tail -1 >> gpurun_out/r02_other_configs.jsonl; done
-cut -c1-60 gpurun_out/r02_other_configs.jsonl
+python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
+python bench.py > gpurun_out/bench_cfg2_1gpu.json 2> gpurun_out/bench_cfg2_1gpu.err; tail -c 400 gpurun_out/bench_cfg2_1gpu.json
