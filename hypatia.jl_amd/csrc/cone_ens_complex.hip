@@ -63,6 +63,11 @@ __global__ void cens_add0_kernel(int ncols, double* __restrict__ out, long ldo, 
   out[(long)j * ldo] += c1 * s + c2 * s * s;
 }
 
+// p[0] = v (add = 0) or p[0] += v: scalars travel as kernel arguments, not through an asynchronous copy from the host stack
+__global__ void cens_scalar0_kernel(double* __restrict__ p, double v, int add) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = add ? p[0] + v : v;
+}
+
 // out[:, j] = x[:, j] - a * x[0, j] / (twou2 + a[0])
 __global__ void cens_sm_kernel(int dim, int ncols, const double* __restrict__ x, long ldx, const double* __restrict__ a, double twou2,
                                double* __restrict__ out, long ldo) {
@@ -128,8 +133,7 @@ void CplxEnsCone::update_grad() {   // :134-150
 
 // grad[0] += v (one element; through the stream)
 void CplxEnsCone::dev_axpby_scalar0(double v) {
-  ctx.h2d(ctx.dscal.d() + 40, &v, sizeof(double));
-  hipLaunchKernelGGL(cens_add0_kernel, dim3(1), dim3(64), 0, ctx.stream, 1, grad.d(), (long)dim, ctx.dscal.d() + 40, 1L, 1.0, 0.0);
+  hipLaunchKernelGGL(cens_scalar0_kernel, dim3(1), dim3(64), 0, ctx.stream, grad.d(), v, 1);
   HYP_CHECK(hipGetLastError());
 }
 
@@ -170,8 +174,8 @@ void CplxEnsCone::inv_hess_prod(double* prod, long ldp, const double* arr, long 
   if (!ainv_ready) {   // a = A^-1 e_u
     xw.ensure((size_t)dim * sizeof(double));
     ctx.zero(xw.p, (size_t)dim * sizeof(double));
-    const double one = 1.0;
-    ctx.h2d(xw.p, &one, sizeof(double));
+    hipLaunchKernelGGL(cens_scalar0_kernel, dim3(1), dim3(64), 0, ctx.stream, xw.d(), 1.0, 0);
+    HYP_CHECK(hipGetLastError());
     apply_ainv(ainv.d(), dim, xw.d(), dim, 1);
     ainv_ready = true;
   }
