@@ -354,7 +354,7 @@ void PsdCone::two_sided(const double* R, int kr2, int kr3, double* prod, long ld
 
 bool PsdCone::use_fused(int ncols) const {
   static const bool enabled = [] { const char* e = getenv("HYP_PSD_FUSED"); return !(e && e[0] == '0'); }();
-  static const int min_cols = [] { const char* e = getenv("HYP_PSD_FUSED_MIN"); return e ? atoi(e) : 4; }();
+  static const int min_cols = [] { const char* e = getenv("HYP_PSD_FUSED_MIN"); return e ? atoi(e) : 1; }();   // (1: also the one- and two-column products of the KKT solves -- two launches instead of unpack + four GEMMs + pack; config 2: directions 4.14 -> 3.49 ms)
   return enabled && ncols >= min_cols && psd_two_sided_fused_ok(side);
 }
 
