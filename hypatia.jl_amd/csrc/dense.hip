@@ -897,7 +897,8 @@ Ctx::Ctx(int dev) : device(dev) {
   HYP_CHECK(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, plo));
   if (const char* e = getenv("HYP_TRSV_SB")) trsv_sb = (atoi(e) / NB) * NB;
   scratch.alloc(1 << 20);
-  dscal.alloc(64 * sizeof(double));
+  dscal.alloc(128 * sizeof(double));   // 64 scalar slots; [64, 96) partial maxima and [96] the ticket of dev_sub_absmax
+  HYP_CHECK(hipMemset(dscal.p, 0, 128 * sizeof(double)));
   for (int i = 0; i < 6; ++i) HYP_CHECK(hipEventCreate(&ev[i]));
   host_allocator_keep_pages();
   HYP_CHECK(hipHostMalloc((void**)&h_info, 8192 * sizeof(int), hipHostMallocDefault));   // [0..63] general; [64 + 2 k, 64 + 2 k + 1] cone k of a batched feasibility sweep

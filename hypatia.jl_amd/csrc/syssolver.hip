@@ -531,50 +531,51 @@ void SysSolver::solve3(double* d_sol, const double* d_rhs) {   // qrchol.jl:39-8
 // =============================================================================================
 // device-resident get_directions (systemsolvers/common.jl:15-182)
 // =============================================================================================
-// out[0] = max_i |a_i - b_i| over n entries; a <- a - b in place
-__global__ __launch_bounds__(1024) void sub_absmax_kernel(int n, double* __restrict__ a, const double* __restrict__ b,
-                                                          double* __restrict__ out) {
-  __shared__ double red[16];
+// out[0] = max_i |a_i - b_i| over n entries (NaN if any entry is NaN); a <- a - b in place.  SA_WGS workgroups; the last one to
+// finish (a ticket in device memory, reset for the next call) folds the partial maxima -- one launch; with a single workgroup
+// the ~45 dependent trips per thread took 26 us at config 2, four times per iteration.
+constexpr int SA_WGS = 32;
+__device__ __forceinline__ double nanmax(double m, double o) { return (m != m || o != o) ? __builtin_nan("") : fmax(m, o); }
+__global__ __launch_bounds__(256) void sub_absmax_kernel(int n, double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out,
+                                                         double* __restrict__ part, unsigned* __restrict__ ticket) {
+  __shared__ double red[4];
+  __shared__ bool last;
   double m = 0.0;
   bool bad = false;
-  // (eight independent load pairs in flight per thread: one at a time the ~45 trips of a thread are 45 dependent round trips,
-  //  26 us for the (n + p + 2 q) entries of config 2)
-  for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 1024) {
-    double va[8], vb[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = min(i0 + 1024 * u, n - 1);
-      va[u] = a[i];
-      vb[u] = b[i];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = i0 + 1024 * u;
-      if (i < n) {
-        const double v = va[u] - vb[u];
-        a[i] = v;
-        bad |= (v != v);
-        m = fmax(m, fabs(v));
-      }
-    }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += SA_WGS * 256) {
+    const double v = a[i] - b[i];
+    a[i] = v;
+    bad |= (v != v);
+    m = fmax(m, fabs(v));
   }
   if (bad) m = __builtin_nan("");
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const double o = __shfl_down(m, off);
-    m = (m != m || o != o) ? __builtin_nan("") : fmax(m, o);
-  }
+  for (int off = 32; off > 0; off >>= 1) m = nanmax(m, __shfl_down(m, off));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
-    double r = red[0];
-    for (int w = 1; w < 16; ++w) r = (r != r || red[w] != red[w]) ? __builtin_nan("") : fmax(r, red[w]);
-    out[0] = r;
+    part[blockIdx.x] = nanmax(nanmax(red[0], red[1]), nanmax(red[2], red[3]));
+    __threadfence();
+    last = (atomicAdd(ticket, 1u) == SA_WGS - 1);
+  }
+  __syncthreads();
+  if (last && threadIdx.x < 64) {
+    __threadfence();
+    double r = (threadIdx.x < SA_WGS) ? reinterpret_cast<volatile double*>(part)[threadIdx.x] : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) r = nanmax(r, __shfl_down(r, off));
+    if (threadIdx.x == 0) {
+      out[0] = r;
+      *ticket = 0u;
+    }
   }
 }
 
 void dev_sub_absmax(Ctx& c, int n, double* a, const double* b, double* d_out) {
-  hipLaunchKernelGGL(sub_absmax_kernel, dim3(1), dim3(1024), 0, c.stream, n, a, b, d_out);
+  // partial maxima and the ticket live behind the 64 scalar slots of the context (zeroed at creation, reset by every call)
+  double* part = c.dscal.d() + 64;
+  unsigned* ticket = reinterpret_cast<unsigned*>(c.dscal.d() + 64 + SA_WGS);
+  hipLaunchKernelGGL(sub_absmax_kernel, dim3(SA_WGS), dim3(256), 0, c.stream, n, a, b, d_out, part, ticket);
   HYP_CHECK(hipGetLastError());
 }
 
@@ -987,7 +988,7 @@ double SysSolver::residual(double* res, const double* dir, const double* rhs, Sc
   rsc.tau -= rs.tau;
   rsc.kap -= rs.kap;
   // (the tau / kap slots of the device vectors are kept at zero: the scalars travel on the host)
-  hipLaunchKernelGGL(sub_absmax_kernel, dim3(1), dim3(1024), 0, ctx.stream, dimv(), res, rhs, ctx.dscal.d() + 8);
+  dev_sub_absmax(ctx, dimv(), res, rhs, ctx.dscal.d() + 8);
   ctx.d2h(ctx.h_pinned + 16, ctx.dscal.d() + 8, d);
   ctx.sync();
   double m = ctx.h_pinned[16];
