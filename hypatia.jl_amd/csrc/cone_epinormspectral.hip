@@ -203,7 +203,7 @@ __device__ __forceinline__ double jl_rsqrt(double x) {
   e = fma(-h * r, r, 0.5);
   return fma(r, e, r);
 }
-__global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double* __restrict__ Vg, double* __restrict__ Jg, int max_sweeps) {
+__global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double* __restrict__ Vg, double* __restrict__ Jg, int max_sweeps, int load_j) {
   extern __shared__ __attribute__((aligned(16))) double jl_lds[];
   const int ldv = len | 1;                       // odd stride
   double* V = jl_lds;                            // m columns of length len
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double
   __shared__ int rotated;
   const int tid = threadIdx.x;
   for (long e = tid; e < (long)len * m; e += 1024) V[(e / len) * ldv + (e % len)] = Vg[e];
-  if (Jg) for (long e = tid; e < (long)m * m; e += 1024) J[(e / m) * ldj + (e % m)] = ((e / m) == (e % m)) ? 1.0 : 0.0;
+  if (Jg) for (long e = tid; e < (long)m * m; e += 1024) J[(e / m) * ldj + (e % m)] = load_j ? Jg[e] : (((e / m) == (e % m)) ? 1.0 : 0.0);   // (load_j: warm start, the rotations continue an earlier product)
   __syncthreads();
   const int mm = (m % 2 == 0) ? m : m + 1;
   const int sub = tid & 31, grp = tid >> 5;      // 32 groups of 32 lanes
@@ -282,7 +282,7 @@ static size_t jacobi_lds_bytes(int len, int m, bool with_j) {
   const size_t b = ((size_t)m * (len | 1) + (with_j ? (size_t)m * (m | 1) : 0)) * sizeof(double);
   return b <= 150 * 1024 ? b : 0;
 }
-static bool jacobi_in_lds(Ctx& ctx, int len, int m, double* V, double* J) {
+static bool jacobi_in_lds(Ctx& ctx, int len, int m, double* V, double* J, bool load_j = false) {
   static const bool on = [] { const char* e = getenv("HYP_JACOBI_LDS"); return !(e && e[0] == '0'); }();
   const size_t lds = jacobi_lds_bytes(len, m, J != nullptr);
   if (!on || lds == 0) return false;
@@ -291,7 +291,7 @@ static bool jacobi_in_lds(Ctx& ctx, int len, int m, double* V, double* J) {
     HYP_CHECK(hipFuncSetAttribute((const void*)jacobi_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(jacobi_lds_kernel, dim3(1), dim3(1024), lds, ctx.stream, len, m, V, J, 60);
+  hipLaunchKernelGGL(jacobi_lds_kernel, dim3(1), dim3(1024), lds, ctx.stream, len, m, V, J, 60, load_j ? 1 : 0);
   HYP_CHECK(hipGetLastError());
   return true;
 }
@@ -444,12 +444,32 @@ double EpiNormSpectralCone::nuclear_norm(const double* d_mat) {
   // rows of the d1 x d2 matrix = columns of its transpose V (d2 x d1): orthogonalise them pairwise
   double* V = t12a.d();
   dev_transpose(ctx, d1, d2, d_mat, d1, V, d2, 1, 0, 0);
-  const int m = d1, mm = (m % 2 == 0) ? m : m + 1;
-  if (m > 1 && !jacobi_in_lds(ctx, d2, m, V, nullptr)) {
+  const int m = d1, mpad = (m % 2 == 0) ? m : m + 1;
+  // warm start as in update_svd: the dual points of consecutive trials are close, the rotations of the last call (Jdual) nearly
+  // orthogonalise the new matrix already.  Only where the one-launch LDS kernel applies (it carries the rotation product).
+  static const bool warm_on = [] { const char* e = getenv("HYP_SVD_WARM"); return !(e && e[0] == '0'); }();
+  bool done = false;
+  if (warm_on && m > 1 && jacobi_lds_bytes(d2, m, true) != 0) {
+    Jdual.ensure((size_t)d1 * d1 * 8);
+    double* V2 = t12b.d();
+    const bool warm = dual_prev_ok && dual_warm_count < 16;
+    if (warm) {
+      mm(ctx, false, d2, d1, d1, V, d2, Jdual.d(), d1, V2, d2, 1.0, 0.0);
+      ++dual_warm_count;
+    } else {
+      dual_warm_count = 0;
+    }
+    done = jacobi_in_lds(ctx, d2, m, warm ? V2 : V, Jdual.d(), warm);
+    if (done) {
+      dual_prev_ok = true;
+      if (warm) V = V2;
+    }
+  }
+  if (m > 1 && !done && !jacobi_in_lds(ctx, d2, m, V, nullptr)) {
     for (int sweep = 0; sweep < 40; ++sweep) {
       ctx.zero(Zinfo.p, sizeof(int));
-      for (int t = 0; t < mm - 1; ++t)
-        hipLaunchKernelGGL(jacobi_round_kernel, dim3(mm / 2), dim3(256), 0, ctx.stream, d2, m, mm, t, V, (long)d2, Zinfo.i());
+      for (int t = 0; t < mpad - 1; ++t)
+        hipLaunchKernelGGL(jacobi_round_kernel, dim3(mpad / 2), dim3(256), 0, ctx.stream, d2, m, mpad, t, V, (long)d2, Zinfo.i());
       if (read_info(ctx, Zinfo.i()) == 0) break;
     }
   }
@@ -596,10 +616,24 @@ bool EpiNormSpectralCone::update_svd() {
   if (svd_updated) return svd_ok;
   const size_t b11 = (size_t)d1 * d1 * 8, b21 = (size_t)d2 * d1 * 8;
   Usvd.ensure(b11); Jm.ensure(b11); V1.ensure(b21); V1T.ensure(b21); Bj.ensure(b21); sig.ensure((size_t)d1 * 8);
-  ctx.d2d(Bj.p, WT.p, b21);                                   // W' (d2 x d1): its columns are the rows of W
-  dev_fill_identity(ctx, d1, Jm.d(), d1);
+  // Warm start: W moves little between line-search trials and iterations, so W' J_prev (J_prev = the rotations accumulated by
+  // the last decomposition) has nearly orthogonal columns already and two or three sweeps finish the job where a cold start
+  // needs eight to ten (the decomposition is ~1 ms at 50 x 100, 40 % of config 3b's kernel time).  Any orthogonal start gives a
+  // valid decomposition; every 16th one starts cold so that rounding in the accumulated J cannot pile up.
+  static const bool warm_on = [] { const char* e = getenv("HYP_SVD_WARM"); return !(e && e[0] == '0'); }();
+  bool warm = false;
+  if (warm_on && svd_prev_ok && svd_warm_count < 16 && d1 > 1) {
+    mm(ctx, false, d2, d1, d1, WT.d(), d2, Usvd.d(), d1, Bj.d(), d2, 1.0, 0.0);
+    ctx.d2d(Jm.p, Usvd.p, b11);
+    ++svd_warm_count;
+    warm = true;
+  } else {
+    ctx.d2d(Bj.p, WT.p, b21);                                   // W' (d2 x d1): its columns are the rows of W
+    dev_fill_identity(ctx, d1, Jm.d(), d1);
+    svd_warm_count = 0;
+  }
   const int m = d1, mm2 = (m % 2 == 0) ? m : m + 1;
-  if (m > 1 && !jacobi_in_lds(ctx, d2, m, Bj.d(), Jm.d())) {
+  if (m > 1 && !jacobi_in_lds(ctx, d2, m, Bj.d(), Jm.d(), warm)) {
     for (int sweep = 0; sweep < 60; ++sweep) {
       ctx.zero(Zinfo.p, sizeof(int));
       for (int t = 0; t < mm2 - 1; ++t)
@@ -612,6 +646,7 @@ bool EpiNormSpectralCone::update_svd() {
   const int nzero = read_info(ctx, Zinfo.i());
   ctx.d2d(Usvd.p, Jm.p, b11);
   svd_ok = true;
+  svd_prev_ok = (nzero == 0);
   if (nzero == d1) {   // W = 0 (the initial point): any orthonormal bases do
     const long tot = std::max((long)d1 * d1, (long)d2 * d1);
     hipLaunchKernelGGL(ens_identity_bases_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx.stream, d1, d2, Usvd.d(), V1.d());

@@ -348,6 +348,11 @@ struct EpiNormSpectralCone : GenericHessCone {   // src/Cones/epinormspectral.jl
   // coordinates U' A [V1 V2] into 2 x 2 blocks over the index pairs (i, j), (j, i), a diagonal scaling on the V2 part and an
   // arrow system coupling u with the diagonal -- see cone_epinormspectral.hip.  HYP_ENS_CLOSED_INV=0 restores the generic path.
   bool closed_inv = true, svd_updated = false, svd_ok = false;
+  bool svd_prev_ok = false;   // Usvd holds the rotations of an earlier decomposition without zero singular values: warm start
+  int svd_warm_count = 0;
+  DBuf Jdual;                 // the same for the nuclear norm of the dual point (is_dual_feas)
+  bool dual_prev_ok = false;
+  int dual_warm_count = 0;
   DBuf Usvd, V1, V1T, sig, Bj, Jm, cw1, cw2, cw3, cw4, cw5;
   void reset_svd() { svd_updated = false; }
   bool update_svd();
