@@ -790,7 +790,7 @@ int hyp_dense_posv(hyp_ctx* ctx, int n, double* A, int lda, double* x, int* info
   c.sync();
   *info = c.h_info[0];
   if (*info == 0) {
-    if (c.trsv_sb > 0 && n >= 2 * c.trsv_sb) {   // same dispatch as SysSolver::tri_solves
+    if (c.trsv_plan_sb(n) > 0) {   // same dispatch as SysSolver::tri_solves
       TriSolvePlan tri;
       tri.build(c, n, dA.d(), lda, dinv.d());
       tri.solve(c, dA.d(), lda, true, dx.d());
@@ -876,7 +876,7 @@ int hyp_dense_lstsq_normal(hyp_ctx* ctx, int m, int n, const double* A, int lda,
   *rcond_est = 0.0;
   if (*info == 0) {
     TriSolvePlan tri;
-    const bool plan = (c.trsv_sb > 0 && n >= 2 * c.trsv_sb);
+    const bool plan = (c.trsv_plan_sb(n) > 0);
     if (plan) tri.build(c, n, dF.d(), n, dinv.d());
     auto solve = [&](double* v) {
       for (int pass = 0; pass < 2; ++pass) {

@@ -121,7 +121,7 @@ void GenericHessCone::inv_hess_prod(double* prod, long ldp, const double* arr, l
   if (ncols <= 0) return;
   if (prod != arr) HYP_CHECK(hipMemcpy2DAsync(prod, ldp * sizeof(double), arr, lda * sizeof(double), (size_t)dim * sizeof(double), ncols,
                                               hipMemcpyDeviceToDevice, ctx.stream));
-  if (ncols == 1 && ctx.trsv_sb > 0 && dim >= 2 * ctx.trsv_sb) {
+  if (ncols == 1 && ctx.trsv_plan_sb(dim) > 0) {
     // one vector against a large factor (check_numerics / get_proxsqr of every line-search trial): the super-block solves
     // of the system solver (76 dependent block steps otherwise); Bunch-Kaufman factor: P before, D^-1 between, P' after
     if (!Hplan.ready(dim)) Hplan.build(ctx, dim, Hfact.d(), dim, Hdinv.d());

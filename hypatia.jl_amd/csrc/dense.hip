@@ -581,7 +581,7 @@ static void coldot(Ctx& c, int m, int ncols, int mode, const double* M, long ld,
 
 void TriSolvePlan::build(Ctx& c, int n_, const double* U, long ldu, const double* dinv) {
   n = 0;
-  sb = c.trsv_sb;
+  sb = c.trsv_plan_sb(n_);
   static const int refine_env = [] { const char* e = getenv("HYP_TRSV_REFINE"); return e ? atoi(e) : -1; }();
   if (refine_env >= 0) refine = refine_env;
   if (sb <= 0 || n_ <= 0) return;
@@ -895,7 +895,7 @@ Ctx::Ctx(int dev) : device(dev) {
   HYP_CHECK(hipDeviceGetStreamPriorityRange(&plo, &phi));   // (numerically lower = higher priority)
   HYP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, phi));
   HYP_CHECK(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, plo));
-  if (const char* e = getenv("HYP_TRSV_SB")) trsv_sb = (atoi(e) / NB) * NB;
+  if (const char* e = getenv("HYP_TRSV_SB")) { trsv_sb = (atoi(e) / NB) * NB; trsv_sb_forced = true; }
   scratch.alloc(1 << 20);
   dscal.alloc(128 * sizeof(double));   // 64 scalar slots; [64, 96) partial maxima and [96] the ticket of dev_sub_absmax
   HYP_CHECK(hipMemset(dscal.p, 0, 128 * sizeof(double)));

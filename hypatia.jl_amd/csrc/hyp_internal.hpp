@@ -87,7 +87,17 @@ struct Ctx {
   DBuf stage_a, stage_b;   // device staging for host-pointer entry points
   DBuf work_tri;           // workspace of trtri_upper_batched
   int diag_own_cu_lds = -1;   // dynamic LDS that gives the critical-path diagonal-block kernel a CU of its own (-1: not asked yet, 0: refused)
-  int trsv_sb = 1024;      // super-block of the one-right-hand-side triangular solves (HYP_TRSV_SB; 0 = per-128-block path)
+  int trsv_sb = 1024;      // largest super-block of the one-right-hand-side triangular solves (HYP_TRSV_SB; 0 = per-128-block path)
+  bool trsv_sb_forced = false;   // HYP_TRSV_SB given: that size, plan from 2 super-blocks on (the round-1 rule)
+  // super-block size for an n x n factor, 0 = no plan (per-128-block solves).  About three super-blocks: n = 999 (config 3b) ->
+  // 384 (measured: 256: 10.7, 384: 10.4, 512 / no plan: 11.4-11.6 ms per iteration), n >= 3072 -> 1024
+  int trsv_plan_sb(int n) const {
+    if (trsv_sb <= 0) return 0;
+    if (trsv_sb_forced) return n >= 2 * trsv_sb ? trsv_sb : 0;
+    if (n < 512) return 0;
+    const int third = ((n + 2) / 3 + 127) / 128 * 128;
+    return third < trsv_sb ? third : trsv_sb;
+  }
   int* h_info = nullptr;    // pinned host word(s)
   double* h_pinned = nullptr;   // pinned host staging (small vectors / scalars)
   size_t h_pinned_n = 0;

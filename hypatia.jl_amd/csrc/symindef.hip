@@ -73,7 +73,7 @@ void SymIndefSys::update_lhs(int* info, int* used_fallback) {   // symindef.jl:2
   }
   fact_ok = (*info == 0);
   tri.invalidate();
-  if (fact_ok && ctx.trsv_sb > 0 && npq >= 2 * ctx.trsv_sb) tri.build(ctx, npq, fact.d(), npq, dinv.d());
+  if (fact_ok && ctx.trsv_plan_sb(npq) > 0) tri.build(ctx, npq, fact.d(), npq, dinv.d());
 }
 
 void SymIndefSys::solve3(double* h_sol, const double* h_rhs) {   // symindef.jl:264-271: ldiv!(sol.vec, fact, rhs.vec)

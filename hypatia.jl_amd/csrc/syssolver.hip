@@ -439,7 +439,7 @@ void SysSolver::factor_lhs(int* info, int* used_fallback) {   // qrchol.jl:249-2
     // first left the device idle for the round trip (~0.2 ms per iteration, profiles/r02_iteration_timeline.txt); after a
     // failed Cholesky the plan's kernels ran on meaningless numbers and the plan is discarded below
     tri.invalidate();
-    if (ctx.trsv_sb > 0 && nmp >= 2 * ctx.trsv_sb) tri.build(ctx, nmp, lhs_fact.d(), nmp, dinv.d());
+    if (ctx.trsv_plan_sb(nmp) > 0) tri.build(ctx, nmp, lhs_fact.d(), nmp, dinv.d());
     ctx.sync();
     *info = ctx.h_info[0];
     float ms = 0;
@@ -462,7 +462,7 @@ void SysSolver::factor_lhs(int* info, int* used_fallback) {   // qrchol.jl:249-2
   }
   fact_ok = (*info == 0);
   if (use_bk || !fact_ok) tri.invalidate();
-  if (fact_ok && !tri.ready(nmp) && ctx.trsv_sb > 0 && nmp >= 2 * ctx.trsv_sb) tri.build(ctx, nmp, lhs_fact.d(), nmp, dinv.d());
+  if (fact_ok && !tri.ready(nmp) && ctx.trsv_plan_sb(nmp) > 0) tri.build(ctx, nmp, lhs_fact.d(), nmp, dinv.d());
 }
 
 // x <- lhs^-1 x.  Cholesky: U'^-1 then U^-1.  Bunch-Kaufman: the same two sweeps with the unit factor, between a
