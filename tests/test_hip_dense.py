@@ -61,6 +61,45 @@ def test_potrf_and_posv(hip, n):
     assert np.linalg.norm(x - xref) <= 1e-10 * np.linalg.norm(xref) * np.linalg.cond(A)
 
 
+@pytest.mark.parametrize("n", [768, 1000, 1153, 2250])
+def test_potrf_large_lookahead_form(hip, n):
+    """n >= 6 blocks of 128: the look-ahead form (dense.hip: potrf_upper_batched) -- diagonal block, panel and block-row
+    update on the main stream, the rest of each rank-128 update on the helper stream underneath the next block step.
+    Ragged last blocks included."""
+    lib, ctx, L = hip
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, n + 5))
+    A = np.asfortranarray(M @ M.T + 0.5 * np.eye(n))
+    Uref = np.linalg.cholesky(A).T
+    Ad = A.copy(order="F")
+    info = c_int(-1)
+    L.check(lib.hyp_dense_potrf(ctx, n, fp(Ad), n, ctypes.byref(info)), "potrf")
+    assert info.value == 0
+    U = np.triu(Ad)
+    assert np.allclose(U, Uref, rtol=1e-9, atol=1e-10)
+    assert np.linalg.norm(U.T @ U - A) <= 1e-14 * n * np.linalg.norm(A)
+    assert np.array_equal(np.tril(Ad, -1), np.tril(A, -1))
+    # a second factorization right behind the first (the ordering events are reused): same bits
+    Ad2 = A.copy(order="F")
+    L.check(lib.hyp_dense_potrf(ctx, n, fp(Ad2), n, ctypes.byref(info)), "potrf")
+    assert np.array_equal(Ad, Ad2)
+
+
+def test_potrf_large_reports_failed_minor(hip):
+    import scipy.linalg.lapack as lp
+    lib, ctx, L = hip
+    n = 1000
+    rng = np.random.default_rng(5)
+    M = rng.standard_normal((n, n))
+    A = M @ M.T + np.eye(n)
+    A[700, 700] = -1.0
+    Ad = np.asfortranarray(A)
+    info = c_int(0)
+    L.check(lib.hyp_dense_potrf(ctx, n, fp(Ad), n, ctypes.byref(info)), "potrf")
+    _, iref = lp.dpotrf(A, lower=0)
+    assert info.value == iref == 701
+
+
 @pytest.mark.parametrize("n,cond", [(2048, 1e2), (2500, 1e10), (3333, 1e13)])
 def test_posv_superblock_solves(hip, n, cond):
     """n >= 2 * 1024: the one-RHS solves go through the inverted super-blocks + refinement against the
