@@ -5,6 +5,7 @@
 // both right-hand sides.  Arithmetic per column is the reference's (systemsolvers/common.jl:15-182,
 // qrchol.jl:16-98); a column whose residual calls for refinement continues alone through the
 // single-right-hand-side routines of syssolver.hip.
+#include <cstring>
 #include "syssolver.hpp"
 #include <chrono>
 
@@ -717,19 +718,29 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   *n_solves = 0;
   *info = 0;
   *used_fallback = 0;
+  // The caller's vectors are pageable: a hipMemcpyAsync on them stops the host until the copy is done, which left the device
+  // idle for 80-170 us at each of the two direction downloads in the middle of this call (profiles/r02_iteration_timeline.txt).
+  // Everything travels through the library's pinned staging instead ([point | residuals | sol_const | four directions]); the
+  // uploads are queued in front of the Schur assembly, the downloads are copied out after the one synchronisation at the end.
+  double* hs_point = ctx.stage_host((size_t)dv + 2 * (size_t)it + 2 * (size_t)MR * dv);
+  double* hs_res = hs_point + dv;
+  double* hs_const = hs_res + it;
+  double* hs_dirs = hs_const + it;
+  std::memcpy(hs_point, h_point, (size_t)dv * d);
+  std::memcpy(hs_res, h_res, (size_t)it * d);
+  s_point.ensure((size_t)dv * d);
+  s_resid.ensure((size_t)it * d);
+  ctx.h2d(s_point.p, hs_point, (size_t)dv * d);
+  ctx.h2d(s_resid.p, hs_res, (size_t)it * d);
   const auto t0 = std::chrono::steady_clock::now();
   if (nmp > 0) update_lhs_fact(info, used_fallback);                 // combined.jl:64
   if (use_sqrt_out)
     for (size_t k = 0; k < cones.size(); ++k) use_sqrt_out[k] = use_sqrt[k];
-  if (*info != 0) return;
+  if (*info != 0) { ctx.sync(); return; }
   update_const();
-  if (h_sol_const) ctx.d2h(h_sol_const, sol_const.p, (size_t)(n + p + q) * sizeof(double));   // (host mirror of sys.sol_const)
+  if (h_sol_const) ctx.d2h(hs_const, sol_const.p, (size_t)it * d);   // (host mirror of sys.sol_const)
   last_update_lhs_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   const double tau = h_point[it], kap = h_point[ik];
-  s_point.ensure((size_t)dv * d);
-  s_resid.ensure((size_t)(n + p + q) * d);
-  ctx.h2d(s_point.p, h_point, (size_t)dv * d);
-  ctx.h2d(s_resid.p, h_res, (size_t)(n + p + q) * d);
   m_rhs.ensure((size_t)MR * dv * d);
   v_tmp.ensure((size_t)MR * dv * d);   // (also the keeper of dir_cent / dir_pred between the two pairs: v_res below)
   Scal rs[MR], dsc[MR];
@@ -741,7 +752,7 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   *n_solves += ns;
   res_norms[0] = rn[0];
   res_norms[1] = rn[1];
-  ctx.d2h(h_dirs, m_dir.d(), (size_t)MR * dv * d);
+  ctx.d2h(hs_dirs, m_dir.d(), (size_t)MR * dv * d);
   s_dirs.ensure((size_t)MR * dv * d);
   ctx.d2d(s_dirs.p, m_dir.p, (size_t)MR * dv * d);
   const double dtau[MR] = {dsc[0].tau, dsc[1].tau};
@@ -753,8 +764,10 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   *n_solves += ns;
   res_norms[2] = rn[0];
   res_norms[3] = rn[1];
-  ctx.d2h(h_dirs + (long)MR * dv, m_dir.d(), (size_t)MR * dv * d);
+  ctx.d2h(hs_dirs + (long)MR * dv, m_dir.d(), (size_t)MR * dv * d);
   ctx.sync();
+  std::memcpy(h_dirs, hs_dirs, (size_t)2 * MR * dv * d);
+  if (h_sol_const) std::memcpy(h_sol_const, hs_const, (size_t)it * d);
   for (int r = 0; r < MR; ++r) {
     h_dirs[(long)r * dv + it] = d01[r].tau;
     h_dirs[(long)r * dv + ik] = d01[r].kap;

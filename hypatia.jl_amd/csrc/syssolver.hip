@@ -1,6 +1,7 @@
 // QRChol system solver on the device: Schur-complement assembly (batched sqrt-Hessian products +
 // FP64-MFMA syrk), blocked Cholesky, and the 3x3 solve.
 // Reference: /root/reference/src/Solvers/systemsolvers/qrchol.jl (line ranges inline).
+#include <cstring>
 #include "syssolver.hpp"
 
 namespace hyp {
@@ -956,8 +957,14 @@ int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp
   const int len = 2 * q + 2;
   *n_trials = 0;
   *n_loaded = 0;
+  // candidates are formed in pinned memory (two halves in turn) and only the accepted one is copied to the caller's vector:
+  // the upload inside check_cone_points is then a plain asynchronous copy -- from the caller's pageable vector it stopped the
+  // host for the whole transfer, once per trial
+  double* const stage = ctx.stage_host((size_t)2 * len);
+  double* const out = cand;
   for (int idx = start; idx < nsched; ++idx) {
     const double alpha = sched[idx];
+    cand = stage + (size_t)((idx - start) & 1) * len;
     // update_stepper_points (combined.jl:124-170), same operation order as the host mirror
     if (unadj_only) {
       if (cent_only) {
@@ -976,7 +983,10 @@ int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp
       }
     }
     ++*n_trials;
-    if (check_cone_points(cand, min_prox, prox_bound, use_max_prox, nup1, prox_out, n_loaded, irtmu_out)) return idx;
+    if (check_cone_points(cand, min_prox, prox_bound, use_max_prox, nup1, prox_out, n_loaded, irtmu_out)) {
+      std::memcpy(out, cand, (size_t)len * sizeof(double));
+      return idx;
+    }
   }
   return -1;
 }

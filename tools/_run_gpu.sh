@@ -1,5 +1,4 @@
-# Scratch script for one gpurun call (`gpurun --timeout N -- 'bash tools/_run_gpu.sh'`): whatever is measured goes under
-# gpurun_out/, summaries worth keeping are copied to profiles/.  The round's standard batch:
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
-python bench.py > gpurun_out/bench_cfg2_1gpu.json 2> gpurun_out/bench_cfg2_1gpu.err; tail -c 400 gpurun_out/bench_cfg2_1gpu.json
+timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -4
+for i in 1 2; do timeout 600 python bench.py 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['roofline']['frac'])"; done
+for c in 3b 5d; do timeout 900 python bench.py --config $c 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$c', d['ms_per_step'])"; done
