@@ -36,4 +36,5 @@ def make_cone(spec):
 
 def make_model(inst):
     c, A, b, G, h, specs = inst[:6]
-    return Model(c, A, b, G, h, [make_cone(s) for s in specs])
+    offset = inst[6].get("obj_offset", 0.0) if len(inst) > 6 else 0.0
+    return Model(c, A, b, G, h, [make_cone(s) for s in specs], obj_offset=offset)

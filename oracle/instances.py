@@ -14,6 +14,7 @@ from . import arrayutil as au
 
 RT2 = np.sqrt(2.0)
 RT3 = np.sqrt(3.0)
+TEST_TOL = float(np.sqrt(np.sqrt(np.finfo(np.float64).eps)))   # test_tol(T), nativeinstances.jl:29
 
 
 def dimension1():   # nativeinstances.jl:88-108
@@ -358,6 +359,176 @@ KNOWN_ANSWER = {
     "hypoperlogdettri1": hypoperlogdettri1, "hypoperlogdettri2": hypoperlogdettri2, "hypoperlogdettri3": hypoperlogdettri3,
     "hypoperlogdettri4": hypoperlogdettri4,
     "wsosinterppossemideftri1": wsosinterppossemideftri1,
+}
+
+
+# ----------------------------------------------------------------------------------------------
+# More of the reference's native instances for the cones of the device path: the ones whose data come from Julia's random
+# stream (same construction, numpy's stream: their assertions are status-level or property-based), the preprocessing
+# cases (dependent equalities / dependent columns: process.jl:64-365) and the ones with non-default options.  `expect` may
+# carry "tol" (the instance's own tolerance), "obj_offset" and "solver_opts" next to the answers.  Not part of
+# KNOWN_ANSWER (whose members have golden fixtures).
+# ----------------------------------------------------------------------------------------------
+def _randint(rng, lo, hi, shape):
+    return rng.integers(lo, hi + 1, size=shape).astype(np.float64)
+
+
+def consistent1(seed=1):   # :110-130 (dependent rows of A with a consistent b, dependent columns of [A; G] with a consistent c)
+    rng = np.random.default_rng(seed)
+    n, p, q = 30, 15, 30
+    c = np.zeros(n)
+    A = _randint(rng, -9, 9, (p, n))
+    G = 10.0 * np.eye(q, n)
+    r1, r2 = rng.random(), rng.random()
+    A[10:15, :] = r1 * A[0:5, :] - r2 * A[5:10, :]
+    b = A.sum(axis=1)
+    r1, r2 = rng.random(), rng.random()
+    A[:, 10:15] = r1 * A[:, 0:5] - r2 * A[:, 5:10]
+    G[:, 10:15] = r1 * G[:, 0:5] - r2 * G[:, 5:10]
+    c[10:15] = r1 * c[0:5] - r2 * c[5:10]
+    return (c, A, b, G, np.zeros(q), [("nonnegative", q)], dict(status="Optimal", tol=10 * TEST_TOL))
+
+
+def inconsistent1(seed=1):   # :132-148 (dependent rows of A, inconsistent b)
+    rng = np.random.default_rng(seed)
+    n, p, q = 30, 15, 30
+    c = _randint(rng, 0, 9, n)
+    A = _randint(rng, -9, 9, (p, n))
+    b = rng.random(p)
+    r1, r2 = rng.random(), rng.random()
+    A[10:15, :] = r1 * A[0:5, :] - r2 * A[5:10, :]
+    b[10:15] = 2 * (r1 * b[0:5] - r2 * b[5:10])
+    return (c, A, b, -np.eye(q, n), np.zeros(q), [("nonnegative", q)], dict(status="PrimalInconsistent"))
+
+
+def inconsistent2(seed=1):   # :150-167 (dependent columns of [A; G], inconsistent c)
+    rng = np.random.default_rng(seed)
+    n, p, q = 30, 15, 30
+    c = _randint(rng, 0, 9, n)
+    A = _randint(rng, -9, 9, (p, n))
+    G = -np.eye(q, n)
+    b = rng.random(p)
+    r1, r2 = rng.random(), rng.random()
+    A[:, 10:15] = r1 * A[:, 0:5] - r2 * A[:, 5:10]
+    G[:, 10:15] = r1 * G[:, 0:5] - r2 * G[:, 5:10]
+    c[10:15] = 2 * (r1 * c[0:5] - r2 * c[5:10])
+    return (c, A, b, G, np.zeros(q), [("nonnegative", q)], dict(status="DualInconsistent"))
+
+
+def nonnegative1(seed=1):   # :249-263 (obj_offset = 1)
+    rng = np.random.default_rng(seed)
+    n, p, q = 6, 3, 6
+    c = _randint(rng, 0, 9, n)
+    A = _randint(rng, -9, 9, (p, n))
+    return (c, A, A.sum(axis=1), -np.eye(q, n), np.zeros(q), [("nonnegative", q)], dict(status="Optimal", obj_offset=1.0))
+
+
+def nonnegative2(seed=1):   # :265-278
+    rng = np.random.default_rng(seed)
+    n, p, q = 5, 2, 10
+    c = _randint(rng, 0, 9, n)
+    A = _randint(rng, 1, 9, (p, n))
+    G = rng.random((q, n)) - 2.0 * np.eye(q, n)
+    return (c, A, A.sum(axis=1), G, G.sum(axis=1), [("nonnegative", q)], dict(status="Optimal", tol=2 * TEST_TOL))
+
+
+def nonnegative3(seed=1):   # :280-293
+    rng = np.random.default_rng(seed)
+    n, p, q = 15, 6, 15
+    c = _randint(rng, 0, 9, n)
+    A = _randint(rng, -9, 9, (p, n))
+    return (c, A, A.sum(axis=1), -np.eye(q), np.zeros(q), [("nonnegative", q)], dict(status="Optimal", tol=2 * TEST_TOL))
+
+
+def indirect1(seed=1):   # :2592-2606 with the option set of test/runnativetests.jl:89-99: LSQR initial point, no preprocessing or
+    # reduction, loose tolerances; the dense SymIndef system solver stands in for the matrix-free one (out of scope)
+    rng = np.random.default_rng(seed)
+    n, p = 3, 2
+    c = _randint(rng, 0, 9, n)
+    A = _randint(rng, -9, 9, (p, n))
+    return (c, A, A.sum(axis=1), -np.eye(n), np.zeros(n), [("nonnegative", n)],
+            dict(status="Optimal", tol=1e-3, obj_offset=1.0,
+                 solver_opts=dict(init_use_indirect=True, preprocess=False, reduce=False, syssolver="symindef", tol_feas=1e-4, tol_rel_opt=1e-4,
+                                  tol_abs_opt=1e-4, tol_infeas=1e-6)))
+
+
+def doublynonnegativetri3():   # :528-541 (despite its name, a PosSemidefTri(3) instance)
+    return (np.ones(3), np.array([[1.0, 0, 1]]), np.zeros(1), -np.eye(3), np.zeros(3), [("possemideftri", 3)],
+            dict(status="Optimal", primal_obj=0.0, x_norm=0.0))
+
+
+def epinormspectral1(use_dual, seed=1):   # :1038-1072, real member (property-based on the singular values of s and z)
+    rng = np.random.default_rng(seed)
+    Xn, Xm = 3, 4
+    dim = Xn * Xm
+    c = np.concatenate([[1.0], np.zeros(dim)])
+    A = np.hstack([np.zeros((dim, 1)), np.eye(dim)])
+    b = rng.random(dim)
+    h = np.concatenate([[0.0], rng.random(dim)])
+
+    def check(solver, approx):
+        s, z = solver.get_s(), solver.get_z()
+        psv = np.linalg.svd(s[1:].reshape((Xn, Xm), order="F"), compute_uv=False)
+        dsv = np.linalg.svd(z[1:].reshape((Xn, Xm), order="F"), compute_uv=False)
+        if use_dual:
+            assert approx(np.sum(psv), s[0]) and approx(dsv[0], z[0])
+        else:
+            assert approx(psv[0], s[0]) and approx(np.sum(dsv), z[0])
+    return (c, A, b, -np.eye(dim + 1), h, [("epinormspectral", Xn, Xm, use_dual)], dict(status="Optimal", check=check))
+
+
+def hyporootdettri3(is_complex=False, seed=1):   # :1631-1657 (W of rank side - 1: the optimum is u = 0; tol = eps^0.15)
+    rng = np.random.default_rng(seed)
+    side = 3
+    if is_complex:
+        half = 0.2 * (rng.random((side, side - 1)) + 1j * rng.random((side, side - 1)))
+        mat = half @ half.conj().T
+        dim = 1 + side * side
+        sv = _svec_c(mat)
+        spec = ("hyporootdettri_complex", dim, False)
+    else:
+        half = 0.2 * rng.random((side, side - 1))
+        mat = half @ half.T
+        dim = 1 + side * (side + 1) // 2
+        jj, ii = np.tril_indices(side)
+        sv = mat[ii, jj] * np.where(ii == jj, 1.0, RT2)
+        spec = ("hyporootdettri", dim, False)
+    G = np.zeros((dim, 1))
+    G[0, 0] = -1.0
+    h = np.zeros(dim)
+    h[1:] = sv
+    return (np.array([-1.0]), np.zeros((0, 1)), np.zeros(0), G, h, [spec],
+            dict(status="Optimal", primal_obj=0.0, x=[0.0], tol=float(np.finfo(np.float64).eps ** 0.15)))
+
+
+def wsosinterppossemideftri2(seed=1):   # :2407-2427: convexity parameter of x1^4 - 3 x2^2 (Hessian diag(12 x1^2, -6)) on R^2
+    U, pts, Ps = pu.interpolate_free(2, 1, np.random.default_rng(seed))
+    G = np.concatenate([np.ones(U), np.zeros(U), np.ones(U)]).reshape(-1, 1)
+    h = np.concatenate([12 * pts[:, 0] ** 2, np.zeros(U), -6.0 * np.ones(U)])
+    return (np.array([-1.0]), np.zeros((0, 1)), np.zeros(0), G, h, [("wsosinterppossemideftri", 2, U, Ps, False)],
+            dict(status="Optimal", primal_obj=6.0, x=[-6.0]))
+
+
+def wsosinterppossemideftri3(seed=1):   # :2429-2450: feasibility of a fixed SOS matrix polynomial -- a model with NO variables
+    U, pts, Ps = pu.interpolate_free(1, 3, np.random.default_rng(seed))
+    x = pts[:, 0]
+    m11, m12 = x + 2 * x ** 3, np.ones(U)
+    m21, m22 = -x ** 2 + 2, 3 * x ** 2 - x + 1
+    q11 = (m11 * m11 + m21 * m21) / 10
+    q21 = (m12 * m11 + m22 * m21) / 10
+    q22 = (m12 * m12 + m22 * m22) / 10
+    h = np.concatenate([q11, RT2 * q21, q22])
+    return (np.zeros(0), np.zeros((0, 0)), np.zeros(0), np.zeros((3 * U, 0)), h, [("wsosinterppossemideftri", 2, U, Ps, False)],
+            dict(status="Optimal", primal_obj=0.0))
+
+
+MORE_NATIVE = {
+    "consistent1": consistent1, "inconsistent1": inconsistent1, "inconsistent2": inconsistent2,
+    "nonnegative1": nonnegative1, "nonnegative2": nonnegative2, "nonnegative3": nonnegative3, "indirect1": indirect1,
+    "doublynonnegativetri3": doublynonnegativetri3,
+    "epinormspectral1_primal": lambda: epinormspectral1(False), "epinormspectral1_dual": lambda: epinormspectral1(True),
+    "hyporootdettri3": lambda: hyporootdettri3(False), "hyporootdettri3_complex": lambda: hyporootdettri3(True),
+    "wsosinterppossemideftri2": wsosinterppossemideftri2, "wsosinterppossemideftri3": wsosinterppossemideftri3,
 }
 
 

@@ -167,3 +167,14 @@ def interpolate_box(l, u, d, sample=None, rng=None, sample_factor=0):
     Ps = [P0] + [(np.sqrt(1 - pts[:, j] ** 2) * pscale[j])[:, None] * P0sub for j in range(n)]
     trpts = pts * pscale[None, :] + pshift[None, :]
     return U2, trpts, Ps
+
+
+def interpolate_free(n, d, rng=None, sample_factor=10):
+    """interpolate(FreeDomain(n), d): returns (U, pts, Ps) with Ps = [P0].  A domain that is not a box always takes the
+    sampling branch (realinterp.jl:23-25, 49-67): candidates uniform in [-1, 1]^n (realdomains.jl:57-58), points chosen
+    by the pivoted QR of the Chebyshev Vandermonde matrix, no weight polynomials (realdomains.jl:62)."""
+    U = get_U(n, d)
+    rng = rng if rng is not None else np.random.default_rng(1)
+    cand = 2.0 * rng.random((U * sample_factor, n)) - 1.0
+    pts, P0, _ = make_wsos_arrays(0, cand, d)
+    return U, pts, [P0]

@@ -15,6 +15,8 @@ def approx(a, b, tol):
 def build_solve_check(solver, model, inst, tol=TEST_TOL):
     c, A, b, G, h = inst[:5]
     expect = inst[6]
+    tol = expect.get("tol", tol)                 # (instances with a tolerance of their own)
+    offset = expect.get("obj_offset", 0.0)
     solver.load(model)
     solver.solve()
     status = solver.get_status()
@@ -24,8 +26,8 @@ def build_solve_check(solver, model, inst, tol=TEST_TOL):
     rt_tol = np.sqrt(tol)
     if status == "Optimal":
         assert approx(p_obj, d_obj, tol)
-        assert approx(c @ x, p_obj, tol)
-        assert approx(-(b @ y) - h @ z, d_obj, tol)
+        assert approx(c @ x + offset, p_obj, tol)
+        assert approx(-(b @ y) - h @ z + offset, d_obj, tol)
         assert approx(A @ x, b, tol)
         assert approx(G @ x + s, h, tol)
         assert approx(G.T @ z + A.T @ y, -c, tol)
@@ -33,6 +35,10 @@ def build_solve_check(solver, model, inst, tol=TEST_TOL):
     elif status == "PrimalInfeasible":
         assert approx(-(b @ y) - h @ z, d_obj, tol)
         assert approx(G.T @ z, -A.T @ y, rt_tol)
+    elif status == "DualInfeasible":
+        assert approx(c @ x, p_obj, tol)
+        assert approx(G @ x, -s, rt_tol)
+        assert approx(A @ x, np.zeros(len(y)), rt_tol)
     if "primal_obj" in expect:
         assert approx(p_obj, expect["primal_obj"], tol), (p_obj, expect["primal_obj"])
     if "check" in expect:   # property-based expectations of the reference's test (a callable of the solver)

@@ -34,6 +34,27 @@ def test_known_answer_hip(name, reduce):
     build_solve_check(solver, H.make_model(inst), inst)
 
 
+def _more_names():
+    from oracle import instances as I
+    return sorted(I.MORE_NATIVE)
+
+
+@pytest.mark.parametrize("name", _more_names())
+def test_more_native_instances_hip(name):
+    """further native instances of the reference through the HIP path (oracle/instances.py: MORE_NATIVE): dependent
+    equalities / dependent columns (consistent1 Optimal, inconsistent1 PrimalInconsistent, inconsistent2 DualInconsistent:
+    process.jl:64-365), an objective offset, the LSQR initial point without preprocessing (indirect1, on the device SymIndef
+    solver), the rank-deficient hypograph instances at their own tolerance, a model with no variables at all"""
+    import hypatia_jl_amd as H
+    from oracle import instances as I
+    inst = I.MORE_NATIVE[name]()
+    opts = dict(default_tol_relax=10)
+    opts.update(inst[6].get("solver_opts", {}))
+    if opts.get("syssolver") == "symindef":
+        opts["syssolver"] = H.SymIndefDenseSystemSolver()
+    build_solve_check(H.Solver(**opts), H.make_model(inst), inst)
+
+
 @pytest.mark.parametrize("name", ["possemideftri5", "possemideftri6", "possemideftri7"])
 @pytest.mark.parametrize("reduce", [True, False])
 def test_known_answer_hip_complex_psd(name, reduce):

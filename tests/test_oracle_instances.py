@@ -52,3 +52,19 @@ def test_small_polymin_both_forms():
 def test_small_matrixcompletion():
     inst = inst_mod.matrixcompletion(3, 4, seed=2)
     build_solve_check(Solver(default_tol_relax=10), make_model(inst), inst)
+
+
+@pytest.mark.parametrize("name", sorted(inst_mod.MORE_NATIVE))
+def test_more_native_instances(name):
+    """further native instances of the reference for the cones of the device path (oracle/instances.py: MORE_NATIVE): the
+    preprocessing cases (consistent1, inconsistent1 / 2: Optimal, PrimalInconsistent, DualInconsistent), an objective
+    offset, the matrix-free set-up, a rank-deficient hypograph instance at its own tolerance, a model without variables"""
+    inst = inst_mod.MORE_NATIVE[name]()
+    import inspect
+    opts = dict(default_tol_relax=10)
+    known = inspect.signature(Solver.__init__).parameters   # (the oracle has no LSQR initial point: it takes the QR one there)
+    opts.update({k: v for k, v in inst[6].get("solver_opts", {}).items() if k in known})
+    if opts.get("syssolver") == "symindef":
+        from oracle.solvers import SymIndefDenseSystemSolver
+        opts["syssolver"] = SymIndefDenseSystemSolver()
+    build_solve_check(Solver(**opts), make_model(inst), inst)
