@@ -12,6 +12,50 @@ def approx(a, b, tol):
     return np.all(np.abs(a - b) <= tol + tol * np.maximum(np.abs(a), np.abs(b)))
 
 
+def _smat(v):
+    """svec -> symmetric matrix (columns of the upper triangle, off-diagonal entries scaled by sqrt 2: arrayutilities.jl)"""
+    side = int(round((np.sqrt(8 * len(v) + 1) - 1) / 2))
+    M = np.zeros((side, side))
+    k = 0
+    for j in range(side):
+        for i in range(j + 1):
+            M[i, j] = M[j, i] = v[k] if i == j else v[k] / np.sqrt(2.0)
+            k += 1
+    return M
+
+
+def check_membership(specs, s, z, tol):
+    """Solver-independent half of the optimality certificate: s in K and z in K* by the cones' DEFINITIONS (eigenvalues,
+    singular values), not by any barrier code.  With the residual checks of build_solve_check (primal / dual feasibility, zero
+    gap) this certifies the optimum whatever route the iterates took.  Cones without a cheap definition-level test are skipped
+    (for WSOSInterpNonnegative only the moment-matrix side is tested)."""
+    off = 0
+    for spec in specs:
+        kind = spec[0]
+        dim = {"nonnegative": lambda: spec[1], "possemideftri": lambda: spec[1], "epinormspectral": lambda: 1 + spec[1] * spec[2],
+               "wsosinterpnonnegative": lambda: spec[1]}.get(kind)
+        if dim is None:
+            return            # (offsets of later cones would need this cone's dimension: stop at the first unknown kind)
+        dim = dim()
+        sk, zk = s[off:off + dim], z[off:off + dim]
+        off += dim
+        sc = tol * max(1.0, float(np.max(np.abs(sk))), float(np.max(np.abs(zk))))
+        if kind == "nonnegative":
+            assert sk.min() >= -sc and zk.min() >= -sc
+        elif kind == "possemideftri":
+            assert np.linalg.eigvalsh(_smat(sk)).min() >= -sc and np.linalg.eigvalsh(_smat(zk)).min() >= -sc
+        elif kind == "epinormspectral":
+            d1, d2, use_dual = spec[1], spec[2], spec[3]
+            prim, dual = (zk, sk) if use_dual else (sk, zk)      # prim in the spectral-norm cone, dual in the nuclear-norm cone
+            assert prim[0] >= np.linalg.svd(prim[1:].reshape((d1, d2), order="F"), compute_uv=False)[0] - sc
+            assert dual[0] >= np.linalg.svd(dual[1:].reshape((d1, d2), order="F"), compute_uv=False).sum() - sc
+        elif kind == "wsosinterpnonnegative":
+            Ps, use_dual = spec[2], spec[3]
+            mom = sk if use_dual else zk                          # the side that lives in the dual (moment) cone
+            for P in Ps:
+                assert np.linalg.eigvalsh(P.T @ (mom[:, None] * P)).min() >= -sc * max(1.0, float(np.abs(P).max()) ** 2)
+
+
 def build_solve_check(solver, model, inst, tol=TEST_TOL):
     c, A, b, G, h = inst[:5]
     expect = inst[6]
@@ -32,6 +76,7 @@ def build_solve_check(solver, model, inst, tol=TEST_TOL):
         assert approx(G @ x + s, h, tol)
         assert approx(G.T @ z + A.T @ y, -c, tol)
         assert approx(s @ z, 0.0, rt_tol)
+        check_membership(inst[5], s, z, tol)
     elif status == "PrimalInfeasible":
         assert approx(-(b @ y) - h @ z, d_obj, tol)
         assert approx(G.T @ z, -A.T @ y, rt_tol)

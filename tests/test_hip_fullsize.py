@@ -99,3 +99,31 @@ def test_accepted_step_stays_in_the_neighbourhood_and_is_reproducible(solver):
         assert s.iterate() and s.iterate()
         runs.append(s.point.vec.copy())
     assert np.array_equal(runs[0], runs[1])
+
+
+@pytest.mark.timeout(900)
+def test_full_solve_certificate_and_cone_membership():
+    """config 2 solved to the end at full size: status Optimal, the conic certificate of test/nativeinstances.jl:58-65 and --
+    independent of every barrier code -- smat(s) and smat(z) positive semidefinite by their eigenvalues"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import hypatia_jl_amd as H
+    from instance_harness import check_membership
+    from threadpoolctl import threadpool_limits
+    inst = bench.gen_instance(5000, [200], 1)
+    c, A, b, G, h = inst[:5]
+    with threadpool_limits(limits=8, user_api="blas"):
+        s = H.Solver(verbose=False)
+        s.load(H.make_model(inst))
+        s.solve()
+    assert s.status == "Optimal"
+    x, z, sv = s.get_x(), s.get_z(), s.get_s()
+    rel = lambda a, bb: np.linalg.norm(a - bb) / (1 + np.linalg.norm(bb))
+    tol = 1e-6
+    assert abs(s.primal_obj - s.dual_obj) <= tol * (1 + abs(s.primal_obj))
+    assert abs(c @ x - s.primal_obj) <= tol * (1 + abs(s.primal_obj))
+    assert rel(G @ x + sv, h) <= tol
+    assert rel(G.T @ z, -c) <= tol
+    assert abs(sv @ z) <= np.sqrt(tol) * (1 + abs(s.primal_obj))
+    check_membership(inst[5], sv, z, tol)

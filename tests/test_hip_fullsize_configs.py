@@ -22,6 +22,8 @@ def _certificate(solver, inst, tol):
     if len(b):
         assert rel(A @ x, b) <= tol
     assert abs(s @ z) <= np.sqrt(tol) * (1 + abs(solver.primal_obj))
+    from instance_harness import check_membership
+    check_membership(inst[5], s, z, tol)     # s in K, z in K* by the cones' definitions (singular values, moment matrices)
 
 
 @pytest.mark.timeout(600)

@@ -55,6 +55,27 @@ def test_more_native_instances_hip(name):
     build_solve_check(H.Solver(**opts), H.make_model(inst), inst)
 
 
+@pytest.mark.parametrize("maker", ["linearopt", "linearopt_large", "nonnegative1", "nonnegative2", "nonnegative3"])
+def test_lp_objective_matches_highs_hip(maker):
+    """linear programs through the HIP path against an independent solver (scipy's HiGHS): config 1 of BASELINE.json
+    (examples/linearopt, m = 50, n = 100), a larger one of the same family, and the reference's nonnegative1-3 constructions"""
+    import hypatia_jl_amd as H
+    from scipy.optimize import linprog
+    from oracle import instances as I
+    if maker == "linearopt":
+        inst = I.linearopt(50, 100, seed=1)
+    elif maker == "linearopt_large":
+        inst = I.linearopt(300, 800, seed=2)
+    else:
+        inst = I.MORE_NATIVE[maker]()
+    c, A, b, G, h = inst[:5]
+    s = build_solve_check(H.Solver(default_tol_relax=10), H.make_model(inst), inst)
+    r = linprog(c, A_ub=G, b_ub=h, A_eq=A, b_eq=b, bounds=(None, None), method="highs")
+    assert r.status == 0, r.message
+    ref = r.fun + inst[6].get("obj_offset", 0.0)
+    assert abs(s.get_primal_obj() - ref) <= 1e-6 * (1 + abs(ref)), (s.get_primal_obj(), ref)
+
+
 @pytest.mark.parametrize("name", ["possemideftri5", "possemideftri6", "possemideftri7"])
 @pytest.mark.parametrize("reduce", [True, False])
 def test_known_answer_hip_complex_psd(name, reduce):
