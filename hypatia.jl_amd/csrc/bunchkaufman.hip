@@ -37,6 +37,7 @@ namespace {
 constexpr int BK_T = 1024;   // threads of the pivot kernel
 constexpr int BK_TILE = 64;  // trailing update tile
 constexpr int BK_M = 8;      // pending eliminations (pairs of vectors l, w) a trailing update applies at once
+constexpr double BK_SFMIN = 2.2250738585072014e-308;   // dlamch('S')
 constexpr int BK_NI = 5;     // columns per thread in the register-resident fast path of the pivot kernel (n <= BK_T * BK_NI)
 
 struct BkState {
@@ -79,6 +80,11 @@ __device__ __forceinline__ void bk_argmax(double& v, int& ix, double* s_v, int* 
   ix = s_i[16];
 }
 
+// Barrier of the register-resident fast path of the pivot kernel, where the only data the workgroup exchanges are in LDS:
+// its barriers order LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL access of the wavefront
+// (s_waitcnt vmcnt(0)) -- here the prefetch of the next row and the stores of the step just finished, i.e. a full memory
+// round trip in front of each barrier of a step.
+__device__ __forceinline__ void bk_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // symmetric interchange of indices a < b, all rows (the rows above the active block hold U, which the rook variant
 // permutes too, so that ONE permutation describes the factorization).  E(i, j), i <= j, is B[i * ld + j].
 __device__ __forceinline__ void bk_swap(int n, double* __restrict__ B, long ld, int a, int b, int* __restrict__ perm) {
@@ -135,6 +141,7 @@ __global__ __launch_bounds__(BK_T) void bk_pivot_kernel(int n, double* __restric
   if (m == 0 && n <= BK_T * BK_NI) {
     __shared__ double lwin[BK_M - 1][BK_M];   // lwin[p][r] = l_p[k0 + r]
     __shared__ double s_piv;
+    __shared__ int s_flag;
     const int k0 = k;
     double wreg[BK_M - 1][BK_NI], row[BK_NI];
 #pragma unroll
@@ -155,31 +162,42 @@ __global__ __launch_bounds__(BK_T) void bk_pivot_kernel(int n, double* __restric
       const int kn = min(kk + 1, n - 1);
 #pragma unroll
       for (int i = 0; i < BK_NI; ++i) nxt[i] = A[(long)kn * lda + min(t + BK_T * i, n - 1)];
-      double colmax = -1.0;
-      int imax = INT_MAX;
+      // dsytf2_rook keeps the diagonal entry as a 1x1 pivot without interchange iff NOT (|a_kk| < alpha colmax).  Only that
+      // decision is needed here (a step that fails it is redone by the generic loop, which finds the index), and
+      // |a_kk| < alpha max_j |v_j|  <=>  some j has alpha |v_j| > |a_kk|  (rounded multiplication by alpha > 0 is monotone):
+      // the block-wide argmax -- two levels of cross-lane shuffles through the LDS crossbar -- becomes a broadcast of a_kk
+      // and a block-wide OR (a ballot per wavefront, one LDS word).  |a_kk| = 0 or NaN also leaves the fast path.
+      if (t == 0) s_flag = 0;
+#pragma unroll
+      for (int i = 0; i < BK_NI; ++i)
+        if (t + BK_T * i == kk) s_piv = v[i];
+      bk_lds_barrier();
+      const double d = s_piv;
+      const double absakk = fabs(d);
+      bool larger = false;
 #pragma unroll
       for (int i = 0; i < BK_NI; ++i) {
         const int j = t + BK_T * i;
-        if (j == kk) s_piv = v[i];
-        const double a = fabs(v[i]);
-        if (j > kk && j < n && a > colmax) { colmax = a; imax = j; }
+        larger |= (j > kk && j < n && alpha * fabs(v[i]) > absakk);
       }
-      bk_argmax(colmax, imax, s_v, s_i);
-      if (colmax < 0.0) colmax = 0.0;
-      const double d = s_piv;
-      const double absakk = fabs(d);
-      if (fmax(absakk, colmax) == 0.0 || absakk != absakk || absakk < alpha * colmax) {   // not a plain 1x1 pivot
+      if (__ballot(larger) != 0 && (t & 63) == 0) s_flag = 1;
+      bk_lds_barrier();
+      if (s_flag != 0 || !(absakk > 0.0)) {   // not a plain 1x1 pivot
         generic = true;
         break;
       }
       double* w1 = PW + (long)sidx * n;
       double* l1 = PL + (long)sidx * n;
       double* rkk = A + (long)kk * lda;
+      // dsytf2_rook / dlasyf_rook scale the column by the reciprocal of the pivot (R1 = ONE / A(K,K), DSCAL) when
+      // |pivot| >= sfmin and divide entry by entry otherwise: one division per step instead of BK_NI per thread
+      const bool recip = absakk >= BK_SFMIN;
+      const double r1 = 1.0 / d;
 #pragma unroll
       for (int i = 0; i < BK_NI; ++i) {
         const int j = t + BK_T * i;
         const double w = v[i];
-        const double l = w / d;
+        const double l = recip ? w * r1 : w / d;
         if (j > kk && j < n) {
           w1[j] = w; l1[j] = l;
           rkk[j] = l;
@@ -193,7 +211,7 @@ __global__ __launch_bounds__(BK_T) void bk_pivot_kernel(int n, double* __restric
         rkk[kk] = 1.0;
       }
       steps = sidx + 1;
-      __syncthreads();
+      bk_lds_barrier();
     }
     k = k0 + steps;
     m = steps;
@@ -298,10 +316,12 @@ __global__ __launch_bounds__(BK_T) void bk_pivot_kernel(int n, double* __restric
       if (info == 0) info = k + 1;
     } else if (kstep == 1) {
       const double d = rk[k];
+      const bool recip = fabs(d) >= BK_SFMIN;   // (LAPACK's rule, as in the fast path above)
+      const double r1 = 1.0 / d;
       __syncthreads();
       for (int j = k + 1 + t; j < n; j += BK_T) {
         const double w = rk[j];
-        const double l = w / d;
+        const double l = recip ? w * r1 : w / d;
         w1[j] = w; l1[j] = l;
         rk[j] = l;
       }

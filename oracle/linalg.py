@@ -238,7 +238,8 @@ def ldl_rook_forward(mat):
         elif kstep == 1:
             d[k] = A[k, k]
             w = A[k + 1:, k].copy()
-            l = w / d[k]
+            # dsytf2_rook / dlasyf_rook: scale by the reciprocal of the pivot when |pivot| >= sfmin (R1 = ONE / A(K,K), DSCAL)
+            l = w * (1.0 / d[k]) if abs(d[k]) >= np.finfo(np.float64).tiny else w / d[k]
             A[k + 1:, k + 1:] -= np.outer(l, w)
             L[k + 1:, k] = l
         else:

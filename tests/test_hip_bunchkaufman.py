@@ -148,7 +148,9 @@ def test_whole_solve_through_bunchkaufman(monkeypatch, name):
     got = build_solve_check(H.Solver(default_tol_relax=10), H.make_model(inst), inst)
     assert got.syssolver.fallback_kind == 1
     assert got.status == ref.status and abs(got.num_iters - ref.num_iters) <= 1
-    assert abs(got.primal_obj - ref.primal_obj) <= 1e-7 * (1 + abs(ref.primal_obj))
+    # (two convergent runs stop within the solver's own tolerance of the optimum -- tol_rel_opt = 10 sqrt(eps) = 1.5e-7 here --
+    #  not within rounding of each other: their last iterates differ by the factorizations' rounding)
+    assert abs(got.primal_obj - ref.primal_obj) <= 1e-6 * (1 + abs(ref.primal_obj))
 
 
 @pytest.mark.parametrize("kind,args", [("ens", (3, 4)), ("ens", (20, 33)), ("wsos", (2, 10))])
