@@ -25,10 +25,23 @@ __global__ void trace_kernel(int n, const double* A, long lda, double* out) {   
   }
   if (threadIdx.x == 0) out[0] = red[0];
 }
-__global__ void sum_sqrt_kernel(int n, const double* x, double* out) {   // single block
+// out = sum_j ||V[:, j]||_2 over the m columns (length len) of V, one workgroup: a wavefront per column (fixed order within
+// the column: lane-strided partial sums, butterfly), the column norms in `norms` (m doubles), their sum in index order by one
+// tree.  Replaces one dot-product launch per column (50 launches of 4 us per nuclear norm at 50 x 100).
+__global__ __launch_bounds__(256) void colnorm_sum_kernel(int len, int m, const double* __restrict__ V, double* __restrict__ norms, double* __restrict__ out) {
   __shared__ double red[256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int j = w; j < m; j += 4) {
+    const double* v = V + (long)j * len;
+    double s = 0.0;
+    for (int r = lane; r < len; r += 64) s = fma(v[r], v[r], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) norms[j] = sqrt(s);
+  }
+  __syncthreads();
   double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) s += sqrt(fmax(x[i], 0.0));
+  for (int i = threadIdx.x; i < m; i += 256) s += norms[i];
   red[threadIdx.x] = s;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
@@ -203,7 +216,11 @@ __device__ __forceinline__ double jl_rsqrt(double x) {
   e = fma(-h * r, r, 0.5);
   return fma(r, e, r);
 }
-__global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double* __restrict__ Vg, double* __restrict__ Jg, int max_sweeps, int load_j) {
+// tol_rot: a pair is rotated while its cosine |g| / sqrt(a b) exceeds it; tol_big: a sweep whose rotated pairs all had a cosine
+// <= tol_big is the last one (it leaves cosines of the order of m tol_big^2 behind); floor_rel: columns whose norm is below
+// floor_rel ||B||_F are numerically zero and take no part (0: every column does).
+__global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double* __restrict__ Vg, double* __restrict__ Jg, int max_sweeps, int load_j,
+                                                          int* __restrict__ sweeps_out, double tol_rot, double tol_big, double floor_rel) {
   extern __shared__ __attribute__((aligned(16))) double jl_lds[];
   const int ldv = len | 1;                       // odd stride
   double* V = jl_lds;                            // m columns of length len
@@ -214,6 +231,19 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double
   for (long e = tid; e < (long)len * m; e += 1024) V[(e / len) * ldv + (e % len)] = Vg[e];
   if (Jg) for (long e = tid; e < (long)m * m; e += 1024) J[(e / m) * ldj + (e % m)] = load_j ? Jg[e] : (((e / m) == (e % m)) ? 1.0 : 0.0);   // (load_j: warm start, the rotations continue an earlier product)
   __syncthreads();
+  double floor2 = 0.0;
+  if (floor_rel > 0.0) {   // ||B||_F^2 (invariant under the rotations), fixed summation order
+    __shared__ double fr[1024];
+    double f = 0.0;
+    for (long e = tid; e < (long)len * m; e += 1024) { const double x = V[(e / len) * ldv + (e % len)]; f = fma(x, x, f); }
+    fr[tid] = f;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+      if (tid < off) fr[tid] += fr[tid + off];
+      __syncthreads();
+    }
+    floor2 = floor_rel * floor_rel * fr[0];
+  }
   const int mm = (m % 2 == 0) ? m : m + 1;
   const int sub = tid & 31, grp = tid >> 5;      // 32 groups of 32 lanes
   for (int sweep = 0; sweep < max_sweeps && m > 1; ++sweep) {
@@ -233,7 +263,7 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double
           a = fma(x, x, a); b = fma(y, y, b); g = fma(x, y, g);
         }
         a = jl_sum32(a); b = jl_sum32(b); g = jl_sum32(g);
-        if (fabs(g) <= 1e-15 * sqrt(a * b) || g == 0.0) continue;
+        if (fabs(g) <= tol_rot * sqrt(a * b) || g == 0.0 || fmin(a, b) <= floor2) continue;
         // (outside the range where the seeds + Newton steps are safe -- g or zeta near the ends of the exponent range, which
         //  happens when columns of W are ~1e-150 at the end of a solve with a zero optimum -- the plain expansions are used)
         double cs, sn;
@@ -252,7 +282,9 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double
           sn = cs * tt;
         }
         if (!(cs == cs) || !(sn == sn)) continue;
-        if (sub == 0) rotated = 1;
+        // a sweep whose rotated pairs all had a small cosine leaves cosines of the order of its square behind (below the
+        // rotation threshold): it is the last one -- no further sweep just to find nothing to rotate
+        if (sub == 0 && ag > tol_big * sqrt(a * b)) rotated = 1;
         for (int r = sub; r < len; r += 32) {
           const double x = vp[r], y = vq[r];
           vp[r] = cs * x - sn * y;
@@ -270,6 +302,7 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double
       }
       __syncthreads();
     }
+    if (tid == 0 && sweeps_out) *sweeps_out = sweep + 1;
     if (rotated == 0) break;
     __syncthreads();
   }
@@ -282,7 +315,13 @@ static size_t jacobi_lds_bytes(int len, int m, bool with_j) {
   const size_t b = ((size_t)m * (len | 1) + (with_j ? (size_t)m * (m | 1) : 0)) * sizeof(double);
   return b <= 150 * 1024 ? b : 0;
 }
-static bool jacobi_in_lds(Ctx& ctx, int len, int m, double* V, double* J, bool load_j = false) {
+// values_only: the caller wants the SUM of the singular values (the nuclear norm of the dual feasibility test).  With cosines
+// c_pq left between the columns, the Gram matrix is D (I + C) D: its trace is exact, simple eigenvalues move in second order and
+// a cluster d^2 (1 +- c) contributes d (sqrt(1 + c) + sqrt(1 - c)) = d (2 - c^2 / 4) -- the sum of the column norms is the nuclear
+// norm up to O(||C||_F^2) relatively, so cosines of 1e-10 (||C||_F^2 <= m^2 1e-20) are as good as 1e-15 there; and columns below
+// eps ||B||_F are numerically zero, as for LAPACK's own singular values (absolute accuracy eps sigma_max): at a dual point close
+// to the boundary of the cone most columns are such noise, and rotating noise against noise never settles (20 sweeps and more).
+static bool jacobi_in_lds(Ctx& ctx, int len, int m, double* V, double* J, bool load_j = false, bool values_only = false) {
   static const bool on = [] { const char* e = getenv("HYP_JACOBI_LDS"); return !(e && e[0] == '0'); }();
   const size_t lds = jacobi_lds_bytes(len, m, J != nullptr);
   if (!on || lds == 0) return false;
@@ -291,8 +330,16 @@ static bool jacobi_in_lds(Ctx& ctx, int len, int m, double* V, double* J, bool l
     HYP_CHECK(hipFuncSetAttribute((const void*)jacobi_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(jacobi_lds_kernel, dim3(1), dim3(1024), lds, ctx.stream, len, m, V, J, 60, load_j ? 1 : 0);
+  static const bool dbg = [] { const char* e = getenv("HYP_JACOBI_DBG"); return e && e[0] == '1'; }();   // sweeps of every call on stderr
+  int* sw = dbg ? reinterpret_cast<int*>(ctx.dscal.d() + 63) : nullptr;
+  const double tol_rot = values_only ? 1e-10 : 1e-15, tol_big = values_only ? 1e-6 : 1e-8, floor_rel = values_only ? 2.220446049250313e-16 : 0.0;
+  hipLaunchKernelGGL(jacobi_lds_kernel, dim3(1), dim3(1024), lds, ctx.stream, len, m, V, J, 60, load_j ? 1 : 0, sw, tol_rot, tol_big, floor_rel);
   HYP_CHECK(hipGetLastError());
+  if (dbg) {
+    ctx.d2h(ctx.h_info + 32, sw, sizeof(int));
+    ctx.sync();
+    fprintf(stderr, "[jacobi] %d x %d%s%s: %d sweeps\n", len, m, J ? " +J" : "", load_j ? " warm" : "", ctx.h_info[32]);
+  }
   return true;
 }
 
@@ -459,13 +506,13 @@ double EpiNormSpectralCone::nuclear_norm(const double* d_mat) {
     } else {
       dual_warm_count = 0;
     }
-    done = jacobi_in_lds(ctx, d2, m, warm ? V2 : V, Jdual.d(), warm);
+    done = jacobi_in_lds(ctx, d2, m, warm ? V2 : V, Jdual.d(), warm, true);
     if (done) {
       dual_prev_ok = true;
       if (warm) V = V2;
     }
   }
-  if (m > 1 && !done && !jacobi_in_lds(ctx, d2, m, V, nullptr)) {
+  if (m > 1 && !done && !jacobi_in_lds(ctx, d2, m, V, nullptr, false, true)) {
     for (int sweep = 0; sweep < 40; ++sweep) {
       ctx.zero(Zinfo.p, sizeof(int));
       for (int t = 0; t < mpad - 1; ++t)
@@ -473,13 +520,9 @@ double EpiNormSpectralCone::nuclear_norm(const double* d_mat) {
       if (read_info(ctx, Zinfo.i()) == 0) break;
     }
   }
-  // singular values = column norms
-  double* norms2 = tmpd.d();
-  // column sums of squares
-  for (int j0 = 0; j0 < m; j0 += 1) {
-    dev_dot(ctx, d2, V + (long)j0 * d2, V + (long)j0 * d2, norms2 + j0);
-  }
-  hipLaunchKernelGGL(sum_sqrt_kernel, dim3(1), dim3(256), 0, ctx.stream, m, norms2, ctx.dscal.d());
+  // singular values = column norms; their sum in one launch
+  hipLaunchKernelGGL(colnorm_sum_kernel, dim3(1), dim3(256), 0, ctx.stream, d2, m, V, tmpd.d(), ctx.dscal.d());
+  HYP_CHECK(hipGetLastError());
   return read_scalar(ctx, ctx.dscal.d());
 }
 
