@@ -488,6 +488,13 @@ bool EpiNormSpectralCone::update_feas() {   // :107-123
 }
 
 double EpiNormSpectralCone::nuclear_norm(const double* d_mat) {
+  nuclear_norm_launch(d_mat, ctx.dscal.d());
+  return read_scalar(ctx, ctx.dscal.d());
+}
+
+// the device work of the nuclear norm on ctx.stream, the result left in *d_out (no host round trip where the one-launch
+// decomposition applies)
+void EpiNormSpectralCone::nuclear_norm_launch(const double* d_mat, double* d_out) {
   // rows of the d1 x d2 matrix = columns of its transpose V (d2 x d1): orthogonalise them pairwise
   double* V = t12a.d();
   dev_transpose(ctx, d1, d2, d_mat, d1, V, d2, 1, 0, 0);
@@ -521,15 +528,47 @@ double EpiNormSpectralCone::nuclear_norm(const double* d_mat) {
     }
   }
   // singular values = column norms; their sum in one launch
-  hipLaunchKernelGGL(colnorm_sum_kernel, dim3(1), dim3(256), 0, ctx.stream, d2, m, V, tmpd.d(), ctx.dscal.d());
+  hipLaunchKernelGGL(colnorm_sum_kernel, dim3(1), dim3(256), 0, ctx.stream, d2, m, V, tmpd.d(), d_out);
   HYP_CHECK(hipGetLastError());
-  return read_scalar(ctx, ctx.dscal.d());
 }
 
 bool EpiNormSpectralCone::is_dual_feas() {   // :125-132
+  if (dual_cached) return dual_feas_;
   const double ud = read_scalar(ctx, dual_point.d());
   if (ud > EPS) return (ud - nuclear_norm(dual_point.d() + 1)) > EPS;
   return false;
+}
+
+// A primal-feasible line-search candidate needs two independent decompositions, each latency-bound on ONE workgroup: the dual
+// point's for its nuclear norm (is_dual_feas; 0.4 - 1.5 ms at 50 x 100) and the primal point's behind the closed-form inverse
+// Hessian, which the proximity test asks for (0.2 - 0.3 ms).  After the primal feasibility test (the reference's order: an
+// infeasible candidate -- the first steps of the schedule usually are -- costs one small Cholesky and nothing else) the dual
+// chain goes to the helper stream and the primal decomposition runs on the main stream underneath it; one synchronisation
+// joins them.  (The primal decomposition is started on the assumption that the dual point is feasible; if it is not, it ran
+// underneath the dual chain anyway.)
+void EpiNormSpectralCone::prefetch_feas() {
+  static const bool on = [] { const char* e = getenv("HYP_ENS_PREFETCH"); return !(e && e[0] == '0'); }();
+  if (!on || feas_updated) return;
+  if (!update_feas()) return;
+  hipEvent_t e0 = ctx.aux_event(2);
+  HYP_CHECK(hipEventRecord(e0, ctx.stream));                 // (point / dual_point were loaded on the main stream)
+  HYP_CHECK(hipStreamWaitEvent(ctx.stream2, e0, 0));
+  {
+    StreamSwap on_helper(ctx);
+    double* res = ctx.dscal.d() + 40;
+    nuclear_norm_launch(dual_point.d() + 1, res);
+    ctx.d2h(ctx.h_pinned + 40, res, sizeof(double));
+    ctx.d2h(ctx.h_pinned + 41, dual_point.d(), sizeof(double));
+  }
+  static const bool cf = [] { const char* e = getenv("HYP_ENS_CLOSED_INV"); return !(e && e[0] == '0'); }();
+  if (cf) update_svd();
+  hipEvent_t e1 = ctx.aux_event(3);
+  HYP_CHECK(hipEventRecord(e1, ctx.stream2));
+  HYP_CHECK(hipStreamWaitEvent(ctx.stream, e1, 0));
+  ctx.sync();
+  const double nn = ctx.h_pinned[40], ud = ctx.h_pinned[41];
+  dual_feas_ = (ud > EPS) && ((ud - nn) > EPS);
+  dual_cached = true;
 }
 
 void EpiNormSpectralCone::update_grad() {   // :134-150

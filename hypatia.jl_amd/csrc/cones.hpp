@@ -343,6 +343,8 @@ struct EpiNormSpectralCone : GenericHessCone {   // src/Cones/epinormspectral.jl
   const double* dder3(const double* d_dir) override;                                          // :241-294
   void zsolve(double* X, long ldx, int nrhs);    // X <- Z^-1 X
   double nuclear_norm(const double* d_mat /* d1 x d2 col-major */);
+  void nuclear_norm_launch(const double* d_mat, double* d_out);
+  void prefetch_feas() override;
   // Closed-form inverse Hessian (NOT in this Hypatia version, whose inv_hess_prod! is the generic explicit-Hessian
   // Cholesky of Cones.jl:113-118): with W = U S V1' the Hessian of epinormspectral.jl:211-239 decouples in the rotated
   // coordinates U' A [V1 V2] into 2 x 2 blocks over the index pairs (i, j), (j, i), a diagonal scaling on the V2 part and an
