@@ -59,12 +59,19 @@ bool Cone::prox_launch(double irtmu, double* d_out3) {   // the device work of c
   const double* g = get_grad();
   dev_dot(ctx, dim, g, point.d(), d_out3);
   if (!inv_hess_ready()) return false;
-  inv_hess_prod(vec1.d(), dim, g, dim, 1);
-  dev_dot(ctx, dim, vec1.d(), g, d_out3 + 1);
-  ctx.d2d(vec1.p, g, (size_t)dim * sizeof(double));
-  dev_axpby(ctx, dim, irtmu, dual_point.d(), 1.0, vec1.d());
-  inv_hess_prod(vec2.d(), dim, vec1.d(), dim, 1);
-  dev_dot(ctx, dim, vec2.d(), vec1.d(), d_out3 + 2);
+  // both inverse-Hessian products in ONE call on two columns [g, v]: every cone's inv_hess_prod! serves all columns with one
+  // pass over its factor / its matrices (for the generic cones two triangular sweeps over a dim x dim factor instead of four)
+  const size_t vb = (size_t)dim * sizeof(double);
+  prox_in.ensure(2 * vb);
+  prox_out.ensure(2 * vb);
+  double* v0 = prox_in.d();
+  double* v1 = prox_in.d() + dim;
+  ctx.d2d(v0, g, vb);
+  ctx.d2d(v1, g, vb);
+  dev_axpby(ctx, dim, irtmu, dual_point.d(), 1.0, v1);
+  inv_hess_prod(prox_out.d(), dim, prox_in.d(), dim, 2);
+  dev_dot(ctx, dim, prox_out.d(), g, d_out3 + 1);
+  dev_dot(ctx, dim, prox_out.d() + dim, v1, d_out3 + 2);
   return true;
 }
 

@@ -22,7 +22,7 @@ struct Cone {
   int dim = 0;
   double nu = 0;
   bool use_dual_barrier = false;
-  DBuf point, dual_point, grad, dder3v, vec1, vec2;
+  DBuf point, dual_point, grad, dder3v, vec1, vec2, prox_in, prox_out;
   bool feas_updated = false, grad_updated = false, hess_updated = false, inv_hess_updated = false,
        hess_fact_updated = false, is_feas_ = false;
   // is_dual_feas() answered ahead of time by prefetch_feas() / the batched line-search sweep (PsdCone); cleared by every

@@ -130,6 +130,14 @@ void GenericHessCone::inv_hess_prod(double* prod, long ldp, const double* arr, l
     if (hess_fact_bk) Hbk.dsolve(ctx, y, dim, 1);
     Hplan.solve(ctx, Hfact.d(), dim, false, y);
     if (hess_fact_bk) Hbk.scatter(ctx, y, prod, ldp, 1);
+  } else if (ncols == 2 && ctx.trsv_plan_sb(dim) > 0) {   // the pair of the proximity test (Cone::prox_launch): the same sweeps on two columns
+    if (!Hplan.ready(dim)) Hplan.build(ctx, dim, Hfact.d(), dim, Hdinv.d());
+    double* y = hess_fact_bk ? Hbk.gather(ctx, prod, ldp, 2) : prod;
+    const long ldy = hess_fact_bk ? (long)dim : ldp;
+    Hplan.solve_multi(ctx, Hfact.d(), dim, true, y, ldy, 2);
+    if (hess_fact_bk) Hbk.dsolve(ctx, y, dim, 2);
+    Hplan.solve_multi(ctx, Hfact.d(), dim, false, y, ldy, 2);
+    if (hess_fact_bk) Hbk.scatter(ctx, y, prod, ldp, 2);
   } else if (hess_fact_bk) {   // ldiv!(::BunchKaufman, .)
     Hbk.solve(ctx, Hfact.d(), dim, Hdinv.d(), prod, ldp, ncols, trsm_work);
   } else if (ncols == 1) {
@@ -210,6 +218,49 @@ void WsosCone::set_initial_point(double* h) {   // :87
 }
 
 bool WsosCone::update_feas() {   // :89-117
+  // The K chains (scale, Lambda_k = P_k' diag(pt) P_k, its Cholesky) are independent and each is bound by the latency of
+  // the small factorization (0.2 - 0.3 ms; 1.6 ms one after the other at U = 4845, K = 5, with a host round trip per k for
+  // the reference's early exit).  They are dealt out to the two streams by accumulated block steps and all flags come back with
+  // one synchronisation; the point is feasible iff every factorization succeeded, as in the reference's sweep.
+  static const bool par = [] { const char* e = getenv("HYP_WSOS_PAR"); return !(e && e[0] == '0'); }();
+  int Lmax = 0;
+  for (int k = 0; k < K; ++k) Lmax = std::max(Lmax, Ls[k]);
+  // (from 6 block steps on the factorization itself runs on both streams -- and is no longer bound by latency alone)
+  if (par && K >= 2 && K <= 64 && Lmax < 6 * NB) {
+    hipEvent_t e0 = ctx.aux_event(2);
+    HYP_CHECK(hipEventRecord(e0, ctx.stream));                 // (the point was loaded on the main stream)
+    HYP_CHECK(hipStreamWaitEvent(ctx.stream2, e0, 0));
+    int load[2] = {0, 0};
+    for (int k = 0; k < K; ++k) {
+      const int Lk = Ls[k];
+      const int side = (load[1] < load[0]) ? 1 : 0;
+      load[side] += (Lk + NB - 1) / NB;
+      auto chain = [&] {
+        row_scale(ctx, U, Lk, point.d(), P[k].d(), U, SP[k].d(), U);
+        GemmArgs g{};
+        g.M = Lk; g.N = Lk; g.K = U; g.A = SP[k].d(); g.lda = U; g.B = P[k].d(); g.ldb = U; g.C = Lam[k].d(); g.ldc = Lk;
+        g.alpha = 1; g.beta = 0; g.tri = GEMM_UPPER; g.batch = 1;
+        gemm(ctx, true, g);
+        potrf_upper_batched(ctx, Lk, Lam[k].d(), Lk, 0, 1, LamDinv[k].d(), infos.i() + k);
+      };
+      if (side == 1) {
+        StreamSwap on_helper(ctx);
+        chain();
+      } else {
+        chain();
+      }
+    }
+    hipEvent_t e1 = ctx.aux_event(3);
+    HYP_CHECK(hipEventRecord(e1, ctx.stream2));
+    HYP_CHECK(hipStreamWaitEvent(ctx.stream, e1, 0));
+    ctx.d2h(ctx.h_info + 64, infos.p, (size_t)K * sizeof(int));
+    ctx.sync();
+    is_feas_ = true;
+    for (int k = 0; k < K; ++k)
+      if (ctx.h_info[64 + k] != 0) is_feas_ = false;
+    feas_updated = true;
+    return is_feas_;
+  }
   is_feas_ = true;
   for (int k = 0; k < K && is_feas_; ++k) {
     const int Lk = Ls[k];

@@ -915,6 +915,7 @@ Ctx::~Ctx() {
   for (hipEvent_t e : aux)
     if (e) (void)hipEventDestroy(e);
   gemm_scratch.release();
+  gemm_scratch2.release();
   if (stream2) (void)hipStreamDestroy(stream2);
   if (stream) (void)hipStreamDestroy(stream);
 }

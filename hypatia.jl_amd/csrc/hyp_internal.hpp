@@ -82,6 +82,7 @@ struct Ctx {
   hipEvent_t aux[4] = {nullptr, nullptr, nullptr, nullptr};   // fork / join events of the two-stream sections (not the look-ahead pool)
   hipEvent_t aux_event(int i);
   GemmScratch gemm_scratch;   // split-K workspace + syrk tile order of the GEMM launcher (per context, never shared)
+  GemmScratch gemm_scratch2;  // the same for launches on the helper stream (StreamSwap)
   DBuf scratch;       // general device scratch (gemv partial sums)
   DBuf dscal;         // 64 device doubles for scalar results (dots, counts)
   DBuf stage_a, stage_b;   // device staging for host-pointer entry points
@@ -125,8 +126,9 @@ struct Ctx {
 // exchanged for the lifetime of the guard (restored on scope exit, also when a HIP error throws).
 struct StreamSwap {
   Ctx& c;
-  explicit StreamSwap(Ctx& ctx) : c(ctx) { std::swap(c.stream, c.stream2); }
-  ~StreamSwap() { std::swap(c.stream, c.stream2); }
+  // (the GEMM launcher's split-K workspace follows the stream: two products in flight on the two streams must not share it)
+  explicit StreamSwap(Ctx& ctx) : c(ctx) { std::swap(c.stream, c.stream2); std::swap(c.gemm_scratch, c.gemm_scratch2); }
+  ~StreamSwap() { std::swap(c.stream, c.stream2); std::swap(c.gemm_scratch, c.gemm_scratch2); }
   StreamSwap(const StreamSwap&) = delete;
   StreamSwap& operator=(const StreamSwap&) = delete;
 };
