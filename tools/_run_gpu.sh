@@ -1,4 +1,17 @@
+# Scratch script for one gpurun call (`gpurun --timeout N -- 'bash tools/_run_gpu.sh'`): whatever is measured goes under
+# gpurun_out/, summaries worth keeping are copied to profiles/.  The round's standard batch:
 export TMPDIR=/tmp
-timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -4
-for i in 1 2; do timeout 600 python bench.py 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['roofline']['frac'])"; done
-for c in 3b 5d; do timeout 900 python bench.py --config $c 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$c', d['ms_per_step'])"; done
+python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+python bench.py > gpurun_out/bench_cfg2_1gpu.json 2> gpurun_out/bench_cfg2_1gpu.err; tail -c 300 gpurun_out/bench_cfg2_1gpu.json
+rm -f gpurun_out/other_configs.jsonl
+for c in 3b 5p 5d; do python bench.py --config $c 2>/dev/null | tail -1 >> gpurun_out/other_configs.jsonl; done
+python bench.py --config 4 2>/dev/null | tail -1 > gpurun_out/bench_cfg4_1gpu.json
+python -c "
+import json
+for l in open('gpurun_out/other_configs.jsonl'): d=json.loads(l); print(d['config']['workload'][:50], d['ms_per_step'])
+d=json.loads(open('gpurun_out/bench_cfg4_1gpu.json').read()); print('cfg4', d['ms_per_step'], d['roofline']['frac'])"
+rocprofv3 --kernel-trace --stats -d /tmp/prof2 -o b -- python bench.py --steps 40 > gpurun_out/bench_under_profiler.json 2>/dev/null
+python tools/rocpd_stats.py $(find /tmp/prof2 -name "*.db" | head -1) 2>/dev/null | head -40 > gpurun_out/cfg2_kernel_stats.csv; head -4 gpurun_out/cfg2_kernel_stats.csv
+python tools/bench_potrf.py > gpurun_out/bench_potrf.txt 2>&1; cat gpurun_out/bench_potrf.txt
+(python tools/bench_bk.py nearpd 4845; python tools/bench_bk.py indef 5000) 2>&1 | grep device > gpurun_out/bench_bk.txt; cat gpurun_out/bench_bk.txt
