@@ -258,12 +258,32 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double
         double* vp = V + (long)p * ldv;
         double* vq = V + (long)q * ldv;
         double a = 0.0, b = 0.0, g = 0.0;
-        for (int r = sub; r < len; r += 32) {
-          const double x = vp[r], y = vq[r];
-          a = fma(x, x, a); b = fma(y, y, b); g = fma(x, y, g);
+        // columns of up to 128 entries stay in registers between the scalar products and the rotation (all LDS reads of the
+        // pair issued at once, none repeated); same sums in the same order as the loop form
+        const bool in_regs = (len <= 128);
+        double xr[4], yr[4];
+        if (in_regs) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int r = sub + 32 * k;
+            xr[k] = (r < len) ? vp[r] : 0.0;
+            yr[k] = (r < len) ? vq[r] : 0.0;
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { a = fma(xr[k], xr[k], a); b = fma(yr[k], yr[k], b); g = fma(xr[k], yr[k], g); }
+        } else {
+          for (int r = sub; r < len; r += 32) {
+            const double x = vp[r], y = vq[r];
+            a = fma(x, x, a); b = fma(y, y, b); g = fma(x, y, g);
+          }
         }
         a = jl_sum32(a); b = jl_sum32(b); g = jl_sum32(g);
-        if (fabs(g) <= tol_rot * sqrt(a * b) || g == 0.0 || fmin(a, b) <= floor2) continue;
+        // |g| <= tol sqrt(a b) compared on the squares (the double-precision square root expands to ~15 dependent operations in
+        // the middle of the round's critical path); outside the range where a b and g^2 are safely representable, as written
+        const double ab = a * b, g2 = g * g;
+        const bool sq_ok = ab > 1e-280 && ab < 1e280;
+        const bool tiny = sq_ok ? (g2 <= tol_rot * tol_rot * ab) : (fabs(g) <= tol_rot * sqrt(ab));
+        if (tiny || g == 0.0 || fmin(a, b) <= floor2) continue;
         // (outside the range where the seeds + Newton steps are safe -- g or zeta near the ends of the exponent range, which
         //  happens when columns of W are ~1e-150 at the end of a solve with a zero optimum -- the plain expansions are used)
         double cs, sn;
@@ -284,11 +304,22 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double
         if (!(cs == cs) || !(sn == sn)) continue;
         // a sweep whose rotated pairs all had a small cosine leaves cosines of the order of its square behind (below the
         // rotation threshold): it is the last one -- no further sweep just to find nothing to rotate
-        if (sub == 0 && ag > tol_big * sqrt(a * b)) rotated = 1;
-        for (int r = sub; r < len; r += 32) {
-          const double x = vp[r], y = vq[r];
-          vp[r] = cs * x - sn * y;
-          vq[r] = sn * x + cs * y;
+        if (sub == 0 && (sq_ok ? (g2 > tol_big * tol_big * ab) : (ag > tol_big * sqrt(ab)))) rotated = 1;
+        if (in_regs) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int r = sub + 32 * k;
+            if (r < len) {
+              vp[r] = cs * xr[k] - sn * yr[k];
+              vq[r] = sn * xr[k] + cs * yr[k];
+            }
+          }
+        } else {
+          for (int r = sub; r < len; r += 32) {
+            const double x = vp[r], y = vq[r];
+            vp[r] = cs * x - sn * y;
+            vq[r] = sn * x + cs * y;
+          }
         }
         if (Jg) {
           double* jp = J + (long)p * ldj;
