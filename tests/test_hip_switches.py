@@ -1,0 +1,55 @@
+"""The line search evaluates independent pieces of a candidate side by side on the two streams; every such
+path has a switch that restores the one-after-the-other form.  The switches are read once per process, so each setting runs in
+a process of its own; the solves must agree: same status, same iteration count, objective to the solver's own tolerance."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SNIPPET = r"""
+import json, sys
+sys.path.insert(0, %r)
+import hypatia_jl_amd as H
+from oracle import instances as I
+name = sys.argv[1]
+if name == "matrixcompletion":
+    inst = I.matrixcompletion(12, 20, seed=3)
+elif name == "polymin_primal":
+    inst = I.polymin(2, 3, True, seed=2)
+elif name == "polymin_dual":
+    inst = I.polymin(2, 3, False, seed=2)
+else:
+    inst = I.KNOWN_ANSWER[name]()
+s = H.Solver(default_tol_relax=10)
+s.load(H.make_model(inst))
+s.solve()
+print(json.dumps({"status": s.get_status(), "iters": s.get_num_iters(), "obj": s.get_primal_obj()}))
+"""
+
+
+def _run(name, env_extra):
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, "-c", SNIPPET % ROOT, name], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("name,switch", [
+    ("matrixcompletion", "HYP_ENS_PREFETCH"),            # dual decomposition on the helper stream next to the primal one
+    ("epinormspectral3_3x4_dual", "HYP_ENS_PREFETCH"),
+    ("polymin_primal", "HYP_WSOS_PAR"),                   # the K feasibility chains on both streams, one read-back
+    ("polymin_dual", "HYP_WSOS_PAR"),
+    ("wsosinterpnonnegative2", "HYP_WSOS_PAR"),
+])
+def test_side_by_side_candidate_evaluation_matches_sequential(name, switch):
+    on = _run(name, {switch: "1"})
+    off = _run(name, {switch: "0"})
+    assert on["status"] == off["status"] == "Optimal"
+    assert on["iters"] == off["iters"]
+    assert abs(on["obj"] - off["obj"]) <= 1e-6 * (1 + abs(off["obj"]))
