@@ -400,7 +400,8 @@ __global__ __launch_bounds__(256) void svd_finish_kernel(int len, const double* 
 // the d1 x d1 block of the closed-form inverse (one workgroup): R1 = U' R V1, r_u -> A1, a
 //   pairs i != j : A1_ij = z_i z_j / 2 * (u^2 R1_ij - s_i s_j R1_ji) / (u^4 - s_i^2 s_j^2)
 //   arrow        : c_i = 4 u s_i / z_i^2, d_i = 2 (u^2 + s_i^2) / z_i^2;
-//                  a = (r_u + sum c_i R1_ii / d_i) / (Huu - sum c_i^2 / d_i); A1_ii = (R1_ii + c_i a) / d_i
+//                  a = (r_u + sum c_i R1_ii / d_i) / S,  S = Huu - sum c_i^2 / d_i = sum 2 / (u^2 + s_i^2) - (d1 - 1) / u^2
+//                  (evaluated in the second, subtraction-free form); A1_ii = (R1_ii + c_i a) / d_i
 __global__ __launch_bounds__(256) void ens_closed_block_kernel(int d1, double u, double Huu, const double* __restrict__ sig, const double* __restrict__ R1,
                                                                const double* __restrict__ ru, double* __restrict__ A1, double* __restrict__ a_out) {
   __shared__ double red[2][256];
@@ -411,7 +412,12 @@ __global__ __launch_bounds__(256) void ens_closed_block_kernel(int d1, double u,
     const double si = sig[i], zi = u2 - si * si;
     const double ci = 4.0 * u * si / (zi * zi), di = 2.0 * (u2 + si * si) / (zi * zi);
     s0 += ci * R1[(long)i * d1 + i] / di;
-    s1 += ci * ci / di;
+    // the arrow's Schur complement Huu - sum c_i^2 / d_i WITHOUT the subtraction: with Huu = sum_i d_i - (d1 - 1) / u^2 (the
+    // barrier is -sum log(u^2 - s_i^2) + (d1 - 1) log u in these coordinates) and d_i^2 - c_i^2 = 4 / z_i^2, each term is
+    // d_i - c_i^2 / d_i = 2 / (u^2 + s_i^2).  Formed as written it is a difference of two numbers of size 1 / z^2 whose
+    // value is of size 1 / u^2: near the boundary every digit cancels (for d1 = 1 there is nothing else in the sum -- the
+    // 1 x 1 and 1 x 2 cones of tests/test_hip_solver.py::test_edge_case_models_hip ended in SlowProgress / NumericalFailure).
+    s1 += 2.0 / (u2 + si * si);
   }
   red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
   __syncthreads();
@@ -420,7 +426,8 @@ __global__ __launch_bounds__(256) void ens_closed_block_kernel(int d1, double u,
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    a_sh = (ru[0] + red[0][0]) / (Huu - red[1][0]);
+    (void)Huu;
+    a_sh = (ru[0] + red[0][0]) / (red[1][0] - (double)(d1 - 1) / u2);
     a_out[0] = a_sh;
   }
   __syncthreads();

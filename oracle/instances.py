@@ -533,6 +533,47 @@ MORE_NATIVE = {
 
 
 # ----------------------------------------------------------------------------------------------
+# Edge cases of our own (not from the reference's test set): shapes at the ends of the ranges the device code blocks by --
+# no free variables left after the equalities, cones of dimension one, a PSD side that crosses the 128-wide block size of
+# the factorization kernels next to tiny ones, a one-row spectral cone.  Answers are certified by the instance harness
+# (residuals, gap, cone membership by definition); the oracle and the HIP path must both pass.
+# ----------------------------------------------------------------------------------------------
+def edge_p_equals_n(seed=0):
+    rng = np.random.default_rng(seed)
+    n = 4
+    A = rng.standard_normal((n, n)) + 3 * np.eye(n)
+    x0 = rng.random(n) + 0.5
+    return (rng.random(n), A, A @ x0, -np.eye(n), np.zeros(n), [("nonnegative", n)], dict(status="Optimal", x=list(x0)))
+
+
+def edge_tiny_cones():
+    c = np.array([1.0, 1.0, 1.0, 0.5])
+    return (c, np.array([[1.0, 1, 1, 1]]), np.array([2.0]), -np.eye(4), np.zeros(4),
+            [("possemideftri", 1), ("nonnegative", 1), ("epinormspectral", 1, 1, False)], dict(status="Optimal", primal_obj=1.5))
+
+
+def edge_one_row_spectral(use_dual, seed=1):   # EpiNormSpectral(1, 7): the spectral norm of a row is its 2-norm, the nuclear norm too
+    rng = np.random.default_rng(seed)
+    w = rng.standard_normal(7)
+    G = np.zeros((8, 1))
+    G[0, 0] = -1.0
+    h = np.concatenate([[0.0], w])
+    return (np.array([1.0]), np.zeros((0, 1)), np.zeros(0), G, h, [("epinormspectral", 1, 7, use_dual)],
+            dict(status="Optimal", primal_obj=float(np.linalg.norm(w))))
+
+
+def edge_psd_ragged(seed=4):
+    return psd_blocks(24, [1, 2, 5, 17, 130], seed=seed)
+
+
+EDGE_CASES = {
+    "p_equals_n": edge_p_equals_n, "tiny_cones": edge_tiny_cones,
+    "one_row_spectral_primal": lambda: edge_one_row_spectral(False), "one_row_spectral_dual": lambda: edge_one_row_spectral(True),
+    "psd_ragged_sides": edge_psd_ragged,
+}
+
+
+# ----------------------------------------------------------------------------------------------
 # synthetic generators for the BASELINE.json configs
 # ----------------------------------------------------------------------------------------------
 def svec_identity(side):

@@ -55,6 +55,22 @@ def test_more_native_instances_hip(name):
     build_solve_check(H.Solver(**opts), H.make_model(inst), inst)
 
 
+def _edge_names():
+    from oracle import instances as I
+    return sorted(I.EDGE_CASES)
+
+
+@pytest.mark.parametrize("name", _edge_names())
+@pytest.mark.parametrize("reduce", [True, False])
+def test_edge_case_models_hip(name, reduce):
+    """shapes at the ends of the ranges through the HIP path: no free variable left after the equalities, cones of dimension one,
+    PSD sides 1 / 2 / 5 / 17 next to one that crosses the 128-wide blocks of the factorization kernels, a one-row spectral cone"""
+    import hypatia_jl_amd as H
+    from oracle import instances as I
+    inst = I.EDGE_CASES[name]()
+    build_solve_check(H.Solver(default_tol_relax=10, reduce=reduce), H.make_model(inst), inst)
+
+
 @pytest.mark.parametrize("maker", ["linearopt", "linearopt_large", "nonnegative1", "nonnegative2", "nonnegative3"])
 def test_lp_objective_matches_highs_hip(maker):
     """linear programs through the HIP path against an independent solver (scipy's HiGHS): config 1 of BASELINE.json

@@ -87,3 +87,10 @@ def test_lp_objective_matches_highs(maker):
     s = build_solve_check(Solver(default_tol_relax=10), make_model(inst), inst)
     ref = _highs_objective(inst) + inst[6].get("obj_offset", 0.0)
     assert abs(s.get_primal_obj() - ref) <= 1e-6 * (1 + abs(ref)), (s.get_primal_obj(), ref)
+
+
+@pytest.mark.parametrize("name", sorted(inst_mod.EDGE_CASES))
+def test_edge_case_models(name):
+    """shapes at the ends of the ranges (oracle/instances.py: EDGE_CASES): certified by residuals, gap and cone membership"""
+    inst = inst_mod.EDGE_CASES[name]()
+    build_solve_check(Solver(default_tol_relax=10), make_model(inst), inst)
