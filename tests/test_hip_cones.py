@@ -842,6 +842,36 @@ def test_epinormspectral_closed_form_inverse_hessian(d1, d2):
     assert rel(Hg, -np.array(hc.point)) <= 1e-9           # H^-1 g = -point (logarithmic homogeneity)
 
 
+@pytest.mark.parametrize("d1,d2", [(1, 1), (1, 2), (1, 7), (2, 2), (3, 5), (8, 12)])
+@pytest.mark.parametrize("margin", [1e-2, 1e-4, 1e-6])
+def test_epinormspectral_closed_form_inverse_near_the_boundary(d1, d2, margin):
+    """where an interior-point solve spends its last iterations: u = sigma_1 (1 + margin).  The Hessian has condition number
+    ~ 1 / margin^2 there, and a closed form that subtracts large numbers loses everything (the arrow system's Schur complement
+    did, for d1 = 1 completely): H^-1 g = -point must hold to eps * cond, and H (H^-1 v) = v likewise"""
+    import hypatia_jl_amd as H
+    hc = H.EpiNormSpectral(d1, d2)
+    dim = 1 + d1 * d2
+    rng = np.random.default_rng(7 * d1 + d2)
+    hc.setup_data()
+    Wm = rng.standard_normal((d1, d2))
+    Wm /= np.linalg.norm(Wm, 2)
+    pt = np.concatenate([[1.0 + margin], Wm.reshape(-1, order="F")])
+    hc.reset_data()
+    hc.load_point(pt)
+    assert hc.is_feas()
+    g = np.array(hc.get_grad())
+    Hg = np.zeros(dim)
+    hc.inv_hess_prod(Hg, g)
+    tol = 1e-12 / margin ** 2                                # eps * cond(H), with a little room
+    assert abs(Hg @ g - hc.get_nu()) <= tol * hc.get_nu(), (Hg @ g, hc.get_nu())
+    assert rel(Hg, -pt) <= tol, rel(Hg, -pt)
+    V = np.asfortranarray(rng.standard_normal((dim, 2)))
+    HV, back = np.zeros_like(V), np.zeros_like(V)
+    hc.hess_prod(HV, V)
+    hc.inv_hess_prod(back, HV)
+    assert rel(back, V) <= tol, rel(back, V)
+
+
 def test_epinormspectral_closed_form_inverse_at_the_initial_point_and_500x500():
     import hypatia_jl_amd as H
     c = H.EpiNormSpectral(3, 5)                              # W = 0: every singular value vanishes
@@ -870,3 +900,99 @@ def test_epinormspectral_closed_form_inverse_at_the_initial_point_and_500x500():
     big.inv_hess_prod(w, hv)
     assert rel(w, v) <= 1e-9
     assert big.check_numerics()
+
+
+# ---------------------------------------------------------------------------------------------
+# Every device cone close to the boundary of its cone -- where an interior-point solve spends its last iterations and where
+# closed forms that subtract large numbers fail first (the EpiNormSpectral arrow system did).  From the initial point along a
+# random direction, the step to the boundary is found by bisection on the cone's own feasibility test; at (1 - margin) of it the
+# identities of logarithmic homogeneity must hold to eps * cond(H) ~ eps / margin^2.
+# ---------------------------------------------------------------------------------------------
+def _boundary_cones():
+    import hypatia_jl_amd as H
+    from oracle import polyutils as pu
+    rng = np.random.default_rng(11)
+    U2, _, Ps2 = pu.interpolate_box([-1.0, -1.0], [1.0, 1.0], 2, sample=False)
+    U1, _, Ps1 = pu.interpolate_box([-1.0], [1.0], 2, sample=False)
+
+    def sym(n):
+        M = rng.standard_normal((n, n))
+        return M @ M.T + n * np.eye(n)
+
+    def herm(n):
+        M = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        A = M @ M.conj().T + n * np.eye(n)
+        return 0.5 * (A + A.conj().T)
+    return {
+        "nonnegative": lambda: H.Nonnegative(5),
+        "possemideftri": lambda: H.PosSemidefTri(15),
+        "possemideftri_complex": lambda: H.PosSemidefTriComplex(9),
+        "epinormspectral_2x3": lambda: H.EpiNormSpectral(2, 3),
+        "epinormspectral_dual_2x3": lambda: H.EpiNormSpectral(2, 3, use_dual=True),
+        "epinormspectral_complex_2x3": lambda: H.EpiNormSpectralComplex(2, 3),
+        "epinormspectral_complex_1x1": lambda: H.EpiNormSpectralComplex(1, 1),
+        "wsosinterpnonnegative": lambda: H.WSOSInterpNonnegative(U2, Ps2),
+        "wsosinterppossemideftri": lambda: H.WSOSInterpPosSemidefTri(2, U1, Ps1),
+        "linmatrixineq": lambda: H.LinMatrixIneq([sym(4), sym(4) - 3 * np.eye(4), rng.standard_normal((4, 4)) * 0 + np.diag(rng.standard_normal(4))]),
+        "linmatrixineq_complex": lambda: H.LinMatrixIneq([herm(3), herm(3) - 2 * np.eye(3)]),
+        "doublynonnegativetri": lambda: H.DoublyNonnegativeTri(10),
+        "hyporootdettri": lambda: H.HypoRootdetTri(1 + 6),
+        "hyporootdettri_dual": lambda: H.HypoRootdetTri(1 + 6, use_dual=True),
+        "hypoperlogdettri": lambda: H.HypoPerLogdetTri(2 + 6),
+        "hypoperlogdettri_dual": lambda: H.HypoPerLogdetTri(2 + 6, use_dual=True),
+        "hyporootdettri_complex": lambda: H.HypoRootdetTriComplex(1 + 9),
+        "hypoperlogdettri_complex": lambda: H.HypoPerLogdetTriComplex(2 + 9),
+    }
+
+
+@pytest.mark.parametrize("name", ["nonnegative", "possemideftri", "possemideftri_complex", "epinormspectral_2x3", "epinormspectral_dual_2x3",
+                                  "epinormspectral_complex_2x3", "epinormspectral_complex_1x1", "wsosinterpnonnegative",
+                                  "wsosinterppossemideftri", "linmatrixineq", "linmatrixineq_complex", "doublynonnegativetri", "hyporootdettri",
+                                  "hyporootdettri_dual", "hypoperlogdettri", "hypoperlogdettri_dual", "hyporootdettri_complex",
+                                  "hypoperlogdettri_complex"])
+@pytest.mark.parametrize("margin", [1e-2, 1e-4])
+def test_every_cone_near_its_boundary(name, margin):
+    cone = _boundary_cones()[name]()
+    dim = cone.dimension()
+    cone.setup_data()
+    cone.reset_data()
+    p0 = np.zeros(dim)
+    cone.set_initial_point(p0)
+    rng = np.random.default_rng(len(name))
+    for trial in range(3):
+        d = rng.standard_normal(dim)
+        d *= np.linalg.norm(p0) / np.linalg.norm(d)
+
+        def feas(t):
+            cone.reset_data()
+            cone.load_point(p0 + t * d)
+            return bool(cone.is_feas())
+        hi = 1.0
+        while feas(hi) and hi < 1e6:
+            hi *= 2.0
+        if hi >= 1e6:
+            continue                     # a recession direction of the cone: no boundary this way
+        lo = 0.0
+        for _ in range(60):
+            mid = 0.5 * (lo + hi)
+            lo, hi = (mid, hi) if feas(mid) else (lo, mid)
+        pt = p0 + (1.0 - margin) * lo * d
+        cone.reset_data()
+        cone.load_point(pt)
+        assert cone.is_feas()
+        nu = cone.get_nu()
+        g = np.array(cone.get_grad())
+        tol = 1e-11 / margin ** 2
+        assert abs(pt @ g + nu) <= 1e-9 * nu / margin, (name, pt @ g, nu)          # <point, grad> = -nu
+        Hp = np.zeros(dim)
+        cone.hess_prod(Hp, pt)
+        assert rel(Hp, -g) <= tol, (name, "H point = -grad", rel(Hp, -g))
+        Hg = np.zeros(dim)
+        cone.inv_hess_prod(Hg, g)
+        assert rel(Hg, -pt) <= tol, (name, "H^-1 grad = -point", rel(Hg, -pt))
+        assert abs(Hg @ g - nu) <= tol * nu, (name, Hg @ g, nu)
+        V = np.asfortranarray(rng.standard_normal((dim, 2)))
+        HV, back = np.zeros_like(V), np.zeros_like(V)
+        cone.hess_prod(HV, V)
+        cone.inv_hess_prod(back, HV)
+        assert rel(back, V) <= tol, (name, "H^-1 H v = v", rel(back, V))
