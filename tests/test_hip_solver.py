@@ -55,6 +55,42 @@ def test_more_native_instances_hip(name):
     build_solve_check(H.Solver(**opts), H.make_model(inst), inst)
 
 
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_random_mixed_cone_models_hip(seed):
+    """random strictly feasible models over a random mix of the device cones (tests/fuzz_models.py): one to four cones of random
+    kinds, sizes from dimension one, dual-barrier variants, zero to n - 1 equalities, also n > q.  The HIP solve must be Optimal with
+    the full certificate, and agree with the oracle's optimum"""
+    import hypatia_jl_amd as H
+    from fuzz_models import random_model
+    from oracle.build import make_cone as omake, make_model as omodel
+    from oracle.solvers import Solver as OSolver
+    inst = random_model(seed, omake)
+    s = build_solve_check(H.Solver(default_tol_relax=10), H.make_model(inst), inst)
+    o = OSolver(default_tol_relax=10)
+    o.load(omodel(inst))
+    o.solve()
+    assert o.get_status() == "Optimal"
+    assert abs(s.get_primal_obj() - o.get_primal_obj()) <= 1e-6 * (1 + abs(o.get_primal_obj())), (s.get_primal_obj(), o.get_primal_obj())
+    assert abs(s.get_num_iters() - o.get_num_iters()) <= 2, (s.get_num_iters(), o.get_num_iters())
+
+
+@pytest.mark.parametrize("seed", list(range(100, 112)))
+def test_random_mixed_cone_models_larger_hip(seed):
+    """the same with size ranges six times as wide (PSD sides to 41, spectral cones to 23 x 46, n to 48): past the 16-wide MFMA tiles
+    and, for some draws, the single-block paths of the factorization kernels"""
+    import hypatia_jl_amd as H
+    from fuzz_models import random_model
+    from oracle.build import make_cone as omake, make_model as omodel
+    from oracle.solvers import Solver as OSolver
+    inst = random_model(seed, omake, k=6)
+    s = build_solve_check(H.Solver(default_tol_relax=10), H.make_model(inst), inst)
+    o = OSolver(default_tol_relax=10)
+    o.load(omodel(inst))
+    o.solve()
+    assert o.get_status() == "Optimal"
+    assert abs(s.get_primal_obj() - o.get_primal_obj()) <= 1e-6 * (1 + abs(o.get_primal_obj())), (s.get_primal_obj(), o.get_primal_obj())
+
+
 def _edge_names():
     from oracle import instances as I
     return sorted(I.EDGE_CASES)

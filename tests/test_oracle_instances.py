@@ -94,3 +94,12 @@ def test_edge_case_models(name):
     """shapes at the ends of the ranges (oracle/instances.py: EDGE_CASES): certified by residuals, gap and cone membership"""
     inst = inst_mod.EDGE_CASES[name]()
     build_solve_check(Solver(default_tol_relax=10), make_model(inst), inst)
+
+
+@pytest.mark.parametrize("seed", list(range(0, 40, 2)))
+def test_random_mixed_cone_models(seed):
+    """random strictly feasible models over a random mix of cones (tests/fuzz_models.py) on the oracle: Optimal with the certificate"""
+    from fuzz_models import random_model
+    from oracle.build import make_cone
+    inst = random_model(seed, make_cone)
+    build_solve_check(Solver(default_tol_relax=10), make_model(inst), inst)
