@@ -566,7 +566,30 @@ def edge_psd_ragged(seed=4):
     return psd_blocks(24, [1, 2, 5, 17, 130], seed=seed)
 
 
+def edge_infeasible(which):
+    """one-cone models without a solution: the certificate statuses on the cones of the device path"""
+    if which == "psd_unbounded":        # min -tr X over X >= 0
+        return (np.array([-1.0, 0, -1.0]), np.zeros((0, 3)), np.zeros(0), -np.eye(3), np.zeros(3), [("possemideftri", 3)], dict(status="DualInfeasible"))
+    if which == "spectral_infeasible":  # u = -1 with u >= ||W||
+        return (np.zeros(5), np.array([[1.0, 0, 0, 0, 0]]), np.array([-1.0]), -np.eye(5), np.zeros(5), [("epinormspectral", 2, 2, False)],
+                dict(status="PrimalInfeasible"))
+    if which == "spectral_unbounded":   # min -u
+        return (np.array([-1.0, 0, 0, 0, 0]), np.zeros((0, 5)), np.zeros(0), -np.eye(5), np.zeros(5), [("epinormspectral", 2, 2, False)],
+                dict(status="DualInfeasible"))
+    if which == "rootdet_unbounded":    # max u under u <= rootdet(W), W free
+        return (np.array([-1.0, 0, 0, 0]), np.zeros((0, 4)), np.zeros(0), -np.eye(4), np.zeros(4), [("hyporootdettri", 4, False)],
+                dict(status="DualInfeasible"))
+    if which == "wsos_infeasible":      # the constant -1 is not a nonnegative polynomial
+        U, pts, Ps = pu.interpolate_box([-1.0], [1.0], 2)
+        return (np.zeros(1), np.zeros((0, 1)), np.zeros(0), np.zeros((U, 1)), -np.ones(U), [("wsosinterpnonnegative", U, Ps, False)],
+                dict(status="PrimalInfeasible"))
+    raise ValueError(which)
+
+
 EDGE_CASES = {
+    "psd_unbounded": lambda: edge_infeasible("psd_unbounded"), "spectral_infeasible": lambda: edge_infeasible("spectral_infeasible"),
+    "spectral_unbounded": lambda: edge_infeasible("spectral_unbounded"), "rootdet_unbounded": lambda: edge_infeasible("rootdet_unbounded"),
+    "wsos_infeasible": lambda: edge_infeasible("wsos_infeasible"),
     "p_equals_n": edge_p_equals_n, "tiny_cones": edge_tiny_cones,
     "one_row_spectral_primal": lambda: edge_one_row_spectral(False), "one_row_spectral_dual": lambda: edge_one_row_spectral(True),
     "psd_ragged_sides": edge_psd_ragged,
