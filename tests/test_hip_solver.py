@@ -91,6 +91,26 @@ def test_random_mixed_cone_models_larger_hip(seed):
     assert abs(s.get_primal_obj() - o.get_primal_obj()) <= 1e-6 * (1 + abs(o.get_primal_obj())), (s.get_primal_obj(), o.get_primal_obj())
 
 
+@pytest.mark.parametrize("seed", list(range(200, 216)))
+@pytest.mark.parametrize("options", ["qrchol_noreduce", "symindef", "symindef_nopreprocess"])
+def test_random_mixed_cone_models_other_option_sets_hip(seed, options):
+    """the random models under the reference's other option sets (test/runnativetests.jl:80-86, 101-118): QRChol without the
+    reduction, the device SymIndef solver with and without preprocessing -- independent routes to the same optimum"""
+    import hypatia_jl_amd as H
+    from fuzz_models import random_model
+    from oracle.build import make_cone as omake
+    inst = random_model(seed, omake, k=2)
+    ref = build_solve_check(H.Solver(default_tol_relax=10), H.make_model(inst), inst)
+    if options == "qrchol_noreduce":
+        sv = H.Solver(default_tol_relax=10, reduce=False)
+    elif options == "symindef":
+        sv = H.Solver(default_tol_relax=10, reduce=False, syssolver=H.SymIndefDenseSystemSolver())
+    else:
+        sv = H.Solver(default_tol_relax=10, reduce=False, preprocess=False, syssolver=H.SymIndefDenseSystemSolver())
+    got = build_solve_check(sv, H.make_model(inst), inst)
+    assert abs(got.get_primal_obj() - ref.get_primal_obj()) <= 1e-6 * (1 + abs(ref.get_primal_obj()))
+
+
 def _edge_names():
     from oracle import instances as I
     return sorted(I.EDGE_CASES)
