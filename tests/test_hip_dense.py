@@ -85,6 +85,26 @@ def test_potrf_large_lookahead_form(hip, n):
     assert np.array_equal(Ad, Ad2)
 
 
+@pytest.mark.parametrize("n", [127, 128, 129, 255, 257, 383, 385, 511, 512, 513, 640, 641, 767, 768, 769, 895, 1023, 1024, 1025, 1153, 1535, 1537])
+def test_posv_across_the_block_and_plan_thresholds(hip, n):
+    """sizes on either side of every switch of the factor / solve path: the 128-wide block, the 6-block look-ahead form (768), the
+    super-block solve plan (512) and its super-block sizes (ceil(n / 3 / 128) 128, capped at 1024).  Bar: LAPACK's backward error"""
+    import scipy.linalg as sla
+    lib, ctx, L = hip
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, n + 2))
+    A = np.asfortranarray(M @ M.T / n + 1e-3 * np.eye(n))
+    b = rng.standard_normal(n)
+    Ad, x, info = A.copy(order="F"), b.copy(), c_int(-1)
+    L.check(lib.hyp_dense_posv(ctx, n, fp(Ad), n, fp(x), ctypes.byref(info)), "posv")
+    assert info.value == 0
+    xref = sla.cho_solve(sla.cho_factor(A), b)
+    berr = lambda v: np.linalg.norm(A @ v - b) / (np.linalg.norm(A, 2) * np.linalg.norm(v) + np.linalg.norm(b))
+    assert berr(x) <= 4 * berr(xref) + 1e-16, (n, berr(x), berr(xref))
+    Uref = np.linalg.cholesky(A).T
+    assert np.allclose(np.triu(Ad), Uref, rtol=1e-8, atol=1e-10)
+
+
 def test_potrf_large_reports_failed_minor(hip):
     import scipy.linalg.lapack as lp
     lib, ctx, L = hip
