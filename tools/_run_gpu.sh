@@ -12,6 +12,8 @@ import json
 for l in open('gpurun_out/other_configs.jsonl'): d=json.loads(l); print(d['config']['workload'][:50], d['ms_per_step'])
 d=json.loads(open('gpurun_out/bench_cfg4_1gpu.json').read()); print('cfg4', d['ms_per_step'], d['roofline']['frac'])"
 rocprofv3 --kernel-trace --stats -d /tmp/prof2 -o b -- python bench.py --steps 40 > gpurun_out/bench_under_profiler.json 2>/dev/null
-python tools/rocpd_stats.py $(find /tmp/prof2 -name "*.db" | head -1) 2>/dev/null | head -40 > gpurun_out/cfg2_kernel_stats.csv; head -4 gpurun_out/cfg2_kernel_stats.csv
+DB2=$(find /tmp/prof2 -name "*.db" | head -1)
+python tools/rocpd_stats.py $DB2 2>/dev/null | head -40 > gpurun_out/cfg2_kernel_stats.csv; head -4 gpurun_out/cfg2_kernel_stats.csv
+ITER_BACK=3 python tools/rocpd_gaps.py $DB2 0 100000 > gpurun_out/iteration_timeline.txt 2>/dev/null; head -3 gpurun_out/iteration_timeline.txt
 python tools/bench_potrf.py > gpurun_out/bench_potrf.txt 2>&1; cat gpurun_out/bench_potrf.txt
 (python tools/bench_bk.py nearpd 4845; python tools/bench_bk.py indef 5000) 2>&1 | grep device > gpurun_out/bench_bk.txt; cat gpurun_out/bench_bk.txt
