@@ -30,17 +30,42 @@ def _spec(kind, rng, k=1):
             M = rng.standard_normal((side, side))
             As.append(0.5 * (M + M.T) + (side + 1.0) * np.eye(side) * (1.0 if i == 0 else 0.0))
         return ("linmatrixineq", As, bool(rng.integers(0, 2)))
+    if kind == "wsosinterpnonnegative":
+        from oracle import polyutils as pu
+        nv, hd = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+        U, _, Ps = pu.interpolate_box([-1.0] * nv, [1.0] * nv, hd, sample=False)
+        return ("wsosinterpnonnegative", U, Ps, bool(rng.integers(0, 2)))
+    if kind == "wsosinterppossemideftri":
+        from oracle import polyutils as pu
+        U, _, Ps = pu.interpolate_box([-1.0], [1.0], int(rng.integers(1, 3)), sample=False)
+        return ("wsosinterppossemideftri", int(rng.integers(1, 4)), U, Ps, bool(rng.integers(0, 2)))
+    if kind == "possemideftri_complex":
+        s = int(rng.integers(1, 5 * k))
+        return ("possemideftri_complex", s * s)
+    if kind == "epinormspectral_complex":
+        d1 = int(rng.integers(1, 3 * k))
+        return ("epinormspectral_complex", d1, d1 + int(rng.integers(0, 3 * k)), bool(rng.integers(0, 2)))
+    if kind == "hyporootdettri_complex":
+        s = int(rng.integers(1, 4 * k))
+        return ("hyporootdettri_complex", 1 + s * s, bool(rng.integers(0, 2)))
+    if kind == "hypoperlogdettri_complex":
+        s = int(rng.integers(1, 4 * k))
+        return ("hypoperlogdettri_complex", 2 + s * s, bool(rng.integers(0, 2)))
     raise ValueError(kind)
 
 
+ALL_KINDS = ["nonnegative", "possemideftri", "epinormspectral", "doublynonnegativetri", "hyporootdettri", "hypoperlogdettri", "linmatrixineq",
+             "wsosinterpnonnegative", "wsosinterppossemideftri", "possemideftri_complex", "epinormspectral_complex", "hyporootdettri_complex",
+             "hypoperlogdettri_complex"]
 KINDS = ["nonnegative", "possemideftri", "epinormspectral", "doublynonnegativetri", "hyporootdettri", "hypoperlogdettri", "linmatrixineq"]
 
 
-def random_model(seed, make_cone, k=1):
+def random_model(seed, make_cone, k=1, kinds=None):
     """-> instance tuple (c, A, b, G, h, specs, expect); make_cone builds a cone object (oracle or HIP) from a spec"""
     rng = np.random.default_rng(seed)
     ncones = int(rng.integers(1, 5))
-    specs = [_spec(KINDS[int(rng.integers(0, len(KINDS)))], rng, k) for _ in range(ncones)]
+    kinds = kinds or KINDS
+    specs = [_spec(kinds[int(rng.integers(0, len(kinds)))], rng, k) for _ in range(ncones)]
     s0, z0 = [], []
     for sp in specs:
         cone = make_cone(sp)

@@ -111,6 +111,22 @@ def test_random_mixed_cone_models_other_option_sets_hip(seed, options):
     assert abs(got.get_primal_obj() - ref.get_primal_obj()) <= 1e-6 * (1 + abs(ref.get_primal_obj()))
 
 
+@pytest.mark.parametrize("seed,k", [(s, 1) for s in range(300, 340)] + [(s, 3) for s in range(400, 412)])
+def test_random_models_over_all_device_cones_hip(seed, k):
+    """the random models drawn from ALL cone kinds of the device path: the WSOS cones and the complex Hermitian variants included"""
+    import hypatia_jl_amd as H
+    from fuzz_models import random_model, ALL_KINDS
+    from oracle.build import make_cone as omake, make_model as omodel
+    from oracle.solvers import Solver as OSolver
+    inst = random_model(seed, omake, k=k, kinds=ALL_KINDS)
+    s = build_solve_check(H.Solver(default_tol_relax=10), H.make_model(inst), inst)
+    o = OSolver(default_tol_relax=10)
+    o.load(omodel(inst))
+    o.solve()
+    assert o.get_status() == "Optimal"
+    assert abs(s.get_primal_obj() - o.get_primal_obj()) <= 1e-6 * (1 + abs(o.get_primal_obj())), (s.get_primal_obj(), o.get_primal_obj())
+
+
 def _edge_names():
     from oracle import instances as I
     return sorted(I.EDGE_CASES)
