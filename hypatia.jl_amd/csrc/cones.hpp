@@ -79,6 +79,11 @@ struct Cone {
   // queued into d_out3 (device) without a synchronisation, so that a sweep over many cones reads them all back at once;
   // false: no usable inverse Hessian (the caller counts the cone as failed).  Cones with their own get_proxsqr opt out.
   virtual bool prox_batchable() { return true; }
+  // A cheap LOWER bound of the proximity value <v, H^-1 v>, v = irtmu dual + g, that needs no factorization at this point:
+  // by Cauchy-Schwarz in the H inner product <v, H^-1 v> >= <v, w>^2 / <w, H w> for every w.  A candidate whose bound already
+  // exceeds the neighbourhood is rejected exactly as the reference rejects it (its value is at least the bound); anything else
+  // goes on to the real test.  false: no bound available (default).
+  virtual bool prox_lower_bound(double irtmu, double* lb) { (void)irtmu; (void)lb; return false; }
   bool prox_launch(double irtmu, double* d_out3);
   // false when inv_hess_prod has no usable factorization at this point (generic cones whose explicit
   // Hessian fails both its Cholesky and its Bunch-Kaufman factorization, Cones.jl:239-251: the
@@ -223,6 +228,8 @@ struct WsosCone : GenericHessCone {   // src/Cones/wsosinterpnonnegative.jl (rea
   void hess_prod_slow(double* prod, long ldp, const double* arr, long lda, int ncols) override;   // :152-175
   const double* dder3(const double* d_dir) override;                                               // :177-188
   void partial_lambda(int k, const double* d_dir);                                                 // :190-200 -> LU[k]
+  void lambda_of(int k, const double* d_dir);                                                      // its first half -> LL[k] (symmetric)
+  bool prox_lower_bound(double irtmu, double* lb) override;
 };
 
 struct LmiCone : GenericHessCone {   // src/Cones/linmatrixineq.jl (real dense symmetric members; complex Hermitian members embedded)

@@ -863,6 +863,14 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
   if (batched_prox) {
     for (size_t k = 0; k < nc && ok; ++k)
       if (!(cones[k]->is_feas() && cones[k]->is_dual_feas())) ok = false;          // (answered by the prefetch above)
+    // candidates far outside the neighbourhood: rejected on a lower bound of the proximity value, before any Hessian is
+    // assembled or factored for them (Cone::prox_lower_bound; single process only -- sharded ranks leave together below)
+    if (ok && !dist()) {
+      for (size_t k = 0; k < nc && ok; ++k) {
+        double lb = 0.0;
+        if (cones[k]->prox_lower_bound(irtmu, &lb) && lb > proxsqr_bound * (1.0 + 1e-9)) ok = false;
+      }
+    }
     if (ok) {
       group_inverses();   // runs of equal PSD cones: U^-1, X^-1 of all members in one batched launch sequence
       const double gtol = std::sqrt(std::sqrt(EPS)), Htol = 10 * std::sqrt(gtol), negtol = std::sqrt(EPS);

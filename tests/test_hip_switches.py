@@ -24,6 +24,10 @@ elif name == "polymin_primal":
     inst = I.polymin(2, 3, True, seed=2)
 elif name == "polymin_dual":
     inst = I.polymin(2, 3, False, seed=2)
+elif name == "polymin_large_primal":
+    inst = I.polymin(3, 7, True, seed=3)     # U = binomial(17, 3) = 680
+elif name == "polymin_large_dual":
+    inst = I.polymin(3, 7, False, seed=3)
 else:
     inst = I.KNOWN_ANSWER[name]()
 s = H.Solver(default_tol_relax=10)
@@ -46,6 +50,8 @@ def _run(name, env_extra):
     ("polymin_primal", "HYP_WSOS_PAR"),                   # the K feasibility chains on both streams, one read-back
     ("polymin_dual", "HYP_WSOS_PAR"),
     ("wsosinterpnonnegative2", "HYP_WSOS_PAR"),
+    ("polymin_large_primal", "HYP_PROX_LB"),              # candidates rejected on a lower bound of the proximity value (U = 680 >= 512)
+    ("polymin_large_dual", "HYP_PROX_LB"),
 ])
 def test_side_by_side_candidate_evaluation_matches_sequential(name, switch):
     on = _run(name, {switch: "1"})
