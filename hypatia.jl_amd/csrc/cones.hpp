@@ -84,6 +84,9 @@ struct Cone {
   // exceeds the neighbourhood is rejected exactly as the reference rejects it (its value is at least the bound); anything else
   // goes on to the real test.  false: no bound available (default).
   virtual bool prox_lower_bound(double irtmu, double* lb) { (void)irtmu; (void)lb; return false; }
+  // The same idea one step earlier, for cones whose feasibility tests themselves are expensive: called right after a candidate
+  // is loaded, before prefetch_feas; true = the candidate is certainly rejected (primal infeasible, or the proximity bound).
+  virtual bool early_reject(double irtmu, double bound2) { (void)irtmu; (void)bound2; return false; }
   bool prox_launch(double irtmu, double* d_out3);
   // false when inv_hess_prod has no usable factorization at this point (generic cones whose explicit
   // Hessian fails both its Cholesky and its Bunch-Kaufman factorization, Cones.jl:239-251: the
@@ -352,6 +355,9 @@ struct EpiNormSpectralCone : GenericHessCone {   // src/Cones/epinormspectral.jl
   double nuclear_norm(const double* d_mat /* d1 x d2 col-major */);
   void nuclear_norm_launch(const double* d_mat, double* d_out);
   void prefetch_feas() override;
+  bool early_reject(double irtmu, double bound2) override;
+  void closed_inv_apply(double u_used, double* prod, long ldp, const double* arr, long lda, int ncols);
+  double u_svd = 0;           // the epigraph variable of the point Usvd / sig / V1 belong to
   // Closed-form inverse Hessian (NOT in this Hypatia version, whose inv_hess_prod! is the generic explicit-Hessian
   // Cholesky of Cones.jl:113-118): with W = U S V1' the Hessian of epinormspectral.jl:211-239 decouples in the rotated
   // coordinates U' A [V1 V2] into 2 x 2 blocks over the index pairs (i, j), (j, i), a diagonal scaling on the V2 part and an

@@ -854,8 +854,9 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
     ck->load_point((ck->use_dual_barrier ? dz : dsv), irtmu);
     ck->load_dual_point((ck->use_dual_barrier ? dsv : dz));
     ck->reset_data();
-    ck->prefetch_feas();
     *n_loaded = 1;
+    if (!dist() && ck->early_reject(irtmu, proxsqr_bound)) return false;   // (before the cone's feasibility work is queued)
+    ck->prefetch_feas();
     single_loaded = true;
   }
   bool batched_prox = ((nc > 1 || single_loaded) && !local_reject);

@@ -50,6 +50,8 @@ def _run(name, env_extra):
     ("polymin_primal", "HYP_WSOS_PAR"),                   # the K feasibility chains on both streams, one read-back
     ("polymin_dual", "HYP_WSOS_PAR"),
     ("wsosinterpnonnegative2", "HYP_WSOS_PAR"),
+    ("matrixcompletion", "HYP_PROX_LB"),                  # EpiNormSpectral: rejected before either decomposition is started
+    ("epinormspectral3_3x4_dual", "HYP_PROX_LB"),
     ("polymin_large_primal", "HYP_PROX_LB"),              # candidates rejected on a lower bound of the proximity value (U = 680 >= 512)
     ("polymin_large_dual", "HYP_PROX_LB"),
 ])
