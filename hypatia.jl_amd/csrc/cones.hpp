@@ -222,7 +222,7 @@ struct WsosCone : GenericHessCone {   // src/Cones/wsosinterpnonnegative.jl (rea
   int U, K;
   std::vector<int> Ls;
   std::vector<DBuf> P, PT, SP, Lam, LamDinv, LFLP, LFLPT, LU, LL;   // per k
-  DBuf tmpUU, infos;
+  DBuf tmpUU, infos, gparts, trsm_work2;
   WsosCone(Ctx& c, int U, int K, const int* Ls, const double* const* hPs, bool use_dual);
   bool update_feas() override;
   void update_grad() override;

@@ -276,7 +276,53 @@ bool WsosCone::update_feas() {   // :89-117
   return is_feas_;
 }
 
+// out[j] = sum_k parts[k * n + j], k ascending (the order in which the one-stream form accumulates)
+__global__ void sum_parts_kernel(int n, int K, const double* __restrict__ parts, double* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double s = parts[j];
+  for (int k = 1; k < K; ++k) s += parts[(long)k * n + j];
+  out[j] = s;
+}
+
 void WsosCone::update_grad() {   // :119-133
+  // the K chains (triangular solve of P_k' against Lambda_k's factor, column norms, transpose) are independent and short: on the
+  // two streams like the feasibility chains, each with a work space and a partial gradient of its own; the partial gradients
+  // are then added in the order of k, which is the order the one-stream form accumulates in (same bits)
+  static const bool par = [] { const char* e = getenv("HYP_WSOS_PAR"); return !(e && e[0] == '0'); }();
+  if (par && K >= 2 && K <= 64) {
+    gparts.ensure((size_t)K * U * sizeof(double));
+    trsm_work.ensure((size_t)NB * U * sizeof(double));
+    trsm_work2.ensure((size_t)NB * U * sizeof(double));
+    hipEvent_t e0 = ctx.aux_event(2);
+    HYP_CHECK(hipEventRecord(e0, ctx.stream));
+    HYP_CHECK(hipStreamWaitEvent(ctx.stream2, e0, 0));
+    int load[2] = {0, 0};
+    for (int k = 0; k < K; ++k) {
+      const int Lk = Ls[k];
+      const int side = (load[1] < load[0]) ? 1 : 0;
+      load[side] += (Lk + NB - 1) / NB;
+      auto chain = [&](double* work) {
+        ctx.d2d(LFLP[k].p, PT[k].p, (size_t)U * Lk * sizeof(double));
+        trsm_upper_left(ctx, Lk, U, Lam[k].d(), Lk, LamDinv[k].d(), true, LFLP[k].d(), Lk, work);
+        col_dot(ctx, Lk, U, LFLP[k].d(), Lk, LFLP[k].d(), Lk, -1.0, false, gparts.d() + (long)k * U);
+        dev_transpose(ctx, Lk, U, LFLP[k].d(), Lk, LFLPT[k].d(), U, 1, 0, 0);
+      };
+      if (side == 1) {
+        StreamSwap on_helper(ctx);
+        chain(trsm_work2.d());
+      } else {
+        chain(trsm_work.d());
+      }
+    }
+    hipEvent_t e1 = ctx.aux_event(3);
+    HYP_CHECK(hipEventRecord(e1, ctx.stream2));
+    HYP_CHECK(hipStreamWaitEvent(ctx.stream, e1, 0));
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((U + 255) / 256), dim3(256), 0, ctx.stream, U, K, gparts.d(), grad.d());
+    HYP_CHECK(hipGetLastError());
+    grad_updated = true;
+    return;
+  }
   for (int k = 0; k < K; ++k) {
     const int Lk = Ls[k];
     // LFLP_k = L_k^-1 P_k' = U_k'^-1 P_k'   (L_k x U)
@@ -332,9 +378,22 @@ bool WsosCone::prox_lower_bound(double irtmu, double* lb) {
   Hplan.solve(ctx, Hfact.d(), dim, false, vec2.d());                 // w
   double* ds = ctx.dscal.d() + 44;
   dev_dot(ctx, dim, vec1.d(), vec2.d(), ds);
-  for (int k = 0; k < K; ++k) {
-    lambda_of(k, vec2.d());
-    dev_dot(ctx, Ls[k] * Ls[k], LL[k].d(), LL[k].d(), ds + 1 + k);
+  {   // the K Gram products on the two streams (buffers per k)
+    hipEvent_t e0 = ctx.aux_event(2), e1 = ctx.aux_event(3);
+    HYP_CHECK(hipEventRecord(e0, ctx.stream));
+    HYP_CHECK(hipStreamWaitEvent(ctx.stream2, e0, 0));
+    for (int k = 0; k < K; ++k) {
+      if (k & 1) {
+        StreamSwap on_helper(ctx);
+        lambda_of(k, vec2.d());
+        dev_dot(ctx, Ls[k] * Ls[k], LL[k].d(), LL[k].d(), ds + 1 + k);
+      } else {
+        lambda_of(k, vec2.d());
+        dev_dot(ctx, Ls[k] * Ls[k], LL[k].d(), LL[k].d(), ds + 1 + k);
+      }
+    }
+    HYP_CHECK(hipEventRecord(e1, ctx.stream2));
+    HYP_CHECK(hipStreamWaitEvent(ctx.stream, e1, 0));
   }
   ctx.d2h(ctx.h_pinned + 44, ds, (size_t)(1 + K) * sizeof(double));
   ctx.sync();
