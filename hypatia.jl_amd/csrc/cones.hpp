@@ -222,7 +222,8 @@ struct WsosCone : GenericHessCone {   // src/Cones/wsosinterpnonnegative.jl (rea
   int U, K;
   std::vector<int> Ls;
   std::vector<DBuf> P, PT, SP, Lam, LamDinv, LFLP, LFLPT, LU, LL;   // per k
-  DBuf tmpUU, infos, gparts, trsm_work2;
+  DBuf tmpUU, infos, gparts, trsm_work2, LamArena;
+  bool lam_dinv_ready = false;   // LamDinv holds the inverted diagonal blocks of the CURRENT factors Lam (formed with the gradient)
   WsosCone(Ctx& c, int U, int K, const int* Ls, const double* const* hPs, bool use_dual);
   bool update_feas() override;
   void update_grad() override;

@@ -200,11 +200,17 @@ WsosCone::WsosCone(Ctx& c, int U_, int K_, const int* Ls_, const double* const* 
   alloc_common();
   alloc_generic();
   infos.alloc(64 * sizeof(int));
+  size_t lam_total = 0;
+  for (int k = 0; k < K; ++k) lam_total += (((size_t)Ls[k] * Ls[k] + 1) & ~(size_t)1);   // (every matrix 16-byte aligned)
+  LamArena.alloc(lam_total * sizeof(double));   // the Lambda_k back to back: runs of equal L_k factor as ONE batched Cholesky
+  size_t lam_off = 0;
   for (int k = 0; k < K; ++k) {
     const int Lk = Ls[k];
     const size_t pb = (size_t)U * Lk * sizeof(double);
     P.emplace_back(pb); PT.emplace_back(pb); SP.emplace_back(pb); LFLP.emplace_back(pb); LFLPT.emplace_back(pb); LU.emplace_back(pb);
-    Lam.emplace_back((size_t)Lk * Lk * sizeof(double));
+    Lam.emplace_back();
+    Lam.back().view(LamArena.d() + lam_off, (size_t)Lk * Lk * sizeof(double));
+    lam_off += (((size_t)Lk * Lk + 1) & ~(size_t)1);
     LL.emplace_back((size_t)Lk * Lk * sizeof(double));
     LamDinv.emplace_back(dinv_elems(Lk) * sizeof(double));
     ctx.h2d(P[k].p, hPs[k], pb);
@@ -230,18 +236,26 @@ bool WsosCone::update_feas() {   // :89-117
     hipEvent_t e0 = ctx.aux_event(2);
     HYP_CHECK(hipEventRecord(e0, ctx.stream));                 // (the point was loaded on the main stream)
     HYP_CHECK(hipStreamWaitEvent(ctx.stream2, e0, 0));
+    // runs of equal L_k (the weighted bases of a box domain all have the same size) factor as one BATCHED Cholesky: the
+    // latency of one chain for the whole run.  Groups are dealt out to the two streams by accumulated latency.
     int load[2] = {0, 0};
-    for (int k = 0; k < K; ++k) {
-      const int Lk = Ls[k];
+    for (int k0 = 0; k0 < K;) {
+      const int Lk = Ls[k0];
+      int cnt = 1;
+      while (k0 + cnt < K && Ls[k0 + cnt] == Lk) ++cnt;
       const int side = (load[1] < load[0]) ? 1 : 0;
-      load[side] += (Lk + NB - 1) / NB;
+      load[side] += (Lk + NB - 1) / NB + cnt;
       auto chain = [&] {
-        row_scale(ctx, U, Lk, point.d(), P[k].d(), U, SP[k].d(), U);
-        GemmArgs g{};
-        g.M = Lk; g.N = Lk; g.K = U; g.A = SP[k].d(); g.lda = U; g.B = P[k].d(); g.ldb = U; g.C = Lam[k].d(); g.ldc = Lk;
-        g.alpha = 1; g.beta = 0; g.tri = GEMM_UPPER; g.batch = 1;
-        gemm(ctx, true, g);
-        potrf_upper_batched(ctx, Lk, Lam[k].d(), Lk, 0, 1, LamDinv[k].d(), infos.i() + k);
+        for (int k = k0; k < k0 + cnt; ++k) {
+          row_scale(ctx, U, Lk, point.d(), P[k].d(), U, SP[k].d(), U);
+          GemmArgs g{};
+          g.M = Lk; g.N = Lk; g.K = U; g.A = SP[k].d(); g.lda = U; g.B = P[k].d(); g.ldb = U; g.C = Lam[k].d(); g.ldc = Lk;
+          g.alpha = 1; g.beta = 0; g.tri = GEMM_UPPER; g.batch = 1;
+          gemm(ctx, true, g);
+        }
+        // (factor only: the inverted diagonal blocks the gradient's triangular solves use are formed there -- a candidate that
+        //  fails this test, the usual fate of the first steps of the schedule, never needs them)
+        potrf_upper_batched(ctx, Lk, Lam[k0].d(), Lk, (long)(((size_t)Lk * Lk + 1) & ~(size_t)1), cnt, nullptr, infos.i() + k0);
       };
       if (side == 1) {
         StreamSwap on_helper(ctx);
@@ -249,6 +263,7 @@ bool WsosCone::update_feas() {   // :89-117
       } else {
         chain();
       }
+      k0 += cnt;
     }
     hipEvent_t e1 = ctx.aux_event(3);
     HYP_CHECK(hipEventRecord(e1, ctx.stream2));
@@ -259,9 +274,11 @@ bool WsosCone::update_feas() {   // :89-117
     for (int k = 0; k < K; ++k)
       if (ctx.h_info[64 + k] != 0) is_feas_ = false;
     feas_updated = true;
+    lam_dinv_ready = false;
     return is_feas_;
   }
   is_feas_ = true;
+  lam_dinv_ready = true;
   for (int k = 0; k < K && is_feas_; ++k) {
     const int Lk = Ls[k];
     row_scale(ctx, U, Lk, point.d(), P[k].d(), U, SP[k].d(), U);           // diag(pt) P_k
@@ -303,6 +320,7 @@ void WsosCone::update_grad() {   // :119-133
       const int side = (load[1] < load[0]) ? 1 : 0;
       load[side] += (Lk + NB - 1) / NB;
       auto chain = [&](double* work) {
+        if (!lam_dinv_ready) potrf_invert_diag_blocks(ctx, Lk, Lam[k].d(), Lk, 0, 1, LamDinv[k].d());
         ctx.d2d(LFLP[k].p, PT[k].p, (size_t)U * Lk * sizeof(double));
         trsm_upper_left(ctx, Lk, U, Lam[k].d(), Lk, LamDinv[k].d(), true, LFLP[k].d(), Lk, work);
         col_dot(ctx, Lk, U, LFLP[k].d(), Lk, LFLP[k].d(), Lk, -1.0, false, gparts.d() + (long)k * U);
@@ -320,10 +338,12 @@ void WsosCone::update_grad() {   // :119-133
     HYP_CHECK(hipStreamWaitEvent(ctx.stream, e1, 0));
     hipLaunchKernelGGL(sum_parts_kernel, dim3((U + 255) / 256), dim3(256), 0, ctx.stream, U, K, gparts.d(), grad.d());
     HYP_CHECK(hipGetLastError());
+    lam_dinv_ready = true;
     grad_updated = true;
     return;
   }
   for (int k = 0; k < K; ++k) {
+    if (!lam_dinv_ready) potrf_invert_diag_blocks(ctx, Ls[k], Lam[k].d(), Ls[k], 0, 1, LamDinv[k].d());
     const int Lk = Ls[k];
     // LFLP_k = L_k^-1 P_k' = U_k'^-1 P_k'   (L_k x U)
     ctx.d2d(LFLP[k].p, PT[k].p, (size_t)U * Lk * sizeof(double));
@@ -332,6 +352,7 @@ void WsosCone::update_grad() {   // :119-133
     col_dot(ctx, Lk, U, LFLP[k].d(), Lk, LFLP[k].d(), Lk, -1.0, k > 0, grad.d());     // grad_j -= ||LFLP_k[:, j]||^2
     dev_transpose(ctx, Lk, U, LFLP[k].d(), Lk, LFLPT[k].d(), U, 1, 0, 0);
   }
+  lam_dinv_ready = true;
   grad_updated = true;
 }
 
