@@ -864,12 +864,16 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
   if (batched_prox) {
     for (size_t k = 0; k < nc && ok; ++k)
       if (!(cones[k]->is_feas() && cones[k]->is_dual_feas())) ok = false;          // (answered by the prefetch above)
+    static const bool tdbg = [] { const char* e = getenv("HYP_TRIAL_DBG"); return e && e[0] == '1'; }();
+    if (tdbg && !ok) fprintf(stderr, "[trial] infeasible\n");
     // candidates far outside the neighbourhood: rejected on a lower bound of the proximity value, before any Hessian is
     // assembled or factored for them (Cone::prox_lower_bound; single process only -- sharded ranks leave together below)
     if (ok && !dist()) {
       for (size_t k = 0; k < nc && ok; ++k) {
         double lb = 0.0;
-        if (cones[k]->prox_lower_bound(irtmu, &lb) && lb > proxsqr_bound * (1.0 + 1e-9)) ok = false;
+        const bool have = cones[k]->prox_lower_bound(irtmu, &lb);
+        if (have && lb > proxsqr_bound * (1.0 + 1e-9)) ok = false;
+        if (tdbg) fprintf(stderr, "[trial] bound %s %.4g (limit %.4g)%s\n", have ? "=" : "n/a", lb, proxsqr_bound, ok ? "" : " -> rejected");
       }
     }
     if (ok) {
