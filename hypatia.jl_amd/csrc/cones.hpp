@@ -83,7 +83,8 @@ struct Cone {
   // by Cauchy-Schwarz in the H inner product <v, H^-1 v> >= <v, w>^2 / <w, H w> for every w.  A candidate whose bound already
   // exceeds the neighbourhood is rejected exactly as the reference rejects it (its value is at least the bound); anything else
   // goes on to the real test.  false: no bound available (default).
-  virtual bool prox_lower_bound(double irtmu, double* lb) { (void)irtmu; (void)lb; return false; }
+  // `limit`: the value beyond which the candidate is rejected -- an implementation may stop refining its bound once it is passed.
+  virtual bool prox_lower_bound(double irtmu, double limit, double* lb) { (void)irtmu; (void)limit; (void)lb; return false; }
   // The same idea one step earlier, for cones whose feasibility tests themselves are expensive: called right after a candidate
   // is loaded, before prefetch_feas; true = the candidate is certainly rejected (primal infeasible, or the proximity bound).
   virtual bool early_reject(double irtmu, double bound2) { (void)irtmu; (void)bound2; return false; }
@@ -233,7 +234,10 @@ struct WsosCone : GenericHessCone {   // src/Cones/wsosinterpnonnegative.jl (rea
   const double* dder3(const double* d_dir) override;                                               // :177-188
   void partial_lambda(int k, const double* d_dir);                                                 // :190-200 -> LU[k]
   void lambda_of(int k, const double* d_dir);                                                      // its first half -> LL[k] (symmetric)
-  bool prox_lower_bound(double irtmu, double* lb) override;
+  bool prox_lower_bound(double irtmu, double limit, double* lb) override;
+  void gram_norms(const double* d_dir, double* d_out);     // d_out[k] = || LFLP_k diag(dir) LFLP_k' ||_F^2 (LL[k] left in place), both streams
+  void hess_vec_from_LL(double* d_out);                    // H dir from the LL[k] of the last gram_norms(dir): sum_k diag(LFLP_k' LL_k LFLP_k)
+  DBuf lbP, lbHP, lbR;
 };
 
 struct LmiCone : GenericHessCone {   // src/Cones/linmatrixineq.jl (real dense symmetric members; complex Hermitian members embedded)

@@ -871,7 +871,7 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
     if (ok && !dist()) {
       for (size_t k = 0; k < nc && ok; ++k) {
         double lb = 0.0;
-        const bool have = cones[k]->prox_lower_bound(irtmu, &lb);
+        const bool have = cones[k]->prox_lower_bound(irtmu, proxsqr_bound * (1.0 + 1e-9), &lb);
         if (have && lb > proxsqr_bound * (1.0 + 1e-9)) ok = false;
         if (tdbg) fprintf(stderr, "[trial] bound %s %.4g (limit %.4g)%s\n", have ? "=" : "n/a", lb, proxsqr_bound, ok ? "" : " -> rejected");
       }
