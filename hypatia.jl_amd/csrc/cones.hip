@@ -294,6 +294,53 @@ void PsdCone::prefetch_feas() {
   prefetch_finish(0);
 }
 
+// sum over the svec entries of (scal * t_i - e_i)^2, e = svec(I): || scal T - I ||_F^2 for T = smat(t) (the sqrt(2) scaling of
+// the off-diagonal svec entries makes the svec 2-norm the Frobenius norm); one workgroup
+__global__ __launch_bounds__(1024) void psd_prox_direct_kernel(int side, const double* __restrict__ t, double scal, double* __restrict__ out) {
+  __shared__ double red[1024];
+  const int dim = side * (side + 1) / 2;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < dim; i += 1024) {
+    // svec index i = column j, row r (r <= j) with i = j (j + 1) / 2 + r: the diagonal entries sit at j (j + 3) / 2
+    int j = (int)((sqrt(8.0 * (double)i + 1.0) - 1.0) * 0.5);
+    while ((long)(j + 1) * (j + 2) / 2 <= i) ++j;
+    while ((long)j * (j + 1) / 2 > i) --j;
+    const bool diag = (i == j * (j + 3) / 2);
+    const double v = scal * t[i] - (diag ? 1.0 : 0.0);
+    s = fma(v, v, s);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// For this cone the proximity value has a form that needs no inverse: with X = U'U, g = -svec(X^-1) and H^-1 v = X V X,
+//   <v, H^-1 v> = tr(V X V X) = || U V U' ||_F^2,  V = Z / sqrt(mu) - X^-1  =>  U V U' = U Z U' / sqrt(mu) - I,
+// one two-sided product of the dual point with the factor the feasibility test left behind.  The reference's route -- inverse of
+// U, X^-1, gradient, two more two-sided products -- gives the same number up to rounding; a candidate for which this one is
+// beyond the neighbourhood by more than that (1e-6 relative) is rejected here, every other one goes the reference's way.
+bool PsdCone::prox_lower_bound(double irtmu, double limit, double* lb) {
+  static const bool on = [] { const char* e = getenv("HYP_PROX_LB"); return !(e && e[0] == '0'); }();
+  if (!on || !feas_updated || !is_feas_ || inv_ready || side < 32) return false;
+  (void)limit;
+  dev_zero_strict_lower(ctx, side, U.d(), side, 1, 0);
+  dev_transpose(ctx, side, side, U.d(), side, UT.d(), side, 1, 0, 0);
+  two_sided(UT.d(), KR_GE_N, KR_GE_M, vec1.d(), dim, dual_point.d(), dim, 1);     // svec(U Z U')
+  double* ds = ctx.dscal.d() + 44;
+  hipLaunchKernelGGL(psd_prox_direct_kernel, dim3(1), dim3(1024), 0, ctx.stream, side, vec1.d(), irtmu, ds);
+  HYP_CHECK(hipGetLastError());
+  ctx.d2h(ctx.h_pinned + 44, ds, sizeof(double));
+  ctx.sync();
+  const double v = ctx.h_pinned[44];
+  if (!(v == v) || !(v < INFINITY)) return false;
+  *lb = v / (1.0 + 1e-6);     // (the caller rejects on lb > limit: leave room for the rounding of the two routes)
+  return true;
+}
+
 bool PsdCone::is_dual_feas() {   // :92-95
   if (dual_cached) return dual_feas_;
   svec_unpack(ctx, side, 1, dual_point.d(), dim, tmpmat.d());

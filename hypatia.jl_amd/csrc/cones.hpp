@@ -137,6 +137,7 @@ struct PsdCone : Cone {   // src/Cones/possemideftri.jl (real symmetric)
     dual_cached = false;
   }
   void prefetch_feas() override;
+  bool prox_lower_bound(double irtmu, double limit, double* lb) override;
   bool prefetch_launch(int slot) override;
   void prefetch_finish(int slot) override;
   bool update_feas() override;

@@ -868,7 +868,7 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
     if (tdbg && !ok) fprintf(stderr, "[trial] infeasible\n");
     // candidates far outside the neighbourhood: rejected on a lower bound of the proximity value, before any Hessian is
     // assembled or factored for them (Cone::prox_lower_bound; single process only -- sharded ranks leave together below)
-    if (ok && !dist()) {
+    if (ok && !dist() && nc <= 2) {   // (each bound is a read-back of its own: for models of one or two large cones)
       for (size_t k = 0; k < nc && ok; ++k) {
         double lb = 0.0;
         const bool have = cones[k]->prox_lower_bound(irtmu, proxsqr_bound * (1.0 + 1e-9), &lb);

@@ -20,6 +20,10 @@ from oracle import instances as I
 name = sys.argv[1]
 if name == "matrixcompletion":
     inst = I.matrixcompletion(12, 20, seed=3)
+elif name == "psd_single":
+    inst = I.psd_blocks(40, [48], seed=5)
+elif name == "psd_pair":
+    inst = I.psd_blocks(50, [40, 33], seed=6)
 elif name == "polymin_primal":
     inst = I.polymin(2, 3, True, seed=2)
 elif name == "polymin_dual":
@@ -50,6 +54,8 @@ def _run(name, env_extra):
     ("polymin_primal", "HYP_WSOS_PAR"),                   # the K feasibility chains on both streams, one read-back
     ("polymin_dual", "HYP_WSOS_PAR"),
     ("wsosinterpnonnegative2", "HYP_WSOS_PAR"),
+    ("psd_single", "HYP_PROX_LB"),                        # PosSemidefTri: the proximity value from U Z U' / sqrt(mu) - I, no inverse
+    ("psd_pair", "HYP_PROX_LB"),
     ("matrixcompletion", "HYP_PROX_LB"),                  # EpiNormSpectral: rejected before either decomposition is started
     ("epinormspectral3_3x4_dual", "HYP_PROX_LB"),
     ("polymin_large_primal", "HYP_PROX_LB"),              # candidates rejected on a lower bound of the proximity value (U = 680 >= 512)
