@@ -996,3 +996,35 @@ def test_every_cone_near_its_boundary(name, margin):
         cone.hess_prod(HV, V)
         cone.inv_hess_prod(back, HV)
         assert rel(back, V) <= tol, (name, "H^-1 H v = v", rel(back, V))
+
+
+# ---------------------------------------------------------------------------------------------
+# EpiNormSpectral dual feasibility = a nuclear norm from the values-only Jacobi iteration (cosine threshold 1e-10, columns below
+# eps ||B||_F treated as zero, one-launch column norms): the decision must be right a relative 1e-9 either side of the boundary,
+# also for the matrices a solve produces late -- nearly low rank, singular values spread over twelve orders of magnitude
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d1,d2", [(2, 2), (3, 5), (8, 8), (20, 33), (50, 100)])
+@pytest.mark.parametrize("kind", ["random", "lowrank_plus_noise", "graded"])
+def test_epinormspectral_dual_feasibility_at_the_boundary(d1, d2, kind):
+    import hypatia_jl_amd as H
+    rng = np.random.default_rng(1000 * d1 + d2 + len(kind))
+    if kind == "random":
+        W = rng.standard_normal((d1, d2))
+    elif kind == "lowrank_plus_noise":
+        r = max(1, d1 // 4)
+        W = rng.standard_normal((d1, r)) @ rng.standard_normal((r, d2)) + 1e-17 * rng.standard_normal((d1, d2))
+    else:
+        Q1, _ = np.linalg.qr(rng.standard_normal((d1, d1)))
+        Q2, _ = np.linalg.qr(rng.standard_normal((d2, d2)))
+        W = (Q1 * np.logspace(0, -12, d1)) @ Q2[:d1, :]
+    nn = float(np.linalg.svd(W, compute_uv=False).sum())
+    cone = H.EpiNormSpectral(d1, d2)
+    cone.setup_data()
+    pt = np.zeros(1 + d1 * d2)
+    cone.set_initial_point(pt)
+    for rep in range(2):                       # (the second round starts from the first one's rotations: the warm start)
+        for margin, expect in ((1e-9, True), (-1e-9, False), (1e-6, True), (-1e-6, False)):
+            cone.reset_data()
+            cone.load_point(pt)
+            cone.load_dual_point(np.concatenate([[nn * (1 + margin)], W.reshape(-1, order="F")]))
+            assert bool(cone.is_dual_feas()) == expect, (kind, d1, d2, margin, rep)
