@@ -48,6 +48,16 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix spec; measured 77.8 with tools/probe_mfma.hip (profiles/)
 
 
+def algorithm_record():
+    """which route through the library a bench line timed: the switches are read from the environment by the
+    library itself, once per process; the defaults leave the reference's ORDER of operations in three places"""
+    on = lambda name: os.environ.get(name, "1")[:1] != "0"
+    return {"ens_closed_form_inverse": on("HYP_ENS_CLOSED_INV"), "prox_lower_bound": on("HYP_PROX_LB"),
+            "side_by_side_candidate_evaluation": on("HYP_ENS_PREFETCH") and on("HYP_WSOS_PAR"),
+            "triangular_solve_refinement_steps": int(os.environ.get("HYP_TRSM_REFINE", "2")),
+            "reference_route": not (on("HYP_ENS_CLOSED_INV") or on("HYP_PROX_LB") or on("HYP_ENS_PREFETCH") or on("HYP_WSOS_PAR"))}
+
+
 def pmc_traffic(n, q):
     """HBM bytes per syrk launch from the committed PMC passes (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE); only
     valid for the configuration they were collected on, else None."""
@@ -259,7 +269,7 @@ def main_multi(args, world, rank, local_rank):
             "config": {"workload": ("configs[3]: %d x PosSemidefTri side=%d (q=%d), dense random G q x n, n=%d, p=0; the fixed instance at every N, "
                                     "%d cones per rank" % (ncones, side, q, n, len(mine))) if strong else
                                    ("configs[1] block per GPU: %d x PosSemidefTri side=%d (q=%d total), dense random G, n=%d, p=0" % (world, side, q, n)),
-                       "n": n, "q": q, "seed": args.seed, "parallelism": "cone-shard x%d" % world,
+                       "n": n, "q": q, "seed": args.seed, "algorithm": algorithm_record(), "parallelism": "cone-shard x%d" % world,
                        "exchange": "RCCL all-reduce (sum, f64, n x n) of the Schur matrix per iteration + small per-solve / per-trial all-reduces, "
                                    + ("issued by the library on its own stream (hyp_sys_set_comm_rccl)" if in_lib else "through the torch.distributed callback")},
             "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<true, 4, 1> + splitk_reduce (per-rank Schur syrk, upper)", "achieved": achieved,
@@ -409,7 +419,7 @@ def run_headline(args, world, rank, local_rank, multi, comm=None):
         "data": "synthetic",
         "config": {"workload": ("configs[1]: single PosSemidefTri side=%d (q=%d), dense random G q x n, n=%d, p=0" % (args.side, q, args.n)) if args.config == "2"
                                else ("configs[3]: 64 x PosSemidefTri side=80 (q=%d), dense random G q x n, n=%d, p=0, all cones on one GPU" % (q, args.n)),
-                   "n": args.n, "q": q, "seed": args.seed,
+                   "n": args.n, "q": q, "seed": args.seed, "algorithm": algorithm_record(),
                    **({"parallelism": "K-panel shard of the Schur product x%d, model replicated; one RCCL all-reduce (sum, f64, n x n) per iteration" % world}
                       if comm is not None else {})},
         "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<true, 4, 1> (Schur syrk, upper)", "achieved": achieved,
@@ -545,7 +555,7 @@ def main_other(args):
         "value": iters / loop_s, "unit": "iterations/s", "iterations_per_s": iters / loop_s, "n_gpus": 1, "steps": iters, "warmup": 2,
         "ms_per_step": loop_s / iters * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": work, "n": int(s.model.n), "p": int(s.model.p), "q": int(s.model.q), "seed": args.seed, "solves_timed": nsolve_runs,
-                   "final_status": status},
+                   "final_status": status, "algorithm": algorithm_record()},
         "roofline": {"bound": "mfma", "kernel": "blocked upper Cholesky, n = %d (potrf_diag_mfma + potrf_panel_mfma + gemm_f64 trailing updates)" % n_fact,
                      "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                      "launch_ms": ms.value, "flops_per_launch": flops},

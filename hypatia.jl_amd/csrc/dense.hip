@@ -410,19 +410,116 @@ void trsv_upper(Ctx& c, int n, const double* U, long ldu, const double* dinv, bo
   HYP_CHECK(hipGetLastError());
 }
 
-// X <- op(U)^-1 X for nrhs right-hand sides through GEMMs against the inverted diagonal blocks.
+// ---- diagonal block of the blocked triangular solve on MANY right-hand sides ----------------------------------------------
+// X_k <- op(T)^-1 X_k for one diagonal block T = U[k0:k0+nb, k0:k0+nb] and nrhs columns, in place: x0 = op(D) y with the
+// stored inverse D = inv(T), then `refine` steps x += op(D) (y - op(T) x) against the factor block itself -- the same scheme
+// as the one-vector solves above (diag_solve), so that dtrsm's backward error is kept (Cones.jl:113-118 / 209-218,
+// wsosinterpnonnegative.jl:106-112 call ldiv! on the factor; a plain product with the inverted block has a forward error
+// of cond(T) eps and moved late iterates of models with generic-Hessian cones away from the oracle's: DESIGN.md section 7).
+// One workgroup = 16 columns; thread (r = tid & 127, half = tid >> 7) owns row r of 8 columns, the multiplied slab sits in
+// LDS (read as broadcasts), operand entries stream from L2: coalesced along r for D, D' and T; for T' (forward sweep) every
+// lane walks its own column of T.  A wavefront only visits the k range its 64 rows need (triangular operands).
+template <bool COALESCED, bool LOWER>
+__device__ __forceinline__ void tdr_product(const double* __restrict__ M, long ld, int nb, int r, int kbeg, int kend,
+                                            const double* __restrict__ Vs, int half, double sign, double (&acc)[8]) {
+  const int rc = min(r, nb - 1);
+  const bool rok = r < nb;
+  constexpr int UN = 8;
+  int k = kbeg;
+  for (; k + UN <= kend; k += UN) {
+    double m[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) m[u] = COALESCED ? M[(long)(k + u) * ld + rc] : M[(long)rc * ld + (k + u)];   // (unconditional loads)
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const bool in_tri = LOWER ? (k + u <= r) : (k + u >= r);
+      const double mv = (rok && in_tri) ? sign * m[u] : 0.0;
+      const double* v = Vs + (k + u) * 16 + 8 * half;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += mv * v[j];
+    }
+  }
+  for (; k < kend; ++k) {
+    double mk = COALESCED ? M[(long)k * ld + rc] : M[(long)rc * ld + k];
+    const bool in_tri = LOWER ? (k <= r) : (k >= r);
+    mk = (rok && in_tri) ? sign * mk : 0.0;
+    const double* v = Vs + k * 16 + 8 * half;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += mk * v[j];
+  }
+}
+
+__global__ __launch_bounds__(256) void trsm_diag_refined_kernel(const double* __restrict__ T, long ldt, const double* __restrict__ dinv_blk,
+                                                                int nb, int trans, double* __restrict__ X, long ldx, int nrhs, int refine) {
+  __shared__ __attribute__((aligned(16))) double Ys[NB * 16];
+  __shared__ __attribute__((aligned(16))) double Xs[NB * 16];
+  __shared__ __attribute__((aligned(16))) double Rs[NB * 16];
+  const int tid = threadIdx.x, r = tid & (NB - 1), half = tid >> 7;
+  const int c0 = blockIdx.x * 16;
+  const int r0 = 64 * ((tid >> 6) & 1);   // first row of this wavefront
+  // forward sweep (trans): op(D) = D' (lower, stored second), op(T) = T' (lower); backward: D and T (upper)
+  const double* Dop = dinv_blk + (trans ? (long)NB * NB : 0);
+  const int kbeg = trans ? 0 : r0, kend = trans ? min(nb, r0 + 64) : nb;
+  for (int e = tid; e < NB * 16; e += 256) {
+    const int k = e & (NB - 1), c = e >> 7;
+    Ys[k * 16 + c] = (k < nb && c0 + c < nrhs) ? X[(long)(c0 + c) * ldx + k] : 0.0;
+  }
+  __syncthreads();
+  double x[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = 0.0;
+  if (trans) tdr_product<true, true>(Dop, NB, nb, r, kbeg, kend, Ys, half, 1.0, x);
+  else tdr_product<true, false>(Dop, NB, nb, r, kbeg, kend, Ys, half, 1.0, x);
+  for (int it = 0; it < refine; ++it) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Xs[r * 16 + 8 * half + j] = x[j];
+    __syncthreads();
+    double res[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) res[j] = Ys[r * 16 + 8 * half + j];
+    if (trans) tdr_product<false, true>(T, ldt, nb, r, kbeg, kend, Xs, half, -1.0, res);
+    else tdr_product<true, false>(T, ldt, nb, r, kbeg, kend, Xs, half, -1.0, res);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Rs[r * 16 + 8 * half + j] = res[j];
+    __syncthreads();
+    if (trans) tdr_product<true, true>(Dop, NB, nb, r, kbeg, kend, Rs, half, 1.0, x);
+    else tdr_product<true, false>(Dop, NB, nb, r, kbeg, kend, Rs, half, 1.0, x);
+  }
+  if (r < nb) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + 8 * half + j;
+      if (c < nrhs) X[(long)c * ldx + r] = x[j];
+    }
+  }
+}
+
+int trsm_refine_steps() {
+  static const int v = [] { const char* e = getenv("HYP_TRSM_REFINE"); const int t = e ? atoi(e) : 2; return t < 0 ? 0 : (t > 4 ? 4 : t); }();
+  return v;
+}
+
+// X <- op(U)^-1 X for nrhs right-hand sides: diagonal blocks through their stored inverses + refinement against the factor
+// (trsm_diag_refined_kernel; HYP_TRSM_REFINE=0: plain products with the inverted blocks, the first two rounds' form),
+// the rest through GEMMs.
 void trsm_upper_left(Ctx& c, int n, int nrhs, const double* U, long ldu, const double* dinv, bool trans, double* X, long ldx,
                      double* work) {
   if (n <= 0 || nrhs <= 0) return;
   const int nblk = (n + NB - 1) / NB;
+  const int refine = trsm_refine_steps();
   if (trans) {   // forward: for k: X_k <- Dinv_k' X_k ; X_{k+1:} -= U[k, k+1:]' X_k
     for (int kb = 0; kb < nblk; ++kb) {
       const int k0 = kb * NB, nb = std::min(NB, n - k0), m = n - k0 - nb;
-      GemmArgs t{};
-      t.M = nb; t.N = nrhs; t.K = nb; t.A = dinv + (long)kb * DINV_BLK; t.lda = NB;
-      t.B = X + k0; t.ldb = ldx; t.C = X + k0; t.ldc = ldx; t.alpha = 1; t.beta = 0; t.krange = KR_LE_M; t.batch = 1;
-      t.tile_hint = 128;   // in place (see potrf_upper_batched)
-      gemm(c, true, t);
+      if (refine > 0) {
+        hipLaunchKernelGGL(trsm_diag_refined_kernel, dim3((nrhs + 15) / 16), dim3(256), 0, c.stream, U + (long)k0 * ldu + k0, ldu,
+                           dinv + (long)kb * DINV_BLK, nb, 1, X + k0, ldx, nrhs, refine);
+      } else {
+        GemmArgs t{};
+        t.M = nb; t.N = nrhs; t.K = nb; t.A = dinv + (long)kb * DINV_BLK; t.lda = NB;
+        t.B = X + k0; t.ldb = ldx; t.C = X + k0; t.ldc = ldx; t.alpha = 1; t.beta = 0; t.krange = KR_LE_M; t.batch = 1;
+        t.tile_hint = 128;   // in place (see potrf_upper_batched)
+        gemm(c, true, t);
+      }
       if (m > 0) {
         GemmArgs u{};
         u.M = m; u.N = nrhs; u.K = nb; u.A = U + (long)(k0 + nb) * ldu + k0; u.lda = ldu;
@@ -433,13 +530,18 @@ void trsm_upper_left(Ctx& c, int n, int nrhs, const double* U, long ldu, const d
   } else {       // backward: for k desc: X_k <- Dinv_k X_k ; X_{:k} -= U[:k, k] X_k
     for (int kb = nblk - 1; kb >= 0; --kb) {
       const int k0 = kb * NB, nb = std::min(NB, n - k0);
-      // Dinv_k X_k needs a non-aliased output (NN form reads rows of B = all of X_k): use work
-      GemmArgs t{};
-      t.M = nb; t.N = nrhs; t.K = nb; t.A = dinv + (long)kb * DINV_BLK; t.lda = NB;
-      t.B = X + k0; t.ldb = ldx; t.C = work; t.ldc = NB; t.alpha = 1; t.beta = 0; t.krange = KR_GE_M; t.batch = 1;
-      gemm(c, false, t);
-      HYP_CHECK(hipMemcpy2DAsync(X + k0, ldx * sizeof(double), work, NB * sizeof(double), nb * sizeof(double), nrhs,
-                                 hipMemcpyDeviceToDevice, c.stream));
+      if (refine > 0) {
+        hipLaunchKernelGGL(trsm_diag_refined_kernel, dim3((nrhs + 15) / 16), dim3(256), 0, c.stream, U + (long)k0 * ldu + k0, ldu,
+                           dinv + (long)kb * DINV_BLK, nb, 0, X + k0, ldx, nrhs, refine);
+      } else {
+        // Dinv_k X_k needs a non-aliased output (NN form reads rows of B = all of X_k): use work
+        GemmArgs t{};
+        t.M = nb; t.N = nrhs; t.K = nb; t.A = dinv + (long)kb * DINV_BLK; t.lda = NB;
+        t.B = X + k0; t.ldb = ldx; t.C = work; t.ldc = NB; t.alpha = 1; t.beta = 0; t.krange = KR_GE_M; t.batch = 1;
+        gemm(c, false, t);
+        HYP_CHECK(hipMemcpy2DAsync(X + k0, ldx * sizeof(double), work, NB * sizeof(double), nb * sizeof(double), nrhs,
+                                   hipMemcpyDeviceToDevice, c.stream));
+      }
       if (k0 > 0) {
         GemmArgs u{};
         u.M = k0; u.N = nrhs; u.K = nb; u.A = U + (long)k0 * ldu; u.lda = ldu;

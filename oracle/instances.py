@@ -637,11 +637,12 @@ def linearopt(m=50, n=100, seed=1):
     return (c, A, b, -np.eye(n), np.zeros(n), [("nonnegative", n)], dict(status="Optimal"))
 
 
-def polymin(nvars, halfdeg, use_primal, seed=1):
+def polymin(nvars, halfdeg, use_primal, seed=1, keep=None):
     """config 5: examples/polymin/native.jl:56-90 (real, WSOS formulation), random_interp_data
-    (examples/polymin/data_real.jl:23-33) on the box [-1, 1]^n."""
+    (examples/polymin/data_real.jl:23-33) on the box [-1, 1]^n.  keep: a recorded choice of interpolation points
+    (polyutils.choose_interp_pts) for fixtures that must rebuild the same model on another machine."""
     rng = np.random.default_rng(seed)
-    U, pts, Ps = pu.interpolate_box([-1.0] * nvars, [1.0] * nvars, halfdeg, rng=rng)
+    U, pts, Ps = pu.interpolate_box([-1.0] * nvars, [1.0] * nvars, halfdeg, rng=rng, keep=keep)
     vals = rng.standard_normal(U)
     if use_primal:
         return (np.array([-1.0]), np.zeros((0, 1)), np.zeros(0), np.ones((U, 1)), vals,

@@ -72,19 +72,29 @@ def make_chebyshev_vandermonde(pts, deg):
     return V
 
 
-def choose_interp_pts(cand_pts, d):
+LAST_KEEP = None   # the candidate indices the last pivoted QR kept (fixtures record them: see choose_interp_pts)
+
+
+def choose_interp_pts(cand_pts, d, keep=None):
+    """keep = a recorded choice of candidates: the pivot order of LAPACK's dgeqp3 depends on the BLAS build when column norms
+    nearly tie, so a fixture that must describe the SAME model on another machine stores the choice instead of redoing it"""
+    global LAST_KEEP
     n = cand_pts.shape[1]
     U = get_U(n, d)
     V = make_chebyshev_vandermonde(cand_pts, 2 * d)
-    # F = qr!(Array(V'), ColumnNorm()); keep_pts = F.p[1:U]
-    piv = qr(V.T, mode="r", pivoting=True)[1]
-    keep = piv[:U]
+    if keep is None:
+        # F = qr!(Array(V'), ColumnNorm()); keep_pts = F.p[1:U]
+        piv = qr(V.T, mode="r", pivoting=True)[1]
+        keep = piv[:U]
+    keep = np.asarray(keep, dtype=np.int64)
+    assert keep.shape[0] == U
+    LAST_KEEP = keep.copy()
     return V[keep, :], keep
 
 
-def make_wsos_arrays(dom_degree, cand_pts, d):
+def make_wsos_arrays(dom_degree, cand_pts, d, keep=None):
     n = cand_pts.shape[1]
-    V, keep = choose_interp_pts(cand_pts, d)
+    V, keep = choose_interp_pts(cand_pts, d, keep)
     pts = cand_pts[keep, :]
     P0 = V[:, : get_L(n, d)]
     Lsub = get_L(n, (2 * d - dom_degree) // 2)
@@ -115,7 +125,7 @@ def padua_data(d):
     return U, pts, P0, P0[:, : get_L(2, d - 1)]
 
 
-def approxfekete_data(n, d):
+def approxfekete_data(n, d, keep=None):
     npts = prod_consec(n, d)
     cand = np.zeros((npts, n))
     for j in range(1, n + 1):
@@ -131,19 +141,19 @@ def approxfekete_data(n, d):
                 if i >= npts:
                     break
                 l = 0
-    pts, P0, P0sub = make_wsos_arrays(2, cand, d)
+    pts, P0, P0sub = make_wsos_arrays(2, cand, d, keep)
     return pts.shape[0], pts, P0, P0sub
 
 
-def interp_box_unit(n, d):
+def interp_box_unit(n, d, keep=None):
     if n == 1:
         return cheb2_data(d)
     if n == 2:
         return padua_data(d)
-    return approxfekete_data(n, d)
+    return approxfekete_data(n, d, keep)
 
 
-def interpolate_box(l, u, d, sample=None, rng=None, sample_factor=0):
+def interpolate_box(l, u, d, sample=None, rng=None, sample_factor=0, keep=None):
     """interpolate(BoxDomain(l, u), d): returns (U, pts, Ps).  realinterp.jl:11-46."""
     l = np.asarray(l, dtype=np.float64)
     u = np.asarray(u, dtype=np.float64)
@@ -157,11 +167,11 @@ def interpolate_box(l, u, d, sample=None, rng=None, sample_factor=0):
         rng = rng if rng is not None else np.random.default_rng(1)
         # BoxDomain sample: realdomains.jl:87-95
         cand = (rng.random((U * sample_factor, n)) - 0.5) * (u - l)[None, :] + 0.5 * (u + l)[None, :]
-        pts, P0, P0sub = make_wsos_arrays(2, cand, d)
+        pts, P0, P0sub = make_wsos_arrays(2, cand, d, keep)
         g = [(pts[:, i] - l[i]) * (u[i] - pts[:, i]) for i in range(n)]   # weights :98-101
         Ps = [P0] + [np.sqrt(gi)[:, None] * P0sub for gi in g]
         return U, pts, Ps
-    U2, pts, P0, P0sub = interp_box_unit(n, d)
+    U2, pts, P0, P0sub = interp_box_unit(n, d, keep)
     pscale = 0.5 * (u - l)
     pshift = 0.5 * (u + l)
     Ps = [P0] + [(np.sqrt(1 - pts[:, j] ** 2) * pscale[j])[:, None] * P0sub for j in range(n)]

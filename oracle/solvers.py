@@ -443,6 +443,8 @@ def update_rhs_predadj(solver, rhs, dir):   # :27-60
         dot1 = dder3_k @ cone_k.point
         dot2 = irtrtmu * (prim_k_scal @ H_prim_dir_k)
         dder3_viol = abs(dot1 - dot2) / (rteps + abs(dot2))
+        if getattr(solver, "gate_log", None) is not None:   # (test instrumentation: the acceptance test thresholds rounding noise)
+            solver.gate_log.append((solver.num_iters, "pred", k, float(dder3_viol)))
         if dder3_viol < 1e-4:
             rhs.s_views[k][:] = H_prim_dir_k + dder3_k
     taubar = solver.point.tau
@@ -481,6 +483,8 @@ def update_rhs_centadj(solver, rhs, dir):   # :87-118
         dot1 = dder3_k @ cone_k.point
         dot2 = prim_k_scal @ H_prim_dir_k_scal
         dder3_viol = abs(dot1 - dot2) / (rteps + abs(dot2))
+        if getattr(solver, "gate_log", None) is not None:
+            solver.gate_log.append((solver.num_iters, "cent", k, float(dder3_viol)))
         if dder3_viol < 1e-4:
             rhs.s_views[k][:] = dder3_k
     taubar = solver.point.tau

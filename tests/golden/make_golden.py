@@ -6,7 +6,12 @@ Two kinds of data, both small:
                        exported from oracle/instances.py so that they exist as data next to the tests;
   cone_vectors.npz     seeded inputs and the CPU oracle's outputs for every cone oracle of the hot path (grad,
                        hess_prod, inv_hess_prod, sqrt_hess_prod, dder3, proximity) at small sizes;
-  trajectory_psd.json  the oracle's iterate trajectory (objective, mu, tau, step sizes) on a small PSD instance.
+  trajectory_psd.json  the oracle's iterate trajectory (objective, mu, tau, step sizes) on a small PSD instance;
+  trajectory_{ens,wsos,mixed}.json   the same for matrix completion / EpiNormSpectral models, polymin in both forms /
+                       WSOSInterpNonnegative models and mixed PSD + spectral + WSOS models (full solves, and the first three
+                       iterations of config 3b at 50 x 100 and of polymin at U = 680), each with the oracle's trajectory on the
+                       1-ulp-perturbed model (three draws for the full solves) and, per
+                       iterate, how far the acceptance tests of the third-order terms were from their threshold beside it.
 The reference (pure Julia) cannot be executed here, so these vectors are produced by the oracle restatement, which is
 itself pinned by the reference's identities and known answers (tests/test_oracle_*.py).  They freeze the oracle: a
 later edit of oracle/ that changes any number fails tests/test_golden.py, and the GPU tests compare against the same
@@ -142,7 +147,41 @@ def main():
         json.dump({"instance": "oracle.instances.psd_blocks(40, [7, 5], seed=11)", "status": s.status, "num_iters": s.num_iters,
                    "columns": ["primal_obj", "dual_obj", "mu", "tau", "alpha"], "rows": rows,
                    "x": s.get_x().tolist()}, f, indent=1)
+    write_trajectories()
     print("wrote", sorted(os.listdir(HERE)))
+
+
+# trajectories of models over the other two cones of the hot path and of a mixed model (tests/trajectory_harness.py names the
+# instances).  Each record also holds the trajectory of the SAME oracle on a model whose G and h were moved by one ulp per
+# entry: the prefix on which the two agree in every step size is where a comparison of step sizes means something.
+TRAJECTORIES = {
+    "trajectory_ens.json": [("mc_6x8_2", {}), ("mc_12x20_3", {}), ("epinormspectral2_primal", {}), ("epinormspectral3_3x4_dual", {}),
+                            ("mc_50x100_1", {"iter_limit": 3})],
+    "trajectory_wsos.json": [("polymin_2_3_p_2", {}), ("polymin_2_3_d_2", {}), ("polymin_3_4_p_3", {}), ("wsosinterpnonnegative2", {}),
+                             ("polymin_3_7_p_3", {"iter_limit": 3}), ("polymin_3_7_d_3", {"iter_limit": 3})],
+    "trajectory_mixed.json": [("mixed_psd_ens_wsos", {}), ("mixed_dual_barriers", {}), ("mixed_two_wsos_two_ens", {})],
+}
+
+
+def write_trajectories():
+    os.environ["HYP_GOLDEN_REGEN"] = "1"    # (instances are rebuilt from scratch, not from the recorded point choices)
+    import trajectory_harness as T
+    from oracle import polyutils
+    for fname, cases in TRAJECTORIES.items():
+        out = {"columns": list(T.COLS), "cases": {}}
+        for name, opts in cases:
+            polyutils.LAST_KEEP = None
+            inst = T.instance(name)
+            keep = polyutils.LAST_KEEP
+            o = T.oracle_trajectory(inst, **opts)
+            ps = [T.oracle_trajectory(T.perturbed(inst, seed=99 + j), **opts) for j in range(1 if opts else 3)]
+            out["cases"][name] = {"opts": opts, "status": o["status"], "num_iters": o["iters"], "primal_obj": o["p_obj"],
+                                  "rows": o["rows"].tolist(), "perturbed_rows": [p["rows"].tolist() for p in ps],
+                                  "gate_decades": [None if not np.isfinite(g) else round(float(g), 3) for g in o["gate"]]}
+            if name.startswith("polymin_") and keep is not None:   # (the pivoted QR's choice of points: BLAS-build dependent)
+                out["cases"][name]["interp_keep"] = [int(v) for v in keep]
+        with open(os.path.join(HERE, fname), "w") as f:
+            json.dump(out, f, indent=0)
 
 
 if __name__ == "__main__":
