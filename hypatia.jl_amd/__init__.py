@@ -9,7 +9,7 @@ Julia.  It never imports `oracle/` and has no CPU fallback: constructing a cone 
 without the HIP library and a GPU raises.
 """
 from . import _lib            # noqa: F401
-from .cones import Nonnegative, PosSemidefTri, PosSemidefTriComplex, EpiNormSpectral, EpiNormSpectralComplex, WSOSInterpNonnegative, LinMatrixIneq, DoublyNonnegativeTri, HypoRootdetTri, HypoPerLogdetTri, HypoRootdetTriComplex, HypoPerLogdetTriComplex, WSOSInterpPosSemidefTri, Cone   # noqa: F401
+from .cones import Nonnegative, PosSemidefTri, PosSemidefTriComplex, EpiNormSpectral, EpiNormSpectralComplex, WSOSInterpNonnegative, WSOSInterpNonnegativeComplex, LinMatrixIneq, DoublyNonnegativeTri, HypoRootdetTri, HypoPerLogdetTri, HypoRootdetTriComplex, HypoPerLogdetTriComplex, WSOSInterpPosSemidefTri, Cone   # noqa: F401
 from .models import Model                                    # noqa: F401
 from .systemsolvers import QRCholDenseSystemSolver, SymIndefDenseSystemSolver   # noqa: F401
 from .solvers import Solver, CombinedStepper, StepSearcher, Point   # noqa: F401

@@ -33,6 +33,7 @@ SIGNATURES = {
     "hyp_cone_create_epinormspectral": [c_vp, c_int, c_int, c_int, P(c_vp)],
     "hyp_cone_create_epinormspectral_complex": [c_vp, c_int, c_int, c_int, P(c_vp)],
     "hyp_cone_create_wsosinterpnonnegative": [c_vp, c_int, c_int, P(c_int), P(c_vp), c_int, P(c_vp)],
+    "hyp_cone_create_wsosinterpnonnegative_complex": [c_vp, c_int, c_int, P(c_int), P(c_vp), c_int, P(c_vp)],
     "hyp_cone_create_wsosinterppossemideftri": [c_vp, c_int, c_int, c_int, P(c_int), P(c_vp), c_int, P(c_vp)],
     "hyp_cone_create_linmatrixineq": [c_vp, c_int, c_int, c_vp, c_int, P(c_vp)],
     "hyp_cone_create_linmatrixineq_complex": [c_vp, c_int, c_int, c_vp, c_int, P(c_vp)],
@@ -98,6 +99,8 @@ SIGNATURES = {
     "hyp_sys_search_alpha": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_dbl, c_dbl, c_int, c_dbl, c_vp,
                              P(c_int), P(c_dbl), P(c_int), P(c_int), P(c_dbl)],
     "hyp_sys_check_cone_points": [c_vp, c_vp, c_dbl, c_dbl, c_int, c_dbl, P(c_int), P(c_dbl), P(c_int), P(c_dbl)],
+    "hyp_sys_residual_products": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "hyp_sys_allreduce_host": [c_vp, c_vp, c_int, c_int],
     "hyp_sys_load_model": [c_vp, c_vp, c_vp, c_vp, c_vp],
     "hyp_sys_update_lhs": [c_vp, P(c_int), P(c_int), P(c_int), c_vp],
     "hyp_sys_get_directions": [c_vp, c_vp, c_vp, c_dbl, c_dbl, c_int, c_dbl, c_dbl, P(c_dbl), P(c_int)],

@@ -17,6 +17,8 @@ def make_cone(spec):
         return hc.EpiNormSpectralComplex(spec[1], spec[2], use_dual=spec[3])
     if kind == "wsosinterpnonnegative":
         return hc.WSOSInterpNonnegative(spec[1], spec[2], use_dual=spec[3])
+    if kind == "wsosinterpnonnegative_complex":
+        return hc.WSOSInterpNonnegativeComplex(spec[1], spec[2], use_dual=spec[3])
     if kind in ("linmatrixineq", "linmatrixineq_complex"):   # (complex Hermitian members are recognised by their dtype)
         return hc.LinMatrixIneq(spec[1], use_dual=spec[2])
     if kind == "doublynonnegativetri":

@@ -277,6 +277,24 @@ class WSOSInterpNonnegative(_GenericHessMixin, Cone):
         super().__init__(h)
 
 
+class WSOSInterpNonnegativeComplex(_GenericHessMixin, Cone):
+    """Cones.WSOSInterpNonnegative{Float64, ComplexF64}(U, Ps; use_dual)  (wsosinterpnonnegative.jl:15-63 with R = Complex{T}):
+    complex bases (PolyUtils/complex.jl:13-72), real cone vector."""
+
+    def __init__(self, U, Ps, use_dual=False):
+        self._slow = False
+        Ps = [np.asfortranarray(P, dtype=np.complex128) for P in Ps]
+        for P in Ps:
+            assert P.shape[0] == U                                            # :54-56
+        K = len(Ps)
+        Ls = (c_int * K)(*[P.shape[1] for P in Ps])
+        ptrs = (c_vp * K)(*[P.ctypes.data_as(c_vp) for P in Ps])              # (column-major complex128 = (re, im) interleaved)
+        h = c_vp()
+        L.check(L.lib().hyp_cone_create_wsosinterpnonnegative_complex(L.ctx(), int(U), K, Ls, ptrs, int(bool(use_dual)), ctypes.byref(h)),
+                "hyp_cone_create_wsosinterpnonnegative_complex")
+        super().__init__(h)
+
+
 class LinMatrixIneq(_GenericHessMixin, Cone):
     """Cones.LinMatrixIneq{Float64}(As; use_dual)  (linmatrixineq.jl:9-65), dense real symmetric or complex Hermitian members
     (sparse / Diagonal members are densified here; `I` is not accepted, pass np.eye(side))."""

@@ -142,6 +142,13 @@ int hyp_cone_create_wsosinterpnonnegative(hyp_ctx* ctx, int U, int K, const int*
   ctx->c.sync();
   API_END(ctx)
 }
+int hyp_cone_create_wsosinterpnonnegative_complex(hyp_ctx* ctx, int U, int K, const int* Ls, const double* const* Ps, int use_dual, hyp_cone** out) {
+  API_BEGIN
+  HYP_CHECK(hipSetDevice(ctx->c.device));
+  *out = new hyp_cone{ctx, new CplxWsosCone(ctx->c, U, K, Ls, Ps, use_dual != 0)};
+  ctx->c.sync();
+  API_END(ctx)
+}
 int hyp_cone_create_linmatrixineq(hyp_ctx* ctx, int dim, int side, const double* As, int use_dual, hyp_cone** out) {
   API_BEGIN
   HYP_CHECK(hipSetDevice(ctx->c.device));
@@ -565,6 +572,19 @@ int hyp_sys_mul_G(hyp_sys* sys, int trans, double alpha, const double* x, double
   SysSolver* s = sys->s;
   const int nx = trans ? s->q : s->n, ny = trans ? s->n : s->q;
   gemv_host(c, trans != 0, s->q, s->n, alpha, s->G.d(), s->q, x, nx, beta, y, ny);
+  API_END(sys->ctx)
+}
+int hyp_sys_residual_products(hyp_sys* sys, const double* x, const double* z, const double* s, double* out_Gtz, double* out_Gx_s, double* out_dots2) {
+  API_BEGIN
+  HYP_CHECK(hipSetDevice(sys->ctx->c.device));
+  sys->s->residual_products(x, z, s, out_Gtz, out_Gx_s, out_dots2);
+  API_END(sys->ctx)
+}
+int hyp_sys_allreduce_host(hyp_sys* sys, double* buf, int count, int op) {
+  API_BEGIN
+  HYP_CHECK(hipSetDevice(sys->ctx->c.device));
+  HYP_REQUIRE(count >= 0 && count <= 32 && op >= 0 && op <= 2, "hyp_sys_allreduce_host: at most 32 doubles; op 0 sum, 1 max, 2 min");
+  sys->s->allreduce_host(buf, count, op);
   API_END(sys->ctx)
 }
 int hyp_sys_load_model(hyp_sys* sys, const double* c, const double* b, const double* h, const double* A) {

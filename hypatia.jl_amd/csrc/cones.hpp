@@ -14,7 +14,7 @@ bool psd_two_sided_fused_ok(int side);
 void psd_two_sided_fused(Ctx& c, int side, int ncols, const double* R, int rstruct /* 0 full, 1 upper, 2 lower */, const double* arr,
                          long lda, double* prod, long ldp, double* zws /* ncols * side^2 */);
 
-enum ConeKind { CONE_NONNEG = 0, CONE_PSD = 1, CONE_EPINORMSPECTRAL = 2, CONE_WSOS = 3, CONE_LMI = 4, CONE_DNN = 5, CONE_HYPOROOTDET = 6, CONE_HYPOPERLOGDET = 7, CONE_WSOSPSD = 8, CONE_PSD_COMPLEX = 9, CONE_EPINORMSPECTRAL_COMPLEX = 10, CONE_HYPOROOTDET_COMPLEX = 11, CONE_HYPOPERLOGDET_COMPLEX = 12 };
+enum ConeKind { CONE_NONNEG = 0, CONE_PSD = 1, CONE_EPINORMSPECTRAL = 2, CONE_WSOS = 3, CONE_LMI = 4, CONE_DNN = 5, CONE_HYPOROOTDET = 6, CONE_HYPOPERLOGDET = 7, CONE_WSOSPSD = 8, CONE_PSD_COMPLEX = 9, CONE_EPINORMSPECTRAL_COMPLEX = 10, CONE_HYPOROOTDET_COMPLEX = 11, CONE_HYPOPERLOGDET_COMPLEX = 12, CONE_WSOS_COMPLEX = 13 };
 
 struct Cone {
   Ctx& ctx;
@@ -409,6 +409,28 @@ struct CplxHypoCone : GenericHessCone {
   const double* dder3(const double* d_dir) override;
   void to_inner(const double* cvec, long ldc, double* evec, int ncols, const double* scale);      // T
   void from_inner(const double* evec, double* cvec, long ldc, int ncols);                          // T'
+};
+
+// WSOSInterpNonnegative{Float64, ComplexF64}: the real cone at the duplicated point over the embedded bases, barrier halved
+// (cone_wsos_complex.hip).
+struct CplxWsosCone : GenericHessCone {
+  int U;
+  WsosCone* inner;     // bases phi(P_k), 2U x 2L_k (owned)
+  DBuf ea, eb;
+  CplxWsosCone(Ctx& c, int U, int K, const int* Ls, const double* const* hPs /* complex, (re, im) interleaved */, bool use_dual);
+  ~CplxWsosCone() override { delete inner; }
+  void reset_data() override {
+    GenericHessCone::reset_data();
+    inner->reset_data();
+  }
+  bool update_feas() override;
+  void update_grad() override;
+  void update_hess() override;
+  void set_initial_point(double* h_out) override;
+  void hess_prod_slow(double* prod, long ldp, const double* arr, long lda, int ncols) override;
+  const double* dder3(const double* d_dir) override;
+  void dup(const double* in, long ldi, double* out, int ncols);    // E
+  void fold(const double* in, double* out, long ldo, int ncols);   // 1/2 E'
 };
 
 // EpiNormSpectral{Float64, ComplexF64}: the real cone of twice the sides on the embedded matrix, barrier halved, plus the

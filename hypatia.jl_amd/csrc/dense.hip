@@ -416,82 +416,139 @@ void trsv_upper(Ctx& c, int n, const double* U, long ldu, const double* dinv, bo
 // as the one-vector solves above (diag_solve), so that dtrsm's backward error is kept (Cones.jl:113-118 / 209-218,
 // wsosinterpnonnegative.jl:106-112 call ldiv! on the factor; a plain product with the inverted block has a forward error
 // of cond(T) eps and moved late iterates of models with generic-Hessian cones away from the oracle's: DESIGN.md section 7).
-// One workgroup = 16 columns; thread (r = tid & 127, half = tid >> 7) owns row r of 8 columns, the multiplied slab sits in
-// LDS (read as broadcasts), operand entries stream from L2: coalesced along r for D, D' and T; for T' (forward sweep) every
-// lane walks its own column of T.  A wavefront only visits the k range its 64 rows need (triangular operands).
+// One workgroup = 16 columns of X; every product op(M) V (M = D, D', T or T', 128 x 128, V a 128 x 16 slab in LDS) runs on
+// v_mfma_f64_16x16x4: wavefront w owns the row tiles {w, 7 - w} of the result -- with a triangular operand a balanced pair,
+// 36 k-steps of 4 for every wavefront.  The A operands -- one entry of M per lane and k-step -- of BOTH matrices are requested
+// up front (72 loads per lane in flight at once: one exposed L2 latency for the whole kernel; fetched chunk by chunk in front
+// of their MFMAs the kernel spent 4/5 of its time waiting) and stay in registers for the three products with op(D) and the two
+// with op(T); the B operand is one conflict-free ds_read_b64 per k-step (lane l reads Vs[64 kk + l]).  Entries outside the
+// triangle are cut off by a select AFTER an unconditional load (the factor's other triangle holds whatever the factorization
+// left there).
+constexpr int TDR_STEPS = 36;
+
+// step i of wavefront wv -> (tile, k-step): tile wv first, then tile 7 - wv
+template <bool LOWER>
+__device__ __forceinline__ void tdr_step(int wv, int i, int& tile, int& kk, bool& first) {
+  const int nA = LOWER ? 4 * wv + 4 : 32 - 4 * wv;
+  first = i < nA;
+  tile = first ? wv : 7 - wv;
+  const int j = first ? i : i - nA;
+  kk = LOWER ? j : 4 * tile + j;
+}
+
 template <bool COALESCED, bool LOWER>
-__device__ __forceinline__ void tdr_product(const double* __restrict__ M, long ld, int nb, int r, int kbeg, int kend,
-                                            const double* __restrict__ Vs, int half, double sign, double (&acc)[8]) {
-  const int rc = min(r, nb - 1);
-  const bool rok = r < nb;
-  constexpr int UN = 8;
-  int k = kbeg;
-  for (; k + UN <= kend; k += UN) {
-    double m[UN];
+__device__ __forceinline__ void tdr_load(const double* __restrict__ M, long ld, int nb, int wv, double (&a)[TDR_STEPS]) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
 #pragma unroll
-    for (int u = 0; u < UN; ++u) m[u] = COALESCED ? M[(long)(k + u) * ld + rc] : M[(long)rc * ld + (k + u)];   // (unconditional loads)
+  for (int i = 0; i < TDR_STEPS; ++i) {
+    int tile, kk;
+    bool first;
+    tdr_step<LOWER>(wv, i, tile, kk, first);
+    const int rc = min(16 * tile + li, nb - 1), kc = min(4 * kk + lq, nb - 1);   // (clamped: always a valid address)
+    a[i] = COALESCED ? M[(long)kc * ld + rc] : M[(long)rc * ld + kc];
+  }
+}
+template <bool LOWER>
+__device__ __forceinline__ void tdr_mask(int nb, int wv, double sign, double (&a)[TDR_STEPS]) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const bool in_tri = LOWER ? (k + u <= r) : (k + u >= r);
-      const double mv = (rok && in_tri) ? sign * m[u] : 0.0;
-      const double* v = Vs + (k + u) * 16 + 8 * half;
+  for (int i = 0; i < TDR_STEPS; ++i) {
+    int tile, kk;
+    bool first;
+    tdr_step<LOWER>(wv, i, tile, kk, first);
+    const int r = 16 * tile + li, k = 4 * kk + lq;
+    const bool ok = (r < nb) && (k < nb) && (LOWER ? (k <= r) : (k >= r));
+    a[i] = ok ? sign * a[i] : 0.0;
+  }
+}
+// accA / accB: the two row tiles' accumulators; two interleaved chains per tile (a dependent f64 MFMA waits ~95 cycles, an
+// independent one issues after 64)
+template <bool LOWER>
+__device__ __forceinline__ void tdr_product(const double (&a)[TDR_STEPS], int nb, int wv, const double* __restrict__ Vs, d4_t& accA, d4_t& accB) {
+  const int lane = threadIdx.x & 63;
+  d4_t a1 = (d4_t){0.0, 0.0, 0.0, 0.0}, b1 = (d4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += mv * v[j];
+  for (int i = 0; i < TDR_STEPS; ++i) {
+    int tile, kk;
+    bool first;
+    tdr_step<LOWER>(wv, i, tile, kk, first);
+    if (16 * tile >= nb || 4 * kk >= nb) continue;   // (a partial block: rows / k-steps beyond it are structurally zero; wave-uniform)
+    const double bv = Vs[64 * kk + lane];
+    if (first) {
+      if (i & 1) a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bv, a1, 0, 0, 0);
+      else accA = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bv, accA, 0, 0, 0);
+    } else {
+      if (i & 1) b1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bv, b1, 0, 0, 0);
+      else accB = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bv, accB, 0, 0, 0);
     }
   }
-  for (; k < kend; ++k) {
-    double mk = COALESCED ? M[(long)k * ld + rc] : M[(long)rc * ld + k];
-    const bool in_tri = LOWER ? (k <= r) : (k >= r);
-    mk = (rok && in_tri) ? sign * mk : 0.0;
-    const double* v = Vs + k * 16 + 8 * half;
+  accA += a1;
+  accB += b1;
+}
+
+template <bool TRANS>
+__device__ __forceinline__ void tdr_body(const double* __restrict__ T, long ldt, const double* __restrict__ dinv_blk, int nb,
+                                         double* __restrict__ X, long ldx, int nrhs, int refine, double* Ys, double* Xs, double* Rs) {
+  constexpr bool LOWER = TRANS;   // forward sweep: op(D) = D' (lower, stored second), op(T) = T' (lower); backward: D and T (upper)
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const int c0 = blockIdx.x * 16;
+  const double* Dop = dinv_blk + (TRANS ? (long)NB * NB : 0);
+  double dop[TDR_STEPS], top[TDR_STEPS];
+  tdr_load<true, LOWER>(Dop, NB, nb, wv, dop);
+  tdr_load<!TRANS, LOWER>(T, ldt, nb, wv, top);
+  for (int e = tid; e < NB * 16; e += 256) {
+    const int k = e & (NB - 1), c = e >> 7;
+    Ys[k * 16 + c] = (k < nb && c0 + c < nrhs) ? X[(long)(c0 + c) * ldx + k] : 0.0;
+  }
+  tdr_mask<LOWER>(nb, wv, 1.0, dop);
+  tdr_mask<LOWER>(nb, wv, -1.0, top);
+  __syncthreads();
+  const int rowA = 16 * wv + lq, rowB = 16 * (7 - wv) + lq;   // (C/D layout: row = lq + 4 g, col = li)
+  d4_t xA = (d4_t){0.0, 0.0, 0.0, 0.0}, xB = (d4_t){0.0, 0.0, 0.0, 0.0};
+  tdr_product<LOWER>(dop, nb, wv, Ys, xA, xB);                     // x0 = op(D) y
+  for (int it = 0; it < refine; ++it) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] += mk * v[j];
+    for (int g = 0; g < 4; ++g) {
+      Xs[(rowA + 4 * g) * 16 + li] = xA[g];
+      Xs[(rowB + 4 * g) * 16 + li] = xB[g];
+    }
+    __syncthreads();
+    d4_t rA, rB;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      rA[g] = Ys[(rowA + 4 * g) * 16 + li];
+      rB[g] = Ys[(rowB + 4 * g) * 16 + li];
+    }
+    tdr_product<LOWER>(top, nb, wv, Xs, rA, rB);                   // r = y - op(T) x
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      Rs[(rowA + 4 * g) * 16 + li] = rA[g];
+      Rs[(rowB + 4 * g) * 16 + li] = rB[g];
+    }
+    __syncthreads();
+    tdr_product<LOWER>(dop, nb, wv, Rs, xA, xB);                   // x += op(D) r
+  }
+  // through LDS once more, so that the stores run along the rows of a column (128 contiguous doubles per column)
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    Xs[(rowA + 4 * g) * 16 + li] = xA[g];
+    Xs[(rowB + 4 * g) * 16 + li] = xB[g];
+  }
+  __syncthreads();
+  for (int e = tid; e < NB * 16; e += 256) {
+    const int k = e & (NB - 1), c = e >> 7;
+    if (k < nb && c0 + c < nrhs) X[(long)(c0 + c) * ldx + k] = Xs[k * 16 + c];
   }
 }
 
 __global__ __launch_bounds__(256) void trsm_diag_refined_kernel(const double* __restrict__ T, long ldt, const double* __restrict__ dinv_blk,
                                                                 int nb, int trans, double* __restrict__ X, long ldx, int nrhs, int refine) {
-  __shared__ __attribute__((aligned(16))) double Ys[NB * 16];
+  __shared__ __attribute__((aligned(16))) double Ys[NB * 16];   // [k][c]
   __shared__ __attribute__((aligned(16))) double Xs[NB * 16];
   __shared__ __attribute__((aligned(16))) double Rs[NB * 16];
-  const int tid = threadIdx.x, r = tid & (NB - 1), half = tid >> 7;
-  const int c0 = blockIdx.x * 16;
-  const int r0 = 64 * ((tid >> 6) & 1);   // first row of this wavefront
-  // forward sweep (trans): op(D) = D' (lower, stored second), op(T) = T' (lower); backward: D and T (upper)
-  const double* Dop = dinv_blk + (trans ? (long)NB * NB : 0);
-  const int kbeg = trans ? 0 : r0, kend = trans ? min(nb, r0 + 64) : nb;
-  for (int e = tid; e < NB * 16; e += 256) {
-    const int k = e & (NB - 1), c = e >> 7;
-    Ys[k * 16 + c] = (k < nb && c0 + c < nrhs) ? X[(long)(c0 + c) * ldx + k] : 0.0;
-  }
-  __syncthreads();
-  double x[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) x[j] = 0.0;
-  if (trans) tdr_product<true, true>(Dop, NB, nb, r, kbeg, kend, Ys, half, 1.0, x);
-  else tdr_product<true, false>(Dop, NB, nb, r, kbeg, kend, Ys, half, 1.0, x);
-  for (int it = 0; it < refine; ++it) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) Xs[r * 16 + 8 * half + j] = x[j];
-    __syncthreads();
-    double res[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) res[j] = Ys[r * 16 + 8 * half + j];
-    if (trans) tdr_product<false, true>(T, ldt, nb, r, kbeg, kend, Xs, half, -1.0, res);
-    else tdr_product<true, false>(T, ldt, nb, r, kbeg, kend, Xs, half, -1.0, res);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) Rs[r * 16 + 8 * half + j] = res[j];
-    __syncthreads();
-    if (trans) tdr_product<true, true>(Dop, NB, nb, r, kbeg, kend, Rs, half, 1.0, x);
-    else tdr_product<true, false>(Dop, NB, nb, r, kbeg, kend, Rs, half, 1.0, x);
-  }
-  if (r < nb) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = c0 + 8 * half + j;
-      if (c < nrhs) X[(long)c * ldx + r] = x[j];
-    }
-  }
+  if (trans) tdr_body<true>(T, ldt, dinv_blk, nb, X, ldx, nrhs, refine, Ys, Xs, Rs);
+  else tdr_body<false>(T, ldt, dinv_blk, nb, X, ldx, nrhs, refine, Ys, Xs, Rs);
 }
 
 int trsm_refine_steps() {

@@ -349,6 +349,44 @@ void SysSolver::allreduce_host(double* h_buf, int count, int op) {
   ctx.sync();
 }
 
+void SysSolver::residual_products(const double* h_x, const double* h_z, const double* h_s, double* h_Gtz, double* h_Gx_s, double* h_dots) {
+  HYP_REQUIRE(model_loaded, "residual_products: load_model first");
+  const size_t d = sizeof(double);
+  rp_x.ensure(std::max<size_t>(n, 1) * d);
+  rp_t.ensure(std::max<size_t>(n, 1) * d);
+  for (DBuf* b : {&rp_z, &rp_s, &rp_g}) b->ensure(std::max<size_t>(q, 1) * d);
+  double* hs = ctx.stage_host((size_t)n + 2 * (size_t)q);
+  memcpy(hs, h_x, (size_t)n * d);
+  memcpy(hs + n, h_z, (size_t)q * d);
+  memcpy(hs + n + q, h_s, (size_t)q * d);
+  ctx.h2d(rp_x.p, hs, (size_t)n * d);
+  if (q > 0) {
+    ctx.h2d(rp_z.p, hs + n, (size_t)q * d);
+    ctx.h2d(rp_s.p, hs + n + q, (size_t)q * d);
+    gemv(ctx, true, q, n, 1.0, G.d(), q, rp_z.d(), 0.0, rp_t.d());          // G' z (these rows)
+    ctx.d2d(rp_g.p, rp_s.p, (size_t)q * d);
+    gemv(ctx, false, q, n, 1.0, G.d(), q, rp_x.d(), 1.0, rp_g.d());         // G x + s
+  } else {
+    ctx.zero(rp_t.p, (size_t)n * d);
+  }
+  allreduce_dev(rp_t.d(), n, 0);                                            // sum over ranks (in place, stream order)
+  double* dsc = ctx.dscal.d();
+  ctx.zero(dsc, 2 * d);
+  if (q > 0) {
+    dev_dot(ctx, q, mh.d(), rp_z.d(), dsc);
+    dev_dot(ctx, q, rp_z.d(), rp_s.d(), dsc + 1);
+  }
+  ctx.d2h(hs, rp_t.p, (size_t)n * d);
+  if (q > 0) ctx.d2h(hs + n, rp_g.p, (size_t)q * d);
+  ctx.d2h(ctx.h_pinned, dsc, 2 * d);
+  ctx.sync();
+  memcpy(h_Gtz, hs, (size_t)n * d);
+  if (q > 0) memcpy(h_Gx_s, hs + n, (size_t)q * d);
+  h_dots[0] = ctx.h_pinned[0];
+  h_dots[1] = ctx.h_pinned[1];
+  allreduce_host(h_dots, 2, 0);
+}
+
 void SysSolver::block_hess_prod_vec(double* d_out, const double* d_in) {   // qrchol.jl:87-98
   for (size_t k = 0; k < cones.size(); ++k) {
     Cone* ck = cones[k];
@@ -407,14 +445,21 @@ void SysSolver::assemble_lhs() {
     double* prod_k = HGQ2.d() + offs[k];
     if (ck->use_dual_barrier) ck->inv_hess_prod(prod_k, q, gq2 + offs[k], q, nmp);
     else ck->hess_prod(prod_k, q, gq2 + offs[k], q, nmp);
+    // K-panel sharding: a cone that has lost its square root mid-solve (a Hessian whose Cholesky fell through to Bunch-Kaufman:
+    // use_sqrt_hess_oracles answers false, Cones.jl:189-195) takes this branch on every rank at once -- the product prod_k is
+    // replicated, and each rank contracts only ITS rows of the cone, so that the all-reduce below sums to the whole term
+    // exactly as it does for the square-root branch (16-row granularity as above)
+    long r0 = 0, r1 = ck->dim;
+    if (ks_world > 1) {
+      const long per = (((long)ck->dim + ks_world - 1) / ks_world + 15) / 16 * 16;
+      r0 = std::min<long>((long)ck->dim, per * ks_rank);
+      r1 = std::min<long>((long)ck->dim, r0 + per);
+    }
+    if (r1 <= r0) continue;
     GemmArgs g{};
-    g.M = nmp; g.N = nmp; g.K = ck->dim; g.A = gq2 + offs[k]; g.lda = q; g.B = prod_k; g.ldb = q; g.C = lhs.d(); g.ldc = nmp;
+    g.M = nmp; g.N = nmp; g.K = (int)(r1 - r0); g.A = gq2 + offs[k] + r0; g.lda = q; g.B = prod_k + r0; g.ldb = q; g.C = lhs.d(); g.ldc = nmp;
     g.alpha = 1; g.beta = 1; g.tri = GEMM_UPPER; g.krange = KR_ALL; g.batch = 1;
     gemm(ctx, true, g);
-  }
-  if (ks_world > 1) {
-    for (size_t k = 0; k < cones.size(); ++k)
-      HYP_REQUIRE(use_sqrt[k], "K-panel sharding covers the sqrt-Hessian branch of the Schur assembly (qrchol.jl:219-234) only");
   }
   allreduce_lhs();   // the one large exchange: sum of the ranks' Schur contributions (cones or K panels)
 }
@@ -460,6 +505,10 @@ void SysSolver::factor_lhs(int* info, int* used_fallback) {   // qrchol.jl:249-2
       hipLaunchKernelGGL(increase_diag_kernel, dim3((nmp + 255) / 256), dim3(256), 0, ctx.stream, nmp, lhs_fact.d(), (long)nmp);
       *info = bk.factor(ctx, nmp, lhs_fact.d(), nmp, dinv.d());
     }
+  }
+  {   // HYP_FORCE_FACT_FAIL=1 (tests): report every link of the chain as failed, so that the hosts' NumericalFailure path runs
+    const char* ff = getenv("HYP_FORCE_FACT_FAIL");
+    if (ff && ff[0] && ff[0] != '0') *info = 1;
   }
   fact_ok = (*info == 0);
   if (use_bk || !fact_ok) tri.invalidate();

@@ -82,6 +82,10 @@ struct SysSolver {
   void allreduce_lhs();   // the n x n exchange of either sharding mode
   void allreduce_dev(double* d_buf, long count, int op);
   void allreduce_host(double* h_buf, int count, int op);
+  // the products of calc_convergence_params / calc_mu (Solvers.jl:418-483) on THIS process's rows of z, s and G, the sums over
+  // ranks taken here: Gtz (n, summed) = G' z; Gx_s (q, these rows) = G x + s; dots = {h' z, z' s} (summed)
+  DBuf rp_x, rp_z, rp_s, rp_t, rp_g;
+  void residual_products(const double* h_x, const double* h_z, const double* h_s, double* h_Gtz, double* h_Gx_s, double* h_dots);
 
   // ---- device-resident direction solves (systemsolvers/common.jl:15-182): the 6x6 system of one
   // stepper direction, reduced 6 -> 4 -> 3 on the device, with the reference's iterative refinement.

@@ -35,6 +35,7 @@ class Comm:
         self.device = device or ("cuda" if dist.get_backend() == "nccl" else "cpu")
         self._ops = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}
         self.n_collectives = 0
+        self.payload_log = []
         self.hist = None     # HYP_PROFILE=1: {(origin, payload doubles, op): calls}
         import os
         if os.environ.get("HYP_PROFILE", "0") not in ("", "0"):
@@ -43,6 +44,8 @@ class Comm:
 
     def _count(self, origin, count, op):
         self.n_collectives += 1
+        if str(origin).startswith("host"):      # (the library's own exchanges are counted by hyp_sys_comm_stats)
+            self.payload_log.append(int(count))   # doubles per host-level collective, in order: tests assert what an iteration exchanges
         if self.hist is not None:
             self.hist[(origin, int(count), str(op))] += 1
 
@@ -384,13 +387,60 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
         self.native_caps = frozenset({"fused", "search"})
         self.cand_in_temp = False
         self._ql_n = self.rows.shape[0]
+        # row-local driver state (solvers.py: calc_mu, calc_convergence_params, the accepted candidate): on this rank only ITS
+        # rows of the z / s vectors are maintained -- no q-vector is exchanged inside an iteration.  Needs contiguous rows
+        # (partition_cones deals out contiguous blocks of cones).
+        r = self.rows
+        contiguous = r.shape[0] > 0 and np.array_equal(r, np.arange(r[0], r[0] + r.shape[0]))
+        if contiguous and os.environ.get("HYP_DIST_ROW_LOCAL", "1") not in ("0",):
+            self.rsl = slice(int(r[0]), int(r[0]) + int(r.shape[0]))
+            self.row_local = True
+            self._last_cand = None
+
+    row_local = False
+
+    def point_version(self, pt):
+        return (id(pt), float(pt.tau), float(pt.kap), float(pt.x[0]) if pt.x.shape[0] else 0.0,
+                float(pt.z[self.rsl][0]) if self._ql_n else 0.0)
+
+    def residual_products(self, pt):
+        """hyp_sys_residual_products on this rank's rows: {Gtz (n, summed over ranks), Gx_s (local rows), hz, zs (summed)}"""
+        n, ql = self.n, self._ql_n
+        Gtz, Gx_s, dots = np.zeros(n), np.zeros(max(ql, 1)), np.zeros(2)
+        z = np.ascontiguousarray(pt.z[self.rsl])
+        sv = np.ascontiguousarray(pt.s[self.rsl])
+        L.check(L.lib().hyp_sys_residual_products(self.local._h, L.vec_ptr(np.ascontiguousarray(pt.x)), L.vec_ptr(z), L.vec_ptr(sv),
+                                                  L.vec_ptr(Gtz), L.vec_ptr(Gx_s), L.vec_ptr(dots)), "hyp_sys_residual_products")
+        return {"Gtz": Gtz, "Gx_s": Gx_s[:ql], "hz": float(dots[0]), "zs": float(dots[1]), "version": self.point_version(pt)}
+
+    def reduce_max(self, vals):
+        vals = np.ascontiguousarray(vals, dtype=np.float64)
+        L.check(L.lib().hyp_sys_allreduce_host(self.local._h, L.vec_ptr(vals), int(vals.shape[0]), 1), "hyp_sys_allreduce_host")
+        return vals
+
+    def accept_candidate(self, pt):
+        cand, ql = self._last_cand, self._ql_n
+        assert cand is not None
+        pt.z[self.rsl] = cand[:ql]
+        pt.tau = cand[ql]
+        pt.s[self.rsl] = cand[ql + 1:2 * ql + 1]
+        pt.kap = cand[2 * ql + 1]
+
+    def gather_rows(self, pt):
+        for v in (pt.z, pt.s):
+            full = np.zeros(self.q)
+            full[self.rsl] = v[self.rsl]
+            self.comm.allreduce(full)
+            v[:] = full
 
     def _local_ztsk(self, pt):
-        return np.concatenate([pt.z[self.rows], [pt.tau], pt.s[self.rows], [pt.kap]])
+        rows = self.rsl if self.row_local else self.rows
+        return np.concatenate([pt.z[rows], [pt.tau], pt.s[rows], [pt.kap]])
 
     def step_directions_native(self, solver, stepper):
         import ctypes
-        model, rows, n, ql = solver.model, self.rows, self.n, self._ql_n
+        model, n, ql = solver.model, self.n, self._ql_n
+        rows = self.rsl if self.row_local else self.rows     # (a slice: views, no gather of 2 q_local entries per vector)
         c_int = ctypes.c_int
         pt = solver.point
         vec_l = np.concatenate([pt.x, pt.z[rows], [pt.tau], pt.s[rows], [pt.kap]])
@@ -410,19 +460,27 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
         if info.value != 0:
             print("positive definite linear system factorization failed")
             return False
-        # global z / s parts of the four directions: every rank contributes its rows, one all-reduce
         q = self.q
-        zs = np.zeros((4, 2 * q))
-        for k in range(4):
-            zs[k, rows] = dirs_l[k, n:n + ql]
-            zs[k, q + rows] = dirs_l[k, n + ql + 1:n + 2 * ql + 1]
-        self.comm.allreduce(zs)
-        for k, d in enumerate((stepper.dir_cent, stepper.dir_pred, stepper.dir_centadj, stepper.dir_predadj)):
-            d.x[:] = dirs_l[k, :n]
-            d.z[:] = zs[k, :q]
-            d.s[:] = zs[k, q:]
-            d.tau = dirs_l[k, n + ql]
-            d.kap = dirs_l[k, -1]
+        if self.row_local:   # every rank keeps its own rows of the directions; nobody needs the others'
+            for k, d in enumerate((stepper.dir_cent, stepper.dir_pred, stepper.dir_centadj, stepper.dir_predadj)):
+                d.x[:] = dirs_l[k, :n]
+                d.z[self.rsl] = dirs_l[k, n:n + ql]
+                d.s[self.rsl] = dirs_l[k, n + ql + 1:n + 2 * ql + 1]
+                d.tau = dirs_l[k, n + ql]
+                d.kap = dirs_l[k, -1]
+        else:
+            # global z / s parts of the four directions: every rank contributes its rows, one all-reduce
+            zs = np.zeros((4, 2 * q))
+            for k in range(4):
+                zs[k, rows] = dirs_l[k, n:n + ql]
+                zs[k, q + rows] = dirs_l[k, n + ql + 1:n + 2 * ql + 1]
+            self.comm.allreduce(zs)
+            for k, d in enumerate((stepper.dir_cent, stepper.dir_pred, stepper.dir_centadj, stepper.dir_predadj)):
+                d.x[:] = dirs_l[k, :n]
+                d.z[:] = zs[k, :q]
+                d.s[:] = zs[k, q:]
+                d.tau = dirs_l[k, n + ql]
+                d.kap = dirs_l[k, -1]
         solver.n_solves += ns.value
         assert not any(np.isnan(resn[k]) for k in range(4))
         if solver.max_ref_steps > 0:
@@ -451,6 +509,7 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
             float(searcher.prox_bound), int(bool(searcher.use_max_prox)), float(searcher.nup1), L.vec_ptr(cand), ctypes.byref(idx),
             ctypes.byref(prox), ctypes.byref(nt), ctypes.byref(nl), ctypes.byref(irtmu)), "hyp_sys_search_alpha")
         searcher.n_trials += nt.value
+        self._last_cand = cand
         # host mirrors of this rank's cones follow the last candidate they were loaded with
         off = 0
         for j, k in enumerate(model.local_ks):
@@ -503,6 +562,8 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
     def update_lhs(self, solver):
         model = solver.model
         self.update_lhs_fact(solver)
+        if self.last_info != 0:   # (no factorization: the stepper ends in NumericalFailure on every rank -- the same matrix everywhere)
+            return self
         self.block_hess_prod_full(self.rhs_const.z, model.h)
         self.solve_subsystem3(solver, self.sol_const, self.rhs_const)
         return self

@@ -486,8 +486,15 @@ class CombinedStepper:
                         solver.status = "NumericalFailure"
                         self.prev_alpha = alpha
                         return False
-        self.update_stepper_points(alpha, point, False)
         sysv = solver.syssolver
+        if getattr(sysv, "row_local", False):
+            # cone-sharded solver: this rank's rows of z / s (and tau, kap) are the accepted candidate the library formed and
+            # loaded its cones with; x is replicated; the other ranks' rows are never read on this rank
+            self.update_stepper_points_x(alpha, point)
+            sysv.accept_candidate(point)
+            self.prev_alpha = alpha
+            return True
+        self.update_stepper_points(alpha, point, False)
         if _cap(sysv, "search") and getattr(sysv, "cand_in_temp", True):
             point.ztsk[:] = self.temp.ztsk   # exactly the accepted candidate the cones were loaded with (formed natively)
         self.prev_alpha = alpha
@@ -510,6 +517,28 @@ class CombinedStepper:
         assert not (np.isnan(ra) or np.isnan(rb))
         if solver.max_ref_steps > 0:
             solver.worst_dir_res = max(solver.worst_dir_res, ra, rb)
+
+    def update_stepper_points_x(self, alpha, point):   # the x / y entries of :124-170 (same operation order per entry)
+        k = point.n + point.p
+        cand = point.vec[:k]
+        sel = lambda pt: pt.vec[:k]
+        dir_cent, dir_pred = sel(self.dir_cent), sel(self.dir_pred)
+        if self.unadj_only:
+            if self.cent_only:
+                cand += alpha * dir_cent
+            else:
+                cand += alpha * dir_pred + (1 - alpha) * dir_cent
+        else:
+            dir_centadj = sel(self.dir_centadj)
+            alpha_sqr = alpha ** 2
+            if self.cent_only:
+                cand += alpha * dir_cent + alpha_sqr * dir_centadj
+            else:
+                dir_predadj = sel(self.dir_predadj)
+                alpha_m1 = 1 - alpha
+                alpha_m1sqr = alpha_m1 ** 2
+                cand += (alpha * dir_pred + alpha_sqr * dir_predadj + alpha_m1 * dir_cent
+                         + alpha_m1sqr * dir_centadj)
 
     def update_stepper_points(self, alpha, point, ztsk_only):   # :124-170
         if ztsk_only:
@@ -743,10 +772,59 @@ class Solver:
 
     def calc_mu(self):   # :418-423
         pt = self.point
+        sysv = self.syssolver
+        if getattr(sysv, "row_local", False):
+            # cone-sharded solver: z / s hold this rank's rows; one device call forms G'z, G x + s, h'z and z's for the point
+            # (sums over ranks inside the library) -- calc_convergence_params of the next pass reads the same record
+            rp = self._row_products = sysv.residual_products(pt)
+            self.mu = (rp["zs"] + pt.tau * pt.kap) / (self.model.nu + 1)
+            return self.mu
         self.mu = (pt.z @ pt.s + pt.tau * pt.kap) / (self.model.nu + 1)
         return self.mu
 
+    def _calc_convergence_params_row_local(self):   # :425-483 on a cone-sharded solver
+        model, point, sysv = self.model, self.point, self.syssolver
+        tau = point.tau
+        rp = getattr(self, "_row_products", None)
+        if rp is None or rp["version"] != sysv.point_version(point):
+            rp = sysv.residual_products(point)
+        self._row_products = None
+        rows = sysv.rsl
+        xr = rp["Gtz"]
+        self.x_norm_res_t = _norm_inf(xr)
+        xr = xr + model.c * tau
+        self.x_norm_res = _norm_inf(xr) / tau
+        self.x_residual[:] = -xr
+        x_feas = self.x_norm_res * self.x_conv_tol
+        self.y_norm_res_t = self.y_norm_res = 0.0
+        y_feas = 0.0
+        zr = rp["Gx_s"]                        # this rank's rows of G x + s
+        zn_t = _norm_inf(zr)
+        zr = zr - model.h[rows] * tau
+        zn = _norm_inf(zr)
+        self.z_residual[rows] = zr
+        norms = sysv.reduce_max(np.array([zn_t, zn]))
+        self.z_norm_res_t = float(norms[0])
+        self.z_norm_res = float(norms[1]) / tau
+        z_feas = self.z_norm_res * self.z_conv_tol
+        self.primal_obj_t = model.c @ point.x
+        self.dual_obj_t = -rp["hz"]
+        self.tau_residual = self.primal_obj_t - self.dual_obj_t + point.kap
+        tau_feas = abs(self.tau_residual)
+        improv = 0.0
+        for curr, prev in ((x_feas, self.x_feas), (y_feas, self.y_feas), (z_feas, self.z_feas), (tau_feas, self.tau_feas)):
+            if np.isnan(prev) or np.isnan(curr):
+                continue
+            improv = max(improv, (prev - curr) / (abs(prev) + EPS))
+        self.x_feas, self.y_feas, self.z_feas, self.tau_feas = x_feas, y_feas, z_feas, tau_feas
+        self.primal_obj = self.primal_obj_t / tau + model.obj_offset
+        self.dual_obj = self.dual_obj_t / tau + model.obj_offset
+        self.gap = rp["zs"]
+        return improv
+
     def calc_convergence_params(self):   # :425-483
+        if getattr(self.syssolver, "row_local", False):
+            return self._calc_convergence_params_row_local()
         model, point = self.model, self.point
         tau = point.tau
         xr = self.syssolver.mul_G(True, point.z)
@@ -1127,6 +1205,8 @@ def find_initial_y(solver, init_z, reduce):   # process.jl:182-365
 
 def postprocess(solver):   # process.jl:385-458
     point, result = solver.point, solver.result
+    if getattr(solver.syssolver, "row_local", False):
+        solver.syssolver.gather_rows(point)   # cone-sharded solver: every rank gets all rows of z and s, once, for the result
     om = solver.orig_model
     if solver.status in ("PrimalInfeasible", "DualInfeasible"):
         tau = 1.0

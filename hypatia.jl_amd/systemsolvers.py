@@ -111,8 +111,13 @@ class QRCholDenseSystemSolver:
             if info.value != 0:
                 print("positive definite linear system factorization failed")
             return self
+        self.last_info = 0
         if model.n - model.p > 0:
             self.update_lhs_fact(solver)
+            if self.last_info != 0:
+                # every link of posdef_fact_copy! failed (qrchol.jl:253-255): there is no factorization to solve the constant
+                # column with; the stepper sees last_info and ends in NumericalFailure (combined.jl:97-117)
+                return self
         hh = np.ascontiguousarray(model.h)
         L.check(L.lib().hyp_sys_block_hess_prod(self._h, L.vec_ptr(self.rhs_const.z), L.vec_ptr(hh)), "hyp_sys_block_hess_prod")
         self.solve_subsystem3(solver, self.sol_const, self.rhs_const)

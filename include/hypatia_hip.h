@@ -51,6 +51,10 @@ int hyp_cone_create_epinormspectral_complex(hyp_ctx* ctx, int d1, int d2, int us
 /* Cones.WSOSInterpNonnegative{Float64,Float64}(U, Ps; use_dual) (wsosinterpnonnegative.jl:49-63):
  * Ps[k] is U x Ls[k], column-major; the matrices are copied to the device */
 int hyp_cone_create_wsosinterpnonnegative(hyp_ctx* ctx, int U, int K, const int* Ls, const double* const* Ps, int use_dual, hyp_cone** out);
+/* Cones.WSOSInterpNonnegative{Float64,ComplexF64}(U, Ps; use_dual) (wsosinterpnonnegative.jl:15, 49-63 with R = Complex{T}; bases
+ * from src/PolyUtils/complex.jl:13-72): Ps[k] is a U x Ls[k] matrix of complex numbers, (re, im) interleaved = Matrix{ComplexF64},
+ * column-major; the cone vector stays real (dim = U); nu = sum_k Ls[k] */
+int hyp_cone_create_wsosinterpnonnegative_complex(hyp_ctx* ctx, int U, int K, const int* Ls, const double* const* Ps, int use_dual, hyp_cone** out);
 /* Cones.LinMatrixIneq{Float64}(As; use_dual) (linmatrixineq.jl:36-65), real dense symmetric members: As holds the
  * dim matrices one after the other, each side x side column-major (A_1 positive definite, dim <= side (side + 1) / 2);
  * copied to the device.  nu = side. */
@@ -170,6 +174,15 @@ int hyp_sys_mul_G(hyp_sys* sys, int trans, double alpha, const double* x, double
  * solve_system / solve_subsystem4 (common.jl:129-182), setup_rhs3 (qrchol.jl:16-37) and the residual
  * apply_lhs (common.jl:79-121) all on the GPU; only the right-hand side goes in and the direction
  * comes out.  Vectors use Hypatia's Point layout [x(n); y(p); z(q); tau; s(q); kap] (point.jl:5-54). */
+/* The products of Solvers.calc_convergence_params and calc_mu (src/Solvers/Solvers.jl:418-483: G' z, G x + s, h' z, z' s) in
+ * one call on the resident G.  On a cone-sharded solver (hyp_sys_set_comm / hyp_sys_set_comm_rccl) z, s and out_Gx_s are THIS
+ * process's rows and the sums over ranks are taken inside (one all-reduce of n doubles, one of two): out_Gtz (n) = G' z summed,
+ * out_Gx_s (q) = G x + s on these rows, out_dots2 = {h' z, z' s} summed -- no q-vector ever leaves a rank.  Needs
+ * hyp_sys_load_model (for h). */
+int hyp_sys_residual_products(hyp_sys* sys, const double* x, const double* z, const double* s, double* out_Gtz, double* out_Gx_s, double* out_dots2);
+/* In-place all-reduce of up to 32 host doubles over the solver's communicator (op 0 sum, 1 max, 2 min; a no-op on a single-GPU
+ * solver): the residual norms of Solvers.jl:425-483 on a cone-sharded solver */
+int hyp_sys_allreduce_host(hyp_sys* sys, double* buf, int count, int op);
 /* model.c (n), model.b (p), model.h (q), model.A (p x n col-major, NULL when p = 0) after preprocessing */
 int hyp_sys_load_model(hyp_sys* sys, const double* c, const double* b, const double* h, const double* A);
 /* update_lhs (qrchol.jl:181-199): update_lhs_fact + sol_const = solve_subsystem3([-c; b; H h]); the

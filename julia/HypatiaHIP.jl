@@ -1,7 +1,7 @@
 # HypatiaHIP.jl -- the reference-side binding of libhypatia_hip.so (include/hypatia_hip.h).
 #
 # New subtypes of Hypatia's two extension points and nothing else:
-#   * Cones.Cone{Float64}                      (src/Cones/Cones.jl:27)          -> nine HIP cone types below
+#   * Cones.Cone{Float64}                      (src/Cones/Cones.jl:27)          -> fourteen HIP cone types below
 #   * Solvers.QRCholSystemSolver{Float64}      (systemsolvers/qrchol.jl:14)     -> HIPQRCholDenseSystemSolver
 #   * Solvers.SymIndefSystemSolver{Float64}    (systemsolvers/symindef.jl:29)   -> HIPSymIndefDenseSystemSolver
 # Use:  solver = Solvers.Solver{Float64}(syssolver = HypatiaHIP.HIPQRCholDenseSystemSolver())
@@ -104,6 +104,7 @@ end
 @hipcone EpiNormSpectral            # Cones.EpiNormSpectral{Float64, Float64}          epinormspectral.jl:13-66
 @hipcone EpiNormSpectralComplex     # Cones.EpiNormSpectral{Float64, ComplexF64}       epinormspectral.jl:13-66 (dim = 1 + 2 d1 d2)
 @hipcone WSOSInterpNonnegative      # Cones.WSOSInterpNonnegative{Float64, Float64}    wsosinterpnonnegative.jl:16-63
+@hipcone WSOSInterpNonnegativeComplex   # Cones.WSOSInterpNonnegative{Float64, ComplexF64} wsosinterpnonnegative.jl:15-63 (complex Ps, real cone vector)
 @hipcone LinMatrixIneq              # Cones.LinMatrixIneq{Float64} (dense real symmetric or complex Hermitian members) linmatrixineq.jl:9-65
 @hipcone DoublyNonnegativeTri       # Cones.DoublyNonnegativeTri{Float64}              doublynonnegativetri.jl:9-52
 @hipcone HypoRootdetTri             # Cones.HypoRootdetTri{Float64, Float64}           hyporootdettri.jl:9-59
@@ -169,6 +170,23 @@ function WSOSInterpNonnegative(U::Int, Ps::Vector{Matrix{Float64}}; use_dual::Bo
             CTX[], U, length(Ps), Ls, ptrs, use_dual, h), "hyp_cone_create_wsosinterpnonnegative")
     end
     return WSOSInterpNonnegative(h[], Ps)
+end
+
+# complex bases (src/PolyUtils/complex.jl:13-72): a Matrix{ComplexF64} is (re, im) interleaved, column-major, which is what the
+# C-ABI takes
+function WSOSInterpNonnegativeComplex(U::Int, Ps::Vector{Matrix{ComplexF64}}; use_dual::Bool = false)
+    for Pk in Ps
+        @assert size(Pk, 1) == U                                                  # wsosinterpnonnegative.jl:54-56
+    end
+    Ls = Cint[size(Pk, 2) for Pk in Ps]
+    ptrs = Ptr{Float64}[Ptr{Float64}(pointer(Pk)) for Pk in Ps]
+    h = new_handle()
+    GC.@preserve Ps ptrs begin
+        check(ccall((:hyp_cone_create_wsosinterpnonnegative_complex, lib), Cint,
+            (Ptr{Cvoid}, Cint, Cint, Ptr{Cint}, Ptr{Ptr{Float64}}, Cint, Ptr{Ptr{Cvoid}}),
+            CTX[], U, length(Ps), Ls, ptrs, use_dual, h), "hyp_cone_create_wsosinterpnonnegative_complex")
+    end
+    return WSOSInterpNonnegativeComplex(h[], Ps)
 end
 
 function WSOSInterpPosSemidefTri(R::Int, U::Int, Ps::Vector{Matrix{Float64}}; use_dual::Bool = false)

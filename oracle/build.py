@@ -29,6 +29,9 @@ def make_cone(spec):
     if kind == "epinormspectral_complex":
         from .cones_complex import EpiNormSpectralComplex
         return EpiNormSpectralComplex(spec[1], spec[2], use_dual=spec[3])
+    if kind == "wsosinterpnonnegative_complex":
+        from .cones_complex import WSOSInterpNonnegativeComplex
+        return WSOSInterpNonnegativeComplex(spec[1], spec[2], use_dual=spec[3])
     if kind == "linmatrixineq_complex":
         from .cones_complex import LinMatrixIneqComplex
         return LinMatrixIneqComplex(spec[1], use_dual=spec[2])

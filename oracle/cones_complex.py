@@ -1,5 +1,5 @@
-"""TEST INFRASTRUCTURE (CPU oracle), not the product: complex variants of PosSemidefTri, EpiNormSpectral, LinMatrixIneq, HypoRootdetTri and HypoPerLogdetTri, the item of
-SURVEY 8(f) rank 3 that the device path does not cover yet ("complex Hermitian variants").  Restates
+"""TEST INFRASTRUCTURE (CPU oracle), not the product: complex variants of PosSemidefTri, EpiNormSpectral, LinMatrixIneq, HypoRootdetTri, HypoPerLogdetTri and
+WSOSInterpNonnegative (src/Cones/wsosinterpnonnegative.jl:15-200 with complex bases), the "complex Hermitian variants" of SURVEY 8(f) rank 3.  Restates
 reference src/Cones/possemideftri.jl:9-207, src/Cones/epinormspectral.jl:13-294 (R = Complex{Float64}), src/Cones/linmatrixineq.jl:9-159 (Hermitian members) and the complex
 vectorisation helpers of
 src/Cones/arrayutilities.jl:13,81,103-108 (lengths), :188-210 (smat_to_svec!), :240-262 (svec_to_smat!), :308-352 (symm_kron!),
@@ -11,6 +11,7 @@ The svec of a Hermitian matrix holds, column by column over the upper triangle, 
 pair (re, -im) of sqrt(2)*mat[i, j], i.e. (re, im) of the lower-triangle entry."""
 import numpy as np
 import scipy.linalg as sla
+from scipy.linalg import lapack
 
 from . import arrayutil as au
 from .cones import Cone, _cols
@@ -479,6 +480,103 @@ class LinMatrixIneqComplex(Cone):
         Z = dir_mat @ dir_mat.conj().T
         for i in range(self.dim):
             self.dder3_[i] = np.vdot(Z, self.sumAinvAs[i]).real
+        return self.dder3_
+
+
+# ----------------------------------------------------------------------------------------------
+class WSOSInterpNonnegativeComplex(Cone):
+    """wsosinterpnonnegative.jl:15-200 with R = Complex{T}: real-valued Hermitian polynomials, complex bases `Ps`
+    (PolyUtils/complex.jl:13-72), REAL cone vector of U interpolant values.  The barrier is for the DUAL cone:
+    use_dual_barrier = !use_dual (:58).  Lambda_k = P_k' Diag(pt) P_k is Hermitian."""
+
+    def __init__(self, U, Ps, use_dual=False):
+        for Pk in Ps:
+            assert Pk.shape[0] == U                            # :54-56
+        self.use_dual_barrier_ = not use_dual                  # :58
+        self.dim = U
+        self.Ps = [np.asfortranarray(Pk, dtype=complex) for Pk in Ps]
+        self.nu = sum(Pk.shape[1] for Pk in Ps)                # :61
+
+    def reset_data(self):   # :66-68
+        self.feas_updated = self.grad_updated = self.hess_updated = self.inv_hess_updated = False
+        self.hess_fact_updated = False
+        self.use_hess_prod_slow = self.use_hess_prod_slow_updated = False
+
+    def setup_extra_data(self):   # :70-85
+        K = len(self.Ps)
+        self.LamF = [None] * K
+        self.LamFLP = [None] * K
+
+    def get_nu(self):
+        return self.nu
+
+    def set_initial_point(self, arr):   # :87
+        arr[:] = 1.0
+        return arr
+
+    def update_feas(self):   # :89-117 (the Ps_order timing sort only changes evaluation order)
+        assert not self.feas_updated
+        self.is_feas_ = True
+        for k, Pk in enumerate(self.Ps):
+            LUk = Pk.conj().T * self.point[None, :]            # Pk' * Diagonal(point)
+            LLk = LUk @ Pk
+            c, info = lapack.zpotrf(LLk, lower=1, clean=1)     # cholesky!(Hermitian(LLk, :L), check = false)
+            self.LamF[k] = c
+            if info != 0:
+                self.is_feas_ = False
+                break
+        self.feas_updated = True
+        return self.is_feas_
+
+    def update_grad(self):   # :119-133
+        assert self.is_feas_
+        self.grad[:] = 0
+        for k, Pk in enumerate(self.Ps):
+            LFLP = sla.solve_triangular(self.LamF[k], Pk.conj().T, lower=True)   # ldiv!(LamFLP_k, LamF_k.L, P_k')
+            self.LamFLP[k] = LFLP
+            self.grad -= np.sum(np.abs(LFLP) ** 2, axis=0)                        # sum(abs2, LamFLP_k[:, j])
+        self.grad_updated = True
+        return self.grad
+
+    def update_hess(self):   # :135-150 (upper triangle)
+        assert self.grad_updated
+        H = np.zeros((self.dim, self.dim))
+        for k in range(len(self.Ps)):
+            UU = self.LamFLP[k].conj().T @ self.LamFLP[k]      # outer_prod!(LamFLP_k, UU, true, false)
+            H += np.triu(np.abs(UU) ** 2)                      # abs2(UU[i, j])
+        self.hess_ = H
+        self.hess_updated = True
+        return self.hess_
+
+    def _partial_lambda(self, dir, LFLP):   # :190-200
+        LU = LFLP * dir[None, :]
+        LL = LU @ LFLP.conj().T
+        LLh = np.triu(LL) + np.triu(LL, 1).conj().T            # Hermitian(LLk) reads the upper triangle
+        np.fill_diagonal(LLh, LLh.diagonal().real)
+        return LLh @ LFLP
+
+    def hess_prod_slow(self, prod, arr):   # :152-175
+        if not self.use_hess_prod_slow_updated:
+            self.update_use_hess_prod_slow()
+        assert self.hess_updated
+        if not self.use_hess_prod_slow:
+            return self.hess_prod(prod, arr)
+        assert self.grad_updated
+        P, A = _cols(prod), _cols(arr)
+        P[:] = 0
+        for k in range(len(self.Ps)):
+            LFLP = self.LamFLP[k]
+            for j in range(A.shape[1]):
+                LU = self._partial_lambda(A[:, j], LFLP)
+                P[:, j] += np.sum(LFLP.conj() * LU, axis=0).real   # real(dot(LamFLP_k[:, i], LU_k[:, i]))
+        return prod
+
+    def dder3(self, dir):   # :177-188
+        assert self.grad_updated
+        self.dder3_[:] = 0
+        for k in range(len(self.Ps)):
+            LU = self._partial_lambda(dir, self.LamFLP[k])
+            self.dder3_ += np.sum(np.abs(LU) ** 2, axis=0)
         return self.dder3_
 
 

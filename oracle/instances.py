@@ -893,6 +893,26 @@ def hypoperlogdettri3_complex(seed=1):   # :1861-1884, complex member
             dict(status="Optimal", check=check))
 
 
+def wsosinterpnonnegative4(seed=1):   # :2345-2363: min of 1 + |z|^2 over the unit disc = 1, complex WSOS certificate
+    rng = np.random.default_rng(seed)
+    gs = [lambda z: 1.0 - float(np.sum(np.abs(z) ** 2))]
+    points, Ps = pu.interpolate_complex(1, 2, gs, [1], rng=rng)
+    U = len(points)
+    hvals = np.array([1.0 + float(np.sum(np.abs(z) ** 2)) for z in points])
+    return (np.array([-1.0]), np.zeros((0, 1)), np.zeros(0), np.ones((U, 1)), hvals,
+            [("wsosinterpnonnegative_complex", U, Ps, False)], dict(status="Optimal", primal_obj=-1.0))
+
+
+def wsosinterpnonnegative5(seed=1):   # :2365-2383: the same minimum over the bidisc, dual form
+    rng = np.random.default_rng(seed)
+    gs = [lambda z: 1.0 - abs(z[0]) ** 2, lambda z: 1.0 - abs(z[1]) ** 2]
+    points, Ps = pu.interpolate_complex(2, 2, gs, [1, 1], rng=rng)
+    U = len(points)
+    cvals = np.array([1.0 + float(np.sum(np.abs(z) ** 2)) for z in points])
+    return (cvals, np.ones((1, U)), np.array([1.0]), -np.eye(U), np.zeros(U),
+            [("wsosinterpnonnegative_complex", U, Ps, True)], dict(status="Optimal", primal_obj=1.0))
+
+
 KNOWN_ANSWER_COMPLEX = {
     "hypoperlogdettri1_complex": hypoperlogdettri1_complex, "hypoperlogdettri2_complex": hypoperlogdettri2_complex,
     "hypoperlogdettri3_complex": hypoperlogdettri3_complex,
@@ -910,4 +930,5 @@ KNOWN_ANSWER_COMPLEX = {
     "epinormspectral3_complex_1x3_dual": lambda: epinormspectral3_complex(1, 3, True),
     "epinormspectral3_complex_2x2": lambda: epinormspectral3_complex(2, 2, False),
     "epinormspectral3_complex_3x4_dual": lambda: epinormspectral3_complex(3, 4, True),
+    "wsosinterpnonnegative4": wsosinterpnonnegative4, "wsosinterpnonnegative5": wsosinterpnonnegative5,
 }

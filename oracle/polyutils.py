@@ -188,3 +188,48 @@ def interpolate_free(n, d, rng=None, sample_factor=10):
     cand = 2.0 * rng.random((U * sample_factor, n)) - 1.0
     pts, P0, _ = make_wsos_arrays(0, cand, d)
     return U, pts, [P0]
+
+
+def interpolate_complex(halfdeg, n, gs, g_halfdegs, rng=None, sample_factor=10, keep=None):
+    """interpolate(Complex{T}, halfdeg, n, gs, g_halfdegs): src/PolyUtils/complex.jl:13-72 (use_qr = false).  Returns (points, Ps):
+    U = L^2 points in C^n chosen from sample_factor * U random points of the domain {z in the unit box : g(z) > 0 for g in gs} by
+    the pivoted QR of the transposed Vandermonde matrix of the basis z^a conj(z)^b, and the complex bases P0 = the monomial
+    columns, P_i = Diagonal(sqrt(g_i(points))) P0[:, 1:L_i].  The random draws come from numpy's generator instead of Julia's
+    (the instances built on it assert optimal values that do not depend on the points)."""
+    global LAST_KEEP
+    rng = rng if rng is not None else np.random.default_rng(1)
+    L = comb(n + halfdeg, n)
+    U = L * L
+    L_basis = [a for t in range(halfdeg + 1) for a in multiexponents(n, t)]
+
+    def mon_pow(z, ex):
+        out = 1.0 + 0.0j
+        for i, e in enumerate(ex):
+            out *= z[i] ** e
+        return out
+
+    num_samples = sample_factor * U
+    samples = []
+    while len(samples) < num_samples:                                   # :37-47
+        z = np.array([complex(2 * rng.random() - 1, 2 * rng.random() - 1) for _ in range(n)])
+        if all(g(z) > 0 for g in gs):
+            samples.append(z)
+    # V[s, l * L + k] = z^L_basis[k] * conj(z)^L_basis[l]  (:28-31: l outer, k inner)
+    V = np.zeros((num_samples, U), dtype=complex)
+    for si, z in enumerate(samples):
+        zp = np.array([mon_pow(z, a) for a in L_basis])
+        V[si, :] = np.outer(np.conj(zp), zp).reshape(-1)               # row-major (l, k) -> l * L + k
+    if keep is None:
+        piv = qr(V.T, mode="r", pivoting=True)[1]                       # qr(Matrix(transpose(V)), ColumnNorm()), :52
+        keep = piv[:U]
+    keep = np.asarray(keep, dtype=np.int64)
+    LAST_KEEP = keep.copy()
+    points = [samples[i] for i in keep]
+    V = V[keep, :]
+    P0 = V[:, :L]                                                       # :57
+    Ps = [np.asfortranarray(P0)]
+    for g, ghd in zip(gs, g_halfdegs):                                  # :62-69
+        gi = np.array([g(z) for z in points], dtype=float)
+        Li = comb(n + halfdeg - ghd, n)
+        Ps.append(np.asfortranarray(np.sqrt(gi)[:, None] * P0[:, :Li]))
+    return points, Ps

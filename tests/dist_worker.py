@@ -96,10 +96,15 @@ def run(rank, world, port, inst_args, out_path, backend="oracle", transport="glo
         lb = D.HipLocalSys if backend == "hip" else OracleLocalSys
         solver = H.Solver(verbose=False, syssolver=D.DistQRCholDenseSystemSolver(comm, local_backend=lb))
         solver.load(model)
+        marks = []
+        solver.iter_callback = lambda sv: marks.append(len(comm.payload_log))   # (first call: set-up is over; last: before postprocess)
         solver.solve()
+        in_loop = comm.payload_log[marks[0]:marks[-1]] if len(marks) >= 2 else []
         if rank == 0:
             np.savez(out_path, status=solver.status, iters=solver.num_iters, p_obj=solver.primal_obj, d_obj=solver.dual_obj,
                      x=solver.get_x(), s=solver.get_s(), z=solver.get_z(), ncoll=comm.n_collectives,
+                     max_host_payload_in_loop=(max(in_loop) if in_loop else 0), host_collectives_in_loop=len(in_loop),
+                     row_local=bool(getattr(solver.syssolver, "row_local", False)), q=model.q, n=model.n,
                      hooked=bool(getattr(solver.syssolver, "_hooked", False)), worst_dir_res=solver.worst_dir_res,
                      rccl_in_library=bool(getattr(solver.syssolver, "rccl_in_library", False)), lib_exchanges=_lib_exchanges(solver))
     finally:
@@ -118,7 +123,10 @@ def run_kshard(rank, world, port, inst_args, out_path, backend="oracle"):
         import hypatia_jl_amd as H
         from hypatia_jl_amd import distributed as D
         from oracle import instances as I
-        inst = I.psd_blocks(*inst_args)
+        if inst_args and inst_args[0] == "polymin":
+            inst = I.polymin(*inst_args[1:])
+        else:
+            inst = I.psd_blocks(*inst_args)
         if backend == "hip":
             comm = D.Comm(device="cuda")
             solver = H.Solver(verbose=False, syssolver=D.KShardQRCholDenseSystemSolver(comm))

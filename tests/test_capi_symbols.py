@@ -159,7 +159,7 @@ def test_julia_binding_matches_the_header():
     must = {"hyp_cone_create_nonnegative", "hyp_cone_create_possemideftri", "hyp_cone_create_epinormspectral", "hyp_cone_create_wsosinterpnonnegative",
             "hyp_cone_create_linmatrixineq", "hyp_cone_create_doublynonnegativetri", "hyp_cone_create_hyporootdettri", "hyp_cone_create_hypoperlogdettri",
             "hyp_cone_create_wsosinterppossemideftri", "hyp_cone_create_possemideftri_complex", "hyp_cone_create_epinormspectral_complex",
-            "hyp_cone_create_linmatrixineq_complex", "hyp_cone_create_hyporootdettri_complex", "hyp_cone_create_hypoperlogdettri_complex", "hyp_cone_use_dual_barrier", "hyp_cone_get_nu", "hyp_cone_dimension", "hyp_sys_create",
+            "hyp_cone_create_linmatrixineq_complex", "hyp_cone_create_hyporootdettri_complex", "hyp_cone_create_hypoperlogdettri_complex", "hyp_cone_create_wsosinterpnonnegative_complex", "hyp_cone_use_dual_barrier", "hyp_cone_get_nu", "hyp_cone_dimension", "hyp_sys_create",
             "hyp_sys_load", "hyp_sys_update_lhs_fact", "hyp_sys_solve3", "hyp_sys_block_hess_prod", "hyp_symindef_create", "hyp_symindef_load",
             "hyp_symindef_update_lhs", "hyp_symindef_solve3", "hyp_cone_update_use_hess_prod_slow", "hyp_cone_set_use_hess_prod_slow"}
     assert must <= seen, sorted(must - seen)

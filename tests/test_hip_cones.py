@@ -747,6 +747,85 @@ def test_linmatrixineq_complex_vs_oracle(side, count):
 
 
 # ---------------------------------------------------------------------------------------------
+# WSOSInterpNonnegative{T, Complex{T}} (the sixth complex variant): the real cone at the duplicated point over the
+# embedded bases, barrier halved (csrc/cone_wsos_complex.hip)
+# ---------------------------------------------------------------------------------------------
+def _rand_interp_c(num_vars, halfdeg, seed=1):   # test/cone.jl:306-315 (complex Ps on the unit ball)
+    from oracle import polyutils as pu
+    gs = [lambda z: 1.0 - float(np.sum(np.abs(z) ** 2))]
+    points, Ps = pu.interpolate_complex(halfdeg, num_vars, gs, [1], rng=np.random.default_rng(seed))
+    return len(points), Ps
+
+
+@pytest.mark.parametrize("num_vars,halfdeg", [(1, 1), (1, 3), (2, 1), (2, 2), (3, 1)])
+def test_wsosinterpnonnegative_complex_identities(num_vars, halfdeg):   # test/cone.jl:757-762 with R = Complex
+    import hypatia_jl_amd as H
+    U, Ps = _rand_interp_c(num_vars, halfdeg)
+    run_test_oracles(H.WSOSInterpNonnegativeComplex(U, Ps), init_tol=np.inf)
+
+
+@pytest.mark.parametrize("num_vars,halfdeg,use_dual", [(1, 1, False), (1, 3, True), (2, 1, False), (2, 2, True), (3, 1, False), (2, 4, False),
+                                                        (3, 2, True)])
+def test_wsosinterpnonnegative_complex_vs_oracle(num_vars, halfdeg, use_dual):
+    """every oracle against the complex CPU restatement (oracle/cones_complex.py: Hermitian Lambda_k, complex Cholesky, abs2
+    Hessian) at a random interior point; up to U = 225 (two variables, half-degree 4) and U = 100 in three variables"""
+    import hypatia_jl_amd as H
+    from oracle import cones_complex as occ
+    rng = np.random.default_rng(100 * num_vars + halfdeg)
+    U, Ps = _rand_interp_c(num_vars, halfdeg)
+    hc, oc = H.WSOSInterpNonnegativeComplex(U, Ps, use_dual=use_dual), occ.WSOSInterpNonnegativeComplex(U, Ps, use_dual=use_dual)
+    nu = sum(P.shape[1] for P in Ps)
+    assert hc.dimension() == oc.dimension() == U and hc.get_nu() == oc.get_nu() == nu
+    assert hc.use_dual_barrier() == oc.use_dual_barrier() == (not use_dual)        # wsosinterpnonnegative.jl:58
+    pt = np.zeros(U)
+    oc.set_initial_point(pt)
+    pt2 = np.zeros(U)
+    hc.set_initial_point(pt2)
+    assert np.array_equal(pt, pt2)
+    pt = pt * (1.0 + 0.3 * (2 * rng.random(U) - 1))
+    for c in (hc, oc):
+        c.setup_data()
+        c.reset_data()
+        c.load_point(pt, 0.9)
+        assert c.is_feas()
+    g_o = np.array(oc.get_grad())
+    assert rel(np.array(hc.get_grad()), g_o) < 1e-11
+    dual = -g_o * (1.0 + 0.05 * (2 * rng.random(U) - 1))
+    for c in (hc, oc):
+        c.load_dual_point(dual)
+        assert c.is_dual_feas()
+    V = np.asfortranarray(rng.standard_normal((U, 3)))
+    for name in ("hess_prod", "inv_hess_prod", "hess_prod_slow"):
+        Ph, Po = np.zeros((U, 3), order="F"), np.zeros((U, 3), order="F")
+        getattr(hc, name)(Ph, V)
+        getattr(oc, name)(Po, V)
+        assert rel(Ph, Po) < 1e-9, name
+    if hc.use_sqrt_hess_oracles(U) and oc.use_sqrt_hess_oracles(U):
+        for name in ("sqrt_hess_prod", "inv_sqrt_hess_prod"):
+            Ph, Po = np.zeros((U, 3), order="F"), np.zeros((U, 3), order="F")
+            getattr(hc, name)(Ph, V)
+            getattr(oc, name)(Po, V)
+            assert rel(Ph, Po) < 1e-8, name
+    d = V[:, 0].copy() * 0.01
+    assert rel(np.array(hc.dder3(d)), np.array(oc.dder3(d))) < 1e-10
+    ph, po = hc.get_proxsqr(0.9, True), oc.get_proxsqr(0.9, True)
+    assert abs(ph - po) <= 1e-8 * max(1.0, abs(po))
+    for c in (hc, oc):
+        c.use_hess_prod_slow = True
+        c.use_hess_prod_slow_updated = True
+    Ph, Po = np.zeros((U, 3), order="F"), np.zeros((U, 3), order="F")
+    hc.hess_prod_slow(Ph, V)
+    oc.hess_prod_slow(Po, V)
+    assert rel(Ph, Po) < 1e-10
+    # an infeasible point (every Lambda_k negative definite) is infeasible on both sides
+    bad = -pt
+    for c in (hc, oc):
+        c.reset_data()
+        c.load_point(bad, 1.0)
+        assert not c.is_feas()
+
+
+# ---------------------------------------------------------------------------------------------
 # PosSemidefTri{T, Complex{T}} (SURVEY 8f-3: complex Hermitian variant) through the interleaved real embedding
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("side", [1, 2, 3, 5, 12])
@@ -932,6 +1011,7 @@ def _boundary_cones():
         "epinormspectral_complex_2x3": lambda: H.EpiNormSpectralComplex(2, 3),
         "epinormspectral_complex_1x1": lambda: H.EpiNormSpectralComplex(1, 1),
         "wsosinterpnonnegative": lambda: H.WSOSInterpNonnegative(U2, Ps2),
+        "wsosinterpnonnegative_complex": lambda: H.WSOSInterpNonnegativeComplex(*_rand_interp_c(2, 1)),
         "wsosinterppossemideftri": lambda: H.WSOSInterpPosSemidefTri(2, U1, Ps1),
         "linmatrixineq": lambda: H.LinMatrixIneq([sym(4), sym(4) - 3 * np.eye(4), rng.standard_normal((4, 4)) * 0 + np.diag(rng.standard_normal(4))]),
         "linmatrixineq_complex": lambda: H.LinMatrixIneq([herm(3), herm(3) - 2 * np.eye(3)]),
@@ -947,7 +1027,7 @@ def _boundary_cones():
 
 @pytest.mark.parametrize("name", ["nonnegative", "possemideftri", "possemideftri_complex", "epinormspectral_2x3", "epinormspectral_dual_2x3",
                                   "epinormspectral_complex_2x3", "epinormspectral_complex_1x1", "wsosinterpnonnegative",
-                                  "wsosinterppossemideftri", "linmatrixineq", "linmatrixineq_complex", "doublynonnegativetri", "hyporootdettri",
+                                  "wsosinterpnonnegative_complex", "wsosinterppossemideftri", "linmatrixineq", "linmatrixineq_complex", "doublynonnegativetri", "hyporootdettri",
                                   "hyporootdettri_dual", "hypoperlogdettri", "hypoperlogdettri_dual", "hyporootdettri_complex",
                                   "hypoperlogdettri_complex"])
 @pytest.mark.parametrize("margin", [1e-2, 1e-4])

@@ -51,6 +51,27 @@ def test_library_rccl_allreduce_on_a_device_buffer():
     assert p.exitcode == 0
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("native", ["1", "0"])
+def test_sharded_total_factorization_failure(native, monkeypatch):
+    """the same on two ranks: both see the failed factorization of the (identical, all-reduced) Schur matrix and both end in
+    NumericalFailure -- no rank raises from a solve with a factorization that does not exist, none is left waiting in a collective"""
+    monkeypatch.setenv("HYP_DIST_NATIVE", native)
+    monkeypatch.setenv("HYP_FORCE_FACT_FAIL", "1")
+    import dist_worker
+    port = _free_port()
+    out = os.path.join(tempfile.mkdtemp(), "dist_fail.npz")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=dist_worker.run, args=(r, 2, port, (60, [8, 6, 7], 4), out, "hip", "gloo")) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    res = np.load(out)
+    assert str(res["status"]) == "NumericalFailure" and int(res["iters"]) == 0
+
+
 def _run_sharded(native, inst_args=(120, [20, 12, 16, 9], 4), world=2, transport="gloo"):
     import dist_worker
     from oracle import instances as I
@@ -70,6 +91,12 @@ def _run_sharded(native, inst_args=(120, [20, 12, 16, 9], 4), world=2, transport
     ref.load(make_model(I.psd_blocks(*inst_args)))
     ref.solve()
     assert bool(res["hooked"]) == (native == "1")
+    if native == "1":
+        # the device-resident sharded step: every rank keeps only ITS rows of z / s and of the four directions; inside the
+        # iteration loop nothing of length q crosses the host-level transport (the library's own exchanges are the n x n Schur
+        # sum, n-vectors and scalars: hyp_sys_comm_stats), and the solution still matches the oracle's (below)
+        assert bool(res["row_local"])
+        assert int(res["max_host_payload_in_loop"]) <= max(int(res["n"]), 32), (int(res["max_host_payload_in_loop"]), int(res["q"]))
     assert str(res["status"]) == ref.status == "Optimal"
     assert abs(int(res["iters"]) - ref.num_iters) <= 1
     assert abs(float(res["p_obj"]) - ref.primal_obj) <= 1e-7 * (1 + abs(ref.primal_obj))
@@ -107,3 +134,33 @@ def test_kshard_single_cone_solve_matches_oracle():
     # one exchange of the Schur matrix's packed upper triangle per assembly (one per iteration), nothing else
     assert int(res["iters"]) <= res["exchanges"][0] <= int(res["iters"]) + 3
     assert res["exchanges"][1] == res["exchanges"][0] * (150 * 151 // 2)
+
+
+@pytest.mark.timeout(600)
+def test_kshard_cone_without_square_root(monkeypatch):
+    """K-panel sharding when the cone has no square-root oracle: with HYP_FORCE_BK=1 the WSOS cone's Hessian factorization is the
+    Bunch-Kaufman fallback, use_sqrt_hess_oracles answers false (Cones.jl:189-195) and the Schur assembly takes the hess_prod
+    branch (qrchol.jl:240-246) -- every rank contracts its rows of the cone and the all-reduce sums to the whole term.  Same
+    optimum as the oracle on the same model."""
+    import dist_worker
+    from oracle import instances as I
+    from oracle.build import make_model
+    from oracle.solvers import Solver as OSolver
+    monkeypatch.setenv("HYP_FORCE_BK", "1")
+    inst_args = ("polymin", 2, 3, False, 2)   # dual form: n = U - 1 = 27 after the reduction, one WSOS cone of dimension 28
+    port = _free_port()
+    out = os.path.join(tempfile.mkdtemp(), "kshard_nosqrt.npz")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=dist_worker.run_kshard, args=(r, 2, port, inst_args, out, "hip")) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(500)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    res = np.load(out)
+    ref = OSolver(verbose=False)
+    ref.load(make_model(I.polymin(2, 3, False, seed=2)))
+    ref.solve()
+    assert str(res["status"]) == ref.status == "Optimal"
+    assert abs(float(res["p_obj"]) - ref.primal_obj) <= 1e-6 * (1 + abs(ref.primal_obj))
+    assert res["exchanges"][0] >= int(res["iters"])

@@ -215,6 +215,41 @@ def test_known_answer_hip_complex_hypograph_cones(name):
     build_solve_check(solver, H.make_model(inst), inst)
 
 
+@pytest.mark.parametrize("name", ["wsosinterpnonnegative4", "wsosinterpnonnegative5"])
+@pytest.mark.parametrize("reduce", [True, False])
+def test_known_answer_hip_complex_wsos(name, reduce):
+    """the reference's two complex WSOSInterpNonnegative instances (test/nativeinstances.jl:2345-2383: the minimum of 1 + |z|^2 over
+    the unit disc / the bidisc, primal and dual form) through the HIP path, and the same optimum and iteration count as the oracle"""
+    import hypatia_jl_amd as H
+    from oracle import instances as I
+    from oracle.build import make_model as omodel
+    from oracle.solvers import Solver as OSolver
+    inst = I.KNOWN_ANSWER_COMPLEX[name]()
+    hs = build_solve_check(H.Solver(default_tol_relax=10, reduce=reduce), H.make_model(inst), inst)
+    os_ = build_solve_check(OSolver(default_tol_relax=10, reduce=reduce), omodel(inst), inst)
+    assert abs(hs.primal_obj - os_.primal_obj) <= 1e-6 * (1 + abs(os_.primal_obj))
+    assert abs(hs.num_iters - os_.num_iters) <= 2
+
+
+@pytest.mark.parametrize("path", ["fused", "unfused", "host_composed"])
+def test_total_factorization_failure_ends_in_numerical_failure(path, monkeypatch):
+    """every link of posdef_fact_copy! failed (HYP_FORCE_FACT_FAIL=1 reports that from hyp_sys_update_lhs_fact / _update_lhs /
+    _step_directions): the reference warns (qrchol.jl:253-255) and its step ends in NumericalFailure (combined.jl:97-117) -- on
+    every composition of the step, not in an exception from the constant-column solve"""
+    import hypatia_jl_amd as H
+    from oracle import instances as I
+    monkeypatch.setenv("HYP_FORCE_FACT_FAIL", "1")
+    if path == "unfused":
+        monkeypatch.setenv("HYP_NO_FUSED_STEP", "1")
+    if path == "host_composed":
+        monkeypatch.setenv("HYP_NO_NATIVE", "1")
+    s = H.Solver()
+    s.load(H.make_model(I.psd_blocks(30, [6, 4], seed=1)))
+    s.solve()
+    assert s.status == "NumericalFailure"
+    assert s.num_iters == 0
+
+
 def _trajectory(solver_cls, model, **opts):
     rows = []
     s = solver_cls(**opts)

@@ -150,3 +150,39 @@ def test_hypoperlogdettri_complex_barrier():   # test/cone.jl:657-665
         return -np.log(v * np.linalg.slogdet(W / v)[1] - u) - np.log(v) - np.linalg.slogdet(W)[1]
 
     run_test_barrier(occ.HypoPerLogdetTriComplex(2 + side * side), barrier)
+
+
+def _rand_interp_complex(num_vars, halfdeg):   # test/cone.jl:306-315: complex Ps on the unit ball (numpy's draws instead of Julia's)
+    from oracle import polyutils as pu
+    gs = [lambda z: 1.0 - float(np.sum(np.abs(z) ** 2))]
+    points, Ps = pu.interpolate_complex(halfdeg, num_vars, gs, [1], rng=np.random.default_rng(1))
+    return len(points), Ps
+
+
+@pytest.mark.parametrize("num_vars,halfdeg", [(1, 1), (1, 3), (2, 1), (2, 2), (3, 1)])
+def test_wsosinterpnonnegative_complex_oracles(num_vars, halfdeg):   # test/cone.jl:757-762 with R = Complex
+    U, Ps = _rand_interp_complex(num_vars, halfdeg)
+    assert U == Ps[0].shape[1] ** 2                                  # U = L^2 (PolyUtils/complex.jl:26-27)
+    run_test_oracles(occ.WSOSInterpNonnegativeComplex(U, Ps), init_tol=np.inf)
+
+
+def test_wsosinterpnonnegative_complex_barrier():   # test/cone.jl:764-768 with R = Complex
+    U, Ps = _rand_interp_complex(2, 1)
+    run_test_barrier(occ.WSOSInterpNonnegativeComplex(U, Ps),
+                     lambda s: -sum(np.linalg.slogdet(P.conj().T @ (s[:, None] * P))[1] for P in Ps))
+
+
+def test_complex_interpolation_bases():
+    """PolyUtils/complex.jl:13-72: U = L^2 points inside the domain, P0 = the monomial columns z^a (first column all ones), weighted
+    bases sqrt(g_i) P0[:, 1:L_i]; Lambda(1) = P' P is Hermitian positive definite (a unisolvent point set)"""
+    from oracle import polyutils as pu
+    gs = [lambda z: 1.0 - abs(z[0]) ** 2, lambda z: 1.0 - abs(z[1]) ** 2]
+    pts, Ps = pu.interpolate_complex(2, 2, gs, [1, 1], rng=np.random.default_rng(3))
+    assert len(pts) == 36 and [P.shape for P in Ps] == [(36, 6), (36, 3), (36, 3)]
+    assert all(g(z) > 0 for z in pts for g in gs)
+    assert np.allclose(Ps[0][:, 0], 1.0)
+    assert np.allclose(Ps[0][:, 1], [z[0] for z in pts]) and np.allclose(Ps[0][:, 2], [z[1] for z in pts])   # multiexponents order
+    assert np.allclose(Ps[1], np.sqrt([gs[0](z) for z in pts])[:, None] * Ps[0][:, :3])
+    for P in Ps:
+        lam = P.conj().T @ P
+        assert np.allclose(lam, lam.conj().T) and np.all(np.linalg.eigvalsh(lam) > 0)
