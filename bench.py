@@ -94,10 +94,10 @@ def gen_instance(n, sides, seed):
 
 
 def ref_1gpu(config):
-    """the committed single-GPU figure of the SAME workload (profiles/r02_bench_cfg4_1gpu.json, `python bench.py --config 4`):
+    """the committed single-GPU figure of the SAME workload (profiles/r03_bench_cfg4_1gpu.json, `python bench.py --config 4`):
     the driver's own N = 1 run is the headline configuration (config 2), not this workload"""
     try:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_bench_cfg%s_1gpu.json" % config)
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_bench_cfg%s_1gpu.json" % config)
         with open(path) as f:
             rec = json.loads(f.read().strip().splitlines()[-1])
         return {"iterations_per_s": rec["iterations_per_s"], "ms_per_step": rec["ms_per_step"], "source": "profiles/" + os.path.basename(path)}
