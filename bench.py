@@ -512,9 +512,21 @@ def main_other(args):
     from oracle import instances as I       # instance generators only (data)
     from threadpoolctl import threadpool_limits
     t_setup = time.perf_counter()
+    solver_opts = {}
     if args.config == "3b":
         inst = I.matrixcompletion(50, 100, seed=args.seed)
         work = "configs[2] at the largest size the reference admits: matrix completion, EpiNormSpectral 50 x 100 (dim 5001)"
+    elif args.config == "3c":
+        # configs[2] PAST the reference's limit: its generic inv_hess_prod! needs the explicit dim x dim Hessian and a Cholesky of
+        # it per line-search trial (Cones.jl:113-118: 65 GB and 2.4e14 flop per trial at 300 x 300), the closed-form inverse
+        # Hessian of this library needs neither -- what binds is HBM for the dense G.  Known positions drawn as the reference
+        # draws them (examples/matrixcompletion/native.jl:29-43).  NOT the reference's algorithm for this cone.
+        assert os.environ.get("HYP_ENS_CLOSED_INV", "1")[:1] != "0", "--config 3c needs the closed-form inverse Hessian"
+        sd = args.mc_side
+        inst = I.matrixcompletion(sd, sd, seed=args.seed, with_replacement=True)
+        work = ("configs[2] beyond the reference's own size limit: matrix completion, EpiNormSpectral %d x %d (dim %d), closed-form inverse "
+                "Hessian -- not the reference's algorithm for this cone" % (sd, sd, 1 + sd * sd))
+        solver_opts = dict(init_use_indirect=True)   # (G has orthogonal columns: LSQR, the reference's init_use_indirect, ends in three steps)
     else:
         from oracle import polyutils as pu
         rng = np.random.default_rng(args.seed)
@@ -533,10 +545,14 @@ def main_other(args):
     phases = dict(upsys=0.0, getdir=0.0, search=0.0)
     status = None
     with threadpool_limits(limits=args.cpu_threads, user_api="blas"):
-        warm = H.Solver(verbose=False, iter_limit=2)          # untimed: first-touch allocations, kernel loading
-        warm.load(H.make_model(inst)); warm.solve()
+        if args.config != "3c":
+            warm = H.Solver(verbose=False, iter_limit=2, **solver_opts)          # untimed: first-touch allocations, kernel loading
+            warm.load(H.make_model(inst)); warm.solve()
+        lib.hyp_reset_timers(ctx)                             # (the executed-work counters of hyp_get_kernel_stats start here)
+        if args.config == "3c":
+            steps = 1                                         # one whole solve
         while iters < steps:
-            s = H.Solver(verbose=args.verbose)
+            s = H.Solver(verbose=args.verbose, **solver_opts)
             s.load(H.make_model(inst))
             s.solve()
             iters += s.num_iters; loop_s += s.iter_time; solves += s.n_solves; trials += s.stepper.searcher.n_trials
@@ -544,21 +560,62 @@ def main_other(args):
                 phases[k] += getattr(s, "time_" + k)
             status = s.status
             nsolve_runs += 1
-    n_fact = (s.model.n - s.model.p) if args.config in ("5d", "3b") else s.model.cones[0].dimension()
-    ms = ctypes.c_double(0)
-    lib.hyp_bench_potrf.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
-    lib.hyp_bench_potrf(ctx, int(n_fact), 5, ctypes.byref(ms))
-    flops = float(n_fact) ** 3 / 3.0
-    achieved = flops / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+    # ---- roofline of the ITERATION: algorithmic flops of what one iteration does / its wall time, next to the
+    # same with only the work that was actually executed counted (the proximity lower bound skips Hessians the reference would
+    # assemble and factor), and the dominant kernel of the committed trace of this very command (profiles/)
+    ks = (ctypes.c_double * 8)()
+    lib.hyp_get_kernel_stats(ctx, ks)
+    n_upfact, n_hfact, n_bk, n_grad = ks[3], ks[5], ks[6], ks[7]
+    nm = s.model.n - s.model.p
+    cone = s.model.cones[0]
+    dimc = cone.dimension()
+    if args.config in ("3b", "3c"):
+        d1, d2 = (50, 100) if args.config == "3b" else (args.mc_side, args.mc_side)
+        # closed-form oracles: d1^2 d2-sized GEMMs per column; Schur assembly through the hess_prod branch (qrchol.jl:240-246):
+        # H G (nm columns, ~12 GEMMs of 2 d1^2 d2 each) + G'(H G) (nm^2 q) + Cholesky nm^3 / 3
+        f_col = 12 * 2.0 * d1 * d1 * d2
+        f_uplhs = nm * f_col + float(nm) ** 2 * s.model.q + float(nm) ** 3 / 3
+        f_trial_ref = float(dimc) ** 3 / 3 + 2.0 * d1 * d1 * d2          # the reference's per-trial explicit-Hessian Cholesky (Cones.jl:113-118)
+        f_trial_exec = 30 * 2.0 * d1 * d1 * d2                            # feasibility + two decompositions + closed-form inverse on two columns
+        f_solve = 4.0 * s.model.q * nm + 2.0 * nm * nm
+        trace_kernel = ("launch-bound: ~900 kernels of ~10 us per iteration; largest share jacobi_lds_kernel (profiles/r03_cfg3b_kernel_stats.csv)"
+                        if args.config == "3b" else "gemm_f64_kernel (G' (H G), n^2 q flop) and the blocked Cholesky of the n x n Schur matrix")
+        alg = (f_uplhs * n_upfact + trials * f_trial_ref + solves * f_solve) / iters
+        exe = (f_uplhs * n_upfact + trials * f_trial_exec + n_hfact * float(dimc) ** 3 / 3 + solves * f_solve) / iters
+    else:
+        Ls = [P.shape[1] for P in Ps]
+        f_feas = sum(2.0 * U * L * L + L ** 3 / 3.0 for L in Ls)          # Lambda_k = P_k' diag(x) P_k and its Cholesky (wsosinterpnonnegative.jl:89-117)
+        f_grad = sum(1.0 * L * L * U for L in Ls)                         # L_k^-1 P_k' (:119-133)
+        f_hess = sum(1.0 * U * U * L for L in Ls)                         # (P_k Lambda_k^-1 P_k')^.2, upper triangle (:135-150)
+        f_chol = float(U) ** 3 / 3                                        # Cones.jl:239-251
+        f_trial = f_feas + f_grad + f_hess + f_chol                      # = 9.1e10 at U = 4845
+        if args.config == "5d":
+            f_uplhs = 1.0 * U * U * nm + float(nm) ** 2 * s.model.q + float(nm) ** 3 / 3    # triangular product U_H G (q = U), syrk, Cholesky
+        else:
+            f_uplhs = 2.0 * U * U + 1.0                                                     # n = 1: one inverse-Hessian product
+        f_solve = 4.0 * s.model.q * max(nm, 1) + 2.0 * nm * nm + 4.0 * U * U
+        trace_kernel = ("gemm_f64_kernel<true,2,0> (the cone's L x L x U and U x U x L Gram products), then potrf_tiles_kernel / bk_pivot_kernel "
+                        "(profiles/r03_cfg%s_kernel_stats.csv)" % args.config)
+        alg = (f_uplhs * n_upfact + trials * f_trial + solves * f_solve) / iters
+        exe = (f_uplhs * n_upfact + trials * f_feas + n_grad * f_grad + n_hfact * (f_hess + f_chol) + solves * f_solve) / iters
+    ms_it = loop_s / iters * 1e3
+    achieved = alg / (ms_it * 1e-3) / 1e12
+    executed = exe / (ms_it * 1e-3) / 1e12
     out = {
         "metric": "IPM iterations/sec (+ ms per KKT solve): " + work + " (Float64, QRCholDense + CombinedStepper)",
         "value": iters / loop_s, "unit": "iterations/s", "iterations_per_s": iters / loop_s, "n_gpus": 1, "steps": iters, "warmup": 2,
-        "ms_per_step": loop_s / iters * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "ms_per_step": ms_it, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": work, "n": int(s.model.n), "p": int(s.model.p), "q": int(s.model.q), "seed": args.seed, "solves_timed": nsolve_runs,
                    "final_status": status, "algorithm": algorithm_record()},
-        "roofline": {"bound": "mfma", "kernel": "blocked upper Cholesky, n = %d (potrf_diag_mfma + potrf_panel_mfma + gemm_f64 trailing updates)" % n_fact,
+        "roofline": {"bound": "mfma", "kernel": "whole iteration; dominant kernels by the trace: " + trace_kernel,
                      "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                     "launch_ms": ms.value, "flops_per_launch": flops},
+                     "what": "reference-algorithm flops of one iteration (SURVEY 8(d): update_lhs + N_t trials + N_s solves, measured N_t and N_s) / "
+                             "wall time per iteration; executed_* counts only the stages that actually ran (Hessians skipped on the proximity "
+                             "lower bound are not counted)",
+                     "flops_per_step": alg, "executed_flops_per_step": exe, "executed_achieved": executed,
+                     "executed_frac": executed / FP64_MFMA_PEAK_TFLOPS,
+                     "per_step": {"search_trials": trials / iters, "cone_gradients": n_grad / iters, "cone_hessian_factorizations": n_hfact / iters,
+                                  "bunch_kaufman_factorizations": n_bk / iters, "schur_factorizations": n_upfact / iters}},
         "phases_ms_per_step": {k: v / iters * 1e3 for k, v in phases.items()},
         "kkt_solves_per_step": solves / iters, "ms_per_kkt_solve": phases["getdir"] / max(solves, 1) * 1e3,
         "search_trials_per_step": trials / iters, "setup_s": t_setup,
@@ -576,6 +633,7 @@ def main():
     ap.add_argument("--config", default=None, help="2 (headline, N = 1 default) | 4 (64 x PSD(80), strong scaling, N > 1 default) | 2w (one PSD block per rank) | 3b | 5p | 5d")
     ap.add_argument("--nvars", dest="n", type=int, default=5000)
     ap.add_argument("--psd-side", dest="side", type=int, default=200)
+    ap.add_argument("--mc-side", dest="mc_side", type=int, default=200, help="--config 3c: side of the square matrix to complete (300: G = 29 GB)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-iters", type=int, default=2, help="oracle iterations timed for cpu_baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=8, help="host BLAS threads for the cpu_baseline leg and the host-side setup")
@@ -590,12 +648,12 @@ def main():
     multi = world > 1 or bool(os.environ.get("HYP_FORCE_DIST"))   # HYP_FORCE_DIST=1: exercise the RCCL path with a single rank
     if args.config is None:
         args.config = "4" if multi else "2"
-    if args.config in ("3b", "5p", "5d"):
+    if args.config in ("3b", "3c", "5p", "5d"):
         if multi:
             raise SystemExit("--config %s is a single-GPU line" % args.config)
         return main_other(args)
     if args.config not in ("2", "4", "2w"):
-        raise SystemExit("--config must be 2, 4, 2w, 3b, 5p or 5d")
+        raise SystemExit("--config must be 2, 4, 2w, 3b, 3c, 5p or 5d")
     if args.steps is None:
         args.steps = 220 if args.config == "2" else 30
     if args.warmup is None:

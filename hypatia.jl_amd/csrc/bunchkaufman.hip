@@ -470,6 +470,7 @@ __global__ void bk_dsolve_kernel(int n, int nr, const double* __restrict__ dd, c
 }  // namespace
 
 int BKFact::factor(Ctx& c, int n_, double* A, long lda, double* dinv) {
+  c.kstat[6] += 1;   // (Bunch-Kaufman factorizations: the fallback of a failed Cholesky, cone Hessian or Schur matrix)
   n = n_;
   if (n <= 0) return 0;
   const size_t d = sizeof(double);

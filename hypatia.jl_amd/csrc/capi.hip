@@ -31,7 +31,8 @@ void rccl_destroy(void* comm);
 
 static thread_local std::string g_last_error;
 
-#define API_BEGIN try {
+// (the thread's message is cleared on entry: hyp_last_error after a SUCCESSFUL call must not show an earlier call's failure)
+#define API_BEGIN try { g_last_error.clear();
 #define API_END(ctxp)                                                         \
     return 0;                                                                 \
   } catch (const HipError& e) {                                               \
@@ -857,11 +858,13 @@ int hyp_qrcp_factor(hyp_ctx* ctx, int m, int n, const double* A, int lda, const 
 }
 int hyp_qrcp_get(hyp_qrcp* q, int* jpvt, double* R, double* rdiag, double* qtb) {
   API_BEGIN
+  HYP_CHECK(hipSetDevice(q->ctx->c.device));
   qrcp_get(q->f, jpvt, R, rdiag, qtb);
   API_END(q->ctx)
 }
 int hyp_qrcp_apply_q(hyp_qrcp* q, int trans, double* vec) {
   API_BEGIN
+  HYP_CHECK(hipSetDevice(q->ctx->c.device));
   qrcp_apply_q(q->f, trans != 0, vec);
   API_END(q->ctx)
 }

@@ -638,6 +638,7 @@ bool EpiNormSpectralCone::early_reject(double irtmu, double bound2) {
 }
 
 void EpiNormSpectralCone::update_grad() {   // :134-150
+  ctx.kstat[7] += 1;
   ctx.d2d(tau.p, W.p, (size_t)d1 * d2 * 8);
   zsolve(tau.d(), d1, d2);                                              // tau = Z^-1 W
   // Zi = Z^-1 = U^-1 U^-T

@@ -77,6 +77,7 @@ bool GenericHessCone::update_hess_fact() {   // Cones.jl:239-251: posdef_fact_co
   const bool force_bk = fb && fb[0] && fb[0] != '0';
   hess_fact_bk = false;
   hess_fact_ok = false;
+  ctx.kstat[5] += 1;   // (cone Hessian factorizations: bench.py's executed-work count)
   if (!force_bk) {
     ctx.d2d(Hfact.p, H.p, (size_t)dim * dim * sizeof(double));
     potrf_upper_batched(ctx, dim, Hfact.d(), dim, 0, 1, Hdinv.d(), Hinfo.i());
@@ -303,6 +304,7 @@ __global__ void sum_parts_kernel(int n, int K, const double* __restrict__ parts,
 }
 
 void WsosCone::update_grad() {   // :119-133
+  ctx.kstat[7] += 1;   // (gradients of generic-Hessian cones)
   // the K chains (triangular solve of P_k' against Lambda_k's factor, column norms, transpose) are independent and short: on the
   // two streams like the feasibility chains, each with a work space and a partial gradient of its own; the partial gradients
   // are then added in the order of k, which is the order the one-stream form accumulates in (same bits)

@@ -130,19 +130,45 @@ __global__ void qr_colupd_kernel(int m, int k, int kk, int j0, double* __restric
 }
 
 // dlarfg on A(rk : m, k): beta = -sign(alpha) hypot(alpha, xnorm); tau = (beta - alpha) / beta; v = x / (alpha - beta)
-__global__ void qr_larfg_kernel(int k, int nparts, const double* __restrict__ A, long lda, const double* __restrict__ part, double* __restrict__ tau,
+__global__ void qr_larfg_kernel(int m, int k, int nparts, const double* __restrict__ A, long lda, const double* __restrict__ part, double* __restrict__ tau,
                                 QrState* st) {
   if (st->stop) return;
   if (threadIdx.x != 0) return;
   double s = 0.0;
   for (int b = 0; b < nparts; ++b) s += part[b];
-  const double xnorm = sqrt(s);
+  double xnorm = sqrt(s);
+  if (!(s > 1e-280 && s < 1e280)) {   // squares near the ends of the exponent range: dnrm2's scaled sum over the tail (rare, serial)
+    double scl = 0.0, ssq = 1.0;
+    for (int i = k + 1; i < m; ++i) {
+      const double a = fabs(A[(long)k * lda + i]);
+      if (a > 0.0) {
+        if (scl < a) { ssq = 1.0 + ssq * (scl / a) * (scl / a); scl = a; }
+        else ssq += (a / scl) * (a / scl);
+      }
+    }
+    xnorm = scl * sqrt(ssq);
+  }
   const double alpha = A[(long)k * lda + k];
   double t = 0.0, scale = 0.0, beta = alpha;
   if (xnorm != 0.0) {
     beta = -copysign(hypot(alpha, xnorm), alpha);
-    t = (beta - alpha) / beta;
-    scale = 1.0 / (alpha - beta);
+    // dlarfg's guard for tiny columns: while |beta| < safmin = dlamch('S') / dlamch('E'), x, alpha and beta are scaled up by
+    // 1 / safmin (at most 20 times), tau and the scaling of x are formed there, beta is scaled back
+    const double safmin = 2.2250738585072014e-308 / 1.1102230246251565e-16, rsafmn = 1.0 / safmin;
+    double a_s = alpha, xs = 1.0;
+    int knt = 0;
+    if (fabs(beta) < safmin) {
+      do {
+        ++knt;
+        xs *= rsafmn;
+        beta *= rsafmn;
+        a_s *= rsafmn;
+      } while (fabs(beta) < safmin && knt < 20);
+      beta = -copysign(hypot(a_s, xnorm * xs), a_s);
+    }
+    t = (beta - a_s) / beta;
+    scale = xs / (a_s - beta);
+    for (int j = 0; j < knt; ++j) beta *= safmin;
   }
   tau[k] = t;
   st->tau = t;
@@ -314,7 +340,7 @@ void QrcpFact::factor() {
       hipLaunchKernelGGL(qr_swap_kernel, dim3((m + QT - 1) / QT), dim3(QT), 0, st, m, k, kk, j, a(), lda, Ft.d(), S);
       const int nparts = (m - k + QT - 1) / QT;
       hipLaunchKernelGGL(qr_colupd_kernel, dim3(nparts), dim3(QT), 0, st, m, k, kk, j, a(), lda, Ft.d(), part.d(), S);
-      hipLaunchKernelGGL(qr_larfg_kernel, dim3(1), dim3(64), 0, st, k, nparts, a(), lda, part.d(), tau.d(), S);
+      hipLaunchKernelGGL(qr_larfg_kernel, dim3(1), dim3(64), 0, st, m, k, nparts, a(), lda, part.d(), tau.d(), S);
       hipLaunchKernelGGL(qr_scale_kernel, dim3(nparts), dim3(QT), 0, st, m, k, a(), lda, S);
       if (nt - k - 1 > 0) hipLaunchKernelGGL(qr_gemv_kernel, dim3(nt - k - 1), dim3(QT), 0, st, m, k, kk, j, a(), lda, Ft.d(), S);
       if (kk > 0) hipLaunchKernelGGL(qr_auxv_kernel, dim3(kk), dim3(QT), 0, st, m, k, j, a(), lda, auxv.d(), S);

@@ -76,6 +76,68 @@ class Comm:
         self.dist.barrier()
 
 
+def init_library_rccl(comm, sys_handle):
+    """RCCL inside the library for one hyp_sys: rank 0 creates the unique id (hyp_comm_unique_id), torch.distributed only carries
+    its 128 bytes, every rank joins (hyp_comm_init_rank) and hands the communicator to its solver (hyp_sys_set_comm_rccl).
+    Every step is AGREED on by all ranks (a MIN all-reduce of the local outcome) before the next collective is entered, so a
+    failure on one rank -- the id, ncclCommInitRank, a self-check all-reduce whose sum is known -- can neither raise on that rank
+    alone nor leave the others waiting: all ranks return None together and the caller falls back to the callback transport.
+    Returns the hyp_comm handle (to be released with release_library_rccl) or None."""
+    import ctypes
+    import os
+    torch, dist = comm.torch, comm.dist
+    if dist.get_backend() != "nccl" or os.environ.get("HYP_DIST_RCCL", "1") in ("0",):
+        return None
+    lib = L.lib()
+
+    def all_ok(ok):
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    uid = ctypes.create_string_buffer(128)
+    ok = True
+    if comm.rank == 0:
+        ok = lib.hyp_comm_unique_id(uid) == 0
+    box = [uid.raw]
+    dist.broadcast_object_list(box, src=0)
+    why = "hyp_comm_unique_id"
+    hc = ctypes.c_void_p()
+    if all_ok(ok):
+        uid = ctypes.create_string_buffer(box[0], 128)
+        ok = lib.hyp_comm_init_rank(L.ctx(), comm.world, comm.rank, uid, ctypes.byref(hc)) == 0
+        why = "hyp_comm_init_rank"
+        if all_ok(ok):
+            # start-up self-check: sum of (rank + 1) over the new communicator, on a device buffer, before anything depends on it
+            t = torch.full((8,), float(comm.rank + 1), dtype=torch.float64, device="cuda")
+            ok = lib.hyp_comm_allreduce(hc, ctypes.c_void_p(t.data_ptr()), 8, 0) == 0
+            torch.cuda.synchronize()
+            ok = ok and bool(torch.all(t == comm.world * (comm.world + 1) / 2.0).item())
+            why = "self-check all-reduce"
+            if all_ok(ok):
+                L.check(lib.hyp_sys_set_comm_rccl(sys_handle, hc), "hyp_sys_set_comm_rccl")
+                return hc
+        if hc.value:
+            lib.hyp_comm_destroy(hc)
+    if comm.rank == 0:
+        print("hypatia_jl_amd: RCCL inside the library is not available (%s failed on some rank); collectives go through "
+              "torch.distributed" % why)
+    return None
+
+
+def release_library_rccl(sys_handle, hc):
+    """detach the communicator from the solver, then destroy it (ncclCommDestroy)"""
+    if hc is None:
+        return
+    try:
+        lib = L.lib()
+        if sys_handle is not None:
+            lib.hyp_sys_set_comm_rccl(sys_handle, None)
+        lib.hyp_comm_destroy(hc)
+    except Exception:
+        pass
+
+
 def partition_cones(ncones, world):
     """contiguous blocks of cones per rank (config 4: 64 cones -> 8 per GPU)"""
     base, rem = divmod(ncones, world)
@@ -348,33 +410,8 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
         self._cb = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_int)(_allreduce)
         lib, h = L.lib(), self.local._h
         self.rccl_in_library = False
-        if dist.get_backend() == "nccl" and os.environ.get("HYP_DIST_RCCL", "1") not in ("0",):
-            # RCCL inside the library: rank 0 creates the unique id, torch.distributed only carries its 128 bytes; from
-            # here on the exchanges of the fused routines are ncclAllReduce calls on the library's own stream
-            # (every rank takes the same branch: a failure anywhere is agreed on through torch.distributed and all ranks
-            # fall back to the callback together)
-            def _all_ok(ok):
-                t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)
-                return bool(t.item())
-            uid = ctypes.create_string_buffer(128)
-            ok = True
-            if self.comm.rank == 0:
-                ok = lib.hyp_comm_unique_id(uid) == 0
-            box = [uid.raw]
-            dist.broadcast_object_list(box, src=0)
-            hc = ctypes.c_void_p()
-            if _all_ok(ok):
-                uid = ctypes.create_string_buffer(box[0], 128)
-                ok = lib.hyp_comm_init_rank(L.ctx(), self.comm.world, self.comm.rank, uid, ctypes.byref(hc)) == 0
-                if _all_ok(ok):
-                    self._hyp_comm = hc
-                    L.check(lib.hyp_sys_set_comm_rccl(h, hc), "hyp_sys_set_comm_rccl")
-                    self.rccl_in_library = True
-                elif ok:
-                    lib.hyp_comm_destroy(hc)
-            if not self.rccl_in_library and self.comm.rank == 0:
-                print("hypatia_jl_amd: RCCL inside the library is not available (%s); collectives go through torch.distributed" % L.last_error())
+        self._hyp_comm = init_library_rccl(self.comm, h)   # (agreed on by all ranks; None: the callback below)
+        self.rccl_in_library = self._hyp_comm is not None
         if not self.rccl_in_library:
             L.check(lib.hyp_sys_set_comm(h, ctypes.cast(self._cb, ctypes.c_void_p), None, ctypes.c_void_p(stage.data_ptr()), int(stage.numel())),
                     "hyp_sys_set_comm")
@@ -398,6 +435,12 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
             self._last_cand = None
 
     row_local = False
+
+    def close(self):
+        """release the library's communicator (every rank, before the process group goes away)"""
+        loc = getattr(self, "local", None)
+        release_library_rccl(getattr(loc, "_h", None), getattr(self, "_hyp_comm", None))
+        self._hyp_comm = None
 
     def point_version(self, pt):
         return (id(pt), float(pt.tau), float(pt.kap), float(pt.x[0]) if pt.x.shape[0] else 0.0,
@@ -809,20 +852,9 @@ class KShardQRCholDenseSystemSolver(QRCholDenseSystemSolver):
         super().load(solver)
         lib, h, comm = L.lib(), self._h, self.comm
         dist, torch = comm.dist, comm.torch
-        self.rccl_in_library = False
-        if dist.get_backend() == "nccl" and os.environ.get("HYP_DIST_RCCL", "1") not in ("0",):
-            uid = ctypes.create_string_buffer(128)
-            if comm.rank == 0:
-                L.check(lib.hyp_comm_unique_id(uid), "hyp_comm_unique_id")
-            box = [uid.raw]
-            dist.broadcast_object_list(box, src=0)
-            uid = ctypes.create_string_buffer(box[0], 128)
-            hc = ctypes.c_void_p()
-            L.check(lib.hyp_comm_init_rank(L.ctx(), comm.world, comm.rank, uid, ctypes.byref(hc)), "hyp_comm_init_rank")
-            self._hyp_comm = hc
-            L.check(lib.hyp_sys_set_comm_rccl(h, hc), "hyp_sys_set_comm_rccl")
-            self.rccl_in_library = True
-        else:
+        self._hyp_comm = init_library_rccl(comm, h)
+        self.rccl_in_library = self._hyp_comm is not None
+        if not self.rccl_in_library:
             nmp = self.n - self.p
             self._stage = torch.empty(max(nmp * nmp, 1024), dtype=torch.float64, device="cuda")
             stage = self._stage
@@ -843,3 +875,17 @@ class KShardQRCholDenseSystemSolver(QRCholDenseSystemSolver):
                     "hyp_sys_set_comm")
         L.check(lib.hyp_sys_set_kshard(h, comm.rank, comm.world), "hyp_sys_set_kshard")
         return self
+
+    def close(self):
+        """release the library's communicator (every rank, before the process group goes away)"""
+        release_library_rccl(getattr(self, "_h", None), getattr(self, "_hyp_comm", None))
+        self._hyp_comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+        sup = getattr(super(), "__del__", None)
+        if sup is not None:
+            sup()

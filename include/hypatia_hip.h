@@ -34,7 +34,8 @@ int hyp_device_count(int* out);
 int hyp_get_timers(hyp_ctx* ctx, double* out10);
 int hyp_reset_timers(hyp_ctx* ctx);
 /* HIP-event timings (ms, accumulated since the last reset) of the update_lhs phases measured on the
- * library stream: out8 = [sqrt-Hessian products, Schur syrk, Cholesky, #update_lhs_fact, #syrk launches, 0, 0, 0] */
+ * library stream: out8 = [sqrt-Hessian products, Schur syrk, Cholesky, #update_lhs_fact, #syrk launches, #Hessian factorizations of
+ * generic cones (Cones.jl:239-251), #Bunch-Kaufman factorizations (dense.jl:164-165), #gradients of generic-Hessian cones] */
 int hyp_get_kernel_stats(hyp_ctx* ctx, double* out8);
 
 /* ---- cone lifecycle: constructors of src/Cones/nonnegative.jl:27-33, possemideftri.jl:36-46 --- */

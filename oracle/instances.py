@@ -651,19 +651,29 @@ def polymin(nvars, halfdeg, use_primal, seed=1, keep=None):
             [("wsosinterpnonnegative", U, Ps, True)], dict(status="Optimal"))
 
 
-def matrixcompletion(d1, d2, seed=1, known_frac=0.8):
+def matrixcompletion(d1, d2, seed=1, known_frac=0.8, with_replacement=False):
     """config 3b: examples/matrixcompletion/native.jl:23-70 shape, spectral-norm objective with
-    EpiNormSpectral(d1, d2): minimize u s.t. (u, W) in cone, known entries of W fixed."""
+    EpiNormSpectral(d1, d2): minimize u s.t. (u, W) in cone, known entries of W fixed.
+    with_replacement: the reference's own sampling rule (:29-43): round(0.8 d1 d2) positions drawn WITH replacement and values
+    uniform in [-1, 1], so that a fraction 1 - exp(-0.8) = 0.551 of the entries ends up known (n = 1 + 0.449 d1 d2)."""
     rng = np.random.default_rng(seed)
-    mask = rng.random((d1, d2)) < known_frac
-    vals = rng.standard_normal((d1, d2))
+    if with_replacement:
+        nk = int(round(d1 * d2 * known_frac))
+        rows, cols = rng.integers(0, d1, nk), rng.integers(0, d2, nk)
+        kv = 2 * rng.random(nk) - 1
+        mask = np.zeros((d1, d2), dtype=bool)
+        vals = np.zeros((d1, d2))
+        vals[rows, cols] = kv          # (a repeated position keeps its last draw, as the reference's loop does)
+        mask[rows, cols] = True
+    else:
+        mask = rng.random((d1, d2)) < known_frac
+        vals = rng.standard_normal((d1, d2))
     unknown = np.argwhere(~mask.reshape(-1, order="F")).ravel()
     nvar = 1 + unknown.shape[0]
     dim = 1 + d1 * d2
-    G = np.zeros((dim, nvar))
+    G = np.zeros((dim, nvar), order="F")
     G[0, 0] = -1
-    for j, idx in enumerate(unknown):
-        G[1 + idx, 1 + j] = -1
+    G[1 + unknown, 1 + np.arange(unknown.shape[0])] = -1
     h = np.zeros(dim)
     h[1:] = np.where(mask.reshape(-1, order="F"), vals.reshape(-1, order="F"), 0.0)
     c = np.zeros(nvar)

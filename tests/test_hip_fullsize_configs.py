@@ -59,6 +59,31 @@ def test_config3b_matrix_completion_full_size():
 
 
 @pytest.mark.timeout(900)
+def test_config3c_matrix_completion_beyond_the_reference_limit():
+    """matrix completion with EpiNormSpectral at 150 x 150 (dim 22 501, n = 10 086): 4.5 times the dimension at which the
+    reference's own route stops being feasible (an explicit 22 501^2 Hessian = 4 GB and its Cholesky per line-search trial,
+    Cones.jl:113-118), solved through the closed-form inverse Hessian; the reference's sampling rule for the known entries
+    (examples/matrixcompletion/native.jl:29-43).  Checked without any barrier code: the conic certificate of
+    test/nativeinstances.jl:58-65, s in the spectral-norm cone and z in the nuclear-norm cone by their singular values, and the
+    completed matrix agrees with the known entries."""
+    import hypatia_jl_amd as H
+    from oracle import instances as I          # instance generator only (data)
+    d = 150
+    inst = I.matrixcompletion(d, d, seed=1, with_replacement=True)
+    assert abs((inst[3].shape[1] - 1) / (d * d) - 0.449) < 0.01           # 1 - exp(-0.8) of the entries known
+    s = H.Solver(verbose=False, init_use_indirect=True)
+    s.load(H.make_model(inst))
+    s.solve()
+    _certificate(s, inst, 1e-6)
+    # the objective is the spectral norm of the completed matrix, whose known entries are the data
+    h = inst[4]
+    W = s.get_s()[1:].reshape((d, d), order="F")
+    known = np.abs(inst[3][1:, 1:]).sum(axis=1) == 0
+    assert np.allclose(W.reshape(-1, order="F")[known], h[1:][known], atol=1e-6)
+    assert abs(np.linalg.svd(W, compute_uv=False)[0] - s.primal_obj) <= 1e-5 * (1 + s.primal_obj)
+
+
+@pytest.mark.timeout(900)
 def test_config5_polymin_primal_full_size():
     import hypatia_jl_amd as H
     from oracle import polyutils as pu         # interpolation basis (data)

@@ -36,6 +36,33 @@ def test_qrcp_matches_lapack_on_full_rank_matrices(m, n):
     assert _rel(xs, np.linalg.lstsq(M, b, rcond=None)[0]) <= 1e-10
 
 
+@pytest.mark.parametrize("scale", [1e-150, 1e-300])
+def test_qrcp_on_tiny_columns(scale):
+    """columns near the bottom of the exponent range.  At 1e-150 everything equals LAPACK's (pivots, R, Q'b).  At 1e-300 the
+    SQUARED column norms the pivot search works on underflow (dgeqp3 keeps scaled norms), so the pivot order is the identity
+    instead of LAPACK's -- but every reflector is still dlarfg's: its norm comes from dnrm2's scaled sum and |beta| < dlamch('S') /
+    dlamch('E') ~ 2e-292 takes the rescaling loop, so Q stays orthogonal and A P = Q R holds relative to the matrix's own scale"""
+    from hypatia_jl_amd.solvers import DeviceQRCP
+    rng = np.random.default_rng(11)
+    m, n = 60, 9
+    M = rng.standard_normal((m, n)) * rng.uniform(0.5, 2.0, n)[None, :] * scale
+    b = rng.standard_normal(m)
+    f = DeviceQRCP(M, b)
+    piv, R, rdiag, qtb = f.get()
+    assert abs(np.linalg.norm(qtb) - np.linalg.norm(b)) <= 1e-12 * np.linalg.norm(b)
+    x = rng.standard_normal(m)
+    assert _rel(f.apply_q(f.apply_q(x, True), False), x) <= 1e-12
+    for j in range(n):   # A P = Q R, column by column
+        col = np.zeros(m)
+        col[:n] = R[:n, j] / scale
+        assert _rel(f.apply_q(col, False), M[:, piv[j]] / scale) <= 1e-11
+    if scale > 1e-200:
+        Qs, Rs, ps = sla.qr(M, mode="full", pivoting=True)
+        assert np.array_equal(piv, ps)
+        assert _rel(R / scale, np.triu(Rs[:n, :]) / scale) <= 1e-11
+        assert _rel(qtb[:n], (Qs.T @ b)[:n]) <= 1e-11
+
+
 @pytest.mark.parametrize("m,n,rank", [(40, 12, 7), (400, 150, 100), (1500, 300, 299)])
 def test_qrcp_rank_decision_on_rank_deficient_matrices(m, n, rank):
     """get_rank_est (process.jl:373-382): number of |R_ii| above init_tol_qr = 1000 eps"""
