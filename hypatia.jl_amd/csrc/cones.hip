@@ -390,9 +390,13 @@ void PsdCone::two_sided(const double* R, int kr2, int kr3, double* prod, long ld
   const long s2 = (long)side * side;
   const long ws_cap = 1L << 27;   // doubles per workspace (1 GiB)
   int chunk = (int)std::min<long>(ncols, std::max<long>(1, ws_cap / s2));
+  const bool fused = use_fused(ncols);
+  // HYP_TS_CHUNK_MB: the two passes of the fused product run chunk by chunk with the intermediate Z of a chunk held to that
+  // many MB (A/B switch: does pass 2 find Z in the 256 MB Infinity Cache?)
+  static const long z_mb = [] { const char* e = getenv("HYP_TS_CHUNK_MB"); return e ? atol(e) : 0L; }();
+  if (fused && z_mb > 0) chunk = (int)std::max<long>(8, std::min<long>(chunk, (z_mb << 20) / (s2 * (long)sizeof(double))));
   ws1.ensure((size_t)chunk * s2 * sizeof(double));
   ws2.ensure((size_t)chunk * s2 * sizeof(double));
-  const bool fused = use_fused(ncols);
   for (int c0 = 0; c0 < ncols; c0 += chunk) {
     const int nc = std::min(chunk, ncols - c0);
     if (fused) {   // one workgroup per matrix, svec conversions fused (psd_twosided.hip)

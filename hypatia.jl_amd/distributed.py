@@ -110,6 +110,7 @@ def init_library_rccl(comm, sys_handle):
         if all_ok(ok):
             # start-up self-check: sum of (rank + 1) over the new communicator, on a device buffer, before anything depends on it
             t = torch.full((8,), float(comm.rank + 1), dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()       # (the fill ran on torch's stream, the all-reduce runs on the library's)
             ok = lib.hyp_comm_allreduce(hc, ctypes.c_void_p(t.data_ptr()), 8, 0) == 0
             torch.cuda.synchronize()
             ok = ok and bool(torch.all(t == comm.world * (comm.world + 1) / 2.0).item())
