@@ -62,7 +62,7 @@ def pmc_traffic(n, q):
     """HBM bytes per syrk launch from the committed PMC passes (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE); only
     valid for the configuration they were collected on, else None."""
     try:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_summary.json")
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_summary.json")
         with open(path) as f:
             rec = json.load(f)["syrk"]
         if rec["algorithmic_bytes_per_launch"] == q * n * 8 + n * (n + 1) // 2 * 8:
@@ -424,7 +424,7 @@ def run_headline(args, world, rank, local_rank, multi, comm=None):
                       if comm is not None else {})},
         "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<true, 4, 1> (Schur syrk, upper)", "achieved": achieved,
                      "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                     "traffic": pmc_traffic(args.n, q), "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 PMC, profiles/r02_pmc_summary.json)",
+                     "traffic": pmc_traffic(args.n, q), "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 PMC, profiles/r03_pmc_summary.json)",
                      "launch_ms": syrk_ms, "flops_per_launch": syrk_flops},
         "phases_ms_per_step": {"sqrt_hess_prod": ks[0] / args.steps, "syrk": ks[1] / args.steps, "cholesky": ks[2] / args.steps,
                                "update_lhs": solver.time_upsys / args.steps * 1e3, "get_directions": solver.time_getdir / args.steps * 1e3,

@@ -437,6 +437,12 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
 
     row_local = False
 
+    def agree_any(self, flag):
+        """True on every rank iff `flag` is true on some rank (decisions that depend on a rank's own clock)"""
+        v = np.array([1.0 if flag else 0.0])
+        self.comm.allreduce(v, "max")
+        return bool(v[0] > 0.5)
+
     def close(self):
         """release the library's communicator (every rank, before the process group goes away)"""
         loc = getattr(self, "local", None)
@@ -876,6 +882,13 @@ class KShardQRCholDenseSystemSolver(QRCholDenseSystemSolver):
                     "hyp_sys_set_comm")
         L.check(lib.hyp_sys_set_kshard(h, comm.rank, comm.world), "hyp_sys_set_kshard")
         return self
+
+    def agree_any(self, flag):
+        """True on every rank iff `flag` is true on some rank: the ranks run the same deterministic solve, and the one decision
+        that depends on a rank's own clock (time_limit) must not let one of them leave the all-reduces alone"""
+        v = np.array([1.0 if flag else 0.0])
+        self.comm.allreduce(v, "max")
+        return bool(v[0] > 0.5)
 
     def close(self):
         """release the library's communicator (every rank, before the process group goes away)"""

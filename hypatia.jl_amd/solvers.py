@@ -728,7 +728,11 @@ class Solver:
         if self.num_iters == self.iter_limit:
             self.status = "IterationLimit"
             return False
-        if time.perf_counter() - self._start_time >= self.time_limit:
+        timed_out = time.perf_counter() - self._start_time >= self.time_limit
+        agree = getattr(self.syssolver, "agree_any", None)
+        if agree is not None and np.isfinite(self.time_limit):
+            timed_out = agree(timed_out)   # multi-GPU: a wall-clock decision is taken by all ranks together or by none
+        if timed_out:
             self.status = "TimeLimit"
             return False
         if improv < self.tol_slow:

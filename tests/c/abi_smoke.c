@@ -188,6 +188,78 @@ int main(void) {
     for (int j = 0; j < N2; ++j) r += (i <= j ? lhs2[j * N2 + i] : lhs2[i * N2 + j]) * sol2[j];
     REQUIRE(fabs(r - rhs2[i]) < 1e-9);
   }
+  /* ---- the residual products of Solvers.jl:418-483 in one call (single GPU: the sums over ranks are the local values) */
+  {
+    double cvec[N2] = {0.3, -0.1, 0.2}, hvec[Q2], bdummy[1] = {0.0};
+    for (int i = 0; i < Q2; ++i) hvec[i] = 0.1 * (i + 1);
+    CHECK(hyp_sys_load_model(sys, cvec, bdummy, hvec, NULL));
+    double xx[N2] = {0.5, -1.0, 0.25}, zz[Q2], ss[Q2], gtz[N2], gxs[Q2], dots[2];
+    for (int i = 0; i < Q2; ++i) { zz[i] = 0.01 * (i + 1); ss[i] = 1.0 - 0.02 * i; }
+    CHECK(hyp_sys_residual_products(sys, xx, zz, ss, gtz, gxs, dots));
+    double hz = 0, zs = 0;
+    for (int i = 0; i < Q2; ++i) { hz += hvec[i] * zz[i]; zs += zz[i] * ss[i]; }
+    REQUIRE(fabs(dots[0] - hz) < 1e-12 && fabs(dots[1] - zs) < 1e-12);
+    for (int j = 0; j < N2; ++j) {
+      double r = 0;
+      for (int i = 0; i < Q2; ++i) r += G2[j * Q2 + i] * zz[i];
+      REQUIRE(fabs(gtz[j] - r) < 1e-12);
+    }
+    for (int i = 0; i < Q2; ++i) {
+      double r = ss[i];
+      for (int j = 0; j < N2; ++j) r += G2[j * Q2 + i] * xx[j];
+      REQUIRE(fabs(gxs[i] - r) < 1e-12);
+    }
+    double two[2] = {1.5, -2.5};
+    CHECK(hyp_sys_allreduce_host(sys, two, 2, 1));           /* no communicator: a no-op */
+    REQUIRE(two[0] == 1.5 && two[1] == -2.5);
+  }
+
+  /* ---- WSOSInterpNonnegative with COMPLEX bases (wsosinterpnonnegative.jl:15 with R = Complex{T}): Ps[k] = U x L_k complex
+   *      numbers, (re, im) interleaved; the cone vector stays real.  U = 4, one basis of two columns [1, z] at four points of
+   *      the unit disc: Lambda(pt) = P' diag(pt) P is Hermitian 2 x 2, nu = 2 */
+  {
+    enum { CU = 4 };
+    static const double zr[CU] = {0.5, -0.3, 0.1, -0.6}, zi[CU] = {0.2, 0.7, -0.8, -0.1};
+    double CP0[2 * CU * 2];
+    for (int i = 0; i < CU; ++i) { CP0[2 * i] = 1.0; CP0[2 * i + 1] = 0.0; CP0[2 * (CU + i)] = zr[i]; CP0[2 * (CU + i) + 1] = zi[i]; }
+    const double* CPs[1] = {CP0};
+    const int CLs[1] = {2};
+    hyp_cone* cw = NULL;
+    CHECK(hyp_cone_create_wsosinterpnonnegative_complex(ctx, CU, 1, CLs, CPs, 0, &cw));
+    CHECK(hyp_cone_dimension(cw, &dim));
+    CHECK(hyp_cone_get_nu(cw, &nu));
+    CHECK(hyp_cone_use_dual_barrier(cw, &udb));
+    REQUIRE(dim == CU && nu == 2.0 && udb == 1);
+    double cpt[CU] = {1.2, 0.7, 0.9, 1.4}, cg[CU], cv[CU] = {0.3, -0.2, 0.1, 0.25}, chv[CU], cww[CU];
+    CHECK(hyp_cone_load_point(cw, cpt, 1.0));
+    CHECK(hyp_cone_reset_data(cw));
+    CHECK(hyp_cone_is_feas(cw, &feas));
+    REQUIRE(feas == 1);
+    CHECK(hyp_cone_grad(cw, cg));
+    gp = 0;
+    for (int i = 0; i < CU; ++i) gp += cg[i] * cpt[i];
+    REQUIRE(fabs(gp + nu) < 1e-12);                          /* <grad, point> = -nu */
+    /* the gradient from the definition: -|e_i' P Lambda^-1 P' e_i| with Lambda = [[a, b], [conj b, d]] */
+    double a = 0, d = 0, br = 0, bi = 0;
+    for (int i = 0; i < CU; ++i) { a += cpt[i]; d += cpt[i] * (zr[i] * zr[i] + zi[i] * zi[i]); br += cpt[i] * zr[i]; bi += cpt[i] * zi[i]; }
+    const double det = a * d - (br * br + bi * bi);
+    for (int i = 0; i < CU; ++i) {
+      const double m2 = zr[i] * zr[i] + zi[i] * zi[i];
+      /* [1, conj z] Lambda^-1 [1; z] = (d - 2 Re(b z) ... ) / det with Lambda^-1 = [[d, -b], [-conj b, a]] / det */
+      const double quad = (d - 2.0 * (br * zr[i] + bi * zi[i]) + a * m2) / det;
+      REQUIRE(fabs(cg[i] + quad) < 1e-11);
+    }
+    CHECK(hyp_cone_hess_prod(cw, chv, CU, cv, CU, 1));
+    CHECK(hyp_cone_inv_hess_prod(cw, cww, CU, chv, CU, 1));
+    for (int i = 0; i < CU; ++i) REQUIRE(fabs(cww[i] - cv[i]) < 1e-10);
+    double cneg[CU] = {-1.0, -1.0, -1.0, -1.0};
+    CHECK(hyp_cone_load_point(cw, cneg, 1.0));
+    CHECK(hyp_cone_reset_data(cw));
+    CHECK(hyp_cone_is_feas(cw, &feas));
+    REQUIRE(feas == 0);
+    CHECK(hyp_cone_destroy(cw));
+  }
+
   CHECK(hyp_sys_destroy(sys));
   CHECK(hyp_cone_destroy(ens));
   CHECK(hyp_cone_destroy(wsos));
