@@ -353,38 +353,31 @@ void SysSolver::residual_products(const double* h_x, const double* h_z, const do
   HYP_REQUIRE(model_loaded, "residual_products: load_model first");
   const size_t d = sizeof(double);
   rp_x.ensure(std::max<size_t>(n, 1) * d);
-  rp_t.ensure(std::max<size_t>(n, 1) * d);
+  rp_t.ensure(((size_t)n + 2) * d);                                        // [G' z (n); h' z; z' s]: ONE sum over the ranks
   for (DBuf* b : {&rp_z, &rp_s, &rp_g}) b->ensure(std::max<size_t>(q, 1) * d);
-  double* hs = ctx.stage_host((size_t)n + 2 * (size_t)q);
+  double* hs = ctx.stage_host((size_t)n + 2 * (size_t)q + 2);
   memcpy(hs, h_x, (size_t)n * d);
   memcpy(hs + n, h_z, (size_t)q * d);
   memcpy(hs + n + q, h_s, (size_t)q * d);
   ctx.h2d(rp_x.p, hs, (size_t)n * d);
+  ctx.zero(rp_t.p, ((size_t)n + 2) * d);
   if (q > 0) {
     ctx.h2d(rp_z.p, hs + n, (size_t)q * d);
     ctx.h2d(rp_s.p, hs + n + q, (size_t)q * d);
     gemv(ctx, true, q, n, 1.0, G.d(), q, rp_z.d(), 0.0, rp_t.d());          // G' z (these rows)
     ctx.d2d(rp_g.p, rp_s.p, (size_t)q * d);
     gemv(ctx, false, q, n, 1.0, G.d(), q, rp_x.d(), 1.0, rp_g.d());         // G x + s
-  } else {
-    ctx.zero(rp_t.p, (size_t)n * d);
+    dev_dot(ctx, q, mh.d(), rp_z.d(), rp_t.d() + n);
+    dev_dot(ctx, q, rp_z.d(), rp_s.d(), rp_t.d() + n + 1);
   }
-  allreduce_dev(rp_t.d(), n, 0);                                            // sum over ranks (in place, stream order)
-  double* dsc = ctx.dscal.d();
-  ctx.zero(dsc, 2 * d);
-  if (q > 0) {
-    dev_dot(ctx, q, mh.d(), rp_z.d(), dsc);
-    dev_dot(ctx, q, rp_z.d(), rp_s.d(), dsc + 1);
-  }
-  ctx.d2h(hs, rp_t.p, (size_t)n * d);
-  if (q > 0) ctx.d2h(hs + n, rp_g.p, (size_t)q * d);
-  ctx.d2h(ctx.h_pinned, dsc, 2 * d);
+  allreduce_dev(rp_t.d(), (long)n + 2, 0);                                  // sum over ranks (in place, stream order)
+  ctx.d2h(hs, rp_t.p, ((size_t)n + 2) * d);
+  if (q > 0) ctx.d2h(hs + n + 2, rp_g.p, (size_t)q * d);
   ctx.sync();
   memcpy(h_Gtz, hs, (size_t)n * d);
-  if (q > 0) memcpy(h_Gx_s, hs + n, (size_t)q * d);
-  h_dots[0] = ctx.h_pinned[0];
-  h_dots[1] = ctx.h_pinned[1];
-  allreduce_host(h_dots, 2, 0);
+  h_dots[0] = hs[n];
+  h_dots[1] = hs[n + 1];
+  if (q > 0) memcpy(h_Gx_s, hs + n + 2, (size_t)q * d);
 }
 
 void SysSolver::block_hess_prod_vec(double* d_out, const double* d_in) {   // qrchol.jl:87-98

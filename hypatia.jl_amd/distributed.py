@@ -450,8 +450,10 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
         self._hyp_comm = None
 
     def point_version(self, pt):
-        return (id(pt), float(pt.tau), float(pt.kap), float(pt.x[0]) if pt.x.shape[0] else 0.0,
-                float(pt.z[self.rsl][0]) if self._ql_n else 0.0)
+        """fingerprint of this rank's part of a point: the record calc_mu leaves for calc_convergence_params is only reused for
+        the very point it was computed at"""
+        z, sv = pt.z[self.rsl], pt.s[self.rsl]
+        return (id(pt), float(pt.tau), float(pt.kap), float(pt.x @ pt.x), float(z @ z), float(sv @ sv))
 
     def residual_products(self, pt):
         """hyp_sys_residual_products on this rank's rows: {Gtz (n, summed over ranks), Gx_s (local rows), hz, zs (summed)}"""

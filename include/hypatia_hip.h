@@ -177,7 +177,7 @@ int hyp_sys_mul_G(hyp_sys* sys, int trans, double alpha, const double* x, double
  * comes out.  Vectors use Hypatia's Point layout [x(n); y(p); z(q); tau; s(q); kap] (point.jl:5-54). */
 /* The products of Solvers.calc_convergence_params and calc_mu (src/Solvers/Solvers.jl:418-483: G' z, G x + s, h' z, z' s) in
  * one call on the resident G.  On a cone-sharded solver (hyp_sys_set_comm / hyp_sys_set_comm_rccl) z, s and out_Gx_s are THIS
- * process's rows and the sums over ranks are taken inside (one all-reduce of n doubles, one of two): out_Gtz (n) = G' z summed,
+ * process's rows and the sums over ranks are taken inside (ONE all-reduce of n + 2 doubles): out_Gtz (n) = G' z summed,
  * out_Gx_s (q) = G x + s on these rows, out_dots2 = {h' z, z' s} summed -- no q-vector ever leaves a rank.  Needs
  * hyp_sys_load_model (for h). */
 int hyp_sys_residual_products(hyp_sys* sys, const double* x, const double* z, const double* s, double* out_Gtz, double* out_Gx_s, double* out_dots2);
