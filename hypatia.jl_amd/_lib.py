@@ -117,6 +117,7 @@ SIGNATURES = {
     "hyp_dense_syrk": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int],
     "hyp_dense_potrf": [c_vp, c_int, c_vp, c_int, P(c_int)],
     "hyp_dense_posv": [c_vp, c_int, c_vp, c_int, c_vp, P(c_int)],
+    "hyp_dense_posv_multi": [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, P(c_int)],
     "hyp_dense_sysv_rook": [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, P(c_int), c_vp, c_vp, c_vp, c_vp],
     "hyp_dense_lstsq_normal": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, P(c_dbl), P(c_int)],
     "hyp_dense_gemv": [c_vp, c_int, c_int, c_int, c_dbl, c_vp, c_int, c_vp, c_dbl, c_vp],

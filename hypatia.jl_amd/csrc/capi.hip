@@ -827,6 +827,27 @@ int hyp_dense_posv(hyp_ctx* ctx, int n, double* A, int lda, double* x, int* info
   c.sync();
   API_END(ctx)
 }
+int hyp_dense_posv_multi(hyp_ctx* ctx, int n, double* A, int lda, double* X, int nrhs, int ldx, int* info) {
+  API_BEGIN
+  Ctx& c = ctx->c;
+  HYP_CHECK(hipSetDevice(c.device));
+  HYP_REQUIRE(n >= 1 && nrhs >= 1 && lda >= n && ldx >= n, "posv_multi: sizes");
+  DBuf dA((size_t)lda * n * 8), dinv(dinv_elems(n) * 8), dX((size_t)ldx * nrhs * 8), dinfo(64), work((size_t)NB * nrhs * 8);
+  c.h2d(dA.p, A, (size_t)lda * n * 8);
+  c.h2d(dX.p, X, (size_t)ldx * nrhs * 8);
+  potrf_upper_batched(c, n, dA.d(), lda, 0, 1, dinv.d(), dinfo.i());
+  c.d2h(c.h_info, dinfo.p, sizeof(int));
+  c.sync();
+  *info = c.h_info[0];
+  if (*info == 0) {   // U' U X = B: the blocked multi-column sweeps every cone's ldiv! goes through (trsm_upper_left)
+    trsm_upper_left(c, n, nrhs, dA.d(), lda, dinv.d(), true, dX.d(), ldx, work.d());
+    trsm_upper_left(c, n, nrhs, dA.d(), lda, dinv.d(), false, dX.d(), ldx, work.d());
+  }
+  c.d2h(A, dA.p, (size_t)lda * n * 8);
+  c.d2h(X, dX.p, (size_t)ldx * nrhs * 8);
+  c.sync();
+  API_END(ctx)
+}
 int hyp_dense_sysv_rook(hyp_ctx* ctx, int n, double* A, int lda, double* x, int nrhs, int ldx, int* info, int* perm, int* blk,
                         double* d_out, double* e_out) {
   API_BEGIN

@@ -414,8 +414,9 @@ void trsv_upper(Ctx& c, int n, const double* U, long ldu, const double* dinv, bo
 // X_k <- op(T)^-1 X_k for one diagonal block T = U[k0:k0+nb, k0:k0+nb] and nrhs columns, in place: x0 = op(D) y with the
 // stored inverse D = inv(T), then `refine` steps x += op(D) (y - op(T) x) against the factor block itself -- the same scheme
 // as the one-vector solves above (diag_solve), so that dtrsm's backward error is kept (Cones.jl:113-118 / 209-218,
-// wsosinterpnonnegative.jl:106-112 call ldiv! on the factor; a plain product with the inverted block has a forward error
-// of cond(T) eps and moved late iterates of models with generic-Hessian cones away from the oracle's: DESIGN.md section 7).
+// wsosinterpnonnegative.jl:106-112 call ldiv! on the factor; measured on U'U X = B the plain products with the inverted blocks
+// have 3 to 15 times LAPACK's columnwise backward error -- 3e-16 at cond 1e8, 1.4e-15 at cond 1e14 --, the refined ones
+// exactly LAPACK's: DESIGN.md section 7).
 // One workgroup = 16 columns of X; every product op(M) V (M = D, D', T or T', 128 x 128, V a 128 x 16 slab in LDS) runs on
 // v_mfma_f64_16x16x4: wavefront w owns the row tiles {w, 7 - w} of the result -- with a triangular operand a balanced pair,
 // 36 k-steps of 4 for every wavefront.  The A operands -- one entry of M per lane and k-step -- of BOTH matrices are requested

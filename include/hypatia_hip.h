@@ -267,6 +267,10 @@ int hyp_dense_syrk(hyp_ctx* ctx, int N, int K, const double* A, int lda, double*
 int hyp_dense_potrf(hyp_ctx* ctx, int n, double* A, int lda, int* info);
 /* dposv 'U': A (upper triangle read) is overwritten by its Cholesky factor U, x (in: b) by A^-1 b */
 int hyp_dense_posv(hyp_ctx* ctx, int n, double* A, int lda, double* x, int* info);
+/* the same with nrhs right-hand sides (X: n x nrhs, leading dimension ldx, overwritten by the solution): the blocked multi-column
+ * triangular sweeps behind every cone's ldiv! on a factor (Cones.jl:113-118, wsosinterpnonnegative.jl:124) -- diagonal blocks
+ * through their inverses + two refinement steps against the factor, i.e. dtrsm's backward error (dense.jl:164-200) */
+int hyp_dense_posv_multi(hyp_ctx* ctx, int n, double* A, int lda, double* X, int nrhs, int ldx, int* info);
 /* Symmetric indefinite solve through the rook-pivoted factorization P A P' = U' D U (the reference's
  * bunchkaufman!(Symmetric(A, :U), true, check = false) + ldiv!: symm_fact!, src/linearalgebra/dense.jl:164-165).
  * A: upper triangle in, U (unit upper, diagonal explicit) out.  perm / blk / d / e (length n, each may be NULL)

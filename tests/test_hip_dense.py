@@ -141,6 +141,35 @@ def test_posv_superblock_solves(hip, n, cond):
     assert np.linalg.norm(x - xref) <= 1e-12 * cond * np.linalg.norm(xref)
 
 
+@pytest.mark.parametrize("n,nrhs,cond", [(1, 3, 1.0), (17, 1, 1e6), (50, 100, 1e8), (64, 16, 1e10), (65, 17, 1e8), (128, 33, 1e10), (129, 5, 1e6),
+                                         (200, 1000, 1e10), (495, 600, 1e8), (330, 4845, 1e6), (50, 100, 1e14), (128, 33, 1e15)])
+def test_posv_multi_has_substitution_backward_error(hip, n, nrhs, cond):
+    """the multi-column triangular sweeps (trsm_upper_left: inverted diagonal blocks + two refinement steps against the factor, the
+    wave-local kernel for blocks of at most 64 rows, the 128-row kernel otherwise, partial last blocks, ragged column counts)
+    against LAPACK's dpotrs on ill-conditioned matrices: column by column the backward error of substitution"""
+    import scipy.linalg as sla
+    lib, ctx, L = hip
+    rng = np.random.default_rng(1000 * n + nrhs)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    ev = np.logspace(0, -np.log10(cond), n) if n > 1 else np.ones(1)
+    A = (Q * ev) @ Q.T
+    A = np.asfortranarray(0.5 * (A + A.T))
+    # half the columns random, half images of O(1) vectors.  Measured (1x MI355X): with the refinement the backward error equals
+    # LAPACK's (1.0e-16 .. 1.8e-16 against 0.9e-16 .. 1.8e-16) at every conditioning tried; the plain products with the inverted
+    # blocks (HYP_TRSM_REFINE=0) give 3e-16 .. 5e-16 at cond 1e8 .. 1e10 and 7e-16 .. 1.4e-15 at cond 1e14 .. 1e15 -- the last
+    # two cases of this list fail without the refinement, the others pass either way
+    B = np.asfortranarray(rng.standard_normal((n, nrhs)))
+    B[:, ::2] = A @ rng.standard_normal((n, B[:, ::2].shape[1]))
+    Ad, X, info = A.copy(order="F"), B.copy(order="F"), c_int(-1)
+    L.check(lib.hyp_dense_posv_multi(ctx, n, fp(Ad), n, fp(X), nrhs, n, ctypes.byref(info)), "posv_multi")
+    assert info.value == 0
+    Xref = sla.cho_solve(sla.cho_factor(A), B)
+    nA = np.linalg.norm(A, 2)
+    berr = lambda V: np.max(np.linalg.norm(A @ V - B, axis=0) / (nA * np.linalg.norm(V, axis=0) + np.linalg.norm(B, axis=0)))
+    assert berr(X) <= 4 * berr(Xref) + 2e-16, (berr(X), berr(Xref))
+    assert np.linalg.norm(X - Xref) <= 1e-11 * cond * np.linalg.norm(Xref)
+
+
 def test_superblock_solve_kernels_same_sums_with_and_without_batched_loads(tmp_path):
     """the dot-product kernels of the super-block solves exist in two forms (all loads of a lane issued at once, or four at a
     time: HYP_COLDOT_BATCH); the switch is read once per process, so each form runs in a process of its own -- bitwise equal"""
