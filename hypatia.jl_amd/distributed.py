@@ -76,22 +76,28 @@ class Comm:
         self.dist.barrier()
 
 
-def init_library_rccl(comm, sys_handle):
+def init_library_rccl(comm, sys_handle, lib=None, lib_ctx=None):
     """RCCL inside the library for one hyp_sys: rank 0 creates the unique id (hyp_comm_unique_id), torch.distributed only carries
     its 128 bytes, every rank joins (hyp_comm_init_rank) and hands the communicator to its solver (hyp_sys_set_comm_rccl).
     Every step is AGREED on by all ranks (a MIN all-reduce of the local outcome) before the next collective is entered, so a
     failure on one rank -- the id, ncclCommInitRank, a self-check all-reduce whose sum is known -- can neither raise on that rank
     alone nor leave the others waiting: all ranks return None together and the caller falls back to the callback transport.
-    Returns the hyp_comm handle (to be released with release_library_rccl) or None."""
+    Returns the hyp_comm handle (to be released with release_library_rccl) or None.
+    lib / lib_ctx: the library binding and its context; the world-2 CPU test of THIS protocol (tests/test_distributed_gloo.py)
+    injects a stand-in that fails where it is told to, over gloo -- the product passes nothing and needs the nccl back end."""
     import ctypes
     import os
     torch, dist = comm.torch, comm.dist
-    if dist.get_backend() != "nccl" or os.environ.get("HYP_DIST_RCCL", "1") in ("0",):
+    injected = lib is not None
+    if not injected and (dist.get_backend() != "nccl" or os.environ.get("HYP_DIST_RCCL", "1") in ("0",)):
         return None
-    lib = L.lib()
+    if not injected:
+        lib, lib_ctx = L.lib(), L.ctx()
+    dev = "cuda" if comm.device == "cuda" else "cpu"
+    sync = torch.cuda.synchronize if dev == "cuda" else (lambda: None)
 
     def all_ok(ok):
-        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item())
 
@@ -105,18 +111,20 @@ def init_library_rccl(comm, sys_handle):
     hc = ctypes.c_void_p()
     if all_ok(ok):
         uid = ctypes.create_string_buffer(box[0], 128)
-        ok = lib.hyp_comm_init_rank(L.ctx(), comm.world, comm.rank, uid, ctypes.byref(hc)) == 0
+        ok = lib.hyp_comm_init_rank(lib_ctx, comm.world, comm.rank, uid, ctypes.byref(hc)) == 0
         why = "hyp_comm_init_rank"
         if all_ok(ok):
             # start-up self-check: sum of (rank + 1) over the new communicator, on a device buffer, before anything depends on it
-            t = torch.full((8,), float(comm.rank + 1), dtype=torch.float64, device="cuda")
-            torch.cuda.synchronize()       # (the fill ran on torch's stream, the all-reduce runs on the library's)
+            t = torch.full((8,), float(comm.rank + 1), dtype=torch.float64, device=dev)
+            sync()       # (the fill ran on torch's stream, the all-reduce runs on the library's)
             ok = lib.hyp_comm_allreduce(hc, ctypes.c_void_p(t.data_ptr()), 8, 0) == 0
-            torch.cuda.synchronize()
+            sync()
             ok = ok and bool(torch.all(t == comm.world * (comm.world + 1) / 2.0).item())
             why = "self-check all-reduce"
             if all_ok(ok):
-                L.check(lib.hyp_sys_set_comm_rccl(sys_handle, hc), "hyp_sys_set_comm_rccl")
+                rc = lib.hyp_sys_set_comm_rccl(sys_handle, hc)
+                if not injected:
+                    L.check(rc, "hyp_sys_set_comm_rccl")
                 return hc
         if hc.value:
             lib.hyp_comm_destroy(hc)

@@ -182,3 +182,61 @@ def run_comm_selftest():
         L.check(lib.hyp_comm_allreduce(hc, ctypes.c_void_p(t.data_ptr()), 1000, op), "hyp_comm_allreduce")
     assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float64))
     L.check(lib.hyp_comm_destroy(hc), "hyp_comm_destroy")
+
+
+class FakeCommLib:
+    """stand-in for the library's communicator entry points (hyp_comm_*): fails where `fail` says, on the rank `bad_rank`; its
+    all-reduce is torch.distributed's on the same buffer, so that a healthy run passes the self-check"""
+
+    def __init__(self, rank, world, fail, bad_rank, dist, torch):
+        self.rank, self.world, self.fail, self.bad, self.dist, self.torch = rank, world, fail, bad_rank, dist, torch
+        self.destroyed = 0
+        self.attached = False
+
+    def _bad(self, what):
+        return self.fail == what and self.rank == self.bad
+
+    def hyp_comm_unique_id(self, buf):
+        buf.raw = bytes(range(128))
+        return 1 if self._bad("unique_id") else 0
+
+    def hyp_comm_init_rank(self, ctx, world, rank, uid, out):
+        import ctypes
+        if self._bad("init_rank"):
+            return 1
+        assert bytes(uid.raw) == bytes(range(128)) and world == self.world and rank == self.rank
+        ctypes.cast(out, ctypes.POINTER(ctypes.c_void_p))[0] = 4242
+        return 0
+
+    def hyp_comm_allreduce(self, hc, ptr, count, op):
+        import ctypes
+        import numpy as np
+        arr = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_double)), shape=(count,))
+        t = self.torch.from_numpy(arr)
+        self.dist.all_reduce(t)
+        if self._bad("self_check"):
+            arr[0] += 1.0          # a communicator that returns a wrong sum on one rank
+        return 0
+
+    def hyp_comm_destroy(self, hc):
+        self.destroyed += 1
+        return 0
+
+    def hyp_sys_set_comm_rccl(self, sys_handle, hc):
+        self.attached = True
+        return 0
+
+
+def run_rccl_bringup(rank, world, port, fail, bad_rank, out_dir):
+    """hypatia.jl_amd.distributed.init_library_rccl over gloo with the stand-in library: every rank must come out the same way"""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        from hypatia_jl_amd import distributed as D
+        comm = D.Comm(device="cpu")
+        lib = FakeCommLib(rank, world, fail, bad_rank, dist, torch)
+        hc = D.init_library_rccl(comm, None, lib=lib, lib_ctx=None)
+        np.savez(os.path.join(out_dir, "bringup_%d.npz" % rank), got=(hc is not None), attached=lib.attached, destroyed=lib.destroyed)
+    finally:
+        dist.destroy_process_group()

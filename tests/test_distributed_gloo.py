@@ -78,3 +78,31 @@ def test_kshard_schur_sum_matches_full_assembly():
     res = np.load(out)
     assert np.allclose(res["lhs"], res["full"], rtol=1e-13, atol=1e-13)
     assert res["ranges"].tolist() == [[0, 32], [32, 45]]
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("fail,bad_rank", [("none", 0), ("unique_id", 0), ("init_rank", 1), ("init_rank", 0), ("self_check", 1)])
+def test_library_communicator_bringup_is_agreed_on_by_all_ranks(fail, bad_rank):
+    """init_library_rccl (the start-up of RCCL inside the library) at world 2 with a stand-in for the hyp_comm_* entry points that
+    fails on ONE rank at a chosen step: both ranks must return together -- both with a communicator attached to their solver, or
+    both without (falling back to the callback transport), the rank whose own step succeeded having destroyed what it created;
+    nobody raises alone, nobody waits in a collective the other never enters (the test would time out)."""
+    import dist_worker
+    port = _free_port()
+    out_dir = tempfile.mkdtemp()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=dist_worker.run_rccl_bringup, args=(r, 2, port, fail, bad_rank, out_dir)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    res = [np.load(os.path.join(out_dir, "bringup_%d.npz" % r)) for r in range(2)]
+    want = (fail == "none")
+    for r in range(2):
+        assert bool(res[r]["got"]) == want and bool(res[r]["attached"]) == want
+    if fail in ("init_rank", "self_check"):
+        # a rank whose hyp_comm_init_rank succeeded gives the communicator back when the ranks agree to fall back
+        for r in range(2):
+            created = not (fail == "init_rank" and r == bad_rank)
+            assert int(res[r]["destroyed"]) == (1 if created else 0)
