@@ -1,4 +1,6 @@
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_hip_dense.py -m gpu -q --tb=short 2>&1 | tail -12
-echo "--- refine=0 for comparison"
-HYP_TRSM_REFINE=0 timeout 600 python -m pytest tests/test_hip_dense.py -m gpu -q --tb=line -k posv_multi 2>&1 | grep -v "^/tmp" | tail -14
+rm -f gpurun_out/other_configs.jsonl
+for c in 3b 5p 5d; do python bench.py --config $c 2>/dev/null | tail -1 >> gpurun_out/other_configs.jsonl; done
+python -c "
+import json
+for l in open('gpurun_out/other_configs.jsonl'): d=json.loads(l); r=d['roofline']; print(d['config']['workload'][:50], round(d['ms_per_step'],2), 'frac', round(r['frac'],4), 'exec', round(r['executed_frac'],4), r['per_step'])"
