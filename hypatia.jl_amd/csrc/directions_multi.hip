@@ -220,37 +220,46 @@ __global__ void gemv_n_multi_reduce_kernel(int m, int nchunks, double alpha, con
   *y = alpha * s + (beta != 0.0 ? beta * (*y) : 0.0);
 }
 
+template <int NR>
+static void gemv_multi_t(Ctx& c, bool trans, int m, int n, double alpha, const double* A, long lda, const double* X, long ldx, double beta, double* Y,
+                         long ldy) {
+  if (trans) {
+    if (n <= 0) return;
+    static const int cb_env = [] { const char* e = getenv("HYP_GEMVT_CB"); return e ? atoi(e) : 4; }();
+    const bool wide = ((((uintptr_t)A | (uintptr_t)X) & 15) == 0) && (lda % 2 == 0) && (ldx % 2 == 0);
+    if (wide && cb_env == 4) {
+      hipLaunchKernelGGL((gemv_t_multi_cb_kernel<NR, 4>), dim3((n + 3) / 4), dim3(256), 0, c.stream, m, n, alpha, A, lda, X, ldx, beta, Y, ldy);
+    } else if (wide && cb_env == 2) {
+      hipLaunchKernelGGL((gemv_t_multi_cb_kernel<NR, 2>), dim3((n + 1) / 2), dim3(256), 0, c.stream, m, n, alpha, A, lda, X, ldx, beta, Y, ldy);
+    } else if (wide && cb_env == 8) {
+      hipLaunchKernelGGL((gemv_t_multi_cb_kernel<NR, 8>), dim3((n + 7) / 8), dim3(256), 0, c.stream, m, n, alpha, A, lda, X, ldx, beta, Y, ldy);
+    } else {
+      hipLaunchKernelGGL((gemv_t_multi_kernel<NR, 256, 2>), dim3(n), dim3(256), 0, c.stream, m, alpha, A, lda, X, ldx, beta, Y, ldy);
+    }
+  } else {
+    if (m <= 0) return;
+    const int nchunks = (n + GM_CHUNK - 1) / GM_CHUNK;
+    c.scratch.ensure(std::max<size_t>((size_t)nchunks * NR * m * sizeof(double), 4096));
+    if (nchunks > 0)
+      hipLaunchKernelGGL((gemv_n_multi_partial_kernel<NR>), dim3((m + 255) / 256, nchunks), dim3(256), 0, c.stream, m, n, A, lda, X, ldx,
+                         c.scratch.d());
+    hipLaunchKernelGGL((gemv_n_multi_reduce_kernel<NR>), dim3((m + 255) / 256, NR), dim3(256), 0, c.stream, m, nchunks, alpha, c.scratch.d(),
+                       beta, Y, ldy);
+  }
+  HYP_CHECK(hipGetLastError());
+}
+// nr = 1, 2 or 3 right-hand sides per pass over A (3: the constant column of update_lhs rides along with the first pair of
+// directions); every column's sums are those of the same column in a pass of its own width class (fixed per-thread row
+// assignment and reduction tree)
 void gemv_multi(Ctx& c, bool trans, int m, int n, int nr, double alpha, const double* A, long lda, const double* X, long ldx, double beta,
                 double* Y, long ldy) {
   if (nr == 1) {
     gemv(c, trans, m, n, alpha, A, lda, X, beta, Y);
     return;
   }
-  HYP_REQUIRE(nr == MR, "gemv_multi: 1 or 2 right-hand sides");
-  if (trans) {
-    if (n <= 0) return;
-    static const int cb_env = [] { const char* e = getenv("HYP_GEMVT_CB"); return e ? atoi(e) : 4; }();
-    const bool wide = ((((uintptr_t)A | (uintptr_t)X) & 15) == 0) && (lda % 2 == 0) && (ldx % 2 == 0);
-    if (wide && cb_env == 4) {
-      hipLaunchKernelGGL((gemv_t_multi_cb_kernel<MR, 4>), dim3((n + 3) / 4), dim3(256), 0, c.stream, m, n, alpha, A, lda, X, ldx, beta, Y, ldy);
-    } else if (wide && cb_env == 2) {
-      hipLaunchKernelGGL((gemv_t_multi_cb_kernel<MR, 2>), dim3((n + 1) / 2), dim3(256), 0, c.stream, m, n, alpha, A, lda, X, ldx, beta, Y, ldy);
-    } else if (wide && cb_env == 8) {
-      hipLaunchKernelGGL((gemv_t_multi_cb_kernel<MR, 8>), dim3((n + 7) / 8), dim3(256), 0, c.stream, m, n, alpha, A, lda, X, ldx, beta, Y, ldy);
-    } else {
-      hipLaunchKernelGGL((gemv_t_multi_kernel<MR, 256, 2>), dim3(n), dim3(256), 0, c.stream, m, alpha, A, lda, X, ldx, beta, Y, ldy);
-    }
-  } else {
-    if (m <= 0) return;
-    const int nchunks = (n + GM_CHUNK - 1) / GM_CHUNK;
-    c.scratch.ensure(std::max<size_t>((size_t)nchunks * MR * m * sizeof(double), 4096));
-    if (nchunks > 0)
-      hipLaunchKernelGGL((gemv_n_multi_partial_kernel<MR>), dim3((m + 255) / 256, nchunks), dim3(256), 0, c.stream, m, n, A, lda, X, ldx,
-                         c.scratch.d());
-    hipLaunchKernelGGL((gemv_n_multi_reduce_kernel<MR>), dim3((m + 255) / 256, MR), dim3(256), 0, c.stream, m, nchunks, alpha, c.scratch.d(),
-                       beta, Y, ldy);
-  }
-  HYP_CHECK(hipGetLastError());
+  HYP_REQUIRE(nr == MR || nr == MR + 1, "gemv_multi: 1, 2 or 3 right-hand sides");
+  if (nr == MR) gemv_multi_t<MR>(c, trans, m, n, alpha, A, lda, X, ldx, beta, Y, ldy);
+  else gemv_multi_t<MR + 1>(c, trans, m, n, alpha, A, lda, X, ldx, beta, Y, ldy);
 }
 
 // ---- super-block triangular solves with two right-hand sides (see TriSolvePlan in dense.hip) -------------
@@ -351,7 +360,12 @@ void TriSolvePlan::solve_multi(Ctx& c, const double* U, long ldu, bool trans, do
     solve(c, U, ldu, trans, x);
     return;
   }
-  HYP_REQUIRE(nr == MR, "TriSolvePlan: 1 or 2 right-hand sides");
+  if (nr == MR + 1) {   // a third column: the pair through the two-column sweeps, the third through the one-column ones
+    solve_multi(c, U, ldu, trans, x, ldx, MR);
+    solve(c, U, ldu, trans, x + (long)MR * ldx);
+    return;
+  }
+  HYP_REQUIRE(nr == MR, "TriSolvePlan: 1, 2 or 3 right-hand sides");
   const int nsb = (n + sb - 1) / sb;
   const size_t blk = (size_t)sb * sb;
   work.ensure((size_t)2 * MR * sb * sizeof(double));
@@ -454,16 +468,19 @@ void SysSolver::get_directions2(double* h_dirs, const double* h_rhss, double mu,
 
 // two right-hand sides already on the device (rhs2 = two Point vectors, tau / kap slots zero, scalars in rs):
 // directions are left in m_dir, their tau / kap in dsc
+// with_const: the constant column of update_lhs (qrchol.jl:191-197: rhs_const = (-c, H h), solved once per iteration) rides
+// along as a THIRD column of this call's solve_subsystem3 -- its two passes over G, its cone product and its scalar products
+// cost the pair nothing extra; sol_const / dot_const are set before the pair's tau is formed from them (common.jl:155-161)
 void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
-                                  double min_impr_tol, Scal* dsc, double* res_norms, int* n_solves) {
+                                  double min_impr_tol, Scal* dsc, double* res_norms, int* n_solves, bool with_const) {
   const size_t d = sizeof(double);
   const int dv = dimv(), it = n + p + q, ik = dv - 1;
   HYP_REQUIRE(p == 0, "pair_solve_device: p = 0 only");
   const int oz = n, os = n + q + 1;
   const long ld3 = n + q;
   for (DBuf* b : {&m_dir, &m_res}) b->ensure((size_t)MR * dv * d);
-  for (DBuf* b : {&m_subr, &m_subs}) b->ensure((size_t)MR * ld3 * d);
-  for (DBuf* b : {&m_Gx, &m_HGx, &m_Gxd}) b->ensure((size_t)MR * q * d);
+  for (DBuf* b : {&m_subr, &m_subs}) b->ensure((size_t)(MR + 1) * ld3 * d);
+  for (DBuf* b : {&m_Gx, &m_HGx, &m_Gxd}) b->ensure((size_t)(MR + 1) * q * d);
   double* dir = m_dir.d();
   double* res = m_res.d();
   double* sr = m_subr.d();
@@ -496,19 +513,30 @@ void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double
       for (int r = 0; r < MR; ++r) dev_axpby(ctx, dk, -1.0, rhs + (long)r * dv + os + o, -1.0, sr + r * ld3 + oz + o);
     }
   }
-  solve3_multi(ss, sr, MR);
+  if (with_const) {   // column MR: rhs_const = (-c, H h)
+    double* rc = sr + (long)MR * ld3;
+    dev_scale_copy(ctx, n, -1.0, mc.d(), rc);
+    block_hess_prod_vec(rc + oz, mh.d());
+  }
+  const int ncol = with_const ? MR + 1 : MR;
+  solve3_multi(ss, sr, ncol);
   double* ds = ctx.dscal.d();
-  for (int r = 0; r < MR; ++r) {
+  for (int r = 0; r < ncol; ++r) {
     dev_dot(ctx, n, mc.d(), ss + r * ld3, ds + 2 * r);
     dev_dot(ctx, q, mh.d(), ss + r * ld3 + oz, ds + 2 * r + 1);
   }
-  ctx.d2h(ctx.h_pinned, ds, 2 * MR * d);
+  ctx.d2h(ctx.h_pinned, ds, 2 * (MR + 1) * d);
   ctx.sync();
   if (dist()) {   // h' z over all ranks' rows
-    double hz[MR] = {ctx.h_pinned[1], ctx.h_pinned[3]};
-    allreduce_host(hz, MR, 0);
+    double hz[MR + 1] = {ctx.h_pinned[1], ctx.h_pinned[3], ctx.h_pinned[5]};
+    allreduce_host(hz, ncol, 0);
     ctx.h_pinned[1] = hz[0];
     ctx.h_pinned[3] = hz[1];
+    ctx.h_pinned[5] = hz[2];
+  }
+  if (with_const) {
+    ctx.d2d(sol_const.p, ss + (long)MR * ld3, (size_t)ld3 * d);
+    dot_const = ctx.h_pinned[2 * MR] + ctx.h_pinned[2 * MR + 1];
   }
   for (int r = 0; r < MR; ++r) {
     const double dot_sub = ctx.h_pinned[2 * r] + ctx.h_pinned[2 * r + 1];
@@ -737,8 +765,13 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   if (use_sqrt_out)
     for (size_t k = 0; k < cones.size(); ++k) use_sqrt_out[k] = use_sqrt[k];
   if (*info != 0) { ctx.sync(); return; }
-  update_const();
-  if (h_sol_const) ctx.d2h(hs_const, sol_const.p, (size_t)it * d);   // (host mirror of sys.sol_const)
+  // (the constant column of update_lhs, qrchol.jl:191-197, is solved as a third column of the first pair below;
+  //  HYP_CONST_COL3=0: on its own, before the pairs, as hyp_sys_update_lhs does)
+  static const bool const3 = [] { const char* e = getenv("HYP_CONST_COL3"); return !(e && e[0] == '0'); }();
+  if (!const3) {
+    update_const();
+    if (h_sol_const) ctx.d2h(hs_const, sol_const.p, (size_t)it * d);   // (host mirror of sys.sol_const)
+  }
   last_update_lhs_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   const double tau = h_point[it], kap = h_point[ik];
   m_rhs.ensure((size_t)MR * dv * d);
@@ -748,7 +781,8 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   int ns = 0;
   // (cent, pred)
   build_rhs_pair(0, m_rhs.d(), s_point.d(), mu, tau, kap, tau_residual, nullptr, nullptr, reinterpret_cast<double*>(rs));
-  pair_solve_device(m_rhs.d(), rs, mu, tau, max_ref_steps, res_norm_cutoff, min_impr_tol, dsc, rn, &ns);
+  pair_solve_device(m_rhs.d(), rs, mu, tau, max_ref_steps, res_norm_cutoff, min_impr_tol, dsc, rn, &ns, const3);
+  if (const3 && h_sol_const) ctx.d2h(hs_const, sol_const.p, (size_t)it * d);   // (host mirror of sys.sol_const)
   *n_solves += ns;
   res_norms[0] = rn[0];
   res_norms[1] = rn[1];

@@ -136,7 +136,7 @@ struct SysSolver {
                        double res_norm_cutoff, double min_impr_tol, double* h_dirs, double* res_norms, int* n_solves, int* use_sqrt_out,
                        int* info, int* used_fallback, double* h_sol_const);
   void pair_solve_device(double* rhs2, const Scal* rs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
-                         double min_impr_tol, Scal* dsc, double* res_norms, int* n_solves);
+                         double min_impr_tol, Scal* dsc, double* res_norms, int* n_solves, bool with_const = false);
   // returns res_norm; dir / rhs are HOST Point vectors (common.jl:15-76)
   double get_directions(double* h_dir, const double* h_rhs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
                         double min_impr_tol, int* n_solves);
