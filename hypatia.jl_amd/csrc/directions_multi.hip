@@ -493,32 +493,35 @@ void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double
     ctx.zero(res + (long)r * dv + ik, d);
   }
 
-  // ---- solve_system for both columns (common.jl:129-182, qrchol.jl:16-37)
-  for (int r = 0; r < MR; ++r) ctx.d2d(sr + r * ld3, rhs + (long)r * dv, (size_t)n * d);
+  // ---- solve_system for both columns (common.jl:129-182, qrchol.jl:16-37).  with_const: the constant column is a genuine
+  // third INPUT column, (x, z, s) = (-c, -h, 0), so that its right-hand side H h (= -H (-h) - 0 below) and its H (G x) come out
+  // of the same three-column cone products (z_const = H G x - H h cancels to ~mu of its terms late in a solve)
+  const int ncol = with_const ? MR + 1 : MR;
+  if (with_const) {
+    double* rc = rhs + (long)MR * dv;                    // (the caller's buffer holds MR + 1 Point vectors)
+    ctx.zero(rc, (size_t)dv * d);
+    dev_scale_copy(ctx, n, -1.0, mc.d(), rc);
+    dev_scale_copy(ctx, q, -1.0, mh.d(), rc + oz);
+  }
+  for (int r = 0; r < ncol; ++r) ctx.d2d(sr + r * ld3, rhs + (long)r * dv, (size_t)n * d);
   for (size_t k = 0; k < cones.size(); ++k) {
     Cone* ck = cones[k];
     const int o = offs[k], dk = ck->dim;
     if (ck->use_dual_barrier) {
-      for (int r = 0; r < MR; ++r) {
+      for (int r = 0; r < ncol; ++r) {
         double* tmp = ss + r * ld3 + oz + o;
         dev_scale_copy(ctx, dk, -1.0, rhs + (long)r * dv + oz + o, tmp);
         dev_axpby(ctx, dk, -1.0, rhs + (long)r * dv + os + o, 1.0, tmp);
       }
-      ck->inv_hess_prod(sr + oz + o, ld3, ss + oz + o, ld3, MR);
-    } else if (const int used = run_hess_prod(k, sr + oz + o, ld3, rhs + oz + o, dv, MR)) {
-      for (int r = 0; r < MR; ++r) dev_axpby(ctx, offs[k + used] - o, -1.0, rhs + (long)r * dv + os + o, -1.0, sr + r * ld3 + oz + o);
+      ck->inv_hess_prod(sr + oz + o, ld3, ss + oz + o, ld3, ncol);
+    } else if (const int used = run_hess_prod(k, sr + oz + o, ld3, rhs + oz + o, dv, ncol)) {
+      for (int r = 0; r < ncol; ++r) dev_axpby(ctx, offs[k + used] - o, -1.0, rhs + (long)r * dv + os + o, -1.0, sr + r * ld3 + oz + o);
       k += used - 1;
     } else {
-      ck->hess_prod(sr + oz + o, ld3, rhs + oz + o, dv, MR);
-      for (int r = 0; r < MR; ++r) dev_axpby(ctx, dk, -1.0, rhs + (long)r * dv + os + o, -1.0, sr + r * ld3 + oz + o);
+      ck->hess_prod(sr + oz + o, ld3, rhs + oz + o, dv, ncol);
+      for (int r = 0; r < ncol; ++r) dev_axpby(ctx, dk, -1.0, rhs + (long)r * dv + os + o, -1.0, sr + r * ld3 + oz + o);
     }
   }
-  if (with_const) {   // column MR: rhs_const = (-c, H h)
-    double* rc = sr + (long)MR * ld3;
-    dev_scale_copy(ctx, n, -1.0, mc.d(), rc);
-    block_hess_prod_vec(rc + oz, mh.d());
-  }
-  const int ncol = with_const ? MR + 1 : MR;
   solve3_multi(ss, sr, ncol);
   double* ds = ctx.dscal.d();
   for (int r = 0; r < ncol; ++r) {
@@ -765,16 +768,19 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   if (use_sqrt_out)
     for (size_t k = 0; k < cones.size(); ++k) use_sqrt_out[k] = use_sqrt[k];
   if (*info != 0) { ctx.sync(); return; }
-  // (the constant column of update_lhs, qrchol.jl:191-197, is solved as a third column of the first pair below;
-  //  HYP_CONST_COL3=0: on its own, before the pairs, as hyp_sys_update_lhs does)
-  static const bool const3 = [] { const char* e = getenv("HYP_CONST_COL3"); return !(e && e[0] == '0'); }();
+  // HYP_CONST_COL3=1: the constant column of update_lhs (qrchol.jl:191-197) rides along as a third column of the first pair
+  // below instead of being solved on its own first.  Measured: -0.33 ms per iteration at config 2 (-1.3 ms at config 4), but
+  // over 24 PSD models 291 iterations instead of 284 and final direction residuals 10 - 1000 times larger in a third of the
+  // solves (z_const = H G x_const - H h cancels to ~mu of its terms; with G x_const from the three-column pass its rounding
+  // no longer matches the one-column products the residual is checked against) -- OFF by default.
+  static const bool const3 = [] { const char* e = getenv("HYP_CONST_COL3"); return e && e[0] == '1'; }();
   if (!const3) {
     update_const();
     if (h_sol_const) ctx.d2h(hs_const, sol_const.p, (size_t)it * d);   // (host mirror of sys.sol_const)
   }
   last_update_lhs_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   const double tau = h_point[it], kap = h_point[ik];
-  m_rhs.ensure((size_t)MR * dv * d);
+  m_rhs.ensure((size_t)(MR + 1) * dv * d);   // (+ the constant column of the first pair)
   v_tmp.ensure((size_t)MR * dv * d);   // (also the keeper of dir_cent / dir_pred between the two pairs: v_res below)
   Scal rs[MR], dsc[MR];
   double rn[MR];
