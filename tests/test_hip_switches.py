@@ -67,3 +67,15 @@ def test_side_by_side_candidate_evaluation_matches_sequential(name, switch):
     assert on["status"] == off["status"] == "Optimal"
     assert on["iters"] == off["iters"]
     assert abs(on["obj"] - off["obj"]) <= 1e-6 * (1 + abs(off["obj"]))
+
+
+@pytest.mark.parametrize("name", ["psd_single", "psd_pair", "matrixcompletion", "polymin_dual"])
+def test_constant_column_as_third_column_solves_the_same_problem(name):
+    """HYP_CONST_COL3=1 (off by default): the constant column of update_lhs rides along with the first pair of
+    directions.  Same optimum; the iterate sequences differ by rounding (the route costs a few per cent more iterations on
+    average, which is why it is off), so the iteration count is only bounded"""
+    on = _run(name, {"HYP_CONST_COL3": "1"})
+    off = _run(name, {"HYP_CONST_COL3": "0"})
+    assert on["status"] == off["status"] == "Optimal"
+    assert abs(on["iters"] - off["iters"]) <= 4
+    assert abs(on["obj"] - off["obj"]) <= 1e-6 * (1 + abs(off["obj"]))
