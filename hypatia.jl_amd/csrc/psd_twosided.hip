@@ -63,10 +63,12 @@ __device__ __forceinline__ void ts_block_range(int T, int nb, int b, int& t0, in
   cnt = base + (b < extra ? 1 : 0);
 }
 
-template <int PASS, int TS_BT>
+template <int PASS, int TS_BT, bool VEC = false>
 __global__ __launch_bounds__(TS_THREADS, (TS_BT <= 4 ? 4 : (TS_BT <= 5 ? 3 : 2))) void psd_ts_kernel(TsArgs p) {
   constexpr int TS_WR = (TS_BT + 3) / 4;        // tile rows per wavefront: w, w + 4
-  constexpr int TS_NREP = TS_BT;                // staged elements per thread per operand per K block (16 BT * 16 / 256)
+  constexpr int TS_NREP = VEC ? 2 * ((TS_BT + 1) / 2) : TS_BT;   // staged elements per thread per operand per K block (16 BT * 16 / 256; VEC: in pairs)
+  constexpr int TS_NREP2 = (TS_BT + 1) / 2;     // VEC: 16-byte loads, k pair 2 (tid & 7), row (tid >> 3) + 32 rep
+  typedef double d2_t __attribute__((ext_vector_type(2)));
   constexpr int TS_OPSZ = 16 * TS_BT * TS_LDK;  // doubles per operand per buffer
   __shared__ double lds[2][2][TS_OPSZ];   // [buffer][A / B][row * LDK + k]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -106,32 +108,67 @@ __global__ __launch_bounds__(TS_THREADS, (TS_BT <= 4 ? 4 : (TS_BT <= 5 ? 3 : 2))
   // Loads are unconditional on clamped indices and nothing is done with the values until store_tiles, after
   // the MFMAs of the current K block: any arithmetic (or select) on a loaded value right here makes the
   // compiler wait for the load -- or sink the load under the predicate -- and serialises the round trips.
-  auto load_tiles = [&](int kt) {
+  // VEC (even side, operands contiguous in k: R always, Z in pass 2): one 16-byte load per lane fetches a k pair, 8 lanes cover
+  // a 128-byte line; (the svec gather of pass 1 stays 8 bytes per lane: above the diagonal consecutive k are a column apart)
+  const int vk = 2 * (tid & 7), vr = tid >> 3;
+  const bool vhalf = (TS_BT & 1) ? (vr < 16) : true;   // odd BT: the last pair of 32 rows is half used (wavefront-uniform)
+  auto load_into = [&](int kt, double (&xa)[TS_NREP], double (&xb)[TS_NREP]) {
     const int kk = min(16 * kt + lk, sm1);
+    const int kk2 = min(16 * kt + vk, s - 2);
+    if (VEC) {
 #pragma unroll
-    for (int rep = 0; rep < TS_NREP; ++rep) {
+      for (int rep = 0; rep < TS_NREP2; ++rep) {
+        if (rep == TS_NREP2 - 1 && !vhalf) break;
+        const d2_t tb = *reinterpret_cast<const d2_t*>(R + min(bcol0 + vr + 32 * rep, sm1) * s + kk2);
+        xb[2 * rep] = tb.x; xb[2 * rep + 1] = tb.y;
+        if (PASS == 2) {
+          const d2_t ta = *reinterpret_cast<const d2_t*>(Aj + min(arow0 + vr + 32 * rep, sm1) * s + kk2);
+          xa[2 * rep] = ta.x; xa[2 * rep + 1] = ta.y;
+        }
+      }
+      if (PASS == 2) return;
+    }
+#pragma unroll
+    for (int rep = 0; rep < TS_BT; ++rep) {
       const int mm = min(arow0 + lr + 16 * rep, sm1);
       if (PASS == 1) {   // V[m, k] from the svec column: column-major upper triangle
         const int lo = min(mm, kk), hi = max(mm, kk);
-        ra[rep] = Aj[hi * (hi + 1) / 2 + lo];   // (32-bit: s <= 2048)
+        xa[rep] = Aj[hi * (hi + 1) / 2 + lo];   // (32-bit: s <= 2048)
       } else {           // Z[k, m]: column m of Z is contiguous in k
-        ra[rep] = Aj[mm * s + kk];
+        xa[rep] = Aj[mm * s + kk];
       }
-      rb[rep] = R[min(bcol0 + lr + 16 * rep, sm1) * s + kk];   // R[k, c]
+      if (!VEC) xb[rep] = R[min(bcol0 + lr + 16 * rep, sm1) * s + kk];   // R[k, c]
     }
   };
-  auto store_tiles = [&](int buf, int kt) {
+  auto store_from = [&](int buf, int kt, const double (&xa)[TS_NREP], const double (&xb)[TS_NREP]) {
     const int kp = 16 * kt + lk;
     const double kmask = (kp < s) ? 1.0 : 0.0;
+    if (VEC) {
+      const double vmask = (16 * kt + vk < s) ? 1.0 : 0.0;   // (even side: both of a pair or neither)
 #pragma unroll
-    for (int rep = 0; rep < TS_NREP; ++rep) {
+      for (int rep = 0; rep < TS_NREP2; ++rep) {
+        if (rep == TS_NREP2 - 1 && !vhalf) break;
+        const int row = vr + 32 * rep;
+        const double cm = (bcol0 + row < s) ? vmask : 0.0;
+        *reinterpret_cast<d2_t*>(&lds[buf][1][row * TS_LDK + vk]) = (d2_t){xb[2 * rep] * cm, xb[2 * rep + 1] * cm};
+        if (PASS == 2) {
+          const double am = (arow0 + row < s) ? vmask : 0.0;
+          *reinterpret_cast<d2_t*>(&lds[buf][0][row * TS_LDK + vk]) = (d2_t){xa[2 * rep] * am, xa[2 * rep + 1] * am};
+        }
+      }
+      if (PASS == 2) return;
+    }
+#pragma unroll
+    for (int rep = 0; rep < TS_BT; ++rep) {
       const int m = arow0 + lr + 16 * rep, c = bcol0 + lr + 16 * rep;
-      double va = ra[rep];
+      double va = xa[rep];
       if (PASS == 1) va = (m == kp) ? va : div_rt2(va);   // off-diagonals: vec[k] / rt2 (arrayutilities.jl:231)
       lds[buf][0][(lr + 16 * rep) * TS_LDK + lk] = va * ((m < s) ? kmask : 0.0);
-      lds[buf][1][(lr + 16 * rep) * TS_LDK + lk] = rb[rep] * ((c < s) ? kmask : 0.0);
+      if (!VEC) lds[buf][1][(lr + 16 * rep) * TS_LDK + lk] = xb[rep] * ((c < s) ? kmask : 0.0);
     }
   };
+  auto load_tiles = [&](int kt) { load_into(kt, ra, rb); };
+  auto store_tiles = [&](int buf, int kt) { store_from(buf, kt, ra, rb); };
 
   const int fr = lane & 15, fk = lane >> 4;
   // Which of this wavefront's 2 x 7 tiles exist (bit 2 c + i): rows li = wave + 4 i < TR, columns c < TC,
@@ -376,7 +413,13 @@ template <int PASS>
 static void ts_launch(Ctx& c, TsArgs a, int bt) {
   a.nb = (a.T + bt - 1) / bt;
   const int grid = ((a.ncols + 7) / 8) * a.nb * a.nb * 8;
+  static const bool vec_on = [] { const char* e = getenv("HYP_TS_VEC"); return !(e && e[0] == '0'); }();
+  const bool vec = vec_on && (a.s % 2 == 0) && ((reinterpret_cast<uintptr_t>(a.R) | (PASS == 2 ? reinterpret_cast<uintptr_t>(a.A) : 0)) % 16 == 0);
+  if (vec && bt == 2) { hipLaunchKernelGGL((psd_ts_kernel<PASS, 2, true>), dim3(grid), dim3(TS_THREADS), 0, c.stream, a); return; }
+  if (vec && bt == 3) { hipLaunchKernelGGL((psd_ts_kernel<PASS, 3, true>), dim3(grid), dim3(TS_THREADS), 0, c.stream, a); return; }
+  if (vec && bt == 4) { hipLaunchKernelGGL((psd_ts_kernel<PASS, 4, true>), dim3(grid), dim3(TS_THREADS), 0, c.stream, a); return; }
   switch (bt) {
+    case 2: hipLaunchKernelGGL((psd_ts_kernel<PASS, 2>), dim3(grid), dim3(TS_THREADS), 0, c.stream, a); break;
     case 3: hipLaunchKernelGGL((psd_ts_kernel<PASS, 3>), dim3(grid), dim3(TS_THREADS), 0, c.stream, a); break;
     case 4: hipLaunchKernelGGL((psd_ts_kernel<PASS, 4>), dim3(grid), dim3(TS_THREADS), 0, c.stream, a); break;
     case 5: hipLaunchKernelGGL((psd_ts_kernel<PASS, 5>), dim3(grid), dim3(TS_THREADS), 0, c.stream, a); break;
@@ -405,10 +448,14 @@ void psd_two_sided_fused(Ctx& c, int side, int ncols, const double* R, int rstru
     HYP_CHECK(hipGetLastError());
     return;
   }
+  // a handful of columns (the Hessian products of the directions and of the line search: 16 workgroups per matrix at 64 x 64,
+  // one wavefront per SIMD walking 16 dependent MFMAs per K block) are cut into 32 x 32 workgroup tiles instead
+  static const int few = [] { const char* e = getenv("HYP_TS_FEW"); return e ? atoi(e) : 8; }();
+  const bool small_grid = ncols <= few;
   a.A = arr; a.lda = lda; a.C = zws; a.ldc = 0;
-  ts_launch<1>(c, a, bt1);
+  ts_launch<1>(c, a, small_grid ? 2 : bt1);
   a.A = zws; a.lda = 0; a.C = prod; a.ldc = ldp;
-  ts_launch<2>(c, a, bt2);
+  ts_launch<2>(c, a, small_grid ? 2 : bt2);
   HYP_CHECK(hipGetLastError());
 }
 
