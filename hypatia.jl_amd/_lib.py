@@ -121,6 +121,7 @@ SIGNATURES = {
     "hyp_dense_sysv_rook": [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, P(c_int), c_vp, c_vp, c_vp, c_vp],
     "hyp_dense_lstsq_normal": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, P(c_dbl), P(c_int)],
     "hyp_dense_gemv": [c_vp, c_int, c_int, c_int, c_dbl, c_vp, c_int, c_vp, c_dbl, c_vp],
+    "hyp_dense_gemv_both": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_dbl, c_vp, c_vp, c_dbl, c_vp, P(c_int)],
     "hyp_bench_syrk": [c_vp, c_int, c_int, c_int, P(c_dbl)],
     "hyp_bench_potrf": [c_vp, c_int, c_int, P(c_dbl)],
     "hyp_bench_trsv": [c_vp, c_int, c_int, P(c_dbl), P(c_dbl)],

@@ -976,6 +976,28 @@ int hyp_dense_gemv(hyp_ctx* ctx, int trans, int m, int n, double alpha, const do
   c.sync();
   API_END(ctx)
 }
+int hyp_dense_gemv_both(hyp_ctx* ctx, int m, int n, int nr, const double* A, int lda, const double* Xn, double beta_n, double* Yn,
+                        const double* Xt, double beta_t, double* Yt, int* used_fused) {
+  API_BEGIN
+  Ctx& c = ctx->c;
+  HYP_REQUIRE(m >= 1 && n >= 1 && (nr == 1 || nr == 2) && lda >= m, "gemv_both: sizes");
+  DBuf dA((size_t)lda * n * 8), dxn((size_t)n * nr * 8), dyn((size_t)m * nr * 8), dxt((size_t)m * nr * 8), dyt((size_t)n * nr * 8);
+  c.h2d(dA.p, A, (size_t)lda * n * 8);
+  c.h2d(dxn.p, Xn, (size_t)n * nr * 8); c.h2d(dyn.p, Yn, (size_t)m * nr * 8);
+  c.h2d(dxt.p, Xt, (size_t)m * nr * 8); c.h2d(dyt.p, Yt, (size_t)n * nr * 8);
+  const bool ok = gemv_both_ok(m, n, dA.d(), lda);
+  if (used_fused) *used_fused = ok ? 1 : 0;
+  if (ok) {
+    gemv_both(c, m, n, nr, dA.d(), lda, dxn.d(), n, beta_n, dyn.d(), m, dxt.d(), m, beta_t, dyt.d(), n);
+  } else {   // what the call sites do when the fused pass does not apply
+    gemv_multi(c, false, m, n, nr, 1.0, dA.d(), lda, dxn.d(), n, beta_n, dyn.d(), m);
+    gemv_multi(c, true, m, n, nr, 1.0, dA.d(), lda, dxt.d(), m, beta_t, dyt.d(), n);
+  }
+  c.d2h(Yn, dyn.p, (size_t)m * nr * 8);
+  c.d2h(Yt, dyt.p, (size_t)n * nr * 8);
+  c.sync();
+  API_END(ctx)
+}
 int hyp_bench_potrf(hyp_ctx* ctx, int n, int reps, double* ms_out) {
   API_BEGIN
   Ctx& c = ctx->c;

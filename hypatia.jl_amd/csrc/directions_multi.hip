@@ -214,8 +214,16 @@ __global__ void gemv_n_multi_reduce_kernel(int m, int nchunks, double alpha, con
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   const int r = blockIdx.y;
   if (row >= m) return;
-  double s = 0.0;
-  for (int k = 0; k < nchunks; ++k) s += partial[((long)k * NR + r) * m + row];
+  double s = 0.0;   // (strictly in chunk order; eight loads in flight at a time)
+  int k = 0;
+  for (; k + 8 <= nchunks; k += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[((long)(k + u) * NR + r) * m + row];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; k < nchunks; ++k) s += partial[((long)k * NR + r) * m + row];
   double* y = Y + (long)r * ldy + row;
   *y = alpha * s + (beta != 0.0 ? beta * (*y) : 0.0);
 }
@@ -248,6 +256,127 @@ static void gemv_multi_t(Ctx& c, bool trans, int m, int n, double alpha, const d
   }
   HYP_CHECK(hipGetLastError());
 }
+// ---- BOTH products of one matrix in ONE pass over it: Yn[:, r] = A Xn[:, r] + beta_n Yn[:, r] and Yt[:, r] = A' Xt[:, r] + beta_t Yt[:, r].
+// Where the algorithm needs G x and G' z of independent vectors at the same moment (the residual of a pair of directions, apply_lhs
+// common.jl:79-121; the residuals of calc_convergence_params, Solvers.jl:425-483) the two HBM-bound passes over the q x n block
+// (804 MB at config 2, 8.3 GB at config 4) become one.  Workgroup = 64 columns (a 16-column strip per wavefront) x a range of rows
+// walked in blocks of 256; lane l owns rows 4 l .. 4 l + 3 of the block (32-byte loads, a wavefront reads 2 KB of a column).  The
+// A' part keeps 16 column sums per lane over the whole range (one shuffle tree at the end, partial per row range); the A part sums a
+// lane's 4 rows over the strip, the four strips meet in LDS, partial per 64-column chunk.  Two ordered reductions finish (the
+// kernels of the one-sided products).  Fixed assignment and order: bitwise reproducible; the sums are NOT those of the one-sided
+// kernels (another order), so a call site uses one form or the other, never a mixture across iterations.
+template <int NR>
+__global__ __launch_bounds__(256) void gemv_both_kernel(int m, int n, const double* __restrict__ A, long lda, const double* __restrict__ Xn, long ldxn,
+                                                        const double* __restrict__ Xt, long ldxt, double* __restrict__ part_n,
+                                                        double* __restrict__ part_t, int rows_per_split) {
+  typedef double d4v_t __attribute__((ext_vector_type(4)));
+  __shared__ double red[2][4][NR][256];   // double-buffered: one barrier per row block
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c0 = blockIdx.x * 64 + 16 * w;
+  const int rbeg = blockIdx.y * rows_per_split, rend = min(m, rbeg + rows_per_split);
+  double xn[NR][16];
+  const double* a[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int c = c0 + j;
+    a[j] = A + (long)min(c, n - 1) * lda;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) xn[r][j] = (c < n) ? Xn[(long)r * ldxn + c] : 0.0;
+  }
+  double st[NR][16];
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) st[r][j] = 0.0;
+  for (int row0 = rbeg; row0 < rend; row0 += 256) {
+    const int r4 = row0 + 4 * lane;
+    const bool full = (r4 + 3 < rend);
+    double xt[NR][4];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xt[r][i] = (r4 + i < rend) ? Xt[(long)r * ldxt + r4 + i] : 0.0;
+    double sn[NR][4];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) sn[r][0] = sn[r][1] = sn[r][2] = sn[r][3] = 0.0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      d4v_t av[8];
+      if (full) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) av[j] = *reinterpret_cast<const d4v_t*>(a[8 * half + j] + r4);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) av[j][i] = (r4 + i < rend) ? a[8 * half + j][r4 + i] : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            sn[r][i] = fma(av[j][i], xn[r][8 * half + j], sn[r][i]);
+            st[r][8 * half + j] = fma(av[j][i], xt[r][i], st[r][8 * half + j]);
+          }
+    }
+    // the four strips' sums of a row meet in LDS.  A wavefront that runs ahead writes buffer b again two blocks later, i.e. after
+    // the next block's barrier, which nobody passes before every reader of this block is done: one barrier per block suffices
+    const int b = ((row0 - rbeg) >> 8) & 1;
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[b][w][r][4 * lane + i] = sn[r][i];
+    __syncthreads();
+    if (row0 + tid < rend) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+        part_n[((long)blockIdx.x * NR + r) * m + row0 + tid] = (red[b][0][r][tid] + red[b][1][r][tid]) + (red[b][2][r][tid] + red[b][3][r][tid]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      double t = st[r][j];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+      if (lane == 0 && c0 + j < n) part_t[((long)blockIdx.y * NR + r) * n + c0 + j] = t;
+    }
+}
+
+bool gemv_both_ok(int m, int n, const double* A, long lda) {
+  static const bool on = [] { const char* e = getenv("HYP_GEMV_BOTH"); return !(e && e[0] == '0'); }();
+  return on && m >= 1024 && n >= 64 && (lda % 4 == 0) && ((uintptr_t)A % 32 == 0);
+}
+
+template <int NR>
+static void gemv_both_t(Ctx& c, int m, int n, const double* A, long lda, const double* Xn, long ldxn, double beta_n, double* Yn, long ldyn,
+                        const double* Xt, long ldxt, double beta_t, double* Yt, long ldyt) {
+  const int nchunks = (n + 63) / 64;
+  int splits = std::max(1, std::min((1536 + nchunks - 1) / nchunks, (m + 1023) / 1024));
+  const int rows_per_split = (((m + splits - 1) / splits) + 255) / 256 * 256;
+  splits = (m + rows_per_split - 1) / rows_per_split;
+  const size_t pn = (size_t)nchunks * NR * m, pt = (size_t)splits * NR * n;
+  c.scratch.ensure((pn + pt) * sizeof(double));
+  double* part_n = c.scratch.d();
+  double* part_t = c.scratch.d() + pn;
+  hipLaunchKernelGGL((gemv_both_kernel<NR>), dim3(nchunks, splits), dim3(256), 0, c.stream, m, n, A, lda, Xn, ldxn, Xt, ldxt, part_n, part_t,
+                     rows_per_split);
+  hipLaunchKernelGGL((gemv_n_multi_reduce_kernel<NR>), dim3((m + 255) / 256, NR), dim3(256), 0, c.stream, m, nchunks, 1.0, part_n, beta_n, Yn, ldyn);
+  hipLaunchKernelGGL((gemv_n_multi_reduce_kernel<NR>), dim3((n + 255) / 256, NR), dim3(256), 0, c.stream, n, splits, 1.0, part_t, beta_t, Yt, ldyt);
+  HYP_CHECK(hipGetLastError());
+}
+// nr = 1 or 2 columns each way; the caller has checked gemv_both_ok
+void gemv_both(Ctx& c, int m, int n, int nr, const double* A, long lda, const double* Xn, long ldxn, double beta_n, double* Yn, long ldyn,
+               const double* Xt, long ldxt, double beta_t, double* Yt, long ldyt) {
+  HYP_REQUIRE(nr == 1 || nr == 2, "gemv_both: 1 or 2 right-hand sides");
+  if (nr == 1) gemv_both_t<1>(c, m, n, A, lda, Xn, ldxn, beta_n, Yn, ldyn, Xt, ldxt, beta_t, Yt, ldyt);
+  else gemv_both_t<2>(c, m, n, A, lda, Xn, ldxn, beta_n, Yn, ldyn, Xt, ldxt, beta_t, Yt, ldyt);
+}
+
 // nr = 1, 2 or 3 right-hand sides per pass over A (3: the constant column of update_lhs rides along with the first pair of
 // directions); every column's sums are those of the same column in a pass of its own width class (fixed per-thread row
 // assignment and reduction tree)
@@ -551,7 +680,14 @@ void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double
     dsc[r].kap = -mu / taubar / taubar * sol_tau + rs[r].kap;
   }
   // sol.s = h tau - rhs.z - G sol.x  (G sol.x from the rounded sol.x, see solve_system; kept for the residual)
-  gemv_multi(ctx, false, q, n, MR, 1.0, G.d(), q, dir, dv, 0.0, m_Gxd.d(), q);
+  // (with a residual to follow, G' dir.z of apply_lhs rides along in the same pass over G)
+  const bool both = (max_ref_steps > 0) && gemv_both_ok(q, n, G.d(), q);
+  if (both) {
+    m_t.ensure((size_t)MR * n * d);
+    gemv_both(ctx, q, n, MR, G.d(), q, dir, dv, 0.0, m_Gxd.d(), q, dir + oz, dv, 0.0, m_t.d(), n);
+  } else {
+    gemv_multi(ctx, false, q, n, MR, 1.0, G.d(), q, dir, dv, 0.0, m_Gxd.d(), q);
+  }
   for (int r = 0; r < MR; ++r) {
     double* sol = dir + (long)r * dv;
     dev_scale_copy(ctx, q, dsc[r].tau, mh.d(), sol + os);
@@ -570,10 +706,12 @@ void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double
       dev_axpby(ctx, q, -1.0, dir + (long)r * dv + os, 1.0, rr + oz);
       dev_axpby(ctx, q, -1.0, m_Gxd.d() + (long)r * q, 1.0, rr + oz);
     }
-    if (dist()) {
-      m_t.ensure((size_t)MR * n * d);
-      gemv_multi(ctx, true, q, n, MR, 1.0, G.d(), q, dir + oz, dv, 0.0, m_t.d(), n);
-      allreduce_dev(m_t.d(), (long)MR * n, 0);
+    if (dist() || both) {
+      if (!both) {
+        m_t.ensure((size_t)MR * n * d);
+        gemv_multi(ctx, true, q, n, MR, 1.0, G.d(), q, dir + oz, dv, 0.0, m_t.d(), n);
+      }
+      if (dist()) allreduce_dev(m_t.d(), (long)MR * n, 0);
       for (int r = 0; r < MR; ++r) dev_axpby(ctx, n, 1.0, m_t.d() + (long)r * n, 1.0, res + (long)r * dv);
     } else {
       gemv_multi(ctx, true, q, n, MR, 1.0, G.d(), q, dir + oz, dv, 1.0, res, dv);

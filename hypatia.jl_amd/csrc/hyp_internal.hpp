@@ -188,6 +188,10 @@ struct BKFact {
 // Y[:, r] = alpha op(A) X[:, r] + beta Y[:, r] for r < nr <= 2: one pass over A serves all right-hand sides
 void gemv_multi(Ctx& c, bool trans, int m, int n, int nr, double alpha, const double* A, long lda, const double* X, long ldx, double beta,
                 double* Y, long ldy);
+// both products of one matrix in one pass over it (directions_multi.hip): Yn = A Xn + beta_n Yn, Yt = A' Xt + beta_t Yt, nr = 1 or 2 columns
+bool gemv_both_ok(int m, int n, const double* A, long lda);
+void gemv_both(Ctx& c, int m, int n, int nr, const double* A, long lda, const double* Xn, long ldxn, double beta_n, double* Yn, long ldyn,
+               const double* Xt, long ldxt, double beta_t, double* Yt, long ldyt);
 // explicit inverse of an upper triangular matrix from its inverted diagonal blocks: Uinv (upper, full
 // storage, strictly-lower part zero).  Used for the small cone matrices.
 void trtri_upper_batched(Ctx& c, int n, const double* U, long ldu, long strideU, const double* dinv, long strideD,

@@ -364,9 +364,13 @@ void SysSolver::residual_products(const double* h_x, const double* h_z, const do
   if (q > 0) {
     ctx.h2d(rp_z.p, hs + n, (size_t)q * d);
     ctx.h2d(rp_s.p, hs + n + q, (size_t)q * d);
-    gemv(ctx, true, q, n, 1.0, G.d(), q, rp_z.d(), 0.0, rp_t.d());          // G' z (these rows)
     ctx.d2d(rp_g.p, rp_s.p, (size_t)q * d);
-    gemv(ctx, false, q, n, 1.0, G.d(), q, rp_x.d(), 1.0, rp_g.d());         // G x + s
+    if (n > 0 && gemv_both_ok(q, n, G.d(), q)) {                             // G' z (these rows) and G x + s in one pass over G
+      gemv_both(ctx, q, n, 1, G.d(), q, rp_x.d(), n, 1.0, rp_g.d(), q, rp_z.d(), q, 0.0, rp_t.d(), n);
+    } else {
+      gemv(ctx, true, q, n, 1.0, G.d(), q, rp_z.d(), 0.0, rp_t.d());
+      gemv(ctx, false, q, n, 1.0, G.d(), q, rp_x.d(), 1.0, rp_g.d());
+    }
     dev_dot(ctx, q, mh.d(), rp_z.d(), rp_t.d() + n);
     dev_dot(ctx, q, rp_z.d(), rp_s.d(), rp_t.d() + n + 1);
   }

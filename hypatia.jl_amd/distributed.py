@@ -365,6 +365,8 @@ class HipLocalSys:
 class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
     """QRCholDenseSystemSolver over cone-sharded data (p = 0, i.e. the default reduce = true path)."""
 
+    one_pass_residual_products = False   # (its residual_products is the row-local form; calc_convergence_params takes that branch itself)
+
     def __init__(self, comm, local_backend=HipLocalSys):
         super().__init__()
         self.comm = comm

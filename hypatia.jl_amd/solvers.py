@@ -831,7 +831,8 @@ class Solver:
             return self._calc_convergence_params_row_local()
         model, point = self.model, self.point
         tau = point.tau
-        xr = self.syssolver.mul_G(True, point.z)
+        rp = self.syssolver.residual_products(point) if getattr(self.syssolver, "one_pass_residual_products", False) else None
+        xr = rp["Gtz"] if rp is not None else self.syssolver.mul_G(True, point.z)
         if model.p:
             xr = xr + model.A.T @ point.y
         self.x_norm_res_t = _norm_inf(xr)
@@ -847,7 +848,7 @@ class Solver:
         self.y_residual[:] = yr
         y_feas = self.y_norm_res * self.y_conv_tol
 
-        zr = self.syssolver.mul_G(False, point.x) + point.s
+        zr = rp["Gx_s"] if rp is not None else self.syssolver.mul_G(False, point.x) + point.s
         self.z_norm_res_t = _norm_inf(zr)
         zr = zr - model.h * tau
         self.z_norm_res = _norm_inf(zr) / tau

@@ -94,6 +94,16 @@ class QRCholDenseSystemSolver:
         L.check(L.lib().hyp_sys_mul_G(self._h, int(trans), float(alpha), L.vec_ptr(xx), float(beta), L.vec_ptr(y)), "hyp_sys_mul_G")
         return y
 
+    one_pass_residual_products = True   # calc_convergence_params takes G' z and G x + s from ONE pass over G
+
+    def residual_products(self, pt):
+        """G' z, G x + s, h' z and z' s of a point in one call (hyp_sys_residual_products: G is read once for both products)"""
+        Gtz, Gx_s, dots = np.zeros(self.n), np.zeros(max(self.q, 1)), np.zeros(2)
+        L.check(L.lib().hyp_sys_residual_products(self._h, L.vec_ptr(np.ascontiguousarray(pt.x)), L.vec_ptr(np.ascontiguousarray(pt.z)),
+                                                  L.vec_ptr(np.ascontiguousarray(pt.s)), L.vec_ptr(Gtz), L.vec_ptr(Gx_s), L.vec_ptr(dots)),
+                "hyp_sys_residual_products")
+        return {"Gtz": Gtz, "Gx_s": Gx_s[:self.q], "hz": float(dots[0]), "zs": float(dots[1])}
+
     # ---- qrchol.jl:181-199
     def update_lhs(self, solver):
         model = solver.model

@@ -299,6 +299,12 @@ int hyp_dense_lstsq_normal(hyp_ctx* ctx, int m, int n, const double* A, int lda,
 /* y = alpha * op(A) x + beta * y (A is m x n col-major; trans != 0: op(A) = A') */
 int hyp_dense_gemv(hyp_ctx* ctx, int trans, int m, int n, double alpha, const double* A, int lda, const double* x, double beta,
                    double* y);
+/* Both products of one matrix in ONE pass over it (test hook of the kernel behind apply_lhs' residual, systemsolvers/common.jl:79-121,
+ * and calc_convergence_params, Solvers.jl:425-483): Yn[:, r] = A Xn[:, r] + beta_n Yn[:, r] (Xn n x nr, Yn m x nr) and
+ * Yt[:, r] = A' Xt[:, r] + beta_t Yt[:, r] (Xt m x nr, Yt n x nr), nr = 1 or 2, all column-major and dense.  used_fused = 1 when the
+ * one-pass kernel applies (m >= 1024, n >= 64, lda % 4 == 0), 0 when the two one-sided products ran instead. */
+int hyp_dense_gemv_both(hyp_ctx* ctx, int m, int n, int nr, const double* A, int lda, const double* Xn, double beta_n, double* Yn,
+                        const double* Xt, double beta_t, double* Yt, int* used_fused);
 /* Measurement helper: HIP-event time (ms, mean of reps) of the blocked upper Cholesky of an n x n positive definite matrix
  * resident in HBM (posdef_fact_copy!'s first link, src/linearalgebra/dense.jl:194-200). */
 int hyp_bench_potrf(hyp_ctx* ctx, int n, int reps, double* ms_out);

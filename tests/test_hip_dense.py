@@ -214,6 +214,33 @@ def test_gemv(hip, trans, m, n):
     assert np.allclose(y, ref, rtol=1e-12, atol=1e-11)
 
 
+@pytest.mark.parametrize("m,n,nr,lda,fused", [(20100, 300, 2, 20100, 1), (20100, 300, 1, 20100, 1), (4845, 200, 2, 4848, 1),
+                                               (1024, 64, 2, 1024, 1), (2051, 131, 1, 2052, 1), (5000, 70, 2, 5001, 0), (600, 90, 2, 600, 0)])
+def test_gemv_both_products_in_one_pass(hip, m, n, nr, lda, fused):
+    """A X and A' Z from one pass over A (the residual of a pair of directions, apply_lhs common.jl:79-121, and the residuals of
+    calc_convergence_params, Solvers.jl:425-483): ragged row and column counts, a leading dimension beyond m, beta on both sides,
+    and the shapes that fall back to the two one-sided products"""
+    lib, ctx, L = hip
+    rng = np.random.default_rng(m + n)
+    A = np.zeros((lda, n), order="F")
+    A[:m] = rng.standard_normal((m, n))
+    A[m:] = np.nan                                   # rows beyond m are never read
+    Xn = np.asfortranarray(rng.standard_normal((n, nr)))
+    Xt = np.asfortranarray(rng.standard_normal((m, nr)))
+    Yn = np.asfortranarray(rng.standard_normal((m, nr)))
+    Yt = np.asfortranarray(rng.standard_normal((n, nr)))
+    Yn0, Yt0 = Yn.copy(), Yt.copy()
+    used = c_int(-1)
+    L.check(lib.hyp_dense_gemv_both(ctx, m, n, nr, fp(A), lda, fp(Xn), 1.0, fp(Yn), fp(Xt), -0.5, fp(Yt), ctypes.byref(used)), "gemv_both")
+    assert used.value == fused
+    assert np.allclose(Yn, A[:m] @ Xn + Yn0, rtol=1e-12, atol=1e-11)
+    assert np.allclose(Yt, A[:m].T @ Xt - 0.5 * Yt0, rtol=1e-12, atol=1e-11)
+    # a second call gives the same bits (fixed assignment and reduction order)
+    Yn2, Yt2 = Yn0.copy(order="F"), Yt0.copy(order="F")
+    L.check(lib.hyp_dense_gemv_both(ctx, m, n, nr, fp(A), lda, fp(Xn), 1.0, fp(Yn2), fp(Xt), -0.5, fp(Yt2), None), "gemv_both")
+    assert np.array_equal(Yn, Yn2) and np.array_equal(Yt, Yt2)
+
+
 @pytest.mark.parametrize("N,K", [(300, 5000), (130, 4100), (257, 900), (1032, 4500), (1300, 4100)])
 def test_syrk_schur_path_with_splitk(hip, N, K):
     """the Schur-assembly syrk (split-K slices + ordered reduction when K is long)"""
