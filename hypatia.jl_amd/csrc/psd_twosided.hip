@@ -276,37 +276,49 @@ __global__ __launch_bounds__(TS_THREADS, (TS_BT <= 4 ? 4 : (TS_BT <= 5 ? 3 : 2))
 // LDS strides: [k][c] operands (R, and Z in pass 2) want consecutive rows 32 dwords apart modulo 64 (S = 16 mod 32 doubles);
 // the row-indexed operand V of pass 1 wants 2 S2 = 4 mod 32 dwords (S2 = 16 T + 2).
 // =============================================================================================
-template <int T>
-__global__ __launch_bounds__(64 * T) void psd_ts_small_kernel(TsArgs p, int cols_per_wg) {
+// TEAMS = 2 (side 80, config 4): two teams of T wavefronts share the staged R and work on two matrices side by side, each in a VZ
+// buffer of its own -- 51 + 2 x 52.5 KB of LDS instead of one workgroup of five wavefronts per CU (103.7 KB: a second one does
+// not fit), so that the barriers, the gather and the operand latencies of one matrix run under the MFMAs of the other.
+template <int T, int TEAMS>
+__global__ __launch_bounds__(64 * T * TEAMS) void psd_ts_small_kernel(TsArgs p, int cols_per_wg) {
   constexpr int N = 16 * T;
   constexpr int S = (N % 32 == 16) ? N : N + 16;
   constexpr int S2 = N + 2;
-  constexpr int THREADS = 64 * T;
+  constexpr int THREADS = 64 * T;            // per team
+  constexpr int ALL = THREADS * TEAMS;
   extern __shared__ __attribute__((aligned(16))) double ts_lds[];
   double* Rs = ts_lds;             // [k][c], N x S
-  double* VZ = ts_lds + N * S;     // [m][k] (V), then Z over the same rows, N x S2
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int gtid = threadIdx.x, lane = gtid & 63;
+  const int gw = __builtin_amdgcn_readfirstlane(gtid >> 6);
+  const int team = gw / T, w = gw % T;
+  const int tid = gtid - team * THREADS;     // within the team
+  double* VZ = ts_lds + N * S + team * (N * S2);   // [m][k] (V), then Z over the same rows, N x S2 (one per team)
   const int q = lane >> 4, nn = lane & 15;
   const int s = p.s;
   const long d = (long)s * (s + 1) / 2;
-  for (int e = tid; e < N * N; e += THREADS) {   // R -> LDS (zero padding beyond s; a triangular R has its zeros in memory)
+  for (int e = gtid; e < N * N; e += ALL) {   // R -> LDS (zero padding beyond s; a triangular R has its zeros in memory)
     const int k = e % N, c = e / N;
     Rs[k * S + c] = (k < s && c < s) ? p.R[(long)c * s + k] : 0.0;
   }
   for (int e = tid; e < N * S2; e += THREADS) VZ[e] = 0.0;
-  const long j0 = (long)blockIdx.x * cols_per_wg;
-  const long j1 = min((long)p.ncols, j0 + cols_per_wg);
+  // team t takes the columns j0 + t, j0 + t + TEAMS, ...; both teams walk the same number of rounds (the barriers are the
+  // workgroup's), a team without a column in the last round idles through it
+  const long jb = (long)blockIdx.x * cols_per_wg;
+  const long j1 = min((long)p.ncols, jb + cols_per_wg);
+  const long j0 = jb + team;
+  const long rounds = (j1 - jb + TEAMS - 1) / TEAMS;
   constexpr int PER = (N * (N + 1) / 2 + THREADS - 1) / THREADS;   // upper-triangle entries per thread
-  int ei[PER], ej[PER];                                            // (i, j) of this thread's entries: the same for every matrix
+  // (i, j) of this thread's entries, the same for every matrix, as the two LDS offsets i S2 + j and j S2 + i (14 bits each:
+  // N S2 <= 96 x 98), bit 28 = diagonal entry, bit 29 = valid -- one register per entry
+  unsigned eo[PER];
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
     const long e = tid + (long)THREADS * u;
     int j = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
     while ((long)(j + 1) * (j + 2) / 2 <= e) ++j;
     while ((long)j * (j + 1) / 2 > e) --j;
-    ei[u] = (int)(e - (long)j * (j + 1) / 2);
-    ej[u] = (e < d) ? j : -1;
+    const int i = (int)(e - (long)j * (j + 1) / 2);
+    eo[u] = (e < d) ? ((unsigned)(i * S2 + j) | ((unsigned)(j * S2 + i) << 14) | ((i == j) ? (1u << 28) : 0u) | (1u << 29)) : 0u;
   }
   double vreg[PER];
   if (j0 < j1) {
@@ -315,19 +327,21 @@ __global__ __launch_bounds__(64 * T) void psd_ts_small_kernel(TsArgs p, int cols
     for (int u = 0; u < PER; ++u) vreg[u] = col[min((long)tid + (long)THREADS * u, d - 1)];
   }
   __syncthreads();
-  for (long j = j0; j < j1; ++j) {
+  for (long rd = 0; rd < rounds; ++rd) {
+    const long j = j0 + rd * TEAMS;
+    const bool live = j < j1;
     // ---- V_j -> LDS, both triangles, off-diagonals / sqrt(2) (arrayutilities.jl:231)
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      if (ej[u] >= 0) {
-        const double v = (ei[u] == ej[u]) ? vreg[u] : div_rt2(vreg[u]);
-        VZ[ei[u] * S2 + ej[u]] = v;
-        VZ[ej[u] * S2 + ei[u]] = v;
+      if (live && (eo[u] >> 29)) {
+        const double v = ((eo[u] >> 28) & 1u) ? vreg[u] : div_rt2(vreg[u]);
+        VZ[eo[u] & 0x3fffu] = v;
+        VZ[(eo[u] >> 14) & 0x3fffu] = v;
       }
     }
     __syncthreads();
-    if (j + 1 < j1) {   // next column's entries: in flight during the two passes
-      const double* __restrict__ col = p.A + (j + 1) * p.lda;
+    if (j + TEAMS < j1) {   // next column's entries: in flight during the two passes
+      const double* __restrict__ col = p.A + (j + TEAMS) * p.lda;
 #pragma unroll
       for (int u = 0; u < PER; ++u) vreg[u] = col[min((long)tid + (long)THREADS * u, d - 1)];
     }
@@ -335,6 +349,7 @@ __global__ __launch_bounds__(64 * T) void psd_ts_small_kernel(TsArgs p, int cols
     d4_t acc[T];
 #pragma unroll
     for (int ct = 0; ct < T; ++ct) acc[ct] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    if (live) {
 #pragma unroll
     for (int kt = 0; kt < T; ++kt) {
       double af[4];
@@ -354,9 +369,11 @@ __global__ __launch_bounds__(64 * T) void psd_ts_small_kernel(TsArgs p, int cols
     for (int ct = 0; ct < T; ++ct)
 #pragma unroll
       for (int r = 0; r < 4; ++r) VZ[(16 * w + q + 4 * r) * S2 + 16 * ct + nn] = acc[ct][r];
+    }
     __syncthreads();
     // ---- pass 2: tile row w of the upper triangle of W = Z' R, computed transposed (D[c][m]) so that 16 lanes hold 16
     //      consecutive ROWS of a column of W = 128 contiguous bytes of the packed column
+    if (live) {
     double* __restrict__ out = p.C + j * p.ldc;
 #pragma unroll
     for (int ct = 0; ct < T; ++ct) acc[ct] = (d4_t){0.0, 0.0, 0.0, 0.0};
@@ -383,27 +400,37 @@ __global__ __launch_bounds__(64 * T) void psd_ts_small_kernel(TsArgs p, int cols
         if (m <= c && c < s) out[(long)c * (c + 1) / 2 + m] = (m == c) ? acc[ct][r] : acc[ct][r] * 1.4142135623730951;   // arrayutilities.jl:176
       }
     }
+    }
     __syncthreads();   // (the next matrix overwrites VZ)
   }
 }
 
-template <int T>
-static void ts_small_launch(Ctx& c, TsArgs a) {
+template <int T, int TEAMS>
+static void ts_small_launch_t(Ctx& c, TsArgs a) {
   constexpr int N = 16 * T;
   constexpr int S = (N % 32 == 16) ? N : N + 16;
   constexpr int S2 = N + 2;
-  const size_t lds = (size_t)(N * S + N * S2) * sizeof(double);
+  const size_t lds = (size_t)(N * S + TEAMS * N * S2) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
-    HYP_CHECK(hipFuncSetAttribute((const void*)psd_ts_small_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HYP_CHECK(hipFuncSetAttribute((const void*)psd_ts_small_kernel<T, TEAMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   // enough workgroups to fill the chip a few times over (R is re-staged per workgroup: keep the ranges long)
   const int per_cu = std::max(1, (int)(160 * 1024 / lds));
   const int want = 256 * per_cu * 2;
-  const int cols_per_wg = std::max(4, (a.ncols + want - 1) / want);
+  const int cols_per_wg = std::max(4 * TEAMS, ((a.ncols + want - 1) / want + TEAMS - 1) / TEAMS * TEAMS);
   const int grid = (a.ncols + cols_per_wg - 1) / cols_per_wg;
-  hipLaunchKernelGGL(psd_ts_small_kernel<T>, dim3(grid), dim3(64 * T), lds, c.stream, a, cols_per_wg);
+  hipLaunchKernelGGL((psd_ts_small_kernel<T, TEAMS>), dim3(grid), dim3(64 * T * TEAMS), lds, c.stream, a, cols_per_wg);
+}
+template <int T>
+static void ts_small_launch(Ctx& c, TsArgs a) {
+  // two teams where one workgroup per CU is all that fits otherwise and two VZ buffers + R still do (side 80: 156 KB)
+  static const bool teams_on = [] { const char* e = getenv("HYP_TS_TEAMS"); return !(e && e[0] == '0'); }();
+  if constexpr (T == 5) {
+    if (teams_on && a.ncols >= 64) { ts_small_launch_t<T, 2>(c, a); return; }
+  }
+  ts_small_launch_t<T, 1>(c, a);
 }
 
 bool psd_two_sided_fused_ok(int side) { return side >= 1 && side <= 2048; }

@@ -1,5 +1,6 @@
 export TMPDIR=/tmp
-python -m pytest tests/test_hip_dense.py -m gpu -q -x -k "gemv" 2>&1 | tail -3
-rm -rf /tmp/pb; rocprofv3 --kernel-trace -d /tmp/pb -o b -- python bench.py --steps 20 --cpu-iters 0 > /dev/null 2>&1
-python tools/rocpd_stats.py $(find /tmp/pb -name "*.db" | head -1) 2>/dev/null | grep -i "gemv_both\|reduce\|name" | cut -c1-150
-python -m pytest tests/test_hip_solver.py tests/test_hip_trajectory.py tests/test_hip_distributed.py tests/test_hip_fullsize.py -m gpu -q -x 2>&1 | tail -3
+python -m pytest tests/test_hip_cones.py -m gpu -q -x -k "psd or Psd or possemidef" 2>&1 | tail -2
+for t in 1 0; do
+HYP_TS_TEAMS=$t python bench.py --config 4 --steps 6 --warmup 2 --cpu-iters 0 > gpurun_out/ex4_$t.json 2>gpurun_out/ex4_$t.err; python -c "
+import json; d=json.loads(open('gpurun_out/ex4_$t.json').read()); print('teams $t', d['ms_per_step'], d.get('phases_ms_per_step'))"
+done
