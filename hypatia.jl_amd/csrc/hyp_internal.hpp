@@ -87,6 +87,7 @@ struct Ctx {
   DBuf dscal;         // 64 device doubles for scalar results (dots, counts)
   DBuf stage_a, stage_b;   // device staging for host-pointer entry points
   DBuf work_tri;           // workspace of trtri_upper_batched
+  DBuf ts_ws;              // PSD two-sided product: zero-padded copy of the factor + the padded intermediates Z_j (psd_twosided.hip)
   int diag_own_cu_lds = -1;   // dynamic LDS that gives the critical-path diagonal-block kernel a CU of its own (-1: not asked yet, 0: refused)
   int trsv_sb = 1024;      // largest super-block of the one-right-hand-side triangular solves (HYP_TRSV_SB; 0 = per-128-block path)
   bool trsv_sb_forced = false;   // HYP_TRSV_SB given: that size, plan from 2 super-blocks on (the round-1 rule)

@@ -262,6 +262,217 @@ __global__ __launch_bounds__(TS_THREADS, (TS_BT <= 4 ? 4 : (TS_BT <= 5 ? 3 : 2))
 }
 
 // =============================================================================================
+// Third form of the two passes (round 3; default for sides > 96): the same tiling with the VALU work of the K loop removed.
+// Cycle stamps in the loop of the kernel above (4 resident workgroups, side 200) gave per K block and wavefront: waiting for the
+// operands requested a block earlier 15 cycles, LDS staging (index clamps, 0 / 1 masks, the division by sqrt(2)) 1000 - 1500,
+// address arithmetic + issue of the next loads 300 - 600, LDS fragments + MFMAs 1200 - 1700, barrier the rest -- nothing waits
+// for memory, but a wavefront's ~100 vector instructions take as long as its 16 MFMAs: on gfx950 the FP64 MFMA runs on the
+// SIMD's FP64 lanes (matrix peak = vector peak, 78.6 TFLOP/s) and vector instructions of the other wavefronts do not issue
+// underneath it, so every VALU instruction in the loop is MFMA time lost ("the parts add up").  Here
+//   * R is copied once per call into a zero-padded 16 T x 16 T square and Z is kept at that leading dimension (pass 1 writes
+//     the padding as exact zeros): no index clamps and no masks on any k-contiguous operand, whose loads become
+//     global_load_dwordx4 v, v_off, s[base] with a per-thread constant offset and a scalar base that advances per K block;
+//   * the svec gather of pass 1 distinguishes, per K block and wavefront-uniformly, blocks left of the row block (offset =
+//     constant + 16 kt), right of it (k (k + 1) / 2 once per block, one add per element) and the diagonal-crossing ones (the
+//     general formula); row / k masks only in edge blocks;
+//   * the K loop is unrolled by two so that LDS addresses are immediates.
+// =============================================================================================
+__global__ void ts_pad_r_kernel(int s, int LD, const double* __restrict__ R, double* __restrict__ Rp) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= LD * LD) return;
+  const int k = e % LD, c = e / LD;
+  Rp[e] = (k < s && c < s) ? R[(long)c * s + k] : 0.0;
+}
+
+template <int PASS, int TS_BT>
+__global__ __launch_bounds__(TS_THREADS, 4) void psd_ts3_kernel(TsArgs p) {
+  static_assert(TS_BT <= 4, "one tile row per wavefront");
+  constexpr int NREP2 = (TS_BT + 1) / 2;     // 16-byte loads: k pair 2 (tid & 7), row (tid >> 3) + 32 rep
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  constexpr int TS_OPSZ = 16 * TS_BT * TS_LDK;
+  __shared__ double lds[2][2][TS_OPSZ];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s = p.s, T = p.T, LD = 16 * T;
+  const long LD2 = (long)LD * LD;
+  const int nbb = p.nb * p.nb;
+  const int g = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+  const long j = (long)(g / nbb) * 8 + xcd;
+  if (j >= p.ncols) return;
+  const int sub = g % nbb;
+  int mt0, TR, ct0, TC;
+  ts_block_range(T, p.nb, sub % p.nb, mt0, TR);
+  ts_block_range(T, p.nb, sub / p.nb, ct0, TC);
+  if (PASS == 2 && mt0 > ct0 + TC - 1) return;
+  const double* __restrict__ Aj = (PASS == 1) ? p.A + j * p.lda : p.A + j * LD2;
+  int kt_lo = 0, kt_hi = T;
+  if (p.rstruct == 1) kt_hi = min(T, ct0 + TC);
+  else if (p.rstruct == 2) kt_lo = ct0;
+
+  d4_t acc[TS_BT];
+#pragma unroll
+  for (int c = 0; c < TS_BT; ++c) acc[c] = (d4_t){0.0, 0.0, 0.0, 0.0};
+
+  const int arow0 = 16 * mt0, bcol0 = 16 * ct0;
+  const int vk = 2 * (tid & 7), vr = tid >> 3;
+  const bool vhalf = (TS_BT & 1) ? (vr < 16) : true;   // odd BT: the last pair of 32 rows is half used (wavefront-uniform)
+  unsigned offB[NREP2], offZ[NREP2];
+  int ldsV[NREP2];
+#pragma unroll
+  for (int rep = 0; rep < NREP2; ++rep) {
+    offB[rep] = (unsigned)(min(bcol0 + vr + 32 * rep, LD - 1) * LD + vk);
+    offZ[rep] = (unsigned)(min(arow0 + vr + 32 * rep, LD - 1) * LD + vk);
+    ldsV[rep] = (vr + 32 * rep) * TS_LDK + vk;
+  }
+  // pass 1 gather: row lr + 16 rep of the block, k = lk of the K block
+  const int lk = tid & 15, lr = tid >> 4;
+  const int sm1 = s - 1;
+  int mrow[TS_BT];
+  unsigned triM[TS_BT];
+#pragma unroll
+  for (int rep = 0; rep < TS_BT; ++rep) {
+    mrow[rep] = min(arow0 + lr + 16 * rep, sm1);
+    triM[rep] = (unsigned)(mrow[rep] * (mrow[rep] + 1) / 2 + lk);
+  }
+  const bool rows_edge = (arow0 + 16 * TS_BT > s);
+
+  d2_t rbv[NREP2], rzv[NREP2];
+  double ra[TS_BT];
+
+  auto load_tiles = [&](int kt) {
+    const double* __restrict__ Rk = p.R + 16 * kt;
+#pragma unroll
+    for (int rep = 0; rep < NREP2; ++rep) {
+      if (rep == NREP2 - 1 && !vhalf) break;
+      rbv[rep] = *reinterpret_cast<const d2_t*>(Rk + offB[rep]);
+    }
+    if (PASS == 2) {
+      const double* __restrict__ Zk = Aj + 16 * kt;
+#pragma unroll
+      for (int rep = 0; rep < NREP2; ++rep) {
+        if (rep == NREP2 - 1 && !vhalf) break;
+        rzv[rep] = *reinterpret_cast<const d2_t*>(Zk + offZ[rep]);
+      }
+    } else {
+      if (16 * kt + 15 < arow0) {            // every k of the block left of every row: V[m, k] = vec[m (m + 1) / 2 + k]
+        const double* __restrict__ Ak = Aj + 16 * kt;
+#pragma unroll
+        for (int rep = 0; rep < TS_BT; ++rep) ra[rep] = Ak[triM[rep]];
+      } else if (16 * kt >= arow0 + 16 * TS_BT) {   // right of every row: vec[k (k + 1) / 2 + m]
+        const int kk = min(16 * kt + lk, sm1);
+        const unsigned tk = (unsigned)(kk * (kk + 1) / 2);
+#pragma unroll
+        for (int rep = 0; rep < TS_BT; ++rep) ra[rep] = Aj[tk + (unsigned)mrow[rep]];
+      } else {
+        const int kk = min(16 * kt + lk, sm1);
+#pragma unroll
+        for (int rep = 0; rep < TS_BT; ++rep) {
+          const int lo = min(mrow[rep], kk), hi = max(mrow[rep], kk);
+          ra[rep] = Aj[(unsigned)(hi * (hi + 1) / 2 + lo)];
+        }
+      }
+    }
+  };
+  auto store_tiles = [&](double (&L)[2][TS_OPSZ], int kt) {
+#pragma unroll
+    for (int rep = 0; rep < NREP2; ++rep) {
+      if (rep == NREP2 - 1 && !vhalf) break;
+      *reinterpret_cast<d2_t*>(&L[1][ldsV[rep]]) = rbv[rep];
+      if (PASS == 2) *reinterpret_cast<d2_t*>(&L[0][ldsV[rep]]) = rzv[rep];
+    }
+    if (PASS == 1) {
+      const bool diag_blk = !(16 * kt + 15 < arow0) && !(16 * kt >= arow0 + 16 * TS_BT);
+      const bool k_edge = (16 * kt + 16 > s);
+      const int kp = 16 * kt + lk;
+#pragma unroll
+      for (int rep = 0; rep < TS_BT; ++rep) {
+        double va = div_rt2(ra[rep]);   // off-diagonals: vec[k] / rt2 (arrayutilities.jl:231)
+        if (diag_blk) va = (arow0 + lr + 16 * rep == kp) ? ra[rep] : va;
+        if (rows_edge || k_edge) va = (arow0 + lr + 16 * rep < s && kp < s) ? va : 0.0;
+        L[0][(lr + 16 * rep) * TS_LDK + lk] = va;
+      }
+    }
+  };
+
+  const int fr = lane & 15, fk = lane >> 4;
+  unsigned tmask = 0;   // bit c: this wavefront's tile (wave, c) exists
+#pragma unroll
+  for (int c = 0; c < TS_BT; ++c) {
+    bool ok = (wave < TR) && (c < TC);
+    if (PASS == 2) ok = ok && (mt0 + wave <= ct0 + c);
+    tmask |= (ok ? 1u : 0u) << c;
+  }
+  tmask = __builtin_amdgcn_readfirstlane(tmask);
+
+  auto compute = [&](int kt, const double (&L)[2][TS_OPSZ]) {
+    unsigned need = tmask;
+    if (p.rstruct == 1) {
+      const int cmin = max(0, kt - ct0);
+      need = (cmin >= TS_BT) ? 0u : (need & (~0u << cmin));
+    } else if (p.rstruct == 2) {
+      const int cmax = kt - ct0;
+      need = (cmax < 0) ? 0u : ((cmax >= TS_BT - 1) ? need : (need & ((1u << (cmax + 1)) - 1u)));
+    }
+    if (need == 0u) return;
+    const double* as = L[0] + (wave * 16 + fr) * TS_LDK + fk;
+    const double* bs = L[1] + fr * TS_LDK + fk;
+    double af[4], bf[TS_BT][4];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) af[q4] = as[4 * q4];
+#pragma unroll
+    for (int c = 0; c < TS_BT; ++c)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) bf[c][q4] = bs[c * 16 * TS_LDK + 4 * q4];
+    // (tile by tile, the four k-chunks of a tile back to back on its accumulator: with the k-chunks outside -- consecutive MFMAs on
+    //  different accumulators -- pass 1 took 1.94 instead of 1.69 ms at 48 x 48 and spilled at 64 x 64)
+#pragma unroll
+    for (int c = 0; c < TS_BT; ++c) {
+      if (!((need >> c) & 1u)) continue;
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[c][q4], af[q4], acc[c], 0, 0, 0);
+    }
+  };
+
+  if (kt_hi > kt_lo) {
+    load_tiles(kt_lo);
+    store_tiles(lds[0], kt_lo);
+    if (kt_lo + 1 < kt_hi) load_tiles(kt_lo + 1);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int kt = kt_lo; kt < kt_hi; kt += 2) {
+      if (kt + 1 < kt_hi) store_tiles(lds[1], kt + 1);
+      if (kt + 2 < kt_hi) load_tiles(kt + 2);
+      compute(kt, lds[0]);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (kt + 1 >= kt_hi) break;
+      if (kt + 2 < kt_hi) store_tiles(lds[0], kt + 2);
+      if (kt + 3 < kt_hi) load_tiles(kt + 3);
+      compute(kt + 1, lds[1]);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  }
+
+  if (wave >= TR) return;
+  const int m = 16 * (mt0 + wave) + fr;
+#pragma unroll
+  for (int c = 0; c < TS_BT; ++c) {
+    if (c >= TC) continue;
+    if (PASS == 2 && mt0 + wave > ct0 + c) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int col = 16 * (ct0 + c) + fk + 4 * r;
+      if (PASS == 1) {
+        p.C[j * LD2 + (long)col * LD + m] = acc[c][r];   // (rows / columns beyond s: exact zeros, the padding pass 2 relies on)
+      } else {
+        if (m <= col && col < s) {
+          const double v = acc[c][r];
+          p.C[j * p.ldc + (long)col * (col + 1) / 2 + m] = (m == col) ? v : v * 1.4142135623730951;   // mat[i, j] * rt2 (arrayutilities.jl:176)
+        }
+      }
+    }
+  }
+}
+
+// =============================================================================================
 // Small sides (<= 96, i.e. T <= 6 tiles: config 4's side 80): the whole two-sided product of a matrix stays on one CU.
 // One workgroup of T wavefronts per matrix; R (shared by every column of the cone) is staged in LDS once per workgroup, which
 // then walks a contiguous range of columns: V_j gathered from the svec column into LDS (both triangles), wavefront w computes
@@ -479,6 +690,31 @@ void psd_two_sided_fused(Ctx& c, int side, int ncols, const double* R, int rstru
   // one wavefront per SIMD walking 16 dependent MFMAs per K block) are cut into 32 x 32 workgroup tiles instead
   static const int few = [] { const char* e = getenv("HYP_TS_FEW"); return e ? atoi(e) : 8; }();
   const bool small_grid = ncols <= few;
+  static const bool ts3_on = [] { const char* e = getenv("HYP_TS3"); return !(e && e[0] == '0'); }();
+  if (ts3_on && (long)a.T * 16 * a.T * 16 * 2 < (1L << 31)) {   // (32-bit element offsets inside a matrix)
+    const int LD = 16 * a.T;
+    const long LD2 = (long)LD * LD;
+    c.ts_ws.ensure(((size_t)ncols + 1) * LD2 * sizeof(double));
+    double* Rp = c.ts_ws.d();
+    double* Z = Rp + LD2;
+    hipLaunchKernelGGL(ts_pad_r_kernel, dim3((unsigned)((LD2 + 255) / 256)), dim3(256), 0, c.stream, side, LD, R, Rp);
+    a.R = Rp;
+    const int b1 = small_grid ? 2 : bt1, b2 = small_grid ? 2 : bt2;
+    a.A = arr; a.lda = lda; a.C = Z; a.ldc = 0;
+    a.nb = (a.T + b1 - 1) / b1;
+    unsigned grid = (unsigned)(((ncols + 7) / 8) * a.nb * a.nb * 8);
+    if (b1 == 2) hipLaunchKernelGGL((psd_ts3_kernel<1, 2>), dim3(grid), dim3(TS_THREADS), 0, c.stream, a);
+    else if (b1 == 3) hipLaunchKernelGGL((psd_ts3_kernel<1, 3>), dim3(grid), dim3(TS_THREADS), 0, c.stream, a);
+    else hipLaunchKernelGGL((psd_ts3_kernel<1, 4>), dim3(grid), dim3(TS_THREADS), 0, c.stream, a);
+    a.A = Z; a.lda = 0; a.C = prod; a.ldc = ldp;
+    a.nb = (a.T + b2 - 1) / b2;
+    grid = (unsigned)(((ncols + 7) / 8) * a.nb * a.nb * 8);
+    if (b2 == 2) hipLaunchKernelGGL((psd_ts3_kernel<2, 2>), dim3(grid), dim3(TS_THREADS), 0, c.stream, a);
+    else if (b2 == 3) hipLaunchKernelGGL((psd_ts3_kernel<2, 3>), dim3(grid), dim3(TS_THREADS), 0, c.stream, a);
+    else hipLaunchKernelGGL((psd_ts3_kernel<2, 4>), dim3(grid), dim3(TS_THREADS), 0, c.stream, a);
+    HYP_CHECK(hipGetLastError());
+    return;
+  }
   a.A = arr; a.lda = lda; a.C = zws; a.ldc = 0;
   ts_launch<1>(c, a, small_grid ? 2 : bt1);
   a.A = zws; a.lda = 0; a.C = prod; a.ldc = ldp;
