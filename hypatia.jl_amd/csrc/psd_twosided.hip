@@ -276,6 +276,12 @@ __global__ __launch_bounds__(TS_THREADS, (TS_BT <= 4 ? 4 : (TS_BT <= 5 ? 3 : 2))
 //     constant + 16 kt), right of it (k (k + 1) / 2 once per block, one add per element) and the diagonal-crossing ones (the
 //     general formula); row / k masks only in edge blocks;
 //   * the K loop is unrolled by two so that LDS addresses are immediates.
+// Measured at side 200, 5000 columns: 2.75 -> 2.59 ms for the two passes (pass 1 1.69 -> 1.53, pass 2 unchanged at 1.05: its
+// loop was already light).  Tried on top and not kept: a PERSISTENT form (4 workgroups per CU walking a list of (matrix, block)
+// items as one flattened sequence of K blocks, the next item's first operands requested during the current item's last MFMAs):
+// 2.88 ms with the items dealt round robin with a prime stride (3.63 with stride 128, where a workgroup meets the same block of
+// every matrix); rotating the wavefront-to-tile-row assignment between workgroups (a block of three tile rows idles one
+// wavefront): +-0; two matrices per workgroup sharing the R operand (25 % fewer operand bytes, half the occupancy): 2.79 vs 2.75.
 // =============================================================================================
 __global__ void ts_pad_r_kernel(int s, int LD, const double* __restrict__ R, double* __restrict__ Rp) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
