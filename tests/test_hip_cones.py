@@ -89,6 +89,34 @@ def test_oracle_vs_hip(kind, dim):
     assert abs(ph - po) <= 1e-9 * max(1.0, abs(po))
 
 
+@pytest.mark.parametrize("side,ncols", [(97, 1), (97, 70), (113, 9), (129, 70), (143, 33), (200, 9), (207, 12), (209, 3)])
+def test_psd_two_sided_products_sides_beyond_96(side, ncols):
+    """the two-pass form of the PSD products (psd_ts3_kernel: zero-padded factor and intermediate) at odd and even sides, with the
+    column counts that select its 32 x 32 (<= 8 columns) and 64 x 64 / 48 x 48 workgroup tiles, through all four products
+    (possemideftri.jl:126-195: upper and lower triangular factors) and with strided column views"""
+    dim = side * (side + 1) // 2
+    hc, oc = _pair("psd", dim)
+    rng = np.random.default_rng(side + ncols)
+    for c in (hc, oc):
+        c.setup_data()
+    pt = np.zeros(dim)
+    oc.set_initial_point(pt)
+    pt += 0.1 * (2 * rng.random(dim) - 1) / np.sqrt(max(1, dim / 50))
+    for c in (hc, oc):
+        c.reset_data()
+        c.load_point(pt, 1.3)
+        assert c.is_feas()
+        c.get_grad()
+    big_in = np.asfortranarray(rng.standard_normal((dim + 3, ncols)))
+    for name in ("hess_prod", "inv_hess_prod", "sqrt_hess_prod", "inv_sqrt_hess_prod"):
+        out_h = np.full((dim + 2, ncols), 7.0, order="F")
+        out_o = np.full((dim + 2, ncols), 7.0, order="F")
+        getattr(hc, name)(out_h[1:1 + dim, :], big_in[2:2 + dim, :])
+        getattr(oc, name)(out_o[1:1 + dim, :], big_in[2:2 + dim, :])
+        assert rel(out_h, out_o) < TOL * 10, name
+        assert np.all(out_h[0] == 7.0) and np.all(out_h[1 + dim:] == 7.0)
+
+
 def test_infeasible_points_detected():
     import hypatia_jl_amd as H
     c = H.PosSemidefTri(6)
