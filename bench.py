@@ -23,8 +23,8 @@ Workloads (--config; default "2" at N = 1, "4" at N > 1):
       n x n) per iteration inside the library, replicated factorization.  value = IPM iterations/s.  The
       same line carries "same_workload_1gpu" (the committed single-GPU figure of THIS instance: the driver's
       own N = 1 run is the headline config 2) and "headline_config2_kshard" (config 2 on the same ranks).
-  2w  the round-1 multi-GPU workload (one PosSemidefTri(200) block per rank, "weak" scaling), kept for
-      comparison.
+  2w  one PosSemidefTri(200) block of the headline configuration per rank ("weak" scaling; at N = 1 this IS config 2);
+      value = blocks x iterations/s.  The N > 1 line of config 4 carries it as "weak_config2_block_per_gpu".
   3b | 5p | 5d  the other configurations (matrix completion / polymin primal / polymin dual) on one GPU: same schema,
       a step = one IPM iteration of the full solve.
 """
@@ -177,6 +177,32 @@ def main_multi(args, world, rank, local_rank):
     import hypatia_jl_amd as H
     from hypatia_jl_amd import distributed as D
     comm = D.Comm(device="cuda")
+
+    def one(args):
+        """one cone-sharded workload on the ranks of this job: returns the record (rank 0) or None"""
+        return _run_cone_sharded(args, world, rank, comm, H, D, torch)
+
+    out = one(args)
+    strong = (args.config == "4")
+    if strong and not args.no_secondary:
+        # weak-scaling record of the same job: one PosSemidefTri(200) block of the headline configuration per rank (at N = 1 this
+        # IS config 2, the workload of the driver's N = 1 line), value = blocks x iterations/s
+        import copy
+        aw = copy.copy(args)
+        aw.config, aw.steps, aw.warmup, aw.cpu_iters = "2w", 40, 3, 0
+        try:
+            w = one(aw)
+            if rank == 0:
+                out["weak_config2_block_per_gpu"] = {k: w[k] for k in ("metric", "value", "unit", "ms_per_step", "iterations_per_s", "steps", "scaling",
+                                                                       "config", "phases_ms_per_step", "collectives_per_step")}
+        except Exception as e:
+            if rank == 0:
+                out["weak_config2_block_per_gpu"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return _finish_multi(args, world, rank, local_rank, comm, out, strong, dist)
+
+
+def _run_cone_sharded(args, world, rank, comm, H, D, torch):
+    lib_mod = H._lib
     n = args.n
     strong = (args.config == "4")
     side = 80 if strong else args.side
@@ -291,11 +317,21 @@ def main_multi(args, world, rank, local_rank):
                 print("collectives %-40s %8d doubles op %-5s : %.1f per step" % (key[0], key[1], key[2], cnt / max(args.steps, 1)), file=sys.stderr)
     else:
         out = None
+    try:   # (the library's communicator of this solver goes before the next workload brings up its own)
+        solver.syssolver.close()
+    except Exception:
+        pass
+    solver = model = cones = G_r = None
+    import gc
+    gc.collect()
+    return out
+
+
+def _finish_multi(args, world, rank, local_rank, comm, out, strong, dist):
     if strong and not args.no_secondary:
         # secondary record of the same job: the HEADLINE workload (config 2, the one the N = 1 bench line is quoted on) on the
         # same ranks -- one cone, model replicated, K-panel shard of the Schur product
         import copy
-        solver = model = cones = G_r = None
         a2 = copy.copy(args)
         a2.config, a2.steps, a2.warmup, a2.cpu_iters = "2", args.secondary_steps, 3, 0
         try:
