@@ -301,14 +301,23 @@ __global__ __launch_bounds__(TS_THREADS, 4) void psd_ts3_kernel(TsArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int s = p.s, T = p.T, LD = 16 * T;
   const long LD2 = (long)LD * LD;
-  const int nbb = p.nb * p.nb;
+  // (pass 2 launches the blocks on or above the diagonal only: column by column, (0,0) (0,1) (1,1) (0,2) ...)
+  const int nbb = (PASS == 1) ? p.nb * p.nb : p.nb * (p.nb + 1) / 2;
   const int g = blockIdx.x >> 3, xcd = blockIdx.x & 7;
   const long j = (long)(g / nbb) * 8 + xcd;
   if (j >= p.ncols) return;
-  const int sub = g % nbb;
+  int sub = g % nbb;
+  int rb, cb;
+  if (PASS == 1) {
+    rb = sub % p.nb; cb = sub / p.nb;
+  } else {
+    cb = 0;
+    while (sub > cb) { sub -= cb + 1; ++cb; }
+    rb = sub;
+  }
   int mt0, TR, ct0, TC;
-  ts_block_range(T, p.nb, sub % p.nb, mt0, TR);
-  ts_block_range(T, p.nb, sub / p.nb, ct0, TC);
+  ts_block_range(T, p.nb, rb, mt0, TR);
+  ts_block_range(T, p.nb, cb, ct0, TC);
   if (PASS == 2 && mt0 > ct0 + TC - 1) return;
   const double* __restrict__ Aj = (PASS == 1) ? p.A + j * p.lda : p.A + j * LD2;
   int kt_lo = 0, kt_hi = T;
@@ -714,7 +723,7 @@ void psd_two_sided_fused(Ctx& c, int side, int ncols, const double* R, int rstru
     else hipLaunchKernelGGL((psd_ts3_kernel<1, 4>), dim3(grid), dim3(TS_THREADS), 0, c.stream, a);
     a.A = Z; a.lda = 0; a.C = prod; a.ldc = ldp;
     a.nb = (a.T + b2 - 1) / b2;
-    grid = (unsigned)(((ncols + 7) / 8) * a.nb * a.nb * 8);
+    grid = (unsigned)(((ncols + 7) / 8) * (a.nb * (a.nb + 1) / 2) * 8);
     if (b2 == 2) hipLaunchKernelGGL((psd_ts3_kernel<2, 2>), dim3(grid), dim3(TS_THREADS), 0, c.stream, a);
     else if (b2 == 3) hipLaunchKernelGGL((psd_ts3_kernel<2, 3>), dim3(grid), dim3(TS_THREADS), 0, c.stream, a);
     else hipLaunchKernelGGL((psd_ts3_kernel<2, 4>), dim3(grid), dim3(TS_THREADS), 0, c.stream, a);
