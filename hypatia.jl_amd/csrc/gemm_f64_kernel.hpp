@@ -332,6 +332,76 @@ static const int* upper_tile_map(GemmScratch& gs, int T, long nblk) {
   return gs.tile_map;
 }
 
+// The thin last tile column of the Schur syrk (n = 5000 = 39 x 128 + 8): C[i, N0 + e] = alpha * <A[:, i], A[:, N0 + e]> + beta * C for
+// the r <= 32 edge columns and every row i <= N0 + e.  As a GEMM with 64-wide tiles it took 0.31 ms at K = 20100 (MFMA tiles that
+// are mostly padding behind a loader shaped for square tiles: 2.6 TB/s); it is n dot products per edge column over ONE pass
+// through A, i.e. a multi-right-hand-side A'x with the edge columns as the x's: CB columns of A per workgroup, the R edge
+// columns re-read from L2, 16-byte loads, fixed per-thread row assignment and reduction tree (bitwise reproducible).
+template <int CB, int R>
+__global__ __launch_bounds__(256) void syrk_edge_kernel(int K, int N, int N0, int e0, int r, const double* __restrict__ A, long lda, double alpha,
+                                                        double beta, double* __restrict__ C, long ldc) {
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  __shared__ double red[CB][R][4];
+  const int i0 = blockIdx.x * CB;
+  const double* a[CB];
+  const double* x[R];
+#pragma unroll
+  for (int c = 0; c < CB; ++c) a[c] = A + (long)min(i0 + c, N - 1) * lda;
+#pragma unroll
+  for (int e = 0; e < R; ++e) x[e] = A + (long)min(N0 + e0 + e, N - 1) * lda;
+  double s[CB][R][2];
+#pragma unroll
+  for (int c = 0; c < CB; ++c)
+#pragma unroll
+    for (int e = 0; e < R; ++e) s[c][e][0] = s[c][e][1] = 0.0;
+  const int nfull = K / 512;
+  for (int b = 0; b < nfull; ++b) {
+    const int k = 512 * b + 2 * threadIdx.x;
+    d2_t av[CB], xv[R];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) av[c] = *reinterpret_cast<const d2_t*>(a[c] + k);
+#pragma unroll
+    for (int e = 0; e < R; ++e) xv[e] = *reinterpret_cast<const d2_t*>(x[e] + k);
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+#pragma unroll
+      for (int e = 0; e < R; ++e) {
+        s[c][e][0] = fma(av[c].x, xv[e].x, s[c][e][0]);
+        s[c][e][1] = fma(av[c].y, xv[e].y, s[c][e][1]);
+      }
+  }
+  for (int k = 512 * nfull + threadIdx.x; k < K; k += 256) {   // element-wise tail
+    double xs[R];
+#pragma unroll
+    for (int e = 0; e < R; ++e) xs[e] = x[e][k];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+      const double a0 = a[c][k];
+#pragma unroll
+      for (int e = 0; e < R; ++e) s[c][e][0] = fma(a0, xs[e], s[c][e][0]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CB; ++c)
+#pragma unroll
+    for (int e = 0; e < R; ++e) {
+      double t = s[c][e][0] + s[c][e][1];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+      if ((threadIdx.x & 63) == 0) red[c][e][threadIdx.x >> 6] = t;
+    }
+  __syncthreads();
+  if (threadIdx.x < CB * R) {
+    const int c = threadIdx.x / R, e = threadIdx.x % R;
+    const int i = i0 + c, col = N0 + e0 + e;
+    if (i < N && e0 + e < r && i <= col) {
+      const double t = (red[c][e][0] + red[c][e][1]) + (red[c][e][2] + red[c][e][3]);
+      double* dst = C + (long)col * ldc + i;
+      *dst = alpha * t + (beta != 0.0 ? beta * (*dst) : 0.0);
+    }
+  }
+}
+
 hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch* gs) {
   if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return hipSuccess;
   // Schur syrk with a thin last tile column (n = 5000 = 39 x 128 + 8): the 128-wide edge workgroup tiles
@@ -350,6 +420,12 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch*
     s.C = a.C + (long)N0 * a.ldc;
     s.tri = GEMM_UPPER_RECT; s.tri_off = N0;
     s.tile_hint = 64; s.splitk_req = 8;
+    static const bool edge_on = [] { const char* e = getenv("HYP_SYRK_EDGE"); return !(e && atoi(e) == 0); }();
+    if (edge_on && ((uintptr_t)a.A % 16 == 0) && (a.lda % 2 == 0)) {
+      for (int e0 = 0; e0 < r; e0 += 8)
+        hipLaunchKernelGGL((syrk_edge_kernel<4, 8>), dim3((a.N + 3) / 4), dim3(256), 0, st, a.K, a.N, N0, e0, r, a.A, a.lda, a.alpha, a.beta, a.C, a.ldc);
+      return hipGetLastError();
+    }
     return gemm_f64_launch(st, transa, s, gs);
   }
   // tile choice: the 128 x 128 tile unless the product is too small to fill the chip with it
