@@ -553,6 +553,17 @@ function mul_G!(y::Vector{Float64}, sys::HIPQRCholDenseSystemSolver, trans::Bool
     return y
 end
 
+# G' z, G x + s, h' z and z' s of one point from ONE pass over the device-resident G: what calc_convergence_params
+# (Solvers.jl:432, 450, 468-472) forms with two products; on a cone-sharded solver z and s are the rank's rows and the x-space
+# results are summed over the ranks
+function residual_products!(Gtz::Vector{Float64}, Gx_s::Vector{Float64}, dots::Vector{Float64}, sys::HIPQRCholDenseSystemSolver,
+        x::Vector{Float64}, z::Vector{Float64}, s::Vector{Float64})
+    check(ccall((:hyp_sys_residual_products, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        sys.handle, x, z, s, Gtz, Gx_s, dots), "hyp_sys_residual_products")
+    return (Gtz, Gx_s, dots)
+end
+
 # =============================================================================================
 # preprocessing: column-pivoted QR of [A; G] on the device (find_initial_x, src/Solvers/process.jl:64-178)
 # =============================================================================================
