@@ -349,11 +349,15 @@ __global__ __launch_bounds__(256) void syrk_edge_kernel(int K, int N, int N0, in
   for (int c = 0; c < CB; ++c) a[c] = A + (long)min(i0 + c, N - 1) * lda;
 #pragma unroll
   for (int e = 0; e < R; ++e) x[e] = A + (long)min(N0 + e0 + e, N - 1) * lda;
-  double s[CB][R][2];
+  // (NS = 2: even and odd rows of a pair in separate sums; CB = 8 has room for one sum per dot product only)
+  constexpr int NS = (CB * R <= 32) ? 2 : 1;
+  double s[CB][R][NS];
 #pragma unroll
   for (int c = 0; c < CB; ++c)
 #pragma unroll
-    for (int e = 0; e < R; ++e) s[c][e][0] = s[c][e][1] = 0.0;
+    for (int e = 0; e < R; ++e)
+#pragma unroll
+      for (int h = 0; h < NS; ++h) s[c][e][h] = 0.0;
   const int nfull = K / 512;
   for (int b = 0; b < nfull; ++b) {
     const int k = 512 * b + 2 * threadIdx.x;
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(256) void syrk_edge_kernel(int K, int N, int N0, in
 #pragma unroll
       for (int e = 0; e < R; ++e) {
         s[c][e][0] = fma(av[c].x, xv[e].x, s[c][e][0]);
-        s[c][e][1] = fma(av[c].y, xv[e].y, s[c][e][1]);
+        s[c][e][NS - 1] = fma(av[c].y, xv[e].y, s[c][e][NS - 1]);
       }
   }
   for (int k = 512 * nfull + threadIdx.x; k < K; k += 256) {   // element-wise tail
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(256) void syrk_edge_kernel(int K, int N, int N0, in
   for (int c = 0; c < CB; ++c)
 #pragma unroll
     for (int e = 0; e < R; ++e) {
-      double t = s[c][e][0] + s[c][e][1];
+      double t = (NS == 2) ? s[c][e][0] + s[c][e][NS - 1] : s[c][e][0];
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
       if ((threadIdx.x & 63) == 0) red[c][e][threadIdx.x >> 6] = t;
@@ -422,8 +426,13 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch*
     s.tile_hint = 64; s.splitk_req = 8;
     static const bool edge_on = [] { const char* e = getenv("HYP_SYRK_EDGE"); return !(e && atoi(e) == 0); }();
     if (edge_on && ((uintptr_t)a.A % 16 == 0) && (a.lda % 2 == 0)) {
-      for (int e0 = 0; e0 < r; e0 += 8)
-        hipLaunchKernelGGL((syrk_edge_kernel<4, 8>), dim3((a.N + 3) / 4), dim3(256), 0, st, a.K, a.N, N0, e0, r, a.A, a.lda, a.alpha, a.beta, a.C, a.ldc);
+      // columns of A per workgroup: every workgroup re-reads the edge columns from L2 (R K doubles), so long K wants more of them
+      static const int cb_env = [] { const char* e = getenv("HYP_SYRK_EDGE_CB"); return e ? atoi(e) : 0; }();
+      const int cb = cb_env ? cb_env : (a.K >= 65536 ? 8 : 4);
+      for (int e0 = 0; e0 < r; e0 += 8) {
+        if (cb == 8) hipLaunchKernelGGL((syrk_edge_kernel<8, 8>), dim3((a.N + 7) / 8), dim3(256), 0, st, a.K, a.N, N0, e0, r, a.A, a.lda, a.alpha, a.beta, a.C, a.ldc);
+        else hipLaunchKernelGGL((syrk_edge_kernel<4, 8>), dim3((a.N + 3) / 4), dim3(256), 0, st, a.K, a.N, N0, e0, r, a.A, a.lda, a.alpha, a.beta, a.C, a.ldc);
+      }
       return hipGetLastError();
     }
     return gemm_f64_launch(st, transa, s, gs);

@@ -241,6 +241,31 @@ def test_gemv_both_products_in_one_pass(hip, m, n, nr, lda, fused):
     assert np.array_equal(Yn, Yn2) and np.array_equal(Yt, Yt2)
 
 
+@pytest.mark.parametrize("N,K", [(1032, 70001), (1044, 66000)])
+def test_syrk_thin_last_tile_column_long_k(hip, N, K):
+    """the edge columns of the Schur syrk (n = 39 x 128 + 8 at config 2) at a K where the edge kernel takes eight columns of A per
+    workgroup (config 4: K = 207 360), odd K (element-wise tail) and an edge of 20 columns (three passes): against numpy on the
+    edge columns, the rest of the upper triangle spot-checked, the lower triangle untouched"""
+    lib, ctx, L = hip
+    rng = np.random.default_rng(N + K)
+    A = np.asfortranarray(rng.standard_normal((K, N), dtype=np.float32).astype(np.float64))
+    C = np.full((N, N), 3.0, order="F")
+    L.check(lib.hyp_dense_syrk(ctx, N, K, fp(A), K, fp(C), N), "syrk")
+    N0 = N - N % 128
+    ref_edge = A.T @ A[:, N0:]
+    for e in range(N - N0):
+        col = N0 + e
+        assert np.allclose(C[:col + 1, col], ref_edge[:col + 1, e], rtol=1e-12, atol=1e-9), e
+        assert np.all(C[col + 1:, col] == 3.0)
+    cols = [0, 1, 127, 128, 500, N0 - 1]
+    ref = A.T @ A[:, cols]
+    for t, col in enumerate(cols):
+        assert np.allclose(C[:col + 1, col], ref[:col + 1, t], rtol=1e-12, atol=1e-9)
+    C2 = np.full((N, N), 3.0, order="F")
+    L.check(lib.hyp_dense_syrk(ctx, N, K, fp(A), K, fp(C2), N), "syrk")
+    assert np.array_equal(C, C2)
+
+
 @pytest.mark.parametrize("N,K", [(300, 5000), (130, 4100), (257, 900), (1032, 4500), (1300, 4100)])
 def test_syrk_schur_path_with_splitk(hip, N, K):
     """the Schur-assembly syrk (split-K slices + ordered reduction when K is long)"""

@@ -1,4 +1,6 @@
 export TMPDIR=/tmp
-for v in 1 0; do
-HYP_POTRF_HOSTTIME=1 HYP_PLAN_OVERLAP=$v timeout 300 python bench.py --steps 6 --warmup 2 --cpu-iters 0 > /dev/null 2> gpurun_out/err_$v.txt; grep -c "" gpurun_out/err_$v.txt; grep "potrf host" gpurun_out/err_$v.txt | tail -3
+python -m pytest tests/test_hip_dense.py -m gpu -q -x -k "syrk" 2>&1 | tail -3
+for cb in 8 4; do
+rm -rf /tmp/p4; HYP_SYRK_EDGE_CB=$cb rocprofv3 --kernel-trace -d /tmp/p4 -o b -- python bench.py --config 4 --steps 4 --warmup 1 --cpu-iters 0 > /dev/null 2>&1
+echo cb $cb; python tools/rocpd_stats.py $(find /tmp/p4 -name "*.db" | head -1) 2>/dev/null | grep "gemm_f64_kernel<true, 4, 1>\|syrk_edge\|splitk" | cut -c1-160
 done
