@@ -426,9 +426,10 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch*
     s.tile_hint = 64; s.splitk_req = 8;
     static const bool edge_on = [] { const char* e = getenv("HYP_SYRK_EDGE"); return !(e && atoi(e) == 0); }();
     if (edge_on && ((uintptr_t)a.A % 16 == 0) && (a.lda % 2 == 0)) {
-      // columns of A per workgroup: every workgroup re-reads the edge columns from L2 (R K doubles), so long K wants more of them
-      static const int cb_env = [] { const char* e = getenv("HYP_SYRK_EDGE_CB"); return e ? atoi(e) : 0; }();
-      const int cb = cb_env ? cb_env : (a.K >= 65536 ? 8 : 4);
+      // columns of A per workgroup: every workgroup re-reads the edge columns from L2 (R K doubles); eight measured better than
+      // four at K = 207 360 (config 4: 1.66 vs 2.19 ms per launch) and at K = 20 100 (config 2: syrk phase 8.30 vs 8.36 ms)
+      static const int cb_env = [] { const char* e = getenv("HYP_SYRK_EDGE_CB"); return e ? atoi(e) : 8; }();
+      const int cb = cb_env;
       for (int e0 = 0; e0 < r; e0 += 8) {
         if (cb == 8) hipLaunchKernelGGL((syrk_edge_kernel<8, 8>), dim3((a.N + 7) / 8), dim3(256), 0, st, a.K, a.N, N0, e0, r, a.A, a.lda, a.alpha, a.beta, a.C, a.ldc);
         else hipLaunchKernelGGL((syrk_edge_kernel<4, 8>), dim3((a.N + 3) / 4), dim3(256), 0, st, a.K, a.N, N0, e0, r, a.A, a.lda, a.alpha, a.beta, a.C, a.ldc);
