@@ -377,6 +377,16 @@ void gemv_both(Ctx& c, int m, int n, int nr, const double* A, long lda, const do
   else gemv_both_t<2>(c, m, n, A, lda, Xn, ldxn, beta_n, Yn, ldyn, Xt, ldxt, beta_t, Yt, ldyt);
 }
 
+// one right-hand side through the four-columns-per-workgroup kernel (called by gemv() for long columns); false: operands not aligned
+bool gemv_t_cb1(Ctx& c, int m, int n, double alpha, const double* A, long lda, const double* x, double beta, double* y) {
+  static const bool on = [] { const char* e = getenv("HYP_GEMVT_CB1"); return !(e && e[0] == '0'); }();
+  const bool wide = ((((uintptr_t)A | (uintptr_t)x) & 15) == 0) && (lda % 2 == 0);
+  if (!on || !wide) return false;
+  hipLaunchKernelGGL((gemv_t_multi_cb_kernel<1, 4>), dim3((n + 3) / 4), dim3(256), 0, c.stream, m, n, alpha, A, lda, x, (long)m, beta, y, (long)n);
+  HYP_CHECK(hipGetLastError());
+  return true;
+}
+
 // nr = 1, 2 or 3 right-hand sides per pass over A (3: the constant column of update_lhs rides along with the first pair of
 // directions); every column's sums are those of the same column in a pass of its own width class (fixed per-thread row
 // assignment and reduction tree)
