@@ -605,6 +605,27 @@ void SysSolver::get_directions2(double* h_dirs, const double* h_rhss, double mu,
   }
 }
 
+// out[:, r] = k0_r x0[:, r] (*) k1_r x1[:, r] (*) k2_r x2[:, r] for r < nr columns in ONE launch, with exactly the roundings of the
+// dev_scale_copy / dev_axpby sequence it replaces (a product, then one fused multiply-add per further term; x1 / x2 may be null);
+// a leading dimension of 0 = the same vector for every column.  The paired solve issued 9 of those small launches per column.
+struct LinK { double k0[3], k1[3], k2[3]; };
+__global__ void lincomb_cols_kernel(int n, const double* __restrict__ x0, long ld0, const double* __restrict__ x1, long ld1,
+                                    const double* __restrict__ x2, long ld2, double* __restrict__ out, long ldo, LinK k) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (i >= n) return;
+  double v = __dmul_rn(k.k0[r], x0[(long)r * ld0 + i]);
+  if (x1) v = __fma_rn(k.k1[r], x1[(long)r * ld1 + i], v);
+  if (x2) v = __fma_rn(k.k2[r], x2[(long)r * ld2 + i], v);
+  out[(long)r * ldo + i] = v;
+}
+static void lincomb_cols(Ctx& c, int n, int nr, const double* x0, long ld0, const double* x1, long ld1, const double* x2, long ld2, double* out,
+                         long ldo, const LinK& k) {
+  if (n <= 0 || nr <= 0) return;
+  hipLaunchKernelGGL(lincomb_cols_kernel, dim3((n + 255) / 256, nr), dim3(256), 0, c.stream, n, x0, ld0, x1, ld1, x2, ld2, out, ldo, k);
+  HYP_CHECK(hipGetLastError());
+}
+
 // two right-hand sides already on the device (rhs2 = two Point vectors, tau / kap slots zero, scalars in rs):
 // directions are left in m_dir, their tau / kap in dsc
 // with_const: the constant column of update_lhs (qrchol.jl:191-197: rhs_const = (-c, H h), solved once per iteration) rides
@@ -680,14 +701,16 @@ void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double
     ctx.d2d(sol_const.p, ss + (long)MR * ld3, (size_t)ld3 * d);
     dot_const = ctx.h_pinned[2 * MR] + ctx.h_pinned[2 * MR + 1];
   }
-  for (int r = 0; r < MR; ++r) {
-    const double dot_sub = ctx.h_pinned[2 * r] + ctx.h_pinned[2 * r + 1];
-    const double sol_tau = (rs[r].tau + rs[r].kap + dot_sub) / (mu / taubar / taubar - dot_const);
-    double* sol = dir + (long)r * dv;
-    ctx.d2d(sol, ss + r * ld3, (size_t)ld3 * d);
-    dev_axpby(ctx, (int)ld3, sol_tau, sol_const.d(), 1.0, sol);
-    dsc[r].tau = sol_tau;
-    dsc[r].kap = -mu / taubar / taubar * sol_tau + rs[r].kap;
+  {
+    LinK k{};
+    for (int r = 0; r < MR; ++r) {
+      const double dot_sub = ctx.h_pinned[2 * r] + ctx.h_pinned[2 * r + 1];
+      const double sol_tau = (rs[r].tau + rs[r].kap + dot_sub) / (mu / taubar / taubar - dot_const);
+      dsc[r].tau = sol_tau;
+      dsc[r].kap = -mu / taubar / taubar * sol_tau + rs[r].kap;
+      k.k0[r] = 1.0; k.k1[r] = sol_tau;
+    }
+    lincomb_cols(ctx, (int)ld3, MR, ss, ld3, sol_const.d(), 0, nullptr, 0, dir, dv, k);   // sol = sol_sub + sol_tau sol_const
   }
   // sol.s = h tau - rhs.z - G sol.x  (G sol.x from the rounded sol.x, see solve_system; kept for the residual)
   // (with a residual to follow, G' dir.z of apply_lhs rides along in the same pass over G)
@@ -698,23 +721,21 @@ void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double
   } else {
     gemv_multi(ctx, false, q, n, MR, 1.0, G.d(), q, dir, dv, 0.0, m_Gxd.d(), q);
   }
-  for (int r = 0; r < MR; ++r) {
-    double* sol = dir + (long)r * dv;
-    dev_scale_copy(ctx, q, dsc[r].tau, mh.d(), sol + os);
-    dev_axpby(ctx, q, -1.0, rhs + (long)r * dv + oz, 1.0, sol + os);
-    dev_axpby(ctx, q, -1.0, m_Gxd.d() + (long)r * q, 1.0, sol + os);
+  {
+    LinK k{};
+    for (int r = 0; r < MR; ++r) { k.k0[r] = dsc[r].tau; k.k1[r] = -1.0; k.k2[r] = -1.0; }
+    lincomb_cols(ctx, q, MR, mh.d(), 0, rhs + oz, dv, m_Gxd.d(), q, dir + os, dv, k);
   }
   *n_solves += MR;
   for (int r = 0; r < MR; ++r) res_norms[r] = 0.0;
 
   if (max_ref_steps > 0) {
     // ---- residual of both columns (apply_lhs, common.jl:79-121)
-    for (int r = 0; r < MR; ++r) {
-      double* rr = res + (long)r * dv;
-      dev_scale_copy(ctx, n, dsc[r].tau, mc.d(), rr);                                   // res.x = c tau (+ G' z below)
-      dev_scale_copy(ctx, q, dsc[r].tau, mh.d(), rr + oz);                              // res.z = h tau - s - G x
-      dev_axpby(ctx, q, -1.0, dir + (long)r * dv + os, 1.0, rr + oz);
-      dev_axpby(ctx, q, -1.0, m_Gxd.d() + (long)r * q, 1.0, rr + oz);
+    {
+      LinK k{};
+      for (int r = 0; r < MR; ++r) { k.k0[r] = dsc[r].tau; k.k1[r] = -1.0; k.k2[r] = -1.0; }
+      lincomb_cols(ctx, n, MR, mc.d(), 0, nullptr, 0, nullptr, 0, res, dv, k);                       // res.x = c tau (+ G' z below)
+      lincomb_cols(ctx, q, MR, mh.d(), 0, dir + os, dv, m_Gxd.d(), q, res + oz, dv, k);              // res.z = h tau - s - G x
     }
     if (dist() || both) {
       if (!both) {

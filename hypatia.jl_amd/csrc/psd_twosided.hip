@@ -706,7 +706,10 @@ void psd_two_sided_fused(Ctx& c, int side, int ncols, const double* R, int rstru
   static const int few = [] { const char* e = getenv("HYP_TS_FEW"); return e ? atoi(e) : 8; }();
   const bool small_grid = ncols <= few;
   static const bool ts3_on = [] { const char* e = getenv("HYP_TS3"); return !(e && e[0] == '0'); }();
-  if (ts3_on && (long)a.T * 16 * a.T * 16 * 2 < (1L << 31)) {   // (32-bit element offsets inside a matrix)
+  // (products of a few columns keep the round-2 kernel: they are bound by latency, not by vector work, and the copy of R into its
+  //  padded square -- a launch of its own, 36 times per config-2 iteration -- costs them more than the lighter loop returns:
+  //  19.8 us per product against 19.1 + 4.5)
+  if (ts3_on && !small_grid && (long)a.T * 16 * a.T * 16 * 2 < (1L << 31)) {   // (32-bit element offsets inside a matrix)
     const int LD = 16 * a.T;
     const long LD2 = (long)LD * LD;
     c.ts_ws.ensure(((size_t)ncols + 1) * LD2 * sizeof(double));
