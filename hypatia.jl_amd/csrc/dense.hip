@@ -1019,6 +1019,31 @@ void dev_dot(Ctx& c, int n, const double* x, const double* y, double* d_out) {
   hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(1024), 0, c.stream, n, x, y, d_out);
   HYP_CHECK(hipGetLastError());
 }
+// up to 8 independent dot products in ONE launch (one workgroup each; every sum is the sum dot_kernel forms)
+__global__ __launch_bounds__(1024) void dots_kernel(DotSpecs sp) {
+  __shared__ double red[16];
+  const int b = blockIdx.x;
+  const int n = sp.n[b];
+  const double* __restrict__ x = sp.x[b];
+  const double* __restrict__ y = sp.y[b];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) s += x[i] * y[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < 16; ++k) t += red[k];
+    *sp.out[b] = t;
+  }
+}
+void dev_dots(Ctx& c, const DotSpecs& sp) {
+  if (sp.count <= 0) return;
+  HYP_REQUIRE(sp.count <= 8, "dev_dots: at most 8 dot products per launch");
+  hipLaunchKernelGGL(dots_kernel, dim3(sp.count), dim3(1024), 0, c.stream, sp);
+  HYP_CHECK(hipGetLastError());
+}
 
 __global__ void axpby_kernel(int n, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

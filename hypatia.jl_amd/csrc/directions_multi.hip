@@ -684,9 +684,13 @@ void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double
   }
   solve3_multi(ss, sr, ncol);
   double* ds = ctx.dscal.d();
-  for (int r = 0; r < ncol; ++r) {
-    dev_dot(ctx, n, mc.d(), ss + r * ld3, ds + 2 * r);
-    dev_dot(ctx, q, mh.d(), ss + r * ld3 + oz, ds + 2 * r + 1);
+  {
+    DotSpecs sp;
+    for (int r = 0; r < ncol; ++r) {
+      sp.add(n, mc.d(), ss + r * ld3, ds + 2 * r);
+      sp.add(q, mh.d(), ss + r * ld3 + oz, ds + 2 * r + 1);
+    }
+    dev_dots(ctx, sp);
   }
   ctx.d2h(ctx.h_pinned, ds, 2 * (MR + 1) * d);
   ctx.sync();
@@ -759,11 +763,15 @@ void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double
       ck->hess_prod_slow(res + os + o, dv, dir + po, dv, MR);
       for (int r = 0; r < MR; ++r) dev_axpby(ctx, dk, 1.0, dir + (long)r * dv + du, 1.0, res + (long)r * dv + os + o);
     }
-    for (int r = 0; r < MR; ++r) {
-      dev_dot(ctx, n, mc.d(), dir + (long)r * dv, ds + 2 * r);
-      dev_dot(ctx, q, mh.d(), dir + (long)r * dv + oz, ds + 2 * r + 1);
-      dev_sub_absmax(ctx, dv, res + (long)r * dv, rhs + (long)r * dv, ds + 8 + r);
+    {
+      DotSpecs sp;
+      for (int r = 0; r < MR; ++r) {
+        sp.add(n, mc.d(), dir + (long)r * dv, ds + 2 * r);
+        sp.add(q, mh.d(), dir + (long)r * dv + oz, ds + 2 * r + 1);
+      }
+      dev_dots(ctx, sp);
     }
+    for (int r = 0; r < MR; ++r) dev_sub_absmax(ctx, dv, res + (long)r * dv, rhs + (long)r * dv, ds + 8 + r);
     ctx.d2h(ctx.h_pinned, ds, 16 * d);
     ctx.sync();
     if (dist()) {

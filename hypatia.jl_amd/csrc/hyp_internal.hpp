@@ -204,6 +204,15 @@ void gemv(Ctx& c, bool trans, int m, int n, double alpha, const double* A, long 
 
 // level-1 helpers (device scalars are read back through ctx pinned memory by the callers)
 void dev_dot(Ctx& c, int n, const double* x, const double* y, double* d_out);          // *d_out = <x,y>
+struct DotSpecs {   // several dot products as one launch (dev_dots): *out[k] = <x[k], y[k]> over n[k] entries
+  int count = 0;
+  int n[8];
+  const double* x[8];
+  const double* y[8];
+  double* out[8];
+  void add(int n_, const double* x_, const double* y_, double* out_) { n[count] = n_; x[count] = x_; y[count] = y_; out[count] = out_; ++count; }
+};
+void dev_dots(Ctx& c, const DotSpecs& sp);
 void dev_axpby(Ctx& c, int n, double a, const double* x, double b, double* y);          // y = a x + b y
 void dev_scale_copy(Ctx& c, int n, double a, const double* x, double* y);               // y = a x
 void dev_transpose(Ctx& c, int m, int n, const double* A, long lda, double* B, long ldb, int batch, long strideA,

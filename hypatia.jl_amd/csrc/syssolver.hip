@@ -656,9 +656,13 @@ void SysSolver::update_const() {
   block_hess_prod_vec(r + n + p, mh.d());
   solve3(sol_const.d(), r);
   double* ds = ctx.dscal.d();
-  dev_dot(ctx, n, mc.d(), sol_const.d(), ds);
-  dev_dot(ctx, p, mb.d(), sol_const.d() + n, ds + 1);
-  dev_dot(ctx, q, mh.d(), sol_const.d() + n + p, ds + 2);
+  {
+    DotSpecs sp;
+    sp.add(n, mc.d(), sol_const.d(), ds);
+    sp.add(p, mb.d(), sol_const.d() + n, ds + 1);
+    sp.add(q, mh.d(), sol_const.d() + n + p, ds + 2);
+    dev_dots(ctx, sp);
+  }
   ctx.d2h(ctx.h_pinned, ds, 3 * sizeof(double));
   ctx.sync();
   double hz = ctx.h_pinned[2];
