@@ -1038,6 +1038,15 @@ __global__ __launch_bounds__(1024) void dots_kernel(DotSpecs sp) {
     *sp.out[b] = t;
   }
 }
+__global__ void zero_slots_kernel(ZeroSlots z) {
+  if ((int)threadIdx.x < z.count) *z.p[threadIdx.x] = 0.0;
+}
+void dev_zero_slots(Ctx& c, const ZeroSlots& z) {
+  if (z.count <= 0) return;
+  HYP_REQUIRE(z.count <= 16, "dev_zero_slots: at most 16 slots");
+  hipLaunchKernelGGL(zero_slots_kernel, dim3(1), dim3(64), 0, c.stream, z);
+  HYP_CHECK(hipGetLastError());
+}
 void dev_dots(Ctx& c, const DotSpecs& sp) {
   if (sp.count <= 0) return;
   HYP_REQUIRE(sp.count <= 8, "dev_dots: at most 8 dot products per launch");

@@ -646,11 +646,13 @@ void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double
   double* sr = m_subr.d();
   double* ss = m_subs.d();
   Scal rsc[MR];
-  for (int r = 0; r < MR; ++r) {
-    ctx.zero(dir + (long)r * dv + it, d);
-    ctx.zero(dir + (long)r * dv + ik, d);
-    ctx.zero(res + (long)r * dv + it, d);
-    ctx.zero(res + (long)r * dv + ik, d);
+  {   // (the tau / kap slots of the work vectors stay zero: eight doubles, one launch)
+    ZeroSlots z;
+    for (int r = 0; r < MR; ++r) {
+      z.add(dir + (long)r * dv + it); z.add(dir + (long)r * dv + ik);
+      z.add(res + (long)r * dv + it); z.add(res + (long)r * dv + ik);
+    }
+    dev_zero_slots(ctx, z);
   }
 
   // ---- solve_system for both columns (common.jl:129-182, qrchol.jl:16-37).  with_const: the constant column is a genuine

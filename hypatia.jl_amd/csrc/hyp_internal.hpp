@@ -213,6 +213,12 @@ struct DotSpecs {   // several dot products as one launch (dev_dots): *out[k] = 
   void add(int n_, const double* x_, const double* y_, double* out_) { n[count] = n_; x[count] = x_; y[count] = y_; out[count] = out_; ++count; }
 };
 void dev_dots(Ctx& c, const DotSpecs& sp);
+struct ZeroSlots {   // up to 16 single doubles set to zero by one launch (dev_zero_slots)
+  int count = 0;
+  double* p[16];
+  void add(double* q) { p[count++] = q; }
+};
+void dev_zero_slots(Ctx& c, const ZeroSlots& z);
 void dev_axpby(Ctx& c, int n, double a, const double* x, double b, double* y);          // y = a x + b y
 void dev_scale_copy(Ctx& c, int n, double a, const double* x, double* y);               // y = a x
 void dev_transpose(Ctx& c, int m, int n, const double* A, long lda, double* B, long ldb, int batch, long strideA,
