@@ -844,6 +844,10 @@ static void coldot(Ctx& c, int m, int ncols, int mode, const double* M, long ld,
     hipLaunchKernelGGL(coldot_kernel, dim3((ncols + 3) / 4), dim3(256), 0, c.stream, m, ncols, mode, M, ld, v, base, alpha, out);
 }
 
+void coldot_single(Ctx& c, int m, int ncols, int mode, const double* M, long ld, const double* v, const double* base, double alpha, double* out) {
+  coldot(c, m, ncols, mode, M, ld, v, base, alpha, out);
+}
+
 void TriSolvePlan::build(Ctx& c, int n_, const double* U, long ldu, const double* dinv) {
   n = 0;
   sb = c.trsv_plan_sb(n_);

@@ -494,6 +494,126 @@ static void coldot2(Ctx& c, int m, int ncols, int mode, const double* M, long ld
     hipLaunchKernelGGL(coldot2_kernel, dim3((ncols + 3) / 4), dim3(256), 0, c.stream, m, ncols, mode, M, ld, v, ldv, base, ldb, alpha, out, ldo);
 }
 
+// Three columns at once, M read once: columns 0 and 1 (v, v + ldv) with EXACTLY the sums of coldot2_batched_kernel, the third (v3)
+// with exactly those of coldot_batched_kernel (dense.hip) -- the constant column of update_lhs rides along with the first pair of
+// directions through the super-block solves (30 launches per triangular solve fewer per iteration) and every number stays what the
+// separate solves gave.  m <= 1024.
+__global__ __launch_bounds__(256) void coldot3_batched_kernel(int m, int ncols, int mode, const double* __restrict__ M, long ld,
+                                                              const double* __restrict__ v, long ldv, const double* __restrict__ v3,
+                                                              const double* base, long ldb, const double* base3, double alpha, double* out,
+                                                              long ldo, double* out3) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= ncols) return;
+  const int lane = threadIdx.x & 63;
+  int i0 = 0, i1 = m;
+  if (mode == 1) i1 = min(j + 1, m);
+  else if (mode == 2) i0 = min(j, m);
+  const double* a = M + (long)j * ld;
+  const int ilast = max(i1 - 1, 0);
+  double av[16], v0[16], v1[16], v2[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int i = min(i0 + lane + 64 * k, ilast);
+    av[k] = a[i];
+    v0[k] = v[i];
+    v1[k] = v[ldv + i];
+    v2[k] = v3[i];
+  }
+  const double b0 = base ? base[j] : 0.0, b1 = base ? base[ldb + j] : 0.0, b2 = base3 ? base3[j] : 0.0;
+  double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {   // (columns 0, 1: coldot2_batched_kernel)
+    const int i = i0 + lane + 128 * g;
+    if (i + 64 < i1) {
+      s0 += av[2 * g] * v0[2 * g];
+      s1 += av[2 * g + 1] * v0[2 * g + 1];
+      t0 += av[2 * g] * v1[2 * g];
+      t1 += av[2 * g + 1] * v1[2 * g + 1];
+    } else if (i < i1) {
+      s0 += av[2 * g] * v0[2 * g];
+      t0 += av[2 * g] * v1[2 * g];
+    }
+  }
+  double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {   // (column 2: coldot_batched_kernel)
+    const int i = i0 + lane + 256 * g;
+    if (i + 192 < i1) {
+      u0 += av[4 * g] * v2[4 * g];
+      u1 += av[4 * g + 1] * v2[4 * g + 1];
+      u2 += av[4 * g + 2] * v2[4 * g + 2];
+      u3 += av[4 * g + 3] * v2[4 * g + 3];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        if (i + 64 * t < i1) u0 += av[4 * g + t] * v2[4 * g + t];
+    }
+  }
+  double s = s0 + s1, t = t0 + t1, u = (u0 + u1) + (u2 + u3);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_down(s, off);
+    t += __shfl_down(t, off);
+    u += __shfl_down(u, off);
+  }
+  if (lane == 0) {
+    out[j] = b0 + alpha * s;
+    out[ldo + j] = b1 + alpha * t;
+    out3[j] = b2 + alpha * u;
+  }
+}
+void coldot_single(Ctx& c, int m, int ncols, int mode, const double* M, long ld, const double* v, const double* base, double alpha, double* out);   // dense.hip
+static void coldot3(Ctx& c, int m, int ncols, int mode, const double* M, long ld, const double* v, long ldv, const double* v3, const double* base,
+                    long ldb, const double* base3, double alpha, double* out, long ldo, double* out3) {
+  if (ncols <= 0) return;
+  if (m <= 1024 && coldot_batched_on()) {
+    hipLaunchKernelGGL(coldot3_batched_kernel, dim3((ncols + 3) / 4), dim3(256), 0, c.stream, m, ncols, mode, M, ld, v, ldv, v3, base, ldb, base3,
+                       alpha, out, ldo, out3);
+  } else {   // (longer columns: the two separate kernels)
+    coldot2(c, m, ncols, mode, M, ld, v, ldv, base, ldb, alpha, out, ldo);
+    coldot_single(c, m, ncols, mode, M, ld, v3, base3, alpha, out3);
+  }
+}
+
+// the pair x[:, 0:2] (leading dimension ldx) and a third right-hand side x3 through the super-block sweeps together: the steps of
+// solve_multi (nr = 2) and solve() with every product of the three columns in one launch
+void TriSolvePlan::solve_multi3(Ctx& c, const double* U, long ldu, bool trans, double* x, long ldx, double* x3) {
+  const int nsb = (n + sb - 1) / sb;
+  const size_t blk = (size_t)sb * sb;
+  work.ensure((size_t)2 * (MR + 1) * sb * sizeof(double));
+  double* t = work.d();                   // [sb x 2]
+  double* e = work.d() + MR * sb;         // [sb x 2]
+  double* t3 = work.d() + 2 * MR * sb;    // [sb]
+  double* e3 = t3 + sb;                   // [sb]
+  for (int s = 0; s < nsb; ++s) {
+    const int b = trans ? s : nsb - 1 - s;
+    const int r0 = b * sb, m = std::min(sb, n - r0);
+    double* xb = x + r0;
+    double* xb3 = x3 + r0;
+    const double* Dm = trans ? U + (long)r0 * ldu + r0 : UT.d() + (long)r0 * n + r0;
+    const long ldd = trans ? ldu : n;
+    const double* Bm = (trans ? Binv.d() : BinvT.d()) + b * blk;
+    const int mode = trans ? 1 : 2;
+    coldot3(c, m, m, mode, Bm, sb, xb, ldx, xb3, nullptr, 0, nullptr, 1.0, t, sb, t3);                                   // t = B x_b
+    for (int it = 0; it < refine; ++it) {
+      coldot3(c, m, m, mode, Dm, ldd, t, sb, t3, xb, ldx, xb3, -1.0, e, sb, e3);                                         // e = x_b - T t
+      const bool last = (it + 1 == refine);
+      coldot3(c, m, m, mode, Bm, sb, e, sb, e3, t, sb, t3, 1.0, last ? xb : t, last ? ldx : sb, last ? xb3 : t3);        // t += B e
+    }
+    if (refine == 0) {
+      HYP_CHECK(hipMemcpy2DAsync(xb, ldx * sizeof(double), t, sb * sizeof(double), m * sizeof(double), MR, hipMemcpyDeviceToDevice, c.stream));
+      HYP_CHECK(hipMemcpyAsync(xb3, t3, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, c.stream));
+    }
+    if (trans) {
+      const int rest = n - (r0 + m);
+      coldot3(c, m, rest, 0, U + (long)(r0 + m) * ldu + r0, ldu, xb, ldx, xb3, x + r0 + m, ldx, x3 + r0 + m, -1.0, x + r0 + m, ldx, x3 + r0 + m);
+    } else {
+      coldot3(c, m, r0, 0, UT.d() + r0, n, xb, ldx, xb3, x, ldx, x3, -1.0, x, ldx, x3);
+    }
+  }
+  HYP_CHECK(hipGetLastError());
+}
+
 void TriSolvePlan::solve_multi(Ctx& c, const double* U, long ldu, bool trans, double* x, long ldx, int nr) {
   if (nr == 1) {
     solve(c, U, ldu, trans, x);
@@ -538,7 +658,7 @@ void TriSolvePlan::solve_multi(Ctx& c, const double* U, long ldu, bool trans, do
 }
 
 // ---- solve_subsystem3 for nr columns (qrchol.jl:39-85 with p = 0: Q = I) --------------------------------
-void SysSolver::solve3_multi(double* sol, const double* rhs, int nr) {
+void SysSolver::solve3_multi(double* sol, const double* rhs, int nr, double* x_third) {
   const size_t d = sizeof(double);
   const long ld3 = n + q;
   HYP_REQUIRE(p == 0, "solve3_multi: p = 0 only");
@@ -555,9 +675,15 @@ void SysSolver::solve3_multi(double* sol, const double* rhs, int nr) {
   if (tri.ready(nmp)) {
     double* y = use_bk ? bk.gather(ctx, sol, ld3, nr) : sol;   // Bunch-Kaufman factor: P before, D^-1 between, P' after
     const long ldy = use_bk ? nmp : ld3;
-    tri.solve_multi(ctx, lhs_fact.d(), nmp, true, y, ldy, nr);
-    if (use_bk) bk.dsolve(ctx, y, ldy, nr);
-    tri.solve_multi(ctx, lhs_fact.d(), nmp, false, y, ldy, nr);
+    if (x_third && !use_bk && nr == MR) {   // (the constant column's triangular solves ride along: see step_directions)
+      tri.solve_multi3(ctx, lhs_fact.d(), nmp, true, y, ldy, x_third);
+      tri.solve_multi3(ctx, lhs_fact.d(), nmp, false, y, ldy, x_third);
+    } else {
+      HYP_REQUIRE(!x_third, "solve3_multi: the third column needs the Cholesky factor's plan");
+      tri.solve_multi(ctx, lhs_fact.d(), nmp, true, y, ldy, nr);
+      if (use_bk) bk.dsolve(ctx, y, ldy, nr);
+      tri.solve_multi(ctx, lhs_fact.d(), nmp, false, y, ldy, nr);
+    }
     if (use_bk) bk.scatter(ctx, y, sol, ld3, nr);
   } else {
     for (int r = 0; r < nr; ++r) tri_solves(sol + r * ld3);
@@ -632,7 +758,7 @@ static void lincomb_cols(Ctx& c, int n, int nr, const double* x0, long ld0, cons
 // along as a THIRD column of this call's solve_subsystem3 -- its two passes over G, its cone product and its scalar products
 // cost the pair nothing extra; sol_const / dot_const are set before the pair's tau is formed from them (common.jl:155-161)
 void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
-                                  double min_impr_tol, Scal* dsc, double* res_norms, int* n_solves, bool with_const) {
+                                  double min_impr_tol, Scal* dsc, double* res_norms, int* n_solves, bool with_const, bool joint_const) {
   const size_t d = sizeof(double);
   const int dv = dimv(), it = n + p + q, ik = dv - 1;
   HYP_REQUIRE(p == 0, "pair_solve_device: p = 0 only");
@@ -684,7 +810,7 @@ void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double
       for (int r = 0; r < ncol; ++r) dev_axpby(ctx, dk, -1.0, rhs + (long)r * dv + os + o, -1.0, sr + r * ld3 + oz + o);
     }
   }
-  solve3_multi(ss, sr, ncol);
+  solve3_multi(ss, sr, ncol, joint_const ? sol_const.d() : nullptr);
   double* ds = ctx.dscal.d();
   {
     DotSpecs sp;
@@ -692,10 +818,16 @@ void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double
       sp.add(n, mc.d(), ss + r * ld3, ds + 2 * r);
       sp.add(q, mh.d(), ss + r * ld3 + oz, ds + 2 * r + 1);
     }
+    if (joint_const) {   // the rest of the constant solve (solve3 after its triangular solves) and its two dot products
+      update_const_post();
+      sp.add(n, mc.d(), sol_const.d(), ds + 2 * MR);
+      sp.add(q, mh.d(), sol_const.d() + n, ds + 2 * MR + 1);
+    }
     dev_dots(ctx, sp);
   }
   ctx.d2h(ctx.h_pinned, ds, 2 * (MR + 1) * d);
   ctx.sync();
+  if (joint_const) dot_const = ctx.h_pinned[2 * MR] + ctx.h_pinned[2 * MR + 1];
   if (dist()) {   // h' z over all ranks' rows
     double hz[MR + 1] = {ctx.h_pinned[1], ctx.h_pinned[3], ctx.h_pinned[5]};
     allreduce_host(hz, ncol, 0);
@@ -953,10 +1085,16 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   // solves (z_const = H G x_const - H h cancels to ~mu of its terms; with G x_const from the three-column pass its rounding
   // no longer matches the one-column products the residual is checked against) -- OFF by default.
   static const bool const3 = [] { const char* e = getenv("HYP_CONST_COL3"); return e && e[0] == '1'; }();
-  if (!const3) {
+  // Default: the constant column keeps its own right-hand side, its own passes over G and cone products (the numbers of
+  // update_const()), but its two triangular solves -- 60 launches of ~5 us -- ride along with the first pair's as a third column
+  // of the same launches (coldot3: per column the very sums of the separate kernels).  HYP_CONST_TRI3=0: solved on its own first.
+  static const bool tri3 = [] { const char* e = getenv("HYP_CONST_TRI3"); return !(e && e[0] == '0'); }();
+  const bool joint = !const3 && tri3 && !dist() && !use_bk && nmp > 0 && tri.ready(nmp) && tri.sb > 0 && tri.sb <= 1024;
+  if (!const3 && !joint) {
     update_const();
     if (h_sol_const) ctx.d2h(hs_const, sol_const.p, (size_t)it * d);   // (host mirror of sys.sol_const)
   }
+  if (joint) update_const_pre();
   last_update_lhs_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   const double tau = h_point[it], kap = h_point[ik];
   m_rhs.ensure((size_t)(MR + 1) * dv * d);   // (+ the constant column of the first pair)
@@ -966,8 +1104,8 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   int ns = 0;
   // (cent, pred)
   build_rhs_pair(0, m_rhs.d(), s_point.d(), mu, tau, kap, tau_residual, nullptr, nullptr, reinterpret_cast<double*>(rs));
-  pair_solve_device(m_rhs.d(), rs, mu, tau, max_ref_steps, res_norm_cutoff, min_impr_tol, dsc, rn, &ns, const3);
-  if (const3 && h_sol_const) ctx.d2h(hs_const, sol_const.p, (size_t)it * d);   // (host mirror of sys.sol_const)
+  pair_solve_device(m_rhs.d(), rs, mu, tau, max_ref_steps, res_norm_cutoff, min_impr_tol, dsc, rn, &ns, const3, joint);
+  if ((const3 || joint) && h_sol_const) ctx.d2h(hs_const, sol_const.p, (size_t)it * d);   // (host mirror of sys.sol_const)
   *n_solves += ns;
   res_norms[0] = rn[0];
   res_norms[1] = rn[1];

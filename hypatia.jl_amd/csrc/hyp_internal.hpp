@@ -167,6 +167,7 @@ struct TriSolvePlan {
   void build(Ctx& c, int n_, const double* U, long ldu, const double* dinv);
   void solve(Ctx& c, const double* U, long ldu, bool trans, double* x);
   void solve_multi(Ctx& c, const double* U, long ldu, bool trans, double* x, long ldx, int nr);   // nr <= 2 right-hand sides
+  void solve_multi3(Ctx& c, const double* U, long ldu, bool trans, double* x, long ldx, double* x3);   // the pair x[:, 0:2] and a third vector x3 together
 };
 // bunchkaufman.hip : symmetric indefinite factorization with rook pivoting, the reference's fallback of a failed
 // Cholesky (symm_fact!, dense.jl:164-165; posdef_fact_copy!, dense.jl:194-215).  P A P' = U' D U with U unit upper

@@ -670,6 +670,29 @@ void SysSolver::update_const() {
   dot_const = ctx.h_pinned[0] + (p > 0 ? ctx.h_pinned[1] : 0.0) + hz;
 }
 
+// update_const() in two halves around the triangular solves (p = 0, one process, Cholesky factor): pre leaves lhs-space right-hand
+// side x + G' z in sol_const's x part, post continues solve3 from there (z = H (G x) - z); the dot products and dot_const are the
+// caller's (pair_solve_device)
+void SysSolver::update_const_pre() {
+  HYP_REQUIRE(model_loaded && p == 0 && !dist(), "update_const_pre: single process, p = 0");
+  const size_t d = sizeof(double);
+  double* r = sub_rhs.d();
+  dev_scale_copy(ctx, n, -1.0, mc.d(), r);
+  block_hess_prod_vec(r + n, mh.d());
+  double* sol = sol_const.d();
+  ctx.d2d(sol, r, (size_t)(n + q) * d);
+  double* t = QpbxGHbz.d();
+  ctx.d2d(t, sol, (size_t)n * d);
+  gemv(ctx, true, q, n, 1.0, G.d(), q, sol + n, 1.0, t);     // :51-53
+  ctx.d2d(sol, t, (size_t)n * d);                            // :66-69 (the solves follow, with the first pair's)
+}
+void SysSolver::update_const_post() {
+  double* sol = sol_const.d();
+  gemv(ctx, false, q, n, 1.0, G.d(), q, sol, 0.0, Gx.d());   // :73
+  block_hess_prod_vec(HGx.d(), Gx.d());                      // :74
+  dev_axpby(ctx, q, 1.0, HGx.d(), -1.0, sol + n);            // :76  z = HGx - z
+}
+
 SysSolver::Scal SysSolver::solve_system(double* sol, const double* rhs, Scal rs, double mu, double taubar) {
   const size_t d = sizeof(double);
   const int oz = n + p, os = n + p + q + 1;

@@ -100,6 +100,8 @@ struct SysSolver {
   int dimv() const { return n + p + q + 1 + q + 1; }
   void load_model(const double* hc, const double* hb, const double* hh, const double* hA);
   void update_const();                                                          // qrchol.jl:191-197
+  void update_const_pre();                                                      // the same in two halves around the triangular solves
+  void update_const_post();
   struct Scal { double tau, kap; };
   Scal solve_system(double* d_sol, const double* d_rhs, Scal rhs, double mu, double taubar);   // common.jl:129-182
   Scal apply_lhs(double* d_res, const double* d_dir, Scal dir, double mu, double taubar);      // common.jl:79-121
@@ -115,7 +117,7 @@ struct SysSolver {
   // ---- two right-hand sides at once (directions_multi.hip): the stepper's (cent, pred) and (centadj, predadj)
   // pairs are independent, and every pass over G / the factor / the cone matrices serves both columns
   DBuf m_rhs, m_dir, m_res, m_subr, m_subs, m_t, m_Gx, m_HGx, m_Gxd;
-  void solve3_multi(double* sol, const double* rhs, int nr);   // p == 0 only; columns n + q apart
+  void solve3_multi(double* sol, const double* rhs, int nr, double* x_third = nullptr);   // p == 0 only; columns n + q apart; x_third: a third lhs-space right-hand side through the same triangular sweeps
   void get_directions2(double* h_dirs, const double* h_rhss, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
                        double min_impr_tol, double* res_norms, int* n_solves);
   // search_alpha (search.jl:46-69) with the candidate of update_stepper_points (combined.jl:124-170) formed here:
@@ -136,7 +138,7 @@ struct SysSolver {
                        double res_norm_cutoff, double min_impr_tol, double* h_dirs, double* res_norms, int* n_solves, int* use_sqrt_out,
                        int* info, int* used_fallback, double* h_sol_const);
   void pair_solve_device(double* rhs2, const Scal* rs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
-                         double min_impr_tol, Scal* dsc, double* res_norms, int* n_solves, bool with_const = false);
+                         double min_impr_tol, Scal* dsc, double* res_norms, int* n_solves, bool with_const = false, bool joint_const = false);
   // returns res_norm; dir / rhs are HOST Point vectors (common.jl:15-76)
   double get_directions(double* h_dir, const double* h_rhs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
                         double min_impr_tol, int* n_solves);

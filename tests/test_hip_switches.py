@@ -24,6 +24,8 @@ elif name == "psd_single":
     inst = I.psd_blocks(40, [48], seed=5)
 elif name == "psd_pair":
     inst = I.psd_blocks(50, [40, 33], seed=6)
+elif name == "psd_plan":                     # n = 600: the factor has a super-block solve plan (n >= 512)
+    inst = I.psd_blocks(600, [36, 20], seed=7)
 elif name == "polymin_primal":
     inst = I.polymin(2, 3, True, seed=2)
 elif name == "polymin_dual":
@@ -35,9 +37,11 @@ elif name == "polymin_large_dual":
 else:
     inst = I.KNOWN_ANSWER[name]()
 s = H.Solver(default_tol_relax=10)
+trace = []
+s.iter_callback = lambda sv: trace.append((sv.primal_obj, sv.dual_obj, sv.mu, sv.point.tau, sv.x_feas, sv.z_feas))
 s.load(H.make_model(inst))
 s.solve()
-print(json.dumps({"status": s.get_status(), "iters": s.get_num_iters(), "obj": s.get_primal_obj()}))
+print(json.dumps({"status": s.get_status(), "iters": s.get_num_iters(), "obj": s.get_primal_obj(), "trace": trace}))
 """
 
 
@@ -79,3 +83,15 @@ def test_constant_column_as_third_column_solves_the_same_problem(name):
     assert on["status"] == off["status"] == "Optimal"
     assert abs(on["iters"] - off["iters"]) <= 4
     assert abs(on["obj"] - off["obj"]) <= 1e-6 * (1 + abs(off["obj"]))
+
+
+def test_constant_column_through_the_pair_s_triangular_solves_changes_no_bit():
+    """default since round 3 (HYP_CONST_TRI3): the two triangular solves of the constant column of update_lhs (qrchol.jl:191-197) ride
+    along with the first pair of directions as a third column of the same launches (coldot3: per column the sums of the separate
+    kernels).  Every iterate of a solve must be the one the separate constant solve gives, to the last bit"""
+    on = _run("psd_plan", {"HYP_CONST_TRI3": "1"})
+    off = _run("psd_plan", {"HYP_CONST_TRI3": "0"})
+    assert on["status"] == off["status"] == "Optimal"
+    assert on["iters"] == off["iters"] >= 8
+    assert on["trace"] == off["trace"]
+
