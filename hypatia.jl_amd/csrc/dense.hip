@@ -984,17 +984,22 @@ __global__ void gemv_n_reduce_kernel(int m, int nchunks, double alpha, const dou
   y[row] = alpha * s + (beta != 0.0 ? beta * y[row] : 0.0);
 }
 
-bool gemv_t_cb1(Ctx& c, int m, int n, double alpha, const double* A, long lda, const double* x, double beta, double* y);   // directions_multi.hip
+void gemv_t_one(Ctx& c, int m, int n, double alpha, const double* A, long lda, const double* x, double beta, double* y);    // directions_multi.hip
+void gemv_n_one(Ctx& c, int m, int n, double alpha, const double* A, long lda, const double* x, double beta, double* y);    // directions_multi.hip
 
 void gemv(Ctx& c, bool trans, int m, int n, double alpha, const double* A, long lda, const double* x, double beta, double* y) {
   if (trans) {
     if (n <= 0) return;
-    // long columns (the q x n block of G): four columns per workgroup with x loaded once for them (the kernel of the paired
-    // passes with one right-hand side): 4.6 -> 5.8 TB/s at config 2
-    if (m >= 4096 && n >= 64 && gemv_t_cb1(c, m, n, alpha, A, lda, x, beta, y)) return;
+    // through the kernels of the paired passes with one right-hand side: four columns per workgroup with x loaded once for
+    // them when the operands are 16-byte aligned (4.6 -> 5.8 TB/s on the q x n block of G at config 2), and in every case the
+    // sums a column gets in a two- or three-column pass (see gemv_n_one)
+    static const bool one_on = [] { const char* e = getenv("HYP_GEMVN_ONE"); return !(e && e[0] == '0'); }();
+    if (one_on) { gemv_t_one(c, m, n, alpha, A, lda, x, beta, y); return; }
     hipLaunchKernelGGL(gemv_t_kernel, dim3(n), dim3(256), 0, c.stream, m, n, alpha, A, lda, x, beta, y);
   } else {
     if (m <= 0) return;
+    static const bool one_on = [] { const char* e = getenv("HYP_GEMVN_ONE"); return !(e && e[0] == '0'); }();
+    if (one_on) { gemv_n_one(c, m, n, alpha, A, lda, x, beta, y); return; }
     const int nchunks = (n + GEMV_N_CHUNK - 1) / GEMV_N_CHUNK;
     c.scratch.ensure(std::max<size_t>((size_t)nchunks * m * sizeof(double), 4096));
     if (nchunks > 0)

@@ -188,6 +188,9 @@ __global__ __launch_bounds__(256) void gemv_n_multi_partial_kernel(int m, int n,
   __syncthreads();
   if (row >= m) return;
   const double* a = A + (long)c0 * lda + row;
+  // (two interleaved partial sums per 256-column chunk, then the chunks in order; the one-right-hand-side product of gemv() runs
+  //  through this kernel with NR = 1 since round 3, so that a column has the same sums whether it is computed alone, in a pair or
+  //  as the third column of the first paired solve: tools/diag_const3.py)
   double s[NR][2];
 #pragma unroll
   for (int r = 0; r < NR; ++r) s[r][0] = s[r][1] = 0.0;
@@ -377,14 +380,12 @@ void gemv_both(Ctx& c, int m, int n, int nr, const double* A, long lda, const do
   else gemv_both_t<2>(c, m, n, A, lda, Xn, ldxn, beta_n, Yn, ldyn, Xt, ldxt, beta_t, Yt, ldyt);
 }
 
-// one right-hand side through the four-columns-per-workgroup kernel (called by gemv() for long columns); false: operands not aligned
-bool gemv_t_cb1(Ctx& c, int m, int n, double alpha, const double* A, long lda, const double* x, double beta, double* y) {
-  static const bool on = [] { const char* e = getenv("HYP_GEMVT_CB1"); return !(e && e[0] == '0'); }();
-  const bool wide = ((((uintptr_t)A | (uintptr_t)x) & 15) == 0) && (lda % 2 == 0);
-  if (!on || !wide) return false;
-  hipLaunchKernelGGL((gemv_t_multi_cb_kernel<1, 4>), dim3((n + 3) / 4), dim3(256), 0, c.stream, m, n, alpha, A, lda, x, (long)m, beta, y, (long)n);
-  HYP_CHECK(hipGetLastError());
-  return true;
+// y = alpha A x + beta y with the sums of the multi-column kernel (gemv() routes its one-right-hand-side product here)
+void gemv_n_one(Ctx& c, int m, int n, double alpha, const double* A, long lda, const double* x, double beta, double* y) {
+  gemv_multi_t<1>(c, false, m, n, alpha, A, lda, x, (long)n, beta, y, (long)m);
+}
+void gemv_t_one(Ctx& c, int m, int n, double alpha, const double* A, long lda, const double* x, double beta, double* y) {
+  gemv_multi_t<1>(c, true, m, n, alpha, A, lda, x, (long)m, beta, y, (long)n);
 }
 
 // nr = 1, 2 or 3 right-hand sides per pass over A (3: the constant column of update_lhs rides along with the first pair of
@@ -678,6 +679,9 @@ void SysSolver::solve3_multi(double* sol, const double* rhs, int nr, double* x_t
     if (x_third && !use_bk && nr == MR) {   // (the constant column's triangular solves ride along: see step_directions)
       tri.solve_multi3(ctx, lhs_fact.d(), nmp, true, y, ldy, x_third);
       tri.solve_multi3(ctx, lhs_fact.d(), nmp, false, y, ldy, x_third);
+    } else if (!x_third && !use_bk && nr == MR + 1) {   // (the constant column as third column of the pair: the same launches)
+      tri.solve_multi3(ctx, lhs_fact.d(), nmp, true, y, ldy, y + (long)MR * ldy);
+      tri.solve_multi3(ctx, lhs_fact.d(), nmp, false, y, ldy, y + (long)MR * ldy);
     } else {
       HYP_REQUIRE(!x_third, "solve3_multi: the third column needs the Cholesky factor's plan");
       tri.solve_multi(ctx, lhs_fact.d(), nmp, true, y, ldy, nr);
@@ -1079,13 +1083,16 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   if (use_sqrt_out)
     for (size_t k = 0; k < cones.size(); ++k) use_sqrt_out[k] = use_sqrt[k];
   if (*info != 0) { ctx.sync(); return; }
-  // HYP_CONST_COL3=1: the constant column of update_lhs (qrchol.jl:191-197) rides along as a third column of the first pair
-  // below instead of being solved on its own first.  Measured: -0.33 ms per iteration at config 2 (-1.3 ms at config 4), but
-  // over 24 PSD models 291 iterations instead of 284 and final direction residuals 10 - 1000 times larger in a third of the
-  // solves (z_const = H G x_const - H h cancels to ~mu of its terms; with G x_const from the three-column pass its rounding
-  // no longer matches the one-column products the residual is checked against) -- OFF by default.
-  static const bool const3 = [] { const char* e = getenv("HYP_CONST_COL3"); return e && e[0] == '1'; }();
-  // Default: the constant column keeps its own right-hand side, its own passes over G and cone products (the numbers of
+  // The constant column of update_lhs (qrchol.jl:191-197: rhs_const = (-c, H h), one solve_subsystem3 per iteration) rides along
+  // as a THIRD column of the first paired solve: its right-hand side, both passes over G, the cone products and the triangular
+  // solves come out of the pair's launches (two passes over G, ~70 launches and a host synchronisation fewer per iteration).
+  // Every column of every kernel on that path is computed with exactly the sums it gets when computed alone (the multi-column
+  // G x kernel has the one-column kernel's four partial sums since round 3 -- that was the one kernel that differed, and the
+  // reason this was off until then: tools/diag_const3.py), so the iterates are bitwise those of the separate solve
+  // (tests/test_hip_switches.py).  Not with a Bunch-Kaufman factor (gather / scatter of two columns).  HYP_CONST_COL3=0: off.
+  static const bool const3_env = [] { const char* e = getenv("HYP_CONST_COL3"); return !(e && e[0] == '0'); }();
+  const bool const3 = const3_env && !use_bk;
+  // With HYP_CONST_COL3=0: the constant column keeps its own right-hand side, its own passes over G and cone products (the numbers of
   // update_const()), but its two triangular solves -- 60 launches of ~5 us -- ride along with the first pair's as a third column
   // of the same launches (coldot3: per column the very sums of the separate kernels).  HYP_CONST_TRI3=0: solved on its own first.
   static const bool tri3 = [] { const char* e = getenv("HYP_CONST_TRI3"); return !(e && e[0] == '0'); }();
