@@ -62,6 +62,11 @@ struct Cone {
   virtual void hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) = 0;
   virtual void inv_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) = 0;
   virtual bool use_sqrt_hess_oracles(int arr_dim) = 0;
+  // true: hess_prod / inv_hess_prod on k columns give every column exactly the sums it gets when it is the only column (the
+  // PSD two-sided kernels, the elementwise cones) -- what lets the constant column of update_lhs ride along with the first pair of
+  // directions without changing a bit (SysSolver::step_directions).  The generic explicit-Hessian cones multiply several columns
+  // with the GEMM and one with the gemv: false.
+  virtual bool products_columnwise() const { return false; }
   virtual void sqrt_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) = 0;
   virtual void inv_sqrt_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) = 0;
   virtual void hess_prod_slow(double* prod, long ldp, const double* arr, long lda, int ncols) { hess_prod(prod, ldp, arr, lda, ncols); }
@@ -98,6 +103,7 @@ struct Cone {
 };
 
 struct NonnegCone : Cone {   // src/Cones/nonnegative.jl
+  bool products_columnwise() const override { return true; }
   NonnegCone(Ctx& c, int dim);
   bool update_feas() override;
   bool is_dual_feas() override;
@@ -114,6 +120,7 @@ struct NonnegCone : Cone {   // src/Cones/nonnegative.jl
 };
 
 struct PsdCone : Cone {   // src/Cones/possemideftri.jl (real symmetric)
+  bool products_columnwise() const override { return true; }
   int side;
   // side x side col-major device matrices
   DBuf X;        // smat(point), both triangles

@@ -1089,9 +1089,13 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   // Every column of every kernel on that path is computed with exactly the sums it gets when computed alone (the multi-column
   // G x kernel has the one-column kernel's four partial sums since round 3 -- that was the one kernel that differed, and the
   // reason this was off until then: tools/diag_const3.py), so the iterates are bitwise those of the separate solve
-  // (tests/test_hip_switches.py).  Not with a Bunch-Kaufman factor (gather / scatter of two columns).  HYP_CONST_COL3=0: off.
+  // (tests/test_hip_switches.py).  Not with a Bunch-Kaufman factor (gather / scatter of two columns) and only for cones whose
+  // multi-column products are column-wise the one-column ones.  HYP_CONST_COL3=0: off.
   static const bool const3_env = [] { const char* e = getenv("HYP_CONST_COL3"); return !(e && e[0] == '0'); }();
-  const bool const3 = const3_env && !use_bk;
+  bool cones_ok = true;   // (see Cone::products_columnwise; config 5's WSOS cone: with the switch forced on, 0.48 instead of 0.13
+                          //  Bunch-Kaufman fall-backs per iteration and 10.3 instead of 6.6 ms in the directions)
+  for (const Cone* ck : cones) cones_ok = cones_ok && ck->products_columnwise();
+  const bool const3 = const3_env && !use_bk && cones_ok;
   // With HYP_CONST_COL3=0: the constant column keeps its own right-hand side, its own passes over G and cone products (the numbers of
   // update_const()), but its two triangular solves -- 60 launches of ~5 us -- ride along with the first pair's as a third column
   // of the same launches (coldot3: per column the very sums of the separate kernels).  HYP_CONST_TRI3=0: solved on its own first.
