@@ -994,12 +994,12 @@ void gemv(Ctx& c, bool trans, int m, int n, double alpha, const double* A, long 
     // them when the operands are 16-byte aligned (4.6 -> 5.8 TB/s on the q x n block of G at config 2), and in every case the
     // sums a column gets in a two- or three-column pass (see gemv_n_one)
     static const bool one_on = [] { const char* e = getenv("HYP_GEMVN_ONE"); return !(e && e[0] == '0'); }();
-    if (one_on) { gemv_t_one(c, m, n, alpha, A, lda, x, beta, y); return; }
+    if (one_on && c.gemv_one) { gemv_t_one(c, m, n, alpha, A, lda, x, beta, y); return; }
     hipLaunchKernelGGL(gemv_t_kernel, dim3(n), dim3(256), 0, c.stream, m, n, alpha, A, lda, x, beta, y);
   } else {
     if (m <= 0) return;
     static const bool one_on = [] { const char* e = getenv("HYP_GEMVN_ONE"); return !(e && e[0] == '0'); }();
-    if (one_on) { gemv_n_one(c, m, n, alpha, A, lda, x, beta, y); return; }
+    if (one_on && c.gemv_one) { gemv_n_one(c, m, n, alpha, A, lda, x, beta, y); return; }
     const int nchunks = (n + GEMV_N_CHUNK - 1) / GEMV_N_CHUNK;
     c.scratch.ensure(std::max<size_t>((size_t)nchunks * m * sizeof(double), 4096));
     if (nchunks > 0)

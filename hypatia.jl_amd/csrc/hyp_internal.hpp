@@ -83,6 +83,7 @@ struct Ctx {
   hipEvent_t aux_event(int i);
   GemmScratch gemm_scratch;   // split-K workspace + syrk tile order of the GEMM launcher (per context, never shared)
   GemmScratch gemm_scratch2;  // the same for launches on the helper stream (StreamSwap)
+  bool gemv_one = false;   // gemv(): one-right-hand-side products through the multi-column kernels (set by SysSolver::sgemv for its call)
   DBuf scratch;       // general device scratch (gemv partial sums)
   DBuf dscal;         // 64 device doubles for scalar results (dots, counts)
   DBuf stage_a, stage_b;   // device staging for host-pointer entry points

@@ -368,8 +368,8 @@ void SysSolver::residual_products(const double* h_x, const double* h_z, const do
     if (n > 0 && gemv_both_ok(q, n, G.d(), q)) {                             // G' z (these rows) and G x + s in one pass over G
       gemv_both(ctx, q, n, 1, G.d(), q, rp_x.d(), n, 1.0, rp_g.d(), q, rp_z.d(), q, 0.0, rp_t.d(), n);
     } else {
-      gemv(ctx, true, q, n, 1.0, G.d(), q, rp_z.d(), 0.0, rp_t.d());
-      gemv(ctx, false, q, n, 1.0, G.d(), q, rp_x.d(), 1.0, rp_g.d());
+      sgemv(true, q, n, 1.0, G.d(), q, rp_z.d(), 0.0, rp_t.d());
+      sgemv(false, q, n, 1.0, G.d(), q, rp_x.d(), 1.0, rp_g.d());
     }
     dev_dot(ctx, q, mh.d(), rp_z.d(), rp_t.d() + n);
     dev_dot(ctx, q, rp_z.d(), rp_s.d(), rp_t.d() + n + 1);
@@ -527,6 +527,24 @@ void SysSolver::tri_solves(double* d_x) {
 
 void SysSolver::potrs(double* d_x) { tri_solves(d_x); }
 
+// One-right-hand-side products with G (and A, Q): for models whose cones are column-wise (Cone::products_columnwise) through the
+// multi-column kernels with one column, so that a column has the same sums wherever it is formed (step_directions); for the others
+// through the one-column kernels of rounds 1-2 -- their constant column keeps products of its own, and with them the arithmetic
+// their trajectories were pinned with (tests/test_hip_trajectory.py: mixed_dual_barriers ended in SlowProgress otherwise).
+void SysSolver::sgemv(bool trans, int m, int n_, double alpha, const double* A, long lda, const double* x, double beta, double* y) {
+  bool cw = true;
+  for (const Cone* ck : cones) cw = cw && ck->products_columnwise();
+  const bool keep = ctx.gemv_one;
+  ctx.gemv_one = cw;
+  try {
+    gemv(ctx, trans, m, n_, alpha, A, lda, x, beta, y);
+  } catch (...) {
+    ctx.gemv_one = keep;
+    throw;
+  }
+  ctx.gemv_one = keep;
+}
+
 void SysSolver::solve3(double* d_sol, const double* d_rhs) {   // qrchol.jl:39-85
   const size_t d = sizeof(double);
   if (d_sol != d_rhs) ctx.d2d(d_sol, d_rhs, (size_t)(n + p + q) * d);
@@ -537,24 +555,24 @@ void SysSolver::solve3(double* d_sol, const double* d_rhs) {   // qrchol.jl:39-8
   // t = Q' (x + G' z)                                                   :51-53
   if (dist()) {   // G = this rank's rows: sum the partial G' z over the ranks, then add the (replicated) x once
     HYP_REQUIRE(p == 0, "sys: the sharded path assumes the reduced model (p = 0)");
-    gemv(ctx, true, q, n, 1.0, G.d(), q, z, 0.0, t);
+    sgemv(true, q, n, 1.0, G.d(), q, z, 0.0, t);
     allreduce_dev(t, n, 0);
     dev_axpby(ctx, n, 1.0, x, 1.0, t);
   } else {
     ctx.d2d(t, x, (size_t)n * d);
-    gemv(ctx, true, q, n, 1.0, G.d(), q, z, 1.0, t);
+    sgemv(true, q, n, 1.0, G.d(), q, z, 1.0, t);
   }
   if (p > 0) {
-    gemv(ctx, true, n, n, 1.0, Qm.d(), n, t, 0.0, tmpn.d());
+    sgemv(true, n, n, 1.0, Qm.d(), n, t, 0.0, tmpn.d());
     ctx.d2d(t, tmpn.p, (size_t)n * d);
     // y <- R'^-1 y ; sol.vec[1:p] = y                                   :55-57
-    gemv(ctx, true, p, p, 1.0, Rinv.d(), p, y, 0.0, tmpn.d());
+    sgemv(true, p, p, 1.0, Rinv.d(), p, y, 0.0, tmpn.d());
     ctx.d2d(y, tmpn.p, (size_t)p * d);
     ctx.d2d(x, y, (size_t)p * d);
     if (nmp > 0) {                                                       // :59-63
-      gemv(ctx, false, q, p, 1.0, GQ1.d(), q, y, 0.0, GQ1x.d());
+      sgemv(false, q, p, 1.0, GQ1.d(), q, y, 0.0, GQ1x.d());
       block_hess_prod_vec(HGQ1x.d(), GQ1x.d());
-      gemv(ctx, true, q, nmp, -1.0, GQ2s.d(), q, HGQ1x.d(), 1.0, t + p);
+      sgemv(true, q, nmp, -1.0, GQ2s.d(), q, HGQ1x.d(), 1.0, t + p);
     }
   }
   if (nmp > 0) {                                                         // :66-69
@@ -562,16 +580,16 @@ void SysSolver::solve3(double* d_sol, const double* d_rhs) {   // qrchol.jl:39-8
     tri_solves(x + p);
   }
   if (p > 0) {                                                           // :71  x = Q x
-    gemv(ctx, false, n, n, 1.0, Qm.d(), n, x, 0.0, tmpn.d());
+    sgemv(false, n, n, 1.0, Qm.d(), n, x, 0.0, tmpn.d());
     ctx.d2d(x, tmpn.p, (size_t)n * d);
   }
-  gemv(ctx, false, q, n, 1.0, G.d(), q, x, 0.0, Gx.d());                 // :73
+  sgemv(false, q, n, 1.0, G.d(), q, x, 0.0, Gx.d());                 // :73
   block_hess_prod_vec(HGx.d(), Gx.d());                                  // :74
   dev_axpby(ctx, q, 1.0, HGx.d(), -1.0, z);                              // :76  z = HGx - z
   if (p > 0) {                                                           // :78-82
     ctx.d2d(tmpn.p, t, (size_t)p * d);
-    gemv(ctx, true, q, p, -1.0, GQ1.d(), q, HGx.d(), 1.0, tmpn.d());
-    gemv(ctx, false, p, p, 1.0, Rinv.d(), p, tmpn.d(), 0.0, y);
+    sgemv(true, q, p, -1.0, GQ1.d(), q, HGx.d(), 1.0, tmpn.d());
+    sgemv(false, p, p, 1.0, Rinv.d(), p, tmpn.d(), 0.0, y);
   }
 }
 
@@ -683,12 +701,12 @@ void SysSolver::update_const_pre() {
   ctx.d2d(sol, r, (size_t)(n + q) * d);
   double* t = QpbxGHbz.d();
   ctx.d2d(t, sol, (size_t)n * d);
-  gemv(ctx, true, q, n, 1.0, G.d(), q, sol + n, 1.0, t);     // :51-53
+  sgemv(true, q, n, 1.0, G.d(), q, sol + n, 1.0, t);     // :51-53
   ctx.d2d(sol, t, (size_t)n * d);                            // :66-69 (the solves follow, with the first pair's)
 }
 void SysSolver::update_const_post() {
   double* sol = sol_const.d();
-  gemv(ctx, false, q, n, 1.0, G.d(), q, sol, 0.0, Gx.d());   // :73
+  sgemv(false, q, n, 1.0, G.d(), q, sol, 0.0, Gx.d());   // :73
   block_hess_prod_vec(HGx.d(), Gx.d());                      // :74
   dev_axpby(ctx, q, 1.0, HGx.d(), -1.0, sol + n);            // :76  z = HGx - z
 }
@@ -736,7 +754,7 @@ SysSolver::Scal SysSolver::solve_system(double* sol, const double* rhs, Scal rs,
   // sol.s = h * tau - rhs.z - G sol.x     (common.jl:139-141).  G sol.x is formed from the rounded sol.x itself
   // (NOT as G sol_sub.x + tau G sol_const.x: when the two parts cancel, that sum loses the consistency
   // between x and s that the residual check relies on); it is kept for the residual, which needs the same product.
-  gemv(ctx, false, q, n, 1.0, G.d(), q, sol, 0.0, Gx_dir.d());
+  sgemv(false, q, n, 1.0, G.d(), q, sol, 0.0, Gx_dir.d());
   Gx_dir_valid = true;
   dev_scale_copy(ctx, q, sol_tau, mh.d(), sol + os);
   dev_axpby(ctx, q, -1.0, rhs + oz, 1.0, sol + os);
@@ -753,22 +771,22 @@ SysSolver::Scal SysSolver::apply_lhs(double* res, const double* dir, Scal ds_, d
   const double tau_dir = ds_.tau, kap_dir = ds_.kap;
   // res.x = c tau + G' z (+ A' y)
   if (dist()) {
-    gemv(ctx, true, q, n, 1.0, G.d(), q, dir + oz, 0.0, res);
+    sgemv(true, q, n, 1.0, G.d(), q, dir + oz, 0.0, res);
     allreduce_dev(res, n, 0);
     dev_axpby(ctx, n, tau_dir, mc.d(), 1.0, res);
   } else {
     dev_scale_copy(ctx, n, tau_dir, mc.d(), res);
-    gemv(ctx, true, q, n, 1.0, G.d(), q, dir + oz, 1.0, res);
+    sgemv(true, q, n, 1.0, G.d(), q, dir + oz, 1.0, res);
   }
   // res.z = h tau - s - G x
   dev_scale_copy(ctx, q, tau_dir, mh.d(), res + oz);
   dev_axpby(ctx, q, -1.0, dir + os, 1.0, res + oz);
   if (Gx_dir_valid) dev_axpby(ctx, q, -1.0, Gx_dir.d(), 1.0, res + oz);   // G dir.x was just formed by solve_system
-  else gemv(ctx, false, q, n, -1.0, G.d(), q, dir, 1.0, res + oz);
+  else sgemv(false, q, n, -1.0, G.d(), q, dir, 1.0, res + oz);
   if (p > 0) {
-    gemv(ctx, true, p, n, 1.0, mA.d(), p, dir + n, 1.0, res);                  // res.x += A' y
+    sgemv(true, p, n, 1.0, mA.d(), p, dir + n, 1.0, res);                  // res.x += A' y
     dev_scale_copy(ctx, p, tau_dir, mb.d(), res + n);                           // res.y = b tau - A x
-    gemv(ctx, false, p, n, -1.0, mA.d(), p, dir, 1.0, res + n);
+    sgemv(false, p, n, -1.0, mA.d(), p, dir, 1.0, res + n);
   }
   for (size_t k = 0; k < cones.size(); ++k) {   // res.s_k = H_k prim_dir_k + dual_dir_k
     Cone* ck = cones[k];

@@ -99,6 +99,7 @@ struct SysSolver {
   bool Gx_dir_valid = false;
   int dimv() const { return n + p + q + 1 + q + 1; }
   void load_model(const double* hc, const double* hb, const double* hh, const double* hA);
+  void sgemv(bool trans, int m, int n_, double alpha, const double* A, long lda, const double* x, double beta, double* y);
   void update_const();                                                          // qrchol.jl:191-197
   void update_const_pre();                                                      // the same in two halves around the triangular solves
   void update_const_post();
