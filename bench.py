@@ -406,6 +406,8 @@ def run_headline(args, world, rank, local_rank, multi, comm=None):
         lib.reset()
     n_solves0 = solver.n_solves
     n_trials0 = solver.stepper.searcher.n_trials
+    screen_stats = getattr(solver.syssolver, "search_screen_stats", None)
+    screens0 = screen_stats() if screen_stats is not None else (0, 0)
     for f in ("upsys", "upfact", "uprhs", "getdir", "search"):
         setattr(solver, "time_" + f, 0.0)
     lib.hyp_ctx_synchronize(ctx)      # (every C-ABI call is synchronous; this is the device-wide fence)
@@ -468,6 +470,10 @@ def run_headline(args, world, rank, local_rank, multi, comm=None):
         "kkt_solves_per_step": n_solves / args.steps,
         "ms_per_kkt_solve": solver.time_getdir / max(n_solves, 1) * 1e3,
         "search_trials_per_step": n_trials / args.steps,
+        # of those, the candidates the side-by-side screen rejected (batches of up to 8, one read-back each) -- the others
+        # went through the sequential acceptance test
+        "search_screens_per_step": ((screen_stats()[0] - screens0[0]) / args.steps) if screen_stats is not None else 0.0,
+        "search_trials_screened_out_per_step": ((screen_stats()[1] - screens0[1]) / args.steps) if screen_stats is not None else 0.0,
         "setup_s": t_setup,
         # the reference's ten timers (Solvers.jl:86-96): set-up ones for the whole solve set-up, the others per timed step
         "hypatia_timers_s": {"rescale": getattr(solver, "time_rescale", 0.0), "initx": getattr(solver, "time_initx", 0.0),

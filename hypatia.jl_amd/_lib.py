@@ -98,6 +98,9 @@ SIGNATURES = {
     "hyp_sys_bench_gemv": [c_vp, c_int, c_vp],
     "hyp_sys_search_alpha": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_dbl, c_dbl, c_int, c_dbl, c_vp,
                              P(c_int), P(c_dbl), P(c_int), P(c_int), P(c_dbl)],
+    "hyp_sys_search_screen_stats": [c_vp, P(c_int), c_vp, c_vp],
+    "hyp_sys_search_alpha_resident": [c_vp, c_int, c_int, c_vp, c_int, c_int, c_dbl, c_dbl, c_int, c_dbl, c_vp,
+                                      P(c_int), P(c_dbl), P(c_int), P(c_int), P(c_dbl)],
     "hyp_sys_check_cone_points": [c_vp, c_vp, c_dbl, c_dbl, c_int, c_dbl, P(c_int), P(c_dbl), P(c_int), P(c_dbl)],
     "hyp_sys_residual_products": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "hyp_sys_allreduce_host": [c_vp, c_vp, c_int, c_int],

@@ -750,6 +750,21 @@ int hyp_sys_search_alpha(hyp_sys* sys, const double* point_ztsk, const double* d
                                          nsched, start, min_prox, prox_bound, use_max_prox != 0, nup1, cand_ztsk, prox, n_trials, n_loaded, irtmu);
   API_END(sys->ctx)
 }
+int hyp_sys_search_alpha_resident(hyp_sys* sys, int unadj_only, int cent_only, const double* alpha_sched, int nsched, int start, double min_prox,
+                                  double prox_bound, int use_max_prox, double nup1, double* cand_ztsk, int* accepted_index, double* prox,
+                                  int* n_trials, int* n_loaded, double* irtmu) {
+  API_BEGIN
+  *accepted_index = sys->s->search_alpha(nullptr, nullptr, nullptr, nullptr, nullptr, unadj_only != 0, cent_only != 0, alpha_sched, nsched, start,
+                                         min_prox, prox_bound, use_max_prox != 0, nup1, cand_ztsk, prox, n_trials, n_loaded, irtmu, true);
+  API_END(sys->ctx)
+}
+int hyp_sys_search_screen_stats(hyp_sys* sys, int* usable, long long* screens, long long* rejected) {
+  API_BEGIN
+  *usable = sys->s->screen_usable() ? 1 : 0;
+  *screens = sys->s->screen_count;
+  *rejected = sys->s->screen_rejected;
+  API_END(sys->ctx)
+}
 int hyp_sys_get_lhs(hyp_sys* sys, double* out) {
   API_BEGIN
   Ctx& c = sys->ctx->c;

@@ -1064,6 +1064,7 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   *n_solves = 0;
   *info = 0;
   *used_fallback = 0;
+  s_resident = false;
   // The caller's vectors are pageable: a hipMemcpyAsync on them stops the host until the copy is done, which left the device
   // idle for 80-170 us at each of the two direction downloads in the middle of this call (profiles/r02_iteration_timeline.txt).
   // Everything travels through the library's pinned staging instead ([point | residuals | sol_const | four directions]); the
@@ -1121,7 +1122,7 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   res_norms[0] = rn[0];
   res_norms[1] = rn[1];
   ctx.d2h(hs_dirs, m_dir.d(), (size_t)MR * dv * d);
-  s_dirs.ensure((size_t)MR * dv * d);
+  s_dirs.ensure((size_t)2 * MR * dv * d);   // (all four directions stay here for search_alpha(..., resident))
   ctx.d2d(s_dirs.p, m_dir.p, (size_t)MR * dv * d);
   const double dtau[MR] = {dsc[0].tau, dsc[1].tau};
   const Scal d01[MR] = {dsc[0], dsc[1]};
@@ -1133,6 +1134,7 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   res_norms[2] = rn[0];
   res_norms[3] = rn[1];
   ctx.d2h(hs_dirs + (long)MR * dv, m_dir.d(), (size_t)MR * dv * d);
+  ctx.d2d(s_dirs.d() + (long)MR * dv, m_dir.p, (size_t)MR * dv * d);
   ctx.sync();
   std::memcpy(h_dirs, hs_dirs, (size_t)2 * MR * dv * d);
   if (h_sol_const) std::memcpy(h_sol_const, hs_const, (size_t)it * d);
@@ -1141,7 +1143,14 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
     h_dirs[(long)r * dv + ik] = d01[r].kap;
     h_dirs[(long)(MR + r) * dv + it] = dsc[r].tau;
     h_dirs[(long)(MR + r) * dv + ik] = dsc[r].kap;
+    s_tk[1 + r][0] = d01[r].tau;
+    s_tk[1 + r][1] = d01[r].kap;
+    s_tk[1 + MR + r][0] = dsc[r].tau;
+    s_tk[1 + MR + r][1] = dsc[r].kap;
   }
+  s_tk[0][0] = tau;
+  s_tk[0][1] = kap;
+  s_resident = (MR == 2);   // the point (s_point) and the four directions (s_dirs) are on the device until the next call
 }
 
 }  // namespace hyp

@@ -3,6 +3,7 @@
 // Reference: /root/reference/src/Solvers/systemsolvers/qrchol.jl (line ranges inline).
 #include <cstring>
 #include "syssolver.hpp"
+#include <chrono>
 
 namespace hyp {
 
@@ -1054,43 +1055,255 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
   return true;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Side-by-side screening of line-search candidates (see syssolver.hpp).  The schedule walk of search.jl:46-69 visits the
+// candidates one after the other, and each visit is a latency-bound chain of small kernels (two side-200 factorizations, one
+// two-sided product, two read-backs: ~200 us on an otherwise idle chip) behind 20 us of host arithmetic that forms the
+// candidate; config 2 walks 7.8 candidates per iteration.  The candidates are known in advance (the schedule is fixed), so the
+// tests that REJECT -- search.jl:86-116 on the scalars, PosSemidefTri's update_feas / is_dual_feas (possemideftri.jl:80-95)
+// and the proximity bound (Cones.jl:294-310, in the inverse-free form of PsdCone::prox_lower_bound) -- run for all remaining
+// candidates of the schedule at once, batch = candidates.  The walk then skips what the screen rejected and hands the first
+// survivor to check_cone_points: acceptance, the cone's state afterwards and the trial count are those of the sequential walk.
+// The screen's numbers are not bitwise the sequential test's (tree-summed <z, s>, factor of the unscaled primal point, GEMM
+// route for U Z U'), so it rejects only beyond a relative margin of 1e-6 on the scalar tests and 1e-5 on the proximity value.
+// ---------------------------------------------------------------------------------------------
+struct ScreenForm {
+  double alpha[SysSolver::SCREEN_MAX], a2[SysSolver::SCREEN_MAX], am1[SysSolver::SCREEN_MAX], am1s[SysSolver::SCREEN_MAX];
+  double tau[SysSolver::SCREEN_MAX], kap[SysSolver::SCREEN_MAX];   // the candidates' tau / kap (formed on the host)
+  int mode;   // 0: pt + alpha dc; 1: pt + (alpha dp + am1 dc); 2: pt + (alpha dc + a2 dca); 3: all four (combined.jl:124-170)
+};
+// candidate g = update_stepper_points(alpha_g) over the ztsk rows, the host loop's operations in the host loop's order (no
+// contraction: a survivor downloaded from here is bitwise the candidate the host forms)
+__global__ __launch_bounds__(256) void screen_form_kernel(int q, const double* __restrict__ pt, const double* __restrict__ dc,
+                                                          const double* __restrict__ dp, const double* __restrict__ dca,
+                                                          const double* __restrict__ dpa, ScreenForm f, double* __restrict__ cands) {
+#pragma clang fp contract(off)   // (device code contracts a * b + c into an fma by default, and ROCm's __dadd_rn is a plain +)
+  const int len = 2 * q + 2;
+  const int i = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+  if (i >= len) return;
+  double v;
+  if (i == q) v = f.tau[g];
+  else if (i == len - 1) v = f.kap[g];
+  else {
+    const double al = f.alpha[g];
+    if (f.mode == 0) v = pt[i] + al * dc[i];
+    else if (f.mode == 1) v = pt[i] + (al * dp[i] + f.am1[g] * dc[i]);
+    else if (f.mode == 2) v = pt[i] + (al * dc[i] + f.a2[g] * dca[i]);
+    else v = pt[i] + (((al * dp[i] + f.a2[g] * dpa[i]) + f.am1[g] * dc[i]) + f.am1s[g] * dca[i]);
+  }
+  cands[(long)g * len + i] = v;
+}
+struct ScreenScal { double v[SysSolver::SCREEN_MAX]; };
+// sz_g = <z_g, s_g>; scal_g = 1 / mu_g with mu_g = (sz_g + taukap_g) / nup1   (search.jl:90-100); one workgroup per candidate
+__global__ __launch_bounds__(1024) void screen_dot_kernel(int dm, const double* __restrict__ cands, long len, long off_s, ScreenScal taukap,
+                                                          double nup1, double* __restrict__ sz, double* __restrict__ scal) {
+  __shared__ double red[1024];
+  const int g = blockIdx.x;
+  const double* z = cands + (long)g * len;
+  const double* sv = z + off_s;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < dm; i += 1024) acc = fma(z[i], sv[i], acc);
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    sz[g] = red[0];
+    scal[g] = nup1 / (red[0] + taukap.v[g]);
+  }
+}
+// out[g] = || scal_g W_g - I ||_F^2 over the full side x side matrix W_g (= the svec sum of psd_prox_direct_kernel for a symmetric W)
+__global__ __launch_bounds__(1024) void screen_prox_kernel(int side, const double* __restrict__ W, long stride, const double* __restrict__ scal_d,
+                                                           double* __restrict__ out) {
+  __shared__ double red[1024];
+  const int g = blockIdx.x;
+  const double* w = W + (long)g * stride;
+  const double scal = scal_d[g];
+  const int tot = side * side;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < tot; i += 1024) {
+    const int c = i / side, r = i - c * side;
+    const double v = scal * w[i] - (r == c ? 1.0 : 0.0);
+    s = fma(v, v, s);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[g] = red[0];
+}
+
+bool SysSolver::screen_usable() const {
+  static const bool on = [] { const char* e = getenv("HYP_SEARCH_SCREEN"); return !(e && e[0] == '0'); }();
+  static const bool lb_on = [] { const char* e = getenv("HYP_PROX_LB"); return !(e && e[0] == '0'); }();
+  if (!on || !lb_on || dist() || cones.size() != 1 || cones[0]->kind != CONE_PSD || cones[0]->use_dual_barrier) return false;
+  return static_cast<const PsdCone*>(cones[0])->side >= 32;
+}
+
+void SysSolver::screen_candidates(const double* cd, int K, const double* tau, const double* kap, double min_prox, double prox_bound,
+                                  double nup1, char* rej) {
+  const double EPS = 2.220446049250313e-16;
+  HYP_REQUIRE(K >= 1 && K <= SCREEN_MAX, "screen_candidates: batch size");
+  const PsdCone* pc = static_cast<const PsdCone*>(cones[0]);
+  const int sd = pc->side, dm = pc->dim;
+  const long len = 2L * q + 2, s2 = (long)sd * sd;
+  const double proxsqr_bound = prox_bound * prox_bound;
+  ScreenScal tk{};
+  for (int g = 0; g < K; ++g) tk.v[g] = tau[g] * kap[g];
+  // device layout behind the candidates (screen_buf, laid out by search_alpha): 2 K matrices (K primal, K dual: ONE batched
+  // factorization) | U' | smat(dual) | Z U' | U Z U' | K x [<z, s>, 1 / mu, proximity value]
+  double* P = screen_buf.d() + (long)SCREEN_MAX * len;
+  double* D = P + K * s2;
+  double* UT = D + K * s2;
+  double* Z = UT + K * s2;
+  double* T = Z + K * s2;
+  double* W = T + K * s2;
+  double* outv = screen_buf.d() + (long)SCREEN_MAX * len + 6L * SCREEN_MAX * s2;
+  screen_info.ensure((size_t)2 * SCREEN_MAX * sizeof(int));
+  hipLaunchKernelGGL(screen_dot_kernel, dim3(K), dim3(1024), 0, ctx.stream, dm, cd, len, (long)q + 1, tk, nup1, outv, outv + SCREEN_MAX);
+  svec_unpack(ctx, sd, K, cd + q + 1, len, P);              // PsdCone::update_feas (possemideftri.jl:80-90), of the UNSCALED s:
+                                                            // the factor of s / sqrt(mu) is this one over mu^(1/4)
+  svec_unpack(ctx, sd, K, cd, len, D);                      // PsdCone::is_dual_feas (:92-95): z sits at the head of a candidate
+  ctx.d2d(Z, D, (size_t)K * s2 * sizeof(double));
+  potrf_upper_batched(ctx, sd, P, sd, s2, 2 * K, nullptr, screen_info.i());
+  // PsdCone::prox_lower_bound: || U Z U' / mu - I ||_F^2 with U' U = smat(s)
+  dev_zero_strict_lower(ctx, sd, P, sd, K, s2);
+  dev_transpose(ctx, sd, sd, P, sd, UT, sd, K, s2, s2);
+  GemmArgs a{};   // T = Z U'  (Z symmetric: its transpose form; U' lower triangular)
+  a.M = sd; a.N = sd; a.K = sd; a.A = Z; a.lda = sd; a.strideA = s2; a.B = UT; a.ldb = sd; a.strideB = s2; a.C = T; a.ldc = sd; a.strideC = s2;
+  a.alpha = 1; a.beta = 0; a.tri = GEMM_FULL; a.krange = KR_GE_N; a.batch = K;
+  gemm(ctx, true, a);
+  GemmArgs b{};   // W = U T  (op(A) = (U')' = U upper triangular)
+  b.M = sd; b.N = sd; b.K = sd; b.A = UT; b.lda = sd; b.strideA = s2; b.B = T; b.ldb = sd; b.strideB = s2; b.C = W; b.ldc = sd; b.strideC = s2;
+  b.alpha = 1; b.beta = 0; b.tri = GEMM_FULL; b.krange = KR_GE_M; b.batch = K;
+  gemm(ctx, true, b);
+  hipLaunchKernelGGL(screen_prox_kernel, dim3(K), dim3(1024), 0, ctx.stream, sd, W, s2, outv + SCREEN_MAX, outv + 2 * SCREEN_MAX);
+  HYP_CHECK(hipGetLastError());
+  int* hi = ctx.h_info + 64;
+  double* hv = ctx.h_pinned + 64;
+  ctx.d2h(hi, screen_info.p, (size_t)2 * K * sizeof(int));
+  ctx.d2h(hv, outv, (size_t)3 * SCREEN_MAX * sizeof(double));
+  ctx.sync();
+  ++screen_count;
+  const double M = 1e-6;
+  auto lt = [M](double x, double y) { return x < y - M * std::fabs(y); };   // x < y beyond the margin (false for NaN)
+  auto gt = [M](double x, double y) { return x > y + M * std::fabs(y); };
+  const double limit = proxsqr_bound * (1.0 + 1e-9);
+  for (int g = 0; g < K; ++g) {   // search.jl:86-116 in the order of check_cone_points
+    const double taukap = tk.v[g], sz = hv[g], v = hv[2 * SCREEN_MAX + g];
+    const double mu = (sz + taukap) / nup1, taukap_rel = taukap / mu, nu_k = pc->nu, rel = sz / (mu * nu_k);
+    bool r = false;
+    if (std::min(std::min(tau[g], kap[g]), taukap) < EPS) r = true;   // (exact: host scalars)
+    else if (lt(sz, EPS) || lt(mu, EPS)) r = true;
+    else if (lt(taukap_rel, min_prox) || gt((taukap_rel - 1.0) * (taukap_rel - 1.0), proxsqr_bound)) r = true;
+    else if (lt(rel, min_prox) || gt(nu_k * (rel - 1.0) * (rel - 1.0), proxsqr_bound)) r = true;
+    else if (hi[g] != 0 || hi[K + g] != 0) r = true;
+    else if (v == v && v < INFINITY && v / (1.0 + 1e-5) > limit) r = true;
+    rej[g] = r ? 1 : 0;
+    screen_rejected += rej[g];
+  }
+}
+
 int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp, const double* dca, const double* dpa, bool unadj_only,
                             bool cent_only, const double* sched, int nsched, int start, double min_prox, double prox_bound,
                             bool use_max_prox, double nup1, double* cand, double* prox_out, int* n_trials, int* n_loaded,
-                            double* irtmu_out) {
+                            double* irtmu_out, bool resident) {
   const int len = 2 * q + 2;
   *n_trials = 0;
   *n_loaded = 0;
-  // candidates are formed in pinned memory (two halves in turn) and only the accepted one is copied to the caller's vector:
+  const bool screen = screen_usable();
+  HYP_REQUIRE(!resident || (screen && s_resident), "search_alpha: no resident directions (step_directions first; one PosSemidefTri cone)");
+  // candidates are formed in pinned memory and only the accepted one is copied to the caller's vector:
   // the upload inside check_cone_points is then a plain asynchronous copy -- from the caller's pageable vector it stopped the
   // host for the whole transfer, once per trial
-  double* const stage = ctx.stage_host((size_t)2 * len);
+  double* const stage = ctx.stage_host((size_t)(screen && !resident ? SCREEN_MAX : 2) * len);
   double* const out = cand;
-  for (int idx = start; idx < nsched; ++idx) {
-    const double alpha = sched[idx];
-    cand = stage + (size_t)((idx - start) & 1) * len;
-    // update_stepper_points (combined.jl:124-170), same operation order as the host mirror
-    if (unadj_only) {
-      if (cent_only) {
-        for (int i = 0; i < len; ++i) cand[i] = pt[i] + alpha * dc[i];
-      } else {
-        const double am1 = 1.0 - alpha;
-        for (int i = 0; i < len; ++i) cand[i] = pt[i] + (alpha * dp[i] + am1 * dc[i]);
-      }
+  const int mode = unadj_only ? (cent_only ? 0 : 1) : (cent_only ? 2 : 3);
+  auto coef = [&](double alpha, double& a2, double& am1, double& am1s) { a2 = alpha * alpha; am1 = 1.0 - alpha; am1s = am1 * am1; };
+  auto form1 = [&](double alpha, double p0, double c0, double p1, double ca, double pa) {   // update_stepper_points (combined.jl:124-170)
+    double a2, am1, am1s;
+    coef(alpha, a2, am1, am1s);
+    if (mode == 0) return p0 + alpha * c0;
+    if (mode == 1) return p0 + (alpha * p1 + am1 * c0);
+    if (mode == 2) return p0 + (alpha * c0 + a2 * ca);
+    return p0 + (((alpha * p1 + a2 * pa) + am1 * c0) + am1s * ca);
+  };
+  auto form = [&](double* c, double alpha) {   // same operation order as the host mirror
+    double a2, am1, am1s;
+    coef(alpha, a2, am1, am1s);
+    if (mode == 0) {
+      for (int i = 0; i < len; ++i) c[i] = pt[i] + alpha * dc[i];
+    } else if (mode == 1) {
+      for (int i = 0; i < len; ++i) c[i] = pt[i] + (alpha * dp[i] + am1 * dc[i]);
+    } else if (mode == 2) {
+      for (int i = 0; i < len; ++i) c[i] = pt[i] + (alpha * dc[i] + a2 * dca[i]);
     } else {
-      const double a2 = alpha * alpha;
-      if (cent_only) {
-        for (int i = 0; i < len; ++i) cand[i] = pt[i] + (alpha * dc[i] + a2 * dca[i]);
-      } else {
-        const double am1 = 1.0 - alpha, am1s = am1 * am1;
-        for (int i = 0; i < len; ++i) cand[i] = pt[i] + (((alpha * dp[i] + a2 * dpa[i]) + am1 * dc[i]) + am1s * dca[i]);
-      }
+      for (int i = 0; i < len; ++i) c[i] = pt[i] + (((alpha * dp[i] + a2 * dpa[i]) + am1 * dc[i]) + am1s * dca[i]);
     }
+  };
+  int idx = start;
+  while (idx < nsched) {
+    const int K = screen ? std::min((int)SCREEN_MAX, nsched - idx) : 1;
+    if (K >= 2 || resident) {
+      char rej[SCREEN_MAX];
+      double ctau[SCREEN_MAX], ckap[SCREEN_MAX];
+      const long s2 = (long)static_cast<const PsdCone*>(cones[0])->side * static_cast<const PsdCone*>(cones[0])->side;
+      screen_buf.ensure((size_t)((long)SCREEN_MAX * len + 6L * SCREEN_MAX * s2 + 3 * SCREEN_MAX) * sizeof(double));
+      double* cd = screen_buf.d();
+      if (resident) {   // the five vectors are on the device: so are the candidates
+        ScreenForm f{};
+        f.mode = mode;
+        for (int g = 0; g < K; ++g) {
+          const double al = sched[idx + g];
+          f.alpha[g] = al;
+          coef(al, f.a2[g], f.am1[g], f.am1s[g]);
+          f.tau[g] = ctau[g] = form1(al, s_tk[0][0], s_tk[1][0], s_tk[2][0], s_tk[3][0], s_tk[4][0]);
+          f.kap[g] = ckap[g] = form1(al, s_tk[0][1], s_tk[1][1], s_tk[2][1], s_tk[3][1], s_tk[4][1]);
+        }
+        const long dv = dimv(), o = n + p;
+        const double* D = s_dirs.d();
+        hipLaunchKernelGGL(screen_form_kernel, dim3((len + 255) / 256, K), dim3(256), 0, ctx.stream, q, s_point.d() + o, D + o, D + dv + o,
+                           D + 2 * dv + o, D + 3 * dv + o, f, cd);
+      } else {
+        for (int g = 0; g < K; ++g) {
+          double* c = stage + (size_t)g * len;
+          form(c, sched[idx + g]);
+          ctau[g] = c[q];
+          ckap[g] = c[len - 1];
+        }
+        ctx.h2d(cd, stage, (size_t)K * len * sizeof(double));
+      }
+      screen_candidates(cd, K, ctau, ckap, min_prox, prox_bound, nup1, rej);
+      for (int g = 0; g < K; ++g) {
+        ++*n_trials;
+        if (rej[g]) continue;
+        if (resident) {   // a survivor comes back for the sequential test (bitwise the candidate the host would have formed)
+          cand = stage;
+          ctx.d2h(cand, cd + (size_t)g * len, (size_t)len * sizeof(double));
+          ctx.sync();
+        } else {
+          cand = stage + (size_t)g * len;
+        }
+        if (check_cone_points(cand, min_prox, prox_bound, use_max_prox, nup1, prox_out, n_loaded, irtmu_out)) {
+          std::memcpy(out, cand, (size_t)len * sizeof(double));
+          return idx + g;
+        }
+      }
+      idx += K;
+      continue;
+    }
+    cand = stage + (size_t)((idx - start) & 1) * len;
+    form(cand, sched[idx]);
     ++*n_trials;
     if (check_cone_points(cand, min_prox, prox_bound, use_max_prox, nup1, prox_out, n_loaded, irtmu_out)) {
       std::memcpy(out, cand, (size_t)len * sizeof(double));
       return idx;
     }
+    ++idx;
   }
   return -1;
 }

@@ -112,6 +112,24 @@ struct SysSolver {
   DBuf cand_d;
   bool check_cone_points(const double* h_ztsk, double min_prox, double prox_bound, bool use_max_prox, double nup1, double* prox_out,
                          int* n_loaded, double* irtmu_out);
+  // Side-by-side screening of the remaining candidates of the schedule walk (a model of ONE primal-barrier PosSemidefTri cone,
+  // single process): the two feasibility factorizations and the inverse-free proximity value of up to SCREEN_MAX candidates
+  // in one batched launch sequence and one read-back.  rej[g] = 1 only where check_cone_points would certainly reject
+  // candidate g (scalar tests, a failed factorization, or the proximity bound missed by more than the rounding of the two
+  // routes); every other candidate still goes through check_cone_points, which alone accepts.
+  // The candidates are formed ON THE DEVICE when the point and the four directions are still there from step_directions
+  // (search_alpha(..., resident = true)); otherwise on the host and uploaded.
+  static constexpr int SCREEN_MAX = 18;   // the reference's whole schedule (search.jl:41-43)
+  DBuf screen_buf, screen_info;
+  long screen_count = 0, screen_rejected = 0;   // statistics: screens run, candidates they rejected
+  bool screen_usable() const;
+  // d_cands: K candidates [z; tau; s; kap] of length 2 q + 2 on the device (their tau / kap slots are not read: tau, kap)
+  void screen_candidates(const double* d_cands, int K, const double* tau, const double* kap, double min_prox, double prox_bound, double nup1,
+                         char* rej);
+  // what step_directions left on the device: the point, the four directions (s_dirs: cent, pred, centadj, predadj) and the
+  // tau / kap entries of the five vectors (which travel on the host)
+  bool s_resident = false;
+  double s_tk[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
   double residual(double* res, const double* dir, const double* rhs, Scal rs, Scal dcur, Scal& rsc, double mu, double taubar);
   double refine(double* rhs, double* dir, double* res, double* tmp, Scal rs, Scal& dsc, Scal rsc, double res_norm, double mu, double taubar,
                 int max_ref_steps, double res_norm_cutoff, double min_impr_tol, int* n_solves);
@@ -126,7 +144,8 @@ struct SysSolver {
   // host `ztsk` views (length 2 q + 2): the current point and the four stepper directions
   int search_alpha(const double* pt, const double* d_cent, const double* d_pred, const double* d_centadj, const double* d_predadj,
                    bool unadj_only, bool cent_only, const double* sched, int nsched, int start, double min_prox, double prox_bound,
-                   bool use_max_prox, double nup1, double* cand_out, double* prox_out, int* n_trials, int* n_loaded, double* irtmu_out);
+                   bool use_max_prox, double nup1, double* cand_out, double* prox_out, int* n_trials, int* n_loaded, double* irtmu_out,
+                   bool resident = false);   // resident: the five vectors are those step_directions left on the device (host pointers unused)
   // ---- the direction phase of CombinedStepper.step (steppers/combined.jl:60-95) in one call: update_lhs, the four
   // right-hand sides of steppers/common.jl:7-118 built on the device, and the two paired solves.  h_point = current
   // Point vector; h_res = [x_residual(n); y_residual(p); z_residual(q)] and tau_residual from calc_convergence_params;

@@ -471,21 +471,25 @@ class CombinedStepper:
             self.dir_predadj.vec[:] = dir.vec
 
         self.unadj_only = self.cent_only = False
-        t0 = T(); alpha = search_alpha(point, model, self); solver.time_search += T() - t0
-        if alpha == 0:
-            self.unadj_only = True
+        try:
             t0 = T(); alpha = search_alpha(point, model, self); solver.time_search += T() - t0
             if alpha == 0:
-                self.cent_only = True
-                self.unadj_only = False
+                self.unadj_only = True
                 t0 = T(); alpha = search_alpha(point, model, self); solver.time_search += T() - t0
                 if alpha == 0:
-                    self.unadj_only = True
+                    self.cent_only = True
+                    self.unadj_only = False
                     t0 = T(); alpha = search_alpha(point, model, self); solver.time_search += T() - t0
                     if alpha == 0:
-                        solver.status = "NumericalFailure"
-                        self.prev_alpha = alpha
-                        return False
+                        self.unadj_only = True
+                        t0 = T(); alpha = search_alpha(point, model, self); solver.time_search += T() - t0
+                        if alpha == 0:
+                            solver.status = "NumericalFailure"
+                            self.prev_alpha = alpha
+                            return False
+        finally:
+            if fused:
+                sysv._dirs_resident = False   # (the point moves below: the device copies of this step's vectors are stale)
         sysv = solver.syssolver
         if getattr(sysv, "row_local", False):
             # cone-sharded solver: this rank's rows of z / s (and tau, kap) are the accepted candidate the library formed and

@@ -157,6 +157,7 @@ class QRCholDenseSystemSolver:
         assert not any(np.isnan(resn[k]) for k in range(4))
         if solver.max_ref_steps > 0:
             solver.worst_dir_res = max(solver.worst_dir_res, *[resn[k] for k in range(4)])
+        self._dirs_resident = True   # (until CombinedStepper.step is done with its searches: search_alpha_native)
         return True
 
     def last_update_lhs_seconds(self):
@@ -195,12 +196,20 @@ class QRCholDenseSystemSolver:
         cand = stepper.temp
         idx, nt, nl = c_int(-1), c_int(0), c_int(0)
         prox, irtmu = ctypes.c_double(0.0), ctypes.c_double(0.0)
-        L.check(L.lib().hyp_sys_search_alpha(
-            self._h, L.vec_ptr(point.ztsk), L.vec_ptr(stepper.dir_cent.ztsk), L.vec_ptr(stepper.dir_pred.ztsk),
-            L.vec_ptr(stepper.dir_centadj.ztsk), L.vec_ptr(stepper.dir_predadj.ztsk), int(stepper.unadj_only), int(stepper.cent_only),
-            L.vec_ptr(sc), len(sc), int(sched - 1), float(searcher.min_prox), float(searcher.prox_bound), int(bool(searcher.use_max_prox)),
-            float(searcher.nup1), L.vec_ptr(cand.ztsk), ctypes.byref(idx), ctypes.byref(prox), ctypes.byref(nt), ctypes.byref(nl),
-            ctypes.byref(irtmu)), "hyp_sys_search_alpha")
+        if getattr(self, "_dirs_resident", False) and self._screen_ok():
+            # the point and the directions are the ones step_directions_native left on the device (the stepper has not touched
+            # them since): the schedule's candidates are formed and screened there, nothing of length q is uploaded
+            L.check(L.lib().hyp_sys_search_alpha_resident(
+                self._h, int(stepper.unadj_only), int(stepper.cent_only), L.vec_ptr(sc), len(sc), int(sched - 1), float(searcher.min_prox),
+                float(searcher.prox_bound), int(bool(searcher.use_max_prox)), float(searcher.nup1), L.vec_ptr(cand.ztsk), ctypes.byref(idx),
+                ctypes.byref(prox), ctypes.byref(nt), ctypes.byref(nl), ctypes.byref(irtmu)), "hyp_sys_search_alpha_resident")
+        else:
+            L.check(L.lib().hyp_sys_search_alpha(
+                self._h, L.vec_ptr(point.ztsk), L.vec_ptr(stepper.dir_cent.ztsk), L.vec_ptr(stepper.dir_pred.ztsk),
+                L.vec_ptr(stepper.dir_centadj.ztsk), L.vec_ptr(stepper.dir_predadj.ztsk), int(stepper.unadj_only), int(stepper.cent_only),
+                L.vec_ptr(sc), len(sc), int(sched - 1), float(searcher.min_prox), float(searcher.prox_bound),
+                int(bool(searcher.use_max_prox)), float(searcher.nup1), L.vec_ptr(cand.ztsk), ctypes.byref(idx), ctypes.byref(prox),
+                ctypes.byref(nt), ctypes.byref(nl), ctypes.byref(irtmu)), "hyp_sys_search_alpha")
         searcher.n_trials += nt.value
         for k in range(nl.value):
             model.cones[k]._mirror_loaded(cand.primal_views[k], irtmu.value, cand.dual_views[k])
@@ -210,6 +219,22 @@ class QRCholDenseSystemSolver:
             return float(sc[idx.value])
         searcher.prev_sched = len(sc) + 1
         return 0.0
+
+    def _screen_ok(self):
+        """the side-by-side candidate screen applies to the loaded model (one PosSemidefTri cone) and HYP_SEARCH_RESIDENT is not 0"""
+        if not hasattr(self, "_screen_usable"):
+            self.search_screen_stats()
+            if os.environ.get("HYP_SEARCH_RESIDENT", "1") == "0":
+                self._screen_usable = False
+        return self._screen_usable
+
+    def search_screen_stats(self):
+        """(screens run, candidates rejected by them) of the side-by-side candidate screen inside search_alpha_native"""
+        u, a, b = c_int(0), ctypes.c_longlong(0), ctypes.c_longlong(0)
+        L.check(L.lib().hyp_sys_search_screen_stats(self._h, ctypes.byref(u), ctypes.byref(a), ctypes.byref(b)), "hyp_sys_search_screen_stats")
+        if not hasattr(self, "_screen_usable"):
+            self._screen_usable = bool(u.value)
+        return a.value, b.value
 
     # ---- common.jl:15-76 on the device
     def get_directions_native(self, solver, dir, rhs, min_impr_tol=0.5):

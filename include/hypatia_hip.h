@@ -255,6 +255,19 @@ int hyp_sys_search_alpha(hyp_sys* sys, const double* point_ztsk, const double* d
                          const double* dir_predadj, int unadj_only, int cent_only, const double* alpha_sched, int nsched, int start,
                          double min_prox, double prox_bound, int use_max_prox, double nup1, double* cand_ztsk, int* accepted_index,
                          double* prox, int* n_trials, int* n_loaded, double* irtmu);
+/* hyp_sys_search_alpha for the point and the four directions of the LAST hyp_sys_step_directions call, which are still on the
+ * device: nothing of length q is uploaded, the candidates of the whole schedule are formed there (combined.jl:124-170, the host
+ * loop's operations in the host loop's order) and screened side by side; only a candidate that survives the screen comes back for
+ * the sequential acceptance test.  For the caller who has not touched the vectors since that call (steppers/combined.jl:60-118
+ * does not).  Error unless hyp_sys_search_screen_stats reports usable and a step_directions call preceded. */
+int hyp_sys_search_alpha_resident(hyp_sys* sys, int unadj_only, int cent_only, const double* alpha_sched, int nsched, int start, double min_prox,
+                                  double prox_bound, int use_max_prox, double nup1, double* cand_ztsk, int* accepted_index, double* prox,
+                                  int* n_trials, int* n_loaded, double* irtmu);
+/* The side-by-side candidate screen inside hyp_sys_search_alpha[_resident] (a model of one primal-barrier PosSemidefTri cone, single
+ * process: the rejecting tests of search.jl:86-116 / possemideftri.jl:80-95 / Cones.jl:294-310 for all remaining candidates of the
+ * schedule at once; acceptance stays with the sequential test): usable = 1 where it applies (0: HYP_SEARCH_SCREEN=0, several
+ * cones, sharded), screens run so far and candidates they rejected. */
+int hyp_sys_search_screen_stats(hyp_sys* sys, int* usable, long long* screens, long long* rejected);
 int hyp_sys_get_lhs(hyp_sys* sys, double* out_nmpxnmp);        /* upper triangle meaningful (tests) */
 
 /* ---- dense kernels exposed for parity tests and micro-benchmarks ------------------------------- */

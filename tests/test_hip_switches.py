@@ -22,6 +22,8 @@ if name == "matrixcompletion":
     inst = I.matrixcompletion(12, 20, seed=3)
 elif name == "psd_single":
     inst = I.psd_blocks(40, [48], seed=5)
+elif name == "psd_single_wide":             # one cone of side 72 (three 16-column tile rows and a ragged one)
+    inst = I.psd_blocks(90, [72], seed=9)
 elif name == "psd_pair":
     inst = I.psd_blocks(50, [40, 33], seed=6)
 elif name == "psd_plan":                     # n = 600: the factor has a super-block solve plan (n >= 512)
@@ -43,7 +45,9 @@ trace = []
 s.iter_callback = lambda sv: trace.append((sv.primal_obj, sv.dual_obj, sv.mu, sv.point.tau, sv.x_feas, sv.z_feas))
 s.load(H.make_model(inst))
 s.solve()
-print(json.dumps({"status": s.get_status(), "iters": s.get_num_iters(), "obj": s.get_primal_obj(), "trace": trace}))
+screens = s.syssolver.search_screen_stats() if hasattr(s.syssolver, "search_screen_stats") else (0, 0)
+print(json.dumps({"status": s.get_status(), "iters": s.get_num_iters(), "obj": s.get_primal_obj(), "trace": trace,
+                  "trials": s.stepper.searcher.n_trials, "screens": screens}))
 """
 
 
@@ -98,3 +102,24 @@ def test_constant_column_in_the_first_paired_solve_changes_no_bit():
         assert all(r["status"] == "Optimal" for r in runs)
         assert runs[0]["iters"] == runs[1]["iters"] == runs[2]["iters"] >= 8
         assert runs[0]["trace"] == runs[1]["trace"] == runs[2]["trace"], name
+
+
+@pytest.mark.parametrize("name", ["psd_single", "psd_single_wide"])
+def test_screened_schedule_walk_changes_no_bit(name):
+    """round 3: for a model of one PosSemidefTri cone the schedule walk of search_alpha screens all remaining candidates side by
+    side (HYP_SEARCH_SCREEN) -- the tests that reject, batched over the candidates -- and only survivors go
+    through the sequential acceptance test; in the fused step the candidates are formed on the device from the directions
+    step_directions left there (HYP_SEARCH_RESIDENT; off: formed on the host and uploaded).  The screen may only reject what the
+    sequential test rejects: same accepted step in every iteration, hence the same iterates to the last bit, and the same number
+    of candidates visited -- in all three forms."""
+    on = _run(name, {})
+    host = _run(name, {"HYP_SEARCH_RESIDENT": "0"})
+    off = _run(name, {"HYP_SEARCH_SCREEN": "0"})
+    assert on["status"] == host["status"] == off["status"] == "Optimal"
+    assert on["iters"] == host["iters"] == off["iters"] >= 8
+    assert on["trace"] == off["trace"]
+    assert host["trace"] == off["trace"]
+    assert on["trials"] == host["trials"] == off["trials"]
+    assert off["screens"] == [0, 0]
+    for r in (on, host):
+        assert r["screens"][0] >= r["iters"] and r["screens"][1] > 0   # (it ran, and it rejected something)

@@ -1,7 +1,11 @@
-export TMPDIR=/tmp
-timeout 300 python -m pytest tests/test_hip_cones.py -m gpu -q -x -k "psd or possemidef or beyond or oracle_vs_hip" 2>&1 | tail -2
-timeout 600 python -m pytest tests/test_hip_fullsize_configs.py -m gpu -q -x -k "config4 or 4" 2>&1 | tail -2
-for t in 1 0 1; do
-HYP_TS_TEAMS=$t timeout 300 python bench.py --config 4 --steps 8 --warmup 2 --cpu-iters 0 2>/dev/null | tail -1 > gpurun_out/ex4.json; python -c "
-import json; d=json.loads(open('gpurun_out/ex4.json').read()); print('teams $t', d['ms_per_step'], d['phases_ms_per_step']['sqrt_hess_prod'])"
+#!/bin/bash
+cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 300 python tools/_dbg_res.py 2>&1 | tail -4
+timeout 900 python -m pytest tests/test_hip_switches.py -q -x -m gpu -k "screened" 2>&1 | tail -8
+for e in "A=1" "HYP_SEARCH_RESIDENT=0" "HYP_SEARCH_SCREEN=0" "A=1"; do
+  env $e timeout 600 python bench.py --steps 60 --warmup 5 --cpu-iters 0 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.readlines()[-1])
+print('$e', round(d['ms_per_step'], 3), 'search', round(d['phases_ms_per_step']['search'], 3), 'trials', d['search_trials_per_step'], 'screens', d.get('search_screens_per_step'), 'rej', d.get('search_trials_screened_out_per_step'))"
 done
+timeout 1200 python -m pytest tests/test_hip_trajectory.py tests/test_hip_solver.py tests/test_hip_fullsize_configs.py -q -x -m gpu 2>&1 | tail -3
