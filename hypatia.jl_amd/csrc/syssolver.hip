@@ -960,7 +960,9 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
     if (tdbg && !ok) fprintf(stderr, "[trial] infeasible\n");
     // candidates far outside the neighbourhood: rejected on a lower bound of the proximity value, before any Hessian is
     // assembled or factored for them (Cone::prox_lower_bound; single process only -- sharded ranks leave together below)
-    if (ok && !dist() && nc <= 2) {   // (each bound is a read-back of its own: for models of one or two large cones)
+    // (not for a survivor of the side-by-side screen: the screen has just evaluated this very bound for it, batched with the
+    //  other candidates, and found it within the neighbourhood -- the proximity value itself decides below)
+    if (ok && !dist() && nc <= 2 && !screen_survivor) {   // (each bound is a read-back of its own: for models of one or two large cones)
       for (size_t k = 0; k < nc && ok; ++k) {
         double lb = 0.0;
         const bool have = cones[k]->prox_lower_bound(irtmu, proxsqr_bound * (1.0 + 1e-9), &lb);
@@ -1246,6 +1248,7 @@ int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp
     }
   };
   int idx = start;
+  static const bool skip_lb = [] { const char* e = getenv("HYP_SCREEN_SKIP_LB"); return !(e && e[0] == '0'); }();
   while (idx < nsched) {
     const int K = screen ? std::min((int)SCREEN_MAX, nsched - idx) : 1;
     if (K >= 2 || resident) {
@@ -1288,7 +1291,10 @@ int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp
         } else {
           cand = stage + (size_t)g * len;
         }
-        if (check_cone_points(cand, min_prox, prox_bound, use_max_prox, nup1, prox_out, n_loaded, irtmu_out)) {
+        screen_survivor = skip_lb;
+        const bool acc = check_cone_points(cand, min_prox, prox_bound, use_max_prox, nup1, prox_out, n_loaded, irtmu_out);
+        screen_survivor = false;
+        if (acc) {
           std::memcpy(out, cand, (size_t)len * sizeof(double));
           return idx + g;
         }

@@ -114,12 +114,14 @@ def test_screened_schedule_walk_changes_no_bit(name):
     of candidates visited -- in all three forms."""
     on = _run(name, {})
     host = _run(name, {"HYP_SEARCH_RESIDENT": "0"})
+    lb = _run(name, {"HYP_SCREEN_SKIP_LB": "0"})   # (a survivor's proximity lower bound evaluated again by the sequential test)
     off = _run(name, {"HYP_SEARCH_SCREEN": "0"})
-    assert on["status"] == host["status"] == off["status"] == "Optimal"
-    assert on["iters"] == host["iters"] == off["iters"] >= 8
+    assert on["status"] == host["status"] == lb["status"] == off["status"] == "Optimal"
+    assert on["iters"] == host["iters"] == lb["iters"] == off["iters"] >= 8
     assert on["trace"] == off["trace"]
     assert host["trace"] == off["trace"]
-    assert on["trials"] == host["trials"] == off["trials"]
+    assert lb["trace"] == off["trace"]
+    assert on["trials"] == host["trials"] == lb["trials"] == off["trials"]
     assert off["screens"] == [0, 0]
-    for r in (on, host):
+    for r in (on, host, lb):
         assert r["screens"][0] >= r["iters"] and r["screens"][1] > 0   # (it ran, and it rejected something)
