@@ -498,9 +498,13 @@ class CombinedStepper:
             sysv.accept_candidate(point)
             self.prev_alpha = alpha
             return True
-        self.update_stepper_points(alpha, point, False)
         if _cap(sysv, "search") and getattr(sysv, "cand_in_temp", True):
-            point.ztsk[:] = self.temp.ztsk   # exactly the accepted candidate the cones were loaded with (formed natively)
+            # the z / tau / s / kap rows ARE the accepted candidate the cones were loaded with (formed natively, same operations):
+            # only the x / y rows are formed here
+            self.update_stepper_points_x(alpha, point)
+            point.ztsk[:] = self.temp.ztsk
+        else:
+            self.update_stepper_points(alpha, point, False)
         self.prev_alpha = alpha
         return True
 
