@@ -947,7 +947,11 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
     ck->load_dual_point((ck->use_dual_barrier ? dsv : dz));
     ck->reset_data();
     *n_loaded = 1;
-    if (!dist() && ck->early_reject(irtmu, proxsqr_bound)) return false;   // (before the cone's feasibility work is queued)
+    if (!dist() && ck->early_reject(irtmu, proxsqr_bound)) {   // (before the cone's feasibility work is queued)
+      static const bool edbg = [] { const char* e = getenv("HYP_TRIAL_DBG"); return e && e[0] == '1'; }();
+      if (edbg) fprintf(stderr, "[trial] early reject (%s)\n", ck->is_feas() ? "bound" : "infeasible");
+      return false;
+    }
     ck->prefetch_feas();
     single_loaded = true;
   }
