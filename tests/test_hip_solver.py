@@ -475,6 +475,60 @@ def test_native_search_alpha_matches_host_walk():
     assert abs(prox_native - st.searcher.prox) <= 1e-9 * (1 + prox_native)
 
 
+def test_resident_search_alpha_same_candidate_and_error_paths():
+    """hyp_sys_search_alpha_resident (one PosSemidefTri cone: candidates formed on the device from what step_directions left
+    there, screened side by side) against hyp_sys_search_alpha on the host vectors of the same step: same accepted index, the
+    accepted candidate bit for bit, same proximity value, same number of candidates visited.  And its contract: an error
+    (no crash, message from hyp_last_error) without a preceding step_directions and for a model the screen does not apply to."""
+    import ctypes
+    import hypatia_jl_amd as H
+    from hypatia_jl_amd import _lib as L
+    from oracle import instances as I
+    inst = I.psd_blocks(40, [48], seed=5)
+    hs = H.Solver(iter_limit=3)
+    hs.load(H.make_model(inst)); hs.solve()
+    st, sysv = hs.stepper, hs.syssolver
+    assert sysv._screen_ok()
+    results = []
+    irtmu = 1.0 / np.sqrt(hs.mu)
+    for resident in (True, False):
+        for k, cone in enumerate(hs.model.cones):       # the cones back at the iterate (a search leaves them at its candidate)
+            cone.reset_data()
+            cone.load_point(hs.point.primal_views[k], irtmu)
+            cone.load_dual_point(hs.point.dual_views[k])
+            assert cone.is_feas()
+        hs.calc_convergence_params()
+        hs.res_norm_cutoff = 1e-4 * max(hs.x_norm_res, hs.y_norm_res, hs.z_norm_res, hs.tau_feas)
+        assert sysv.step_directions_native(hs, st)      # (same point both times: the same directions to the last bit)
+        sysv._dirs_resident = resident
+        st.unadj_only = st.cent_only = False
+        n0 = st.searcher.n_trials
+        a = sysv.search_alpha_native(hs.model, hs.point, st, 1)
+        results.append((a, st.temp.ztsk.copy(), st.searcher.prox, st.searcher.n_trials - n0))
+        sysv._dirs_resident = False
+    (a1, c1, p1, t1), (a2, c2, p2, t2) = results
+    assert a1 == a2 > 0 and t1 == t2
+    assert np.array_equal(c1, c2)
+    assert p1 == p2
+
+    def resident_rc(solver):
+        sv = solver.syssolver
+        sc = np.ascontiguousarray(solver.stepper.searcher.alpha_sched, dtype=np.float64)
+        cand = np.zeros(2 * solver.model.q + 2)
+        idx, nt, nl = ctypes.c_int(-1), ctypes.c_int(0), ctypes.c_int(0)
+        prox, irt = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        return L.lib().hyp_sys_search_alpha_resident(sv._h, 0, 0, L.vec_ptr(sc), len(sc), 0, 0.01, 0.99, 1, float(solver.model.nu + 1),
+                                                     L.vec_ptr(cand), ctypes.byref(idx), ctypes.byref(prox), ctypes.byref(nt), ctypes.byref(nl),
+                                                     ctypes.byref(irt))
+    fresh = H.Solver(iter_limit=0)
+    fresh.load(H.make_model(inst)); fresh.solve()          # system solver loaded, no step taken
+    assert resident_rc(fresh) != 0
+    two = H.Solver(iter_limit=2)
+    two.load(H.make_model(I.psd_blocks(40, [40, 33], seed=6))); two.solve()   # two cones: the screen does not apply
+    assert not two.syssolver._screen_ok()
+    assert resident_rc(two) != 0
+
+
 # ---------------------------------------------------------------------------------------------
 # SymIndefDenseSystemSolver (SURVEY 8f-4): the 3x3 symmetric indefinite form, Bunch-Kaufman on the device
 # ---------------------------------------------------------------------------------------------
