@@ -85,7 +85,7 @@ def test_potrf_large_lookahead_form(hip, n):
     assert np.array_equal(Ad, Ad2)
 
 
-@pytest.mark.parametrize("n", [127, 128, 129, 255, 257, 383, 385, 511, 512, 513, 640, 641, 767, 768, 769, 895, 1023, 1024, 1025, 1153, 1535, 1537])
+@pytest.mark.parametrize("n", [127, 128, 129, 255, 257, 383, 385, 511, 512, 513, 640, 641, 767, 768, 769, 895, 1023, 1024, 1025, 1153, 1535, 1537, 2049, 3073, 3210])
 def test_posv_across_the_block_and_plan_thresholds(hip, n):
     """sizes on either side of every switch of the factor / solve path: the 128-wide block, the 6-block look-ahead form (768), the
     super-block solve plan (512) and its super-block sizes (ceil(n / 3 / 128) 128, capped at 1024).  Bar: LAPACK's backward error"""
