@@ -102,6 +102,7 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
     if (c.diag_own_cu_lds < 0) c.diag_own_cu_lds = tiles ? potrf_diag_mfma_own_cu_lds() : potrf_diag_own_cu_lds();
     own_cu_lds = c.diag_own_cu_lds;
   }
+  int last_la = -1;   // last block step whose trailing update went to the helper stream and has not been joined yet
   for (int kb = 0; kb < nblk; ++kb) {
     const int k0 = kb * NB;
     const int nb = std::min(NB, n - k0);
@@ -114,10 +115,19 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
     double* A22 = A + (long)(k0 + nb) * lda + (k0 + nb);
     if (tiles) potrf_panel_mfma_launch(c.stream, batch, A, lda, strideA, k0, m);
     else potrf_panel_solve_launch(c.stream, batch, A, lda, strideA, k0, m);   // A12 <- U11^-T A12 (substitution)
-    if (!lookahead) {
+    // (the last block steps, whose whole trailing update is a ~15 us GEMM, run on the main stream alone: the two ordering
+    //  events of a look-ahead step cost more there -- ~6 us of queue hand-over each -- than the update they would hide)
+    static const int la_min = [] { const char* e = getenv("HYP_POTRF_LA_MIN"); return e ? atoi(e) : 1536; }();
+    const bool la_step = lookahead && m > la_min;
+    if (!la_step) {
+      if (lookahead && last_la >= 0) {   // the helper stream's last update touched everything below: join it once
+        HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(2 * last_la + 1), 0));
+        last_la = -1;
+      }
       potrf_step_gemms(c, c.stream, nb, m, m, A12, A12, lda, strideA, A22, GEMM_UPPER, batch);   // A22 -= A12' A12 (upper)
       continue;
     }
+    last_la = kb;
     const int nb1 = std::min(NB, m);       // block row k+1
     const int mr = m - nb1;                // rows beyond it
     hipEvent_t Tk = c.pool_event(2 * kb), Rk = c.pool_event(2 * kb + 1);
@@ -135,7 +145,7 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
     }
     HYP_CHECK(hipEventRecord(Rk, c.stream2));
   }
-  if (lookahead && nblk >= 2) HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(2 * (nblk - 2) + 1), 0));
+  if (lookahead && last_la >= 0) HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(2 * last_la + 1), 0));
   if (dinv) potrf_invert_diag_blocks(c, n, A, lda, strideA, batch, dinv);
 }
 
