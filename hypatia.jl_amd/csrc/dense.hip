@@ -1148,8 +1148,9 @@ void dev_zero_strict_lower(Ctx& c, int n, double* A, long lda, int batch, long s
 // unpack: one workgroup per (32 x 32 tile of the upper triangle, column of arr).  The tile is read from the
 // packed column (rows contiguous), written to V[i, j] and -- through an LDS transpose -- to V[j, i], so
 // that every global access is a contiguous 256-byte run.
+// (column col of the packed input sits at (col / group) * ldg + (col % group) * ldarr: groups of columns with a stride of their own)
 __global__ __launch_bounds__(256) void svec_unpack_div_kernel(int side, int ntile, const double* __restrict__ arr, long ldarr,
-                                                              double* __restrict__ mats, int ncols) {
+                                                              double* __restrict__ mats, int ncols, int group, long ldg) {
   __shared__ double tile[32][33];
   // blockIdx.x enumerates upper tiles (ti <= tj) column by column: idx = tj (tj + 1) / 2 + ti
   int tj = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
@@ -1158,7 +1159,7 @@ __global__ __launch_bounds__(256) void svec_unpack_div_kernel(int side, int ntil
   const int ti = blockIdx.x - tj * (tj + 1) / 2;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
   for (int col = blockIdx.y; col < ncols; col += gridDim.y) {
-    const double* a = arr + (long)col * ldarr;
+    const double* a = arr + (long)(col / group) * ldg + (long)(col % group) * ldarr;
     double* V = mats + (long)col * side * side;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1185,7 +1186,15 @@ void svec_unpack(Ctx& c, int side, int ncols, const double* arr, long ldarr, dou
   if (ncols <= 0) return;
   const int nt = (side + 31) / 32;
   hipLaunchKernelGGL(svec_unpack_div_kernel, dim3(nt * (nt + 1) / 2, std::min(ncols, 4096)), dim3(256), 0, c.stream, side, nt, arr, ldarr, mats,
-                     ncols);
+                     ncols, ncols, 0L);
+  HYP_CHECK(hipGetLastError());
+}
+void svec_unpack_grouped(Ctx& c, int side, int ngroups, int group, const double* arr, long ldg, long ldarr, double* mats) {
+  const int ncols = ngroups * group;
+  if (ncols <= 0) return;
+  const int nt = (side + 31) / 32;
+  hipLaunchKernelGGL(svec_unpack_div_kernel, dim3(nt * (nt + 1) / 2, std::min(ncols, 4096)), dim3(256), 0, c.stream, side, nt, arr, ldarr, mats,
+                     ncols, group, ldg);
   HYP_CHECK(hipGetLastError());
 }
 // pack: thread per packed entry run; one workgroup handles (32-column band j, column of arr)

@@ -232,6 +232,8 @@ void dev_zero_strict_lower(Ctx& c, int n, double* A, long lda, int batch, long s
 // svec <-> smat for batches of columns: arr is (d x ncols, ld = ldarr); mats is ncols blocks of s x s
 // (col-major, contiguous).  unpack fills BOTH triangles (symmetric); pack reads the upper triangle.
 void svec_unpack(Ctx& c, int side, int ncols, const double* arr, long ldarr, double* mats);
+// the same for ngroups x group columns: column (g, k) of the packed input at arr + g * ldg + k * ldarr, matrices written back to back
+void svec_unpack_grouped(Ctx& c, int side, int ngroups, int group, const double* arr, long ldg, long ldarr, double* mats);
 void svec_pack(Ctx& c, int side, int ncols, const double* mats, double* arr, long ldarr, double scale);
 
 // gemm wrapper on ctx.stream

@@ -1143,11 +1143,136 @@ __global__ __launch_bounds__(1024) void screen_prox_kernel(int side, const doubl
   if (threadIdx.x == 0) out[g] = red[0];
 }
 
-bool SysSolver::screen_usable() const {
+int SysSolver::screen_mode() const {
   static const bool on = [] { const char* e = getenv("HYP_SEARCH_SCREEN"); return !(e && e[0] == '0'); }();
   static const bool lb_on = [] { const char* e = getenv("HYP_PROX_LB"); return !(e && e[0] == '0'); }();
-  if (!on || !lb_on || dist() || cones.size() != 1 || cones[0]->kind != CONE_PSD || cones[0]->use_dual_barrier) return false;
-  return static_cast<const PsdCone*>(cones[0])->side >= 32;
+  static const bool run_on = [] { const char* e = getenv("HYP_SEARCH_SCREEN_RUN"); return !(e && e[0] == '0'); }();
+  if (!on || !lb_on || dist() || cones.empty()) return 0;
+  if (cones.size() == 1)
+    return (cones[0]->kind == CONE_PSD && !cones[0]->use_dual_barrier && static_cast<const PsdCone*>(cones[0])->side >= 32) ? 1 : 0;
+  if (!run_on || psd_runs.size() != 1 || psd_runs[0].k0 != 0 || (size_t)psd_runs[0].count != cones.size()) return 0;
+  for (const Cone* ck : cones)
+    if (ck->kind != CONE_PSD || ck->use_dual_barrier) return 0;
+  return 2;
+}
+
+// ---- the same screen for a model that is ONE RUN of equal PosSemidefTri cones (config 4: 64 cones of side 80): batch =
+// candidates x cones.  Per candidate g and cone k the device returns <z, s>, both factorization flags, || W ||_F^2 and tr W for
+// W = U Z U' (U' U = smat(s_k)); mu_g needs the sum over the cones, so the proximity value is finished on the host:
+// || W / mu - I ||_F^2 = ||W||^2 / mu^2 - 2 tr W / mu + side.  Aggregation and bound as in check_cone_points (search.jl:118-136).
+__global__ __launch_bounds__(256) void screen_dot_run_kernel(int dm, const double* __restrict__ cands, long len, long off_s, int B,
+                                                             double* __restrict__ sz) {
+  __shared__ double red[256];
+  const int k = blockIdx.x, g = blockIdx.y;
+  const double* z = cands + (long)g * len + (long)k * dm;
+  const double* sv = z + off_s;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < dm; i += 256) acc = fma(z[i], sv[i], acc);
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sz[(long)g * B + k] = red[0];
+}
+// out2[2 m] = || W_m ||_F^2, out2[2 m + 1] = tr W_m
+__global__ __launch_bounds__(256) void screen_norm_trace_kernel(int side, const double* __restrict__ W, long stride, double* __restrict__ out2) {
+  __shared__ double r0[256], r1[256];
+  const long m = blockIdx.x;
+  const double* w = W + m * stride;
+  const int tot = side * side;
+  double s = 0.0, t = 0.0;
+  for (int i = threadIdx.x; i < tot; i += 256) {
+    const double v = w[i];
+    s = fma(v, v, s);
+    const int c = i / side;
+    if (i - c * side == c) t += v;
+  }
+  r0[threadIdx.x] = s;
+  r1[threadIdx.x] = t;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) { r0[threadIdx.x] += r0[threadIdx.x + off]; r1[threadIdx.x] += r1[threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out2[2 * m] = r0[0]; out2[2 * m + 1] = r1[0]; }
+}
+
+void SysSolver::screen_candidates_run(const double* cd, int K, const double* tau, const double* kap, double min_prox, double prox_bound,
+                                      double nup1, bool use_max_prox, char* rej) {
+  const double EPS = 2.220446049250313e-16;
+  HYP_REQUIRE(K >= 1 && K <= SCREEN_MAX, "screen_candidates_run: batch size");
+  const PsdRun& r = psd_runs[0];
+  const int sd = r.side, B = r.count, dm = cones[0]->dim;
+  const long len = 2L * q + 2, s2 = (long)sd * sd, KB = (long)K * B, MB = (long)SCREEN_MAX * B;
+  const double proxsqr_bound = prox_bound * prox_bound;
+  double* P = screen_buf.d() + (long)SCREEN_MAX * len;   // layout as in screen_candidates, matrices per (candidate, cone)
+  double* D = P + KB * s2;
+  double* UT = D + KB * s2;
+  double* Z = UT + KB * s2;
+  double* T = Z + KB * s2;
+  double* W = T + KB * s2;
+  double* outv = screen_buf.d() + (long)SCREEN_MAX * len + 6L * MB * s2;   // [sz (MB) | norm, trace (2 MB)]
+  screen_info.ensure((size_t)2 * MB * sizeof(int));
+  hipLaunchKernelGGL(screen_dot_run_kernel, dim3(B, K), dim3(256), 0, ctx.stream, dm, cd, len, (long)q + 1, B, outv);
+  svec_unpack_grouped(ctx, sd, K, B, cd + q + 1, len, dm, P);    // PsdCone::update_feas (possemideftri.jl:80-90) of the unscaled s_k
+  svec_unpack_grouped(ctx, sd, K, B, cd, len, dm, D);            // PsdCone::is_dual_feas (:92-95)
+  ctx.d2d(Z, D, (size_t)KB * s2 * sizeof(double));
+  potrf_upper_batched(ctx, sd, P, sd, s2, (int)(2 * KB), nullptr, screen_info.i());
+  dev_zero_strict_lower(ctx, sd, P, sd, (int)KB, s2);
+  dev_transpose(ctx, sd, sd, P, sd, UT, sd, (int)KB, s2, s2);
+  GemmArgs a{};   // T = Z U'
+  a.M = sd; a.N = sd; a.K = sd; a.A = Z; a.lda = sd; a.strideA = s2; a.B = UT; a.ldb = sd; a.strideB = s2; a.C = T; a.ldc = sd; a.strideC = s2;
+  a.alpha = 1; a.beta = 0; a.tri = GEMM_FULL; a.krange = KR_GE_N; a.batch = (int)KB;
+  gemm(ctx, true, a);
+  GemmArgs b{};   // W = U T
+  b.M = sd; b.N = sd; b.K = sd; b.A = UT; b.lda = sd; b.strideA = s2; b.B = T; b.ldb = sd; b.strideB = s2; b.C = W; b.ldc = sd; b.strideC = s2;
+  b.alpha = 1; b.beta = 0; b.tri = GEMM_FULL; b.krange = KR_GE_M; b.batch = (int)KB;
+  gemm(ctx, true, b);
+  hipLaunchKernelGGL(screen_norm_trace_kernel, dim3((unsigned)KB), dim3(256), 0, ctx.stream, sd, W, s2, outv + MB);
+  HYP_CHECK(hipGetLastError());
+  HYP_REQUIRE(64 + 2 * KB <= 8192 && 128 + 3 * (size_t)KB <= ctx.h_pinned_n, "screen_candidates_run: too many cones for the pinned buffers");
+  int* hi = ctx.h_info + 64;
+  double* hv = ctx.h_pinned + 128;
+  ctx.d2h(hi, screen_info.p, (size_t)2 * KB * sizeof(int));
+  ctx.d2h(hv, outv, (size_t)KB * sizeof(double));
+  ctx.d2h(hv + KB, outv + MB, (size_t)2 * KB * sizeof(double));
+  ctx.sync();
+  ++screen_count;
+  const double M = 1e-6;
+  auto lt = [M](double x, double y) { return x < y - M * std::fabs(y); };
+  auto gt = [M](double x, double y) { return x > y + M * std::fabs(y); };
+  const double limit = proxsqr_bound * (1.0 + 1e-9);
+  for (int g = 0; g < K; ++g) {
+    const double taukap = tau[g] * kap[g];
+    const double* szk = hv + (long)g * B;
+    const double* nt = hv + KB + 2L * g * B;
+    bool rj = false;
+    if (std::min(std::min(tau[g], kap[g]), taukap) < EPS) rj = true;
+    double szsum = 0.0;
+    for (int k = 0; k < B && !rj; ++k) {
+      if (lt(szk[k], EPS)) rj = true;
+      szsum += szk[k];
+    }
+    const double mu = (szsum + taukap) / nup1, taukap_rel = taukap / mu;
+    const double taukap_proxsqr = (taukap_rel - 1.0) * (taukap_rel - 1.0);
+    if (!rj && (lt(mu, EPS) || lt(taukap_rel, min_prox) || gt(taukap_proxsqr, proxsqr_bound))) rj = true;
+    double agg = taukap_proxsqr;
+    for (int k = 0; k < B && !rj; ++k) {
+      const double nu_k = cones[k]->nu, rel = szk[k] / (mu * nu_k);
+      if (lt(rel, min_prox) || gt(nu_k * (rel - 1.0) * (rel - 1.0), proxsqr_bound)) rj = true;
+      else if (hi[(long)g * B + k] != 0 || hi[KB + (long)g * B + k] != 0) rj = true;
+      else {
+        const double v = nt[2 * k] / (mu * mu) - 2.0 * nt[2 * k + 1] / mu + (double)sd;
+        if (!(v == v) || !(v < INFINITY)) { agg = NAN; break; }   // (no verdict from a value that is not a number)
+        agg = use_max_prox ? std::max(agg, v) : agg + v;
+      }
+    }
+    if (!rj && agg == agg && agg / (1.0 + 1e-5) > limit) rj = true;
+    rej[g] = rj ? 1 : 0;
+    screen_rejected += rej[g];
+  }
 }
 
 void SysSolver::screen_candidates(const double* cd, int K, const double* tau, const double* kap, double min_prox, double prox_bound,
@@ -1221,8 +1346,9 @@ int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp
   const int len = 2 * q + 2;
   *n_trials = 0;
   *n_loaded = 0;
-  const bool screen = screen_usable();
-  HYP_REQUIRE(!resident || (screen && s_resident), "search_alpha: no resident directions (step_directions first; one PosSemidefTri cone)");
+  const int smode = screen_mode();
+  const bool screen = smode != 0;
+  HYP_REQUIRE(!resident || (screen && s_resident), "search_alpha: no resident directions (step_directions first; a model the candidate screen applies to)");
   // candidates are formed in pinned memory and only the accepted one is copied to the caller's vector:
   // the upload inside check_cone_points is then a plain asynchronous copy -- from the caller's pageable vector it stopped the
   // host for the whole transfer, once per trial
@@ -1259,7 +1385,8 @@ int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp
       char rej[SCREEN_MAX];
       double ctau[SCREEN_MAX], ckap[SCREEN_MAX];
       const long s2 = (long)static_cast<const PsdCone*>(cones[0])->side * static_cast<const PsdCone*>(cones[0])->side;
-      screen_buf.ensure((size_t)((long)SCREEN_MAX * len + 6L * SCREEN_MAX * s2 + 3 * SCREEN_MAX) * sizeof(double));
+      const long nmat = (long)SCREEN_MAX * (long)cones.size();   // matrices per buffer: candidates x cones
+      screen_buf.ensure((size_t)((long)SCREEN_MAX * len + 6L * nmat * s2 + 3 * nmat) * sizeof(double));
       double* cd = screen_buf.d();
       if (resident) {   // the five vectors are on the device: so are the candidates
         ScreenForm f{};
@@ -1284,7 +1411,8 @@ int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp
         }
         ctx.h2d(cd, stage, (size_t)K * len * sizeof(double));
       }
-      screen_candidates(cd, K, ctau, ckap, min_prox, prox_bound, nup1, rej);
+      if (smode == 1) screen_candidates(cd, K, ctau, ckap, min_prox, prox_bound, nup1, rej);
+      else screen_candidates_run(cd, K, ctau, ckap, min_prox, prox_bound, nup1, use_max_prox, rej);
       for (int g = 0; g < K; ++g) {
         ++*n_trials;
         if (rej[g]) continue;

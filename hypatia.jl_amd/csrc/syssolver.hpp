@@ -122,7 +122,10 @@ struct SysSolver {
   static constexpr int SCREEN_MAX = 18;   // the reference's whole schedule (search.jl:41-43)
   DBuf screen_buf, screen_info;
   long screen_count = 0, screen_rejected = 0;   // statistics: screens run, candidates they rejected
-  bool screen_usable() const;
+  bool screen_usable() const { return screen_mode() != 0; }
+  int screen_mode() const;   // 0: no screen; 1: one PosSemidefTri cone; 2: one run of equal PosSemidefTri cones is the whole model
+  void screen_candidates_run(const double* d_cands, int K, const double* tau, const double* kap, double min_prox, double prox_bound,
+                             double nup1, bool use_max_prox, char* rej);
   bool screen_survivor = false;   // set around the check_cone_points call of a candidate the screen has passed: its proximity lower bound is not evaluated again
   // d_cands: K candidates [z; tau; s; kap] of length 2 q + 2 on the device (their tau / kap slots are not read: tau, kap)
   void screen_candidates(const double* d_cands, int K, const double* tau, const double* kap, double min_prox, double prox_bound, double nup1,

@@ -24,6 +24,8 @@ elif name == "psd_single":
     inst = I.psd_blocks(40, [48], seed=5)
 elif name == "psd_single_wide":             # one cone of side 72 (three 16-column tile rows and a ragged one)
     inst = I.psd_blocks(90, [72], seed=9)
+elif name == "psd_run":                     # five equal cones: one run is the whole model (the grouped path of config 4)
+    inst = I.psd_blocks(60, [24, 24, 24, 24, 24], seed=11)
 elif name == "psd_pair":
     inst = I.psd_blocks(50, [40, 33], seed=6)
 elif name == "psd_plan":                     # n = 600: the factor has a super-block solve plan (n >= 512)
@@ -104,9 +106,9 @@ def test_constant_column_in_the_first_paired_solve_changes_no_bit():
         assert runs[0]["trace"] == runs[1]["trace"] == runs[2]["trace"], name
 
 
-@pytest.mark.parametrize("name", ["psd_single", "psd_single_wide"])
+@pytest.mark.parametrize("name", ["psd_single", "psd_single_wide", "psd_run"])
 def test_screened_schedule_walk_changes_no_bit(name):
-    """round 3: for a model of one PosSemidefTri cone the schedule walk of search_alpha screens all remaining candidates side by
+    """round 3: for a model of one PosSemidefTri cone (or of one run of equal ones: batch = candidates x cones) the schedule walk of search_alpha screens all remaining candidates side by
     side (HYP_SEARCH_SCREEN) -- the tests that reject, batched over the candidates -- and only survivors go
     through the sequential acceptance test; in the fused step the candidates are formed on the device from the directions
     step_directions left there (HYP_SEARCH_RESIDENT; off: formed on the host and uploaded).  The screen may only reject what the

@@ -1,11 +1,10 @@
 #!/bin/bash
 cd /root/repo; export TMPDIR=/tmp
-run() { env $1 $2 $3 timeout 600 python bench.py --steps 60 --warmup 5 --cpu-iters 0 2>/tmp/e.txt | python -c "
+timeout 900 python -m pytest tests/test_hip_switches.py -q -x -m gpu -k "screened" 2>&1 | tail -8
+run() { env $1 timeout 900 python bench.py --config 4 --steps 20 --warmup 3 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.readlines()[-1]); p = d['phases_ms_per_step']
-print('$1 $2 $3', round(d['ms_per_step'], 3), 'sqrt', round(p['sqrt_hess_prod'], 3), 'syrk', round(p['syrk'], 3), 'chol', round(p['cholesky'], 3), 'upd', round(p['update_lhs'], 3), 'dir', round(p['get_directions'], 3), 'search', round(p['search'], 3))"; grep "^\[warm\]" /tmp/e.txt | head -1; }
-run HYP_WARM=0 A=1 B=1
-run HYP_WARM=150 HYP_WARM_WGS=256 HYP_WARM_PRIO=0
-run HYP_WARM=150 HYP_WARM_WGS=64 HYP_WARM_PRIO=0
-run HYP_WARM=0 A=1 B=1
-run HYP_WARM=200 HYP_WARM_WGS=256 HYP_WARM_PRIO=0
+print('$1', round(d['ms_per_step'], 3), 'upd', round(p['update_lhs'], 3), 'dir', round(p['get_directions'], 3), 'search', round(p['search'], 3), 'trials', d['search_trials_per_step'], 'screens', d.get('search_screens_per_step'), 'rej', d.get('search_trials_screened_out_per_step'), 'restarts', d.get('restarts_in_timed_region'))"; }
+run A=1
+run HYP_SEARCH_SCREEN_RUN=0
+run A=1
