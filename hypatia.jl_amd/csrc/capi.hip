@@ -647,6 +647,7 @@ int hyp_sys_set_comm(hyp_sys* sys, int (*allreduce)(void* user, long count, int 
   HYP_REQUIRE(allreduce == nullptr || (device_staging != nullptr && capacity_doubles >= (long)s->nmp * s->nmp),
               "set_comm: the staging buffer must hold the n x n Schur matrix");
   s->comm_fn = allreduce;
+  s->screen_agreed = -1;
   s->comm_user = user;
   s->comm_stage = (double*)device_staging;
   s->comm_cap = capacity_doubles;
@@ -691,6 +692,7 @@ int hyp_sys_set_comm_rccl(hyp_sys* sys, hyp_comm* comm) {
   API_BEGIN
   HYP_REQUIRE(comm == nullptr || comm->ctx == sys->ctx, "set_comm_rccl: the communicator belongs to another context");
   sys->s->rccl_comm = comm ? comm->nccl : nullptr;
+  sys->s->screen_agreed = -1;
   API_END(sys->ctx)
 }
 int hyp_sys_set_kshard(hyp_sys* sys, int rank, int world) {

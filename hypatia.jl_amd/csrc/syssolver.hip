@@ -334,8 +334,11 @@ void SysSolver::allreduce_host(double* h_buf, int count, int op) {
   comm_calls += 1;
   comm_doubles += (double)count;
   if (rccl_comm) {   // scalars: through the context's device scalar buffer (64 doubles)
-    HYP_REQUIRE(count <= 32, "sys: host all-reduce payload");
     double* d = ctx.dscal.d() + 32;
+    if (count > 32) {   // (the candidate screen's vectors: a few numbers per candidate)
+      ar_dev.ensure((size_t)count * sizeof(double));
+      d = ar_dev.d();
+    }
     ctx.h2d(d, h_buf, (size_t)count * sizeof(double));
     rccl_allreduce_inplace(rccl_comm, d, count, op, ctx.stream);
     ctx.d2h(h_buf, d, (size_t)count * sizeof(double));
@@ -664,6 +667,7 @@ void SysSolver::load_model(const double* hc, const double* hb, const double* hh,
   Gx_dir.ensure(std::max(q, 1) * d);
   ctx.sync();
   model_loaded = true;
+  screen_agreed = -1;
 }
 
 // rhs_const = [-c; b; H h], sol_const = solve_subsystem3(rhs_const)   (qrchol.jl:191-197)
@@ -1147,9 +1151,12 @@ int SysSolver::screen_mode() const {
   static const bool on = [] { const char* e = getenv("HYP_SEARCH_SCREEN"); return !(e && e[0] == '0'); }();
   static const bool lb_on = [] { const char* e = getenv("HYP_PROX_LB"); return !(e && e[0] == '0'); }();
   static const bool run_on = [] { const char* e = getenv("HYP_SEARCH_SCREEN_RUN"); return !(e && e[0] == '0'); }();
-  if (!on || !lb_on || dist() || cones.empty()) return 0;
+  // (sharded: the run form only -- every rank screens ITS cones and two all-reduces of a few numbers per candidate make the
+  //  verdict the same on all ranks; HYP_SEARCH_SCREEN_DIST=0: off)
+  static const bool dist_on = [] { const char* e = getenv("HYP_SEARCH_SCREEN_DIST"); return !(e && e[0] == '0'); }();
+  if (!on || !lb_on || cones.empty() || (dist() && !dist_on)) return 0;
   if (cones.size() == 1)
-    return (cones[0]->kind == CONE_PSD && !cones[0]->use_dual_barrier && static_cast<const PsdCone*>(cones[0])->side >= 32) ? 1 : 0;
+    return (!dist() && cones[0]->kind == CONE_PSD && !cones[0]->use_dual_barrier && static_cast<const PsdCone*>(cones[0])->side >= 32) ? 1 : 0;
   if (!run_on || psd_runs.size() != 1 || psd_runs[0].k0 != 0 || (size_t)psd_runs[0].count != cones.size()) return 0;
   for (const Cone* ck : cones)
     if (ck->kind != CONE_PSD || ck->use_dual_barrier) return 0;
@@ -1244,32 +1251,49 @@ void SysSolver::screen_candidates_run(const double* cd, int K, const double* tau
   auto lt = [M](double x, double y) { return x < y - M * std::fabs(y); };
   auto gt = [M](double x, double y) { return x > y + M * std::fabs(y); };
   const double limit = proxsqr_bound * (1.0 + 1e-9);
+  // first exchange (sharded): the candidates' <z, s> over all ranks' cones, and whether any cone anywhere fails the sign test
+  std::vector<double> v1(2 * (size_t)K, 0.0), v2(3 * (size_t)K, 0.0);
+  for (int g = 0; g < K; ++g) {
+    const double* szk = hv + (long)g * B;
+    for (int k = 0; k < B; ++k) {
+      if (lt(szk[k], EPS)) v1[K + g] = 1.0;
+      v1[g] += szk[k];
+    }
+  }
+  if (dist()) allreduce_host(v1.data(), 2 * K, 0);
+  // second exchange: [a cone fails a test | no verdict (a value that is not a number) | proximity aggregate of this rank's cones]
+  std::vector<double> mus(K, 0.0), tkp(K, 0.0);
+  std::vector<char> scal_rej(K, 0);
   for (int g = 0; g < K; ++g) {
     const double taukap = tau[g] * kap[g];
     const double* szk = hv + (long)g * B;
     const double* nt = hv + KB + 2L * g * B;
-    bool rj = false;
-    if (std::min(std::min(tau[g], kap[g]), taukap) < EPS) rj = true;
-    double szsum = 0.0;
-    for (int k = 0; k < B && !rj; ++k) {
-      if (lt(szk[k], EPS)) rj = true;
-      szsum += szk[k];
+    const double mu = (v1[g] + taukap) / nup1, taukap_rel = taukap / mu;
+    mus[g] = mu;
+    tkp[g] = (taukap_rel - 1.0) * (taukap_rel - 1.0);
+    if (std::min(std::min(tau[g], kap[g]), taukap) < EPS || v1[K + g] > 0.5 || lt(mu, EPS) || lt(taukap_rel, min_prox) ||
+        gt(tkp[g], proxsqr_bound)) {   // (the same decision on every rank: replicated scalars and all-reduced sums)
+      scal_rej[g] = 1;
+      continue;
     }
-    const double mu = (szsum + taukap) / nup1, taukap_rel = taukap / mu;
-    const double taukap_proxsqr = (taukap_rel - 1.0) * (taukap_rel - 1.0);
-    if (!rj && (lt(mu, EPS) || lt(taukap_rel, min_prox) || gt(taukap_proxsqr, proxsqr_bound))) rj = true;
-    double agg = taukap_proxsqr;
-    for (int k = 0; k < B && !rj; ++k) {
+    double agg = 0.0;
+    for (int k = 0; k < B; ++k) {
       const double nu_k = cones[k]->nu, rel = szk[k] / (mu * nu_k);
-      if (lt(rel, min_prox) || gt(nu_k * (rel - 1.0) * (rel - 1.0), proxsqr_bound)) rj = true;
-      else if (hi[(long)g * B + k] != 0 || hi[KB + (long)g * B + k] != 0) rj = true;
-      else {
-        const double v = nt[2 * k] / (mu * mu) - 2.0 * nt[2 * k + 1] / mu + (double)sd;
-        if (!(v == v) || !(v < INFINITY)) { agg = NAN; break; }   // (no verdict from a value that is not a number)
-        agg = use_max_prox ? std::max(agg, v) : agg + v;
-      }
+      if (lt(rel, min_prox) || gt(nu_k * (rel - 1.0) * (rel - 1.0), proxsqr_bound)) { v2[g] = 1.0; break; }
+      if (hi[(long)g * B + k] != 0 || hi[KB + (long)g * B + k] != 0) { v2[g] = 1.0; break; }
+      const double v = nt[2 * k] / (mu * mu) - 2.0 * nt[2 * k + 1] / mu + (double)sd;
+      if (!(v == v) || !(v < INFINITY)) { v2[K + g] = 1.0; break; }
+      agg = use_max_prox ? std::max(agg, v) : agg + v;
     }
-    if (!rj && agg == agg && agg / (1.0 + 1e-5) > limit) rj = true;
+    v2[2 * K + g] = (v2[g] > 0.5 || v2[K + g] > 0.5) ? 0.0 : std::max(agg, 0.0);
+  }
+  if (dist()) allreduce_host(v2.data(), 3 * K, use_max_prox ? 1 : 0);
+  for (int g = 0; g < K; ++g) {
+    bool rj = scal_rej[g] != 0 || v2[g] > 0.5;
+    if (!rj && !(v2[K + g] > 0.5)) {
+      const double agg = use_max_prox ? std::max(tkp[g], v2[2 * K + g]) : tkp[g] + v2[2 * K + g];
+      if (agg / (1.0 + 1e-5) > limit) rj = true;
+    }
     rej[g] = rj ? 1 : 0;
     screen_rejected += rej[g];
   }
@@ -1346,7 +1370,15 @@ int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp
   const int len = 2 * q + 2;
   *n_trials = 0;
   *n_loaded = 0;
-  const int smode = screen_mode();
+  int smode = screen_mode();
+  if (dist()) {   // every rank must walk the same way: the screen runs only if it applies on all of them (agreed once per model)
+    if (screen_agreed < 0) {
+      double v = -(double)smode;
+      allreduce_host(&v, 1, 1);
+      screen_agreed = (int)(-v);
+    }
+    smode = std::min(smode, screen_agreed) == 2 ? 2 : 0;
+  }
   const bool screen = smode != 0;
   HYP_REQUIRE(!resident || (screen && s_resident), "search_alpha: no resident directions (step_directions first; a model the candidate screen applies to)");
   // candidates are formed in pinned memory and only the accepted one is copied to the caller's vector:

@@ -81,6 +81,7 @@ struct SysSolver {
   bool dist() const { return (comm_fn != nullptr || rccl_comm != nullptr) && ks_world <= 1; }
   void allreduce_lhs();   // the n x n exchange of either sharding mode
   void allreduce_dev(double* d_buf, long count, int op);
+  DBuf ar_dev;   // device staging of allreduce_host for payloads beyond the context's 32 scalar slots
   void allreduce_host(double* h_buf, int count, int op);
   // the products of calc_convergence_params / calc_mu (Solvers.jl:418-483) on THIS process's rows of z, s and G, the sums over
   // ranks taken here: Gtz (n, summed) = G' z; Gx_s (q, these rows) = G x + s; dots = {h' z, z' s} (summed)
@@ -123,6 +124,7 @@ struct SysSolver {
   DBuf screen_buf, screen_info;
   long screen_count = 0, screen_rejected = 0;   // statistics: screens run, candidates they rejected
   bool screen_usable() const { return screen_mode() != 0; }
+  int screen_agreed = -1;    // sharded: the minimum of the ranks' screen_mode(), agreed once per model (-1: not yet)
   int screen_mode() const;   // 0: no screen; 1: one PosSemidefTri cone; 2: one run of equal PosSemidefTri cones is the whole model
   void screen_candidates_run(const double* d_cands, int K, const double* tau, const double* kap, double min_prox, double prox_bound,
                              double nup1, bool use_max_prox, char* rej);

@@ -373,6 +373,8 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
         self.local_backend = local_backend
 
     def load(self, solver):
+        self.__dict__.pop("_screen_usable", None)   # (the candidate screen is decided per loaded model)
+        self._dirs_resident = False
         model = solver.model
         assert model.p == 0, "the sharded solver assumes the reduced model (p = 0)"
         self.n, self.p, self.q = model.n, 0, model.q
@@ -547,7 +549,20 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
         assert not any(np.isnan(resn[k]) for k in range(4))
         if solver.max_ref_steps > 0:
             solver.worst_dir_res = max(solver.worst_dir_res, *[resn[k] for k in range(4)])
+        self._dirs_resident = True   # (this rank's rows of the point and the directions stay on the device: search_alpha_native)
         return True
+
+    def _screen_ok(self):
+        """the side-by-side candidate screen applies on EVERY rank (each rank's cones one run of equal PosSemidefTri cones): then
+        the walk may form its candidates from the device-resident rows (hyp_sys_search_alpha_resident); agreed once per load"""
+        if not hasattr(self, "_screen_usable"):
+            import ctypes, os
+            u, a, b = ctypes.c_int(0), ctypes.c_longlong(0), ctypes.c_longlong(0)
+            L.check(L.lib().hyp_sys_search_screen_stats(self.local._h, ctypes.byref(u), ctypes.byref(a), ctypes.byref(b)),
+                    "hyp_sys_search_screen_stats")
+            ok = bool(u.value) and os.environ.get("HYP_SEARCH_RESIDENT", "1") != "0"
+            self._screen_usable = self.reduce_max([0.0 if ok else 1.0])[0] < 0.5
+        return self._screen_usable
 
     def last_update_lhs_seconds(self):
         import ctypes
@@ -561,15 +576,24 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
         searcher = stepper.searcher
         sc = np.ascontiguousarray(searcher.alpha_sched, dtype=np.float64)
         ql = self._ql_n
-        loc = [self._local_ztsk(p) for p in (point, stepper.dir_cent, stepper.dir_pred, stepper.dir_centadj, stepper.dir_predadj)]
         cand = np.zeros(2 * ql + 2)
         idx, nt, nl = c_int(-1), c_int(0), c_int(0)
         prox, irtmu = ctypes.c_double(0.0), ctypes.c_double(0.0)
-        L.check(L.lib().hyp_sys_search_alpha(
-            self.local._h, L.vec_ptr(loc[0]), L.vec_ptr(loc[1]), L.vec_ptr(loc[2]), L.vec_ptr(loc[3]), L.vec_ptr(loc[4]),
-            int(stepper.unadj_only), int(stepper.cent_only), L.vec_ptr(sc), len(sc), int(sched - 1), float(searcher.min_prox),
-            float(searcher.prox_bound), int(bool(searcher.use_max_prox)), float(searcher.nup1), L.vec_ptr(cand), ctypes.byref(idx),
-            ctypes.byref(prox), ctypes.byref(nt), ctypes.byref(nl), ctypes.byref(irtmu)), "hyp_sys_search_alpha")
+        if getattr(self, "_dirs_resident", False) and self._screen_ok():
+            # this rank's rows of the point and of the directions are still on the device (step_directions_native): the schedule's
+            # candidates are formed and screened there; two small all-reduces make the verdicts the same on every rank
+            L.check(L.lib().hyp_sys_search_alpha_resident(
+                self.local._h, int(stepper.unadj_only), int(stepper.cent_only), L.vec_ptr(sc), len(sc), int(sched - 1),
+                float(searcher.min_prox), float(searcher.prox_bound), int(bool(searcher.use_max_prox)), float(searcher.nup1),
+                L.vec_ptr(cand), ctypes.byref(idx), ctypes.byref(prox), ctypes.byref(nt), ctypes.byref(nl), ctypes.byref(irtmu)),
+                "hyp_sys_search_alpha_resident")
+        else:
+            loc = [self._local_ztsk(p) for p in (point, stepper.dir_cent, stepper.dir_pred, stepper.dir_centadj, stepper.dir_predadj)]
+            L.check(L.lib().hyp_sys_search_alpha(
+                self.local._h, L.vec_ptr(loc[0]), L.vec_ptr(loc[1]), L.vec_ptr(loc[2]), L.vec_ptr(loc[3]), L.vec_ptr(loc[4]),
+                int(stepper.unadj_only), int(stepper.cent_only), L.vec_ptr(sc), len(sc), int(sched - 1), float(searcher.min_prox),
+                float(searcher.prox_bound), int(bool(searcher.use_max_prox)), float(searcher.nup1), L.vec_ptr(cand), ctypes.byref(idx),
+                ctypes.byref(prox), ctypes.byref(nt), ctypes.byref(nl), ctypes.byref(irtmu)), "hyp_sys_search_alpha")
         searcher.n_trials += nt.value
         self._last_cand = cand
         # host mirrors of this rank's cones follow the last candidate they were loaded with

@@ -47,6 +47,8 @@ class QRCholDenseSystemSolver:
 
     # ---- qrchol.jl:138-179
     def load(self, solver):
+        self.__dict__.pop("_screen_usable", None)   # (the candidate screen is decided per loaded model)
+        self._dirs_resident = False
         model = solver.model
         n, p, q = model.n, model.p, model.q
         lib = L.lib()

@@ -259,14 +259,18 @@ int hyp_sys_search_alpha(hyp_sys* sys, const double* point_ztsk, const double* d
  * device: nothing of length q is uploaded, the candidates of the whole schedule are formed there (combined.jl:124-170, the host
  * loop's operations in the host loop's order) and screened side by side; only a candidate that survives the screen comes back for
  * the sequential acceptance test.  For the caller who has not touched the vectors since that call (steppers/combined.jl:60-118
- * does not).  Error unless hyp_sys_search_screen_stats reports usable and a step_directions call preceded. */
+ * does not).  Error unless hyp_sys_search_screen_stats reports usable (sharded: on EVERY rank -- agree on it first, all ranks
+ * must make the same call) and a step_directions call preceded.  Sharded: the vectors are this rank's rows, as for
+ * hyp_sys_search_alpha. */
 int hyp_sys_search_alpha_resident(hyp_sys* sys, int unadj_only, int cent_only, const double* alpha_sched, int nsched, int start, double min_prox,
                                   double prox_bound, int use_max_prox, double nup1, double* cand_ztsk, int* accepted_index, double* prox,
                                   int* n_trials, int* n_loaded, double* irtmu);
-/* The side-by-side candidate screen inside hyp_sys_search_alpha[_resident] (a model of one primal-barrier PosSemidefTri cone, single
- * process: the rejecting tests of search.jl:86-116 / possemideftri.jl:80-95 / Cones.jl:294-310 for all remaining candidates of the
- * schedule at once; acceptance stays with the sequential test): usable = 1 where it applies (0: HYP_SEARCH_SCREEN=0, several
- * cones, sharded), screens run so far and candidates they rejected. */
+/* The side-by-side candidate screen inside hyp_sys_search_alpha[_resident]: the rejecting tests of search.jl:86-116 /
+ * possemideftri.jl:80-95 / Cones.jl:294-310 for all remaining candidates of the schedule at once; acceptance stays with the
+ * sequential test.  Applies to a model of one primal-barrier PosSemidefTri cone (single process) and to a model whose cones -- on
+ * a sharded solver: this rank's cones, on every rank -- are one run of at least four equal primal-barrier PosSemidefTri cones
+ * (batch = candidates x cones; sharded: two all-reduces of a few numbers per candidate make the verdicts the same on all ranks).
+ * usable = 1 where it applies to this handle (0 also with HYP_SEARCH_SCREEN=0), screens run so far and candidates they rejected. */
 int hyp_sys_search_screen_stats(hyp_sys* sys, int* usable, long long* screens, long long* rejected);
 int hyp_sys_get_lhs(hyp_sys* sys, double* out_nmpxnmp);        /* upper triangle meaningful (tests) */
 

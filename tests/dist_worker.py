@@ -65,6 +65,18 @@ def _lib_exchanges(solver):
         return np.zeros(2)
 
 
+def _screen_stats(solver):
+    try:
+        import ctypes
+        import hypatia_jl_amd as H
+        u, a, b = ctypes.c_int(0), ctypes.c_longlong(0), ctypes.c_longlong(0)
+        H._lib.check(H._lib.lib().hyp_sys_search_screen_stats(solver.syssolver.local._h, ctypes.byref(u), ctypes.byref(a), ctypes.byref(b)),
+                     "hyp_sys_search_screen_stats")
+        return np.array([u.value, a.value, b.value], dtype=np.float64)
+    except Exception:
+        return np.zeros(3)
+
+
 def run(rank, world, port, inst_args, out_path, backend="oracle", transport="gloo"):
     if backend == "hip":
         import torch   # noqa: F401  (first: one HIP runtime per process)
@@ -106,7 +118,8 @@ def run(rank, world, port, inst_args, out_path, backend="oracle", transport="glo
                      max_host_payload_in_loop=(max(in_loop) if in_loop else 0), host_collectives_in_loop=len(in_loop),
                      row_local=bool(getattr(solver.syssolver, "row_local", False)), q=model.q, n=model.n,
                      hooked=bool(getattr(solver.syssolver, "_hooked", False)), worst_dir_res=solver.worst_dir_res,
-                     rccl_in_library=bool(getattr(solver.syssolver, "rccl_in_library", False)), lib_exchanges=_lib_exchanges(solver))
+                     rccl_in_library=bool(getattr(solver.syssolver, "rccl_in_library", False)), lib_exchanges=_lib_exchanges(solver),
+                     screen_stats=_screen_stats(solver))
     finally:
         dist.destroy_process_group()
 

@@ -17,7 +17,11 @@ def test_sharded_hip_solve_with_runs_of_equal_cones(monkeypatch):
     """8 equal PSD cones, 4 per rank: each rank's cones form a run (group arena, batched feasibility / inverses / products /
     proximity scalars) inside the native sharded step"""
     monkeypatch.setenv("HYP_DIST_NATIVE", "1")
-    _run_sharded("1", inst_args=(90, [6] * 8, 3))
+    res = _run_sharded("1", inst_args=(90, [6] * 8, 3))
+    # the line search's candidates are screened side by side on every rank (candidates formed from the device-resident rows, two
+    # small all-reduces per search make the verdicts the same on both ranks): it ran in every iteration and rejected candidates
+    usable, screens, rejected = [int(v) for v in res["screen_stats"]]
+    assert usable == 1 and screens >= int(res["iters"]) and rejected > 0
 
 
 @pytest.mark.timeout(600)
