@@ -999,11 +999,20 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
           for (size_t k = 0; k < nc; ++k) {
             const double dk = cones[k]->dim, nuk = cones[k]->nu;
             const double* hp = ctx.h_pinned + 3 * k;
-            if (std::fabs(1 + hp[0] / nuk) > gtol * dk || std::fabs(1 - hp[1] / nuk) > Htol * dk) { ok = false; break; }   // Cones.jl:273-290
+            if (std::fabs(1 + hp[0] / nuk) > gtol * dk || std::fabs(1 - hp[1] / nuk) > Htol * dk) {   // Cones.jl:273-290
+              if (tdbg) fprintf(stderr, "[trial] run: numerics of cone %zu (%.3g, %.3g)\n", k, 1 + hp[0] / nuk, 1 - hp[1] / nuk);
+              ok = false;
+              break;
+            }
             const double pk = (hp[2] < -negtol * dk) ? INFINITY : std::fabs(hp[2]);                                        // Cones.jl:294-310
             agg = use_max_prox ? std::max(agg, pk) : agg + pk;
-            if (!dist() && !(agg < proxsqr_bound)) { ok = false; break; }
+            if (!dist() && !(agg < proxsqr_bound)) {
+              if (tdbg) fprintf(stderr, "[trial] run: proximity %.6g at cone %zu (bound %.6g)\n", agg, k, proxsqr_bound);
+              ok = false;
+              break;
+            }
           }
+          if (tdbg && ok) fprintf(stderr, "[trial] run: accepted so far, aggregate %.6g\n", agg);
           run_done = true;
         }
       }
@@ -1296,6 +1305,9 @@ void SysSolver::screen_candidates_run(const double* cd, int K, const double* tau
     }
     rej[g] = rj ? 1 : 0;
     screen_rejected += rej[g];
+    static const bool sdbg = [] { const char* e = getenv("HYP_TRIAL_DBG"); return e && e[0] == '1'; }();
+    if (sdbg) fprintf(stderr, "[screen] cand %d: scalars %d, cone test %g, no verdict %g, aggregate %.6g -> %s\n", g, (int)scal_rej[g], v2[g],
+                      v2[K + g], use_max_prox ? std::max(tkp[g], v2[2 * K + g]) : tkp[g] + v2[2 * K + g], rj ? "rejected" : "passed on");
   }
 }
 
@@ -1379,6 +1391,11 @@ int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp
     }
     smode = std::min(smode, screen_agreed) == 2 ? 2 : 0;
   }
+  // Candidates formed on the HOST (the caller's vectors) cost ~0.6 us per 1000 entries each and an upload: worth it for the 18 x
+  // 40 202 entries of config 2 (line search 1.54 -> 1.03 ms), not for the 18 x 414 722 of config 4 (sharded, one rank: 7.2 -> 8.9 ms).
+  // Without the resident vectors the screen therefore runs only up to 2^20 candidate entries, and never sharded (the ranks' row
+  // counts differ, the decision must not).
+  if (!resident && (dist() || (long)SCREEN_MAX * len > (1L << 20))) smode = 0;
   const bool screen = smode != 0;
   HYP_REQUIRE(!resident || (screen && s_resident), "search_alpha: no resident directions (step_directions first; a model the candidate screen applies to)");
   // candidates are formed in pinned memory and only the accepted one is copied to the caller's vector:
