@@ -1164,11 +1164,15 @@ int SysSolver::screen_mode() const {
   //  verdict the same on all ranks; HYP_SEARCH_SCREEN_DIST=0: off)
   static const bool dist_on = [] { const char* e = getenv("HYP_SEARCH_SCREEN_DIST"); return !(e && e[0] == '0'); }();
   if (!on || !lb_on || cones.empty() || (dist() && !dist_on)) return 0;
-  if (cones.size() == 1)
-    return (!dist() && cones[0]->kind == CONE_PSD && !cones[0]->use_dual_barrier && static_cast<const PsdCone*>(cones[0])->side >= 32) ? 1 : 0;
-  if (!run_on || psd_runs.size() != 1 || psd_runs[0].k0 != 0 || (size_t)psd_runs[0].count != cones.size()) return 0;
+  if (cones.size() == 1 && !dist())
+    return (cones[0]->kind == CONE_PSD && !cones[0]->use_dual_barrier && static_cast<const PsdCone*>(cones[0])->side >= 32) ? 1 : 0;
+  // (equal primal-barrier PosSemidefTri cones, back to back: the screen reads the candidates only, no cone state, so the cones need
+  //  not form a grouped run; sharded, one cone per rank -- the weak-scaling workload -- is the same thing with one matrix per
+  //  candidate)
+  if (!run_on) return 0;
+  const int sd0 = (cones[0]->kind == CONE_PSD) ? static_cast<const PsdCone*>(cones[0])->side : -1;
   for (const Cone* ck : cones)
-    if (ck->kind != CONE_PSD || ck->use_dual_barrier) return 0;
+    if (ck->kind != CONE_PSD || ck->use_dual_barrier || static_cast<const PsdCone*>(ck)->side != sd0) return 0;
   return 2;
 }
 
@@ -1219,8 +1223,7 @@ void SysSolver::screen_candidates_run(const double* cd, int K, const double* tau
                                       double nup1, bool use_max_prox, char* rej) {
   const double EPS = 2.220446049250313e-16;
   HYP_REQUIRE(K >= 1 && K <= SCREEN_MAX, "screen_candidates_run: batch size");
-  const PsdRun& r = psd_runs[0];
-  const int sd = r.side, B = r.count, dm = cones[0]->dim;
+  const int sd = static_cast<const PsdCone*>(cones[0])->side, B = (int)cones.size(), dm = cones[0]->dim;
   const long len = 2L * q + 2, s2 = (long)sd * sd, KB = (long)K * B, MB = (long)SCREEN_MAX * B;
   const double proxsqr_bound = prox_bound * prox_bound;
   double* P = screen_buf.d() + (long)SCREEN_MAX * len;   // layout as in screen_candidates, matrices per (candidate, cone)

@@ -125,7 +125,7 @@ struct SysSolver {
   long screen_count = 0, screen_rejected = 0;   // statistics: screens run, candidates they rejected
   bool screen_usable() const { return screen_mode() != 0; }
   int screen_agreed = -1;    // sharded: the minimum of the ranks' screen_mode(), agreed once per model (-1: not yet)
-  int screen_mode() const;   // 0: no screen; 1: one PosSemidefTri cone; 2: one run of equal PosSemidefTri cones is the whole model
+  int screen_mode() const;   // 0: no screen; 1: one PosSemidefTri cone (single process); 2: equal PosSemidefTri cones are the whole (local) model
   void screen_candidates_run(const double* d_cands, int K, const double* tau, const double* kap, double min_prox, double prox_bound,
                              double nup1, bool use_max_prox, char* rej);
   bool screen_survivor = false;   // set around the check_cone_points call of a candidate the screen has passed: its proximity lower bound is not evaluated again

@@ -267,9 +267,9 @@ int hyp_sys_search_alpha_resident(hyp_sys* sys, int unadj_only, int cent_only, c
                                   int* n_trials, int* n_loaded, double* irtmu);
 /* The side-by-side candidate screen inside hyp_sys_search_alpha[_resident]: the rejecting tests of search.jl:86-116 /
  * possemideftri.jl:80-95 / Cones.jl:294-310 for all remaining candidates of the schedule at once; acceptance stays with the
- * sequential test.  Applies to a model of one primal-barrier PosSemidefTri cone (single process) and to a model whose cones -- on
- * a sharded solver: this rank's cones, on every rank -- are one run of at least four equal primal-barrier PosSemidefTri cones
- * (batch = candidates x cones; sharded: two all-reduces of a few numbers per candidate make the verdicts the same on all ranks).
+ * sequential test.  Applies to a model whose cones -- on a sharded solver: this rank's cones, on every rank -- are all
+ * primal-barrier PosSemidefTri cones of one size (one cone or many: batch = candidates x cones; sharded: two all-reduces of a few
+ * numbers per candidate make the verdicts the same on all ranks).
  * usable = 1 where it applies to this handle (0 also with HYP_SEARCH_SCREEN=0), screens run so far and candidates they rejected. */
 int hyp_sys_search_screen_stats(hyp_sys* sys, int* usable, long long* screens, long long* rejected);
 int hyp_sys_get_lhs(hyp_sys* sys, double* out_nmpxnmp);        /* upper triangle meaningful (tests) */

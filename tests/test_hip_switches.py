@@ -26,6 +26,8 @@ elif name == "psd_single_wide":             # one cone of side 72 (three 16-colu
     inst = I.psd_blocks(90, [72], seed=9)
 elif name == "psd_run":                     # five equal cones: one run is the whole model (the grouped path of config 4)
     inst = I.psd_blocks(60, [24, 24, 24, 24, 24], seed=11)
+elif name == "psd_trio":                    # three equal cones: too few for a grouped run, the per-cone sweep of check_cone_points
+    inst = I.psd_blocks(50, [20, 20, 20], seed=12)
 elif name == "psd_pair":
     inst = I.psd_blocks(50, [40, 33], seed=6)
 elif name == "psd_plan":                     # n = 600: the factor has a super-block solve plan (n >= 512)
@@ -106,7 +108,7 @@ def test_constant_column_in_the_first_paired_solve_changes_no_bit():
         assert runs[0]["trace"] == runs[1]["trace"] == runs[2]["trace"], name
 
 
-@pytest.mark.parametrize("name", ["psd_single", "psd_single_wide", "psd_run"])
+@pytest.mark.parametrize("name", ["psd_single", "psd_single_wide", "psd_run", "psd_trio"])
 def test_screened_schedule_walk_changes_no_bit(name):
     """round 3: for a model of one PosSemidefTri cone (or of one run of equal ones: batch = candidates x cones) the schedule walk of search_alpha screens all remaining candidates side by
     side (HYP_SEARCH_SCREEN) -- the tests that reject, batched over the candidates -- and only survivors go
