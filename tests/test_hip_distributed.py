@@ -25,6 +25,16 @@ def test_sharded_hip_solve_with_runs_of_equal_cones(monkeypatch):
 
 
 @pytest.mark.timeout(600)
+def test_sharded_hip_solve_one_equal_cone_per_rank(monkeypatch):
+    """the weak-scaling layout (bench.py --config 2w): two equal PSD cones, ONE per rank.  The candidate screen runs per rank with one
+    matrix per candidate, its two all-reduces make the verdicts the same on both ranks; same solve as the oracle's"""
+    monkeypatch.setenv("HYP_DIST_NATIVE", "1")
+    res = _run_sharded("1", inst_args=(70, [14, 14], 5))
+    usable, screens, rejected = [int(v) for v in res["screen_stats"]]
+    assert usable == 1 and screens >= int(res["iters"]) and rejected > 0
+
+
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("native", ["1", "0"])
 def test_sharded_hip_solve_matches_oracle(native, monkeypatch):
     """native = 1: every rank runs the fused device routines on its rows / cones and the library calls back for the
