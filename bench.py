@@ -4,7 +4,8 @@
 A "step" is ONE interior-point iteration of Hypatia's CombinedStepper (update_lhs: sqrt-Hessian
 products + Schur syrk + Cholesky; four direction solves with refinement; line search).  Inputs are resident
 in HBM when the timed region starts.  If the solver converges inside the timed region it is put back at its
-initial iterate and keeps stepping.
+initial iterate and keeps stepping: the call that found it converged and the restart are TIME inside the region, not
+steps (`restarts_in_timed_region`) -- every counted step is a full iteration.
 
     python bench.py --gpus N --steps K --warmup W [--config 2|4|2w]
 prints ONE JSON line (rank 0): metric/value/unit + roofline (dominant kernel = the FP64-MFMA Schur syrk,
