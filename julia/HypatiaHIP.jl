@@ -564,6 +564,49 @@ function residual_products!(Gtz::Vector{Float64}, Gx_s::Vector{Float64}, dots::V
     return (Gtz, Gx_s, dots)
 end
 
+# ---------------------------------------------------------------------------------------------
+# The fused fast path of step(::CombinedStepper) (steppers/combined.jl:53-120), for a stepper method that wants it (p = 0):
+#   step_directions!      update_lhs + update_rhs_cent / _pred / _centadj / _predadj + the two paired solves in ONE device call
+#   search_alpha_resident the schedule walk of search.jl:46-69 on the point and directions that call left on the device: for models
+#                         of equal PosSemidefTri cones all remaining candidates are formed there and screened side by side, only the
+#                         survivor goes through check_cone_points; returns the accepted alpha (0 = none) with the accepted
+#                         candidate's z / tau / s / kap rows in cand_ztsk (copy them into point.ztsk: they are what the cones hold)
+# ---------------------------------------------------------------------------------------------
+function step_directions!(dirs4::Matrix{Float64}, res_norms::Vector{Float64}, sys::HIPQRCholDenseSystemSolver, solver, residuals::Vector{Float64})
+    ns = Ref{Cint}(0); info = Ref{Cint}(0); fb = Ref{Cint}(0)
+    flags = zeros(Cint, max(length(solver.model.cones), 1))
+    check(ccall((:hyp_sys_step_directions, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble, Cint, Cdouble, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Cint}, Ptr{Cint},
+            Ptr{Cint}, Ptr{Cint}, Ptr{Float64}),
+        sys.handle, solver.point.vec, residuals, solver.tau_residual, solver.mu, solver.max_ref_steps, solver.res_norm_cutoff, 0.5, dirs4,
+        res_norms, ns, flags, info, fb, sys.sol_const.vec), "hyp_sys_step_directions")
+    return (info[] == 0, Int(ns[]))
+end
+
+function search_screen_usable(sys::HIPQRCholDenseSystemSolver)
+    usable = Ref{Cint}(0); screens = Ref{Clonglong}(0); rejected = Ref{Clonglong}(0)
+    check(ccall((:hyp_sys_search_screen_stats, lib), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Clonglong}, Ptr{Clonglong}),
+        sys.handle, usable, screens, rejected), "hyp_sys_search_screen_stats")
+    return usable[] != 0
+end
+
+function search_alpha_resident(cand_ztsk::Vector{Float64}, sys::HIPQRCholDenseSystemSolver, stepper, searcher, start_sched::Int)
+    sched = Vector{Float64}(searcher.alpha_sched)
+    idx = Ref{Cint}(-1); prox = Ref{Cdouble}(0.0); nt = Ref{Cint}(0); nl = Ref{Cint}(0); irtmu = Ref{Cdouble}(0.0)
+    check(ccall((:hyp_sys_search_alpha_resident, lib), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Cint, Cint, Cdouble, Cdouble, Cint, Cdouble, Ptr{Float64}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cint},
+            Ptr{Cint}, Ptr{Cdouble}),
+        sys.handle, stepper.unadj_only, stepper.cent_only, sched, length(sched), start_sched - 1, searcher.min_prox, searcher.prox_bound,
+        searcher.use_max_prox, searcher.nup1, cand_ztsk, idx, prox, nt, nl, irtmu), "hyp_sys_search_alpha_resident")
+    if idx[] >= 0
+        searcher.prox = prox[]
+        searcher.prev_sched = idx[] + 1
+        return sched[idx[] + 1]
+    end
+    searcher.prev_sched = length(sched) + 1
+    return 0.0
+end
+
 # =============================================================================================
 # preprocessing: column-pivoted QR of [A; G] on the device (find_initial_x, src/Solvers/process.jl:64-178)
 # =============================================================================================
