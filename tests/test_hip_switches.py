@@ -44,7 +44,9 @@ elif name == "polymin_large_dual":
     inst = I.polymin(3, 7, False, seed=3)
 else:
     inst = I.KNOWN_ANSWER[name]()
-s = H.Solver(default_tol_relax=10)
+import os
+stepper = H.CombinedStepper(use_max_prox=False) if os.environ.get("HYP_TEST_SUM_PROX") == "1" else None   # (search.jl:8-39)
+s = H.Solver(default_tol_relax=10, stepper=stepper)
 trace = []
 s.iter_callback = lambda sv: trace.append((sv.primal_obj, sv.dual_obj, sv.mu, sv.point.tau, sv.x_feas, sv.z_feas))
 s.load(H.make_model(inst))
@@ -129,3 +131,16 @@ def test_screened_schedule_walk_changes_no_bit(name):
     assert off["screens"] == [0, 0]
     for r in (on, host, lb):
         assert r["screens"][0] >= r["iters"] and r["screens"][1] > 0   # (it ran, and it rejected something)
+
+
+@pytest.mark.parametrize("name", ["psd_single", "psd_run"])
+def test_screened_schedule_walk_with_summed_proximity(name):
+    """the same with use_max_prox = false (search.jl:126-131: the cones' proximity values add up instead of the largest one
+    counting): the screen aggregates as the sequential test does, the iterates are bitwise those of the sequential walk"""
+    on = _run(name, {"HYP_TEST_SUM_PROX": "1"})
+    off = _run(name, {"HYP_TEST_SUM_PROX": "1", "HYP_SEARCH_SCREEN": "0"})
+    assert on["status"] == off["status"] == "Optimal"
+    assert on["iters"] == off["iters"] >= 8
+    assert on["trace"] == off["trace"]
+    assert on["trials"] == off["trials"]
+    assert on["screens"][0] >= on["iters"] and on["screens"][1] > 0 and off["screens"] == [0, 0]
