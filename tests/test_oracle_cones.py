@@ -167,3 +167,37 @@ def test_wsosinterppossemideftri_barrier():   # test/cone.jl:782-803
     def barrier(s):
         return -sum(np.linalg.slogdet(cone._block_matrix(s, Pk))[1] for Pk in Ps)
     run_test_barrier(cone, barrier)
+
+
+@pytest.mark.parametrize("side", [3, 8, 17])
+def test_possemideftri_proximity_identity_of_the_candidate_screen(side):
+    """the device's side-by-side candidate screen evaluates PosSemidefTri's proximity value in an inverse-free
+    form: with smat(s) = U'U and v = z / sqrt(mu) + g(s / sqrt(mu)),  <v, H^-1 v> = || U Z U' / mu - I ||_F^2  (U the factor of
+    the UNSCALED primal point; = ||W||^2 / mu^2 - 2 tr W / mu + side for W = U Z U').  Here against the oracle's get_proxsqr
+    (Cones.jl:294-310) on points near and far from the central path."""
+    rng = np.random.default_rng(side)
+    dim = au.svec_length(side)
+    for spread in (0.05, 0.5, 3.0):
+        A = rng.standard_normal((side, side))
+        S = A @ A.T / side + np.eye(side)
+        w, V = np.linalg.eigh(S)
+        mu = 0.37
+        Z = (V * (mu / w * np.exp(spread * rng.standard_normal(side)))) @ V.T     # Z S / mu = I up to the spread
+        Z = (Z + Z.T) / 2
+        s, z = np.zeros(dim), np.zeros(dim)
+        au.smat_to_svec(s, np.triu(S))
+        au.smat_to_svec(z, np.triu(Z))
+        irtmu = 1.0 / np.sqrt(mu)
+        cone = oc.PosSemidefTri(dim)
+        cone.setup_data()
+        cone.load_point(s, irtmu)
+        cone.load_dual_point(z)
+        cone.reset_data()
+        assert cone.is_feas()
+        ref = cone.get_proxsqr(irtmu, True)
+        U = np.linalg.cholesky(S).T                                               # S = U'U
+        W = U @ Z @ U.T
+        direct = np.linalg.norm(W / mu - np.eye(side), "fro") ** 2
+        expanded = np.sum(W * W) / mu ** 2 - 2.0 * np.trace(W) / mu + side
+        assert abs(direct - ref) <= 1e-9 * (1 + ref), (side, spread, direct, ref)
+        assert abs(expanded - ref) <= 1e-9 * (1 + ref), (side, spread, expanded, ref)
