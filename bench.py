@@ -55,7 +55,11 @@ def algorithm_record():
     on = lambda name: os.environ.get(name, "1")[:1] != "0"
     return {"ens_closed_form_inverse": on("HYP_ENS_CLOSED_INV"), "prox_lower_bound": on("HYP_PROX_LB"),
             "side_by_side_candidate_evaluation": on("HYP_ENS_PREFETCH") and on("HYP_WSOS_PAR"),
+            # models of equal PosSemidefTri cones: the rejecting tests of ALL remaining candidates of the schedule at once, the
+            # survivor through the sequential test (same accepted step, same iterates: DESIGN.md section 7)
+            "line_search_candidate_screen": on("HYP_SEARCH_SCREEN") and on("HYP_PROX_LB"),
             "triangular_solve_refinement_steps": int(os.environ.get("HYP_TRSM_REFINE", "2")),
+            # (the candidate screen needs the proximity bound: off with HYP_PROX_LB=0)
             "reference_route": not (on("HYP_ENS_CLOSED_INV") or on("HYP_PROX_LB") or on("HYP_ENS_PREFETCH") or on("HYP_WSOS_PAR"))}
 
 
