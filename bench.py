@@ -154,6 +154,22 @@ def gen_block(n, side, k, seed):
     return G_k
 
 
+def gen_polymin5(primal_form, seed, keep=None, nvars=4, halfdeg=8):
+    """configs[4] generator (examples/polymin/native.jl:56-90 in both forms): interpolation points from twice as many random
+    candidates on the box by pivoted QR, a quartic objective sampled at them.  keep = a recorded choice of the points (the pivot order of
+    dgeqp3 can depend on the BLAS build; the full-size golden trajectories of tests/golden/ record theirs)."""
+    from oracle import polyutils as pu      # (interpolation data = instance data)
+    rng = np.random.default_rng(seed)
+    U, pts, Ps = pu.interpolate_box([-1.0] * nvars, [1.0] * nvars, halfdeg, rng=rng, sample_factor=2, keep=keep)
+    a = rng.uniform(-0.5, 0.5, nvars)
+    vals = np.sum((pts - a) ** 2, axis=1) + (pts[:, 0] * pts[:, 1] - pts[:, 2] * pts[:, 3]) ** 2 + 0.3 * pts[:, 0] * pts[:, 2]
+    if primal_form:
+        inst = (np.array([-1.0]), np.zeros((0, 1)), np.zeros(0), np.ones((U, 1)), vals, [("wsosinterpnonnegative", U, Ps, False)], {})
+    else:
+        inst = (vals, np.ones((1, U)), np.array([1.0]), -np.eye(U), np.zeros(U), [("wsosinterpnonnegative", U, Ps, True)], {})
+    return inst, U, Ps
+
+
 def emit_json_line(out):
     """the ONE JSON line, guaranteed to be the last thing on stdout: RCCL prints a version banner through C stdio, which (block-
     buffered when stdout is a pipe) would otherwise surface at exit, after the line; whatever a library writes later goes nowhere"""
@@ -488,7 +504,7 @@ def run_headline(args, world, rank, local_rank, multi, comm=None):
         "kkt_solves_per_step": n_solves / args.steps,
         "ms_per_kkt_solve": solver.time_getdir / max(n_solves, 1) * 1e3,
         "search_trials_per_step": n_trials / args.steps,
-        # of those, the candidates the side-by-side screen rejected (batches of up to 8, one read-back each) -- the others
+        # of those, the candidates the side-by-side screen rejected (batches of up to SCREEN_MAX = 18 = the whole schedule, one read-back each) -- the others
         # went through the sequential acceptance test
         "search_screens_per_step": ((screen_stats()[0] - screens0[0]) / args.steps) if screen_stats is not None else 0.0,
         "search_trials_screened_out_per_step": ((screen_stats()[1] - screens0[1]) / args.steps) if screen_stats is not None else 0.0,
@@ -588,15 +604,7 @@ def main_other(args):
                 "Hessian -- not the reference's algorithm for this cone" % (sd, sd, 1 + sd * sd))
         solver_opts = dict(init_use_indirect=True)   # (G has orthogonal columns: LSQR, the reference's init_use_indirect, ends in three steps)
     else:
-        from oracle import polyutils as pu
-        rng = np.random.default_rng(args.seed)
-        U, pts, Ps = pu.interpolate_box([-1.0] * 4, [1.0] * 4, 8, rng=rng, sample_factor=2)
-        a = rng.uniform(-0.5, 0.5, 4)
-        vals = np.sum((pts - a) ** 2, axis=1) + (pts[:, 0] * pts[:, 1] - pts[:, 2] * pts[:, 3]) ** 2 + 0.3 * pts[:, 0] * pts[:, 2]
-        if args.config == "5p":
-            inst = (np.array([-1.0]), np.zeros((0, 1)), np.zeros(0), np.ones((U, 1)), vals, [("wsosinterpnonnegative", U, Ps, False)], {})
-        else:
-            inst = (vals, np.ones((1, U)), np.array([1.0]), -np.eye(U), np.zeros(U), [("wsosinterpnonnegative", U, Ps, True)], {})
+        inst, U, Ps = gen_polymin5(args.config == "5p", args.seed)
         work = "configs[4]: polymin, WSOSInterpNonnegative, 4 variables, half-degree 8 (U = %d), %s form" % (U, "primal" if args.config == "5p" else "dual")
     t_setup = time.perf_counter() - t_setup
     steps = args.steps if args.steps is not None else 40

@@ -1150,6 +1150,7 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   }
   s_tk[0][0] = tau;
   s_tk[0][1] = kap;
+  s_resident_q = q;
   s_resident = (MR == 2);   // the point (s_point) and the four directions (s_dirs) are on the device until the next call
 }
 

@@ -246,6 +246,7 @@ int SysSolver::run_hess_prod(size_t k, double* prod, long ldp, const double* arr
 
 void SysSolver::load(const double* hG, const double* hGQ1, const double* hGQ2, const double* hQ, const double* hR) {
   const size_t d = sizeof(double);
+  s_resident = false;   // (resident directions belong to the G they were computed with)
   ctx.h2d(G.p, hG, (size_t)q * n * d);
   if (p > 0) {
     HYP_REQUIRE(hQ && hR, "sys: Q, R are required when p > 0");
@@ -668,6 +669,7 @@ void SysSolver::load_model(const double* hc, const double* hb, const double* hh,
   ctx.sync();
   model_loaded = true;
   screen_agreed = -1;
+  s_resident = false;   // (the point and directions of an earlier model are not this model's)
 }
 
 // rhs_const = [-c; b; H h], sol_const = solve_subsystem3(rhs_const)   (qrchol.jl:191-197)
@@ -1164,8 +1166,9 @@ int SysSolver::screen_mode() const {
   //  verdict the same on all ranks; HYP_SEARCH_SCREEN_DIST=0: off)
   static const bool dist_on = [] { const char* e = getenv("HYP_SEARCH_SCREEN_DIST"); return !(e && e[0] == '0'); }();
   if (!on || !lb_on || cones.empty() || (dist() && !dist_on)) return 0;
-  if (cones.size() == 1 && !dist())
-    return (cones[0]->kind == CONE_PSD && !cones[0]->use_dual_barrier && static_cast<const PsdCone*>(cones[0])->side >= 32) ? 1 : 0;
+  if (cones.size() == 1 && !dist())   // (the one-cone form lays its buffers out for the whole schedule: all of it must fit)
+    return (cones[0]->kind == CONE_PSD && !cones[0]->use_dual_barrier && static_cast<const PsdCone*>(cones[0])->side >= 32 &&
+            screen_kmax() == SCREEN_MAX) ? 1 : 0;
   // (equal primal-barrier PosSemidefTri cones, back to back: the screen reads the candidates only, no cone state, so the cones need
   //  not form a grouped run; sharded, one cone per rank -- the weak-scaling workload -- is the same thing with one matrix per
   //  candidate)
@@ -1173,7 +1176,22 @@ int SysSolver::screen_mode() const {
   const int sd0 = (cones[0]->kind == CONE_PSD) ? static_cast<const PsdCone*>(cones[0])->side : -1;
   for (const Cone* ck : cones)
     if (ck->kind != CONE_PSD || ck->use_dual_barrier || static_cast<const PsdCone*>(ck)->side != sd0) return 0;
-  return 2;
+  return screen_kmax() >= 2 ? 2 : 0;   // (too many cones / too large a side for a batch of two: the sequential walk)
+}
+
+// Candidates per batch that the screen's buffers admit for THIS model (all cones PosSemidefTri of one side): the flags and sums of the
+// K x B (candidate, cone) pairs come back through the pinned blocks (64 + 2 K B of h_info's 8192 ints, 128 + 3 K B of h_pinned's
+// doubles) and screen_buf holds K candidates + 6 K B side x side matrices, bounded by a byte budget (HYP_SCREEN_MB, default 2048).
+// A model beyond these walks the schedule in smaller batches, or sequentially (screen_mode() = 0) when not even two candidates fit.
+int SysSolver::screen_kmax() const {
+  static const long budget = [] { const char* e = getenv("HYP_SCREEN_MB"); return (e ? std::max(1L, atol(e)) : 2048L) << 20; }();
+  if (cones.empty() || cones[0]->kind != CONE_PSD) return 0;
+  const long B = (long)cones.size(), sd = static_cast<const PsdCone*>(cones[0])->side, s2 = sd * sd, len = 2L * q + 2;
+  long k = SCREEN_MAX;
+  k = std::min(k, (8192L - 64) / (2 * B));
+  k = std::min(k, ((long)ctx.h_pinned_n - 128) / (3 * B));
+  k = std::min(k, budget / ((len + 6 * B * s2 + 3 * B) * (long)sizeof(double)));
+  return (int)std::max(k, 0L);
 }
 
 // ---- the same screen for a model that is ONE RUN of equal PosSemidefTri cones (config 4: 64 cones of side 80): batch =
@@ -1222,17 +1240,18 @@ __global__ __launch_bounds__(256) void screen_norm_trace_kernel(int side, const 
 void SysSolver::screen_candidates_run(const double* cd, int K, const double* tau, const double* kap, double min_prox, double prox_bound,
                                       double nup1, bool use_max_prox, char* rej) {
   const double EPS = 2.220446049250313e-16;
-  HYP_REQUIRE(K >= 1 && K <= SCREEN_MAX, "screen_candidates_run: batch size");
+  const int kcap = screen_kmax();
+  HYP_REQUIRE(K >= 1 && K <= kcap, "screen_candidates_run: batch size");
   const int sd = static_cast<const PsdCone*>(cones[0])->side, B = (int)cones.size(), dm = cones[0]->dim;
-  const long len = 2L * q + 2, s2 = (long)sd * sd, KB = (long)K * B, MB = (long)SCREEN_MAX * B;
+  const long len = 2L * q + 2, s2 = (long)sd * sd, KB = (long)K * B, MB = (long)kcap * B;
   const double proxsqr_bound = prox_bound * prox_bound;
-  double* P = screen_buf.d() + (long)SCREEN_MAX * len;   // layout as in screen_candidates, matrices per (candidate, cone)
+  double* P = screen_buf.d() + (long)kcap * len;   // layout as in screen_candidates, matrices per (candidate, cone)
   double* D = P + KB * s2;
   double* UT = D + KB * s2;
   double* Z = UT + KB * s2;
   double* T = Z + KB * s2;
   double* W = T + KB * s2;
-  double* outv = screen_buf.d() + (long)SCREEN_MAX * len + 6L * MB * s2;   // [sz (MB) | norm, trace (2 MB)]
+  double* outv = screen_buf.d() + (long)kcap * len + 6L * MB * s2;   // [sz (MB) | norm, trace (2 MB)]
   screen_info.ensure((size_t)2 * MB * sizeof(int));
   hipLaunchKernelGGL(screen_dot_run_kernel, dim3(B, K), dim3(256), 0, ctx.stream, dm, cd, len, (long)q + 1, B, outv);
   svec_unpack_grouped(ctx, sd, K, B, cd + q + 1, len, dm, P);    // PsdCone::update_feas (possemideftri.jl:80-90) of the unscaled s_k
@@ -1292,6 +1311,10 @@ void SysSolver::screen_candidates_run(const double* cd, int K, const double* tau
     for (int k = 0; k < B; ++k) {
       const double nu_k = cones[k]->nu, rel = szk[k] / (mu * nu_k);
       if (lt(rel, min_prox) || gt(nu_k * (rel - 1.0) * (rel - 1.0), proxsqr_bound)) { v2[g] = 1.0; break; }
+      // A failed factorization rejects without a margin although the sequential test factors s_k / sqrt(mu), not s_k: the two can
+      // disagree only where a pivot is at rounding level, i.e. smat(s_k) or smat(z_k) is numerically singular -- and then W = U Z U' / mu
+      // has an eigenvalue at rounding level, || W - I ||_F^2 >= 1 - O(eps cond) > prox_bound^2 = 0.98, so the sequential walk
+      // rejects the candidate on proximity (search.jl:126-136) whichever way ITS factorization falls.  Same accepted step either way.
       if (hi[(long)g * B + k] != 0 || hi[KB + (long)g * B + k] != 0) { v2[g] = 1.0; break; }
       const double v = nt[2 * k] / (mu * mu) - 2.0 * nt[2 * k + 1] / mu + (double)sd;
       if (!(v == v) || !(v < INFINITY)) { v2[K + g] = 1.0; break; }
@@ -1371,7 +1394,7 @@ void SysSolver::screen_candidates(const double* cd, int K, const double* tau, co
     else if (lt(sz, EPS) || lt(mu, EPS)) r = true;
     else if (lt(taukap_rel, min_prox) || gt((taukap_rel - 1.0) * (taukap_rel - 1.0), proxsqr_bound)) r = true;
     else if (lt(rel, min_prox) || gt(nu_k * (rel - 1.0) * (rel - 1.0), proxsqr_bound)) r = true;
-    else if (hi[g] != 0 || hi[K + g] != 0) r = true;
+    else if (hi[g] != 0 || hi[K + g] != 0) r = true;   // (no margin needed: see screen_candidates_run)
     else if (v == v && v < INFINITY && v / (1.0 + 1e-5) > limit) r = true;
     rej[g] = r ? 1 : 0;
     screen_rejected += rej[g];
@@ -1400,7 +1423,9 @@ int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp
   // counts differ, the decision must not).
   if (!resident && (dist() || (long)SCREEN_MAX * len > (1L << 20))) smode = 0;
   const bool screen = smode != 0;
-  HYP_REQUIRE(!resident || (screen && s_resident), "search_alpha: no resident directions (step_directions first; a model the candidate screen applies to)");
+  const int kcap = screen ? screen_kmax() : 1;   // candidates per batch (SCREEN_MAX unless the model is too big for the buffers)
+  HYP_REQUIRE(!resident || (screen && s_resident && s_resident_q == q),
+              "search_alpha: no resident directions (step_directions first; a model the candidate screen applies to)");
   // candidates are formed in pinned memory and only the accepted one is copied to the caller's vector:
   // the upload inside check_cone_points is then a plain asynchronous copy -- from the caller's pageable vector it stopped the
   // host for the whole transfer, once per trial
@@ -1432,13 +1457,13 @@ int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp
   int idx = start;
   static const bool skip_lb = [] { const char* e = getenv("HYP_SCREEN_SKIP_LB"); return !(e && e[0] == '0'); }();
   while (idx < nsched) {
-    const int K = screen ? std::min((int)SCREEN_MAX, nsched - idx) : 1;
+    const int K = screen ? std::min(kcap, nsched - idx) : 1;
     if (K >= 2 || resident) {
       char rej[SCREEN_MAX];
       double ctau[SCREEN_MAX], ckap[SCREEN_MAX];
       const long s2 = (long)static_cast<const PsdCone*>(cones[0])->side * static_cast<const PsdCone*>(cones[0])->side;
-      const long nmat = (long)SCREEN_MAX * (long)cones.size();   // matrices per buffer: candidates x cones
-      screen_buf.ensure((size_t)((long)SCREEN_MAX * len + 6L * nmat * s2 + 3 * nmat) * sizeof(double));
+      const long nmat = (long)kcap * (long)cones.size();   // matrices per buffer: candidates x cones
+      screen_buf.ensure((size_t)((long)kcap * len + 6L * nmat * s2 + 3 * nmat) * sizeof(double));
       double* cd = screen_buf.d();
       if (resident) {   // the five vectors are on the device: so are the candidates
         ScreenForm f{};

@@ -125,6 +125,7 @@ struct SysSolver {
   long screen_count = 0, screen_rejected = 0;   // statistics: screens run, candidates they rejected
   bool screen_usable() const { return screen_mode() != 0; }
   int screen_agreed = -1;    // sharded: the minimum of the ranks' screen_mode(), agreed once per model (-1: not yet)
+  int screen_kmax() const;   // candidates per screening batch the buffers admit for this model (<= SCREEN_MAX; < 2: no screen)
   int screen_mode() const;   // 0: no screen; 1: one PosSemidefTri cone (single process); 2: equal PosSemidefTri cones are the whole (local) model
   void screen_candidates_run(const double* d_cands, int K, const double* tau, const double* kap, double min_prox, double prox_bound,
                              double nup1, bool use_max_prox, char* rej);
@@ -135,6 +136,7 @@ struct SysSolver {
   // what step_directions left on the device: the point, the four directions (s_dirs: cent, pred, centadj, predadj) and the
   // tau / kap entries of the five vectors (which travel on the host)
   bool s_resident = false;
+  int s_resident_q = -1;   // the q the resident vectors were formed with
   double s_tk[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
   double residual(double* res, const double* dir, const double* rhs, Scal rs, Scal dcur, Scal& rsc, double mu, double taubar);
   double refine(double* rhs, double* dir, double* res, double* tmp, Scal rs, Scal& dsc, Scal rsc, double res_norm, double mu, double taubar,

@@ -442,7 +442,11 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
         # (partition_cones deals out contiguous blocks of cones).
         r = self.rows
         contiguous = r.shape[0] > 0 and np.array_equal(r, np.arange(r[0], r[0] + r.shape[0]))
-        if contiguous and os.environ.get("HYP_DIST_ROW_LOCAL", "1") not in ("0",):
+        # The row-local state is only read by the FUSED step (solvers.py CombinedStepper.step): the unfused branches
+        # (HYP_NO_FUSED_STEP=1 / HYP_NO_PAIR=1) build their right-hand sides from full-length point.z / point.s / z_residual,
+        # so with either switch the driver stays replicated.
+        unfused = any(os.environ.get(k, "0") not in ("", "0") for k in ("HYP_NO_FUSED_STEP", "HYP_NO_PAIR"))
+        if contiguous and not unfused and os.environ.get("HYP_DIST_ROW_LOCAL", "1") not in ("0",):
             self.rsl = slice(int(r[0]), int(r[0]) + int(r.shape[0]))
             self.row_local = True
             self._last_cand = None

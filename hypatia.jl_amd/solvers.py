@@ -425,6 +425,7 @@ class CombinedStepper:
 
         sysv = solver.syssolver
         fused = (_cap(sysv, "fused") and model.p == 0 and not _env_on("HYP_NO_PAIR") and not _env_on("HYP_NO_FUSED_STEP"))
+        assert fused or not getattr(sysv, "row_local", False), "the row-local sharded driver needs the fused step (distributed.py)"
         if fused:   # update_lhs + the four right-hand sides + the two paired solves: one device call
             lib_t0 = T()
             ok = sysv.step_directions_native(solver, self)

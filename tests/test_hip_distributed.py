@@ -86,7 +86,19 @@ def test_sharded_total_factorization_failure(native, monkeypatch):
     assert str(res["status"]) == "NumericalFailure" and int(res["iters"]) == 0
 
 
-def _run_sharded(native, inst_args=(120, [20, 12, 16, 9], 4), world=2, transport="gloo"):
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("switch", ["HYP_NO_FUSED_STEP", "HYP_NO_PAIR"])
+def test_sharded_hip_solve_with_the_fused_step_switched_off(switch, monkeypatch):
+    """the documented switches that take the stepper off the fused device step must stay safe on the sharded
+    solver: the unfused branches read full-length point.z / point.s / z_residual, so the driver may not be row-local then
+    (round-3 advisor finding: directions came out silently wrong and different per rank)"""
+    monkeypatch.setenv("HYP_DIST_NATIVE", "1")
+    monkeypatch.setenv(switch, "1")
+    res = _run_sharded("1", expect_row_local=False)
+    assert not bool(res["row_local"])
+
+
+def _run_sharded(native, inst_args=(120, [20, 12, 16, 9], 4), world=2, transport="gloo", expect_row_local=True):
     import dist_worker
     from oracle import instances as I
     from oracle.build import make_model
@@ -105,7 +117,7 @@ def _run_sharded(native, inst_args=(120, [20, 12, 16, 9], 4), world=2, transport
     ref.load(make_model(I.psd_blocks(*inst_args)))
     ref.solve()
     assert bool(res["hooked"]) == (native == "1")
-    if native == "1":
+    if native == "1" and expect_row_local:
         # the device-resident sharded step: every rank keeps only ITS rows of z / s and of the four directions; inside the
         # iteration loop nothing of length q crosses the host-level transport (the library's own exchanges are the n x n Schur
         # sum, n-vectors and scalars: hyp_sys_comm_stats), and the solution still matches the oracle's (below)

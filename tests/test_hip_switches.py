@@ -28,6 +28,8 @@ elif name == "psd_run":                     # five equal cones: one run is the w
     inst = I.psd_blocks(60, [24, 24, 24, 24, 24], seed=11)
 elif name == "psd_trio":                    # three equal cones: too few for a grouped run, the per-cone sweep of check_cone_points
     inst = I.psd_blocks(50, [20, 20, 20], seed=12)
+elif name == "psd_many_small":              # 300 cones of side 3: more (candidate, cone) pairs than the screen's pinned blocks hold at 18 candidates
+    inst = I.psd_blocks(60, [3] * 300, seed=13)
 elif name == "psd_pair":
     inst = I.psd_blocks(50, [40, 33], seed=6)
 elif name == "psd_plan":                     # n = 600: the factor has a super-block solve plan (n >= 512)
@@ -143,4 +145,19 @@ def test_screened_schedule_walk_with_summed_proximity(name):
     assert on["iters"] == off["iters"] >= 8
     assert on["trace"] == off["trace"]
     assert on["trials"] == off["trials"]
+    assert on["screens"][0] >= on["iters"] and on["screens"][1] > 0 and off["screens"] == [0, 0]
+
+
+def test_screen_batches_shrink_for_models_with_many_cones():
+    """round-3 advisor finding: with 226 or more equal PSD cones the 18-candidate batch overran the pinned read-back blocks and
+    search_alpha raised in iteration 1 (the sequential walk had accepted such models).  The batch size now follows the model
+    (SysSolver::screen_kmax: 13 candidates at 300 cones), and a byte budget too small for two candidates (HYP_SCREEN_MB) turns the
+    screen off instead of failing an allocation.  Same iterates, to the bit, in all three forms."""
+    on = _run("psd_many_small", {})
+    tiny = _run("psd_many_small", {"HYP_SCREEN_MB": "1"})     # 1 MiB: 300 cones x 6 matrices x 9 doubles + candidates -> fewer per batch
+    off = _run("psd_many_small", {"HYP_SEARCH_SCREEN": "0"})
+    assert on["status"] == tiny["status"] == off["status"] == "Optimal"
+    assert on["iters"] == tiny["iters"] == off["iters"] >= 8
+    assert on["trace"] == off["trace"] and tiny["trace"] == off["trace"]
+    assert on["trials"] == tiny["trials"] == off["trials"]
     assert on["screens"][0] >= on["iters"] and on["screens"][1] > 0 and off["screens"] == [0, 0]

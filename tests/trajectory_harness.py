@@ -59,17 +59,55 @@ def _wsos_spec(nvars, halfdeg, use_dual):
 
 def _golden_keep(name):
     """the interpolation-point choice a committed trajectory was computed with (None: not recorded / not needed)"""
-    f = os.path.join(ROOT, "tests", "golden", "trajectory_wsos.json")
-    if not os.path.exists(f) or os.environ.get("HYP_GOLDEN_REGEN"):
+    if os.environ.get("HYP_GOLDEN_REGEN"):
         return None
-    rec = json.load(open(f))["cases"].get(name)
-    return None if rec is None else rec.get("interp_keep")
+    for fn in ("trajectory_wsos.json", "trajectory_fullsize.json"):
+        f = os.path.join(ROOT, "tests", "golden", fn)
+        if os.path.exists(f):
+            rec = json.load(open(f))["cases"].get(name)
+            if rec is not None:
+                return rec.get("interp_keep")
+    return None
+
+
+def fullsize_instance(name):
+    """the BASELINE.json configurations AS BENCHMARKED (bench.py's generators) and mid sizes on the same generator:
+      psdfull_<n>_<side>x<count>_<seed>   bench.gen_instance(n, [side] * count, seed): config 2 is psdfull_5000_200x1_1
+      cfg4_<n>_<side>x<count>_<seed>      bench.gen_block per cone (config 4 = cfg4_5000_80x64_1: G = 8.3 GB)
+      cfg5p_<seed> / cfg5d_<seed>         bench.gen_polymin5 (U = 4845), primal / dual form"""
+    import bench
+    kind, rest = name.split("_", 1)
+    if kind == "psdfull":
+        n, sc, seed = rest.split("_")
+        side, count = sc.split("x")
+        return bench.gen_instance(int(n), [int(side)] * int(count), int(seed))
+    if kind == "cfg4":
+        n, sc, seed = rest.split("_")
+        n, seed = int(n), int(seed)
+        side, count = (int(v) for v in sc.split("x"))
+        dim = side * (side + 1) // 2
+        x0 = np.random.default_rng(seed).standard_normal(n)
+        e_k = bench.svec_identity(side)
+        G = np.empty((dim * count, n), order="F")
+        h = np.zeros(dim * count)
+        c = np.zeros(n)
+        for k in range(count):
+            G_k = bench.gen_block(n, side, k, seed)
+            G[k * dim:(k + 1) * dim] = G_k
+            h[k * dim:(k + 1) * dim] = G_k @ x0 + e_k
+            c -= G_k.T @ e_k
+        return (c, np.zeros((0, n)), np.zeros(0), G, h, [("possemideftri", dim)] * count, dict(status="Optimal"))
+    if kind in ("cfg5p", "cfg5d"):
+        return bench.gen_polymin5(kind == "cfg5p", int(rest), keep=_golden_keep(name))[0]
+    raise KeyError(name)
 
 
 def instance(name):
     """named instances of the trajectory tests: matrix completion (examples/matrixcompletion/native.jl:23-70), polymin in both
     forms (examples/polymin/native.jl:56-90), the reference's own EpiNormSpectral / WSOS known-answer instances, mixed models"""
     from oracle import instances as I
+    if name.split("_")[0] in ("psdfull", "cfg4", "cfg5p", "cfg5d"):
+        return fullsize_instance(name)
     if name.startswith("mc_"):                      # mc_<d1>x<d2>_<seed>
         dd, seed = name[3:].split("_")
         d1, d2 = dd.split("x")
@@ -98,13 +136,37 @@ def perturbed(inst, seed=99):
     return inst[:3] + (G2, h2) + inst[5:]
 
 
-def run_trajectory(solver_cls, model, gate_log=None, **opts):
+PROBE_ROWS, PROBE_VECS, PROBE_SEED = 64, 4, 2024
+
+
+def schur_probe(S_upper, seed=PROBE_SEED):
+    """what the full-size fixtures keep of an nm x nm Schur matrix (qrchol.jl:201-257; 200 MB at n = 5000): a seeded 64 x 64
+    sub-block, the diagonal, S V for four seeded probe vectors and the Frobenius norm.  S_upper: its upper triangle (syrk 'U')."""
+    S = np.triu(S_upper)
+    S = S + np.triu(S, 1).T
+    nm = S.shape[0]
+    rng = np.random.default_rng(seed)
+    rows = np.sort(rng.choice(nm, size=min(PROBE_ROWS, nm), replace=False))
+    cols = np.sort(rng.choice(nm, size=min(PROBE_ROWS, nm), replace=False))
+    V = rng.standard_normal((nm, PROBE_VECS))
+    return dict(sub=S[np.ix_(rows, cols)].copy(), diag=np.diag(S).copy(), SV=S @ V, fro=np.array([np.linalg.norm(S)]))
+
+
+def run_trajectory(solver_cls, model, gate_log=None, probe_iters=(), probes=None, **opts):
+    """probe_iters: iteration numbers at whose top the Schur matrix of the PREVIOUS update_lhs is probed into `probes`
+    (1 = the matrix assembled at the initial iterate)"""
     rows = []
     s = solver_cls(**opts)
     if gate_log is not None:
         s.gate_log = gate_log
-    s.iter_callback = lambda sv: rows.append((sv.primal_obj, sv.dual_obj, sv.gap, sv.x_feas, sv.z_feas, sv.point.tau,
-                                              sv.point.kap, sv.mu, getattr(sv.stepper, "prev_alpha", 1.0)))
+
+    def cb(sv):
+        rows.append((sv.primal_obj, sv.dual_obj, sv.gap, sv.x_feas, sv.z_feas, sv.point.tau, sv.point.kap, sv.mu,
+                     getattr(sv.stepper, "prev_alpha", 1.0)))
+        if sv.num_iters in probe_iters:
+            ss = sv.syssolver
+            probes[sv.num_iters] = schur_probe(ss.get_lhs() if hasattr(ss, "get_lhs") else ss.lhs_sub)
+    s.iter_callback = cb
     s.load(model)
     s.solve()
     return s, np.array(rows)
@@ -127,25 +189,26 @@ def gate_margins(gate_log, n_rows):
     return m
 
 
-def oracle_trajectory(inst, **opts):
+def oracle_trajectory(inst, probe_iters=(), **opts):
     from oracle.build import make_model as omodel
     from oracle.solvers import Solver as OSolver
-    log = []
-    s, t = run_trajectory(OSolver, omodel(inst), gate_log=log, **opts)
-    return dict(status=s.status, iters=s.num_iters, p_obj=s.primal_obj, rows=t, gate=gate_margins(log, len(t)))
+    log, probes = [], {}
+    s, t = run_trajectory(OSolver, omodel(inst), gate_log=log, probe_iters=probe_iters, probes=probes, **opts)
+    return dict(status=s.status, iters=s.num_iters, p_obj=s.primal_obj, rows=t, gate=gate_margins(log, len(t)), probes=probes)
 
 
-def hip_trajectory(name, route, **opts):
+def hip_trajectory(name, route, timeout=1800, **opts):
     """HIP trajectory of a named instance under a route (env switches), in a process of its own"""
     env = dict(os.environ)
     for k in REFERENCE_ROUTE:
         env.pop(k, None)
     env.update(route)
     r = subprocess.run([sys.executable, os.path.abspath(__file__), name, json.dumps(opts)], cwd=ROOT, env=env,
-                       capture_output=True, text=True, timeout=1800)
+                       capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     d["rows"] = np.array(d["rows"])
+    d["probes"] = {int(k): {f: np.array(v) for f, v in p.items()} for k, p in d.get("probes", {}).items()}
     return d
 
 
@@ -201,5 +264,7 @@ if __name__ == "__main__":
     import hypatia_jl_amd as Hm
     nm = sys.argv[1]
     opts = json.loads(sys.argv[2]) if len(sys.argv) > 2 else {}
-    s, t = run_trajectory(Hm.Solver, Hm.make_model(instance(nm)), **opts)
-    print(json.dumps(dict(status=s.status, iters=s.num_iters, p_obj=s.primal_obj, rows=t.tolist())))
+    probes = {}
+    s, t = run_trajectory(Hm.Solver, Hm.make_model(instance(nm)), probe_iters=tuple(opts.pop("probe_iters", ())), probes=probes, **opts)
+    print(json.dumps(dict(status=s.status, iters=s.num_iters, p_obj=s.primal_obj, rows=t.tolist(),
+                          probes={str(k): {f: v.tolist() for f, v in p.items()} for k, p in probes.items()})))
