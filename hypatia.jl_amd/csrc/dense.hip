@@ -24,9 +24,12 @@ void potrf_diag_launch(hipStream_t st, bool factor, bool invert, int batch, int 
 int potrf_diag_own_cu_lds();
 void potrf_panel_solve_launch(hipStream_t st, int batch, double* A, long lda, long strideA, int k0, int mcols);
 // potrf_mfma.hip: the same two steps cut into 16 x 16 MFMA tiles (default; HYP_POTRF_MFMA=0 restores the first generation)
-void potrf_diag_mfma_launch(hipStream_t st, int batch, double* A, long lda, long strideA, int n, int k0, int* info, int own_cu_lds);
+void potrf_diag_mfma_launch(hipStream_t st, int batch, double* A, long lda, long strideA, int n, int k0, int* info, int own_cu_lds,
+                            double* tinv = nullptr, long tinv_stride = 0);
+bool potrf_tinv_on();
 int potrf_diag_mfma_own_cu_lds();
-void potrf_panel_mfma_launch(hipStream_t st, int batch, double* A, long lda, long strideA, int k0, int mcols);
+void potrf_panel_mfma_launch(hipStream_t st, int batch, double* A, long lda, long strideA, int k0, int mcols, int coff = 0,
+                             const double* tinv = nullptr, long tinv_stride = 0);
 
 static void potrf_step_gemms(Ctx& c, hipStream_t st, int nb, int M, int N, const double* U12a, const double* U12b, long lda, long strideA,
                              double* C, int tri, int batch, int tile_hint = 0) {
@@ -102,23 +105,30 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
     if (c.diag_own_cu_lds < 0) c.diag_own_cu_lds = tiles ? potrf_diag_mfma_own_cu_lds() : potrf_diag_own_cu_lds();
     own_cu_lds = c.diag_own_cu_lds;
   }
+  // inverses of the 16 x 16 diagonal tiles (potrf_mfma.hip: tile_potrf_inv), one 8-tile record per block step and batch member:
+  // written by the diagonal-block kernel of step kb, read by that step's panel kernels (which may still run, on the helper queue,
+  // when the next diagonal block is being factored: hence a record per step)
+  const bool tinv_on = tiles && potrf_tinv_on();
+  const long tinv_stride = (long)nblk * 2048;
+  if (tinv_on) c.potrf_tinv.ensure((size_t)batch * tinv_stride * sizeof(double));
   int last_la = -1;   // last block step whose trailing update went to the helper stream and has not been joined yet
   for (int kb = 0; kb < nblk; ++kb) {
     const int k0 = kb * NB;
     const int nb = std::min(NB, n - k0);
     const int m = n - k0 - nb;
+    double* tinv = tinv_on ? c.potrf_tinv.d() + (long)kb * 2048 : nullptr;
     // factor only: the inverses of all diagonal blocks are produced by ONE launch after the loop
-    if (tiles) potrf_diag_mfma_launch(c.stream, batch, A, lda, strideA, n, k0, d_info, own_cu_lds);
+    if (tiles) potrf_diag_mfma_launch(c.stream, batch, A, lda, strideA, n, k0, d_info, own_cu_lds, tinv, tinv_stride);
     else potrf_diag_launch(c.stream, true, false, batch, 1, A, lda, strideA, n, k0, dinv, strideD, d_info, own_cu_lds);
     if (m <= 0) break;
     double* A12 = A + (long)(k0 + nb) * lda + k0;
     double* A22 = A + (long)(k0 + nb) * lda + (k0 + nb);
-    if (tiles) potrf_panel_mfma_launch(c.stream, batch, A, lda, strideA, k0, m);
-    else potrf_panel_solve_launch(c.stream, batch, A, lda, strideA, k0, m);   // A12 <- U11^-T A12 (substitution)
     // (the last block steps, whose whole trailing update is a ~15 us GEMM, run on the main stream alone: the two ordering
     //  events of a look-ahead step cost more there -- ~6 us of queue hand-over each -- than the update they would hide)
     static const int la_min = [] { const char* e = getenv("HYP_POTRF_LA_MIN"); return e ? atoi(e) : 1536; }();
     const bool la_step = lookahead && m > la_min;
+    if (tiles) potrf_panel_mfma_launch(c.stream, batch, A, lda, strideA, k0, m, 0, tinv, tinv_stride);
+    else potrf_panel_solve_launch(c.stream, batch, A, lda, strideA, k0, m);   // A12 <- U11^-T A12 (substitution)
     if (!la_step) {
       if (lookahead && last_la >= 0) {   // the helper stream's last update touched everything below: join it once
         HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(2 * last_la + 1), 0));
@@ -127,9 +137,9 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
       potrf_step_gemms(c, c.stream, nb, m, m, A12, A12, lda, strideA, A22, GEMM_UPPER, batch);   // A22 -= A12' A12 (upper)
       continue;
     }
-    last_la = kb;
     const int nb1 = std::min(NB, m);       // block row k+1
     const int mr = m - nb1;                // rows beyond it
+    last_la = kb;
     hipEvent_t Tk = c.pool_event(2 * kb), Rk = c.pool_event(2 * kb + 1);
     if (kb >= 1) HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(2 * (kb - 1) + 1), 0));   // rest(k-1) touched block row k+1 too
     static const int look_tile = [] { const char* e = getenv("HYP_POTRF_LOOK_TILE"); return e ? atoi(e) : 0; }();

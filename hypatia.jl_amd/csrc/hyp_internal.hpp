@@ -38,6 +38,10 @@ struct DBuf {
   DBuf(DBuf&& o) noexcept : p(o.p), bytes(o.bytes), owned(o.owned) { o.p = nullptr; o.bytes = 0; o.owned = true; }
   DBuf(const DBuf&) = delete;
   DBuf& operator=(const DBuf&) = delete;
+  DBuf& operator=(DBuf&& o) noexcept {
+    if (this != &o) { release(); p = o.p; bytes = o.bytes; owned = o.owned; o.p = nullptr; o.bytes = 0; o.owned = true; }
+    return *this;
+  }
   ~DBuf() { release(); }
   void alloc(size_t nbytes) {
     release();
@@ -87,6 +91,8 @@ struct Ctx {
   DBuf scratch;       // general device scratch (gemv partial sums)
   DBuf dscal;         // 64 device doubles for scalar results (dots, counts)
   DBuf stage_a, stage_b;   // device staging for host-pointer entry points
+  DBuf potrf_tinv2;        // (the same for factorizations on the helper stream, see StreamSwap)
+  DBuf potrf_tinv;         // blocked Cholesky: inverses of the 16 x 16 diagonal tiles, per block step (potrf_upper_batched)
   DBuf work_tri;           // workspace of trtri_upper_batched
   DBuf ts_ws;              // PSD two-sided product: zero-padded copy of the factor + the padded intermediates Z_j (psd_twosided.hip)
   int diag_own_cu_lds = -1;   // dynamic LDS that gives the critical-path diagonal-block kernel a CU of its own (-1: not asked yet, 0: refused)
@@ -129,8 +135,9 @@ struct Ctx {
 struct StreamSwap {
   Ctx& c;
   // (the GEMM launcher's split-K workspace follows the stream: two products in flight on the two streams must not share it)
-  explicit StreamSwap(Ctx& ctx) : c(ctx) { std::swap(c.stream, c.stream2); std::swap(c.gemm_scratch, c.gemm_scratch2); }
-  ~StreamSwap() { std::swap(c.stream, c.stream2); std::swap(c.gemm_scratch, c.gemm_scratch2); }
+  // (so does the blocked Cholesky's record of tile inverses: two factorizations may be in flight on the two streams)
+  explicit StreamSwap(Ctx& ctx) : c(ctx) { std::swap(c.stream, c.stream2); std::swap(c.gemm_scratch, c.gemm_scratch2); std::swap(c.potrf_tinv, c.potrf_tinv2); }
+  ~StreamSwap() { std::swap(c.stream, c.stream2); std::swap(c.gemm_scratch, c.gemm_scratch2); std::swap(c.potrf_tinv, c.potrf_tinv2); }
   StreamSwap(const StreamSwap&) = delete;
   StreamSwap& operator=(const StreamSwap&) = delete;
 };

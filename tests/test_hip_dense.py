@@ -333,3 +333,29 @@ def test_lstsq_normal_matches_qr_and_estimates_conditioning(hip, m, n):
     A2[:, -1] = A2[:, 0] + 1e-7 * A2[:, 1]
     L.check(lib.hyp_dense_lstsq_normal(ctx, m, n, fp(A2), m, fp(b), fp(x), ctypes.byref(rc), ctypes.byref(info)), "lstsq_normal")
     assert info.value != 0 or rc.value < 1e-5
+
+
+def _potrf_variant(n, cond, env):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "potrf_variant.py"), str(n)] + ([repr(cond)] if cond else []),
+                       cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("n,cond", [(100, 0), (200, 0), (1000, 0), (1153, 1e12)])
+def test_potrf_forms_of_the_diagonal_block_kernel(n, cond):
+    """round 4: the diagonal-block kernel's fourth form (tile inverses riding along with the 16 x 16 factorizations, solves as MFMA
+    products with one refinement step, the owner's trailing updates deferred by one block step: potrf_mfma.hip).  The deferral moves
+    work between block steps without changing any sum: HYP_POTRF_DEFER=0 (the third form with the same solves) must give the same
+    bits.  The solves themselves are new arithmetic: against the substitution form (HYP_POTRF_TINV=0) the factor keeps LAPACK's
+    backward error, also on a matrix of condition 1e12 (the switches are read once per process: one child process each)."""
+    new = _potrf_variant(n, cond, {})
+    nodefer = _potrf_variant(n, cond, {"HYP_POTRF_DEFER": "0"})
+    subst = _potrf_variant(n, cond, {"HYP_POTRF_TINV": "0"})
+    assert new["info"] == nodefer["info"] == subst["info"] == 0
+    assert new["sha"] == nodefer["sha"]
+    assert new["sha"] != subst["sha"]                     # (different rounding: the comparison below is not vacuous)
+    assert new["berr"] <= 1.5 * subst["berr"] + 1e-19, (new["berr"], subst["berr"])
+    assert new["berr"] <= 4e-16 / n ** 0.5                # || U'U - A || / (n || A ||): a few eps over n^1.5
