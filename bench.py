@@ -485,7 +485,7 @@ def run_headline(args, world, rank, local_rank, multi, comm=None):
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "strong" if (args.config == "4" or comm is not None) else "weak",
+        "scaling": "strong" if (args.config == "4" or comm is not None) else None,   # (one GPU, no comm: nothing scales)
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -559,6 +559,10 @@ def run_headline(args, world, rank, local_rank, multi, comm=None):
             out["cpu_baseline"]["blas3_lower_bound"] = cpu_blas3_bound(args.n, args.side, os.cpu_count() or 8)
             lb = out["cpu_baseline"]["blas3_lower_bound"]["s_per_iteration"]
             out["speedup_vs_cpu_bracket"] = {"vs_port": out["speedup_vs_cpu_port"], "vs_blas3_lower_bound": (lb * out["value"]) if lb > 0 else None}
+            # the ratio to quote: against a BLAS-3-only lower bound of the CPU iteration on ALL host cores; the ratio against the
+            # Python-bound numpy port on 8 threads (speedup_vs_cpu_port) says more about the port than about either machine
+            out["speedup_vs_cpu"] = {"value": out["speedup_vs_cpu_bracket"]["vs_blas3_lower_bound"], "against": "cpu_baseline.blas3_lower_bound",
+                                     "secondary_vs_numpy_port": out["speedup_vs_cpu_port"]}
         except Exception as e:
             print("blas3 bound skipped: %r" % (e,), file=sys.stderr)
     if hasattr(lib, "report"):
@@ -575,20 +579,36 @@ def run_headline(args, world, rank, local_rank, multi, comm=None):
     return out
 
 
-def main_other(args):
+def main_other(args, world=1, rank=0, local_rank=0, multi=False):
     """--config 3b | 5p | 5d: the other BASELINE.json configurations on one GPU, same JSON schema.  A step is one IPM iteration
     of the full solve of the instance (the solve is repeated until `steps` iterations have been timed).
       3b  matrix completion, EpiNormSpectral 50 x 100 (dim 5001): the largest size the reference's algorithm admits
       5p  polymin, WSOSInterpNonnegative, 4 variables, half-degree 8 (U = 4845), primal form (the cone uses the dual barrier)
       5d  the same in dual form (n - p = 4844 unknowns in the Schur system, the "MFMA Hessian-product" form)
+    --config 5p | 5d --gpus N (N > 1; BASELINE configs[4] "1 -> 8 GPU"): ONE WSOS cone, so the model and the iterate are replicated and the
+    ranks split the K dimension (the cone's U rows) of the Schur product -- KShardQRCholDenseSystemSolver, one all-reduce of the n x n
+    partial sums per iteration; the cone's oracles (feasibility chains, gradient, U x U Hessian and its Cholesky per accepted trial),
+    the Schur factorization, the solves and the line search run replicated and bitwise identical on every rank.  "strong" scaling with
+    an Amdahl bound the line states: only update_lhs's product divides by N.
     roofline: the blocked Cholesky of the cone's dim x dim Hessian (Cones.jl:239-251), the dominant kernel chain of every
     accepted line-search trial, timed in isolation with HIP events (hyp_bench_potrf); 3b with the closed-form inverse has no
     such factorization in its loop and reports the Schur-matrix Cholesky instead."""
+    comm = None
+    if multi:
+        import torch                      # before the HIP library: one HIP runtime per process (torch's)
+        import torch.distributed as dist
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        dist.init_process_group(backend=os.environ.get("HYP_DIST_BACKEND", "nccl"))
     import hypatia_jl_amd as H
+    if multi:
+        from hypatia_jl_amd import distributed as D
+        comm = D.Comm(device="cuda")
     from oracle import instances as I       # instance generators only (data)
     from threadpoolctl import threadpool_limits
     t_setup = time.perf_counter()
     solver_opts = {}
+    mk_solver = lambda **kw: H.Solver(syssolver=(D.KShardQRCholDenseSystemSolver(comm) if comm is not None else None), **kw)
     if args.config == "3b":
         inst = I.matrixcompletion(50, 100, seed=args.seed)
         work = "configs[2] at the largest size the reference admits: matrix completion, EpiNormSpectral 50 x 100 (dim 5001)"
@@ -614,16 +634,31 @@ def main_other(args):
     status = None
     with threadpool_limits(limits=args.cpu_threads, user_api="blas"):
         if args.config != "3c":
-            warm = H.Solver(verbose=False, iter_limit=2, **solver_opts)          # untimed: first-touch allocations, kernel loading
+            warm = mk_solver(verbose=False, iter_limit=2, **solver_opts)          # untimed: first-touch allocations, kernel loading
             warm.load(H.make_model(inst)); warm.solve()
+            if comm is not None:
+                warm.syssolver.close()
         lib.hyp_reset_timers(ctx)                             # (the executed-work counters of hyp_get_kernel_stats start here)
         if args.config == "3c":
             steps = 1                                         # one whole solve
+        up_s, comm_calls, comm_doubles = 0.0, 0.0, 0.0
         while iters < steps:
-            s = H.Solver(verbose=args.verbose, **solver_opts)
+            s = mk_solver(verbose=args.verbose and rank == 0, **solver_opts)
             s.load(H.make_model(inst))
+            if comm is not None:     # the timed region of a solve = its iteration loop, bracketed on every rank
+                comm.barrier()
             s.solve()
-            iters += s.num_iters; loop_s += s.iter_time; solves += s.n_solves; trials += s.stepper.searcher.n_trials
+            it_time = s.iter_time
+            if comm is not None:
+                v = np.array([it_time])
+                comm.allreduce(v, "max")        # (MAX over ranks of the same replicated loop)
+                it_time = float(v[0])
+                cs = (ctypes.c_double * 2)()
+                lib.hyp_sys_comm_stats(s.syssolver._h, cs)
+                comm_calls += cs[0]; comm_doubles += cs[1]
+                s.syssolver.close()
+            iters += s.num_iters; loop_s += it_time; solves += s.n_solves; trials += s.stepper.searcher.n_trials
+            up_s += s.time_upsys
             for k in phases:
                 phases[k] += getattr(s, "time_" + k)
             status = s.status
@@ -678,7 +713,8 @@ def main_other(args):
     out = {
         "metric": "IPM iterations/sec (+ ms per KKT solve): " + work + " (Float64, QRCholDense + CombinedStepper)",
         "value": iters / loop_s, "unit": "iterations/s", "iterations_per_s": iters / loop_s, "n_gpus": 1, "steps": iters, "warmup": 2,
-        "ms_per_step": ms_it, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "ms_per_step": ms_it, "higher_is_better": True, "scaling": ("strong" if comm is not None else None), "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
         "config": {"workload": work, "n": int(s.model.n), "p": int(s.model.p), "q": int(s.model.q), "seed": args.seed, "solves_timed": nsolve_runs,
                    "final_status": status, "algorithm": algorithm_record()},
         "roofline": {"bound": "mfma", "kernel": "whole iteration; dominant kernels by the trace: " + trace_kernel,
@@ -694,9 +730,33 @@ def main_other(args):
         "kkt_solves_per_step": solves / iters, "ms_per_kkt_solve": phases["getdir"] / max(solves, 1) * 1e3,
         "search_trials_per_step": trials / iters, "setup_s": t_setup,
     }
+    if comm is not None:
+        # what an N-GPU run of ONE cone can and cannot divide: the Schur product of update_lhs is K-sharded over the
+        # cone's U rows; everything else is replicated.  The Amdahl bound follows from this run's own phase times.
+        out["n_gpus"] = world
+        up_ms = up_s / iters * 1e3
+        shard_ms = (f_uplhs - float(nm) ** 3 / 3) / max(f_uplhs, 1.0) * up_ms if args.config == "5d" else 0.0   # (the product's share of update_lhs by flops)
+        out["config"]["parallelism"] = "k-shard x%d (model replicated, Schur product split over the cone's rows)" % world
+        out["config"]["exchange"] = ("one all-reduce (sum, f64) of the n x n Schur upper triangle per iteration: %.1f calls and %.3g doubles per "
+                                     "iteration" % (comm_calls / iters, comm_doubles / iters))
+        out["k_shard"] = {
+            "scales_with_n_gpus": "the Schur product of update_lhs (triangular product U_H G and G'(.), qrchol.jl:219-246): ~%.1f of %.1f ms per "
+                                  "iteration at this N" % (shard_ms, ms_it),
+            "replicated": "the cone's oracles (feasibility chains, gradient, U x U Hessian + Cholesky per accepted line-search trial, "
+                          "wsosinterpnonnegative.jl:89-150, Cones.jl:239-251), the Schur Cholesky, the solves, the line search",
+            "estimated_speedup_vs_1gpu_from_these_phases": (ms_it + shard_ms * (world - 1)) / ms_it if ms_it > 0 else None,
+            "amdahl_bound_any_n": (ms_it + shard_ms * (world - 1)) / max(ms_it - shard_ms, 1e-9) if ms_it > 0 else None,
+            "why_not_the_hessian": "block-columns of the U x U Hessian over N ranks save <= (1 - 1/N) 1.05 ms per trial and cost an all-gather of "
+                                   "94 MB before the replicated Cholesky (DESIGN.md section 6)"}
     if hasattr(lib, "report"):   # HYP_PROFILE=1: wall time per C-ABI entry point
         print(lib.report(), file=sys.stderr)
-    emit_json_line(out)
+    if rank == 0:
+        emit_json_line(out)
+    if comm is not None:
+        try:
+            comm.dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 def main():
@@ -723,9 +783,9 @@ def main():
     if args.config is None:
         args.config = "4" if multi else "2"
     if args.config in ("3b", "3c", "5p", "5d"):
-        if multi:
+        if multi and args.config not in ("5p", "5d"):
             raise SystemExit("--config %s is a single-GPU line" % args.config)
-        return main_other(args)
+        return main_other(args, world, rank, local_rank, multi)
     if args.config not in ("2", "4", "2w"):
         raise SystemExit("--config must be 2, 4, 2w, 3b, 3c, 5p or 5d")
     if args.steps is None:

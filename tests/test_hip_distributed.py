@@ -190,3 +190,56 @@ def test_kshard_cone_without_square_root(monkeypatch):
     assert str(res["status"]) == ref.status == "Optimal"
     assert abs(float(res["p_obj"]) - ref.primal_obj) <= 1e-6 * (1 + abs(ref.primal_obj))
     assert res["exchanges"][0] >= int(res["iters"])
+
+
+def _torchrun_bench(extra, nproc=2, timeout=1500):
+    """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` exactly as the driver launches the scaling runs,
+    with the gloo transport (both ranks share this box's one GPU; RCCL wants one device per rank): returns the parsed JSON line"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HYP_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(nproc)] + extra
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # ONE JSON line, from rank 0
+    return json.loads(lines[-1])
+
+
+def _check_schema(d, n_gpus, steps=None):
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == n_gpus and d["higher_is_better"] is True and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert d["vs_baseline"] is None and d["scaling"] == "strong"
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and "workload" in d["config"] and "parallelism" in d["config"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in d["roofline"], key
+    if steps is not None:
+        assert d["steps"] == steps
+        assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 1.0) < 1e-6      # iterations/s x s/iteration
+
+
+@pytest.mark.timeout(1800)
+def test_bench_scaling_line_under_torchrun_two_ranks():
+    """schema rehearsal for the driver's SCALE run (8-GPU nodes are not ours to launch): config 4's generator at n = 300, the 64
+    cones dealt out to two ranks, three timed iterations; the line must carry the contract's fields with N = 2"""
+    d = _torchrun_bench(["--nvars", "300", "--steps", "3", "--warmup", "1", "--no-secondary"])
+    _check_schema(d, 2, steps=3)
+    assert "64 x PosSemidefTri" in d["metric"] and d["config"]["n"] == 300
+    assert d["comm"]["collectives_per_step"] > 0 if "comm" in d else True
+
+
+@pytest.mark.timeout(1800)
+def test_bench_config5_kshard_line_under_torchrun_two_ranks():
+    """BASELINE configs[4] "1 -> 8 GPU": ONE WSOS cone (U = 4845, dual form), model replicated, Schur product K-sharded over two ranks;
+    the line says what scales and what is replicated, and the only exchange is one Schur triangle per iteration"""
+    d = _torchrun_bench(["--config", "5d", "--steps", "3"])
+    _check_schema(d, 2)
+    assert d["config"]["final_status"] == "Optimal"
+    ks = d["k_shard"]
+    assert 1.0 <= ks["estimated_speedup_vs_1gpu_from_these_phases"] <= ks["amdahl_bound_any_n"] < 2.5
+    assert "replicated" in ks and "scales_with_n_gpus" in ks

@@ -194,7 +194,7 @@ def oracle_trajectory(inst, probe_iters=(), **opts):
     from oracle.solvers import Solver as OSolver
     log, probes = [], {}
     s, t = run_trajectory(OSolver, omodel(inst), gate_log=log, probe_iters=probe_iters, probes=probes, **opts)
-    return dict(status=s.status, iters=s.num_iters, p_obj=s.primal_obj, rows=t, gate=gate_margins(log, len(t)), probes=probes)
+    return dict(status=s.status, iters=s.num_iters, p_obj=s.primal_obj, rows=t, gate=gate_margins(log, len(t)), probes=probes, x=s.get_x())
 
 
 def hip_trajectory(name, route, timeout=1800, **opts):
