@@ -581,11 +581,17 @@ int hyp_sys_residual_products(hyp_sys* sys, const double* x, const double* z, co
   sys->s->residual_products(x, z, s, out_Gtz, out_Gx_s, out_dots2);
   API_END(sys->ctx)
 }
+int hyp_sys_residual_products2(hyp_sys* sys, const double* x, const double* z, const double* s, double tau, double* out_Gtz, double* out_Gx_s,
+                               double* out_dots2, double* out_norms2) {
+  API_BEGIN
+  sys->s->residual_products2(x, z, s, tau, out_Gtz, out_Gx_s, out_dots2, out_norms2);
+  API_END(sys->ctx)
+}
 int hyp_sys_allreduce_host(hyp_sys* sys, double* buf, int count, int op) {
   API_BEGIN
   HYP_CHECK(hipSetDevice(sys->ctx->c.device));
   HYP_REQUIRE(count >= 0 && count <= 32 && op >= 0 && op <= 2, "hyp_sys_allreduce_host: at most 32 doubles; op 0 sum, 1 max, 2 min");
-  sys->s->allreduce_host(buf, count, op);
+  sys->s->allreduce_host(buf, count, op, 12);
   API_END(sys->ctx)
 }
 int hyp_sys_load_model(hyp_sys* sys, const double* c, const double* b, const double* h, const double* A) {
@@ -693,6 +699,20 @@ int hyp_sys_set_comm_rccl(hyp_sys* sys, hyp_comm* comm) {
   HYP_REQUIRE(comm == nullptr || comm->ctx == sys->ctx, "set_comm_rccl: the communicator belongs to another context");
   sys->s->rccl_comm = comm ? comm->nccl : nullptr;
   sys->s->screen_agreed = -1;
+  sys->s->comm_rank_ = comm ? comm->rank : 0;       // (the layout of the fused exchanges: allreduce_fused)
+  sys->s->comm_world_ = comm ? comm->nranks : 0;
+  API_END(sys->ctx)
+}
+int hyp_sys_set_comm_layout(hyp_sys* sys, int rank, int world) {
+  API_BEGIN
+  HYP_REQUIRE((world == 0 && rank == 0) || (world >= 1 && rank >= 0 && rank < world && world <= 4096), "set_comm_layout: rank / world");
+  sys->s->comm_rank_ = rank;
+  sys->s->comm_world_ = world;
+  API_END(sys->ctx)
+}
+int hyp_sys_comm_hist(hyp_sys* sys, long long* out16) {
+  API_BEGIN
+  for (int i = 0; i < 16; ++i) out16[i] = sys->s->comm_hist[i];
   API_END(sys->ctx)
 }
 int hyp_sys_set_kshard(hyp_sys* sys, int rank, int world) {

@@ -668,7 +668,7 @@ void SysSolver::solve3_multi(double* sol, const double* rhs, int nr, double* x_t
   if (dist()) {   // sum the ranks' partial G' z, then add the replicated x once
     m_t.ensure((size_t)nr * n * d);
     gemv_multi(ctx, true, q, n, nr, 1.0, G.d(), q, sol + n, ld3, 0.0, m_t.d(), n);
-    allreduce_dev(m_t.d(), (long)nr * n, 0);
+    allreduce_dev(m_t.d(), (long)nr * n, 0, 1);
     for (int r = 0; r < nr; ++r) dev_axpby(ctx, n, 1.0, m_t.d() + (long)r * n, 1.0, sol + r * ld3);
   } else {
     gemv_multi(ctx, true, q, n, nr, 1.0, G.d(), q, sol + n, ld3, 1.0, sol, ld3);
@@ -834,7 +834,7 @@ void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double
   if (joint_const) dot_const = ctx.h_pinned[2 * MR] + ctx.h_pinned[2 * MR + 1];
   if (dist()) {   // h' z over all ranks' rows
     double hz[MR + 1] = {ctx.h_pinned[1], ctx.h_pinned[3], ctx.h_pinned[5]};
-    allreduce_host(hz, ncol, 0);
+    allreduce_host(hz, ncol, 0, 2);
     ctx.h_pinned[1] = hz[0];
     ctx.h_pinned[3] = hz[1];
     ctx.h_pinned[5] = hz[2];
@@ -879,13 +879,19 @@ void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double
       lincomb_cols(ctx, n, MR, mc.d(), 0, nullptr, 0, nullptr, 0, res, dv, k);                       // res.x = c tau (+ G' z below)
       lincomb_cols(ctx, q, MR, mh.d(), 0, dir + os, dv, m_Gxd.d(), q, res + oz, dv, k);              // res.z = h tau - s - G x
     }
+    // Sharded, round 4: the residual's three exchanges -- G' z (n-vectors, SUM), the h' z of the directions (SUM) and the residual
+    // norms (MAX) -- travel in ONE all-reduce (allreduce_fused): everything a rank contributes is local (the z / s rows of the
+    // residual do not depend on the summed G' z; only the x rows do, and those are replicated afterwards), so the local maxima
+    // and scalar products are formed first and ride behind the n-vectors.
+    const bool fuse = dist() && fused_ok();
     if (dist() || both) {
       if (!both) {
         m_t.ensure((size_t)MR * n * d);
         gemv_multi(ctx, true, q, n, MR, 1.0, G.d(), q, dir + oz, dv, 0.0, m_t.d(), n);
       }
-      if (dist()) allreduce_dev(m_t.d(), (long)MR * n, 0);
-      for (int r = 0; r < MR; ++r) dev_axpby(ctx, n, 1.0, m_t.d() + (long)r * n, 1.0, res + (long)r * dv);
+      if (dist() && !fuse) allreduce_dev(m_t.d(), (long)MR * n, 0, 3);
+      if (!fuse)
+        for (int r = 0; r < MR; ++r) dev_axpby(ctx, n, 1.0, m_t.d() + (long)r * n, 1.0, res + (long)r * dv);
     } else {
       gemv_multi(ctx, true, q, n, MR, 1.0, G.d(), q, dir + oz, dv, 1.0, res, dv);
     }
@@ -909,12 +915,36 @@ void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double
       }
       dev_dots(ctx, sp);
     }
+    if (fuse) {
+      for (int r = 0; r < MR; ++r) dev_sub_absmax(ctx, dv - oz, res + (long)r * dv + oz, rhs + (long)r * dv + oz, ds + 8 + r);   // this rank's rows
+      if (m_t.bytes < ((size_t)MR * n + 64 + 2 * (size_t)MR * comm_world_) * d) {   // (room for the tail behind the n-vectors)
+        DBuf bigger(((size_t)MR * n + 64 + 2 * (size_t)MR * comm_world_) * d);
+        ctx.d2d(bigger.p, m_t.p, (size_t)MR * n * d);
+        ctx.sync();
+        m_t = std::move(bigger);
+      }
+      FusedTail t;
+      t.nsum = MR; t.nmax = MR;
+      for (int r = 0; r < MR; ++r) { t.sum_src[r] = ds + 2 * r + 1; t.max_src[r] = ds + 8 + r; }
+      double ho[2 * MR];
+      allreduce_fused(m_t.d(), (long)MR * n, t, ho, 3);
+      for (int r = 0; r < MR; ++r) dev_axpby(ctx, n, 1.0, m_t.d() + (long)r * n, 1.0, res + (long)r * dv);
+      for (int r = 0; r < MR; ++r) dev_sub_absmax(ctx, oz, res + (long)r * dv, rhs + (long)r * dv, ds + 12 + r);                // the replicated x rows
+      ctx.d2h(ctx.h_pinned, ds, 16 * d);
+      ctx.sync();
+      for (int r = 0; r < MR; ++r) {
+        ctx.h_pinned[2 * r + 1] = ho[r];
+        const double a = ho[MR + r], b = ctx.h_pinned[12 + r];
+        ctx.h_pinned[8 + r] = (a != a || b != b) ? __builtin_nan("") : std::max(a, b);
+      }
+    } else {
     for (int r = 0; r < MR; ++r) dev_sub_absmax(ctx, dv, res + (long)r * dv, rhs + (long)r * dv, ds + 8 + r);
     ctx.d2h(ctx.h_pinned, ds, 16 * d);
     ctx.sync();
-    if (dist()) {
+    }
+    if (dist() && !fuse) {
       double hz[MR] = {ctx.h_pinned[1], ctx.h_pinned[3]};
-      allreduce_host(hz, MR, 0);
+      allreduce_host(hz, MR, 0, 4);
       ctx.h_pinned[1] = hz[0];
       ctx.h_pinned[3] = hz[1];
       double v[2 * MR];   // residual norms: max over the ranks, NaN flags first
@@ -923,7 +953,7 @@ void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double
         v[r] = (m != m) ? 1.0 : 0.0;
         v[MR + r] = (m != m) ? 0.0 : m;
       }
-      allreduce_host(v, 2 * MR, 1);
+      allreduce_host(v, 2 * MR, 1, 5);
       for (int r = 0; r < MR; ++r) ctx.h_pinned[8 + r] = (v[r] > 0.5) ? __builtin_nan("") : v[MR + r];
     }
     for (int r = 0; r < MR; ++r) {

@@ -306,7 +306,7 @@ void SysSolver::allreduce_lhs() {
     lhs_tri.ensure((size_t)cnt * sizeof(double));
     const dim3 grid((nmp + 255) / 256, nmp);
     hipLaunchKernelGGL(tri_pack_kernel, grid, dim3(256), 0, ctx.stream, nmp, lhs.d(), (long)nmp, lhs_tri.d(), 0);
-    allreduce_dev(lhs_tri.d(), cnt, 0);
+    allreduce_dev(lhs_tri.d(), cnt, 0, 0);
     hipLaunchKernelGGL(tri_pack_kernel, grid, dim3(256), 0, ctx.stream, nmp, lhs.d(), (long)nmp, lhs_tri.d(), 1);
     HYP_CHECK(hipGetLastError());
   } catch (...) {
@@ -316,10 +316,11 @@ void SysSolver::allreduce_lhs() {
   ks_world = kw;
 }
 
-void SysSolver::allreduce_dev(double* d_buf, long count, int op) {
+void SysSolver::allreduce_dev(double* d_buf, long count, int op, int site) {
   if (!dist() || count <= 0) return;
   comm_calls += 1;
   comm_doubles += (double)count;
+  comm_hist[site & 15] += 1;
   if (rccl_comm) {   // in place, on the library stream: the consumers of d_buf are queued behind it
     rccl_allreduce_inplace(rccl_comm, d_buf, count, op, ctx.stream);
     return;
@@ -330,10 +331,46 @@ void SysSolver::allreduce_dev(double* d_buf, long count, int op) {
   HYP_REQUIRE(comm_fn(comm_user, count, op) == 0, "sys: all-reduce callback failed");
   ctx.d2d(d_buf, comm_stage, (size_t)count * sizeof(double));
 }
-void SysSolver::allreduce_host(double* h_buf, int count, int op) {
+// the tail of a fused exchange: sums in place, this rank's maxima in its slots, zeros in the other ranks' slots
+struct FusedPtrs { const double* sum_src[8]; const double* max_src[8]; };
+__global__ void fused_tail_kernel(double* __restrict__ tail, FusedPtrs p, int nsum, int nmax, int rank, int world) {
+  const int i = threadIdx.x;
+  if (i < nsum) tail[i] = *p.sum_src[i];
+  for (int e = i; e < world * nmax; e += blockDim.x) {
+    const int r = e / nmax, j = e - r * nmax;
+    tail[nsum + e] = (r == rank) ? *p.max_src[j] : 0.0;
+  }
+}
+void SysSolver::allreduce_fused(double* d_buf, long npay, const FusedTail& t, double* h_out, int site) {
+  HYP_REQUIRE(dist() && comm_world_ > 0 && t.nsum <= 8 && t.nmax <= 8, "allreduce_fused: communicator layout");
+  const int ntail = t.nsum + comm_world_ * t.nmax;
+  HYP_REQUIRE((size_t)ntail + 32 <= ctx.h_pinned_n - 256, "allreduce_fused: too many ranks for the pinned block");
+  FusedPtrs fp{};
+  for (int i = 0; i < t.nsum; ++i) fp.sum_src[i] = t.sum_src[i];
+  for (int j = 0; j < t.nmax; ++j) fp.max_src[j] = t.max_src[j];
+  hipLaunchKernelGGL(fused_tail_kernel, dim3(1), dim3(64), 0, ctx.stream, d_buf + npay, fp, t.nsum, t.nmax, comm_rank_, comm_world_);
+  HYP_CHECK(hipGetLastError());
+  allreduce_dev(d_buf, npay + ntail, 0, site);
+  double* hp = ctx.h_pinned + 256;
+  ctx.d2h(hp, d_buf + npay, (size_t)ntail * sizeof(double));
+  ctx.sync();
+  for (int i = 0; i < t.nsum; ++i) h_out[i] = hp[i];
+  for (int j = 0; j < t.nmax; ++j) {
+    double m = hp[t.nsum + j];
+    bool nan = (m != m);
+    for (int r = 1; r < comm_world_; ++r) {
+      const double v = hp[t.nsum + r * t.nmax + j];
+      nan = nan || (v != v);
+      if (v > m) m = v;
+    }
+    h_out[t.nsum + j] = nan ? __builtin_nan("") : m;
+  }
+}
+void SysSolver::allreduce_host(double* h_buf, int count, int op, int site) {
   if (!dist() || count <= 0) return;
   comm_calls += 1;
   comm_doubles += (double)count;
+  comm_hist[site & 15] += 1;
   if (rccl_comm) {   // scalars: through the context's device scalar buffer (64 doubles)
     double* d = ctx.dscal.d() + 32;
     if (count > 32) {   // (the candidate screen's vectors: a few numbers per candidate)
@@ -355,10 +392,38 @@ void SysSolver::allreduce_host(double* h_buf, int count, int op) {
 }
 
 void SysSolver::residual_products(const double* h_x, const double* h_z, const double* h_s, double* h_Gtz, double* h_Gx_s, double* h_dots) {
+  residual_products2(h_x, h_z, h_s, 0.0, h_Gtz, h_Gx_s, h_dots, nullptr);
+}
+
+// max_i |a_i - tau b_i| (b may be null: max |a_i|) into out[0]; one workgroup
+__global__ __launch_bounds__(1024) void absmax_diff_kernel(int m, const double* __restrict__ a, const double* __restrict__ b, double tau, double* __restrict__ out) {
+  __shared__ double red[1024];
+  __shared__ int anynan;
+  if (threadIdx.x == 0) anynan = 0;
+  __syncthreads();
+  double v = 0.0;
+  for (int i = threadIdx.x; i < m; i += 1024) {
+    const double e = std::fabs(b ? a[i] - tau * b[i] : a[i]);
+    if (e != e) anynan = 1;
+    v = (e > v) ? e : v;
+  }
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] = (red[threadIdx.x + off] > red[threadIdx.x]) ? red[threadIdx.x + off] : red[threadIdx.x];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = anynan ? __builtin_nan("") : red[0];
+}
+
+// h_norms (may be null) = {max |G x + s|, max |G x + s - h tau|} over ALL ranks' rows (Solvers.jl:447-457): with them the exchange of
+// the sums carries the two maxima as well (allreduce_fused), and the host needs no collective of its own per iteration
+void SysSolver::residual_products2(const double* h_x, const double* h_z, const double* h_s, double tau, double* h_Gtz, double* h_Gx_s, double* h_dots,
+                                   double* h_norms) {
   HYP_REQUIRE(model_loaded, "residual_products: load_model first");
   const size_t d = sizeof(double);
   rp_x.ensure(std::max<size_t>(n, 1) * d);
-  rp_t.ensure(((size_t)n + 2) * d);                                        // [G' z (n); h' z; z' s]: ONE sum over the ranks
+  rp_t.ensure(((size_t)n + 2 + 2 + 2 * (size_t)std::max(comm_world_, 1)) * d);   // [G' z (n); h' z; z' s | the two local maxima | their slots]: ONE sum over the ranks
   for (DBuf* b : {&rp_z, &rp_s, &rp_g}) b->ensure(std::max<size_t>(q, 1) * d);
   double* hs = ctx.stage_host((size_t)n + 2 * (size_t)q + 2);
   memcpy(hs, h_x, (size_t)n * d);
@@ -379,7 +444,38 @@ void SysSolver::residual_products(const double* h_x, const double* h_z, const do
     dev_dot(ctx, q, mh.d(), rp_z.d(), rp_t.d() + n);
     dev_dot(ctx, q, rp_z.d(), rp_s.d(), rp_t.d() + n + 1);
   }
-  allreduce_dev(rp_t.d(), (long)n + 2, 0);                                  // sum over ranks (in place, stream order)
+  double nrm[2] = {0.0, 0.0};
+  if (h_norms) {
+    double* loc = rp_t.d() + n + 2;   // (behind the payload; the slots follow)
+    if (q > 0) {
+      hipLaunchKernelGGL(absmax_diff_kernel, dim3(1), dim3(1024), 0, ctx.stream, q, rp_g.d(), (const double*)nullptr, 0.0, loc);
+      hipLaunchKernelGGL(absmax_diff_kernel, dim3(1), dim3(1024), 0, ctx.stream, q, rp_g.d(), mh.d(), tau, loc + 1);
+      HYP_CHECK(hipGetLastError());
+    } else {
+      ctx.zero(loc, 2 * d);
+    }
+    if (dist() && fused_ok()) {
+      rp_loc.ensure(2 * d);
+      ctx.d2d(rp_loc.p, loc, 2 * d);   // (the tail is written over the scratch position)
+      FusedTail t;
+      t.nmax = 2; t.max_src[0] = rp_loc.d(); t.max_src[1] = rp_loc.d() + 1;
+      allreduce_fused(rp_t.d(), (long)n + 2, t, nrm, 11);
+    } else {
+      allreduce_dev(rp_t.d(), (long)n + 2, 0, 11);
+      ctx.d2h(ctx.h_pinned + 24, loc, 2 * d);
+      ctx.sync();
+      double v[4] = {(ctx.h_pinned[24] != ctx.h_pinned[24]) ? 1.0 : 0.0, (ctx.h_pinned[25] != ctx.h_pinned[25]) ? 1.0 : 0.0, 0.0, 0.0};
+      v[2] = v[0] > 0.5 ? 0.0 : ctx.h_pinned[24];
+      v[3] = v[1] > 0.5 ? 0.0 : ctx.h_pinned[25];
+      if (dist()) allreduce_host(v, 4, 1, 12);
+      nrm[0] = v[0] > 0.5 ? __builtin_nan("") : v[2];
+      nrm[1] = v[1] > 0.5 ? __builtin_nan("") : v[3];
+    }
+    h_norms[0] = nrm[0];
+    h_norms[1] = nrm[1];
+  } else {
+    allreduce_dev(rp_t.d(), (long)n + 2, 0, 11);                            // sum over ranks (in place, stream order)
+  }
   ctx.d2h(hs, rp_t.p, ((size_t)n + 2) * d);
   if (q > 0) ctx.d2h(hs + n + 2, rp_g.p, (size_t)q * d);
   ctx.sync();
@@ -561,7 +657,7 @@ void SysSolver::solve3(double* d_sol, const double* d_rhs) {   // qrchol.jl:39-8
   if (dist()) {   // G = this rank's rows: sum the partial G' z over the ranks, then add the (replicated) x once
     HYP_REQUIRE(p == 0, "sys: the sharded path assumes the reduced model (p = 0)");
     sgemv(true, q, n, 1.0, G.d(), q, z, 0.0, t);
-    allreduce_dev(t, n, 0);
+    allreduce_dev(t, n, 0, 1);
     dev_axpby(ctx, n, 1.0, x, 1.0, t);
   } else {
     ctx.d2d(t, x, (size_t)n * d);
@@ -691,7 +787,7 @@ void SysSolver::update_const() {
   ctx.d2h(ctx.h_pinned, ds, 3 * sizeof(double));
   ctx.sync();
   double hz = ctx.h_pinned[2];
-  if (dist()) allreduce_host(&hz, 1, 0);   // h' z runs over all ranks' rows; c' x is replicated
+  if (dist()) allreduce_host(&hz, 1, 0, 6);   // h' z runs over all ranks' rows; c' x is replicated
   dot_const = ctx.h_pinned[0] + (p > 0 ? ctx.h_pinned[1] : 0.0) + hz;
 }
 
@@ -750,7 +846,7 @@ SysSolver::Scal SysSolver::solve_system(double* sol, const double* rhs, Scal rs,
   ctx.d2h(ctx.h_pinned, ds, 3 * d);
   ctx.sync();
   double hz_sub = ctx.h_pinned[2];
-  if (dist()) allreduce_host(&hz_sub, 1, 0);
+  if (dist()) allreduce_host(&hz_sub, 1, 0, 2);
   const double dot_sub = ctx.h_pinned[0] + (p > 0 ? ctx.h_pinned[1] : 0.0) + hz_sub;
   const double tau_num = rs.tau + rs.kap + dot_sub;
   const double tau_denom = mu / taubar / taubar - dot_const;
@@ -779,7 +875,7 @@ SysSolver::Scal SysSolver::apply_lhs(double* res, const double* dir, Scal ds_, d
   // res.x = c tau + G' z (+ A' y)
   if (dist()) {
     sgemv(true, q, n, 1.0, G.d(), q, dir + oz, 0.0, res);
-    allreduce_dev(res, n, 0);
+    allreduce_dev(res, n, 0, 3);
     dev_axpby(ctx, n, tau_dir, mc.d(), 1.0, res);
   } else {
     dev_scale_copy(ctx, n, tau_dir, mc.d(), res);
@@ -816,7 +912,7 @@ SysSolver::Scal SysSolver::apply_lhs(double* res, const double* dir, Scal ds_, d
   ctx.d2h(ctx.h_pinned + 8, dsc, 3 * d);
   ctx.sync();
   double hz_dir = ctx.h_pinned[9];
-  if (dist()) allreduce_host(&hz_dir, 1, 0);
+  if (dist()) allreduce_host(&hz_dir, 1, 0, 4);
   Scal out;
   out.tau = -ctx.h_pinned[8] - hz_dir - kap_dir - (p > 0 ? ctx.h_pinned[10] : 0.0);
   out.kap = mu / taubar * tau_dir / taubar + kap_dir;
@@ -854,9 +950,12 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
   }
   // (sharded: this rank's cones only -- every decision below is taken on all-reduced quantities, so that all
   //  ranks leave through the same exit and issue the same sequence of collectives)
-  if (dist()) {
+  if (dist() && screen_pass_g_ >= 0 && fused_ok()) {   // a survivor of the candidate screen: the screen has exchanged exactly these two numbers
+    szsum = screen_sz_[screen_pass_g_];
+    ok = (screen_szfail_[screen_pass_g_] < 0.5);
+  } else if (dist()) {
     double v[2] = {szsum, ok ? 0.0 : 1.0};
-    allreduce_host(v, 2, 0);
+    allreduce_host(v, 2, 0, 9);
     szsum = v[0];
     ok = (v[1] < 0.5);
   }
@@ -1063,9 +1162,9 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
   if (dist()) {
     double v[2] = {ok ? 0.0 : 1.0, agg};   // [any failure, proximity aggregate]
     if (use_max_prox) {
-      allreduce_host(v, 2, 1);             // one MAX serves both
+      allreduce_host(v, 2, 1, 10);             // one MAX serves both
     } else {
-      allreduce_host(v, 2, 0);             // SUM: failures count, proximities add
+      allreduce_host(v, 2, 0, 10);             // SUM: failures count, proximities add
     }
     ok = (v[0] < 0.5);
     agg = use_max_prox ? std::max(taukap_proxsqr, v[1]) : taukap_proxsqr + v[1];
@@ -1291,7 +1390,10 @@ void SysSolver::screen_candidates_run(const double* cd, int K, const double* tau
       v1[g] += szk[k];
     }
   }
-  if (dist()) allreduce_host(v1.data(), 2 * K, 0);
+  if (dist()) allreduce_host(v1.data(), 2 * K, 0, 7);
+  if (dist()) {   // (a survivor's sequential test takes its <z, s> over all ranks and the sign flag from here: one exchange fewer per survivor)
+    for (int g = 0; g < K; ++g) { screen_sz_[g] = v1[g]; screen_szfail_[g] = v1[K + g]; }
+  }
   // second exchange: [a cone fails a test | no verdict (a value that is not a number) | proximity aggregate of this rank's cones]
   std::vector<double> mus(K, 0.0), tkp(K, 0.0);
   std::vector<char> scal_rej(K, 0);
@@ -1322,7 +1424,7 @@ void SysSolver::screen_candidates_run(const double* cd, int K, const double* tau
     }
     v2[2 * K + g] = (v2[g] > 0.5 || v2[K + g] > 0.5) ? 0.0 : std::max(agg, 0.0);
   }
-  if (dist()) allreduce_host(v2.data(), 3 * K, use_max_prox ? 1 : 0);
+  if (dist()) allreduce_host(v2.data(), 3 * K, use_max_prox ? 1 : 0, 8);
   for (int g = 0; g < K; ++g) {
     bool rj = scal_rej[g] != 0 || v2[g] > 0.5;
     if (!rj && !(v2[K + g] > 0.5)) {
@@ -1412,7 +1514,7 @@ int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp
   if (dist()) {   // every rank must walk the same way: the screen runs only if it applies on all of them (agreed once per model)
     if (screen_agreed < 0) {
       double v = -(double)smode;
-      allreduce_host(&v, 1, 1);
+      allreduce_host(&v, 1, 1, 13);
       screen_agreed = (int)(-v);
     }
     smode = std::min(smode, screen_agreed) == 2 ? 2 : 0;
@@ -1501,8 +1603,10 @@ int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp
           cand = stage + (size_t)g * len;
         }
         screen_survivor = skip_lb;
+        screen_pass_g_ = (smode == 2) ? g : -1;
         const bool acc = check_cone_points(cand, min_prox, prox_bound, use_max_prox, nup1, prox_out, n_loaded, irtmu_out);
         screen_survivor = false;
+        screen_pass_g_ = -1;
         if (acc) {
           std::memcpy(out, cand, (size_t)len * sizeof(double));
           return idx + g;
@@ -1536,7 +1640,7 @@ double SysSolver::residual(double* res, const double* dir, const double* rhs, Sc
   double m = ctx.h_pinned[16];
   if (dist()) {   // max over the ranks' rows (NaN on any rank must win: max of a flag, then of the value)
     double v[2] = {(m != m) ? 1.0 : 0.0, (m != m) ? 0.0 : m};
-    allreduce_host(v, 2, 1);
+    allreduce_host(v, 2, 1, 5);
     m = (v[0] > 0.5) ? __builtin_nan("") : v[1];
   }
   if (m != m || rsc.tau != rsc.tau || rsc.kap != rsc.kap) return __builtin_nan("");

@@ -80,12 +80,31 @@ struct SysSolver {
   int ks_rank = 0, ks_world = 1;
   bool dist() const { return (comm_fn != nullptr || rccl_comm != nullptr) && ks_world <= 1; }
   void allreduce_lhs();   // the n x n exchange of either sharding mode
-  void allreduce_dev(double* d_buf, long count, int op);
+  // site: where in the iteration the exchange is issued (comm_hist, hyp_sys_comm_hist): 0 Schur sum, 1 solve G'z, 2 solve h'z,
+  // 3 residual (G'z alone, or fused with its scalars), 4 residual h'z, 5 residual norm, 6 constant column h'z, 7 / 8 candidate
+  // screen, 9 / 10 line-search trial (sums / closing), 11 residual_products, 12 host-requested, 13 screen agreement, 15 other
+  void allreduce_dev(double* d_buf, long count, int op, int site = 15);
   DBuf ar_dev;   // device staging of allreduce_host for payloads beyond the context's 32 scalar slots
-  void allreduce_host(double* h_buf, int count, int op);
+  void allreduce_host(double* h_buf, int count, int op, int site = 15);
+  long comm_hist[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // Round 4: ONE exchange for a device payload and the scalars that used to follow it in collectives of their own.  The buffer
+  // is [payload (npay) | scalars to be summed (nsum) | one slot per rank and scalar to be max-ed (world x nmax)]; a rank fills only
+  // its own slots, so a SUM all-reduce returns every rank's value and the maximum (NaN wins) is taken locally -- sums and maxima
+  // travel in the same ncclAllReduce.  Needs the communicator's layout (hyp_sys_set_comm_layout, or the RCCL communicator's).
+  int comm_rank_ = 0, comm_world_ = 0;
+  bool fused_ok() const { static const bool on = [] { const char* e = getenv("HYP_DIST_FUSED"); return !(e && e[0] == '0'); }(); return on && comm_world_ > 0; }
+  struct FusedTail { int nsum = 0, nmax = 0; const double* sum_src[8]; const double* max_src[8]; };
+  // d_buf must have room for npay + nsum + world * nmax doubles; h_out receives nsum sums, then nmax maxima
+  void allreduce_fused(double* d_buf, long npay, const FusedTail& t, double* h_out, int site);
+  double screen_sz_[18];      // sharded: the screen's all-reduced <z, s> and failure flag of each candidate ...
+  double screen_szfail_[18];
+  int screen_pass_g_ = -1;                 // ... and which of them check_cone_points is being asked about (-1: none)
   // the products of calc_convergence_params / calc_mu (Solvers.jl:418-483) on THIS process's rows of z, s and G, the sums over
   // ranks taken here: Gtz (n, summed) = G' z; Gx_s (q, these rows) = G x + s; dots = {h' z, z' s} (summed)
   DBuf rp_x, rp_z, rp_s, rp_t, rp_g;
+  DBuf rp_loc;   // residual_products2: the two local maxima in front of their exchange
+  void residual_products2(const double* h_x, const double* h_z, const double* h_s, double tau, double* h_Gtz, double* h_Gx_s, double* h_dots,
+                          double* h_norms);
   void residual_products(const double* h_x, const double* h_z, const double* h_s, double* h_Gtz, double* h_Gx_s, double* h_dots);
 
   // ---- device-resident direction solves (systemsolvers/common.jl:15-182): the 6x6 system of one

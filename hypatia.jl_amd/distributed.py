@@ -428,6 +428,9 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
         if not self.rccl_in_library:
             L.check(lib.hyp_sys_set_comm(h, ctypes.cast(self._cb, ctypes.c_void_p), None, ctypes.c_void_p(stage.data_ptr()), int(stage.numel())),
                     "hyp_sys_set_comm")
+        # (rank / world of the transport: lets the library send the scalars of a solve behind its n-vectors -- one exchange for three;
+        #  the RCCL communicator carries its own layout, the callback does not)
+        L.check(lib.hyp_sys_set_comm_layout(h, int(self.comm.rank), int(self.comm.world)), "hyp_sys_set_comm_layout")
         cc = np.ascontiguousarray(model.c, dtype=np.float64)
         hl = np.ascontiguousarray(model.h[self.rows], dtype=np.float64)
         bb = np.zeros(1)
@@ -472,14 +475,25 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
         return (id(pt), float(pt.tau), float(pt.kap), float(pt.x @ pt.x), float(z @ z), float(sv @ sv))
 
     def residual_products(self, pt):
-        """hyp_sys_residual_products on this rank's rows: {Gtz (n, summed over ranks), Gx_s (local rows), hz, zs (summed)}"""
+        """hyp_sys_residual_products2 on this rank's rows: {Gtz (n, summed over ranks), Gx_s (local rows), hz, zs (summed), and the two
+        residual norms of Solvers.jl:447-457 over all ranks' rows (zn_t = max |G x + s|, zn = max |G x + s - h tau|)} -- ONE exchange"""
+        import ctypes
         n, ql = self.n, self._ql_n
-        Gtz, Gx_s, dots = np.zeros(n), np.zeros(max(ql, 1)), np.zeros(2)
+        Gtz, Gx_s, dots, norms = np.zeros(n), np.zeros(max(ql, 1)), np.zeros(2), np.zeros(2)
         z = np.ascontiguousarray(pt.z[self.rsl])
         sv = np.ascontiguousarray(pt.s[self.rsl])
-        L.check(L.lib().hyp_sys_residual_products(self.local._h, L.vec_ptr(np.ascontiguousarray(pt.x)), L.vec_ptr(z), L.vec_ptr(sv),
-                                                  L.vec_ptr(Gtz), L.vec_ptr(Gx_s), L.vec_ptr(dots)), "hyp_sys_residual_products")
-        return {"Gtz": Gtz, "Gx_s": Gx_s[:ql], "hz": float(dots[0]), "zs": float(dots[1]), "version": self.point_version(pt)}
+        L.check(L.lib().hyp_sys_residual_products2(self.local._h, L.vec_ptr(np.ascontiguousarray(pt.x)), L.vec_ptr(z), L.vec_ptr(sv),
+                                                   ctypes.c_double(float(pt.tau)), L.vec_ptr(Gtz), L.vec_ptr(Gx_s), L.vec_ptr(dots),
+                                                   L.vec_ptr(norms)), "hyp_sys_residual_products2")
+        return {"Gtz": Gtz, "Gx_s": Gx_s[:ql], "hz": float(dots[0]), "zs": float(dots[1]), "zn_t": float(norms[0]), "zn": float(norms[1]),
+                "tau": float(pt.tau), "version": self.point_version(pt)}
+
+    def comm_hist(self):
+        """exchanges the library has issued for this solver, by place in the iteration (hyp_sys_comm_hist)"""
+        import ctypes
+        out = (ctypes.c_longlong * 16)()
+        L.check(L.lib().hyp_sys_comm_hist(self.local._h, out), "hyp_sys_comm_hist")
+        return [int(v) for v in out]
 
     def reduce_max(self, vals):
         vals = np.ascontiguousarray(vals, dtype=np.float64)

@@ -181,6 +181,11 @@ int hyp_sys_mul_G(hyp_sys* sys, int trans, double alpha, const double* x, double
  * out_Gx_s (q) = G x + s on these rows, out_dots2 = {h' z, z' s} summed -- no q-vector ever leaves a rank.  Needs
  * hyp_sys_load_model (for h). */
 int hyp_sys_residual_products(hyp_sys* sys, const double* x, const double* z, const double* s, double* out_Gtz, double* out_Gx_s, double* out_dots2);
+/* The same plus the two residual norms of Solvers.jl:447-457 over ALL ranks' rows -- out_norms2 = {max |G x + s|, max |G x + s - h tau|}
+ * -- carried by the SAME all-reduce (a slot per rank behind the sums; needs hyp_sys_set_comm_layout or an RCCL communicator, else a
+ * second small exchange): a cone-sharded host then needs no collective of its own per iteration. */
+int hyp_sys_residual_products2(hyp_sys* sys, const double* x, const double* z, const double* s, double tau, double* out_Gtz, double* out_Gx_s,
+                               double* out_dots2, double* out_norms2);
 /* In-place all-reduce of up to 32 host doubles over the solver's communicator (op 0 sum, 1 max, 2 min; a no-op on a single-GPU
  * solver): the residual norms of Solvers.jl:425-483 on a cone-sharded solver */
 int hyp_sys_allreduce_host(hyp_sys* sys, double* buf, int count, int op);
@@ -233,6 +238,15 @@ int hyp_comm_destroy(hyp_comm* comm);
 int hyp_comm_allreduce(hyp_comm* comm, void* device_buf, long count, int op);
 /* route the exchange points of hyp_sys_set_comm's description through the communicator (NULL: back to single GPU / callback) */
 int hyp_sys_set_comm_rccl(hyp_sys* sys, hyp_comm* comm);
+/* rank / world of the communicator behind hyp_sys_set_comm's callback (hyp_sys_set_comm_rccl takes them from its communicator).  With
+ * the layout known, an n-vector exchange carries the scalars that accompany it -- sums in shared slots, maxima in a slot per rank --
+ * in ONE all-reduce instead of three (per solve: G' z with h' z and the residual norm; common.jl:79-121, qrchol.jl:39-85).
+ * world = 0 (default): layout unknown, every reduction is a collective of its own. */
+int hyp_sys_set_comm_layout(hyp_sys* sys, int rank, int world);
+/* exchanges issued since creation by place in the iteration: out16[0] Schur sum, [1] solve G' z, [2] solve h' z, [3] residual (fused),
+ * [4] residual h' z, [5] residual norm, [6] constant column, [7] [8] candidate screen, [9] [10] line-search trial, [11] residual
+ * products, [12] host-requested, [13] screen agreement, [15] other */
+int hyp_sys_comm_hist(hyp_sys* sys, long long* out16);
 /* K-panel sharding of ONE replicated model (a single cone: configs[1] / [2]): with a communicator (or callback) installed
  * and world > 1, hyp_sys_update_lhs / _assemble_lhs sum only rows [q rank / world, q (rank + 1) / world) of the sqrt-Hessian
  * product into the Schur matrix (the K dimension of outer_prod!, qrchol.jl:234) and all-reduce the n x n result; model,

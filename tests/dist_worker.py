@@ -119,7 +119,9 @@ def run(rank, world, port, inst_args, out_path, backend="oracle", transport="glo
                      row_local=bool(getattr(solver.syssolver, "row_local", False)), q=model.q, n=model.n,
                      hooked=bool(getattr(solver.syssolver, "_hooked", False)), worst_dir_res=solver.worst_dir_res,
                      rccl_in_library=bool(getattr(solver.syssolver, "rccl_in_library", False)), lib_exchanges=_lib_exchanges(solver),
-                     screen_stats=_screen_stats(solver))
+                     screen_stats=_screen_stats(solver), n_solves=solver.n_solves,
+                     comm_hist=np.array(solver.syssolver.comm_hist() if hasattr(solver.syssolver, "comm_hist") and
+                                        getattr(solver.syssolver, "_hooked", False) else [0] * 16))
     finally:
         dist.destroy_process_group()
 

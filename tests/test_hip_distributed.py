@@ -98,6 +98,32 @@ def test_sharded_hip_solve_with_the_fused_step_switched_off(switch, monkeypatch)
     assert not bool(res["row_local"])
 
 
+@pytest.mark.timeout(600)
+def test_sharded_step_exchanges_per_iteration(monkeypatch):
+    """round 4: what a cone-sharded iteration exchanges, by place in the iteration (hyp_sys_comm_hist).  The scalars that accompany an
+    n-vector travel behind it in the SAME all-reduce (sums in shared slots, maxima in a slot per rank): the residual's h'z and norm
+    exchanges are gone (sites 4, 5), a screen survivor's <z, s> comes from the screen's exchange (site 9), the residual norms of
+    calc_convergence_params ride with G'z / h'z / z's (site 12 = host-requested reductions: none).  Per iteration: one Schur
+    triangle, three exchanges per paired solve, one for the residual products, two for the screen, one per survivor -- at most
+    12 plus three per refinement solve (with HYP_DIST_FUSED=0, the form of round 3, the same solve needs more than 18)."""
+    monkeypatch.setenv("HYP_DIST_NATIVE", "1")
+    res = _run_sharded("1", inst_args=(90, [6] * 8, 3))
+    hist = [int(v) for v in res["comm_hist"]]
+    iters, n_solves = int(res["iters"]), int(res["n_solves"])
+    assert hist[0] == iters                                   # the Schur sum
+    assert hist[4] == 0 and hist[5] == 0 and hist[12] == 0, hist
+    assert hist[9] == 0 and hist[7] >= iters and hist[8] >= iters, hist     # the screen ran; no survivor paid for its sums again
+    refinements = n_solves - 4 * iters
+    assert refinements >= 0
+    per_iter = sum(hist) / iters
+    assert per_iter <= 12.0 + 3.0 * refinements / iters + 0.5, (per_iter, hist, refinements)
+    monkeypatch.setenv("HYP_DIST_FUSED", "0")
+    old = _run_sharded("1", inst_args=(90, [6] * 8, 3))
+    hist_old = [int(v) for v in old["comm_hist"]]
+    assert sum(hist_old) / int(old["iters"]) > per_iter + 5.0, (hist_old, hist)
+    assert int(old["iters"]) == iters and abs(float(old["p_obj"]) - float(res["p_obj"])) <= 1e-9 * (1 + abs(float(res["p_obj"])))
+
+
 def _run_sharded(native, inst_args=(120, [20, 12, 16, 9], 4), world=2, transport="gloo", expect_row_local=True):
     import dist_worker
     from oracle import instances as I

@@ -1,4 +1,4 @@
 #!/bin/bash
+# scratch for one-off gpurun calls (`gpurun --timeout N -- 'bash tools/_x.sh'`); the round's standard batch is tools/_run_gpu.sh
 cd /root/repo; export TMPDIR=/tmp
-python tools/potrf_accuracy.py make
-for v in "" "HYP_POTRF_DEFER=0" "HYP_POTRF_TINV=0" "HYP_POTRF_MFMA=0"; do echo "== $v"; env $v python tools/potrf_accuracy.py eval; done
+python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; tail -8 gpurun_out/pytest_gpu.log
