@@ -49,6 +49,18 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix spec; measured 77.8 with tools/probe_mfma.hip (profiles/)
 
 
+def blas_threads(want):
+    """host BLAS threads for a `threadpool_limits` block: never MORE than the pool was started with.  Under `torch.distributed.run`
+    (OMP_NUM_THREADS=1 in every rank) OpenBLAS sizes its buffers for one thread, and raising the limit to 8 afterwards crashed
+    scipy's threaded LAPACK calls (dgeqp3 / dorgqr of find_initial_y: SIGSEGV in rank 0 of `--config 5d --gpus 2`)."""
+    try:
+        from threadpoolctl import threadpool_info
+        cur = max([int(d.get("num_threads", 1)) for d in threadpool_info() if d.get("user_api") == "blas"] or [1])
+    except Exception:
+        cur = 1
+    return max(1, min(int(want), cur))
+
+
 def algorithm_record():
     """which route through the library a bench line timed: the switches are read from the environment by the
     library itself, once per process; the defaults leave the reference's ORDER of operations in three places"""
@@ -121,7 +133,7 @@ def cpu_blas3_bound(n, side, threads):
     V = rng.standard_normal((ncol, side, side))
     HG = np.asfortranarray(rng.standard_normal((dim, n)))
     S = rng.standard_normal((n, n + 8)); S = np.asfortranarray(S @ S.T + n * np.eye(n))
-    with threadpool_limits(limits=threads, user_api="blas"):
+    with threadpool_limits(limits=blas_threads(threads), user_api="blas"):
         t0 = time.perf_counter(); W = np.matmul(Ui.T, np.matmul(V, Ui)); t_ts = (time.perf_counter() - t0) * n / ncol
         t0 = time.perf_counter(); sla.blas.dsyrk(1.0, HG, trans=1, lower=0); t_syrk = time.perf_counter() - t0
         t0 = time.perf_counter(); sla.lapack.dpotrf(S, lower=0, overwrite_a=True); t_chol = time.perf_counter() - t0
@@ -251,7 +263,7 @@ def _run_cone_sharded(args, world, rank, comm, H, D, torch):
     t_setup = time.perf_counter()
     from threadpoolctl import threadpool_limits
     host_threads = max(1, min(args.cpu_threads, (os.cpu_count() or 8) // world))   # untimed host set-up: the ranks share the host cores
-    with threadpool_limits(limits=host_threads, user_api="blas"):
+    with threadpool_limits(limits=blas_threads(host_threads), user_api="blas"):
         solver = H.Solver(verbose=args.verbose and rank == 0, syssolver=D.DistQRCholDenseSystemSolver(comm))
         solver.load(model)
         solver.setup()
@@ -404,13 +416,13 @@ def run_headline(args, world, rank, local_rank, multi, comm=None):
             G[k * dim4:(k + 1) * dim4] = gen_block(args.n, side4, k, args.seed)
         x0 = np.random.default_rng(args.seed).standard_normal(args.n)
         e = np.tile(svec_identity(side4), nc4)
-        with threadpool_limits(limits=args.cpu_threads, user_api="blas"):
+        with threadpool_limits(limits=blas_threads(args.cpu_threads), user_api="blas"):
             inst = (-(G.T @ e), np.zeros((0, args.n)), np.zeros(0), G, G @ x0 + e, [("possemideftri", dim4)] * nc4, dict(status="Optimal"))
         args.cpu_iters = 0      # (the CPU port needs ~20 s per iteration here; the baseline is quoted on the headline configuration)
     else:
         inst = gen_instance(args.n, [args.side], args.seed)
     q = inst[3].shape[0]
-    with threadpool_limits(limits=args.cpu_threads, user_api="blas"):   # host preprocessing (rescale, QR for the initial x): untimed setup
+    with threadpool_limits(limits=blas_threads(args.cpu_threads), user_api="blas"):   # host preprocessing (rescale, QR for the initial x): untimed setup
         solver = H.Solver(verbose=args.verbose and rank == 0, init_use_indirect=(args.config == "4"),
                           syssolver=(D.KShardQRCholDenseSystemSolver(comm) if comm is not None else None))
         solver.load(H.make_model(inst))
@@ -540,7 +552,7 @@ def run_headline(args, world, rank, local_rank, multi, comm=None):
         # (tools/cpu_baseline_threads.py: 1 -> 8.4 s, 8 -> 3.7 s, 32 -> 7.0 s, 256 -> 17.6 s per iteration; the
         # per-column loop of the PSD products is many small BLAS calls, which large pools slow down)
         from threadpoolctl import threadpool_limits
-        with threadpool_limits(limits=args.cpu_threads, user_api="blas"):
+        with threadpool_limits(limits=blas_threads(args.cpu_threads), user_api="blas"):
             os_ = OSolver(verbose=False, iter_limit=args.cpu_iters)
             os_.load(omodel(inst))
             os_.solve()
@@ -632,7 +644,7 @@ def main_other(args, world=1, rank=0, local_rank=0, multi=False):
     iters, loop_s, solves, trials, nsolve_runs = 0, 0.0, 0, 0, 0
     phases = dict(upsys=0.0, getdir=0.0, search=0.0)
     status = None
-    with threadpool_limits(limits=args.cpu_threads, user_api="blas"):
+    with threadpool_limits(limits=blas_threads(args.cpu_threads), user_api="blas"):
         if args.config != "3c":
             warm = mk_solver(verbose=False, iter_limit=2, **solver_opts)          # untimed: first-touch allocations, kernel loading
             warm.load(H.make_model(inst)); warm.solve()
@@ -735,7 +747,8 @@ def main_other(args, world=1, rank=0, local_rank=0, multi=False):
         # cone's U rows; everything else is replicated.  The Amdahl bound follows from this run's own phase times.
         out["n_gpus"] = world
         up_ms = up_s / iters * 1e3
-        shard_ms = (f_uplhs - float(nm) ** 3 / 3) / max(f_uplhs, 1.0) * up_ms if args.config == "5d" else 0.0   # (the product's share of update_lhs by flops)
+        # the product's share of update_lhs: HIP-event time of the square-root-Hessian product + syrk at THIS N (hyp_get_kernel_stats [0], [1])
+        shard_ms = min(up_ms, (ks[0] + ks[1]) / iters) if args.config == "5d" else 0.0
         out["config"]["parallelism"] = "k-shard x%d (model replicated, Schur product split over the cone's rows)" % world
         out["config"]["exchange"] = ("one all-reduce (sum, f64) of the n x n Schur upper triangle per iteration: %.1f calls and %.3g doubles per "
                                      "iteration" % (comm_calls / iters, comm_doubles / iters))

