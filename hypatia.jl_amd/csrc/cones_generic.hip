@@ -171,6 +171,15 @@ void GenericHessCone::inv_sqrt_hess_prod(double* prod, long ldp, const double* a
   HYP_REQUIRE(hess_fact_updated && hess_fact_ok && !hess_fact_bk, "inv_sqrt_hess_prod: no Cholesky factor");
   if (prod != arr) HYP_CHECK(hipMemcpy2DAsync(prod, ldp * sizeof(double), arr, lda * sizeof(double), (size_t)dim * sizeof(double), ncols,
                                               hipMemcpyDeviceToDevice, ctx.stream));
+  if (ncols >= 1 && ncols <= 2 && ctx.trsv_plan_sb(dim) > 0) {
+    // one or two columns against a large factor (polymin in primal form: n = 1, so update_lhs applies U'^-1 to ONE column of length
+    // U = 4845 -- 38 block steps of the multi-column solve, 1.3 ms of launches, against 0.15 ms through the super-block plan the
+    // proximity test builds for this factor anyway; profiles/r04_cfg5p_trial_timeline.txt)
+    if (!Hplan.ready(dim)) Hplan.build(ctx, dim, Hfact.d(), dim, Hdinv.d());
+    if (ncols == 1) Hplan.solve(ctx, Hfact.d(), dim, true, prod);
+    else Hplan.solve_multi(ctx, Hfact.d(), dim, true, prod, ldp, 2);
+    return;
+  }
   trsm_work.ensure((size_t)NB * std::max(ncols, 1) * sizeof(double));
   trsm_upper_left(ctx, dim, ncols, Hfact.d(), dim, Hdinv.d(), true, prod, ldp, trsm_work.d());
 }

@@ -564,6 +564,30 @@ function residual_products!(Gtz::Vector{Float64}, Gx_s::Vector{Float64}, dots::V
     return (Gtz, Gx_s, dots)
 end
 
+# the same with the two residual norms of Solvers.jl:447-457 over ALL ranks' rows (norms = [max |G x + s|, max |G x + s - h tau|]) riding
+# in the same exchange: a cone-sharded host needs no collective of its own per iteration
+function residual_products_norms!(Gtz::Vector{Float64}, Gx_s::Vector{Float64}, dots::Vector{Float64}, norms::Vector{Float64},
+        sys::HIPQRCholDenseSystemSolver, x::Vector{Float64}, z::Vector{Float64}, s::Vector{Float64}, tau::Float64)
+    check(ccall((:hyp_sys_residual_products2, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        sys.handle, x, z, s, tau, Gtz, Gx_s, dots, norms), "hyp_sys_residual_products2")
+    return (Gtz, Gx_s, dots, norms)
+end
+
+# rank / world of the transport behind hyp_sys_set_comm's callback (an MPI communicator's, say): with it the scalars of a solve travel
+# behind its n-vectors in one all-reduce; hyp_sys_set_comm_rccl takes the layout from its communicator
+function set_comm_layout!(sys::HIPQRCholDenseSystemSolver, rank::Integer, world::Integer)
+    check(ccall((:hyp_sys_set_comm_layout, lib), Cint, (Ptr{Cvoid}, Cint, Cint), sys.handle, rank, world), "hyp_sys_set_comm_layout")
+    return sys
+end
+
+# exchanges issued since creation, by place in the iteration (see hyp_sys_comm_hist in include/hypatia_hip.h)
+function comm_hist(sys::HIPQRCholDenseSystemSolver)
+    out = zeros(Clonglong, 16)
+    check(ccall((:hyp_sys_comm_hist, lib), Cint, (Ptr{Cvoid}, Ptr{Clonglong}), sys.handle, out), "hyp_sys_comm_hist")
+    return out
+end
+
 # ---------------------------------------------------------------------------------------------
 # The fused fast path of step(::CombinedStepper) (steppers/combined.jl:53-120), for a stepper method that wants it (p = 0):
 #   step_directions!      update_lhs + update_rhs_cent / _pred / _centadj / _predadj + the two paired solves in ONE device call
