@@ -122,6 +122,7 @@ SIGNATURES = {
     "hyp_dense_gemm": [c_vp, c_int, c_int, c_int, c_int, c_int, c_dbl, c_vp, c_int, c_vp, c_int, c_dbl, c_vp, c_int],
     "hyp_dense_syrk": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int],
     "hyp_dense_potrf": [c_vp, c_int, c_vp, c_int, P(c_int)],
+    "hyp_dense_posdef_solve": [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, P(c_int), P(c_int), P(c_int)],
     "hyp_dense_posv": [c_vp, c_int, c_vp, c_int, c_vp, P(c_int)],
     "hyp_dense_posv_multi": [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, P(c_int)],
     "hyp_dense_sysv_rook": [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, P(c_int), c_vp, c_vp, c_vp, c_vp],

@@ -425,10 +425,21 @@ __global__ __launch_bounds__(256) void bk_update_kernel(int n, double* __restric
   }
 }
 
-__global__ void bk_init_kernel(int n, BkState* st, int* perm) {
+__global__ void bk_init_kernel(int n, BkState* st, int* perm, int k0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) perm[i] = i;
-  if (i == 0) { st->knext = 0; st->k = 0; st->kstep = 1; st->skip = 0; st->info = 0; st->n2x2 = 0; st->npend = 0; st->flush = 0; st->base = 0; }
+  if (i == 0) { st->knext = k0; st->k = k0; st->kstep = 1; st->skip = 0; st->info = 0; st->n2x2 = 0; st->npend = 0; st->flush = 0; st->base = k0; }
+}
+// factor_from: row i < k0 of a Cholesky factor (E(i, j) at B[i * ld + j], j >= i) -> row of the unit factor, its pivot into D
+__global__ __launch_bounds__(256) void bk_unit_rows_kernel(int n, double* __restrict__ B, long ld, double* __restrict__ dd, double* __restrict__ de,
+                                                           int* __restrict__ blk) {
+  const int i = blockIdx.x;
+  double* r = B + (long)i * ld;
+  const double u = r[i];
+  const double inv = 1.0 / u;
+  __syncthreads();
+  for (int j = i + 1 + threadIdx.x; j < n; j += 256) r[j] *= inv;
+  if (threadIdx.x == 0) { r[i] = 1.0; dd[i] = u * u; de[i] = 0.0; blk[i] = 0; }
 }
 
 __global__ void bk_gather_kernel(int n, int nr, const int* __restrict__ perm, const double* __restrict__ x, long ldx,
@@ -469,10 +480,13 @@ __global__ void bk_dsolve_kernel(int n, int nr, const double* __restrict__ dd, c
 
 }  // namespace
 
-int BKFact::factor(Ctx& c, int n_, double* A, long lda, double* dinv) {
+int BKFact::factor(Ctx& c, int n_, double* A, long lda, double* dinv) { return factor_from(c, n_, A, lda, dinv, 0); }
+
+int BKFact::factor_from(Ctx& c, int n_, double* A, long lda, double* dinv, int k0) {
   c.kstat[6] += 1;   // (Bunch-Kaufman factorizations: the fallback of a failed Cholesky, cone Hessian or Schur matrix)
   n = n_;
   if (n <= 0) return 0;
+  HYP_REQUIRE(k0 >= 0 && k0 < n, "Bunch-Kaufman: start column");
   const size_t d = sizeof(double);
   dd.ensure((size_t)n * d);
   de.ensure((size_t)n * d);
@@ -484,13 +498,14 @@ int BKFact::factor(Ctx& c, int n_, double* A, long lda, double* dinv) {
   double* B = tr.d();
   dev_transpose(c, n, n, A, lda, B, n, 1, 0, 0);   // B[i * n + j] = A(i, j): the upper triangle, transposed
   BkState* st = (BkState*)state.p;
-  hipLaunchKernelGGL(bk_init_kernel, dim3((n + 255) / 256), dim3(256), 0, c.stream, n, st, perm.i());
+  hipLaunchKernelGGL(bk_init_kernel, dim3((n + 255) / 256), dim3(256), 0, c.stream, n, st, perm.i(), k0);
+  if (k0 > 0) hipLaunchKernelGGL(bk_unit_rows_kernel, dim3(k0), dim3(256), 0, c.stream, n, B, (long)n, dd.d(), de.d(), blk.i());
   // Launch pairs are enqueued in chunks; after each chunk the host reads how far the device got.  A pair either completes
   // a step or only requests a flush (always followed by a pair that completes one), so after q further pairs the next
   // column is at least known + q / 2: that bounds the trailing block an update launch can meet.
-  const int CH = std::min(128, 2 * n + 2);
-  int known = 0;
-  for (int chunk = 0; chunk < 4 * n / CH + 8 && known < n; ++chunk) {
+  const int CH = std::min(128, 2 * (n - k0) + 2);
+  int known = k0;
+  for (int chunk = 0; chunk < 4 * (n - k0) / CH + 8 && known < n; ++chunk) {
     for (int q = 0; q < CH; ++q) {
       hipLaunchKernelGGL(bk_pivot_kernel, dim3(1), dim3(BK_T), 0, c.stream, n, B, (long)n, st, dd.d(), de.d(), blk.i(), perm.i(), wl.d());
       const int rem = n - 1 - (known + q / 2);
@@ -511,6 +526,21 @@ int BKFact::factor(Ctx& c, int n_, double* A, long lda, double* dinv) {
   const BkState* hs = (const BkState*)c.h_info;
   n_2x2 = hs->n2x2;
   return hs->info;
+}
+
+int bk_after_failed_cholesky(Ctx& c, BKFact& bk, int n, double* A, long lda, double* dinv, int* d_info_scratch, int chol_info) {
+  static const bool hybrid = [] { const char* e = getenv("HYP_BK_HYBRID"); return !(e && e[0] == '0'); }();
+  const int kb = (chol_info > 0) ? (chol_info - 1) / NB : 0;   // block step of the failing pivot: the steps before it succeeded
+  if (hybrid && kb >= 1 && kb * NB < n) {
+    potrf_upper_batched(c, n, A, lda, 0, 1, nullptr, d_info_scratch, kb);
+    c.d2h(c.h_info + 41, d_info_scratch, sizeof(int));
+    c.sync();
+    if (c.h_info[41] == 0) return bk.factor_from(c, n, A, lda, dinv, kb * NB);
+    // (cannot happen -- the same kernels on the same data succeeded a moment ago --; the matrix is then half eliminated: the caller's
+    //  copy is gone, so report the failure as a singular pivot rather than factor garbage)
+    return c.h_info[41];
+  }
+  return bk.factor(c, n, A, lda, dinv);
 }
 
 double* BKFact::gather(Ctx& c, const double* x, long ldx, int nr) {

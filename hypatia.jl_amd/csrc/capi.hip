@@ -905,6 +905,45 @@ int hyp_dense_sysv_rook(hyp_ctx* ctx, int n, double* A, int lda, double* x, int 
   c.sync();
   API_END(ctx)
 }
+// posdef_fact_copy! (dense.jl:194-215) on a host matrix, then ldiv!: Cholesky; if it fails, symm_fact! through bk_after_failed_cholesky
+// (the Cholesky steps in front of the failing pivot's block kept, rook pivoting behind them).  used_fallback 0 / 1; bk_start = the
+// column the rook-pivoted elimination started from (0: the whole matrix).  Tests.
+int hyp_dense_posdef_solve(hyp_ctx* ctx, int n, double* A, int lda, double* x, int nrhs, int ldx, int* info, int* used_fallback, int* bk_start) {
+  API_BEGIN
+  Ctx& c = ctx->c;
+  HYP_REQUIRE(n >= 1 && lda >= n && nrhs >= 0 && ldx >= n, "posdef_solve: sizes");
+  DBuf dA((size_t)lda * n * 8), dF((size_t)lda * n * 8), dinv(dinv_elems(n) * 8), dx((size_t)ldx * std::max(nrhs, 1) * 8), dinfo(64), work;
+  c.h2d(dA.p, A, (size_t)lda * n * 8);
+  if (nrhs > 0) c.h2d(dx.p, x, (size_t)ldx * nrhs * 8);
+  c.d2d(dF.p, dA.p, (size_t)lda * n * 8);
+  potrf_upper_batched(c, n, dF.d(), lda, 0, 1, dinv.d(), dinfo.i());
+  c.d2h(c.h_info, dinfo.p, sizeof(int));
+  c.sync();
+  const int ci = c.h_info[0];
+  *used_fallback = 0;
+  *bk_start = 0;
+  *info = ci;
+  if (ci == 0) {
+    if (nrhs > 0) {
+      work.ensure((size_t)NB * nrhs * 8);
+      trsm_upper_left(c, n, nrhs, dF.d(), lda, dinv.d(), true, dx.d(), ldx, work.d());
+      trsm_upper_left(c, n, nrhs, dF.d(), lda, dinv.d(), false, dx.d(), ldx, work.d());
+    }
+  } else {
+    *used_fallback = 1;
+    BKFact bk;
+    c.d2d(dF.p, dA.p, (size_t)lda * n * 8);
+    static const bool hybrid = [] { const char* e = getenv("HYP_BK_HYBRID"); return !(e && e[0] == '0'); }();
+    const int kb = (ci - 1) / NB;
+    *bk_start = (hybrid && kb >= 1 && kb * NB < n) ? kb * NB : 0;
+    *info = bk_after_failed_cholesky(c, bk, n, dF.d(), lda, dinv.d(), dinfo.i(), ci);
+    if (*info == 0 && nrhs > 0) bk.solve(c, dF.d(), lda, dinv.d(), dx.d(), ldx, nrhs, work);
+  }
+  c.d2h(A, dF.p, (size_t)lda * n * 8);
+  if (nrhs > 0) c.d2h(x, dx.p, (size_t)ldx * nrhs * 8);
+  c.sync();
+  API_END(ctx)
+}
 // Least squares x = argmin || A x - b || for a tall dense A (m x n) known to be well conditioned: Cholesky of A'A on the
 // device, one step of corrected semi-normal equations (x += (R'R)^-1 A'(b - A x)) and an estimate of
 // sigma_min(A) / sigma_max(A) from power iterations with the factor, so that the caller can decide whether to trust it.

@@ -77,18 +77,23 @@ bool GenericHessCone::update_hess_fact() {   // Cones.jl:239-251: posdef_fact_co
   const bool force_bk = fb && fb[0] && fb[0] != '0';
   hess_fact_bk = false;
   hess_fact_ok = false;
+  int hinfo_fail = 0;
   ctx.kstat[5] += 1;   // (cone Hessian factorizations: bench.py's executed-work count)
   if (!force_bk) {
     ctx.d2d(Hfact.p, H.p, (size_t)dim * dim * sizeof(double));
     potrf_upper_batched(ctx, dim, Hfact.d(), dim, 0, 1, Hdinv.d(), Hinfo.i());
-    hess_fact_ok = (read_info(ctx, Hinfo.i()) == 0);
+    const int hinfo = read_info(ctx, Hinfo.i());
+    hess_fact_ok = (hinfo == 0);
+    hinfo_fail = hinfo;
+    static const bool tdbg = [] { const char* e = getenv("HYP_TRIAL_DBG"); return e && e[0] == '1'; }();
+    if (tdbg && hinfo != 0) fprintf(stderr, "[hess] Cholesky of the %d x %d Hessian failed at pivot %d\n", dim, dim, hinfo);
   }
   if (hess_fact_ok) {
     dev_zero_strict_lower(ctx, dim, Hfact.d(), dim, 1, 0);
   } else {
     hess_fact_bk = true;
     ctx.d2d(Hfact.p, H.p, (size_t)dim * dim * sizeof(double));
-    hess_fact_ok = (Hbk.factor(ctx, dim, Hfact.d(), dim, Hdinv.d()) == 0);
+    hess_fact_ok = (bk_after_failed_cholesky(ctx, Hbk, dim, Hfact.d(), dim, Hdinv.d(), Hinfo.i(), force_bk ? 0 : hinfo_fail) == 0);
   }
   hess_fact_updated = true;
   Hplan.invalidate();

@@ -86,7 +86,7 @@ hipEvent_t Ctx::pool_event(size_t i) {
   return ev_pool[i];
 }
 
-void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int batch, double* dinv, int* d_info) {
+void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int batch, double* dinv, int* d_info, int kb_stop) {
   if (n <= 0 || batch <= 0) return;
   c.zero(d_info, sizeof(int) * batch);
   const long strideD = (long)dinv_elems(n);
@@ -113,6 +113,7 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
   if (tinv_on) c.potrf_tinv.ensure((size_t)batch * tinv_stride * sizeof(double));
   int last_la = -1;   // last block step whose trailing update went to the helper stream and has not been joined yet
   for (int kb = 0; kb < nblk; ++kb) {
+    if (kb_stop >= 0 && kb >= kb_stop) break;
     const int k0 = kb * NB;
     const int nb = std::min(NB, n - k0);
     const int m = n - k0 - nb;
@@ -156,7 +157,7 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
     HYP_CHECK(hipEventRecord(Rk, c.stream2));
   }
   if (lookahead && last_la >= 0) HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(2 * last_la + 1), 0));
-  if (dinv) potrf_invert_diag_blocks(c, n, A, lda, strideA, batch, dinv);
+  if (dinv && kb_stop < 0) potrf_invert_diag_blocks(c, n, A, lda, strideA, batch, dinv);
 }
 
 void potrf_invert_diag_blocks(Ctx& c, int n, double* A, long lda, long strideA, int batch, double* dinv, long strideD) {

@@ -151,7 +151,9 @@ struct StreamSwap {
 // layout [batch][block][2][NB*NB] col-major, ld NB (DINV_BLK doubles per block).
 // d_info[b] = 0 or the 1-based index of the first non-positive pivot (LAPACK dpotrf convention).
 // dinv == nullptr: factor only (feasibility checks); potrf_invert_diag_blocks produces the block inverses later.
-void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int batch, double* dinv, int* d_info);
+void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int batch, double* dinv, int* d_info, int kb_stop = -1);
+// (kb_stop >= 0: only block steps 0 .. kb_stop - 1, each with its whole trailing update: rows < NB kb_stop hold rows of the factor, the
+//  trailing block its Schur complement -- the start of the hybrid factorization of BKFact::factor_from)
 void potrf_invert_diag_blocks(Ctx& c, int n, double* A /* factored */, long lda, long strideA, int batch, double* dinv,
                               long strideD = 0 /* doubles between the batch members' dinv; 0: dinv_elems(n) */);
 constexpr long DINV_BLK = 2L * NB * NB;
@@ -190,11 +192,22 @@ struct BKFact {
   // blocks for trsv_upper / trsm_upper_left / TriSolvePlan.  Returns LAPACK's info: 0 or the 1-based index of the
   // first exactly singular pivot (issuccess(fact) = info == 0).  Synchronizes.
   int factor(Ctx& c, int n_, double* A, long lda, double* dinv);
+  // Round 4.  The matrices a failed Cholesky hands over fail at their LAST pivots (config 5: 4841 - 4845 of 4845, every one of 20
+  // fall-backs): the leading k0 columns have a perfectly good Cholesky elimination.  A holds rows 0 .. k0 - 1 of that factor
+  // (potrf_upper_batched(..., kb_stop)) and the Schur complement behind them; the rows become rows of the unit factor (U_ij / U_ii,
+  // D_ii = U_ii^2) and the rook-pivoted elimination runs on the trailing block only (its interchanges permute the columns of the
+  // rows above, as dsytrf_rook's do).  P A P' = U' D U as from factor(): the same solves apply.  22 ms -> the trailing block's share.
+  int factor_from(Ctx& c, int n_, double* A, long lda, double* dinv, int k0);
   double* gather(Ctx& c, const double* x, long ldx, int nr);          // tmp[:, r] = P x[:, r]; returns tmp (ld n)
   void dsolve(Ctx& c, double* y, long ldy, int nr);                   // y <- D^-1 y
   void scatter(Ctx& c, const double* y, double* x, long ldx, int nr); // x[:, r] = P' y[:, r] (y with ld n)
   void solve(Ctx& c, const double* U, long ldu, const double* dinv, double* x, long ldx, int nr, DBuf& trsm_work);
 };
+// symm_fact! behind a failed Cholesky (dense.jl:194-215, the second link of posdef_fact_copy!): A = the matrix again (upper triangle),
+// chol_info = the 1-based pivot the Cholesky failed at (0: unknown / forced: the plain rook-pivoted factorization from column 0).
+// With the failing pivot in block step kb >= 1 the first kb block steps are redone as Cholesky steps and only the trailing block is
+// eliminated with rook pivoting (BKFact::factor_from; HYP_BK_HYBRID=0: always from column 0).  Returns BKFact's info.
+int bk_after_failed_cholesky(Ctx& c, BKFact& bk, int n, double* A, long lda, double* dinv, int* d_info_scratch, int chol_info);
 // Y[:, r] = alpha op(A) X[:, r] + beta Y[:, r] for r < nr <= 2: one pass over A serves all right-hand sides
 void gemv_multi(Ctx& c, bool trans, int m, int n, int nr, double alpha, const double* A, long lda, const double* X, long ldx, double beta,
                 double* Y, long ldy);

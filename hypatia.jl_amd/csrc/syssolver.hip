@@ -595,8 +595,9 @@ void SysSolver::factor_lhs(int* info, int* used_fallback) {   // qrchol.jl:249-2
   if (force_bk || *info != 0) {
     use_bk = true;
     *used_fallback = 1;
+    const int chol_info = force_bk ? 0 : *info;
     ctx.d2d(lhs_fact.p, lhs.p, (size_t)nmp * nmp * sizeof(double));
-    *info = bk.factor(ctx, nmp, lhs_fact.d(), nmp, dinv.d());
+    *info = bk_after_failed_cholesky(ctx, bk, nmp, lhs_fact.d(), nmp, dinv.d(), d_info.i(), chol_info);
     if (*info != 0) {
       *used_fallback = 2;
       ctx.d2d(lhs_fact.p, lhs.p, (size_t)nmp * nmp * sizeof(double));

@@ -308,6 +308,10 @@ int hyp_dense_posv_multi(hyp_ctx* ctx, int n, double* A, int lda, double* X, int
  * describe the factorization: perm[i] = original index in position i; blk[i] = 0 for a 1x1 pivot d[i], 1 / 2 for
  * the two rows of a 2x2 pivot [[d[i], e[i]], [e[i], d[i+1]]].  x (n x nrhs, ld ldx) is overwritten with A^-1 x.
  * info = 0, or the 1-based position of the first exactly singular pivot (LAPACK dsytrf_rook). */
+/* posdef_fact_copy! + ldiv! on a host matrix (dense.jl:194-215): Cholesky, and behind a failed one the symmetric indefinite
+ * factorization -- the Cholesky steps in front of the failing pivot's 128-column block kept, rook pivoting (dsytrf_rook's rule) on
+ * the trailing block only; bk_start = the column it started from (0: the whole matrix, also with HYP_BK_HYBRID=0) */
+int hyp_dense_posdef_solve(hyp_ctx* ctx, int n, double* A, int lda, double* x, int nrhs, int ldx, int* info, int* used_fallback, int* bk_start);
 int hyp_dense_sysv_rook(hyp_ctx* ctx, int n, double* A, int lda, double* x, int nrhs, int ldx, int* info, int* perm, int* blk,
                         double* d, double* e);
 /* Column-pivoted Householder QR on the device with LAPACK dgeqp3's semantics (= Julia's qr!(AG, ColumnNorm()) of

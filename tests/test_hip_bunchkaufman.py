@@ -185,3 +185,56 @@ def test_generic_cone_inverse_hessian_through_bunchkaufman(monkeypatch, kind, ar
     assert hc.check_numerics() == oc.check_numerics()
     ph, po = hc.get_proxsqr(0.9, True), oc.get_proxsqr(0.9, True)
     assert abs(ph - po) <= 1e-7 * max(1.0, abs(po))
+
+
+def _late_failure_matrix(n, nbad, rng, cond=1e8):
+    """symmetric, positive definite on its leading n - nbad columns, with nbad negative eigen-directions that a Cholesky meets at its
+    LAST pivots -- the shape of the matrices that reach symm_fact! in the solver (cone Hessians at the end of a solve)"""
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = np.logspace(0, -np.log10(cond), n)
+    A = (Q * lam) @ Q.T
+    A = 0.5 * (A + A.T)
+    L = np.linalg.cholesky(A)
+    D = np.ones(n)
+    D[n - nbad:] = -1.0                      # A' = L D L': the same elimination, the last nbad pivots negative
+    Ab = (L * D) @ L.T
+    return 0.5 * (Ab + Ab.T)
+
+
+@pytest.mark.parametrize("n,nbad", [(300, 3), (700, 5), (1153, 1), (1153, 40), (2250, 2), (200, 4), (640, 1)])
+def test_hybrid_factorization_behind_a_late_cholesky_failure(hip, n, nbad):
+    """round 4: behind a failed Cholesky the block steps in front of the failing pivot's block are kept and only the trailing block
+    goes through the rook-pivoted elimination (BKFact::factor_from).  Against numpy's solve: LAPACK's backward error; bk_start says
+    the hybrid path ran (failure beyond the first 128 columns) or not (n = 200: one block, and with HYP_BK_HYBRID=0 always 0)."""
+    lib, ctx, L = hip
+    rng = np.random.default_rng(n + nbad)
+    A = _late_failure_matrix(n, nbad, rng)
+    B = rng.standard_normal((n, 3))
+    Ad = np.asfortranarray(np.triu(A) + np.tril(np.full((n, n), 7.5), -1))   # the strict lower triangle must not be read
+    X = np.asfortranarray(B.copy())
+    info, fb, start = c_int(-1), c_int(-1), c_int(-1)
+    L.check(lib.hyp_dense_posdef_solve(ctx, n, fp(Ad), n, fp(X), 3, n, ctypes.byref(info), ctypes.byref(fb), ctypes.byref(start)), "posdef_solve")
+    assert info.value == 0 and fb.value == 1
+    fail_col = n - nbad                                    # 0-based column of the first negative pivot
+    assert start.value == (fail_col // 128) * 128
+    Xref = np.linalg.solve(A, B)
+    berr = lambda Xc: np.linalg.norm(A @ Xc - B) / (np.linalg.norm(A, 2) * np.linalg.norm(Xc) + np.linalg.norm(B))
+    assert berr(X) <= 10 * berr(Xref) + 1e-15, (berr(X), berr(Xref))
+    assert np.linalg.norm(X - Xref) <= 1e-6 * np.linalg.norm(Xref)          # (condition 1e8)
+    # the plain rook-pivoted factorization of the same matrix solves the same system
+    _, X2, info2, *_ = device_sysv(hip, A, B)
+    assert info2 == 0 and np.linalg.norm(X - X2) <= 1e-6 * np.linalg.norm(Xref)
+
+
+def test_posdef_solve_cholesky_branch(hip):
+    lib, ctx, L = hip
+    rng = np.random.default_rng(3)
+    n = 500
+    M = rng.standard_normal((n, n + 5))
+    A = M @ M.T + np.eye(n)
+    b = rng.standard_normal(n)
+    Ad, x = np.asfortranarray(A.copy()), b.copy()
+    info, fb, start = c_int(-1), c_int(-1), c_int(-1)
+    L.check(lib.hyp_dense_posdef_solve(ctx, n, fp(Ad), n, fp(x), 1, n, ctypes.byref(info), ctypes.byref(fb), ctypes.byref(start)), "posdef_solve")
+    assert info.value == 0 and fb.value == 0 and start.value == 0
+    assert np.linalg.norm(x - np.linalg.solve(A, b)) <= 1e-9 * np.linalg.norm(b)
