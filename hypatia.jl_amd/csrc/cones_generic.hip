@@ -324,34 +324,29 @@ void WsosCone::update_grad() {   // :119-133
   // are then added in the order of k, which is the order the one-stream form accumulates in (same bits)
   static const bool par = [] { const char* e = getenv("HYP_WSOS_PAR"); return !(e && e[0] == '0'); }();
   if (par && K >= 2 && K <= 64) {
+    // (round 4: the chains are dealt out to Ctx::max_lanes() streams -- three by default, see there; a chain's kernels and their
+    //  order do not depend on the lane, so neither do its bits)
+    const int nl = std::min(K, Ctx::max_lanes());
     gparts.ensure((size_t)K * U * sizeof(double));
     trsm_work.ensure((size_t)NB * U * sizeof(double));
-    trsm_work2.ensure((size_t)NB * U * sizeof(double));
-    hipEvent_t e0 = ctx.aux_event(2);
-    HYP_CHECK(hipEventRecord(e0, ctx.stream));
-    HYP_CHECK(hipStreamWaitEvent(ctx.stream2, e0, 0));
-    int load[2] = {0, 0};
+    trsm_work2.ensure((size_t)NB * U * sizeof(double) * (size_t)std::max(1, nl - 1));
+    fork_lanes(ctx, nl);
+    std::vector<int> load(nl, 0);
     for (int k = 0; k < K; ++k) {
       const int Lk = Ls[k];
-      const int side = (load[1] < load[0]) ? 1 : 0;
+      int side = 0;
+      for (int i = 1; i < nl; ++i)
+        if (load[i] < load[side]) side = i;
       load[side] += (Lk + NB - 1) / NB;
-      auto chain = [&](double* work) {
-        if (!lam_dinv_ready) potrf_invert_diag_blocks(ctx, Lk, Lam[k].d(), Lk, 0, 1, LamDinv[k].d());
-        ctx.d2d(LFLP[k].p, PT[k].p, (size_t)U * Lk * sizeof(double));
-        trsm_upper_left(ctx, Lk, U, Lam[k].d(), Lk, LamDinv[k].d(), true, LFLP[k].d(), Lk, work);
-        col_dot(ctx, Lk, U, LFLP[k].d(), Lk, LFLP[k].d(), Lk, -1.0, false, gparts.d() + (long)k * U);
-        dev_transpose(ctx, Lk, U, LFLP[k].d(), Lk, LFLPT[k].d(), U, 1, 0, 0);
-      };
-      if (side == 1) {
-        StreamSwap on_helper(ctx);
-        chain(trsm_work2.d());
-      } else {
-        chain(trsm_work.d());
-      }
+      double* work = (side == 0) ? trsm_work.d() : trsm_work2.d() + (size_t)(side - 1) * NB * U;
+      LaneSwitch on_lane(ctx, side);
+      if (!lam_dinv_ready) potrf_invert_diag_blocks(ctx, Lk, Lam[k].d(), Lk, 0, 1, LamDinv[k].d());
+      ctx.d2d(LFLP[k].p, PT[k].p, (size_t)U * Lk * sizeof(double));
+      trsm_upper_left(ctx, Lk, U, Lam[k].d(), Lk, LamDinv[k].d(), true, LFLP[k].d(), Lk, work);
+      col_dot(ctx, Lk, U, LFLP[k].d(), Lk, LFLP[k].d(), Lk, -1.0, false, gparts.d() + (long)k * U);
+      dev_transpose(ctx, Lk, U, LFLP[k].d(), Lk, LFLPT[k].d(), U, 1, 0, 0);
     }
-    hipEvent_t e1 = ctx.aux_event(3);
-    HYP_CHECK(hipEventRecord(e1, ctx.stream2));
-    HYP_CHECK(hipStreamWaitEvent(ctx.stream, e1, 0));
+    join_lanes(ctx, nl);
     hipLaunchKernelGGL(sum_parts_kernel, dim3((U + 255) / 256), dim3(256), 0, ctx.stream, U, K, gparts.d(), grad.d());
     HYP_CHECK(hipGetLastError());
     lam_dinv_ready = true;
@@ -402,46 +397,30 @@ void WsosCone::lambda_of(int k, const double* d_dir) {   // LL_k = LFLP_k diag(d
 // the K Gram products of the gradient's LFLP_k (0.3 ms at U = 4845) -- not the U x U Hessian (1.2 ms), its Cholesky (3.4 ms),
 // the solve plan (0.65 ms) and the solves (0.4 ms) a candidate costs that far outside the neighbourhood.
 void WsosCone::gram_norms(const double* d_dir, double* d_out) {
-  hipEvent_t e0 = ctx.aux_event(2), e1 = ctx.aux_event(3);
-  HYP_CHECK(hipEventRecord(e0, ctx.stream));
-  HYP_CHECK(hipStreamWaitEvent(ctx.stream2, e0, 0));
+  const int nl = std::min(K, Ctx::max_lanes());
+  fork_lanes(ctx, nl);
   for (int k = 0; k < K; ++k) {
-    if (k & 1) {
-      StreamSwap on_helper(ctx);
-      lambda_of(k, d_dir);
-      dev_dot(ctx, Ls[k] * Ls[k], LL[k].d(), LL[k].d(), d_out + k);
-    } else {
-      lambda_of(k, d_dir);
-      dev_dot(ctx, Ls[k] * Ls[k], LL[k].d(), LL[k].d(), d_out + k);
-    }
+    LaneSwitch on_lane(ctx, k % nl);
+    lambda_of(k, d_dir);
+    dev_dot(ctx, Ls[k] * Ls[k], LL[k].d(), LL[k].d(), d_out + k);
   }
-  HYP_CHECK(hipEventRecord(e1, ctx.stream2));
-  HYP_CHECK(hipStreamWaitEvent(ctx.stream, e1, 0));
+  join_lanes(ctx, nl);
 }
 
 void WsosCone::hess_vec_from_LL(double* d_out) {   // :152-175 (the matrix-free Hessian product), partial sums per k as in update_grad
   gparts.ensure((size_t)K * U * sizeof(double));
-  hipEvent_t e0 = ctx.aux_event(2), e1 = ctx.aux_event(3);
-  HYP_CHECK(hipEventRecord(e0, ctx.stream));
-  HYP_CHECK(hipStreamWaitEvent(ctx.stream2, e0, 0));
+  const int nl = std::min(K, Ctx::max_lanes());
+  fork_lanes(ctx, nl);
   for (int k = 0; k < K; ++k) {
     const int Lk = Ls[k];
-    auto chain = [&] {
-      GemmArgs b{};   // LU = LL * LFLP  (L x U)
-      b.M = Lk; b.N = U; b.K = Lk; b.A = LL[k].d(); b.lda = Lk; b.B = LFLP[k].d(); b.ldb = Lk; b.C = LU[k].d(); b.ldc = Lk;
-      b.alpha = 1; b.beta = 0; b.batch = 1;
-      gemm(ctx, true, b);
-      col_dot(ctx, Lk, U, LFLP[k].d(), Lk, LU[k].d(), Lk, 1.0, false, gparts.d() + (long)k * U);
-    };
-    if (k & 1) {
-      StreamSwap on_helper(ctx);
-      chain();
-    } else {
-      chain();
-    }
+    LaneSwitch on_lane(ctx, k % nl);
+    GemmArgs b{};   // LU = LL * LFLP  (L x U)
+    b.M = Lk; b.N = U; b.K = Lk; b.A = LL[k].d(); b.lda = Lk; b.B = LFLP[k].d(); b.ldb = Lk; b.C = LU[k].d(); b.ldc = Lk;
+    b.alpha = 1; b.beta = 0; b.batch = 1;
+    gemm(ctx, true, b);
+    col_dot(ctx, Lk, U, LFLP[k].d(), Lk, LU[k].d(), Lk, 1.0, false, gparts.d() + (long)k * U);
   }
-  HYP_CHECK(hipEventRecord(e1, ctx.stream2));
-  HYP_CHECK(hipStreamWaitEvent(ctx.stream, e1, 0));
+  join_lanes(ctx, nl);
   hipLaunchKernelGGL(sum_parts_kernel, dim3((U + 255) / 256), dim3(256), 0, ctx.stream, U, K, gparts.d(), d_out);
   HYP_CHECK(hipGetLastError());
 }

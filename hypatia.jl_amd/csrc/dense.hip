@@ -77,6 +77,49 @@ hipEvent_t Ctx::aux_event(int i) {
   return aux[i];
 }
 
+// Measured at config 5 (U = 4845, K = 5 chains): 2 lanes 25.2 / 30.0 ms per iteration (primal / dual
+// form), 3 lanes 24.4 / 29.9, 4 to 6 lanes 31-34 / 36-40 -- the Gram products of the proximity bound (five split-K GEMMs of ~500
+// workgroups each) side by side on five queues cost 3 ms a time where they take 0.33 ms on two, although the same section is
+// harmless under rocprofv3 and in tools/probe_lanes.hip; the gradient's chains alone gain 0.1 ms from six lanes (their
+// triangular-solve kernels already fill the chip two at a time).  Hence three.
+int Ctx::max_lanes() {
+  static const int v = [] { const char* e = getenv("HYP_LANES"); const int x = e ? atoi(e) : 3; return std::min(8, std::max(2, x)); }();
+  return v;
+}
+
+Ctx::Lane& Ctx::lane(int i) {
+  while ((int)lanes.size() <= i) lanes.push_back(nullptr);
+  if (!lanes[i]) {
+    Lane* L = new Lane();
+    int plo = 0, phi = 0;
+    HYP_CHECK(hipDeviceGetStreamPriorityRange(&plo, &phi));
+    HYP_CHECK(hipStreamCreateWithPriority(&L->s, hipStreamNonBlocking, phi));
+    HYP_CHECK(hipEventCreateWithFlags(&L->done, hipEventDisableTiming));
+    lanes[i] = L;
+  }
+  return *lanes[i];
+}
+
+void fork_lanes(Ctx& c, int nlanes) {
+  hipEvent_t e0 = c.aux_event(2);
+  HYP_CHECK(hipEventRecord(e0, c.stream));
+  if (nlanes > 1) HYP_CHECK(hipStreamWaitEvent(c.stream2, e0, 0));
+  for (int i = 2; i < nlanes; ++i) HYP_CHECK(hipStreamWaitEvent(c.lane(i).s, e0, 0));
+}
+
+void join_lanes(Ctx& c, int nlanes) {
+  if (nlanes > 1) {
+    hipEvent_t e1 = c.aux_event(3);
+    HYP_CHECK(hipEventRecord(e1, c.stream2));
+    HYP_CHECK(hipStreamWaitEvent(c.stream, e1, 0));
+  }
+  for (int i = 2; i < nlanes; ++i) {
+    Ctx::Lane& L = c.lane(i);
+    HYP_CHECK(hipEventRecord(L.done, L.s));
+    HYP_CHECK(hipStreamWaitEvent(c.stream, L.done, 0));
+  }
+}
+
 hipEvent_t Ctx::pool_event(size_t i) {
   while (ev_pool.size() <= i) {
     hipEvent_t e;
@@ -1262,6 +1305,13 @@ Ctx::~Ctx() {
     if (e) (void)hipEventDestroy(e);
   gemm_scratch.release();
   gemm_scratch2.release();
+  for (Lane* L : lanes)
+    if (L) {
+      L->gs.release();
+      if (L->done) (void)hipEventDestroy(L->done);
+      if (L->s) (void)hipStreamDestroy(L->s);
+      delete L;
+    }
   if (stream2) (void)hipStreamDestroy(stream2);
   if (stream) (void)hipStreamDestroy(stream);
 }

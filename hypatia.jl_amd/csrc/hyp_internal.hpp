@@ -85,6 +85,12 @@ struct Ctx {
   hipEvent_t pool_event(size_t i);
   hipEvent_t aux[4] = {nullptr, nullptr, nullptr, nullptr};   // fork / join events of the two-stream sections (not the look-ahead pool)
   hipEvent_t aux_event(int i);
+  // Lanes 2, 3, ...: further streams, each with the per-stream scratch a launcher takes from the context, for sections made of
+  // SEVERAL independent latency-bound chains (the K bases of a WSOS cone): lane 0 is the main stream, lane 1 the helper stream.
+  struct Lane;
+  std::vector<Lane*> lanes;
+  Lane& lane(int i);
+  static int max_lanes();   // HYP_LANES (default 3; 2 = the two streams only)
   GemmScratch gemm_scratch;   // split-K workspace + syrk tile order of the GEMM launcher (per context, never shared)
   GemmScratch gemm_scratch2;  // the same for launches on the helper stream (StreamSwap)
   bool gemv_one = false;   // gemv(): one-right-hand-side products through the multi-column kernels (set by SysSolver::sgemv for its call)
@@ -141,6 +147,31 @@ struct StreamSwap {
   StreamSwap(const StreamSwap&) = delete;
   StreamSwap& operator=(const StreamSwap&) = delete;
 };
+
+struct Ctx::Lane {
+  hipStream_t s = nullptr;
+  GemmScratch gs;
+  DBuf tinv;
+  hipEvent_t done = nullptr;
+};
+
+// Run a section on lane i (0: where we are, 1: the helper stream, >= 2: a stream of its own); join_lanes makes the main stream wait
+// for everything queued on the lanes used since fork_lanes.
+struct LaneSwitch {
+  Ctx& c;
+  int i;
+  explicit LaneSwitch(Ctx& ctx, int lane) : c(ctx), i(lane) { flip(); }
+  ~LaneSwitch() { flip(); }
+  LaneSwitch(const LaneSwitch&) = delete;
+  LaneSwitch& operator=(const LaneSwitch&) = delete;
+ private:
+  void flip() {
+    if (i == 1) { std::swap(c.stream, c.stream2); std::swap(c.gemm_scratch, c.gemm_scratch2); std::swap(c.potrf_tinv, c.potrf_tinv2); }
+    else if (i >= 2) { Ctx::Lane& L = c.lane(i); std::swap(c.stream, L.s); std::swap(c.gemm_scratch, L.gs); std::swap(c.potrf_tinv, L.tinv); }
+  }
+};
+void fork_lanes(Ctx& c, int nlanes);   // lanes 1 .. nlanes - 1 wait for what is queued on the main stream now
+void join_lanes(Ctx& c, int nlanes);   // the main stream waits for lanes 1 .. nlanes - 1
 
 // ---------------------------------------------------------------------------------------------
 // dense.hip : factorizations, triangular solves, level-1/2 kernels (all on ctx.stream, device ptrs)

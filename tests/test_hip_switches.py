@@ -87,6 +87,17 @@ def test_side_by_side_candidate_evaluation_matches_sequential(name, switch):
     assert abs(on["obj"] - off["obj"]) <= 1e-6 * (1 + abs(off["obj"]))
 
 
+@pytest.mark.parametrize("name", ["polymin_primal", "polymin_large_primal", "polymin_large_dual"])
+def test_one_lane_per_wsos_chain_changes_no_bit(name):
+    """HYP_LANES (round 4, default 3): the K independent chains of a WSOS cone's gradient, of the proximity bound's Gram products and of
+    its Hessian-vector product each run on a stream of their own instead of two streams; a chain's kernels and partial results do
+    not depend on where it runs."""
+    many = _run(name, {"HYP_LANES": "6"})
+    two = _run(name, {"HYP_LANES": "2"})
+    assert many["status"] == two["status"] == "Optimal"
+    assert many["trace"] == two["trace"] and many["trials"] == two["trials"]
+
+
 @pytest.mark.parametrize("name", ["psd_single", "psd_pair", "matrixcompletion", "polymin_dual"])
 def test_constant_column_as_third_column_solves_the_same_problem(name):
     """HYP_CONST_COL3 (on by default since round 3): the constant column of update_lhs rides along with the
