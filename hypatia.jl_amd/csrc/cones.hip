@@ -391,6 +391,7 @@ void PsdCone::two_sided(const double* R, int kr2, int kr3, double* prod, long ld
   const long ws_cap = 1L << 27;   // doubles per workspace (1 GiB)
   int chunk = (int)std::min<long>(ncols, std::max<long>(1, ws_cap / s2));
   const bool fused = use_fused(ncols);
+  if (fused && kr2 == KR_LE_N && psd_two_sided_onchip(ctx, side, ncols, R, 1, arr, lda, prod, ldp)) return;   // (no workspace, no chunks)
   // HYP_TS_CHUNK_MB: the two passes of the fused product run chunk by chunk with the intermediate Z of a chunk held to that
   // many MB (A/B switch: does pass 2 find Z in the 256 MB Infinity Cache?)
   static const long z_mb = [] { const char* e = getenv("HYP_TS_CHUNK_MB"); return e ? atol(e) : 0L; }();

@@ -11,6 +11,8 @@ namespace hyp {
 
 // psd_twosided.hip: prod[:, j] = svec(R' smat(arr[:, j]) R) with the svec conversions fused (side <= 208)
 bool psd_two_sided_fused_ok(int side);
+// one workgroup per matrix, the intermediate product in registers (psd_twosided4.hip); false: not applicable, nothing done
+bool psd_two_sided_onchip(Ctx& c, int side, int ncols, const double* R, int rstruct, const double* arr, long lda, double* prod, long ldp);
 void psd_two_sided_fused(Ctx& c, int side, int ncols, const double* R, int rstruct /* 0 full, 1 upper, 2 lower */, const double* arr,
                          long lda, double* prod, long ldp, double* zws /* ncols * side^2 */);
 

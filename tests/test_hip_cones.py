@@ -117,6 +117,37 @@ def test_psd_two_sided_products_sides_beyond_96(side, ncols):
         assert np.all(out_h[0] == 7.0) and np.all(out_h[1 + dim:] == 7.0)
 
 
+@pytest.mark.parametrize("side,ncols", [(129, 193), (144, 200), (160, 260), (161, 200), (177, 333), (192, 200), (200, 517), (207, 200), (208, 257)])
+def test_psd_sqrt_hess_prod_on_chip_form(side, ncols):
+    """round 4: sqrt_hess_prod on >= 192 columns at sides of 9 .. 13 MFMA tiles goes through psd_ts4_kernel (the intermediate product
+    in accumulator registers, one workgroup per matrix and column set: csrc/psd_twosided4.hip); every tile count, sides on and off
+    the tile edge, more matrices than workgroups (517 > 256) and strided column views, against the oracle's product
+    (possemideftri.jl:161-177)"""
+    dim = side * (side + 1) // 2
+    hc, oc = _pair("psd", dim)
+    rng = np.random.default_rng(side + ncols)
+    for c in (hc, oc):
+        c.setup_data()
+    pt = np.zeros(dim)
+    oc.set_initial_point(pt)
+    pt += 0.1 * (2 * rng.random(dim) - 1) / np.sqrt(max(1, dim / 50))
+    for c in (hc, oc):
+        c.reset_data()
+        c.load_point(pt, 1.3)
+        assert c.is_feas()
+        c.get_grad()
+    big_in = np.asfortranarray(rng.standard_normal((dim + 3, ncols)))
+    out_h = np.full((dim + 2, ncols), 7.0, order="F")
+    out_o = np.full((dim + 2, ncols), 7.0, order="F")
+    hc.sqrt_hess_prod(out_h[1:1 + dim, :], big_in[2:2 + dim, :])
+    oc.sqrt_hess_prod(out_o[1:1 + dim, :], big_in[2:2 + dim, :])
+    assert rel(out_h, out_o) < TOL * 10
+    assert np.all(out_h[0] == 7.0) and np.all(out_h[1 + dim:] == 7.0)
+    # column by column as well: the worst column, not only the Frobenius norm of the block
+    err = np.max(np.linalg.norm(out_h[1:1 + dim] - out_o[1:1 + dim], axis=0) / np.linalg.norm(out_o[1:1 + dim], axis=0))
+    assert err < TOL * 10
+
+
 def test_infeasible_points_detected():
     import hypatia_jl_amd as H
     c = H.PosSemidefTri(6)

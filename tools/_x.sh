@@ -1,5 +1,6 @@
 #!/bin/bash
 # scratch for one-off gpurun calls (`gpurun --timeout N -- 'bash tools/_x.sh'`); the round's standard batch is tools/_run_gpu.sh
 cd /root/repo; export TMPDIR=/tmp
-for v in "HYP_LANES_MASK=1" "HYP_LANES_MASK=2" "HYP_LANES_MASK=4" "HYP_LANES_MASK=0"; do for c in 5p; do echo "== $c $v"; env HYP_LANES=6 $v python bench.py --config $c --cpu-iters 0 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],2), d['steps'], d['config']['final_status'], {k:round(v,2) for k,v in d['phases_ms_per_step'].items()})"; done; done
+for v in "HYP_TS4=1" "HYP_TS4=0" "HYP_TS4=1"; do echo "== $v"; env $v python bench.py --cpu-iters 0 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],3), d['steps'], d['roofline']['frac'], {k:round(v,2) for k,v in d['phases_ms_per_step'].items()}, round(d['kkt_solves_per_step'],2))"; done
+timeout 1500 python -m pytest tests/test_hip_fullsize_trajectory.py tests/test_hip_fullsize.py -m gpu -q -x -k "psdfull or fullsize" 2>&1 | tail -4
