@@ -100,25 +100,28 @@ __device__ __forceinline__ void ts4_wave(const Ts4Args& p, double* __restrict__ 
 
   // (V's K slice and R's row slice are only read by the first product, i.e. while t <= SET_MAX)
 // (index clamps only where a tile meets the edge -- the last tile row / K block; 24-bit multiplies: every index is below 2^15)
+// (32-bit BYTE offsets from a uniform base: the form global_load takes as scalar base + vector offset -- with element indices the
+//  compiler built a 64-bit address per load, two 64-bit vector operations each, and vector operations wait for the FP64 MFMAs)
 #define TS4_TRI(v) (__umul24((unsigned)(v), (unsigned)(v) + 1u) >> 1)
+#define TS4_AT(BASE, IDX) (*reinterpret_cast<const double*>(reinterpret_cast<const char*>(BASE) + (size_t)(unsigned)((IDX) * 8u)))
 #define TS4_LOAD_REP(AJ, TT, rep)                                                                                           \
   {                                                                                                                         \
     if ((rep) < (TT)) { /* m = 16 rep + x above the K block: vec[k (k + 1) / 2 + m], k = 16 t + y */                         \
       const int k = ((TT) == T - 1) ? min(16 * (TT) + y, sm1) : 16 * (TT) + y;                                              \
-      if ((TT) <= SET_MAX) vst[rep] = (AJ)[TS4_TRI(k) + (unsigned)(16 * (rep) + x)];                                        \
-      rst[rep] = Rp[(unsigned)((16 * (TT) + y) * LD + 16 * (rep) + x)]; /* column slice: R[16 rep + x, 16 t + y] */          \
+      if ((TT) <= SET_MAX) vst[rep] = TS4_AT(AJ, TS4_TRI(k) + (unsigned)(16 * (rep) + x));                                  \
+      rst[rep] = TS4_AT(Rp, (unsigned)((16 * (TT) + y) * LD + 16 * (rep) + x)); /* column slice: R[16 rep + x, 16 t + y] */  \
     } else if ((rep) > (TT)) { /* m = 16 rep + y below: vec[m (m + 1) / 2 + k], k = 16 t + x */                              \
       const int m = ((rep) == T - 1) ? min(16 * (rep) + y, sm1) : 16 * (rep) + y;                                           \
       if ((TT) <= SET_MAX) {                                                                                                \
-        vst[rep] = (AJ)[TS4_TRI(m) + (unsigned)(16 * (TT) + x)];                                                            \
-        rst[rep] = Rp[(unsigned)((16 * (rep) + y) * LD + 16 * (TT) + x)]; /* row slice: R[16 t + x, 16 rep + y] */           \
+        vst[rep] = TS4_AT(AJ, TS4_TRI(m) + (unsigned)(16 * (TT) + x));                                                      \
+        rst[rep] = TS4_AT(Rp, (unsigned)((16 * (rep) + y) * LD + 16 * (TT) + x)); /* row slice: R[16 t + x, 16 rep + y] */   \
       }                                                                                                                     \
     } else {                                                                                                                \
       const int m = ((TT) == T - 1) ? min(16 * (TT) + y, sm1) : 16 * (TT) + y;                                              \
       const int k = ((TT) == T - 1) ? min(16 * (TT) + x, sm1) : 16 * (TT) + x;                                              \
       const int lo = min(m, k), hi = max(m, k);                                                                             \
-      if ((TT) <= SET_MAX) vst[rep] = (AJ)[TS4_TRI(hi) + (unsigned)lo];                                                     \
-      rst[rep] = Rp[(unsigned)((16 * (TT) + y) * LD + 16 * (TT) + x)]; /* the diagonal block: member of both slices */       \
+      if ((TT) <= SET_MAX) vst[rep] = TS4_AT(AJ, TS4_TRI(hi) + (unsigned)lo);                                               \
+      rst[rep] = TS4_AT(Rp, (unsigned)((16 * (TT) + y) * LD + 16 * (TT) + x)); /* the diagonal block: member of both slices */ \
     }                                                                                                                       \
   }
 #define TS4_LOAD_STAGE(JJ, TT)                                                                                              \
@@ -294,7 +297,8 @@ __device__ __forceinline__ void ts4_wave(const Ts4Args& p, double* __restrict__ 
             const int col = 16 * t + fq + 4 * r;
             if (row <= col && col < s) {
               const double v = Y[ci][0][r] + Y[ci][1][r];
-              Cj[(long)col * (col + 1) / 2 + row] = (row == col) ? v : v * 1.4142135623730951;   // mat[i, j] * rt2 (arrayutilities.jl:176)
+              *reinterpret_cast<double*>(reinterpret_cast<char*>(Cj) + (size_t)(unsigned)((TS4_TRI(col) + (unsigned)row) * 8u)) =
+                  (row == col) ? v : v * 1.4142135623730951;   // mat[i, j] * rt2 (arrayutilities.jl:176)
             }
           }
         }
@@ -310,6 +314,7 @@ __device__ __forceinline__ void ts4_wave(const Ts4Args& p, double* __restrict__ 
 #undef TS4_STAMP
 #undef TS4_LOAD_STAGE
 #undef TS4_LOAD_REP
+#undef TS4_AT
 #undef TS4_TRI
 }
 
