@@ -24,6 +24,6 @@ python tools/bench_potrf.py > gpurun_out/bench_potrf.txt 2>&1; cat gpurun_out/be
 # PMC passes: one counter group per run, kernel trace only (no other trace domains)
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   tag=$(echo $grp | cut -d' ' -f1); rm -rf /tmp/pmc_$tag
-  rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex "gemm_f64_kernel<true, 4, 1>|psd_ts3_kernel|psd_ts_kernel|splitk_reduce" -d /tmp/pmc_$tag -o b -- python bench.py --steps 2 --warmup 1 --cpu-iters 0 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex "gemm_f64_kernel<true, 4, 1>|psd_ts4_kernel|psd_ts3_kernel|psd_ts_kernel|splitk_reduce" -d /tmp/pmc_$tag -o b -- python bench.py --steps 2 --warmup 1 --cpu-iters 0 > /dev/null 2>&1
   python tools/rocpd_pmc.py $(find /tmp/pmc_$tag -name "*.db" | head -1) > gpurun_out/pmc_$tag.txt 2>&1; head -12 gpurun_out/pmc_$tag.txt
 done
