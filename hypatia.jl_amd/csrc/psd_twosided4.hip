@@ -287,19 +287,26 @@ __device__ __forceinline__ void ts4_wave(const Ts4Args& p, double* __restrict__ 
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        // register r of a result tile: column c = 16 t + fq + 4 r of W, row 16 a + fj
+        // register r of a result tile: column c = 16 t + fq + 4 r of W, row 16 a + fj.  Only the diagonal tile (a = t) has entries
+        // below the diagonal to skip and diagonal entries to leave unscaled, only the last tile column can pass the edge: everywhere
+        // else the stores are unconditional (vector instructions between the MFMAs are MFMA time lost)
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci) {
           if (!p2[ci]) continue;
           const int row = 16 * AC[ci] + fj;
+          const int col0 = 16 * t + fq;
+          unsigned off = (TS4_TRI(col0) + (unsigned)row) * 8u;   // tri(c + 4) = tri(c) + 4 c + 10
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int col = 16 * t + fq + 4 * r;
-            if (row <= col && col < s) {
-              const double v = Y[ci][0][r] + Y[ci][1][r];
-              *reinterpret_cast<double*>(reinterpret_cast<char*>(Cj) + (size_t)(unsigned)((TS4_TRI(col) + (unsigned)row) * 8u)) =
-                  (row == col) ? v : v * 1.4142135623730951;   // mat[i, j] * rt2 (arrayutilities.jl:176)
+            const int col = col0 + 4 * r;
+            const double v = Y[ci][0][r] + Y[ci][1][r];
+            double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(Cj) + (size_t)off);
+            if (AC[ci] == t) {
+              if (row <= col && (t < T - 1 || col < s)) *dst = (row == col) ? v : v * 1.4142135623730951;   // mat[i, j] * rt2 (arrayutilities.jl:176)
+            } else {
+              if (t < T - 1 || col < s) *dst = v * 1.4142135623730951;
             }
+            off += (unsigned)(4 * col + 10) * 8u;
           }
         }
       }
