@@ -1,6 +1,4 @@
 #!/bin/bash
 # scratch for one-off gpurun calls (`gpurun --timeout N -- 'bash tools/_x.sh'`); the round's standard batch is tools/_run_gpu.sh
 cd /root/repo; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_hip_cones.py -m gpu -q -x -k "on_chip" 2>&1 | tail -3
-HYP_TS4_PROBE=1 python tools/bench_psd_ts.py 200 5000 1 2>&1 | tail -9 | cut -c1-250
-for v in "HYP_TS4=1"; do rm -rf /tmp/p4; env $v rocprofv3 --kernel-trace --stats -d /tmp/p4 -o b -- python tools/bench_psd_ts.py 200 5000 3 > /dev/null 2>&1; echo "== $v"; python tools/rocpd_stats.py $(find /tmp/p4 -name "*.db" | head -1) 2>/dev/null | grep -i "psd_ts" | cut -c1-150; done
+for f in 0 8 16 32 48 64 96; do echo "== HYP_POTRF_FREE_CUS=$f"; HYP_POTRF_FREE_CUS=$f python tools/bench_potrf.py 5000 4845 2250 2>&1 | tail -3; done
