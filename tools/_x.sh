@@ -1,4 +1,6 @@
 #!/bin/bash
 # scratch for one-off gpurun calls (`gpurun --timeout N -- 'bash tools/_x.sh'`); the round's standard batch is tools/_run_gpu.sh
 cd /root/repo; export TMPDIR=/tmp
-for f in 0 8 16 32 48 64 96; do echo "== HYP_POTRF_FREE_CUS=$f"; HYP_POTRF_FREE_CUS=$f python tools/bench_potrf.py 5000 4845 2250 2>&1 | tail -3; done
+HYP_TS4_PROBE=1 python tools/bench_psd_ts.py 200 5000 1 2>&1 | grep probe | cut -c1-260 > gpurun_out/ts4_probe8.txt
+rm -rf /tmp/p4; rocprofv3 --kernel-trace --stats -d /tmp/p4 -o b -- python tools/bench_psd_ts.py 200 5000 3 > /dev/null 2>&1; python tools/rocpd_stats.py $(find /tmp/p4 -name "*.db" | head -1) 2>/dev/null | grep -i "psd_ts" | cut -c1-150 >> gpurun_out/ts4_probe8.txt
+cat gpurun_out/ts4_probe8.txt
