@@ -530,6 +530,20 @@ def run_headline(args, world, rank, local_rank, multi, comm=None):
                              "search_per_step": solver.time_search / args.steps},
     }
 
+    # the other two MFMA-bound kernels of update_lhs_fact, by the same rule (algorithmic flops of SURVEY 8d over the HIP-event time of the
+    # phase inside the timed region): the PSD cone's two-sided product on the q x n block (side^3 (1 + 2/3) flop per column: a
+    # triangular factor on both sides, the upper triangle of the result) and the Cholesky of the Schur matrix (n^3 / 3)
+    if args.config == "2" and comm is None and ks[0] > 0 and ks[2] > 0:
+        ts_flops = (5.0 / 3.0) * float(args.side) ** 3 * args.n
+        ts_ms, ch_ms = ks[0] / args.steps, ks[2] / args.steps
+        out["roofline_sqrt_hess_prod"] = {"bound": "mfma", "kernel": "psd_ts4_kernel (U^-T V U^-1 on the %d columns of G; sides 129 .. 208, else the two-pass kernels)" % args.n,
+                                          "achieved": ts_flops / ts_ms / 1e9, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": ts_flops / ts_ms / 1e9 / FP64_MFMA_PEAK_TFLOPS, "launch_ms": ts_ms, "flops_per_launch": ts_flops}
+        ch_flops = float(args.n) ** 3 / 3.0
+        out["roofline_cholesky"] = {"bound": "latency (39 dependent block steps; DESIGN.md section 5)", "kernel": "potrf_tiles4_kernel + potrf_panel_mfma_kernel + look-ahead GEMMs",
+                                    "achieved": ch_flops / ch_ms / 1e9, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": ch_flops / ch_ms / 1e9 / FP64_MFMA_PEAK_TFLOPS, "launch_ms": ch_ms, "flops_per_launch": ch_flops}
+
     # the HBM-bound part of the path: the passes over the resident G that every KKT solve is made of
     # (qrchol.jl:51-53, 71-73), timed with HIP events after the timed region; algorithmic bytes per pass = q * n * 8
     try:

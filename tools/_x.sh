@@ -1,7 +1,6 @@
 #!/bin/bash
 # scratch for one-off gpurun calls (`gpurun --timeout N -- 'bash tools/_x.sh'`); the round's standard batch is tools/_run_gpu.sh
 cd /root/repo; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_hip_cones.py -m gpu -q -x -k "on_chip" 2>&1 | tail -3
-HYP_TS4_PROBE=1 python tools/bench_psd_ts.py 200 5000 1 2>&1 | grep probe | cut -c1-260 > gpurun_out/ts4_probe_db.txt
-rm -rf /tmp/p4; rocprofv3 --kernel-trace --stats -d /tmp/p4 -o b -- python tools/bench_psd_ts.py 200 5000 3 > /dev/null 2>&1; python tools/rocpd_stats.py $(find /tmp/p4 -name "*.db" | head -1) 2>/dev/null | grep -i "psd_ts" | cut -c1-150 >> gpurun_out/ts4_probe_db.txt
-cat gpurun_out/ts4_probe_db.txt
+python bench.py > gpurun_out/bench_cfg2_1gpu.json 2> gpurun_out/bench_cfg2_1gpu.err; python -c "
+import json; d=json.loads(open('gpurun_out/bench_cfg2_1gpu.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline_sqrt_hess_prod'], d['roofline_cholesky'], d['cpu_baseline']['value'])"
+python -m pytest tests/test_hip_distributed.py -m gpu -q -x -k "bench" 2>&1 | tail -2
