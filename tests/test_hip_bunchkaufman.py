@@ -201,7 +201,7 @@ def _late_failure_matrix(n, nbad, rng, cond=1e8):
     return 0.5 * (Ab + Ab.T)
 
 
-@pytest.mark.parametrize("n,nbad", [(300, 3), (700, 5), (1153, 1), (1153, 40), (2250, 2), (200, 4), (640, 1)])
+@pytest.mark.parametrize("n,nbad", [(300, 3), (700, 5), (1153, 1), (1153, 40), (2250, 2), (200, 4), (640, 1), (256, 128), (384, 129), (385, 1), (129, 1)])
 def test_hybrid_factorization_behind_a_late_cholesky_failure(hip, n, nbad):
     """round 4: behind a failed Cholesky the block steps in front of the failing pivot's block are kept and only the trailing block
     goes through the rook-pivoted elimination (BKFact::factor_from).  Against numpy's solve: LAPACK's backward error; bk_start says

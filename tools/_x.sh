@@ -1,6 +1,5 @@
 #!/bin/bash
 # scratch for one-off gpurun calls (`gpurun --timeout N -- 'bash tools/_x.sh'`); the round's standard batch is tools/_run_gpu.sh
 cd /root/repo; export TMPDIR=/tmp
-python bench.py > gpurun_out/bench_cfg2_1gpu.json 2> gpurun_out/bench_cfg2_1gpu.err; python -c "
-import json; d=json.loads(open('gpurun_out/bench_cfg2_1gpu.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline_sqrt_hess_prod'], d['roofline_cholesky'], d['cpu_baseline']['value'])"
-python -m pytest tests/test_hip_distributed.py -m gpu -q -x -k "bench" 2>&1 | tail -2
+python -m pytest tests/test_hip_bunchkaufman.py -m gpu -q -x 2>&1 | tail -3
+for v in "HYP_POTRF_LOOKAHEAD=1" "HYP_POTRF_LOOKAHEAD=0" "HYP_POTRF_LA_MIN=2560" "HYP_POTRF_LA_MIN=3584" "HYP_POTRF_LA_MIN=768" "HYP_POTRF_TRAIL_TILE=128" "HYP_POTRF_TRAIL_TILE=0"; do echo "== $v"; env $v python tools/bench_potrf.py 5000 2>&1 | tail -1; done
