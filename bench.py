@@ -63,7 +63,7 @@ def blas_threads(want):
 
 def algorithm_record():
     """which route through the library a bench line timed: the switches are read from the environment by the
-    library itself, once per process; the defaults leave the reference's ORDER of operations in three places"""
+    library itself, once per process; the defaults leave the reference's ORDER of operations in four places"""
     on = lambda name: os.environ.get(name, "1")[:1] != "0"
     return {"ens_closed_form_inverse": on("HYP_ENS_CLOSED_INV"), "prox_lower_bound": on("HYP_PROX_LB"),
             "side_by_side_candidate_evaluation": on("HYP_ENS_PREFETCH") and on("HYP_WSOS_PAR"),
@@ -72,7 +72,9 @@ def algorithm_record():
             "line_search_candidate_screen": on("HYP_SEARCH_SCREEN") and on("HYP_PROX_LB"),
             "triangular_solve_refinement_steps": int(os.environ.get("HYP_TRSM_REFINE", "2")),
             # (the candidate screen needs the proximity bound: off with HYP_PROX_LB=0)
-            "reference_route": not (on("HYP_ENS_CLOSED_INV") or on("HYP_PROX_LB") or on("HYP_ENS_PREFETCH") or on("HYP_WSOS_PAR"))}
+            # behind a failed Cholesky: the rook-pivoted elimination only from the failing pivot's block on (round 4; 0: the whole matrix)
+            "fallback_keeps_cholesky_blocks": on("HYP_BK_HYBRID"),
+            "reference_route": not (on("HYP_ENS_CLOSED_INV") or on("HYP_PROX_LB") or on("HYP_ENS_PREFETCH") or on("HYP_WSOS_PAR") or on("HYP_BK_HYBRID"))}
 
 
 def pmc_traffic(n, q):

@@ -34,6 +34,7 @@ CASES = {
     "cfg4_5000_80x64_1": ({"iter_limit": 2}, 1, {"iter_limit": 2}, (1, 2)),   # config 4 as benchmarked, first two iterations
     "cfg5p_1": ({"iter_limit": 2}, 1, {"iter_limit": 2}, ()),              # config 5, U = 4845, primal form (n = 1)
     "cfg5d_1": ({"iter_limit": 2}, 1, {"iter_limit": 2}, (1,)),            # dual form: 4844 x 4844 Schur matrix
+    "cfg5pw_1": ({}, 1, {}, ()),                                           # config 5 primal, the WHOLE solve (46 iterations: the last dozen meet Hessians whose Cholesky fails)
 }
 
 
@@ -62,7 +63,7 @@ def main(names):
                "rows": o["rows"].tolist(), "perturbed_rows": [p["rows"].tolist() for p in ps],
                "gate_decades": [None if not np.isfinite(g) else round(float(g), 3) for g in o["gate"]],
                "probe_iters": list(probe_iters), "n": int(len(inst[0])), "p": int(len(inst[2])), "q": int(len(inst[4]))}
-        if name.startswith("cfg5") and keep is not None:
+        if name.startswith("cfg5") and keep is not None and not name.startswith(("cfg5pw", "cfg5dw")):
             rec["interp_keep"] = [int(v) for v in keep]
         out["cases"][name] = rec
         for it, pr in o["probes"].items():

@@ -19,7 +19,7 @@ if ROOT not in sys.path:
 COLS = ("p_obj", "d_obj", "gap", "x_feas", "z_feas", "tau", "kap", "mu", "alpha")
 
 # route = the switches that take the device path off the reference's order of operations
-REFERENCE_ROUTE = {"HYP_ENS_CLOSED_INV": "0", "HYP_PROX_LB": "0", "HYP_ENS_PREFETCH": "0", "HYP_WSOS_PAR": "0"}
+REFERENCE_ROUTE = {"HYP_ENS_CLOSED_INV": "0", "HYP_PROX_LB": "0", "HYP_ENS_PREFETCH": "0", "HYP_WSOS_PAR": "0", "HYP_BK_HYBRID": "0"}
 DEFAULT_ROUTE = {}
 
 
@@ -57,9 +57,9 @@ def _wsos_spec(nvars, halfdeg, use_dual):
     return ("wsosinterpnonnegative", U, Ps, use_dual)
 
 
-def _golden_keep(name):
+def _golden_keep(name, force=False):
     """the interpolation-point choice a committed trajectory was computed with (None: not recorded / not needed)"""
-    if os.environ.get("HYP_GOLDEN_REGEN"):
+    if os.environ.get("HYP_GOLDEN_REGEN") and not force:
         return None
     for fn in ("trajectory_wsos.json", "trajectory_fullsize.json"):
         f = os.path.join(ROOT, "tests", "golden", fn)
@@ -74,7 +74,7 @@ def fullsize_instance(name):
     """the BASELINE.json configurations AS BENCHMARKED (bench.py's generators) and mid sizes on the same generator:
       psdfull_<n>_<side>x<count>_<seed>   bench.gen_instance(n, [side] * count, seed): config 2 is psdfull_5000_200x1_1
       cfg4_<n>_<side>x<count>_<seed>      bench.gen_block per cone (config 4 = cfg4_5000_80x64_1: G = 8.3 GB)
-      cfg5p_<seed> / cfg5d_<seed>         bench.gen_polymin5 (U = 4845), primal / dual form"""
+      cfg5p_<seed> / cfg5d_<seed>         bench.gen_polymin5 (U = 4845), primal / dual form (cfg5pw_ / cfg5dw_: the same, whole solves)"""
     import bench
     kind, rest = name.split("_", 1)
     if kind == "psdfull":
@@ -99,6 +99,8 @@ def fullsize_instance(name):
         return (c, np.zeros((0, n)), np.zeros(0), G, h, [("possemideftri", dim)] * count, dict(status="Optimal"))
     if kind in ("cfg5p", "cfg5d"):
         return bench.gen_polymin5(kind == "cfg5p", int(rest), keep=_golden_keep(name))[0]
+    if kind in ("cfg5pw", "cfg5dw"):   # the SAME instances as cfg5p_<seed> / cfg5d_<seed> (their interpolation points), solved to the end
+        return bench.gen_polymin5(kind == "cfg5pw", int(rest), keep=_golden_keep(kind[:-1] + "_" + rest, force=True))[0]
     raise KeyError(name)
 
 
@@ -106,7 +108,7 @@ def instance(name):
     """named instances of the trajectory tests: matrix completion (examples/matrixcompletion/native.jl:23-70), polymin in both
     forms (examples/polymin/native.jl:56-90), the reference's own EpiNormSpectral / WSOS known-answer instances, mixed models"""
     from oracle import instances as I
-    if name.split("_")[0] in ("psdfull", "cfg4", "cfg5p", "cfg5d"):
+    if name.split("_")[0] in ("psdfull", "cfg4", "cfg5p", "cfg5d", "cfg5pw", "cfg5dw"):
         return fullsize_instance(name)
     if name.startswith("mc_"):                      # mc_<d1>x<d2>_<seed>
         dd, seed = name[3:].split("_")
