@@ -95,6 +95,19 @@ struct Cone {
   // The same idea one step earlier, for cones whose feasibility tests themselves are expensive: called right after a candidate
   // is loaded, before prefetch_feas; true = the candidate is certainly rejected (primal infeasible, or the proximity bound).
   virtual bool early_reject(double irtmu, double bound2) { (void)irtmu; (void)bound2; return false; }
+  // Several candidates of the line search at once (a model of ONE large cone whose rejected candidates are chains of short
+  // launches: WsosCone, wsos_screen.hip).  screen_max(): candidates per batch the cone can take (0: no screen);
+  // screen_ready(): the state the screen needs is there (a Cholesky factor of an earlier Hessian);
+  // screen_batch(): h_pts (C x dim, HOST, already scaled as load_point scales them), h_duals (C x dim, host), irtmu[C];
+  // reject[c] = 1 iff candidate c is certainly rejected by check_cone_points' cone tests (infeasible, or a rigorous lower bound of
+  // its proximity value exceeds `limit`); n_infeas counts the first kind; bounds[c] = the lower bound where one was formed, else
+  // a negative number.  false: nothing was evaluated.
+  virtual int screen_max() const { return 0; }
+  virtual bool screen_ready() { return false; }
+  virtual bool screen_batch(int C, const double* h_pts, const double* h_duals, const double* irtmu, double limit, char* reject, int* n_infeas, double* bounds) {
+    (void)C; (void)h_pts; (void)h_duals; (void)irtmu; (void)limit; (void)reject; (void)n_infeas; (void)bounds;
+    return false;
+  }
   bool prox_launch(double irtmu, double* d_out3);
   // false when inv_hess_prod has no usable factorization at this point (generic cones whose explicit
   // Hessian fails both its Cholesky and its Bunch-Kaufman factorization, Cones.jl:239-251: the
@@ -248,6 +261,11 @@ struct WsosCone : GenericHessCone {   // src/Cones/wsosinterpnonnegative.jl (rea
   void gram_norms(const double* d_dir, double* d_out);     // d_out[k] = || LFLP_k diag(dir) LFLP_k' ||_F^2 (LL[k] left in place), both streams
   void hess_vec_from_LL(double* d_out);                    // H dir from the LL[k] of the last gram_norms(dir): sum_k diag(LFLP_k' LL_k LFLP_k)
   DBuf lbP, lbHP, lbR;
+  // candidate screen (wsos_screen.hip)
+  DBuf scrSP, scrLF, scrLFT, scrLam, scrLL, scrDinv, scrVec, scrInfo;
+  int screen_max() const override;
+  bool screen_ready() override;
+  bool screen_batch(int C, const double* h_pts, const double* h_duals, const double* irtmu, double limit, char* reject, int* n_infeas, double* bounds) override;
 };
 
 struct LmiCone : GenericHessCone {   // src/Cones/linmatrixineq.jl (real dense symmetric members; complex Hermitian members embedded)

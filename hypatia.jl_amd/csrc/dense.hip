@@ -779,6 +779,99 @@ void trsm_upper_left(Ctx& c, int n, int nrhs, const double* U, long ldu, const d
   }
 }
 
+// The forward solve X_b <- U_b'^-1 X_b for a BATCH of factors of one size (the candidate screen of a WSOS cone, wsos_screen.hip:
+// the same bases under several candidate points): the kernels of trsm_upper_left with the batch member in blockIdx.y / the GEMM's
+// batch dimension.  U_b = U + b strideU, dinv_b = dinv + b strideD, X_b = X + b strideX.
+// (the steps of tdr_body for TDR_CH consecutive groups of 16 columns per workgroup, the two operand blocks loaded ONCE for them:
+//  with a batch of factors every launch is (columns / 16) x batch workgroups, each fetching both 128 x 128 blocks for 16 columns --
+//  bound by that traffic at 18 TFLOP/s, profiles/r04_wsos_screen.txt)
+constexpr int TDR_CH = 4;
+__global__ __launch_bounds__(256) void trsm_diag_refined_fwd_batched_kernel(const double* __restrict__ Tb, long ldt, long strideT,
+                                                                            const double* __restrict__ dinv_b, long strideD, int nb,
+                                                                            double* __restrict__ Xb, long ldx, long strideX, int nrhs, int refine) {
+  __shared__ __attribute__((aligned(16))) double Ys[NB * 16];
+  __shared__ __attribute__((aligned(16))) double Xs[NB * 16];
+  __shared__ __attribute__((aligned(16))) double Rs[NB * 16];
+  const long b = blockIdx.y;
+  const double* __restrict__ T = Tb + b * strideT;
+  const double* __restrict__ dinv_blk = dinv_b + b * strideD;
+  double* __restrict__ X = Xb + b * strideX;
+  constexpr bool LOWER = true;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const double* Dop = dinv_blk + (long)NB * NB;
+  double dop[TDR_STEPS], top[TDR_STEPS];
+  tdr_load<true, LOWER>(Dop, NB, nb, wv, dop);
+  tdr_load<false, LOWER>(T, ldt, nb, wv, top);
+  tdr_mask<LOWER>(nb, wv, 1.0, dop);
+  tdr_mask<LOWER>(nb, wv, -1.0, top);
+  const int rowA = 16 * wv + lq, rowB = 16 * (7 - wv) + lq;
+  for (int ch = 0; ch < TDR_CH; ++ch) {
+    const int c0 = (blockIdx.x * TDR_CH + ch) * 16;
+    if (c0 >= nrhs) break;
+    for (int e = tid; e < NB * 16; e += 256) {
+      const int k = e & (NB - 1), c = e >> 7;
+      Ys[k * 16 + c] = (k < nb && c0 + c < nrhs) ? X[(long)(c0 + c) * ldx + k] : 0.0;
+    }
+    __syncthreads();
+    d4_t xA = (d4_t){0.0, 0.0, 0.0, 0.0}, xB = (d4_t){0.0, 0.0, 0.0, 0.0};
+    tdr_product<LOWER>(dop, nb, wv, Ys, xA, xB);
+    for (int it = 0; it < refine; ++it) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        Xs[(rowA + 4 * g) * 16 + li] = xA[g];
+        Xs[(rowB + 4 * g) * 16 + li] = xB[g];
+      }
+      __syncthreads();
+      d4_t rA, rB;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        rA[g] = Ys[(rowA + 4 * g) * 16 + li];
+        rB[g] = Ys[(rowB + 4 * g) * 16 + li];
+      }
+      tdr_product<LOWER>(top, nb, wv, Xs, rA, rB);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        Rs[(rowA + 4 * g) * 16 + li] = rA[g];
+        Rs[(rowB + 4 * g) * 16 + li] = rB[g];
+      }
+      __syncthreads();
+      tdr_product<LOWER>(dop, nb, wv, Rs, xA, xB);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      Xs[(rowA + 4 * g) * 16 + li] = xA[g];
+      Xs[(rowB + 4 * g) * 16 + li] = xB[g];
+    }
+    __syncthreads();
+    for (int e = tid; e < NB * 16; e += 256) {
+      const int k = e & (NB - 1), c = e >> 7;
+      if (k < nb && c0 + c < nrhs) X[(long)(c0 + c) * ldx + k] = Xs[k * 16 + c];
+    }
+    __syncthreads();
+  }
+}
+
+void trsm_upper_left_fwd_batched(Ctx& c, int n, int nrhs, const double* U, long ldu, long strideU, const double* dinv, long strideD,
+                                 double* X, long ldx, long strideX, int batch) {
+  if (n <= 0 || nrhs <= 0 || batch <= 0) return;
+  const int nblk = (n + NB - 1) / NB;
+  const int refine = std::max(1, trsm_refine_steps());
+  for (int kb = 0; kb < nblk; ++kb) {
+    const int k0 = kb * NB, nb = std::min(NB, n - k0), m = n - k0 - nb;
+    hipLaunchKernelGGL(trsm_diag_refined_fwd_batched_kernel, dim3((nrhs + 16 * TDR_CH - 1) / (16 * TDR_CH), batch), dim3(256), 0, c.stream, U + (long)k0 * ldu + k0, ldu,
+                       strideU, dinv + (long)kb * DINV_BLK, strideD, nb, X + k0, ldx, strideX, nrhs, refine);
+    HYP_CHECK(hipGetLastError());
+    if (m > 0) {
+      GemmArgs u{};
+      u.M = m; u.N = nrhs; u.K = nb; u.A = U + (long)(k0 + nb) * ldu + k0; u.lda = ldu; u.strideA = strideU;
+      u.B = X + k0; u.ldb = ldx; u.strideB = strideX; u.C = X + k0 + nb; u.ldc = ldx; u.strideC = strideX;
+      u.alpha = -1; u.beta = 1; u.batch = batch;
+      gemm(c, true, u);
+    }
+  }
+}
+
 // =============================================================================================
 // explicit inverse of small upper-triangular factors (cone matrices), from the diagonal-block inverses
 // =============================================================================================
@@ -984,6 +1077,96 @@ void TriSolvePlan::solve(Ctx& c, const double* U, long ldu, bool trans, double* 
       coldot(c, m, rest, 0, U + (long)(r0 + m) * ldu + r0, ldu, xb, x + r0 + m, -1.0, x + r0 + m);
     } else {
       coldot(c, m, r0, 0, UT.d() + r0, n, xb, x, -1.0, x);   // x[0:r0] -= U[0:r0, block cols] x_b
+    }
+  }
+  HYP_CHECK(hipGetLastError());
+}
+
+// NC right-hand sides per pass over M (NC <= 8; the candidate screen's solves with the cone's previous Hessian factor, one column
+// per candidate): the column products of coldot_batched_kernel with M's column loaded once for all of them.  m <= 1024.
+template <int NC>
+__global__ __launch_bounds__(256) void coldotn_kernel(int m, int ncols, int mode, const double* __restrict__ M, long ld,
+                                                      const double* __restrict__ v, long ldv, const double* base, long ldb, double alpha,
+                                                      double* out, long ldo) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= ncols) return;
+  const int lane = threadIdx.x & 63;
+  int i0 = 0, i1 = m;
+  if (mode == 1) i1 = min(j + 1, m);
+  else if (mode == 2) i0 = min(j, m);
+  const double* a = M + (long)j * ld;
+  const int ilast = max(i1 - 1, 0);
+  double av[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int i = i0 + lane + 64 * k;
+    av[k] = (i < i1) ? a[min(i, ilast)] : 0.0;
+  }
+  double s[NC];
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc) {
+    const double* vc = v + (long)cc * ldv;
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+      t0 += av[k] * vc[min(i0 + lane + 64 * k, ilast)];
+      t1 += av[k + 1] * vc[min(i0 + lane + 64 * (k + 1), ilast)];
+    }
+    s[cc] = t0 + t1;
+  }
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc) {
+    double t = s[cc];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+    if (lane == 0) out[(long)cc * ldo + j] = (base ? base[(long)cc * ldb + j] : 0.0) + alpha * t;
+  }
+}
+
+static void coldotn(Ctx& c, int nc, int m, int ncols, int mode, const double* M, long ld, const double* v, long ldv, const double* base, long ldb,
+                    double alpha, double* out, long ldo) {
+  if (ncols <= 0) return;
+  HYP_REQUIRE(m <= 1024 && nc >= 1 && nc <= 8, "coldotn: at most 1024 rows and 8 right-hand sides");
+  const dim3 grid((ncols + 3) / 4), blk(256);
+#define HYP_CDN(N) case N: hipLaunchKernelGGL(coldotn_kernel<N>, grid, blk, 0, c.stream, m, ncols, mode, M, ld, v, ldv, base, ldb, alpha, out, ldo); break;
+  switch (nc) { HYP_CDN(1) HYP_CDN(2) HYP_CDN(3) HYP_CDN(4) HYP_CDN(5) HYP_CDN(6) HYP_CDN(7) HYP_CDN(8) }
+#undef HYP_CDN
+}
+
+// solve() on nc <= 8 columns of x (leading dimension ldx) at once: the same sweeps, every product one launch for all columns.
+// Not bitwise solve()'s sums (used where only a rigorous bound is formed from the result: WsosCone::screen_batch).
+void TriSolvePlan::solve_n(Ctx& c, const double* U, long ldu, bool trans, double* x, long ldx, int nc) {
+  HYP_REQUIRE(sb <= 1024 && nc >= 1 && nc <= 8, "TriSolvePlan::solve_n: super-blocks of at most 1024 rows, at most 8 columns");
+  const int nsb = (n + sb - 1) / sb;
+  const size_t blk = (size_t)sb * sb;
+  work_n.ensure((size_t)2 * 8 * sb * sizeof(double));
+  double* t = work_n.d();
+  double* e = work_n.d() + (size_t)8 * sb;
+  const int rf = std::max(refine, 0);
+  for (int s = 0; s < nsb; ++s) {
+    const int b = trans ? s : nsb - 1 - s;
+    const int r0 = b * sb, m = std::min(sb, n - r0);
+    double* xb = x + r0;
+    const double* Dm = trans ? U + (long)r0 * ldu + r0 : UT.d() + (long)r0 * n + r0;
+    const long ldd = trans ? ldu : n;
+    const double* Bm = (trans ? Binv.d() : BinvT.d()) + b * blk;
+    const int mode = trans ? 1 : 2;
+    if (rf == 0) {
+      coldotn(c, nc, m, m, mode, Bm, sb, xb, ldx, nullptr, 0, 1.0, t, sb);
+      HYP_CHECK(hipMemcpy2DAsync(xb, ldx * sizeof(double), t, sb * sizeof(double), (size_t)m * sizeof(double), nc, hipMemcpyDeviceToDevice, c.stream));
+    } else {
+      coldotn(c, nc, m, m, mode, Bm, sb, xb, ldx, nullptr, 0, 1.0, t, sb);                       // t = B x_b
+      for (int it = 0; it < rf; ++it) {
+        coldotn(c, nc, m, m, mode, Dm, ldd, t, sb, xb, ldx, -1.0, e, sb);                       // e = x_b - T t
+        if (it + 1 == rf) coldotn(c, nc, m, m, mode, Bm, sb, e, sb, t, sb, 1.0, xb, ldx);       // x_b = t + B e
+        else coldotn(c, nc, m, m, mode, Bm, sb, e, sb, t, sb, 1.0, t, sb);
+      }
+    }
+    if (trans) {
+      const int rest = n - (r0 + m);
+      coldotn(c, nc, m, rest, 0, U + (long)(r0 + m) * ldu + r0, ldu, xb, ldx, x + r0 + m, ldx, -1.0, x + r0 + m, ldx);
+    } else {
+      coldotn(c, nc, m, r0, 0, UT.d() + r0, n, xb, ldx, x, ldx, -1.0, x, ldx);
     }
   }
   HYP_CHECK(hipGetLastError());

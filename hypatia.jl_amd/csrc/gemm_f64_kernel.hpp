@@ -211,7 +211,7 @@ void gemm_f64_kernel(GemmArgs p) {
   //   C[m0 + wm*WT + i*16 + fr, n0 + wn*WT + j*16 + fk + 4r]
   const bool upper = (p.tri != GEMM_FULL);
   if (p.splitk > 1) {   // raw partial sums; alpha / beta / epilogue are applied by splitk_reduce_kernel
-    double* __restrict__ W = p.part + (long)blockIdx.z * p.part_stride;
+    double* __restrict__ W = p.part + ((long)bz * p.splitk + blockIdx.z) * p.part_stride;   // [batch member][slice] (one matrix: bz = 0)
 #pragma unroll
     for (int j = 0; j < TW; ++j)
 #pragma unroll
@@ -286,10 +286,12 @@ void gemm_f64_kernel(GemmArgs p) {
 // tile_rank = launch position per 128 x 128 tile) have S_extra more partial slots, the sub-slices of their last slice.
 __global__ void splitk_reduce_kernel(int M, int N, int upper, int tri_off, int S, const double* __restrict__ part, long part_ld, long part_stride,
                                      double alpha, double beta, double* __restrict__ C, long ldc, int S_extra, int tail_first,
-                                     const int* __restrict__ tile_rank, int T) {
+                                     const int* __restrict__ tile_rank, int T, long part_batch, long strideC) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = blockIdx.y;
   if (m >= M || (upper && m > n + tri_off)) return;
+  part += (long)blockIdx.z * part_batch;   // (batched split-K, requested explicitly: GemmArgs::splitk_req with batch > 1)
+  C += (long)blockIdx.z * strideC;
   double s = 0.0;
   for (int z = 0; z < S; ++z) s += part[(long)z * part_stride + (long)n * part_ld + m];
   if (S_extra > 0 && tile_rank[(m >> 7) + (n >> 7) * T] >= tail_first)
@@ -477,7 +479,9 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch*
     const int S = (int)std::min<long>(std::min<long>(16, 512 / nblk), a.K / 256);
     if (S > 1) a.splitk_req = S;
   }
-  if (gs && a.splitk_req > 1 && a.batch == 1 && a.epi == 0 && a.krange == KR_ALL && a.cm_blk == 0 && a.K / a.splitk_req >= 256) a.splitk = a.splitk_req;
+  // (batch > 1: only on the caller's request -- the candidate screen of the WSOS cone, whose Gram products are a few dozen tiles
+  //  per matrix with K = U; the partial sums are laid out [member][slice])
+  if (gs && a.splitk_req > 1 && a.epi == 0 && a.krange == KR_ALL && a.cm_blk == 0 && a.K / a.splitk_req >= 256) a.splitk = a.splitk_req;
   a.splitk_base = a.splitk; a.tail_q = 1; a.tail_first = 0; a.tail_chunk = 0;
   if (a.splitk > 1) {
     a.kchunk = (((a.K + a.splitk - 1) / a.splitk) + BK - 1) / BK * BK;
@@ -507,7 +511,7 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch*
     }
     a.part_ld = a.M;
     a.part_stride = (long)a.M * a.N;
-    const size_t need = (size_t)a.splitk * a.part_stride * sizeof(double);
+    const size_t need = (size_t)a.splitk * a.part_stride * sizeof(double) * (size_t)a.batch;
     if (need > gs->splitk_ws_bytes) {
       if (gs->splitk_ws) (void)hipFree(gs->splitk_ws);
       gs->splitk_ws = nullptr; gs->splitk_ws_bytes = 0;
@@ -533,9 +537,9 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch*
     else hipLaunchKernelGGL((gemm_f64_kernel<false, 4, 0>), grid, dim3(GEMM_THREADS), 0, st, a);
   }
   if (a.splitk > 1)
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((a.M + 255) / 256, a.N), dim3(256), 0, st, a.M, a.N, a.tri != GEMM_FULL ? 1 : 0, a.tri_off,
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((a.M + 255) / 256, a.N, a.batch), dim3(256), 0, st, a.M, a.N, a.tri != GEMM_FULL ? 1 : 0, a.tri_off,
                        a.splitk_base, a.part, a.part_ld, a.part_stride, a.alpha, a.beta, a.C, a.ldc, a.tail_q - 1, a.tail_first,
-                       a.tile_map ? a.tile_map + 2 * nblk : nullptr, a.tiles_n);
+                       a.tile_map ? a.tile_map + 2 * nblk : nullptr, a.tiles_n, (long)a.splitk * a.part_stride, a.strideC);
   return hipGetLastError();
 }
 

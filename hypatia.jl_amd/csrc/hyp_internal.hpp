@@ -195,6 +195,9 @@ inline size_t dinv_elems(int n) { return (size_t)((n + NB - 1) / NB) * DINV_BLK;
 void trsv_upper(Ctx& c, int n, const double* U, long ldu, const double* dinv, bool trans, double* x);
 void trsm_upper_left(Ctx& c, int n, int nrhs, const double* U, long ldu, const double* dinv, bool trans, double* X,
                      long ldx, double* work /* NB x nrhs */);
+// the forward solve (U'^-1) for a batch of equally sized factors: member b at U + b strideU, dinv + b strideD, X + b strideX
+void trsm_upper_left_fwd_batched(Ctx& c, int n, int nrhs, const double* U, long ldu, long strideU, const double* dinv, long strideD,
+                                 double* X, long ldx, long strideX, int batch);
 // One-right-hand-side solves with a LARGE upper Cholesky factor (the potrs of qrchol.jl:68).  The
 // factor is cut into super-blocks of sb rows; build() inverts the diagonal super-blocks and keeps a
 // transposed copy of U, so that every step of solve() is a set of coalesced column dot products:
@@ -202,13 +205,14 @@ void trsm_upper_left(Ctx& c, int n, int nrhs, const double* U, long ldu, const d
 // factor itself (the result has substitution's backward error), then one rank-sb update of the rest.
 struct TriSolvePlan {
   int n = 0, sb = 0, refine = 2;
-  DBuf Binv, BinvT, UT, work, work2;
+  DBuf Binv, BinvT, UT, work, work2, work_n;
   bool ready(int n_) const { return n == n_ && n_ > 0; }
   void invalidate() { n = 0; }
   void build(Ctx& c, int n_, const double* U, long ldu, const double* dinv);
   void solve(Ctx& c, const double* U, long ldu, bool trans, double* x);
   void solve_multi(Ctx& c, const double* U, long ldu, bool trans, double* x, long ldx, int nr);   // nr <= 2 right-hand sides
   void solve_multi3(Ctx& c, const double* U, long ldu, bool trans, double* x, long ldx, double* x3);   // the pair x[:, 0:2] and a third vector x3 together
+  void solve_n(Ctx& c, const double* U, long ldu, bool trans, double* x, long ldx, int nc);   // nc <= 8 columns, one launch per product (not solve()'s bits)
 };
 // bunchkaufman.hip : symmetric indefinite factorization with rook pivoting, the reference's fallback of a failed
 // Cholesky (symm_fact!, dense.jl:164-165; posdef_fact_copy!, dense.jl:194-215).  P A P' = U' D U with U unit upper

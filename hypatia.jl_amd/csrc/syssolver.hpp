@@ -142,6 +142,9 @@ struct SysSolver {
   static constexpr int SCREEN_MAX = 18;   // the reference's whole schedule (search.jl:41-43)
   DBuf screen_buf, screen_info;
   long screen_count = 0, screen_rejected = 0;   // statistics: screens run, candidates they rejected
+  std::vector<double> gscreen_host;             // host staging of the one-cone generic screen (search_alpha)
+  long screen_checked = 0, screen_mismatch = 0; // HYP_WSOS_SCREEN_CHECK=1: rejected verdicts compared with the sequential test / disagreements
+  bool cand_scalars(const double* h, double min_prox, double prox_bound, double nup1, double* irtmu) const;
   bool screen_usable() const { return screen_mode() != 0; }
   int screen_agreed = -1;    // sharded: the minimum of the ranks' screen_mode(), agreed once per model (-1: not yet)
   int screen_kmax() const;   // candidates per screening batch the buffers admit for this model (<= SCREEN_MAX; < 2: no screen)

@@ -172,3 +172,24 @@ def test_screen_batches_shrink_for_models_with_many_cones():
     assert on["trace"] == off["trace"] and tiny["trace"] == off["trace"]
     assert on["trials"] == tiny["trials"] == off["trials"]
     assert on["screens"][0] >= on["iters"] and on["screens"][1] > 0 and off["screens"] == [0, 0]
+
+
+@pytest.mark.parametrize("name", ["polymin_large_primal", "polymin_large_dual"])
+def test_wsos_candidate_screen_changes_no_bit(name):
+    """round 4 (late): for a model of one large WSOSInterpNonnegative cone the next candidates of the schedule go through the
+    feasibility chains, the gradient's triangular solves and the proximity lower bound TOGETHER (WsosCone::screen_batch,
+    csrc/wsos_screen.hip; HYP_WSOS_SCREEN = candidates per batch, 0 = off); candidates it reports rejected are stepped over, the
+    others are tested by the unchanged sequential code.  The screen may only reject what the sequential test rejects: same
+    accepted step in every iteration, the same iterates to the last bit, the same number of candidates visited.
+    HYP_WSOS_SCREEN_CHECK=1 evaluates every screened-out candidate sequentially as well and raises on a disagreement."""
+    on = _run(name, {})
+    wide = _run(name, {"HYP_WSOS_SCREEN": "8"})
+    off = _run(name, {"HYP_WSOS_SCREEN": "0"})
+    chk = _run(name, {"HYP_WSOS_SCREEN_CHECK": "1"})
+    assert on["status"] == wide["status"] == off["status"] == chk["status"] == "Optimal"
+    assert on["iters"] == wide["iters"] == off["iters"] == chk["iters"] >= 8
+    assert on["trace"] == off["trace"] and wide["trace"] == off["trace"] and chk["trace"] == off["trace"]
+    assert on["trials"] == wide["trials"] == off["trials"] == chk["trials"]
+    assert off["screens"] == [0, 0]
+    for r in (on, wide, chk):
+        assert r["screens"][0] > 0 and r["screens"][1] > 0   # (it ran, and it rejected something)
