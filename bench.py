@@ -70,6 +70,9 @@ def algorithm_record():
             # models of equal PosSemidefTri cones: the rejecting tests of ALL remaining candidates of the schedule at once, the
             # survivor through the sequential test (same accepted step, same iterates: DESIGN.md section 7)
             "line_search_candidate_screen": on("HYP_SEARCH_SCREEN") and on("HYP_PROX_LB"),
+            # one large WSOSInterpNonnegative cone (config 5): the next candidates through feasibility chains, gradient solves and the
+            # proximity bound together; only rejections are taken from it (csrc/wsos_screen.hip; candidates per batch, 0 = off)
+            "wsos_candidate_screen": int(os.environ.get("HYP_WSOS_SCREEN", "4")) if on("HYP_PROX_LB") else 0,
             "triangular_solve_refinement_steps": int(os.environ.get("HYP_TRSM_REFINE", "2")),
             # (the candidate screen needs the proximity bound: off with HYP_PROX_LB=0)
             # behind a failed Cholesky: the rook-pivoted elimination only from the failing pivot's block on (round 4; 0: the whole matrix)

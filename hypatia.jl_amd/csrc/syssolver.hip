@@ -1572,7 +1572,13 @@ int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp
   // candidates are formed in pinned memory and only the accepted one is copied to the caller's vector:
   // the upload inside check_cone_points is then a plain asynchronous copy -- from the caller's pageable vector it stopped the
   // host for the whole transfer, once per trial
-  double* const stage = ctx.stage_host((size_t)(screen && !resident ? SCREEN_MAX : 2) * len);
+  // (the one-cone generic screen, see the sequential branch below, stages its candidates, points and dual points behind the two
+  //  candidate slots of the sequential walk -- pinned as well: an upload from pageable memory stops the host for the transfer and
+  //  cost 2 ms per iteration on some boxes, profiles/r04_wsos_screen.txt)
+  const int gC = (!screen && !dist() && cones.size() == 1) ? std::min(8, cones[0]->screen_max()) : 0;
+  const size_t gextra = gC >= 2 ? (size_t)gC * len + 2 * (size_t)gC * cones[0]->dim : 0;
+  double* const stage = ctx.stage_host((size_t)(screen && !resident ? SCREEN_MAX : 2) * len + gextra);
+  double* const ghost = stage + (size_t)2 * len;
   double* const out = cand;
   const int mode = unadj_only ? (cent_only ? 0 : 1) : (cent_only ? 2 : 3);
   auto coef = [&](double alpha, double& a2, double& am1, double& am1s) { a2 = alpha * alpha; am1 = 1.0 - alpha; am1s = am1 * am1; };
@@ -1599,11 +1605,9 @@ int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp
   };
   int idx = start;
   static const bool skip_lb = [] { const char* e = getenv("HYP_SCREEN_SKIP_LB"); return !(e && e[0] == '0'); }();
-  const int gC = (!screen && !dist() && cones.size() == 1) ? std::min(8, cones[0]->screen_max()) : 0;   // (generic one-cone screen, see below)
   int gbase = -1;
   std::vector<char> gver;
   std::vector<double> gbnd;   // the screen's lower bound of a candidate's proximity value (negative: none)
-  std::vector<double>& ghost = gscreen_host;
   while (idx < nsched) {
     const int K = screen ? std::min(kcap, nsched - idx) : 1;
     if (K >= 2 || resident) {
@@ -1669,8 +1673,7 @@ int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp
     if (gC >= 2 && (idx < gbase || idx >= gbase + (int)gver.size()) && nsched - idx >= 2 && cones[0]->screen_ready()) {
       Cone* ck = cones[0];
       const int Cn = std::min(gC, nsched - idx), dk = ck->dim;
-      ghost.resize((size_t)Cn * len + 2 * (size_t)Cn * dk);
-      double* gp = ghost.data() + (size_t)Cn * len;
+      double* gp = ghost + (size_t)Cn * len;
       double* gd = gp + (size_t)Cn * dk;
       double girt[8];
       int gmap[8], nbat = 0;
@@ -1678,7 +1681,7 @@ int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp
       gver.assign(Cn, 0);
       gbnd.assign(Cn, -1.0);
       for (int g = 0; g < Cn; ++g) {
-        double* h = ghost.data() + (size_t)g * len;
+        double* h = ghost + (size_t)g * len;
         form(h, sched[idx + g]);
         double irt = 0.0;
         if (!cand_scalars(h, min_prox, prox_bound, nup1, &irt)) continue;

@@ -142,7 +142,6 @@ struct SysSolver {
   static constexpr int SCREEN_MAX = 18;   // the reference's whole schedule (search.jl:41-43)
   DBuf screen_buf, screen_info;
   long screen_count = 0, screen_rejected = 0;   // statistics: screens run, candidates they rejected
-  std::vector<double> gscreen_host;             // host staging of the one-cone generic screen (search_alpha)
   long screen_checked = 0, screen_mismatch = 0; // HYP_WSOS_SCREEN_CHECK=1: rejected verdicts compared with the sequential test / disagreements
   bool cand_scalars(const double* h, double min_prox, double prox_bound, double nup1, double* irtmu) const;
   bool screen_usable() const { return screen_mode() != 0; }

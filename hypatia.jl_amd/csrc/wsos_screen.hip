@@ -166,10 +166,31 @@ bool WsosCone::screen_batch(int C, const double* h_pts, const double* h_duals, c
     k0 += cnt;
   }
   const size_t d = sizeof(double);
-  scrSP.ensure(nSP * d); scrLF.ensure(nSP * d); scrLFT.ensure(nSP * d);
-  scrLam.ensure(nLam * d); scrLL.ensure(nLam * d); scrDinv.ensure(nDinv * d);
-  scrVec.ensure((size_t)(4 * C * U + (size_t)C * K * U + 16 + (size_t)C * K * FROB_SL) * d);
-  scrInfo.ensure((size_t)C * K * sizeof(int));
+  // every buffer is sized for the largest batch the walk can ask for, on the first call: a batch of 2 followed by one of 4 must not
+  // re-allocate (hipFree of a GB synchronises the device and was measured to disturb the queues for milliseconds)
+  const size_t Cm = (size_t)std::max(C, screen_max());
+  scrSP.ensure(nSP / C * Cm * d); scrLF.ensure(nSP / C * Cm * d); scrLFT.ensure(nSP / C * Cm * d);
+  scrLam.ensure(nLam / C * Cm * d); scrLL.ensure(nLam / C * Cm * d); scrDinv.ensure(nDinv / C * Cm * d);
+  scrVec.ensure((size_t)(4 * Cm * U + Cm * K * U + 16 + Cm * K * FROB_SL) * d);
+  scrInfo.ensure(Cm * K * sizeof(int));
+  {   // the launchers' own scratch, for both streams: split-K partial sums (at most 16 slices) and the factorizations' tile inverses
+    size_t ws = 0, tv = 0;
+    for (const Grp& g : grps) {
+      ws = std::max(ws, Cm * g.cnt * 16 * (size_t)g.L * g.L * d);
+      tv = std::max(tv, Cm * g.cnt * (size_t)((g.L + NB - 1) / NB) * 2048 * d);
+    }
+    for (GemmScratch* gs : {&ctx.gemm_scratch, &ctx.gemm_scratch2}) {
+      if (gs->splitk_ws_bytes < ws) {
+        if (gs->splitk_ws) HYP_CHECK(hipFree(gs->splitk_ws));
+        gs->splitk_ws = nullptr; gs->splitk_ws_bytes = 0;
+        HYP_CHECK(hipMalloc((void**)&gs->splitk_ws, ws));
+        gs->splitk_ws_bytes = ws;
+      }
+    }
+    ctx.potrf_tinv.ensure(tv);
+    ctx.potrf_tinv2.ensure(tv);
+    Hplan.work_n.ensure((size_t)2 * 8 * 1024 * d);
+  }
   double* pts = scrVec.d();                       // C x U
   double* duals = pts + (size_t)C * U;            // C x U
   double* V = duals + (size_t)C * U;              // C x U
