@@ -137,6 +137,12 @@ bool WsosCone::screen_ready() {
   if (screen_max() < 2) return false;
   if (!hess_fact_ok || hess_fact_bk || !Hfact.p) return false;
   if (ctx.trsv_plan_sb(dim) <= 0 || ctx.trsv_plan_sb(dim) > 1024) return false;
+  // byte budget of the batch buffers (three U x L_k operand copies per candidate and member; HYP_SCREEN_MB as for the PSD screen,
+  // default 2048 MB per candidate slot x 8): a cone too large for it walks sequentially
+  static const double budget = [] { const char* e = getenv("HYP_SCREEN_MB"); return (e ? atof(e) : 2048.0) * 8.0 * 1048576.0; }();
+  double sumL = 0.0;
+  for (int k = 0; k < K; ++k) sumL += Ls[k];
+  if (3.0 * screen_max() * (double)U * sumL * sizeof(double) > budget) return false;
   return true;
 }
 
@@ -229,7 +235,7 @@ bool WsosCone::screen_batch(int C, const double* h_pts, const double* h_duals, c
       double* SPg = scrSP.d() + g.oSP;
       double* Lamg = scrLam.d() + g.oLam;
       double* Dinvg = scrDinv.d() + g.oDinv;
-      hipLaunchKernelGGL(row_scale_batched_kernel, dim3((U + 255) / 256, std::min(L, 512), nb), dim3(256), 0, ctx.stream, U, L, g.cnt, pts, (long)U, Pp, 0L,
+      hipLaunchKernelGGL(row_scale_batched_kernel, dim3((U + 255) / 256, std::min(L, 64), nb), dim3(256), 0, ctx.stream, U, L, g.cnt, pts, (long)U, Pp, 0L,
                          SPg, g.sUL);
       HYP_CHECK(hipGetLastError());
       for (int t = 0; t < g.cnt; ++t) {   // Lambda_{c, k0 + t} for all c: one batched product per member (its second operand P_k is shared)
@@ -329,7 +335,7 @@ bool WsosCone::screen_batch(int C, const double* h_pts, const double* h_duals, c
       double* LLg = scrLL.d() + g.oLL + b0 * g.sLam;
       Ptr8 in{};
       in.p[0] = LFTg;
-      hipLaunchKernelGGL(row_scale_batched_kernel, dim3((U + 255) / 256, std::min(L, 512), nb), dim3(256), 0, ctx.stream, U, L, g.cnt, Pmb, (long)U, in,
+      hipLaunchKernelGGL(row_scale_batched_kernel, dim3((U + 255) / 256, std::min(L, 64), nb), dim3(256), 0, ctx.stream, U, L, g.cnt, Pmb, (long)U, in,
                          g.sUL, SPg, g.sUL);
       HYP_CHECK(hipGetLastError());
       GemmArgs a{};   // LL_b = (diag(p_c) LFLP_b')' LFLP_b'  (L x L, upper)
