@@ -93,3 +93,23 @@ def test_hip_fullsize_trajectory_matches_oracle(name, route):
         assert np.abs(h["diag"] - g["diag"]).max() <= tol * np.abs(g["diag"]).max(), (name, it, "diagonal")
         assert np.linalg.norm(h["SV"] - g["SV"]) <= tol * np.linalg.norm(g["SV"]), (name, it, "S V")
         assert abs(h["fro"][0] - g["fro"][0]) <= tol * g["fro"][0], (name, it, "norm")
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("name", [n for n in sorted(CASES) if n.startswith("cfg5")])
+def test_fullsize_wsos_candidate_screen_changes_no_bit(name):
+    """config 5 at U = 4845, both forms: the line search's candidate screen (csrc/wsos_screen.hip, on by default) against the
+    sequential walk (HYP_WSOS_SCREEN=0) and against itself in check mode (HYP_WSOS_SCREEN_CHECK=1: every screened-out candidate
+    also goes through the sequential test, a disagreement raises inside the library) -- the same iterates to the last bit and the
+    same number of candidates visited"""
+    rec = CASES[name]
+    runs = [T.hip_trajectory(name, route, timeout=1700, **rec["opts"])
+            for route in ({}, {"HYP_WSOS_SCREEN": "0"}, {"HYP_WSOS_SCREEN_CHECK": "1"})]
+    on, off, chk = runs
+    assert on["status"] == off["status"] == chk["status"]
+    assert on["rows"].shape == off["rows"].shape == chk["rows"].shape
+    assert (on["rows"] == off["rows"]).all() and (chk["rows"] == off["rows"]).all()
+    assert on["trials"] == off["trials"] == chk["trials"]
+    assert off["screens"] == [0, 0]
+    assert on["screens"][0] > 0 and on["screens"][1] > 0      # (it ran, and it rejected something)

@@ -268,5 +268,7 @@ if __name__ == "__main__":
     opts = json.loads(sys.argv[2]) if len(sys.argv) > 2 else {}
     probes = {}
     s, t = run_trajectory(Hm.Solver, Hm.make_model(instance(nm)), probe_iters=tuple(opts.pop("probe_iters", ())), probes=probes, **opts)
-    print(json.dumps(dict(status=s.status, iters=s.num_iters, p_obj=s.primal_obj, rows=t.tolist(),
+    screens = list(s.syssolver.search_screen_stats()) if hasattr(s.syssolver, "search_screen_stats") else [0, 0]
+    print(json.dumps(dict(status=s.status, iters=s.num_iters, p_obj=s.primal_obj, rows=t.tolist(), screens=screens,
+                          trials=int(s.stepper.searcher.n_trials),
                           probes={str(k): {f: v.tolist() for f, v in p.items()} for k, p in probes.items()})))
