@@ -142,6 +142,7 @@ struct SysSolver {
   static constexpr int SCREEN_MAX = 18;   // the reference's whole schedule (search.jl:41-43)
   DBuf screen_buf, screen_info;
   long screen_count = 0, screen_rejected = 0;   // statistics: screens run, candidates they rejected
+  int gprev_acc_ = -1;   // schedule index the previous search_alpha accepted (-1: none): where the one-cone screen's batches stop
   long screen_checked = 0, screen_mismatch = 0; // HYP_WSOS_SCREEN_CHECK=1: rejected verdicts compared with the sequential test / disagreements
   bool cand_scalars(const double* h, double min_prox, double prox_bound, double nup1, double* irtmu) const;
   bool screen_usable() const { return screen_mode() != 0; }
