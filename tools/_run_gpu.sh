@@ -27,3 +27,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GR
   rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex "gemm_f64_kernel<true, 4, 1>|psd_ts4_kernel|psd_ts3_kernel|psd_ts_kernel|splitk_reduce" -d /tmp/pmc_$tag -o b -- python bench.py --steps 2 --warmup 1 --cpu-iters 0 > /dev/null 2>&1
   python tools/rocpd_pmc.py $(find /tmp/pmc_$tag -name "*.db" | head -1) > gpurun_out/pmc_$tag.txt 2>&1; head -12 gpurun_out/pmc_$tag.txt
 done
+# config 5's candidate screen (csrc/wsos_screen.hip): on / off, alternating on this box (the gain is box-dependent: profiles/r04_wsos_screen.txt)
+for i in 1 2; do for C in 4 0; do for c in 5p 5d; do HYP_WSOS_SCREEN=$C python bench.py --config $c 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('HYP_WSOS_SCREEN=$C $c', round(d['ms_per_step'],2), {k:round(v,2) for k,v in d['phases_ms_per_step'].items()})"; done; done; done > gpurun_out/wsos_screen_ab.txt; cat gpurun_out/wsos_screen_ab.txt
