@@ -528,18 +528,92 @@ int BKFact::factor_from(Ctx& c, int n_, double* A, long lda, double* dinv, int k
   return hs->info;
 }
 
-int bk_after_failed_cholesky(Ctx& c, BKFact& bk, int n, double* A, long lda, double* dinv, int* d_info_scratch, int chol_info) {
+// ---- growth guard of the hybrid factorization ----------------------------------------------------------------------------------
+// The block steps kept from the Cholesky are UNPIVOTED eliminations.  dsytrf_rook (the reference's symm_fact!, dense.jl:164-165) is the
+// fall-back because its element growth is bounded; a kept step is as good only while (a) its pivots are not positive by rounding
+// alone, U_ii^2 >= n eps max|a_ii|, and (b) its rows show no growth, U_ij^2 <= 16 max|a_ii| (a positive definite matrix has
+// U_ij^2 <= a_jj).  out[2 b] = min_i U_ii^2, out[2 b + 1] = max_{j >= i} U_ij^2 over the rows i of block step b; out[2 kb] = max|a_ii|
+// of the matrix itself (its diagonal is read from the caller's copy).
+__global__ __launch_bounds__(256) void bk_guard_kernel(int n, int kb, const double* __restrict__ F, long ldf, const double* __restrict__ Asrc,
+                                                       long lds, double* __restrict__ out) {
+  __shared__ double red[2][256];
+  const int b = blockIdx.x, t = threadIdx.x;
+  double mn = INFINITY, mx = 0.0;
+  if (b < kb) {
+    const int i = b * NB + (t & (NB - 1));
+    for (int j = b * NB + (t >> 7); j < n; j += 2) {
+      if (j < i) continue;
+      const double u = F[(long)j * ldf + i], u2 = u * u;
+      if (!(u2 <= mx)) mx = u2;                  // (a NaN sticks)
+      if (j == i && !(u2 >= mn)) mn = u2;
+    }
+  } else {
+    for (int i = t; i < n; i += 256) {
+      const double a = fabs(Asrc[(long)i * lds + i]);
+      if (!(a <= mx)) mx = a;
+    }
+    mn = 0.0;
+  }
+  red[0][t] = mn;
+  red[1][t] = mx;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (t < off) {
+      const double m2 = red[0][t + off], x2 = red[1][t + off];
+      if (!(m2 >= red[0][t])) red[0][t] = m2;
+      if (!(x2 <= red[1][t])) red[1][t] = x2;
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    if (b < kb) { out[2 * b] = red[0][0]; out[2 * b + 1] = red[1][0]; }
+    else out[2 * kb] = red[1][0];
+  }
+}
+
+// number of leading block steps (<= kb) of the partly factored F that pass the guard
+static int bk_guard_steps(Ctx& c, BKFact& bk, int n, int kb, const double* F, long ldf, const double* Asrc, long lds) {
+  static const bool on = [] { const char* e = getenv("HYP_BK_GUARD"); return !(e && e[0] == '0'); }();
+  if (!on) return kb;
+  bk.guard.ensure((size_t)(2 * kb + 1) * sizeof(double));
+  hipLaunchKernelGGL(bk_guard_kernel, dim3(kb + 1), dim3(256), 0, c.stream, n, kb, F, ldf, Asrc, lds, bk.guard.d());
+  std::vector<double> h(2 * kb + 1);
+  c.d2h(h.data(), bk.guard.p, h.size() * sizeof(double));
+  c.sync();
+  const double amax = h[2 * kb];
+  if (!(amax > 0.0) || !std::isfinite(amax)) return 0;
+  const double piv_floor = (double)n * 2.220446049250313e-16 * amax, row_cap = 16.0 * amax;
+  int ok = 0;
+  while (ok < kb && h[2 * ok] >= piv_floor && h[2 * ok + 1] <= row_cap) ++ok;
+  return ok;
+}
+
+int bk_after_failed_cholesky(Ctx& c, BKFact& bk, int n, double* A, long lda, double* dinv, int* d_info_scratch, int chol_info,
+                             const double* A_src, long ld_src) {
   static const bool hybrid = [] { const char* e = getenv("HYP_BK_HYBRID"); return !(e && e[0] == '0'); }();
-  const int kb = (chol_info > 0) ? (chol_info - 1) / NB : 0;   // block step of the failing pivot: the steps before it succeeded
-  if (hybrid && kb >= 1 && kb * NB < n) {
+  int kb = (chol_info > 0) ? (chol_info - 1) / NB : 0;   // block step of the failing pivot: the steps before it succeeded
+  bk.k0_used = 0;
+  bk.guard_trimmed = 0;
+  for (int attempt = 0; hybrid && kb >= 1 && kb * NB < n && attempt < 2; ++attempt) {
     potrf_upper_batched(c, n, A, lda, 0, 1, nullptr, d_info_scratch, kb);
     c.d2h(c.h_info + 41, d_info_scratch, sizeof(int));
     c.sync();
-    if (c.h_info[41] == 0) return bk.factor_from(c, n, A, lda, dinv, kb * NB);
-    // (cannot happen -- the same kernels on the same data succeeded a moment ago --; the matrix is then half eliminated: the caller's
-    //  copy is gone, so report the failure as a singular pivot rather than factor garbage)
-    return c.h_info[41];
+    // (a failure here cannot happen -- the same kernels on the same data succeeded a moment ago --; the matrix is then half eliminated,
+    //  so start again from the caller's copy with the plain factorization)
+    const int ok = (c.h_info[41] == 0) ? bk_guard_steps(c, bk, n, kb, A, lda, A_src, ld_src) : 0;
+    if (ok == kb) {
+      bk.k0_used = kb * NB;
+      ++c.bk_hybrid_count;
+      return bk.factor_from(c, n, A, lda, dinv, kb * NB);
+    }
+    // some kept step fails the guard: the matrix again, and only the steps in front of the first offender (none: plain rook pivoting)
+    bk.guard_trimmed = kb - ok;
+    ++c.bk_guard_trims;
+    HYP_CHECK(hipMemcpy2DAsync(A, (size_t)lda * sizeof(double), A_src, (size_t)ld_src * sizeof(double), (size_t)n * sizeof(double), n,
+                               hipMemcpyDeviceToDevice, c.stream));
+    kb = ok;
   }
+  ++c.bk_plain_count;
   return bk.factor(c, n, A, lda, dinv);
 }
 

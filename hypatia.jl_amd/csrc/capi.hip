@@ -94,6 +94,13 @@ int hyp_reset_timers(hyp_ctx* ctx) {
   for (int i = 0; i < 8; ++i) ctx->c.kstat[i] = 0;
   API_END(ctx)
 }
+int hyp_ctx_bk_stats(hyp_ctx* ctx, long long* out3) {
+  API_BEGIN
+  out3[0] = ctx->c.bk_hybrid_count;
+  out3[1] = ctx->c.bk_guard_trims;
+  out3[2] = ctx->c.bk_plain_count;
+  API_END(ctx)
+}
 int hyp_get_kernel_stats(hyp_ctx* ctx, double* out8) {
   API_BEGIN
   for (int i = 0; i < 8; ++i) out8[i] = ctx->c.kstat[i];
@@ -851,8 +858,7 @@ int hyp_dense_posv(hyp_ctx* ctx, int n, double* A, int lda, double* x, int* info
     if (c.trsv_plan_sb(n) > 0) {   // same dispatch as SysSolver::tri_solves
       TriSolvePlan tri;
       tri.build(c, n, dA.d(), lda, dinv.d());
-      tri.solve(c, dA.d(), lda, true, dx.d());
-      tri.solve(c, dA.d(), lda, false, dx.d());
+      tri.solve_both(c, dA.d(), lda, dx.d(), n, 1);
       c.sync();
     } else {
       trsv_upper(c, n, dA.d(), lda, dinv.d(), true, dx.d());
@@ -933,10 +939,8 @@ int hyp_dense_posdef_solve(hyp_ctx* ctx, int n, double* A, int lda, double* x, i
     *used_fallback = 1;
     BKFact bk;
     c.d2d(dF.p, dA.p, (size_t)lda * n * 8);
-    static const bool hybrid = [] { const char* e = getenv("HYP_BK_HYBRID"); return !(e && e[0] == '0'); }();
-    const int kb = (ci - 1) / NB;
-    *bk_start = (hybrid && kb >= 1 && kb * NB < n) ? kb * NB : 0;
-    *info = bk_after_failed_cholesky(c, bk, n, dF.d(), lda, dinv.d(), dinfo.i(), ci);
+    *info = bk_after_failed_cholesky(c, bk, n, dF.d(), lda, dinv.d(), dinfo.i(), ci, dA.d(), lda);
+    *bk_start = bk.k0_used;
     if (*info == 0 && nrhs > 0) bk.solve(c, dF.d(), lda, dinv.d(), dx.d(), ldx, nrhs, work);
   }
   c.d2h(A, dF.p, (size_t)lda * n * 8);
@@ -999,10 +1003,8 @@ int hyp_dense_lstsq_normal(hyp_ctx* ctx, int m, int n, const double* A, int lda,
     const bool plan = (c.trsv_plan_sb(n) > 0);
     if (plan) tri.build(c, n, dF.d(), n, dinv.d());
     auto solve = [&](double* v) {
-      for (int pass = 0; pass < 2; ++pass) {
-        if (plan) tri.solve(c, dF.d(), n, pass == 0, v);
-        else trsv_upper(c, n, dF.d(), n, dinv.d(), pass == 0, v);
-      }
+      if (plan) { tri.solve_both(c, dF.d(), n, v, n, 1); return; }
+      for (int pass = 0; pass < 2; ++pass) trsv_upper(c, n, dF.d(), n, dinv.d(), pass == 0, v);
     };
     gemv(c, true, m, n, 1.0, dA.d(), lda, db.d(), 0.0, dx.d());           // x = (R'R)^-1 A'b
     solve(dx.d());
@@ -1110,12 +1112,12 @@ int hyp_bench_potrf(hyp_ctx* ctx, int n, int reps, double* ms_out) {
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   API_END(ctx)
 }
-int hyp_bench_trsv(hyp_ctx* ctx, int n, int reps, double* ms_out3, double* x_out) {
+int hyp_bench_trsv(hyp_ctx* ctx, int n, int reps, double* ms_out4, double* x_out) {
   API_BEGIN
   Ctx& c = ctx->c;
   HYP_REQUIRE(n >= 1 && reps >= 1, "bench_trsv: sizes");
-  DBuf dA((size_t)n * n * 8), dinv(dinv_elems(n) * 8), dinfo(64), dx((size_t)2 * n * 8), dx0((size_t)2 * n * 8);
-  std::vector<double> h((size_t)n * n), hx((size_t)2 * n);
+  DBuf dA((size_t)n * n * 8), dinv(dinv_elems(n) * 8), dinfo(64), dx((size_t)3 * n * 8), dx0((size_t)3 * n * 8);
+  std::vector<double> h((size_t)n * n), hx((size_t)3 * n);
   uint64_t s = 88172645463325252ULL;
   for (long j = 0; j < n; ++j)
     for (long i = 0; i <= j; ++i) {
@@ -1133,7 +1135,7 @@ int hyp_bench_trsv(hyp_ctx* ctx, int n, int reps, double* ms_out3, double* x_out
   hipEvent_t e0, e1;
   HYP_CHECK(hipEventCreate(&e0)); HYP_CHECK(hipEventCreate(&e1));
   TriSolvePlan tri;
-  float tb = 0, t1 = 0, t2 = 0;
+  float tb = 0, t1 = 0, t2 = 0, t3 = 0;
   for (int r = 0; r <= reps; ++r) {   // (first pass untimed)
     float ms = 0;
     tri.invalidate();
@@ -1143,27 +1145,33 @@ int hyp_bench_trsv(hyp_ctx* ctx, int n, int reps, double* ms_out3, double* x_out
     HYP_CHECK(hipEventSynchronize(e1));
     HYP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     if (r > 0) tb += ms;
-    c.d2d(dx.p, dx0.p, (size_t)2 * n * 8);
+    c.d2d(dx.p, dx0.p, (size_t)3 * n * 8);
     HYP_CHECK(hipEventRecord(e0, c.stream));
-    tri.solve(c, dA.d(), n, true, dx.d());
-    tri.solve(c, dA.d(), n, false, dx.d());
+    tri.solve_both(c, dA.d(), n, dx.d(), n, 1);
     HYP_CHECK(hipEventRecord(e1, c.stream));
     HYP_CHECK(hipEventSynchronize(e1));
     HYP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     if (r > 0) t1 += ms;
     if (x_out && r == reps) c.d2h(x_out, dx.p, (size_t)n * 8);
-    c.d2d(dx.p, dx0.p, (size_t)2 * n * 8);
+    c.d2d(dx.p, dx0.p, (size_t)3 * n * 8);
     HYP_CHECK(hipEventRecord(e0, c.stream));
-    tri.solve_multi(c, dA.d(), n, true, dx.d(), n, 2);
-    tri.solve_multi(c, dA.d(), n, false, dx.d(), n, 2);
+    tri.solve_both(c, dA.d(), n, dx.d(), n, 2);
     HYP_CHECK(hipEventRecord(e1, c.stream));
     HYP_CHECK(hipEventSynchronize(e1));
     HYP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     if (r > 0) t2 += ms;
     if (x_out && r == reps) c.d2h(x_out + n, dx.p, (size_t)2 * n * 8);
+    c.d2d(dx.p, dx0.p, (size_t)3 * n * 8);
+    HYP_CHECK(hipEventRecord(e0, c.stream));
+    tri.solve_both(c, dA.d(), n, dx.d(), n, 3);
+    HYP_CHECK(hipEventRecord(e1, c.stream));
+    HYP_CHECK(hipEventSynchronize(e1));
+    HYP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0) t3 += ms;
+    if (x_out && r == reps) c.d2h(x_out + 3 * n, dx.p, (size_t)3 * n * 8);
   }
   c.sync();
-  ms_out3[0] = tb / reps; ms_out3[1] = t1 / reps; ms_out3[2] = t2 / reps;
+  ms_out4[0] = tb / reps; ms_out4[1] = t1 / reps; ms_out4[2] = t2 / reps; ms_out4[3] = t3 / reps;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   API_END(ctx)
 }

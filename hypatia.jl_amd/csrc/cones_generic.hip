@@ -93,7 +93,7 @@ bool GenericHessCone::update_hess_fact() {   // Cones.jl:239-251: posdef_fact_co
   } else {
     hess_fact_bk = true;
     ctx.d2d(Hfact.p, H.p, (size_t)dim * dim * sizeof(double));
-    hess_fact_ok = (bk_after_failed_cholesky(ctx, Hbk, dim, Hfact.d(), dim, Hdinv.d(), Hinfo.i(), force_bk ? 0 : hinfo_fail) == 0);
+    hess_fact_ok = (bk_after_failed_cholesky(ctx, Hbk, dim, Hfact.d(), dim, Hdinv.d(), Hinfo.i(), force_bk ? 0 : hinfo_fail, H.d(), dim) == 0);
   }
   hess_fact_updated = true;
   Hplan.invalidate();
@@ -131,19 +131,26 @@ void GenericHessCone::inv_hess_prod(double* prod, long ldp, const double* arr, l
     // one vector against a large factor (check_numerics / get_proxsqr of every line-search trial): the super-block solves
     // of the system solver (76 dependent block steps otherwise); Bunch-Kaufman factor: P before, D^-1 between, P' after
     if (!Hplan.ready(dim)) Hplan.build(ctx, dim, Hfact.d(), dim, Hdinv.d());
-    double* y = hess_fact_bk ? Hbk.gather(ctx, prod, ldp, 1) : prod;
-    Hplan.solve(ctx, Hfact.d(), dim, true, y);
-    if (hess_fact_bk) Hbk.dsolve(ctx, y, dim, 1);
-    Hplan.solve(ctx, Hfact.d(), dim, false, y);
-    if (hess_fact_bk) Hbk.scatter(ctx, y, prod, ldp, 1);
+    if (!hess_fact_bk) {
+      Hplan.solve_both(ctx, Hfact.d(), dim, prod, ldp, 1);
+    } else {
+      double* y = Hbk.gather(ctx, prod, ldp, 1);
+      Hplan.solve(ctx, Hfact.d(), dim, true, y);
+      Hbk.dsolve(ctx, y, dim, 1);
+      Hplan.solve(ctx, Hfact.d(), dim, false, y);
+      Hbk.scatter(ctx, y, prod, ldp, 1);
+    }
   } else if (ncols == 2 && ctx.trsv_plan_sb(dim) > 0) {   // the pair of the proximity test (Cone::prox_launch): the same sweeps on two columns
     if (!Hplan.ready(dim)) Hplan.build(ctx, dim, Hfact.d(), dim, Hdinv.d());
-    double* y = hess_fact_bk ? Hbk.gather(ctx, prod, ldp, 2) : prod;
-    const long ldy = hess_fact_bk ? (long)dim : ldp;
-    Hplan.solve_multi(ctx, Hfact.d(), dim, true, y, ldy, 2);
-    if (hess_fact_bk) Hbk.dsolve(ctx, y, dim, 2);
-    Hplan.solve_multi(ctx, Hfact.d(), dim, false, y, ldy, 2);
-    if (hess_fact_bk) Hbk.scatter(ctx, y, prod, ldp, 2);
+    if (!hess_fact_bk) {
+      Hplan.solve_both(ctx, Hfact.d(), dim, prod, ldp, 2);
+    } else {
+      double* y = Hbk.gather(ctx, prod, ldp, 2);
+      Hplan.solve_multi(ctx, Hfact.d(), dim, true, y, dim, 2);
+      Hbk.dsolve(ctx, y, dim, 2);
+      Hplan.solve_multi(ctx, Hfact.d(), dim, false, y, dim, 2);
+      Hbk.scatter(ctx, y, prod, ldp, 2);
+    }
   } else if (hess_fact_bk) {   // ldiv!(::BunchKaufman, .)
     Hbk.solve(ctx, Hfact.d(), dim, Hdinv.d(), prod, ldp, ncols, trsm_work);
   } else if (ncols == 1) {

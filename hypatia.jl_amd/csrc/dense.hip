@@ -1046,9 +1046,11 @@ void TriSolvePlan::build(Ctx& c, int n_, const double* U, long ldu, const double
   if (!split) dev_transpose(c, n_, n_, U, ldu, UT.d(), n_, 1, 0, 0);
   if (split) HYP_CHECK(hipStreamWaitEvent(c.stream, e1, 0));
   n = n_;
+  ol_prepare(c, ldu);
 }
 
 void TriSolvePlan::solve(Ctx& c, const double* U, long ldu, bool trans, double* x) {
+  if (ol_usable(c, ldu)) { ol_sweep(c, U, trans ? 0 : 1, x, 0, nullptr, 1); return; }
   const int nsb = (n + sb - 1) / sb;
   const size_t blk = (size_t)sb * sb;
   double* t = work.d();
@@ -1466,6 +1468,7 @@ Ctx::Ctx(int dev) : device(dev) {
   int plo = 0, phi = 0;
   HYP_CHECK(hipDeviceGetStreamPriorityRange(&plo, &phi));   // (numerically lower = higher priority)
   HYP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, phi));
+  stream_primary = stream;
   HYP_CHECK(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, plo));
   if (const char* e = getenv("HYP_TRSV_SB")) { trsv_sb = (atoi(e) / NB) * NB; trsv_sb_forced = true; }
   scratch.alloc(1 << 20);

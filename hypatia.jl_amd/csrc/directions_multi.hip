@@ -579,6 +579,7 @@ static void coldot3(Ctx& c, int m, int ncols, int mode, const double* M, long ld
 // the pair x[:, 0:2] (leading dimension ldx) and a third right-hand side x3 through the super-block sweeps together: the steps of
 // solve_multi (nr = 2) and solve() with every product of the three columns in one launch
 void TriSolvePlan::solve_multi3(Ctx& c, const double* U, long ldu, bool trans, double* x, long ldx, double* x3) {
+  if (ol_usable(c, ldu)) { ol_sweep(c, U, trans ? 0 : 1, x, ldx, x3, MR + 1); return; }
   const int nsb = (n + sb - 1) / sb;
   const size_t blk = (size_t)sb * sb;
   work.ensure((size_t)2 * (MR + 1) * sb * sizeof(double));
@@ -615,7 +616,18 @@ void TriSolvePlan::solve_multi3(Ctx& c, const double* U, long ldu, bool trans, d
   HYP_CHECK(hipGetLastError());
 }
 
+void TriSolvePlan::solve_both(Ctx& c, const double* U, long ldu, double* x, long ldx, int nr, double* x3) {
+  HYP_REQUIRE(nr >= 1 && nr <= MR + 1 && (!x3 || nr == MR + 1), "TriSolvePlan::solve_both: 1, 2 or 3 right-hand sides");
+  static const bool fused = [] { const char* e = getenv("HYP_TRSV_ONE_LAUNCH"); return !(e && atoi(e) == 1); }();   // (1: one launch per sweep)
+  if (fused && ol_usable(c, ldu)) { ol_sweep(c, U, 2, x, ldx, x3, nr); return; }
+  for (int pass = 0; pass < 2; ++pass) {
+    if (x3) solve_multi3(c, U, ldu, pass == 0, x, ldx, x3);
+    else solve_multi(c, U, ldu, pass == 0, x, ldx, nr);
+  }
+}
+
 void TriSolvePlan::solve_multi(Ctx& c, const double* U, long ldu, bool trans, double* x, long ldx, int nr) {
+  if (ol_usable(c, ldu) && nr >= 1 && nr <= MR + 1) { ol_sweep(c, U, trans ? 0 : 1, x, ldx, nullptr, nr); return; }
   if (nr == 1) {
     solve(c, U, ldu, trans, x);
     return;
@@ -677,15 +689,16 @@ void SysSolver::solve3_multi(double* sol, const double* rhs, int nr, double* x_t
     double* y = use_bk ? bk.gather(ctx, sol, ld3, nr) : sol;   // Bunch-Kaufman factor: P before, D^-1 between, P' after
     const long ldy = use_bk ? nmp : ld3;
     if (x_third && !use_bk && nr == MR) {   // (the constant column's triangular solves ride along: see step_directions)
-      tri.solve_multi3(ctx, lhs_fact.d(), nmp, true, y, ldy, x_third);
-      tri.solve_multi3(ctx, lhs_fact.d(), nmp, false, y, ldy, x_third);
+      tri.solve_both(ctx, lhs_fact.d(), nmp, y, ldy, MR + 1, x_third);
     } else if (!x_third && !use_bk && nr == MR + 1) {   // (the constant column as third column of the pair: the same launches)
-      tri.solve_multi3(ctx, lhs_fact.d(), nmp, true, y, ldy, y + (long)MR * ldy);
-      tri.solve_multi3(ctx, lhs_fact.d(), nmp, false, y, ldy, y + (long)MR * ldy);
+      tri.solve_both(ctx, lhs_fact.d(), nmp, y, ldy, MR + 1, y + (long)MR * ldy);
+    } else if (!use_bk) {
+      HYP_REQUIRE(!x_third, "solve3_multi: the third column needs the Cholesky factor's plan");
+      tri.solve_both(ctx, lhs_fact.d(), nmp, y, ldy, nr);
     } else {
       HYP_REQUIRE(!x_third, "solve3_multi: the third column needs the Cholesky factor's plan");
       tri.solve_multi(ctx, lhs_fact.d(), nmp, true, y, ldy, nr);
-      if (use_bk) bk.dsolve(ctx, y, ldy, nr);
+      bk.dsolve(ctx, y, ldy, nr);
       tri.solve_multi(ctx, lhs_fact.d(), nmp, false, y, ldy, nr);
     }
     if (use_bk) bk.scatter(ctx, y, sol, ld3, nr);

@@ -81,6 +81,7 @@ struct Ctx {
   double kstat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipStream_t stream2 = nullptr;            // helper stream: look-ahead trailing updates of the blocked Cholesky
+  hipStream_t stream_primary = nullptr;     // the main stream's handle (c.stream unless a StreamSwap / LaneSwitch section is open)
   std::vector<hipEvent_t> ev_pool;          // ordering events between stream and stream2
   hipEvent_t pool_event(size_t i);
   hipEvent_t aux[4] = {nullptr, nullptr, nullptr, nullptr};   // fork / join events of the two-stream sections (not the look-ahead pool)
@@ -101,6 +102,7 @@ struct Ctx {
   DBuf potrf_tinv;         // blocked Cholesky: inverses of the 16 x 16 diagonal tiles, per block step (potrf_upper_batched)
   DBuf work_tri;           // workspace of trtri_upper_batched
   DBuf ts_ws;              // PSD two-sided product: zero-padded copy of the factor + the padded intermediates Z_j (psd_twosided.hip)
+  long bk_hybrid_count = 0, bk_guard_trims = 0, bk_plain_count = 0;   // fall-backs behind a failed Cholesky: hybrid / trimmed by the guard / plain (hyp_ctx_bk_stats)
   int diag_own_cu_lds = -1;   // dynamic LDS that gives the critical-path diagonal-block kernel a CU of its own (-1: not asked yet, 0: refused)
   int trsv_sb = 1024;      // largest super-block of the one-right-hand-side triangular solves (HYP_TRSV_SB; 0 = per-128-block path)
   bool trsv_sb_forced = false;   // HYP_TRSV_SB given: that size, plan from 2 super-blocks on (the round-1 rule)
@@ -209,6 +211,19 @@ struct TriSolvePlan {
   bool ready(int n_) const { return n == n_ && n_ > 0; }
   void invalidate() { n = 0; }
   void build(Ctx& c, int n_, const double* U, long ldu, const double* dinv);
+  // Round 5 (trsv_onelaunch.hip): the same sweeps -- the same sums, bitwise -- as ONE launch each, or one for both sweeps of a
+  // Cholesky potrs; products hand their vectors over through an arena of self-flagging words.  HYP_TRSV_ONE_LAUNCH=0: the launch chains.
+  DBuf ol_rounds, ol_arena;
+  bool ol_ok = false;
+  int ol_n = 0, ol_sb = 0, ol_refine = -1, ol_set = 0;
+  long ol_ldu = 0, ol_asz = 0;
+  int ol_first[3] = {0, 0, 0}, ol_n0[3] = {0, 0, 0}, ol_n1[3] = {0, 0, 0};
+  void ol_prepare(Ctx& c, long ldu);
+  // only on the context's main stream: two such launches side by side on two streams could each hold CUs the other's wavefronts wait for
+  bool ol_usable(const Ctx& c, long ldu) const { return ol_ok && ldu == ol_ldu && c.stream == c.stream_primary; }
+  void ol_sweep(Ctx& c, const double* U, int which, double* x, long ldx, double* x3, int nr);
+  // both sweeps, x <- (U'U)^-1 x on nr = 1, 2 or 3 columns (x3 != nullptr: the third column lives there instead of x + 2 ldx)
+  void solve_both(Ctx& c, const double* U, long ldu, double* x, long ldx, int nr, double* x3 = nullptr);
   void solve(Ctx& c, const double* U, long ldu, bool trans, double* x);
   void solve_multi(Ctx& c, const double* U, long ldu, bool trans, double* x, long ldx, int nr);   // nr <= 2 right-hand sides
   void solve_multi3(Ctx& c, const double* U, long ldu, bool trans, double* x, long ldx, double* x3);   // the pair x[:, 0:2] and a third vector x3 together
@@ -223,6 +238,9 @@ struct BKFact {
   int n_2x2 = 0;                  // number of 2x2 pivot blocks of the last factorization
   DBuf dd, de, blk, perm;         // diagonal / off-diagonal of D, block marks (0: 1x1, 1 / 2: rows of a 2x2), P as a gather map
   DBuf state, wl, tmp, tr;        // tr: n x n work matrix (the factorization runs on the transposed triangle)
+  DBuf guard;                     // bk_after_failed_cholesky: per kept block step min pivot^2 / max row entry^2
+  int k0_used = 0;                // column the last bk_after_failed_cholesky started its rook-pivoted elimination from (0: plain)
+  int guard_trimmed = 0;          // block steps the growth guard refused to keep in that call
   // A: upper triangle in, U out.  dinv (dinv_elems(n) doubles, may be null) receives the inverted diagonal
   // blocks for trsv_upper / trsm_upper_left / TriSolvePlan.  Returns LAPACK's info: 0 or the 1-based index of the
   // first exactly singular pivot (issuccess(fact) = info == 0).  Synchronizes.
@@ -242,7 +260,10 @@ struct BKFact {
 // chol_info = the 1-based pivot the Cholesky failed at (0: unknown / forced: the plain rook-pivoted factorization from column 0).
 // With the failing pivot in block step kb >= 1 the first kb block steps are redone as Cholesky steps and only the trailing block is
 // eliminated with rook pivoting (BKFact::factor_from; HYP_BK_HYBRID=0: always from column 0).  Returns BKFact's info.
-int bk_after_failed_cholesky(Ctx& c, BKFact& bk, int n, double* A, long lda, double* dinv, int* d_info_scratch, int chol_info);
+// Round 5: a kept block step must pass the growth guard (pivot^2 >= n eps max|a_ii|, row entries^2 <= 16 max|a_ii|); the steps from the
+// first offender on are not kept (the matrix is taken again from A_src, leading dimension ld_src: the caller's untouched copy).
+int bk_after_failed_cholesky(Ctx& c, BKFact& bk, int n, double* A, long lda, double* dinv, int* d_info_scratch, int chol_info,
+                             const double* A_src, long ld_src);
 // Y[:, r] = alpha op(A) X[:, r] + beta Y[:, r] for r < nr <= 2: one pass over A serves all right-hand sides
 void gemv_multi(Ctx& c, bool trans, int m, int n, int nr, double alpha, const double* A, long lda, const double* X, long ldx, double beta,
                 double* Y, long ldy);

@@ -597,7 +597,7 @@ void SysSolver::factor_lhs(int* info, int* used_fallback) {   // qrchol.jl:249-2
     *used_fallback = 1;
     const int chol_info = force_bk ? 0 : *info;
     ctx.d2d(lhs_fact.p, lhs.p, (size_t)nmp * nmp * sizeof(double));
-    *info = bk_after_failed_cholesky(ctx, bk, nmp, lhs_fact.d(), nmp, dinv.d(), d_info.i(), chol_info);
+    *info = bk_after_failed_cholesky(ctx, bk, nmp, lhs_fact.d(), nmp, dinv.d(), d_info.i(), chol_info, lhs.d(), nmp);
     if (*info != 0) {
       *used_fallback = 2;
       ctx.d2d(lhs_fact.p, lhs.p, (size_t)nmp * nmp * sizeof(double));
@@ -617,6 +617,7 @@ void SysSolver::factor_lhs(int* info, int* used_fallback) {   // qrchol.jl:249-2
 // x <- lhs^-1 x.  Cholesky: U'^-1 then U^-1.  Bunch-Kaufman: the same two sweeps with the unit factor, between a
 // gather by P, the block-diagonal solve and a scatter.
 void SysSolver::tri_solves(double* d_x) {
+  if (!use_bk && tri.ready(nmp)) { tri.solve_both(ctx, lhs_fact.d(), nmp, d_x, nmp, 1); return; }
   double* y = use_bk ? bk.gather(ctx, d_x, nmp, 1) : d_x;
   for (int pass = 0; pass < 2; ++pass) {
     const bool trans = (pass == 0);

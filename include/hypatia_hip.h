@@ -37,6 +37,10 @@ int hyp_reset_timers(hyp_ctx* ctx);
  * library stream: out8 = [sqrt-Hessian products, Schur syrk, Cholesky, #update_lhs_fact, #syrk launches, #Hessian factorizations of
  * generic cones (Cones.jl:239-251), #Bunch-Kaufman factorizations (dense.jl:164-165), #gradients of generic-Hessian cones] */
 int hyp_get_kernel_stats(hyp_ctx* ctx, double* out8);
+/* fall-backs behind a failed Cholesky since the context was created (posdef_fact_copy!'s second link, dense.jl:194-215, symm_fact!
+ * :164-165): out3 = [hybrid factorizations (Cholesky block steps kept in front of the rook-pivoted trailing block), calls in which the
+ * growth guard refused kept steps, plain rook-pivoted factorizations from column 0] */
+int hyp_ctx_bk_stats(hyp_ctx* ctx, long long* out3);
 
 /* ---- cone lifecycle: constructors of src/Cones/nonnegative.jl:27-33, possemideftri.jl:36-46 --- */
 int hyp_cone_create_nonnegative(hyp_ctx* ctx, int dim, hyp_cone** out);
@@ -308,12 +312,14 @@ int hyp_dense_posv_multi(hyp_ctx* ctx, int n, double* A, int lda, double* X, int
  * describe the factorization: perm[i] = original index in position i; blk[i] = 0 for a 1x1 pivot d[i], 1 / 2 for
  * the two rows of a 2x2 pivot [[d[i], e[i]], [e[i], d[i+1]]].  x (n x nrhs, ld ldx) is overwritten with A^-1 x.
  * info = 0, or the 1-based position of the first exactly singular pivot (LAPACK dsytrf_rook). */
-/* posdef_fact_copy! + ldiv! on a host matrix (dense.jl:194-215): Cholesky, and behind a failed one the symmetric indefinite
- * factorization -- the Cholesky steps in front of the failing pivot's 128-column block kept, rook pivoting (dsytrf_rook's rule) on
- * the trailing block only; bk_start = the column it started from (0: the whole matrix, also with HYP_BK_HYBRID=0) */
-int hyp_dense_posdef_solve(hyp_ctx* ctx, int n, double* A, int lda, double* x, int nrhs, int ldx, int* info, int* used_fallback, int* bk_start);
 int hyp_dense_sysv_rook(hyp_ctx* ctx, int n, double* A, int lda, double* x, int nrhs, int ldx, int* info, int* perm, int* blk,
                         double* d, double* e);
+/* posdef_fact_copy! + ldiv! on a host matrix (dense.jl:194-215): Cholesky, and behind a failed one the symmetric indefinite
+ * factorization -- the Cholesky steps in front of the failing pivot's 128-column block kept WHERE their pivots and rows pass the growth guard
+ * (pivot^2 >= n eps max|a_ii|, row entries^2 <= 16 max|a_ii|: what an unpivoted elimination needs to stay bounded), rook pivoting
+ * (dsytrf_rook's rule) on the trailing block only; bk_start = the column it started from (0: the whole matrix, also with
+ * HYP_BK_HYBRID=0 or when the first block step already fails the guard) */
+int hyp_dense_posdef_solve(hyp_ctx* ctx, int n, double* A, int lda, double* x, int nrhs, int ldx, int* info, int* used_fallback, int* bk_start);
 /* Column-pivoted Householder QR on the device with LAPACK dgeqp3's semantics (= Julia's qr!(AG, ColumnNorm()) of
  * find_initial_x, src/Solvers/process.jl:64-178; the rank decision of :373-382 reads the diagonal of R).  A is m x n column-major
  * (host, copied); rhs (m entries, may be NULL) rides along as an extra column: after the factorization it holds Q' rhs.
@@ -343,10 +349,10 @@ int hyp_dense_gemv_both(hyp_ctx* ctx, int m, int n, int nr, const double* A, int
 /* Measurement helper: HIP-event time (ms, mean of reps) of the blocked upper Cholesky of an n x n positive definite matrix
  * resident in HBM (posdef_fact_copy!'s first link, src/linearalgebra/dense.jl:194-200). */
 int hyp_bench_potrf(hyp_ctx* ctx, int n, int reps, double* ms_out);
-/* Measurement helper for the one- and two-right-hand-side potrs of qrchol.jl:68 on an n x n factor resident in HBM: HIP-event
- * times (ms, mean of reps) of [0] building the super-block solve plan, [1] U'^-1 then U^-1 on one vector, [2] on two vectors.
- * x_out (3 n doubles, may be NULL): the solutions of the last repetition (one vector, then the two), for A/B comparisons. */
-int hyp_bench_trsv(hyp_ctx* ctx, int n, int reps, double* ms_out3, double* x_out);
+/* Measurement helper for the one-, two- and three-right-hand-side potrs of qrchol.jl:68 on an n x n factor resident in HBM: HIP-event
+ * times (ms, mean of reps) of [0] building the super-block solve plan, [1] U'^-1 then U^-1 on one vector, [2] on two vectors, [3] on
+ * three.  x_out (6 n doubles, may be NULL): the solutions of the last repetition (one vector, the two, the three), for A/B comparisons. */
+int hyp_bench_trsv(hyp_ctx* ctx, int n, int reps, double* ms_out4, double* x_out);
 /* time `reps` launches of the syrk C = A'A (A is K x N) with HIP events on the library stream; ms per launch */
 int hyp_bench_syrk(hyp_ctx* ctx, int N, int K, int reps, double* ms_out);
 

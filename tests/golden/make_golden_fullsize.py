@@ -31,10 +31,11 @@ CASES = {
     "psdfull_5000_200x1_1": ({}, 3, {}, (1, 3)),                           # config 2 as benchmarked: the whole solve, and so are its three companions
     "psdfull_1300_113x1_1": ({}, 3, {}, (1,)),                             # psd_ts3 + solve plan, one column chunk
     "psdfull_2500_160x1_1": ({}, 3, {}, (1,)),
-    "cfg4_5000_80x64_1": ({"iter_limit": 2}, 1, {"iter_limit": 2}, (1, 2)),   # config 4 as benchmarked, first two iterations
+    "cfg4_5000_80x64_1": ({"iter_limit": 5}, 3, {"iter_limit": 5}, (1, 2)),   # config 4 as benchmarked, first five iterations
     "cfg5p_1": ({"iter_limit": 2}, 1, {"iter_limit": 2}, ()),              # config 5, U = 4845, primal form (n = 1)
     "cfg5d_1": ({"iter_limit": 2}, 1, {"iter_limit": 2}, (1,)),            # dual form: 4844 x 4844 Schur matrix
-    "cfg5pw_1": ({}, 1, {}, ()),                                           # config 5 primal, the WHOLE solve (46 iterations: the last dozen meet Hessians whose Cholesky fails)
+    "cfg5pw_1": ({}, 3, {"iter_limit": 10}, ()),                           # config 5 primal, the WHOLE solve (46 iterations: the last dozen meet Hessians whose Cholesky fails); companions: first 10 iterates
+    "cfg5dw_1": ({}, 3, {"iter_limit": 10}, ()),                           # config 5 dual, the WHOLE solve
 }
 
 

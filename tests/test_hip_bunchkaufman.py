@@ -226,6 +226,47 @@ def test_hybrid_factorization_behind_a_late_cholesky_failure(hip, n, nbad):
     assert info2 == 0 and np.linalg.norm(X - X2) <= 1e-6 * np.linalg.norm(Xref)
 
 
+def _growth_matrix(n, k, rng, eps=1e-13):
+    """A = Lc Mid Lc' (Lc unit lower triangular, mild): the elimination meets pivots 1, ..., 1, eps (column k), 1, ..., 1 and at the
+    very last column -1/eps: the Cholesky runs to its last pivot, yet row k of its factor has an entry 1/sqrt(eps) -- the
+    [[eps, 1], [1, 0]] example of why an unpivoted elimination has no growth bound, inside a block the hybrid path would keep"""
+    Mid = np.eye(n)
+    Mid[k, k] = eps
+    Mid[n - 1, n - 1] = 0.0
+    Mid[k, n - 1] = Mid[n - 1, k] = 1.0
+    Lc = np.tril(0.3 * rng.standard_normal((n, n)) / np.sqrt(n), -1) + np.eye(n)
+    A = Lc @ Mid @ Lc.T
+    return 0.5 * (A + A.T)
+
+
+@pytest.mark.parametrize("n,k,start_expected", [(400, 200, 128), (400, 50, 0), (700, 300, 256), (1153, 1100, 1024)])
+def test_hybrid_guard_refuses_steps_with_element_growth(hip, n, k, start_expected):
+    """round 5: a leading pivot that is positive only just (1e-13 of the diagonal) inside a block step the hybrid path
+    would keep unpivoted.  The growth guard of bk_after_failed_cholesky (pivot^2 >= n eps max|a_ii|, row entries^2 <= 16 max|a_ii|)
+    keeps only the block steps in front of it -- bk_start says so -- and the solve has LAPACK's backward error: the matrix itself is
+    perfectly conditioned (cond 3.3), it is the unpivoted elimination that would lose 13 digits (row k of the factor reaches 1/sqrt(eps));
+    dsytrf_rook's growth is bounded (reference: symm_fact!, src/linearalgebra/dense.jl:164-165, 194-215)"""
+    lib, ctx, L = hip
+    rng = np.random.default_rng(n + k)
+    A = _growth_matrix(n, k, rng)
+    B = rng.standard_normal((n, 2))
+    Ad = np.asfortranarray(np.triu(A) + np.tril(np.full((n, n), -3.25), -1))
+    X = np.asfortranarray(B.copy())
+    st0 = (ctypes.c_longlong * 3)()
+    L.check(lib.hyp_ctx_bk_stats(ctx, st0), "bk_stats")
+    info, fb, start = c_int(-1), c_int(-1), c_int(-1)
+    L.check(lib.hyp_dense_posdef_solve(ctx, n, fp(Ad), n, fp(X), 2, n, ctypes.byref(info), ctypes.byref(fb), ctypes.byref(start)), "posdef_solve")
+    assert info.value == 0 and fb.value == 1
+    assert start.value == start_expected, start.value        # (unguarded it would be ((n - 1) // 128) * 128)
+    st1 = (ctypes.c_longlong * 3)()
+    L.check(lib.hyp_ctx_bk_stats(ctx, st1), "bk_stats")
+    assert st1[1] == st0[1] + 1                              # the guard trimmed this call
+    assert (st1[0] - st0[0], st1[2] - st0[2]) == ((1, 0) if start_expected > 0 else (0, 1))
+    Xref = np.linalg.solve(A, B)
+    berr = lambda Xc: np.linalg.norm(A @ Xc - B) / (np.linalg.norm(A, 2) * np.linalg.norm(Xc) + np.linalg.norm(B))
+    assert berr(X) <= 10 * berr(Xref) + 1e-15, (berr(X), berr(Xref))
+
+
 def test_posdef_solve_cholesky_branch(hip):
     lib, ctx, L = hip
     rng = np.random.default_rng(3)

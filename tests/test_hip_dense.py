@@ -178,12 +178,34 @@ def test_superblock_solve_kernels_same_sums_with_and_without_batched_loads(tmp_p
     outs = []
     for flag in ("0", "1"):
         out = str(tmp_path / ("trsv%s.npz" % flag))
-        env = dict(os.environ, HYP_COLDOT_BATCH=flag)
+        env = dict(os.environ, HYP_COLDOT_BATCH=flag, HYP_TRSV_ONE_LAUNCH="0")
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_trsv.py"), "2300", "--dump", out], cwd=root, env=env,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.load(out)["x2300"])
     assert np.all(np.isfinite(outs[0])) and np.array_equal(outs[0], outs[1])
+
+
+def test_one_launch_triangular_sweeps_same_bits_as_the_launch_chains(tmp_path):
+    """round 5 (csrc/trsv_onelaunch.hip): both sweeps of a potrs as ONE persistent launch (default), one launch per sweep
+    (HYP_TRSV_ONE_LAUNCH=1) and the chain of one launch per column product (=0) on one, two and three right-hand sides: bitwise equal.
+    Sizes: n = 5000 (five super-blocks of 1024, a ragged last one), 4845, 2300 (three of 768), 999 (three of 384, ragged), 640
+    (256 + 256 + 128), 513 (a last super-block of one row).  qrchol.jl:66-69, Cones.jl:113-118"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sizes = ["5000", "4845", "2300", "999", "640", "513"]
+    outs = []
+    for flag in ("0", "1", "2"):
+        out = str(tmp_path / ("trsv_ol%s.npz" % flag))
+        env = dict(os.environ, HYP_TRSV_ONE_LAUNCH=flag)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_trsv.py")] + sizes + ["--dump", out], cwd=root, env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    for n in sizes:
+        a, b, c = (o["x" + n] for o in outs)
+        assert np.all(np.isfinite(a)) and np.abs(a).max() > 0
+        assert np.array_equal(a, b) and np.array_equal(a, c), n
 
 
 def test_potrf_reports_failed_minor(hip):

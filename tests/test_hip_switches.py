@@ -123,6 +123,20 @@ def test_constant_column_in_the_first_paired_solve_changes_no_bit():
         assert runs[0]["trace"] == runs[1]["trace"] == runs[2]["trace"], name
 
 
+@pytest.mark.parametrize("name", ["psd_plan", "polymin_large_primal", "polymin_large_dual"])
+def test_one_launch_triangular_sweeps_change_no_bit(name):
+    """round 5, HYP_TRSV_ONE_LAUNCH (csrc/trsv_onelaunch.hip): the super-block triangular solves of the Schur factor (potrs of
+    qrchol.jl:66-69) and of a generic cone's Hessian factor (Cones.jl:113-118) as ONE persistent launch for both sweeps (default), as
+    one launch per sweep (=1) and as the round-2 chain of one launch per product (=0).  A wavefront forms a column's product with the
+    chain kernels' loads, accumulators and shuffle tree, so every iterate must be the same to the last bit.  Models with a solve plan:
+    n = 600 (Schur factor) and U = 680 (WSOS Hessian factor, one- and two-column solves of the proximity test, both forms)"""
+    runs = [_run(name, env) for env in ({}, {"HYP_TRSV_ONE_LAUNCH": "1"}, {"HYP_TRSV_ONE_LAUNCH": "0"})]
+    assert all(r["status"] == "Optimal" for r in runs)
+    assert runs[0]["iters"] == runs[1]["iters"] == runs[2]["iters"] >= 8
+    assert runs[0]["trace"] == runs[2]["trace"] and runs[1]["trace"] == runs[2]["trace"], name
+    assert runs[0]["trials"] == runs[1]["trials"] == runs[2]["trials"]
+
+
 @pytest.mark.parametrize("name", ["psd_single", "psd_single_wide", "psd_run", "psd_trio"])
 def test_screened_schedule_walk_changes_no_bit(name):
     """round 3: for a model of one PosSemidefTri cone (or of one run of equal ones: batch = candidates x cones) the schedule walk of search_alpha screens all remaining candidates side by

@@ -11,10 +11,10 @@ if "--dump" in args:
     k = args.index("--dump"); dump = args[k + 1]; del args[k:k + 2]
 out = {}
 for n in [int(a) for a in args] or [5000, 4845, 2250]:
-    ms = (ctypes.c_double * 3)()
-    x = np.zeros(3 * n)
+    ms = (ctypes.c_double * 4)()
+    x = np.zeros(6 * n)
     rc = lib.hyp_bench_trsv(ctx, n, 10, ms, x.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
-    print("trsv n=%d: plan build %.3f ms, one vector %.3f ms, two vectors %.3f ms (rc %d)" % (n, ms[0], ms[1], ms[2], rc))
+    print("trsv n=%d: plan build %.3f ms, one vector %.3f ms, two vectors %.3f ms, three vectors %.3f ms (rc %d)" % (n, ms[0], ms[1], ms[2], ms[3], rc))
     out["x%d" % n] = x
 if dump:
     np.savez(dump, **out)
