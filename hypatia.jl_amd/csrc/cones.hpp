@@ -13,6 +13,8 @@ namespace hyp {
 bool psd_two_sided_fused_ok(int side);
 // one workgroup per matrix, the intermediate product in registers (psd_twosided4.hip); false: not applicable, nothing done
 bool psd_two_sided_onchip(Ctx& c, int side, int ncols, const double* R, int rstruct, const double* arr, long lda, double* prod, long ldp);
+// the same for sides of 3 .. 5 tiles (33 .. 80; config 4): one wavefront per matrix, all of Z in its accumulators (psd_twosided5.hip); arr may alias prod
+bool psd_two_sided_wave(Ctx& c, int side, int ncols, const double* R, int rstruct, const double* arr, long lda, double* prod, long ldp);
 void psd_two_sided_fused(Ctx& c, int side, int ncols, const double* R, int rstruct /* 0 full, 1 upper, 2 lower */, const double* arr,
                          long lda, double* prod, long ldp, double* zws /* ncols * side^2 */);
 

@@ -23,6 +23,7 @@
 // 128-byte stores into column-major Z and into the packed svec column alike.  The workgroups of one
 // matrix are 8 apart in launch order = on the same XCD, sharing V_j / Z_j in its L2.
 // Fixed summation order: bitwise reproducible.
+#include "cones.hpp"
 #include "gemm_f64.hpp"
 #include "hyp_internal.hpp"
 
@@ -688,6 +689,7 @@ void psd_two_sided_fused(Ctx& c, int side, int ncols, const double* R, int rstru
   TsArgs a{};
   a.s = side; a.T = (side + 15) / 16; a.rstruct = rstruct; a.R = R; a.ncols = ncols;
   static const bool small_on = [] { const char* e = getenv("HYP_TS_SMALL"); return !(e && e[0] == '0'); }();
+  if (small_on && psd_two_sided_wave(c, side, ncols, R, rstruct, arr, lda, prod, ldp)) return;   // (round 5: one wavefront per matrix)
   if (small_on && a.T <= 6) {   // one kernel, everything of a matrix on one CU
     a.A = arr; a.lda = lda; a.C = prod; a.ldc = ldp;
     switch (a.T) {

@@ -148,6 +148,42 @@ def test_psd_sqrt_hess_prod_on_chip_form(side, ncols):
     assert err < TOL * 10
 
 
+@pytest.mark.parametrize("side,ncols", [(33, 1000), (48, 600), (50, 513), (64, 520), (65, 2049), (79, 700), (80, 777), (80, 5000)])
+def test_psd_sqrt_hess_prod_one_wavefront_per_matrix(side, ncols):
+    """round 5: sqrt_hess_prod on >= 512 columns at sides of 3 .. 5 MFMA tiles (config 4: side 80) goes through psd_ts5_kernel (one
+    wavefront per matrix, all 25 tiles of the intermediate product in its accumulators: csrc/psd_twosided5.hip); every tile count,
+    sides on and off the tile edge, more matrices than wavefronts (5000 > 1024), strided column views, out of place and IN PLACE,
+    and hess_prod (whose first half is the same kernel), against the oracle (possemideftri.jl:126-142, 161-177)"""
+    dim = side * (side + 1) // 2
+    hc, oc = _pair("psd", dim)
+    rng = np.random.default_rng(side + ncols)
+    for c in (hc, oc):
+        c.setup_data()
+    pt = np.zeros(dim)
+    oc.set_initial_point(pt)
+    pt += 0.1 * (2 * rng.random(dim) - 1) / np.sqrt(max(1, dim / 50))
+    for c in (hc, oc):
+        c.reset_data()
+        c.load_point(pt, 1.3)
+        assert c.is_feas()
+        c.get_grad()
+    big_in = np.asfortranarray(rng.standard_normal((dim + 3, ncols)))
+    for name in ("sqrt_hess_prod", "hess_prod"):
+        out_h = np.full((dim + 2, ncols), 7.0, order="F")
+        out_o = np.full((dim + 2, ncols), 7.0, order="F")
+        getattr(hc, name)(out_h[1:1 + dim, :], big_in[2:2 + dim, :])
+        getattr(oc, name)(out_o[1:1 + dim, :], big_in[2:2 + dim, :])
+        assert rel(out_h, out_o) < TOL * 10, name
+        assert np.all(out_h[0] == 7.0) and np.all(out_h[1 + dim:] == 7.0)
+        err = np.max(np.linalg.norm(out_h[1:1 + dim] - out_o[1:1 + dim], axis=0) / np.linalg.norm(out_o[1:1 + dim], axis=0))
+        assert err < TOL * 10, name
+    # in place
+    io = np.asfortranarray(big_in[2:2 + dim, :].copy())
+    hc.sqrt_hess_prod(io, io)
+    oc.sqrt_hess_prod(out_o[1:1 + dim, :], big_in[2:2 + dim, :])
+    assert rel(io, out_o[1:1 + dim]) < TOL * 10
+
+
 def test_infeasible_points_detected():
     import hypatia_jl_amd as H
     c = H.PosSemidefTri(6)

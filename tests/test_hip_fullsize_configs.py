@@ -2,7 +2,7 @@
 size-independent properties -- the CPU oracle would need minutes per iteration at these sizes:
   3b  matrix completion, EpiNormSpectral 50 x 100 (dim 5001): the largest size the reference's algorithm admits
   4   64 x PosSemidefTri(80), q = 207 360, n = 5000 (G = 8.3 GB resident)
-  5   polymin, WSOSInterpNonnegative, 4 variables, half-degree 8 (U = 4845), primal form
+  5   polymin, WSOSInterpNonnegative, 4 variables, half-degree 8 (U = 4845), primal and dual form
 Properties: the conic certificate of test/nativeinstances.jl:58-65 on the full solve (3b, 5), the Schur matrix on probe
 vectors and the KKT residual of the stepper directions (4), Hessian / inverse-Hessian identities of the big cones."""
 import numpy as np
@@ -116,6 +116,37 @@ def test_config5_polymin_primal_full_size():
     _certificate(s, inst, 1e-6)
     # the optimum is a lower bound of the sampled polynomial
     assert -s.primal_obj <= vals.min() + 1e-6
+
+
+@pytest.mark.timeout(900)
+def test_config5_polymin_dual_full_size():
+    """round 5: config 5 in the DUAL form (examples/polymin/native.jl:56-90 with use_primal = false: c = vals, A = ones(1, U), b = 1,
+    G = -I, the cone itself (not its dual); after the reduction n = U - 1 = 4844 and the 4844 x 4844 Schur matrix is the "MFMA
+    Hessian product" of BASELINE.json's configs[4]) solved to Optimal at U = 4845 and certified without barrier code: primal / dual
+    residuals, zero gap, complementarity, and s in the moment cone by its definition -- every P_k' diag(s) P_k positive
+    semidefinite (check_membership).  The optimum is the same lower bound the primal form finds (strong duality)."""
+    import hypatia_jl_amd as H
+    from oracle import polyutils as pu         # interpolation basis (data)
+    rng = np.random.default_rng(1)
+    U, pts, Ps = pu.interpolate_box([-1.0] * 4, [1.0] * 4, 8, rng=rng, sample_factor=2)
+    assert U == 4845
+    a = rng.uniform(-0.5, 0.5, 4)
+    vals = np.sum((pts - a) ** 2, axis=1) + (pts[:, 0] * pts[:, 1] - pts[:, 2] * pts[:, 3]) ** 2 + 0.3 * pts[:, 0] * pts[:, 2]
+    inst = (vals, np.ones((1, U)), np.array([1.0]), -np.eye(U), np.zeros(U), [("wsosinterpnonnegative", U, Ps, True)], {})
+    s = H.Solver(verbose=False)
+    s.load(H.make_model(inst))
+    s.solve()
+    _certificate(s, inst, 1e-6)
+    # a probability-like measure on the points (x >= 0 in the moment cone, sum x = 1) whose mean value is the bound
+    x = s.get_x()
+    assert abs(x.sum() - 1.0) <= 1e-6 and abs(vals @ x - s.primal_obj) <= 1e-8 * (1 + abs(s.primal_obj))
+    assert s.primal_obj <= vals.min() + 1e-6
+    # the primal form of the same polynomial reaches the same value
+    instp = (np.array([-1.0]), np.zeros((0, 1)), np.zeros(0), np.ones((U, 1)), vals, [("wsosinterpnonnegative", U, Ps, False)], {})
+    sp = H.Solver(verbose=False)
+    sp.load(H.make_model(instp))
+    sp.solve()
+    assert sp.status == "Optimal" and abs(-sp.primal_obj - s.primal_obj) <= 1e-6 * (1 + abs(s.primal_obj))
 
 
 @pytest.mark.timeout(1200)

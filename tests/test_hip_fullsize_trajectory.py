@@ -37,7 +37,8 @@ def _probes():
 
 def test_fullsize_fixtures_cover_the_benchmarked_configurations():
     """(CPU) the committed rows exist for config 2 as benchmarked (whole solve), two mid sizes, config 4 and config 5 in both forms"""
-    for name in ("psdfull_5000_200x1_1", "psdfull_1300_113x1_1", "psdfull_2500_160x1_1", "cfg4_5000_80x64_1", "cfg5p_1", "cfg5d_1"):
+    for name in ("psdfull_5000_200x1_1", "psdfull_1300_113x1_1", "psdfull_2500_160x1_1", "cfg4_5000_80x64_1", "cfg5p_1", "cfg5d_1", "cfg5pw_1",
+                 "cfg5dw_1"):
         assert name in CASES, name
         rec = CASES[name]
         rows = np.array(rec["rows"])
@@ -45,6 +46,11 @@ def test_fullsize_fixtures_cover_the_benchmarked_configurations():
         assert all(len(p) >= 2 for p in rec["perturbed_rows"])
     assert CASES["psdfull_5000_200x1_1"]["status"] == "Optimal" and CASES["psdfull_5000_200x1_1"]["q"] == 20100
     assert CASES["cfg4_5000_80x64_1"]["q"] == 64 * 3240 and CASES["cfg5p_1"]["q"] == 4845
+    # round 5: config 5 to the end in both forms (three perturbed companions for the first ten iterates), config 4 five iterations deep
+    for name in ("cfg5pw_1", "cfg5dw_1"):
+        assert CASES[name]["status"] == "Optimal" and not CASES[name]["opts"] and len(CASES[name]["perturbed_rows"]) == 3
+        assert all(len(p) == 11 for p in CASES[name]["perturbed_rows"])
+    assert CASES["cfg4_5000_80x64_1"]["num_iters"] == 5 and len(CASES["cfg4_5000_80x64_1"]["perturbed_rows"]) == 3
     P = _probes()
     assert set(P["psdfull_5000_200x1_1"]) == {1, 3} and P["psdfull_5000_200x1_1"][1]["diag"].shape == (5000,)
 
@@ -81,6 +87,12 @@ def test_hip_fullsize_trajectory_matches_oracle(name, route):
     if not truncated:
         assert abs(ht["iters"] - rec["num_iters"]) <= 3, (ht["iters"], rec["num_iters"])
         assert abs(ht["p_obj"] - rec["primal_obj"]) <= 1e-7 * (1 + abs(rec["primal_obj"]))
+    if name.startswith(("cfg5pw", "cfg5dw")) and route == "default":
+        # the whole solves of config 5 exist to put the fall-back behind a failed Cholesky of the cone Hessian (dense.jl:194-215) --
+        # on the default route the hybrid form that keeps the Cholesky's finished block steps, csrc/bunchkaufman.hip -- inside an
+        # oracle-compared solve at U = 4845: the comparison must not pass without it having run
+        hybrid, trimmed, plain = ht["bk_stats"]
+        assert hybrid >= 1, ht["bk_stats"]
     if route != "default":
         return
     gp = _probes().get(name, {})

@@ -269,6 +269,9 @@ if __name__ == "__main__":
     probes = {}
     s, t = run_trajectory(Hm.Solver, Hm.make_model(instance(nm)), probe_iters=tuple(opts.pop("probe_iters", ())), probes=probes, **opts)
     screens = list(s.syssolver.search_screen_stats()) if hasattr(s.syssolver, "search_screen_stats") else [0, 0]
+    import ctypes
+    bk = (ctypes.c_longlong * 3)()
+    Hm._lib.check(Hm._lib.lib().hyp_ctx_bk_stats(Hm._lib.ctx(), bk), "bk_stats")
     print(json.dumps(dict(status=s.status, iters=s.num_iters, p_obj=s.primal_obj, rows=t.tolist(), screens=screens,
-                          trials=int(s.stepper.searcher.n_trials),
+                          trials=int(s.stepper.searcher.n_trials), bk_stats=[int(v) for v in bk],
                           probes={str(k): {f: v.tolist() for f, v in p.items()} for k, p in probes.items()})))
