@@ -203,6 +203,10 @@ def emit_json_line(out):
         pass
 
 
+SITE_NAMES = ["schur_sum", "solve_Gtz", "solve_htz", "residual_fused", "residual_htz", "residual_norm", "constant_column", "screen_a", "screen_b",
+              "trial_sums", "trial_closing", "residual_products", "host_requested", "screen_agreement", "schur_incl_pack", "other"]
+
+
 def main_multi(args, world, rank, local_rank):
     """N > 1.  --config 4 (default): the fixed 64 x PosSemidefTri(80) instance, cones partitioned over the ranks (strong scaling);
     --config 2w: one PosSemidefTri(side) block per rank (weak scaling).  Schur matrices summed by one all-reduce per iteration."""
@@ -296,8 +300,11 @@ def _run_cone_sharded(args, world, rank, comm, H, D, torch):
     torch.cuda.synchronize()
     n_coll0 = comm.n_collectives          # (setup -- the LSQR initial point, rescaling -- and warmup are not counted)
     cs0 = np.zeros(2)
+    ct0, ch0 = np.zeros(16), np.zeros(16, dtype=np.int64)
     try:
         H._lib.check(lib.hyp_sys_comm_stats(solver.syssolver.local._h, H._lib.vec_ptr(cs0)), "hyp_sys_comm_stats")
+        H._lib.check(lib.hyp_sys_comm_times(solver.syssolver.local._h, H._lib.vec_ptr(ct0)), "hyp_sys_comm_times")
+        H._lib.check(lib.hyp_sys_comm_hist(solver.syssolver.local._h, ch0.ctypes.data_as(ctypes.c_void_p)), "hyp_sys_comm_hist")
     except Exception:
         pass
     if comm.hist is not None:
@@ -316,10 +323,24 @@ def _run_cone_sharded(args, world, rank, comm, H, D, torch):
     ks = (ctypes.c_double * 8)()
     lib.hyp_get_kernel_stats(ctx, ks)
     cs = np.zeros(2)
+    ct, chh = np.zeros(16), np.zeros(16, dtype=np.int64)
     try:
         H._lib.check(lib.hyp_sys_comm_stats(solver.syssolver.local._h, H._lib.vec_ptr(cs)), "hyp_sys_comm_stats")
+        H._lib.check(lib.hyp_sys_comm_times(solver.syssolver.local._h, H._lib.vec_ptr(ct)), "hyp_sys_comm_times")
+        H._lib.check(lib.hyp_sys_comm_hist(solver.syssolver.local._h, chh.ctypes.data_as(ctypes.c_void_p)), "hyp_sys_comm_hist")
     except Exception:
         pass
+    # what every rank saw (the first N > 1 run must say where a shortfall comes from): per rank its phases, its Schur exchange -- the
+    # collective alone and with the triangle's pack / unpack --, its small exchanges, and how long it waited at the end of the region
+    steps_ = max(args.steps, 1)
+    dct, dch = ct - ct0, chh - ch0
+    small_ms = float(dct[1:14].sum() + dct[15])
+    mine_row = np.array([ks[0] / steps_, ks[1] / steps_, ks[2] / steps_, solver.time_upsys / steps_ * 1e3, solver.time_getdir / steps_ * 1e3,
+                         solver.time_search / steps_ * 1e3, dct[0] / steps_, dct[14] / steps_, small_ms / steps_, float(dch[0]) / steps_,
+                         float(dch[1:14].sum() + dch[15]) / steps_, float(len(mine))])
+    table = np.zeros((world, mine_row.size))
+    table[rank] = mine_row
+    comm.allreduce(table)
     if rank == 0:
         syrk_ms = ks[1] / max(ks[4], 1)
         q_local = dim * len(mine)
@@ -352,6 +373,15 @@ def _run_cone_sharded(args, world, rank, comm, H, D, torch):
             "collectives_per_step": (n_coll + cs[0] - cs0[0]) / max(args.steps, 1),
             "library_exchanges_per_step": (cs[0] - cs0[0]) / max(args.steps, 1),
             "library_exchange_MB_per_step": (cs[1] - cs0[1]) * 8e-6 / max(args.steps, 1),
+            # device time of the exchanges on rank 0 (HIP events around each ncclAllReduce on the library's stream; host clock around the
+            # callback on the torch transport), per iteration
+            "schur_allreduce_ms": dct[0] / steps_,
+            "schur_exchange_ms_incl_pack": dct[14] / steps_,
+            "small_collectives_ms_per_step": small_ms / steps_,
+            "small_collectives_ms_by_site": {SITE_NAMES[i]: dct[i] / steps_ for i in range(16) if i not in (0, 14) and dct[i] > 0},
+            "per_rank_ms_per_step": {"columns": ["sqrt_hess_prod", "syrk", "cholesky", "update_lhs", "get_directions", "search", "schur_allreduce",
+                                                 "schur_exchange_incl_pack", "small_collectives", "schur_exchanges", "small_exchanges", "cones"],
+                                     "rows": [[round(float(v), 4) for v in row] for row in table]},
             "setup_s": t_setup, "instance_generation_s": t_gen,
             "same_workload_1gpu": ref_1gpu(args.config),
         }

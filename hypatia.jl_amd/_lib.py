@@ -107,6 +107,7 @@ SIGNATURES = {
     "hyp_sys_residual_products2": [c_vp, c_vp, c_vp, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp],
     "hyp_sys_set_comm_layout": [c_vp, c_int, c_int],
     "hyp_sys_comm_hist": [c_vp, c_vp],
+    "hyp_sys_comm_times": [c_vp, c_vp],
     "hyp_sys_allreduce_host": [c_vp, c_vp, c_int, c_int],
     "hyp_sys_load_model": [c_vp, c_vp, c_vp, c_vp, c_vp],
     "hyp_sys_update_lhs": [c_vp, P(c_int), P(c_int), P(c_int), c_vp],

@@ -729,6 +729,12 @@ int hyp_sys_set_kshard(hyp_sys* sys, int rank, int world) {
   sys->s->ks_world = world;
   API_END(sys->ctx)
 }
+int hyp_sys_comm_times(hyp_sys* sys, double* out16) {
+  API_BEGIN
+  sys->s->comm_times_flush();
+  for (int i = 0; i < 16; ++i) out16[i] = sys->s->comm_ms[i];
+  API_END(sys->ctx)
+}
 int hyp_sys_comm_stats(hyp_sys* sys, double* out2) {
   API_BEGIN
   out2[0] = (double)sys->s->comm_calls;

@@ -294,11 +294,42 @@ __global__ void tri_pack_kernel(int n, const double* __restrict__ A, long lda, d
   else P[(long)j * (j + 1) / 2 + i] = A[(long)j * lda + i];
 }
 
+hipEvent_t SysSolver::comm_event() {
+  if (!comm_ev_free.empty()) { hipEvent_t e = comm_ev_free.back(); comm_ev_free.pop_back(); return e; }
+  hipEvent_t e;
+  HYP_CHECK(hipEventCreate(&e));
+  return e;
+}
+void SysSolver::comm_time_begin(int site, hipEvent_t* a) {
+  (void)site;
+  if (comm_ev_pending.size() >= 2048) comm_times_flush();   // (bounded: a flush waits for the newest pending pair)
+  *a = comm_event();
+  HYP_CHECK(hipEventRecord(*a, ctx.stream));
+}
+void SysSolver::comm_time_end(int site, hipEvent_t a) {
+  hipEvent_t b = comm_event();
+  HYP_CHECK(hipEventRecord(b, ctx.stream));
+  comm_ev_pending.push_back(CommEv{a, b, site & 15});
+}
+void SysSolver::comm_times_flush() {
+  for (const CommEv& e : comm_ev_pending) {
+    HYP_CHECK(hipEventSynchronize(e.b));
+    float ms = 0;
+    HYP_CHECK(hipEventElapsedTime(&ms, e.a, e.b));
+    comm_ms[e.site] += ms;
+    comm_ev_free.push_back(e.a);
+    comm_ev_free.push_back(e.b);
+  }
+  comm_ev_pending.clear();
+}
+
 void SysSolver::allreduce_lhs() {
   const bool have = (comm_fn != nullptr || rccl_comm != nullptr);
   if (!have || (ks_world <= 1 && !dist())) return;
   const int kw = ks_world;
   ks_world = 1;   // (allreduce_dev is the cone-sharded mode's entry point: borrow it)
+  hipEvent_t ev_whole = nullptr;
+  comm_time_begin(14, &ev_whole);
   try {
     // only the upper triangle is meaningful (syrk 'U'): the ranks exchange its n (n + 1) / 2 entries, not the n^2 of the
     // square buffer -- half the bytes over xGMI for two passes over the matrix in HBM
@@ -314,6 +345,7 @@ void SysSolver::allreduce_lhs() {
     throw;
   }
   ks_world = kw;
+  comm_time_end(14, ev_whole);
 }
 
 void SysSolver::allreduce_dev(double* d_buf, long count, int op, int site) {
@@ -322,13 +354,18 @@ void SysSolver::allreduce_dev(double* d_buf, long count, int op, int site) {
   comm_doubles += (double)count;
   comm_hist[site & 15] += 1;
   if (rccl_comm) {   // in place, on the library stream: the consumers of d_buf are queued behind it
+    hipEvent_t ea = nullptr;
+    comm_time_begin(site, &ea);
     rccl_allreduce_inplace(rccl_comm, d_buf, count, op, ctx.stream);
+    comm_time_end(site, ea);
     return;
   }
   HYP_REQUIRE(count <= comm_cap, "sys: all-reduce payload exceeds the registered staging buffer");
   ctx.d2d(comm_stage, d_buf, (size_t)count * sizeof(double));
   ctx.sync();
+  const auto t0 = std::chrono::steady_clock::now();
   HYP_REQUIRE(comm_fn(comm_user, count, op) == 0, "sys: all-reduce callback failed");
+  comm_ms[site & 15] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   ctx.d2d(d_buf, comm_stage, (size_t)count * sizeof(double));
 }
 // the tail of a fused exchange: sums in place, this rank's maxima in its slots, zeros in the other ranks' slots

@@ -87,6 +87,17 @@ struct SysSolver {
   DBuf ar_dev;   // device staging of allreduce_host for payloads beyond the context's 32 scalar slots
   void allreduce_host(double* h_buf, int count, int op, int site = 15);
   long comm_hist[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // Round 5: device time of the exchanges by site (hyp_sys_comm_times), so that an N-GPU run says where a shortfall comes from.
+  // RCCL in the library: a HIP-event pair around every collective on the library's stream (resolved lazily: comm_times_flush);
+  // callback transport: host clock around the callback.  Slot 14: the Schur exchange INCLUDING its triangle pack / unpack kernels.
+  double comm_ms[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  struct CommEv { hipEvent_t a, b; int site; };
+  std::vector<CommEv> comm_ev_pending;
+  std::vector<hipEvent_t> comm_ev_free;
+  hipEvent_t comm_event();
+  void comm_time_begin(int site, hipEvent_t* a);
+  void comm_time_end(int site, hipEvent_t a);
+  void comm_times_flush();
   // Round 4: ONE exchange for a device payload and the scalars that used to follow it in collectives of their own.  The buffer
   // is [payload (npay) | scalars to be summed (nsum) | one slot per rank and scalar to be max-ed (world x nmax)]; a rank fills only
   // its own slots, so a SUM all-reduce returns every rank's value and the maximum (NaN wins) is taken locally -- sums and maxima

@@ -251,6 +251,11 @@ int hyp_sys_set_comm_layout(hyp_sys* sys, int rank, int world);
  * [4] residual h' z, [5] residual norm, [6] constant column, [7] [8] candidate screen, [9] [10] line-search trial, [11] residual
  * products, [12] host-requested, [13] screen agreement, [15] other */
 int hyp_sys_comm_hist(hyp_sys* sys, long long* out16);
+/* time spent in those exchanges since creation, milliseconds, by the same places (out16[i] belongs to hyp_sys_comm_hist's out16[i]):
+ * RCCL inside the library: HIP events on the library's stream around every ncclAllReduce; callback transport: host clock around the
+ * callback.  out16[14] = the Schur exchange of qrchol.jl:219-246's sum INCLUDING the pack / unpack of its upper triangle (out16[0] is
+ * its collective alone).  Synchronises with the pending exchanges. */
+int hyp_sys_comm_times(hyp_sys* sys, double* out16);
 /* K-panel sharding of ONE replicated model (a single cone: configs[1] / [2]): with a communicator (or callback) installed
  * and world > 1, hyp_sys_update_lhs / _assemble_lhs sum only rows [q rank / world, q (rank + 1) / world) of the sqrt-Hessian
  * product into the Schur matrix (the K dimension of outer_prod!, qrchol.jl:234) and all-reduce the n x n result; model,

@@ -588,6 +588,20 @@ function comm_hist(sys::HIPQRCholDenseSystemSolver)
     return out
 end
 
+# milliseconds spent in those exchanges, by the same places ([15] = slot 14 of the C array: the Schur exchange with its pack / unpack)
+function comm_times(sys::HIPQRCholDenseSystemSolver)
+    out = zeros(Cdouble, 16)
+    check(ccall((:hyp_sys_comm_times, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), sys.handle, out), "hyp_sys_comm_times")
+    return out
+end
+
+# fall-backs behind a failed Cholesky since the context was created: [hybrid, calls trimmed by the growth guard, plain rook pivoting]
+function bk_stats()
+    out = zeros(Clonglong, 3)
+    check(ccall((:hyp_ctx_bk_stats, lib), Cint, (Ptr{Cvoid}, Ptr{Clonglong}), CTX[], out), "hyp_ctx_bk_stats")
+    return out
+end
+
 # ---------------------------------------------------------------------------------------------
 # The fused fast path of step(::CombinedStepper) (steppers/combined.jl:53-120), for a stepper method that wants it (p = 0):
 #   step_directions!      update_lhs + update_rhs_cent / _pred / _centadj / _predadj + the two paired solves in ONE device call

@@ -259,6 +259,15 @@ def test_bench_scaling_line_under_torchrun_two_ranks():
     _check_schema(d, 2, steps=3)
     assert "64 x PosSemidefTri" in d["metric"] and d["config"]["n"] == 300
     assert d["comm"]["collectives_per_step"] > 0 if "comm" in d else True
+    # round 5: the line times its exchanges (one Schur sum per iteration and the small ones, hyp_sys_comm_times) and carries every
+    # rank's phase table, so that the first real N > 1 run says where a shortfall comes from
+    assert d["schur_allreduce_ms"] > 0 and d["schur_exchange_ms_incl_pack"] >= d["schur_allreduce_ms"]
+    assert d["small_collectives_ms_per_step"] > 0 and d["small_collectives_ms_by_site"]
+    pr = d["per_rank_ms_per_step"]
+    assert len(pr["rows"]) == 2 and all(len(r) == len(pr["columns"]) for r in pr["rows"])
+    col = {c: i for i, c in enumerate(pr["columns"])}
+    for r in pr["rows"]:
+        assert r[col["cones"]] == 32 and r[col["syrk"]] > 0 and r[col["schur_exchanges"]] >= 1.0 and r[col["schur_allreduce"]] > 0
 
 
 @pytest.mark.timeout(1800)
