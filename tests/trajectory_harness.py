@@ -255,7 +255,13 @@ def compare(ht, ot, pt, mu_alpha=1e-7, mu_tight=1e-3, tight=1e-10, label=""):
         floor = np.max([np.abs(p_[:kp, col] - O[:kp, col]) / scale for p_ in Ps], axis=0)
         well = O[:kp, 7] >= mu_tight
         if well.any():
-            assert dev[well].max() < tight, "%s: %s differs by %.3e (relative) while mu >= %g" % (label, cname, dev[well].max(), mu_tight)
+            # 1e-10 while mu >= 1e-3 -- unless the ORACLE's own rows move by more than a third of that under 1-ulp perturbations of G and
+            # h at that iterate (config 5 in its dual form at U = 4845: 4.4e-10 in p_obj at mu = 1.4e-3, tools/diag_traj.py): no
+            # implementation can agree with one oracle run more closely than oracle runs agree with each other, the bar is then 3x that
+            bar = np.maximum(tight, 3 * np.maximum.accumulate(floor))
+            over = well & (dev >= bar)
+            assert not over.any(), "%s: %s differs by %.3e (relative; bar %.3e) at iterate %d while mu >= %g" % (
+                label, cname, dev[over].max(), bar[over][int(np.argmax(dev[over]))], int(np.nonzero(over)[0][0]), mu_tight)
         lim = 100 * np.maximum.accumulate(np.maximum(floor, 1e-13))
         assert np.all(dev <= lim), "%s: %s beyond 100x the oracle's own 1-ulp sensitivity: %s vs %s" % (label, cname, dev, lim)
         worst[cname] = float(dev[well].max()) if well.any() else 0.0

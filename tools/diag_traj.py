@@ -1,26 +1,24 @@
-import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""python tools/diag_traj.py NAME [route-json]: the HIP trajectory of a full-size golden case against the committed oracle rows,
+iterate by iterate (relative deviation per column next to the oracle's own 1-ulp sensitivity)."""
+import json, os, sys
 import numpy as np
-import hypatia_jl_amd as H
-from oracle import instances as I
-from oracle.build import make_model as omodel
-from oracle.solvers import Solver as OSolver
-
-def traj(cls, model):
-    rows = []
-    s = cls()
-    s.iter_callback = lambda sv: rows.append((sv.primal_obj, sv.mu, sv.x_feas, sv.z_feas, getattr(sv.stepper, "prev_alpha", 1.0), sv.worst_dir_res))
-    s.load(model); s.solve()
-    return s, np.array(rows)
-
-for (n, sides, seed) in [(60, [10, 8, 3], 2), (150, [24, 17], 3)]:
-    inst = I.psd_blocks(n, sides, seed=seed)
-    hs, ht = traj(H.Solver, H.make_model(inst))
-    os_, ot = traj(OSolver, omodel(inst))
-    rng = np.random.default_rng(99)
-    G2 = inst[3] * (1.0 + np.finfo(float).eps * rng.choice([-1.0, 1.0], size=inst[3].shape))
-    ps_, pt = traj(OSolver, omodel(inst[:3] + (G2,) + inst[4:]))
-    print("case", n, sides, "iters hip/oracle/perturbed:", hs.num_iters, os_.num_iters, ps_.num_iters)
-    k = min(len(ht), len(ot), len(pt))
-    for i in range(k):
-        print(f"{i:3d} mu {ot[i,1]:.3e} | alpha h {ht[i,4]:.4f} o {ot[i,4]:.4f} p {pt[i,4]:.4f} | relmu h {abs(ht[i,1]-ot[i,1])/ot[i,1]:.2e} p {abs(pt[i,1]-ot[i,1])/ot[i,1]:.2e} | dirres h {ht[i,5]:.1e} o {ot[i,5]:.1e}")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import trajectory_harness as T
+name = sys.argv[1]
+route = json.loads(sys.argv[2]) if len(sys.argv) > 2 else {}
+rec = json.load(open(os.path.join(ROOT, "tests", "golden", "trajectory_fullsize.json")))["cases"][name]
+ht = T.hip_trajectory(name, route, **rec["opts"])
+O = np.array(rec["rows"]); Ps = [np.array(p) for p in rec["perturbed_rows"]]; H = ht["rows"]
+k = min(len(H), len(O))
+print(name, route, "HIP", ht["status"], ht["iters"], "oracle", rec["status"], rec["num_iters"], "bk", ht.get("bk_stats"))
+print("cols", T.COLS)
+for i in range(k):
+    kk = min(len(p) for p in Ps)
+    devs = []
+    for col in (0, 1, 7, 5, 3, 4):
+        scale = abs(O[i, col]) + (1e-300 if col in (0, 1, 5, 7) else 1e-6)
+        d = abs(H[i, col] - O[i, col]) / scale
+        f = max(abs(p[i, col] - O[i, col]) / scale for p in Ps) if i < kk else float("nan")
+        devs.append("%.1e/%.1e" % (d, f))
+    print("it %2d mu %.2e alpha H %.4g O %.4g | p_obj d_obj mu tau xfeas zfeas (dev/floor): %s" % (i, O[i, 7], H[i, 8], O[i, 8], " ".join(devs)))
