@@ -31,10 +31,12 @@ int potrf_diag_mfma_own_cu_lds();
 void potrf_panel_mfma_launch(hipStream_t st, int batch, double* A, long lda, long strideA, int k0, int mcols, int coff = 0,
                              const double* tinv = nullptr, long tinv_stride = 0);
 
+int potrf_hiprio();   // potrf_mfma.hip
 static void potrf_step_gemms(Ctx& c, hipStream_t st, int nb, int M, int N, const double* U12a, const double* U12b, long lda, long strideA,
-                             double* C, int tri, int batch, int tile_hint = 0) {
+                             double* C, int tri, int batch, int tile_hint = 0, int hiprio = 0) {
   GemmArgs s{};   // C <- C - U12a' U12b
   s.tile_hint = tile_hint;
+  s.hiprio = hiprio;
   s.M = M; s.N = N; s.K = nb;
   s.A = U12a; s.lda = lda; s.strideA = strideA;
   s.B = U12b; s.ldb = lda; s.strideB = strideA;
@@ -187,7 +189,7 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
     hipEvent_t Tk = c.pool_event(2 * kb), Rk = c.pool_event(2 * kb + 1);
     if (kb >= 1) HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(2 * (kb - 1) + 1), 0));   // rest(k-1) touched block row k+1 too
     static const int look_tile = [] { const char* e = getenv("HYP_POTRF_LOOK_TILE"); return e ? atoi(e) : 0; }();
-    potrf_step_gemms(c, c.stream, nb, nb1, m, A12, A12, lda, strideA, A22, GEMM_UPPER_RECT, 1, look_tile);   // block row k+1: diagonal block (upper) + its row panel
+    potrf_step_gemms(c, c.stream, nb, nb1, m, A12, A12, lda, strideA, A22, GEMM_UPPER_RECT, 1, look_tile, potrf_hiprio());   // block row k+1: diagonal block (upper) + its row panel
     // the big remainder starts only after the main stream's small updates are queued: it then runs
     // underneath the next diagonal-block kernel + panel solve instead of competing with them
     HYP_CHECK(hipEventRecord(Tk, c.stream));

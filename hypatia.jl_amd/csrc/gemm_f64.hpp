@@ -58,6 +58,7 @@ struct GemmArgs {
   int tile_hint;   // 0 = automatic, 64 / 128 = force the block tile edge
   int epi;         // 0: C = alpha*acc + beta*C ; 1: C = (alpha*acc)^2 + beta*C (Hadamard square, WSOS Hessian)
   int tag;         // 1 = the Schur-complement syrk (own kernel symbol, so profiles can tell it apart)
+  int hiprio;      // 1: the wavefronts raise their issue priority (s_setprio 3): a critical-path product beside a bulk one (potrf look-ahead)
   // split-K (set by the launcher): blockIdx.z = slice; slices write raw partial sums to `part`
   // (slice-major copies of C's layout, ldc = part_ld) and a second kernel adds them in slice order
   int tri_off;     // upper forms keep elements with row <= col + tri_off (0 except for off-diagonal strips)

@@ -33,6 +33,7 @@ void gemm_f64_kernel(GemmArgs p) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
+  if (p.hiprio) __builtin_amdgcn_s_setprio(3);
 
   int tm, tn;
   const int bz = blockIdx.y;   // batch index

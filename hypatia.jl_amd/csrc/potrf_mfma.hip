@@ -991,8 +991,9 @@ __device__ __forceinline__ void t4_wave(double* __restrict__ Ab, long lda, int n
 }
 
 __global__ __launch_bounds__(256) void potrf_tiles4_kernel(double* __restrict__ A, long lda, long strideA, int n, int k0, int* __restrict__ info,
-                                                           double* __restrict__ tinv_base, long tinv_stride) {
+                                                           double* __restrict__ tinv_base, long tinv_stride, int potrf_prio) {
   extern __shared__ __attribute__((aligned(16))) double pm_lds[];
+  if (potrf_prio) __builtin_amdgcn_s_setprio(3);
   double* Dt = pm_lds;                   // factor of the current diagonal tile
   double* Mi = pm_lds + TL;              // its inverse, transposed: [i][n]
   double* rinv = pm_lds + 2 * TL;        // 1 / its diagonal
@@ -1026,8 +1027,9 @@ __device__ __forceinline__ constexpr int tix(int a, int b) { return a * 8 - a * 
 
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void potrf_panel_mfma_kernel(double* __restrict__ A, long lda, long strideA, int k0, int mcols, int coff,
-                                                                     const double* __restrict__ tinv_base, long tinv_stride) {
+                                                                     const double* __restrict__ tinv_base, long tinv_stride, int potrf_prio) {
   extern __shared__ __attribute__((aligned(16))) double pm_lds[];
+  if (potrf_prio) __builtin_amdgcn_s_setprio(3);
   double* Ut = pm_lds;               // 36 tiles
   double* rinv = pm_lds + 36 * TL;   // 128
   double* Mt = pm_lds + 36 * TL + NB;   // tinv: the 8 inverses (transposed) of U11's diagonal tiles, tile j at j TL, [i][n]
@@ -1140,6 +1142,17 @@ __global__ __launch_bounds__(64 * WAVES) void potrf_panel_mfma_kernel(double* __
 // ---------------------------------------------------------------------------------------------
 // launchers (same contracts as potrf_diag_launch(factor only) / potrf_panel_solve_launch of potrf_diag.hip)
 // ---------------------------------------------------------------------------------------------
+// Round 5 (profiles/r05_probe_interference.txt): a latency-bound wavefront that shares a SIMD with a wavefront issuing FP64 MFMAs back
+// to back is starved by the instruction arbiter (dependent v_fma_f64 56 - 1300x slower, LDS + barrier loops 50 - 240x); with wavefront
+// priority 3 (s_setprio) it is served between the MFMAs (2.6 - 37x better).  HYP_POTRF_PRIO=1 raises the priority of the kernels on the
+// factorization's critical path -- the diagonal block, the panel, the look-ahead update --, which run beside the helper stream's
+// trailing update.  Measured: n = 5000 2.91 ms with it, 2.89 without (profiles/r05_potrf_prio.txt) -- the real trailing GEMM leaves
+// the arbiter gaps a pure MFMA loop does not, and what slows these kernels down beside it is the MEMORY path (a dependent load takes
+// 4 - 6x longer beside an HBM stream even from an otherwise idle CU), which no priority reaches.  Default off.
+int potrf_hiprio() {
+  static const int on = [] { const char* e = getenv("HYP_POTRF_PRIO"); return (e && atoi(e) == 1) ? 1 : 0; }();
+  return on;
+}
 static bool potrf_la_on() {
   static const bool on = [] { const char* e = getenv("HYP_POTRF_LA"); return !(e && atoi(e) == 0); }();
   return on;
@@ -1157,7 +1170,7 @@ void potrf_diag_mfma_launch(hipStream_t st, int batch, double* A, long lda, long
     if (potrf_tinv_on() && defer) {
       const size_t lds4 = (size_t)(2 * TL + 16 + 3 * 8 * TL + 2) * sizeof(double);
       hipLaunchKernelGGL(potrf_tiles4_kernel, dim3(batch), dim3(256), own_cu_lds > 0 ? std::max<size_t>(lds4, (size_t)own_cu_lds) : lds4, st, A, lda,
-                         strideA, n, k0, info, tinv, tinv_stride);
+                         strideA, n, k0, info, tinv, tinv_stride, potrf_hiprio());
     } else if (potrf_tinv_on()) hipLaunchKernelGGL((potrf_tiles_kernel<4, 8, true>), dim3(batch), dim3(256), want, st, A, lda, strideA, n, k0, info, tinv, tinv_stride);
     else hipLaunchKernelGGL((potrf_tiles_kernel<4, 8, false>), dim3(batch), dim3(256), want, st, A, lda, strideA, n, k0, info, nullptr, 0L);
   } else {
@@ -1192,9 +1205,9 @@ void potrf_panel_mfma_launch(hipStream_t st, int batch, double* A, long lda, lon
     attr_set = true;
   }
   const dim3 grid((mcols + 16 * waves - 1) / (16 * waves), batch);
-  if (waves == 1) hipLaunchKernelGGL(potrf_panel_mfma_kernel<1>, grid, dim3(64), lds, st, A, lda, strideA, k0, mcols, coff, tinv, tinv_stride);
-  else if (waves == 2) hipLaunchKernelGGL(potrf_panel_mfma_kernel<2>, grid, dim3(128), lds, st, A, lda, strideA, k0, mcols, coff, tinv, tinv_stride);
-  else hipLaunchKernelGGL(potrf_panel_mfma_kernel<4>, grid, dim3(256), lds, st, A, lda, strideA, k0, mcols, coff, tinv, tinv_stride);
+  if (waves == 1) hipLaunchKernelGGL(potrf_panel_mfma_kernel<1>, grid, dim3(64), lds, st, A, lda, strideA, k0, mcols, coff, tinv, tinv_stride, potrf_hiprio());
+  else if (waves == 2) hipLaunchKernelGGL(potrf_panel_mfma_kernel<2>, grid, dim3(128), lds, st, A, lda, strideA, k0, mcols, coff, tinv, tinv_stride, potrf_hiprio());
+  else hipLaunchKernelGGL(potrf_panel_mfma_kernel<4>, grid, dim3(256), lds, st, A, lda, strideA, k0, mcols, coff, tinv, tinv_stride, potrf_hiprio());
   HYP_CHECK(hipGetLastError());
 }
 

@@ -31,6 +31,8 @@
 // order makes the other set idle), so no memset node sits between launches.
 #include "hyp_internal.hpp"
 
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 namespace hyp {
@@ -418,7 +420,16 @@ void TriSolvePlan::ol_prepare(Ctx& c, long ldu) {
 }
 
 // which: 0 forward sweep, 1 backward sweep, 2 both.  nr = 1, 2 (columns x, x + ldx) or 3 (and x3).
+// HYP_TRSV_OL_STATS=1: at exit, how many sweeps went through the one-launch kernel (by kind and right-hand sides)
+static long ol_counts[3][4];
+static void ol_report() {
+  for (int w = 0; w < 3; ++w)
+    for (int r = 1; r <= 3; ++r)
+      if (ol_counts[w][r]) fprintf(stderr, "[trsv one-launch] %s, %d right-hand side(s): %ld launches\n", w == 0 ? "forward" : w == 1 ? "backward" : "both", r, ol_counts[w][r]);
+}
 void TriSolvePlan::ol_sweep(Ctx& c, const double* U, int which, double* x, long ldx, double* x3, int nr) {
+  static const bool stats = [] { const char* e = getenv("HYP_TRSV_OL_STATS"); const bool on = e && e[0] == '1'; if (on) atexit(ol_report); return on; }();
+  if (stats) ++ol_counts[which][nr];
   OlArgs a{};
   a.U = U; a.UT = UT.d(); a.Binv = Binv.d(); a.BinvT = BinvT.d();
   const OlRound* rounds = (const OlRound*)ol_rounds.p + ol_first[which];

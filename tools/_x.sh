@@ -1,10 +1,6 @@
 export TMPDIR=/tmp
-python tools/diag_traj.py cfg5dw_1 2>&1 | tail -30
-python tools/diag_traj.py cfg5dw_1 '{"HYP_TRSV_ONE_LAUNCH":"0"}' 2>&1 | tail -14
-python - <<'P'
-import sys
-sys.path.insert(0,'tests')
-import trajectory_harness as T
-print(T.REFERENCE_ROUTE)
-P
-python tools/diag_traj.py cfg5pw_1 2>&1 | tail -30
+cd /tmp && rm -rf /tmp/prof2 && rocprofv3 --kernel-trace --stats -d /tmp/prof2 -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 30 --cpu-iters 0 > $GRAFT_REPO_ROOT/gpurun_out/bench_under_profiler.json 2>/dev/null
+cd $GRAFT_REPO_ROOT
+DB2=$(find /tmp/prof2 -name "*.db" | head -1)
+python tools/rocpd_stats.py $DB2 2>/dev/null | head -40 > gpurun_out/cfg2_kernel_stats.csv; head -30 gpurun_out/cfg2_kernel_stats.csv
+ITER_BACK=3 python tools/rocpd_gaps.py $DB2 0 100000 > gpurun_out/iteration_timeline.txt 2>/dev/null; grep -n "onelaunch" -B3 -A3 gpurun_out/iteration_timeline.txt | head -60
