@@ -267,6 +267,7 @@ struct WsosCone : GenericHessCone {   // src/Cones/wsosinterpnonnegative.jl (rea
   DBuf scrSP, scrLF, scrLFT, scrLam, scrLL, scrDinv, scrVec, scrInfo;
   int screen_max() const override;
   bool screen_ready() override;
+  int screen_splitk(int L, int batch) const;   // K slices of a batch of L x L x U Gram products
   bool screen_batch(int C, const double* h_pts, const double* h_duals, const double* irtmu, double limit, char* reject, int* n_infeas, double* bounds) override;
 };
 

@@ -990,6 +990,10 @@ bool SysSolver::check_cone_points(const double* h, double min_prox, double prox_
   }
   // (sharded: this rank's cones only -- every decision below is taken on all-reduced quantities, so that all
   //  ranks leave through the same exit and issue the same sequence of collectives)
+  // (screen_sz_ is the screen's DEVICE tree sum of <z, s>, not the four-way host sum above, and its failure flag carries
+  //  the screen's margin -- so mu, irtmu and the loaded scaled point of a survivor differ in their last bits between HYP_DIST_FUSED=1
+  //  and 0 and from the single-process walk: the fused sharded path is reproducible run to run, not bitwise against the unfused one;
+  //  tests/test_hip_distributed.py compares the two at 1e-9 in the objective, docs/NUMERICS.md says so)
   if (dist() && screen_pass_g_ >= 0 && fused_ok()) {   // a survivor of the candidate screen: the screen has exchanged exactly these two numbers
     szsum = screen_sz_[screen_pass_g_];
     ok = (screen_szfail_[screen_pass_g_] < 0.5);

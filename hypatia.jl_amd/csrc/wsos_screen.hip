@@ -140,10 +140,30 @@ bool WsosCone::screen_ready() {
   // byte budget of the batch buffers (three U x L_k operand copies per candidate and member; HYP_SCREEN_MB as for the PSD screen,
   // default 2048 MB per candidate slot x 8): a cone too large for it walks sequentially
   static const double budget = [] { const char* e = getenv("HYP_SCREEN_MB"); return (e ? atof(e) : 2048.0) * 8.0 * 1048576.0; }();
-  double sumL = 0.0;
+  double sumL = 0.0, scratch = 0.0;
   for (int k = 0; k < K; ++k) sumL += Ls[k];
-  if (3.0 * screen_max() * (double)U * sumL * sizeof(double) > budget) return false;
+  // ... plus what screen_batch asks of the launchers on BOTH streams: split-K partial sums of the largest run, the tile
+  // inverses of its factorizations, and the batch's L x L matrices (Lambda, LL, the inverted diagonal blocks)
+  for (int k0 = 0; k0 < K;) {
+    int cnt = 1;
+    while (k0 + cnt < K && Ls[k0 + cnt] == Ls[k0]) ++cnt;
+    const double L = Ls[k0], nb = (double)screen_max() * cnt;
+    double wsmax = 0.0;   // (a smaller batch takes more slices per product: the largest request over the batch sizes)
+    for (int c = 1; c <= screen_max(); ++c) wsmax = std::max(wsmax, (double)c * cnt * screen_splitk(Ls[k0], c * cnt) * L * L);
+    scratch = std::max(scratch, 2.0 * (wsmax + nb * ((Ls[k0] + NB - 1) / NB) * 2048.0));
+    scratch += nb * (2.0 * L * L + (double)dinv_elems(Ls[k0]));
+    k0 += cnt;
+  }
+  if ((3.0 * screen_max() * (double)U * sumL + scratch) * sizeof(double) > budget) return false;
   return true;
+}
+
+// K slices for a batch of L x L x U Gram products (64 x 64 tiles of the upper triangle)
+int WsosCone::screen_splitk(int L, int batch) const {
+  const long T = (L + 63) / 64, nb = T * (T + 1) / 2 * batch;
+  long S = std::min<long>(16, std::max<long>(1, 1024 / nb));
+  S = std::min<long>(S, std::max(1, U / 256));
+  return (int)S;
 }
 
 // h_pts: C x U, the candidates' primal points ALREADY scaled by irtmu[c] (Cone::load_point's product); h_duals: C x U; limit: the value
@@ -182,7 +202,8 @@ bool WsosCone::screen_batch(int C, const double* h_pts, const double* h_duals, c
   {   // the launchers' own scratch, for both streams: split-K partial sums (at most 16 slices) and the factorizations' tile inverses
     size_t ws = 0, tv = 0;
     for (const Grp& g : grps) {
-      ws = std::max(ws, Cm * g.cnt * 16 * (size_t)g.L * g.L * d);
+      for (size_t c = 1; c <= Cm; ++c)   // (the slices a batch of c candidates really takes, not 16: a smaller batch takes more per product)
+        ws = std::max(ws, c * g.cnt * (size_t)screen_splitk(g.L, (int)(c * g.cnt)) * (size_t)g.L * g.L * d);
       tv = std::max(tv, Cm * g.cnt * (size_t)((g.L + NB - 1) / NB) * 2048 * d);
     }
     for (GemmScratch* gs : {&ctx.gemm_scratch, &ctx.gemm_scratch2}) {
@@ -210,12 +231,7 @@ bool WsosCone::screen_batch(int C, const double* h_pts, const double* h_duals, c
   for (int c = 0; c < C; ++c) irt.v[c] = irtmu[c];
 
   // ---- F: per run of equal L_k, the runs dealt out to the two streams by their block steps (as update_feas does)
-  auto splitk_for = [&](int L, int batch) {   // K slices for a batch of L x L x U Gram products (64 x 64 tiles of the upper triangle)
-    const long T = (L + 63) / 64, nb = T * (T + 1) / 2 * batch;
-    long S = std::min<long>(16, std::max<long>(1, 1024 / nb));
-    S = std::min<long>(S, std::max(1, U / 256));
-    return (int)S;
-  };
+  auto splitk_for = [&](int L, int batch) { return screen_splitk(L, batch); };
   hipEvent_t e0 = ctx.aux_event(2), e1 = ctx.aux_event(3);
   HYP_CHECK(hipEventRecord(e0, ctx.stream));
   HYP_CHECK(hipStreamWaitEvent(ctx.stream2, e0, 0));

@@ -1,6 +1,18 @@
 export TMPDIR=/tmp
-cd /tmp && rm -rf /tmp/prof2 && rocprofv3 --kernel-trace --stats -d /tmp/prof2 -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 30 --cpu-iters 0 > $GRAFT_REPO_ROOT/gpurun_out/bench_under_profiler.json 2>/dev/null
-cd $GRAFT_REPO_ROOT
-DB2=$(find /tmp/prof2 -name "*.db" | head -1)
-python tools/rocpd_stats.py $DB2 2>/dev/null | head -40 > gpurun_out/cfg2_kernel_stats.csv; head -30 gpurun_out/cfg2_kernel_stats.csv
-ITER_BACK=3 python tools/rocpd_gaps.py $DB2 0 100000 > gpurun_out/iteration_timeline.txt 2>/dev/null; grep -n "onelaunch" -B3 -A3 gpurun_out/iteration_timeline.txt | head -60
+python - > /dev/null 2>&1 <<'P'
+import cProfile, pstats, sys, io
+sys.argv = ["bench.py", "--steps", "60", "--cpu-iters", "0", "--warmup", "3"]
+import runpy
+pr = cProfile.Profile()
+pr.enable()
+try:
+    runpy.run_path("bench.py", run_name="__main__")
+except SystemExit:
+    pass
+pr.disable()
+s = io.StringIO()
+ps = pstats.Stats(pr, stream=s).sort_stats("tottime")
+ps.print_stats(70)
+open("gpurun_out/pyprof.txt", "w").write(s.getvalue()[:16000])
+P
+cut -c1-170 gpurun_out/pyprof.txt | head -90
