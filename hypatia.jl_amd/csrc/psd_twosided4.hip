@@ -55,6 +55,12 @@ template <> struct Ts4Plan<12> { static constexpr int cols[2][4][2] = {{{0, 4}, 
 template <> struct Ts4Plan<11> { static constexpr int cols[2][4][2] = {{{0, 3}, {1, 4}, {2, 5}, {10, -1}}, {{6, -1}, {7, -1}, {8, -1}, {9, -1}}}; };
 template <> struct Ts4Plan<10> { static constexpr int cols[2][4][2] = {{{0, 2}, {1, 3}, {8, -1}, {9, -1}}, {{4, -1}, {5, -1}, {6, -1}, {7, -1}}}; };
 template <> struct Ts4Plan<9> { static constexpr int cols[2][4][2] = {{{0, 1}, {6, -1}, {7, -1}, {8, -1}}, {{2, -1}, {3, -1}, {4, -1}, {5, -1}}}; };
+// round 5: 6 .. 8 tiles (sides 81 .. 128) fit ONE column set -- at most eight block columns, one per wavefront; the second set is empty
+// and not launched (sides <= 80 have psd_ts5_kernel: one wavefront holds all of Z)
+template <> struct Ts4Plan<8> { static constexpr int cols[2][4][2] = {{{0, 7}, {1, 6}, {2, 5}, {3, 4}}, {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}}}; };
+template <> struct Ts4Plan<7> { static constexpr int cols[2][4][2] = {{{0, 6}, {1, 5}, {2, 4}, {3, -1}}, {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}}}; };
+template <> struct Ts4Plan<6> { static constexpr int cols[2][4][2] = {{{0, 3}, {1, 2}, {4, -1}, {5, -1}}, {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}}}; };
+template <int T> constexpr bool ts4_two_sets() { return Ts4Plan<T>::cols[1][0][0] >= 0 || Ts4Plan<T>::cols[1][1][0] >= 0; }
 
 template <int T> constexpr int ts4_ldc() { return ((16 * T - 18 + 31) / 32) * 32 + 18; }   // = 18 mod 32, >= 16 T
 template <int T> constexpr size_t ts4_lds_doubles() { return (size_t)2 * 16 * T * T4_LDK + (size_t)16 * ts4_ldc<T>(); }
@@ -380,16 +386,16 @@ void ts4_launch_nw(Ctx& c, Ts4Args a) {
   static const bool probe = [] { const char* e = getenv("HYP_TS4_PROBE"); return e && e[0] == '1'; }();
   if (!probe) {
     ts4_launch_set<T, 0, NW>(c, a, grid, lds);   // (the two column sets write disjoint tile rows of the result)
-    ts4_launch_set<T, 1, NW>(c, a, grid, lds);
+    if constexpr (ts4_two_sets<T>()) ts4_launch_set<T, 1, NW>(c, a, grid, lds);
     return;
   }
   DBuf pb((size_t)grid * 8 * 8 * sizeof(unsigned long long));
   std::vector<unsigned long long> h((size_t)grid * 64);
-  for (int set = 0; set < 2; ++set) {
+  for (int set = 0; set < (ts4_two_sets<T>() ? 2 : 1); ++set) {
     c.zero(pb.p, pb.bytes);
     a.probe = (unsigned long long*)pb.p;
     if (set == 0) ts4_launch_set<T, 0, NW>(c, a, grid, lds);
-    else ts4_launch_set<T, 1, NW>(c, a, grid, lds);
+    else if constexpr (ts4_two_sets<T>()) ts4_launch_set<T, 1, NW>(c, a, grid, lds);
     c.d2h(h.data(), pb.p, pb.bytes);
     c.sync();
     for (int w = 0; w < NW; ++w) {
@@ -423,7 +429,8 @@ bool psd_two_sided_onchip(Ctx& c, int side, int ncols, const double* R, int rstr
   static const bool on = [] { const char* e = getenv("HYP_TS4"); return !(e && e[0] == '0'); }();
   static const int min_cols = [] { const char* e = getenv("HYP_TS4_MIN"); return e ? atoi(e) : 192; }();
   const int T = (side + 15) / 16;
-  if (!on || rstruct != 1 || T < 9 || T > 13 || ncols < min_cols || arr == prod) return false;
+  static const int tmin = [] { const char* e = getenv("HYP_TS4_TMIN"); return e ? atoi(e) : 6; }();   // (9: sides 81 .. 128 back on the two-pass kernels, round 4)
+  if (!on || rstruct != 1 || T < tmin || T < 6 || T > 13 || ncols < min_cols || arr == prod) return false;
   const int LD = 16 * T;
   const size_t LD2 = (size_t)LD * LD;
   c.ts_ws.ensure(LD2 * sizeof(double));
@@ -432,6 +439,9 @@ bool psd_two_sided_onchip(Ctx& c, int side, int ncols, const double* R, int rstr
   Ts4Args a{};
   a.s = side; a.ncols = ncols; a.A = arr; a.lda = lda; a.Rp = Rp; a.C = prod; a.ldc = ldp;
   switch (T) {
+    case 6: ts4_launch<6>(c, a); break;
+    case 7: ts4_launch<7>(c, a); break;
+    case 8: ts4_launch<8>(c, a); break;
     case 9: ts4_launch<9>(c, a); break;
     case 10: ts4_launch<10>(c, a); break;
     case 11: ts4_launch<11>(c, a); break;

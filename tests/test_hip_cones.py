@@ -117,12 +117,13 @@ def test_psd_two_sided_products_sides_beyond_96(side, ncols):
         assert np.all(out_h[0] == 7.0) and np.all(out_h[1 + dim:] == 7.0)
 
 
-@pytest.mark.parametrize("side,ncols", [(129, 193), (144, 200), (160, 260), (161, 200), (177, 333), (192, 200), (200, 517), (207, 200), (208, 257)])
+@pytest.mark.parametrize("side,ncols", [(129, 193), (144, 200), (160, 260), (161, 200), (177, 333), (192, 200), (200, 517), (207, 200), (208, 257),
+                                        (81, 200), (96, 333), (97, 193), (112, 200), (113, 260), (128, 517)])
 def test_psd_sqrt_hess_prod_on_chip_form(side, ncols):
     """round 4: sqrt_hess_prod on >= 192 columns at sides of 9 .. 13 MFMA tiles goes through psd_ts4_kernel (the intermediate product
     in accumulator registers, one workgroup per matrix and column set: csrc/psd_twosided4.hip); every tile count, sides on and off
     the tile edge, more matrices than workgroups (517 > 256) and strided column views, against the oracle's product
-    (possemideftri.jl:161-177)"""
+    (possemideftri.jl:161-177).  Round 5: 6 .. 8 tiles (sides 81 .. 128) as well, with ONE column set (sides 33 .. 80: the test below)"""
     dim = side * (side + 1) // 2
     hc, oc = _pair("psd", dim)
     rng = np.random.default_rng(side + ncols)
