@@ -74,10 +74,24 @@ def algorithm_record():
             # proximity bound together; only rejections are taken from it (csrc/wsos_screen.hip; candidates per batch, 0 = off)
             "wsos_candidate_screen": int(os.environ.get("HYP_WSOS_SCREEN", "4")) if on("HYP_PROX_LB") else 0,
             "triangular_solve_refinement_steps": int(os.environ.get("HYP_TRSM_REFINE", "2")),
+            # one-vector solves with a large factor: refinement steps asked for, and whether a plan whose inverted super-blocks
+            # measure good enough (rho <= 1e-10: a second step would move nothing above 1e-20) runs one step (round 5; counts: "solve_plans")
+            "superblock_solve_refinement_steps": int(os.environ.get("HYP_TRSV_REFINE", "2")), "superblock_solve_adaptive": {"0": "off", "1": "every plan", "2": "system-solver factors", "3": "cone Hessian factors"}.get(os.environ.get("HYP_TRSV_ADAPT", "3"), "?"),
+            "triangular_sweeps_one_launch": os.environ.get("HYP_TRSV_ONE_LAUNCH", "2") != "0",
             # (the candidate screen needs the proximity bound: off with HYP_PROX_LB=0)
             # behind a failed Cholesky: the rook-pivoted elimination only from the failing pivot's block on (round 4; 0: the whole matrix)
             "fallback_keeps_cholesky_blocks": on("HYP_BK_HYBRID"),
             "reference_route": not (on("HYP_ENS_CLOSED_INV") or on("HYP_PROX_LB") or on("HYP_ENS_PREFETCH") or on("HYP_WSOS_PAR") or on("HYP_BK_HYBRID"))}
+
+
+def plan_stats(lib, ctx):
+    """solve plans built so far and how many of them the adaptive rule gave ONE refinement step (hyp_ctx_plan_stats)"""
+    try:
+        st = (ctypes.c_longlong * 2)()
+        lib.hyp_ctx_plan_stats(ctx, st)
+        return {"built": int(st[0]), "one_refinement_step": int(st[1])}
+    except Exception:
+        return None
 
 
 def pmc_traffic(n, q):
@@ -550,7 +564,7 @@ def run_headline(args, world, rank, local_rank, multi, comm=None):
                                "update_rhs": solver.time_uprhs / args.steps * 1e3, "search": solver.time_search / args.steps * 1e3},
         "kkt_solves_per_step": n_solves / args.steps,
         "ms_per_kkt_solve": solver.time_getdir / max(n_solves, 1) * 1e3,
-        "search_trials_per_step": n_trials / args.steps,
+        "search_trials_per_step": n_trials / args.steps, "solve_plans": plan_stats(lib, ctx),
         # of those, the candidates the side-by-side screen rejected (batches of up to SCREEN_MAX = 18 = the whole schedule, one read-back each) -- the others
         # went through the sequential acceptance test
         "search_screens_per_step": ((screen_stats()[0] - screens0[0]) / args.steps) if screen_stats is not None else 0.0,
@@ -789,7 +803,7 @@ def main_other(args, world=1, rank=0, local_rank=0, multi=False):
                                   "bunch_kaufman_factorizations": n_bk / iters, "schur_factorizations": n_upfact / iters}},
         "phases_ms_per_step": {k: v / iters * 1e3 for k, v in phases.items()},
         "kkt_solves_per_step": solves / iters, "ms_per_kkt_solve": phases["getdir"] / max(solves, 1) * 1e3,
-        "search_trials_per_step": trials / iters, "setup_s": t_setup,
+        "search_trials_per_step": trials / iters, "setup_s": t_setup, "solve_plans": plan_stats(lib, ctx),
     }
     if comm is not None:
         # what an N-GPU run of ONE cone can and cannot divide: the Schur product of update_lhs is K-sharded over the

@@ -26,6 +26,7 @@ SIGNATURES = {
     "hyp_device_count": [P(c_int)],
     "hyp_get_timers": [c_vp, c_vp],
     "hyp_ctx_bk_stats": [c_vp, c_vp],
+    "hyp_ctx_plan_stats": [c_vp, c_vp],
     "hyp_reset_timers": [c_vp],
     "hyp_get_kernel_stats": [c_vp, c_vp],
     "hyp_cone_create_nonnegative": [c_vp, c_int, P(c_vp)],

@@ -101,6 +101,12 @@ int hyp_ctx_bk_stats(hyp_ctx* ctx, long long* out3) {
   out3[2] = ctx->c.bk_plain_count;
   API_END(ctx)
 }
+int hyp_ctx_plan_stats(hyp_ctx* ctx, long long* out2) {
+  API_BEGIN
+  out2[0] = ctx->c.plan_builds;
+  out2[1] = ctx->c.plan_builds_one_step;
+  API_END(ctx)
+}
 int hyp_get_kernel_stats(hyp_ctx* ctx, double* out8) {
   API_BEGIN
   for (int i = 0; i < 8; ++i) out8[i] = ctx->c.kstat[i];

@@ -225,7 +225,7 @@ struct GenericHessCone : Cone {
   BKFact Hbk;
   TriSolvePlan Hplan;          // super-block plan for one-vector solves with a large factor (built on first use per factorization)
   bool use_hess_prod_slow = false, use_hess_prod_slow_updated = false;
-  GenericHessCone(Ctx& c, int kind) : Cone(c, kind) {}
+  GenericHessCone(Ctx& c, int kind) : Cone(c, kind) { Hplan.owner_class = 1; }
   void alloc_generic();
   void ensure_hess_storage(bool with_fact);   // explicit Hessian (and its factor) on first use
   void reset_data() override {

@@ -103,6 +103,7 @@ struct Ctx {
   DBuf work_tri;           // workspace of trtri_upper_batched
   DBuf ts_ws;              // PSD two-sided product: zero-padded copy of the factor + the padded intermediates Z_j (psd_twosided.hip)
   long bk_hybrid_count = 0, bk_guard_trims = 0, bk_plain_count = 0;   // fall-backs behind a failed Cholesky: hybrid / trimmed by the guard / plain (hyp_ctx_bk_stats)
+  long plan_builds = 0, plan_builds_one_step = 0;                    // solve plans built / of them with ONE refinement step by the adaptive rule (hyp_ctx_plan_stats)
   int diag_own_cu_lds = -1;   // dynamic LDS that gives the critical-path diagonal-block kernel a CU of its own (-1: not asked yet, 0: refused)
   int trsv_sb = 1024;      // largest super-block of the one-right-hand-side triangular solves (HYP_TRSV_SB; 0 = per-128-block path)
   bool trsv_sb_forced = false;   // HYP_TRSV_SB given: that size, plan from 2 super-blocks on (the round-1 rule)
@@ -213,14 +214,24 @@ struct TriSolvePlan {
   void build(Ctx& c, int n_, const double* U, long ldu, const double* dinv);
   // Round 5 (trsv_onelaunch.hip): the same sweeps -- the same sums, bitwise -- as ONE launch each, or one for both sweeps of a
   // Cholesky potrs; products hand their vectors over through an arena of self-flagging words.  HYP_TRSV_ONE_LAUNCH=0: the launch chains.
-  DBuf ol_rounds, ol_arena;
+  DBuf ol_rounds[4], ol_arena;    // round tables per number of refinement steps (0 .. 3): the adaptive rule below switches between them
   bool ol_ok = false;
-  int ol_n = 0, ol_sb = 0, ol_refine = -1, ol_set = 0;
+  bool ol_have[4] = {false, false, false, false};
+  int ol_n = 0, ol_sb = 0, ol_set = 0;
   long ol_ldu = 0, ol_asz = 0;
-  int ol_first[3] = {0, 0, 0}, ol_n0[3] = {0, 0, 0}, ol_n1[3] = {0, 0, 0};
+  int ol_first[4][3] = {}, ol_n0[4][3] = {}, ol_n1[4][3] = {};
   void ol_prepare(Ctx& c, long ldu);
+  // Round 5: the second refinement step is dropped where it cannot change a digit.  build() measures the quality of the inverted
+  // super-blocks on two probe vectors, rho = max_b || v - T_b' (B_b' v) ||_inf; a solve x0 = B b then has relative error <= rho and
+  // one refinement step leaves rho^2: with rho <= HYP_TRSV_ADAPT_TOL (1e-10; the probes may underestimate the norm by a factor)
+  // the second step moves nothing above 1e-20.  refine_req = what was asked for (HYP_TRSV_REFINE, default 2), refine = what runs.
+  int refine_req = 2;
+  int owner_class = 0;            // 0: a system solver's factor (Schur matrix, SymIndef), 1: a cone's Hessian factor (HYP_TRSV_ADAPT selects)
+  double rho = -1.0;              // the last build's measurement (-1: not measured)
+  DBuf probe_ws;
+  void measure_quality(Ctx& c, const double* U, long ldu);
   // only on the context's main stream: two such launches side by side on two streams could each hold CUs the other's wavefronts wait for
-  bool ol_usable(const Ctx& c, long ldu) const { return ol_ok && ldu == ol_ldu && c.stream == c.stream_primary; }
+  bool ol_usable(const Ctx& c, long ldu) const { return ol_ok && refine >= 0 && refine <= 3 && ol_have[refine] && ldu == ol_ldu && c.stream == c.stream_primary; }
   void ol_sweep(Ctx& c, const double* U, int which, double* x, long ldx, double* x3, int nr);
   // both sweeps, x <- (U'U)^-1 x on nr = 1, 2 or 3 columns (x3 != nullptr: the third column lives there instead of x + 2 ldx)
   void solve_both(Ctx& c, const double* U, long ldu, double* x, long ldx, int nr, double* x3 = nullptr);

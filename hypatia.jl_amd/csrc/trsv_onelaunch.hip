@@ -376,50 +376,53 @@ static void ol_append_sweep(std::vector<OlRound>& chain, std::vector<OlRound>& u
 
 void TriSolvePlan::ol_prepare(Ctx& c, long ldu) {
   ol_ok = false;
-  if (!trsv_one_launch_on() || n <= 0 || sb <= 0 || sb > 1024 || refine < 0) return;
+  if (!trsv_one_launch_on() || n <= 0 || sb <= 0 || sb > 1024 || refine < 0 || refine > 3) return;
   int dev = 0, cus = 0;
   HYP_CHECK(hipGetDevice(&dev));
   HYP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   if (cus * 2 < 2 * OL_W / 4) return;   // 512 four-wavefront workgroups must be resident at once: at most two per CU asked for
-  const long words = ol_sweep_words(n, sb, refine);
-  if (2 * words > 0x3fffffffL) return;  // (arena offsets are ints)
-  if (ol_n == n && ol_sb == sb && ol_refine == refine && ol_ldu == ldu) { ol_ok = true; return; }
-  // tables: [0] forward sweep alone, [1] backward sweep alone, [2] both sweeps in one launch (the backward sweep reads the forward one's XF)
-  std::vector<OlRound> all;
-  for (int t = 0; t < 3; ++t) {
-    std::vector<OlRound> chain, upd;
-    if (t == 0) ol_append_sweep(chain, upd, n, sb, refine, ldu, true, 0, -1, true);
-    else if (t == 1) ol_append_sweep(chain, upd, n, sb, refine, ldu, false, 0, -1, true);
-    else {
-      ol_append_sweep(chain, upd, n, sb, refine, ldu, true, 0, -1, false);
-      const int nsb = (n + sb - 1) / sb;
-      const long XF = (long)nsb * ol_npad(n) + (long)2 * refine * nsb * sb;
-      ol_append_sweep(chain, upd, n, sb, refine, ldu, false, words, XF, true);
-    }
-    ol_first[t] = (int)all.size();
-    ol_n0[t] = (int)chain.size();
-    ol_n1[t] = (int)upd.size();
-    all.insert(all.end(), chain.begin(), chain.end());
-    all.insert(all.end(), upd.begin(), upd.end());
-  }
-  ol_rounds.ensure(all.size() * sizeof(OlRound));
-  HYP_CHECK(hipMemcpyAsync(ol_rounds.p, all.data(), all.size() * sizeof(OlRound), hipMemcpyHostToDevice, c.stream));
-  HYP_CHECK(hipStreamSynchronize(c.stream));   // (`all` is pageable and dies here; once per (n, sb, refine, ldu))
-  const size_t bytes = ((size_t)2 * 3 * 2 * words + 16) * sizeof(unsigned long long);   // two sets x three right-hand sides x two sweeps (+ a pair read past the last vector)
-  if (ol_arena.bytes < bytes) {
+  // (the arena is laid out for the most refinement steps this plan can run: the per-right-hand-side stride and what a launch clears do
+  //  not change when the adaptive rule moves between tables)
+  const int rmax = std::max(std::max(refine, refine_req), 0);
+  const long words_max = ol_sweep_words(n, sb, std::min(rmax, 3));
+  if (2 * words_max > 0x3fffffffL) return;  // (arena offsets are ints)
+  if (!(ol_n == n && ol_sb == sb && ol_ldu == ldu && ol_asz == 2 * words_max)) {
+    for (bool& h : ol_have) h = false;
+    const size_t bytes = ((size_t)2 * 3 * 2 * words_max + 16) * sizeof(unsigned long long);   // two sets x three right-hand sides x two sweeps (+ a pair read past the last vector)
     ol_arena.ensure(bytes);
-    HYP_CHECK(hipMemsetAsync(ol_arena.p, 0xFF, bytes, c.stream));
-    ol_set = 0;
-  } else if (ol_asz != 2 * words) {
     HYP_CHECK(hipMemsetAsync(ol_arena.p, 0xFF, ol_arena.bytes, c.stream));
     ol_set = 0;
+    ol_asz = 2 * words_max;
+    ol_n = n; ol_sb = sb; ol_ldu = ldu;
   }
-  ol_asz = 2 * words;
-  ol_n = n; ol_sb = sb; ol_refine = refine; ol_ldu = ldu;
+  if (!ol_have[refine]) {
+    // tables: [0] forward sweep alone, [1] backward sweep alone, [2] both sweeps in one launch (the backward sweep reads the forward one's XF)
+    const long words = ol_sweep_words(n, sb, refine);
+    std::vector<OlRound> all;
+    for (int t = 0; t < 3; ++t) {
+      std::vector<OlRound> chain, upd;
+      if (t == 0) ol_append_sweep(chain, upd, n, sb, refine, ldu, true, 0, -1, true);
+      else if (t == 1) ol_append_sweep(chain, upd, n, sb, refine, ldu, false, 0, -1, true);
+      else {
+        ol_append_sweep(chain, upd, n, sb, refine, ldu, true, 0, -1, false);
+        const int nsb = (n + sb - 1) / sb;
+        const long XF = (long)nsb * ol_npad(n) + (long)2 * refine * nsb * sb;
+        ol_append_sweep(chain, upd, n, sb, refine, ldu, false, words, XF, true);
+      }
+      ol_first[refine][t] = (int)all.size();
+      ol_n0[refine][t] = (int)chain.size();
+      ol_n1[refine][t] = (int)upd.size();
+      all.insert(all.end(), chain.begin(), chain.end());
+      all.insert(all.end(), upd.begin(), upd.end());
+    }
+    ol_rounds[refine].ensure(all.size() * sizeof(OlRound));
+    HYP_CHECK(hipMemcpyAsync(ol_rounds[refine].p, all.data(), all.size() * sizeof(OlRound), hipMemcpyHostToDevice, c.stream));
+    HYP_CHECK(hipStreamSynchronize(c.stream));   // (`all` is pageable and dies here; once per (n, sb, refine, ldu))
+    ol_have[refine] = true;
+  }
   ol_ok = true;
 }
 
-// which: 0 forward sweep, 1 backward sweep, 2 both.  nr = 1, 2 (columns x, x + ldx) or 3 (and x3).
 // HYP_TRSV_OL_STATS=1: at exit, how many sweeps went through the one-launch kernel (by kind and right-hand sides)
 static long ol_counts[3][4];
 static void ol_report() {
@@ -432,8 +435,8 @@ void TriSolvePlan::ol_sweep(Ctx& c, const double* U, int which, double* x, long 
   if (stats) ++ol_counts[which][nr];
   OlArgs a{};
   a.U = U; a.UT = UT.d(); a.Binv = Binv.d(); a.BinvT = BinvT.d();
-  const OlRound* rounds = (const OlRound*)ol_rounds.p + ol_first[which];
-  a.nrounds0 = ol_n0[which]; a.nrounds1 = ol_n1[which];
+  const OlRound* rounds = (const OlRound*)ol_rounds[refine].p + ol_first[refine][which];
+  a.nrounds0 = ol_n0[refine][which]; a.nrounds1 = ol_n1[refine][which];
   unsigned long long* base = (unsigned long long*)ol_arena.p;
   a.arena = base + (long)ol_set * 3 * ol_asz;
   a.clear = base + (long)(1 - ol_set) * 3 * ol_asz;

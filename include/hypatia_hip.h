@@ -41,6 +41,10 @@ int hyp_get_kernel_stats(hyp_ctx* ctx, double* out8);
  * :164-165): out3 = [hybrid factorizations (Cholesky block steps kept in front of the rook-pivoted trailing block), calls in which the
  * growth guard refused kept steps, plain rook-pivoted factorizations from column 0] */
 int hyp_ctx_bk_stats(hyp_ctx* ctx, long long* out3);
+/* solve plans of triangular factors built since the context was created (the super-block inverses behind every ldiv! on a large
+ * factor: qrchol.jl:66-69, Cones.jl:113-118) and how many of them run ONE step of refinement against the factor instead of two
+ * because the inverses' measured quality makes the second step void (HYP_TRSV_ADAPT, docs/NUMERICS.md): out2 = [plans, one-step plans] */
+int hyp_ctx_plan_stats(hyp_ctx* ctx, long long* out2);
 
 /* ---- cone lifecycle: constructors of src/Cones/nonnegative.jl:27-33, possemideftri.jl:36-46 --- */
 int hyp_cone_create_nonnegative(hyp_ctx* ctx, int dim, hyp_cone** out);

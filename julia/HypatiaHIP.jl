@@ -595,6 +595,13 @@ function comm_times(sys::HIPQRCholDenseSystemSolver)
     return out
 end
 
+# solve plans built since the context was created, and how many of them run one refinement step instead of two (adaptive rule)
+function plan_stats()
+    out = zeros(Clonglong, 2)
+    check(ccall((:hyp_ctx_plan_stats, lib), Cint, (Ptr{Cvoid}, Ptr{Clonglong}), CTX[], out), "hyp_ctx_plan_stats")
+    return out
+end
+
 # fall-backs behind a failed Cholesky since the context was created: [hybrid, calls trimmed by the growth guard, plain rook pivoting]
 function bk_stats()
     out = zeros(Clonglong, 3)
