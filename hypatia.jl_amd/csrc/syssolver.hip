@@ -300,16 +300,87 @@ hipEvent_t SysSolver::comm_event() {
   HYP_CHECK(hipEventCreate(&e));
   return e;
 }
-void SysSolver::comm_time_begin(int site, hipEvent_t* a) {
+void SysSolver::comm_time_begin(int site, hipEvent_t* a, hipStream_t st) {
   (void)site;
   if (comm_ev_pending.size() >= 2048) comm_times_flush();   // (bounded: a flush waits for the newest pending pair)
   *a = comm_event();
-  HYP_CHECK(hipEventRecord(*a, ctx.stream));
+  HYP_CHECK(hipEventRecord(*a, st ? st : ctx.stream));
 }
-void SysSolver::comm_time_end(int site, hipEvent_t a) {
+void SysSolver::comm_time_end(int site, hipEvent_t a, hipStream_t st) {
   hipEvent_t b = comm_event();
-  HYP_CHECK(hipEventRecord(b, ctx.stream));
+  HYP_CHECK(hipEventRecord(b, st ? st : ctx.stream));
   comm_ev_pending.push_back(CommEv{a, b, site & 15});
+}
+
+// rows [r0, r1) of the upper triangle <-> a contiguous segment: column j >= r0 contributes rows r0 .. min(r1 - 1, j)
+__global__ void tri_pack_rows_kernel(int n, int r0, int r1, const double* __restrict__ A, long lda, double* __restrict__ P, int unpack) {
+  const int j = r0 + blockIdx.y;
+  const int i = r0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n || i >= r1 || i > j) return;
+  const long h = r1 - r0, dj = j - r0;
+  const long off = (j < r1) ? dj * (dj + 1) / 2 : h * (h + 1) / 2 + (dj - h) * h;
+  if (unpack) const_cast<double*>(A)[(long)j * lda + i] = P[off + (i - r0)];
+  else P[off + (i - r0)] = A[(long)j * lda + i];
+}
+
+bool SysSolver::assemble_lhs_overlapped(long kr0, long kr1, int groups) {
+  if (!rccl_comm || groups < 2 || nmp < 1024 || kr1 - kr0 < 1024) return false;
+  const int T = (nmp + 127) / 128;
+  groups = std::min(groups, T);
+  // tile-row boundaries of groups of (nearly) equal area; tile row i has T - i tiles
+  const long total = (long)T * (T + 1) / 2;
+  std::vector<int> bound(1, 0);
+  long acc = 0;
+  for (int i = 0, g = 1; i < T && g < groups; ++i) {
+    acc += T - i;
+    if (acc * groups >= total * g) { bound.push_back(i + 1); ++g; }
+  }
+  if (bound.back() != T) bound.push_back(T);
+  const int ng = (int)bound.size() - 1;
+  const long cnt = (long)nmp * (nmp + 1) / 2;
+  ov_tri.ensure((size_t)cnt * sizeof(double));
+  while ((int)ov_events.size() < 2 * ng) { hipEvent_t e; HYP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ov_events.push_back(e); }
+  hipEvent_t ev_whole = nullptr;
+  comm_time_begin(14, &ev_whole);
+  long seg = 0;
+  for (int g = 0; g < ng; ++g) {
+    const int r0 = bound[g] * 128, r1 = std::min(nmp, bound[g + 1] * 128);
+    const int rows = r1 - r0, cols = nmp - r0;
+    long nblk = 0;
+    for (int i = bound[g]; i < bound[g + 1]; ++i) nblk += T - i;
+    GemmArgs s{};   // lhs[r0:r1, r0:] = HGQ2[K range, r0:r1]' HGQ2[K range, r0:]  (upper trapezoid)
+    s.M = rows; s.N = cols; s.K = (int)(kr1 - kr0);
+    s.A = HGQ2.d() + kr0 + (long)r0 * q; s.lda = q;
+    s.B = s.A; s.ldb = q;
+    s.C = lhs.d() + (long)r0 * nmp + r0; s.ldc = nmp;
+    s.alpha = 1; s.beta = 0; s.tri = GEMM_UPPER_RECT; s.krange = KR_ALL; s.batch = 1; s.tile_hint = 128;
+    // K slices so that the group is about two rounds of 512 resident workgroups
+    int S = (int)std::max<long>(1, std::min<long>(8, (1024 + nblk / 2) / std::max<long>(nblk, 1)));
+    while (S > 1 && s.K / S < 1024) --S;
+    s.splitk_req = S;
+    gemm(ctx, true, s);
+    HYP_CHECK(hipEventRecord(ov_events[2 * g], ctx.stream));
+    HYP_CHECK(hipStreamWaitEvent(ctx.stream2, ov_events[2 * g], 0));
+    const long h = rows;
+    const long segcnt = h * (h + 1) / 2 + (long)(cols - rows) * h;
+    double* P = ov_tri.d() + seg;
+    const dim3 grid((rows + 255) / 256, cols);
+    hipLaunchKernelGGL(tri_pack_rows_kernel, grid, dim3(256), 0, ctx.stream2, nmp, r0, r1, lhs.d(), (long)nmp, P, 0);
+    comm_calls += 1;
+    comm_doubles += (double)segcnt;
+    comm_hist[0] += 1;
+    hipEvent_t ea = nullptr;
+    comm_time_begin(0, &ea, ctx.stream2);
+    rccl_allreduce_inplace(rccl_comm, P, segcnt, 0, ctx.stream2);
+    comm_time_end(0, ea, ctx.stream2);
+    hipLaunchKernelGGL(tri_pack_rows_kernel, grid, dim3(256), 0, ctx.stream2, nmp, r0, r1, lhs.d(), (long)nmp, P, 1);
+    HYP_CHECK(hipEventRecord(ov_events[2 * g + 1], ctx.stream2));
+    seg += segcnt;
+  }
+  HYP_CHECK(hipGetLastError());
+  for (int g = 0; g < ng; ++g) HYP_CHECK(hipStreamWaitEvent(ctx.stream, ov_events[2 * g + 1], 0));
+  comm_time_end(14, ev_whole);
+  return true;
 }
 void SysSolver::comm_times_flush() {
   for (const CommEv& e : comm_ev_pending) {
@@ -565,6 +636,15 @@ void SysSolver::assemble_lhs() {
       const long per = (((long)idx + ks_world - 1) / ks_world + 15) / 16 * 16;
       r0 = std::min<long>((long)idx, per * ks_rank);
       r1 = std::min<long>((long)idx, r0 + per);
+    }
+    // (round 5, HYP_DIST_OVERLAP=G: row groups, each exchanged on the helper stream under the next one's product)
+    static const int ov_groups = [] { const char* e = getenv("HYP_DIST_OVERLAP"); return e ? atoi(e) : 0; }();
+    bool all_sqrt = true;
+    for (int v : use_sqrt) all_sqrt &= (v != 0);
+    if (ov_groups >= 2 && all_sqrt && (dist() || ks_world > 1) && assemble_lhs_overlapped(r0, r1, ov_groups)) {
+      HYP_CHECK(hipEventRecord(ctx.ev[2], ctx.stream));
+      ctx.kstat[4] += 1;
+      return;   // (the exchange is done)
     }
     s.M = nmp; s.N = nmp; s.K = (int)(r1 - r0); s.A = HGQ2.d() + r0; s.lda = q; s.B = HGQ2.d() + r0; s.ldb = q; s.C = lhs.d(); s.ldc = nmp;
     s.alpha = 1; s.beta = 0; s.tri = GEMM_UPPER; s.krange = KR_ALL; s.batch = 1; s.tag = 1;

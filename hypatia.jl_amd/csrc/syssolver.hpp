@@ -95,8 +95,14 @@ struct SysSolver {
   std::vector<CommEv> comm_ev_pending;
   std::vector<hipEvent_t> comm_ev_free;
   hipEvent_t comm_event();
-  void comm_time_begin(int site, hipEvent_t* a);
-  void comm_time_end(int site, hipEvent_t a);
+  void comm_time_begin(int site, hipEvent_t* a, hipStream_t st = nullptr);   // (st: the stream the exchange is queued on; default the library's main stream)
+  void comm_time_end(int site, hipEvent_t a, hipStream_t st = nullptr);
+  // Round 5 (HYP_DIST_OVERLAP = number of row groups, 0 = off): the Schur product emitted in row groups of equal area, each group's
+  // part of the upper triangle all-reduced on the helper stream while the next group is being multiplied (RCCL in the library only,
+  // every cone through its square-root product).  Returns false if the conditions do not hold (the caller takes the one-launch path).
+  bool assemble_lhs_overlapped(long kr0, long kr1, int groups);
+  DBuf ov_tri;
+  std::vector<hipEvent_t> ov_events;
   void comm_times_flush();
   // Round 4: ONE exchange for a device payload and the scalars that used to follow it in collectives of their own.  The buffer
   // is [payload (npay) | scalars to be summed (nsum) | one slot per rank and scalar to be max-ed (world x nmax)]; a rank fills only

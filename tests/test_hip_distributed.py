@@ -54,6 +54,21 @@ def test_library_rccl_exchanges_one_rank(monkeypatch):
     assert res["lib_exchanges"][0] > 50 and res["lib_exchanges"][1] >= 120 * 121 // 2
 
 
+@pytest.mark.timeout(900)
+def test_schur_exchange_overlapped_with_its_production_one_rank(monkeypatch):
+    """round 5, HYP_DIST_OVERLAP=G (off by default: no N > 1 hardware to decide it on): the Schur product is emitted in G row groups of
+    equal area and each group's part of the upper triangle is all-reduced on the helper stream while the next group is multiplied
+    (SysSolver::assemble_lhs_overlapped; qrchol.jl:219-246 is the sum being exchanged).  One rank through the in-library RCCL (the
+    test box has one GPU): n = 1300 = 11 tile rows in 3 groups; the solve must be the oracle's, and the exchange count says the
+    grouped path ran (3 Schur exchanges per iteration instead of 1)."""
+    monkeypatch.setenv("HYP_DIST_NATIVE", "1")
+    monkeypatch.setenv("HYP_DIST_OVERLAP", "3")
+    res = _run_sharded("1", inst_args=(1300, [24] * 8, 7), world=1, transport="nccl")
+    assert bool(res["rccl_in_library"])
+    hist = [int(v) for v in res["comm_hist"]]
+    assert hist[0] >= 3 * int(res["iters"]), (hist[0], int(res["iters"]))
+
+
 def test_library_rccl_allreduce_on_a_device_buffer():
     """hyp_comm_unique_id / _init_rank / _allreduce / _destroy on a device buffer (one rank; in a fresh process, torch first:
     one HIP runtime per process)"""
