@@ -14,6 +14,10 @@
 #include <malloc.h>
 #include "hyp_internal.hpp"
 
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+
 namespace hyp {
 
 void gemm(Ctx& c, bool transa, GemmArgs a) { HYP_CHECK(gemm_f64_launch(c.stream, transa, a, &c.gemm_scratch)); }
@@ -1538,6 +1542,18 @@ Ctx::Ctx(int dev) : device(dev) {
   HYP_CHECK(hipDeviceGetStreamPriorityRange(&plo, &phi));   // (numerically lower = higher priority)
   HYP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, phi));
   stream_primary = stream;
+  {   // the device's persistent-kernel lock (see hyp_internal.hpp)
+    char bus[64] = "";
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev) != hipSuccess) snprintf(bus, sizeof(bus), "dev%d", dev);
+    for (char* p = bus; *p; ++p)
+      if (*p == ':' || *p == '.' || *p == '/') *p = '_';
+    const char* dir = getenv("TMPDIR");
+    char path[256];
+    snprintf(path, sizeof(path), "%s/hypatia_hip_%s.lock", (dir && dir[0]) ? dir : "/tmp", bus);
+    device_lock_fd = open(path, O_CREAT | O_RDWR, 0666);
+    persistent_ok = (device_lock_fd >= 0 && flock(device_lock_fd, LOCK_EX | LOCK_NB) == 0);
+    if (const char* e = getenv("HYP_PERSISTENT")) persistent_ok = (atoi(e) != 0);   // (1: whatever the lock says; 0: never)
+  }
   HYP_CHECK(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, plo));
   if (const char* e = getenv("HYP_TRSV_SB")) { trsv_sb = (atoi(e) / NB) * NB; trsv_sb_forced = true; }
   scratch.alloc(1 << 20);
@@ -1550,6 +1566,7 @@ Ctx::Ctx(int dev) : device(dev) {
   HYP_CHECK(hipHostMalloc((void**)&h_pinned, h_pinned_n * sizeof(double), hipHostMallocDefault));
 }
 Ctx::~Ctx() {
+  if (device_lock_fd >= 0) (void)close(device_lock_fd);   // (releases the lock)
   for (int i = 0; i < 6; ++i)
     if (ev[i]) (void)hipEventDestroy(ev[i]);
   if (h_info) (void)hipHostFree(h_info);

@@ -82,6 +82,12 @@ struct Ctx {
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipStream_t stream2 = nullptr;            // helper stream: look-ahead trailing updates of the blocked Cholesky
   hipStream_t stream_primary = nullptr;     // the main stream's handle (c.stream unless a StreamSwap / LaneSwitch section is open)
+  // A persistent kernel whose workgroups wait for each other (trsv_onelaunch.hip) must be the only one of its kind on the device: two
+  // of them, from two contexts or two PROCESSES sharing a GPU, could each hold CUs the other's unscheduled workgroups need.  The first
+  // context to take an advisory lock on the device (flock on a file named after its PCI bus id, held for the context's life) may
+  // launch them; every other context on that device uses the launch chains.
+  bool persistent_ok = false;
+  int device_lock_fd = -1;
   std::vector<hipEvent_t> ev_pool;          // ordering events between stream and stream2
   hipEvent_t pool_event(size_t i);
   hipEvent_t aux[4] = {nullptr, nullptr, nullptr, nullptr};   // fork / join events of the two-stream sections (not the look-ahead pool)
@@ -231,7 +237,7 @@ struct TriSolvePlan {
   DBuf probe_ws;
   void measure_quality(Ctx& c, const double* U, long ldu);
   // only on the context's main stream: two such launches side by side on two streams could each hold CUs the other's wavefronts wait for
-  bool ol_usable(const Ctx& c, long ldu) const { return ol_ok && refine >= 0 && refine <= 3 && ol_have[refine] && ldu == ol_ldu && c.stream == c.stream_primary; }
+  bool ol_usable(const Ctx& c, long ldu) const { return ol_ok && c.persistent_ok && refine >= 0 && refine <= 3 && ol_have[refine] && ldu == ol_ldu && c.stream == c.stream_primary; }
   void ol_sweep(Ctx& c, const double* U, int which, double* x, long ldx, double* x3, int nr);
   // both sweeps, x <- (U'U)^-1 x on nr = 1, 2 or 3 columns (x3 != nullptr: the third column lives there instead of x + 2 ldx)
   void solve_both(Ctx& c, const double* U, long ldu, double* x, long ldx, int nr, double* x3 = nullptr);

@@ -197,10 +197,17 @@ def test_one_launch_triangular_sweeps_same_bits_as_the_launch_chains(tmp_path):
     outs = []
     for flag in ("0", "1", "2"):
         out = str(tmp_path / ("trsv_ol%s.npz" % flag))
-        env = dict(os.environ, HYP_TRSV_ONE_LAUNCH=flag)
+        # (HYP_PERSISTENT=1: this pytest process may hold the device's persistent-kernel lock through a context of its own -- it launches
+        #  nothing while the tool runs; HYP_TRSV_OL_STATS: the tool's process reports the one-launch sweeps it ran, so the comparison
+        #  cannot pass on launch chains alone)
+        env = dict(os.environ, HYP_TRSV_ONE_LAUNCH=flag, HYP_PERSISTENT="1", HYP_TRSV_OL_STATS="1")
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_trsv.py")] + sizes + ["--dump", out], cwd=root, env=env,
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
+        ran = "[trsv one-launch]" in r.stderr
+        assert ran == (flag != "0"), (flag, r.stderr[-600:])
+        if flag == "2":
+            assert "both, 3 right-hand side(s)" in r.stderr and "both, 1 right-hand side(s)" in r.stderr
         outs.append(np.load(out))
     for n in sizes:
         a, b, c = (o["x" + n] for o in outs)

@@ -61,6 +61,7 @@ print(json.dumps({"status": s.get_status(), "iters": s.get_num_iters(), "obj": s
 
 def _run(name, env_extra):
     env = dict(os.environ, **env_extra)
+    env.setdefault("HYP_PERSISTENT", "1")   # (the pytest process may hold the device's persistent-kernel lock; it launches nothing meanwhile)
     r = subprocess.run([sys.executable, "-c", SNIPPET % ROOT, name], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     return json.loads(r.stdout.strip().splitlines()[-1])

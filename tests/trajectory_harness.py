@@ -205,6 +205,7 @@ def hip_trajectory(name, route, timeout=1800, **opts):
     for k in REFERENCE_ROUTE:
         env.pop(k, None)
     env.update(route)
+    env.setdefault("HYP_PERSISTENT", "1")   # (the pytest process may hold the device's persistent-kernel lock; it launches nothing meanwhile)
     r = subprocess.run([sys.executable, os.path.abspath(__file__), name, json.dumps(opts)], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
