@@ -98,11 +98,14 @@ def pmc_traffic(n, q):
     """HBM bytes per syrk launch from the committed PMC passes (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE); only
     valid for the configuration they were collected on, else None."""
     try:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_pmc_summary.json")
-        with open(path) as f:
-            rec = json.load(f)["syrk"]
-        if rec["algorithmic_bytes_per_launch"] == q * n * 8 + n * (n + 1) // 2 * 8:
-            return rec["hbm_bytes_per_launch"]
+        for rnd in ("r05", "r04"):   # (the newest committed passes)
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", rnd + "_pmc_summary.json")
+            if not os.path.exists(path):
+                continue
+            with open(path) as f:
+                rec = json.load(f)["syrk"]
+            if rec["algorithmic_bytes_per_launch"] == q * n * 8 + n * (n + 1) // 2 * 8:
+                return rec["hbm_bytes_per_launch"]
     except Exception:
         pass
     return None
@@ -133,7 +136,9 @@ def ref_1gpu(config):
     """the committed single-GPU figure of the SAME workload (profiles/r04_bench_cfg4_1gpu.json, `python bench.py --config 4`):
     the driver's own N = 1 run is the headline configuration (config 2), not this workload"""
     try:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_bench_cfg%s_1gpu.json" % config)
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_bench_cfg%s_1gpu.json" % config)
+        if not os.path.exists(path):
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_bench_cfg%s_1gpu.json" % config)
         with open(path) as f:
             rec = json.loads(f.read().strip().splitlines()[-1])
         return {"iterations_per_s": rec["iterations_per_s"], "ms_per_step": rec["ms_per_step"], "source": "profiles/" + os.path.basename(path)}
@@ -557,7 +562,7 @@ def run_headline(args, world, rank, local_rank, multi, comm=None):
                       if comm is not None else {})},
         "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<true, 4, 1> (Schur syrk, upper)", "achieved": achieved,
                      "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                     "traffic": pmc_traffic(args.n, q), "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 PMC, profiles/r04_pmc_summary.json)",
+                     "traffic": pmc_traffic(args.n, q), "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 PMC, profiles/r05_pmc_summary.json; r04_ if absent)",
                      "launch_ms": syrk_ms, "flops_per_launch": syrk_flops},
         "phases_ms_per_step": {"sqrt_hess_prod": ks[0] / args.steps, "syrk": ks[1] / args.steps, "cholesky": ks[2] / args.steps,
                                "update_lhs": solver.time_upsys / args.steps * 1e3, "get_directions": solver.time_getdir / args.steps * 1e3,
@@ -757,7 +762,7 @@ def main_other(args, world=1, rank=0, local_rank=0, multi=False):
         f_trial_ref = float(dimc) ** 3 / 3 + 2.0 * d1 * d1 * d2          # the reference's per-trial explicit-Hessian Cholesky (Cones.jl:113-118)
         f_trial_exec = 40.0 * d1 * d1 * d2                                # (estimate) Z, its Cholesky, tau, two Jacobi decompositions, the closed-form inverse on two columns
         f_solve = 4.0 * s.model.q * nm + 2.0 * nm * nm
-        trace_kernel = ("launch-bound: ~900 kernels of ~10 us per iteration; largest share jacobi_lds_kernel (profiles/r04_cfg3b_kernel_stats.csv)"
+        trace_kernel = ("launch-bound: ~900 kernels of ~10 us per iteration; largest share jacobi_lds_kernel (profiles/r05_cfg3b_kernel_stats.csv)"
                         if args.config == "3b" else "gemm_f64_kernel (G' (H G), n^2 q flop) and the blocked Cholesky of the n x n Schur matrix")
         alg = (f_uplhs * n_upfact + trials * f_trial_ref + solves * f_solve) / iters
         exe = (f_uplhs * n_upfact + trials * f_trial_exec + n_hfact * float(dimc) ** 3 / 3 + solves * f_solve) / iters
@@ -774,7 +779,7 @@ def main_other(args, world=1, rank=0, local_rank=0, multi=False):
             f_uplhs = 2.0 * U * U + 1.0                                                     # n = 1: one inverse-Hessian product
         f_solve = 4.0 * s.model.q * max(nm, 1) + 2.0 * nm * nm + 4.0 * U * U
         trace_kernel = ("gemm_f64_kernel<true,2,0> (the cone's L x L x U and U x U x L Gram products), then potrf_tiles_kernel / bk_pivot_kernel "
-                        "(profiles/r04_cfg%s_kernel_stats.csv)" % args.config)
+                        "(profiles/r05_cfg%s_kernel_stats.csv)" % args.config)
         alg = (f_uplhs * n_upfact + trials * f_trial + solves * f_solve) / iters
         exe = (f_uplhs * n_upfact + trials * f_feas + n_grad * f_grad + n_hfact * (f_hess + f_chol) + solves * f_solve) / iters
     ms_it = loop_s / iters * 1e3
