@@ -377,9 +377,13 @@ static void ol_append_sweep(std::vector<OlRound>& chain, std::vector<OlRound>& u
 void TriSolvePlan::ol_prepare(Ctx& c, long ldu) {
   ol_ok = false;
   if (!trsv_one_launch_on() || n <= 0 || sb <= 0 || sb > 1024 || refine < 0 || refine > 3) return;
-  int dev = 0, cus = 0;
-  HYP_CHECK(hipGetDevice(&dev));
-  HYP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  // (asked once: hipDeviceGetAttribute is a driver round trip -- 0.19 ms of idle GPU behind every plan build when it sat here per call,
+  //  profiles/r05_iteration_timeline.txt against the final one)
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return n;
+  }();
   if (cus * 2 < 2 * OL_W / 4) return;   // 512 four-wavefront workgroups must be resident at once: at most two per CU asked for
   // (the arena is laid out for the most refinement steps this plan can run: the per-right-hand-side stride and what a launch clears do
   //  not change when the adaptive rule moves between tables)
