@@ -534,6 +534,23 @@ void WsosCone::hess_prod_slow(double* prod, long ldp, const double* arr, long ld
 }
 
 const double* WsosCone::dder3(const double* d_dir) {   // :177-188
+  // the K chains (two Gram-type products, a symmetrization, the column sums) are independent and short (~95 us each at U = 4845, twice
+  // per iteration): on the lanes like the gradient's chains, partial sums per k added in the order of k (the one-stream form's bits)
+  static const bool par = [] { const char* e = getenv("HYP_WSOS_PAR"); return !(e && e[0] == '0'); }();
+  if (par && K >= 2 && K <= 64) {
+    const int nl = std::min(K, Ctx::max_lanes());
+    gparts.ensure((size_t)K * U * sizeof(double));
+    fork_lanes(ctx, nl);
+    for (int k = 0; k < K; ++k) {
+      LaneSwitch on_lane(ctx, k % nl);
+      partial_lambda(k, d_dir);
+      col_dot(ctx, Ls[k], U, LU[k].d(), Ls[k], LU[k].d(), Ls[k], 1.0, false, gparts.d() + (long)k * U);
+    }
+    join_lanes(ctx, nl);
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((U + 255) / 256), dim3(256), 0, ctx.stream, U, K, gparts.d(), dder3v.d());
+    HYP_CHECK(hipGetLastError());
+    return dder3v.d();
+  }
   for (int k = 0; k < K; ++k) {
     partial_lambda(k, d_dir);
     col_dot(ctx, Ls[k], U, LU[k].d(), Ls[k], LU[k].d(), Ls[k], 1.0, k > 0, dder3v.d());

@@ -1,2 +1,5 @@
 export TMPDIR=/tmp
-for f in 0 1 2 0 1 2; do echo "HYP_POTRF_EXPERIMENT=$f: $(HYP_POTRF_EXPERIMENT=$f timeout 300 python tools/bench_potrf.py 2>&1 | head -1)"; done
+python -m pytest tests/test_hip_cones.py tests/test_hip_switches.py tests/test_hip_trajectory.py -m gpu -q -x -k "wsos or Wsos or polymin or switch or par" 2>&1 | tail -3
+for i in 1 2; do
+for c in 5p 5d; do echo "$c lanes: $(python bench.py --config $c 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['phases_ms_per_step'])")"; 
+echo "$c PAR=0 : $(HYP_WSOS_PAR=0 python bench.py --config $c 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['phases_ms_per_step'])")"; done; done
