@@ -3,6 +3,7 @@
 // Dual feasibility needs the nuclear norm of a d1 x d2 matrix (svdvals!, :125-132): computed by a
 // one-sided Jacobi (Hestenes) iteration on the rows, one workgroup per row pair per round.
 #include "cones.hpp"
+#include "tds_small.hpp"
 
 namespace hyp {
 
@@ -219,8 +220,19 @@ __device__ __forceinline__ double jl_rsqrt(double x) {
 // tol_rot: a pair is rotated while its cosine |g| / sqrt(a b) exceeds it; tol_big: a sweep whose rotated pairs all had a cosine
 // <= tol_big is the last one (it leaves cosines of the order of m tol_big^2 behind); floor_rel: columns whose norm is below
 // floor_rel ||B||_F are numerically zero and take no part (0: every column does).
+//
+// decide_u (values-only calls of the dual feasibility test, epinormspectral.jl:125-132: u - sum(svdvals(W)) > eps): the caller
+// only wants to know on which side of *decide_u the nuclear norm lies.  In front of every sweep the state B = [b_1 ... b_m]
+// (nuclear norm invariant under the rotations) gives two rigorous bounds from its column norms d_i and cosines c_pq:
+//   ||B||_* <= sum_i d_i                          (B = sum_i b_i e_i', a sum of rank-one matrices of nuclear norm d_i)
+//   ||B||_* >= ||B_S||_* >= <B_S, Q> / ||Q||_2 = sum_{i in S} d_i / sqrt(||I + C_S||_2) >= sum_{i in S} d_i / sqrt(1 + ||C_S||_F)
+// for any subset S of the columns, Q = their normalised columns (S = the columns above 1e-8 of the largest: noise columns have
+// arbitrary cosines).  Once both bounds are on one side of u by more than 1e-10 relatively the sweeps stop: the sum of the column
+// norms the caller then forms decides as the converged value would (it is the upper bound; where the LOWER bound says "outside",
+// so does it).  Closer than that to the boundary the sweeps run to the end as without the test.
 __global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double* __restrict__ Vg, double* __restrict__ Jg, int max_sweeps, int load_j,
-                                                          int* __restrict__ sweeps_out, double tol_rot, double tol_big, double floor_rel) {
+                                                          int* __restrict__ sweeps_out, double tol_rot, double tol_big, double floor_rel,
+                                                          const double* __restrict__ decide_u, double decide_eps) {
   extern __shared__ __attribute__((aligned(16))) double jl_lds[];
   const int ldv = len | 1;                       // odd stride
   double* V = jl_lds;                            // m columns of length len
@@ -232,8 +244,8 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double
   if (Jg) for (long e = tid; e < (long)m * m; e += 1024) J[(e / m) * ldj + (e % m)] = load_j ? Jg[e] : (((e / m) == (e % m)) ? 1.0 : 0.0);   // (load_j: warm start, the rotations continue an earlier product)
   __syncthreads();
   double floor2 = 0.0;
+  __shared__ double fr[1024];   // (the static part has to stay small: 150 KB of the CU's 160 are the caller's to ask for dynamically)
   if (floor_rel > 0.0) {   // ||B||_F^2 (invariant under the rotations), fixed summation order
-    __shared__ double fr[1024];
     double f = 0.0;
     for (long e = tid; e < (long)len * m; e += 1024) { const double x = V[(e / len) * ldv + (e % len)]; f = fma(x, x, f); }
     fr[tid] = f;
@@ -243,10 +255,59 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double
       __syncthreads();
     }
     floor2 = floor_rel * floor_rel * fr[0];
+    __syncthreads();   // (fr is written again by the bounds pass)
   }
   const int mm = (m % 2 == 0) ? m : m + 1;
   const int sub = tid & 31, grp = tid >> 5;      // 32 groups of 32 lanes
+  double* dc_n2 = fr;            // [256] (fr is free again once floor2 is formed)
+  double* dc_part = fr + 256;    // [32]
+  __shared__ int dc_done;
+  const bool decide = (decide_u != nullptr) && m <= 256;
+  const double u_dec = decide ? decide_u[0] : 0.0;
+  if (sweeps_out && tid == 0) *sweeps_out = 0;
   for (int sweep = 0; sweep < max_sweeps && m > 1; ++sweep) {
+    if (decide) {
+      for (int i = grp; i < m; i += 32) {                       // squared column norms of the current state
+        const double* vi = V + (long)i * ldv;
+        double a = 0.0;
+        for (int r = sub; r < len; r += 32) { const double x = vi[r]; a = fma(x, x, a); }
+        a = jl_sum32(a);
+        if (sub == 0) dc_n2[i] = a;
+      }
+      __syncthreads();
+      double amax = 0.0;
+      for (int i = 0; i < m; ++i) amax = fmax(amax, dc_n2[i]);
+      const double thr = 1e-16 * amax;                          // (squared norms: columns below 1e-8 of the largest stay out of S)
+      double c2 = 0.0;                                          // this group's share of sum_{p < q in S} c_pq^2 (read-only pass: no barrier)
+      for (int t = 0; t < mm - 1; ++t)
+        for (int i = grp; i < mm / 2; i += 32) {
+          int p, q;
+          if (i == 0) { p = mm - 1; q = t; }
+          else { p = (t + i) % (mm - 1); q = (t - i + (mm - 1)) % (mm - 1); }
+          if (p >= m || q >= m) continue;
+          const double ap = dc_n2[p], aq = dc_n2[q];
+          if (!(ap > thr) || !(aq > thr)) continue;
+          const double* vp = V + (long)p * ldv;
+          const double* vq = V + (long)q * ldv;
+          double g = 0.0;
+          for (int r = sub; r < len; r += 32) g = fma(vp[r], vq[r], g);
+          g = jl_sum32(g);
+          c2 += (g * g) / (ap * aq);
+        }
+      if (sub == 0) dc_part[grp] = c2;
+      __syncthreads();
+      if (tid == 0) {
+        double s_up = 0.0, s_sub = 0.0, cf2 = 0.0;
+        for (int i = 0; i < m; ++i) { const double d = sqrt(dc_n2[i]); s_up += d; if (dc_n2[i] > thr) s_sub += d; }
+        for (int g2i = 0; g2i < 32; ++g2i) cf2 += dc_part[g2i];
+        const double s_low = s_sub / sqrt(1.0 + sqrt(2.0 * cf2));
+        const bool inside = (u_dec - s_up * (1.0 + 1e-10)) > decide_eps;
+        const bool outside = !((u_dec - s_low * (1.0 - 1e-10)) > decide_eps);
+        dc_done = (inside || outside) && (s_up == s_up) && (s_low == s_low) ? 1 : 0;
+      }
+      __syncthreads();
+      if (dc_done) break;
+    }
     if (tid == 0) rotated = 0;
     __syncthreads();
     for (int t = 0; t < mm - 1; ++t) {
@@ -352,7 +413,8 @@ static size_t jacobi_lds_bytes(int len, int m, bool with_j) {
 // norm up to O(||C||_F^2) relatively, so cosines of 1e-10 (||C||_F^2 <= m^2 1e-20) are as good as 1e-15 there; and columns below
 // eps ||B||_F are numerically zero, as for LAPACK's own singular values (absolute accuracy eps sigma_max): at a dual point close
 // to the boundary of the cone most columns are such noise, and rotating noise against noise never settles (20 sweeps and more).
-static bool jacobi_in_lds(Ctx& ctx, int len, int m, double* V, double* J, bool load_j = false, bool values_only = false) {
+static bool jacobi_in_lds(Ctx& ctx, int len, int m, double* V, double* J, bool load_j = false, bool values_only = false,
+                          const double* d_decide_u = nullptr) {
   static const bool on = [] { const char* e = getenv("HYP_JACOBI_LDS"); return !(e && e[0] == '0'); }();
   const size_t lds = jacobi_lds_bytes(len, m, J != nullptr);
   if (!on || lds == 0) return false;
@@ -364,7 +426,9 @@ static bool jacobi_in_lds(Ctx& ctx, int len, int m, double* V, double* J, bool l
   static const bool dbg = [] { const char* e = getenv("HYP_JACOBI_DBG"); return e && e[0] == '1'; }();   // sweeps of every call on stderr
   int* sw = dbg ? reinterpret_cast<int*>(ctx.dscal.d() + 63) : nullptr;
   const double tol_rot = values_only ? 1e-10 : 1e-15, tol_big = values_only ? 1e-6 : 1e-8, floor_rel = values_only ? 2.220446049250313e-16 : 0.0;
-  hipLaunchKernelGGL(jacobi_lds_kernel, dim3(1), dim3(1024), lds, ctx.stream, len, m, V, J, 60, load_j ? 1 : 0, sw, tol_rot, tol_big, floor_rel);
+  static const bool decide_on = [] { const char* e = getenv("HYP_ENS_DUAL_DECIDE"); return !(e && e[0] == '0'); }();
+  hipLaunchKernelGGL(jacobi_lds_kernel, dim3(1), dim3(1024), lds, ctx.stream, len, m, V, J, 60, load_j ? 1 : 0, sw, tol_rot, tol_big, floor_rel,
+                     (decide_on && values_only) ? d_decide_u : nullptr, EPS);
   HYP_CHECK(hipGetLastError());
   if (dbg) {
     ctx.d2h(ctx.h_info + 32, sw, sizeof(int));
@@ -402,37 +466,38 @@ __global__ __launch_bounds__(256) void svd_finish_kernel(int len, const double* 
 //   arrow        : c_i = 4 u s_i / z_i^2, d_i = 2 (u^2 + s_i^2) / z_i^2;
 //                  a = (r_u + sum c_i R1_ii / d_i) / S,  S = Huu - sum c_i^2 / d_i = sum 2 / (u^2 + s_i^2) - (d1 - 1) / u^2
 //                  (evaluated in the second, subtraction-free form); A1_ii = (R1_ii + c_i a) / d_i
-__global__ __launch_bounds__(256) void ens_closed_block_kernel(int d1, double u, double Huu, const double* __restrict__ sig, const double* __restrict__ R1,
-                                                               const double* __restrict__ ru, double* __restrict__ A1, double* __restrict__ a_out) {
-  __shared__ double red[2][256];
-  __shared__ double a_sh;
+// (body for any block size >= 256: the sums are those of 256 strided partial sums and their tree whatever the block size)
+__device__ __forceinline__ void ens_closed_block_body(int d1, double u, const double* __restrict__ sig, const double* R1, const double* __restrict__ ru,
+                                                      double* A1, double* __restrict__ a_out, double (*red)[256], double* a_sh) {
+  const int tid = threadIdx.x;
   const double u2 = u * u;
   double s0 = 0.0, s1 = 0.0;
-  for (int i = threadIdx.x; i < d1; i += 256) {
-    const double si = sig[i], zi = u2 - si * si;
-    const double ci = 4.0 * u * si / (zi * zi), di = 2.0 * (u2 + si * si) / (zi * zi);
-    s0 += ci * R1[(long)i * d1 + i] / di;
-    // the arrow's Schur complement Huu - sum c_i^2 / d_i WITHOUT the subtraction: with Huu = sum_i d_i - (d1 - 1) / u^2 (the
-    // barrier is -sum log(u^2 - s_i^2) + (d1 - 1) log u in these coordinates) and d_i^2 - c_i^2 = 4 / z_i^2, each term is
-    // d_i - c_i^2 / d_i = 2 / (u^2 + s_i^2).  Formed as written it is a difference of two numbers of size 1 / z^2 whose
-    // value is of size 1 / u^2: near the boundary every digit cancels (for d1 = 1 there is nothing else in the sum -- the
-    // 1 x 1 and 1 x 2 cones of tests/test_hip_solver.py::test_edge_case_models_hip ended in SlowProgress / NumericalFailure).
-    s1 += 2.0 / (u2 + si * si);
+  if (tid < 256) {
+    for (int i = tid; i < d1; i += 256) {
+      const double si = sig[i], zi = u2 - si * si;
+      const double ci = 4.0 * u * si / (zi * zi), di = 2.0 * (u2 + si * si) / (zi * zi);
+      s0 += ci * R1[(long)i * d1 + i] / di;
+      // the arrow's Schur complement Huu - sum c_i^2 / d_i WITHOUT the subtraction: with Huu = sum_i d_i - (d1 - 1) / u^2 (the
+      // barrier is -sum log(u^2 - s_i^2) + (d1 - 1) log u in these coordinates) and d_i^2 - c_i^2 = 4 / z_i^2, each term is
+      // d_i - c_i^2 / d_i = 2 / (u^2 + s_i^2).  Formed as written it is a difference of two numbers of size 1 / z^2 whose
+      // value is of size 1 / u^2: near the boundary every digit cancels (for d1 = 1 there is nothing else in the sum -- the
+      // 1 x 1 and 1 x 2 cones of tests/test_hip_solver.py::test_edge_case_models_hip ended in SlowProgress / NumericalFailure).
+      s1 += 2.0 / (u2 + si * si);
+    }
+    red[0][tid] = s0; red[1][tid] = s1;
   }
-  red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) { red[0][threadIdx.x] += red[0][threadIdx.x + off]; red[1][threadIdx.x] += red[1][threadIdx.x + off]; }
+    if (tid < off) { red[0][tid] += red[0][tid + off]; red[1][tid] += red[1][tid + off]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    (void)Huu;
-    a_sh = (ru[0] + red[0][0]) / (red[1][0] - (double)(d1 - 1) / u2);
-    a_out[0] = a_sh;
+  if (tid == 0) {
+    *a_sh = (ru[0] + red[0][0]) / (red[1][0] - (double)(d1 - 1) / u2);
+    a_out[0] = *a_sh;
   }
   __syncthreads();
-  const double a = a_sh;
-  for (long e = threadIdx.x; e < (long)d1 * d1; e += 256) {
+  const double a = *a_sh;
+  for (long e = tid; e < (long)d1 * d1; e += blockDim.x) {
     const int i = (int)(e % d1), j = (int)(e / d1);
     const double si = sig[i], sj = sig[j], zi = u2 - si * si, zj = u2 - sj * sj;
     double v;
@@ -445,6 +510,13 @@ __global__ __launch_bounds__(256) void ens_closed_block_kernel(int d1, double u,
     }
     A1[e] = v;
   }
+}
+__global__ __launch_bounds__(256) void ens_closed_block_kernel(int d1, double u, double Huu, const double* __restrict__ sig, const double* __restrict__ R1,
+                                                               const double* __restrict__ ru, double* __restrict__ A1, double* __restrict__ a_out) {
+  __shared__ double red[2][256];
+  __shared__ double a_sh;
+  (void)Huu;
+  ens_closed_block_body(d1, u, sig, R1, ru, A1, a_out, red, &a_sh);
 }
 // T (d1 x d2) <- z_i / 2 * (Rt - P)_ij : the part of the rotated right-hand side orthogonal to V1
 __global__ void ens_closed_perp_kernel(int d1, int d2, double u, const double* __restrict__ sig, const double* __restrict__ Rt, const double* __restrict__ P,
@@ -459,6 +531,310 @@ __global__ void ens_identity_bases_kernel(int d1, int d2, double* __restrict__ U
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e < (long)d1 * d1) U[e] = ((e % d1) == (e / d1)) ? 1.0 : 0.0;
   if (e < (long)d2 * d1) V1[e] = ((e % d2) == (e / d2)) ? 1.0 : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One-workgroup forms of the oracles for cones whose matrices fit one CU's LDS (d1 <= 64: config 3b's 50 x 100).  At that size
+// every kernel of the chains above is a 5-20 us launch of one or two workgroups, and an oracle is 8-25 of them in a row (the
+// feasibility test 8, the gradient with the Hessian's auxiliary matrices 22, a Hessian product 8, the closed-form inverse 7):
+// ~900 launches and 7.4 ms per iteration at 0.012 of the MFMA peak.  Here an oracle is ONE launch of 512 threads: the small
+// products on the matrix cores from LDS / L2 operands (wg_mm: one 16 x 16 tile per wavefront at a time, k ascending in steps of 4
+// into one accumulator -- the order gemm_f64_kernel sums in), Z^-1 (.) by the register-resident wavefront program of
+// tds_small.hpp on 16 columns per wavefront (the bits of zsolve), Z's Cholesky factor and its inverse in LDS.
+// HYP_ENS_FUSED=0 restores the launch chains.  epinormspectral.jl:107-123 (feas), :134-170 (grad, hess aux), :211-239 (hess_prod).
+// ---------------------------------------------------------------------------------------------
+constexpr int EF_THREADS = 512;
+
+// fs(m, n, sum_k fa(m, k) fb(k, n)) for the M x N outputs; operands outside M / N / K read as zero
+template <class FA, class FB, class FS>
+__device__ __forceinline__ void wg_mm(int M, int N, int K, FA fa, FB fb, FS fs) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int tm = (M + 15) >> 4, tn = (N + 15) >> 4;
+  for (int t = wave; t < tm * tn; t += nw) {
+    const int mt = t % tm, nt = t / tm;
+    const int m = mt * 16 + li, n = nt * 16 + li;
+    const bool mok = m < M, nok = n < N;
+    d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int k0 = 0; k0 < K; k0 += 4) {
+      const int k = k0 + lk;
+      const double a = (mok && k < K) ? fa(m, k) : 0.0;
+      const double b = (nok && k < K) ? fb(k, n) : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int mo = mt * 16 + 4 * r + lk, no = nt * 16 + li;
+      if (mo < M && no < N) fs(mo, no, acc[r]);
+    }
+  }
+}
+
+// Z^-1 applied NAPPLY times in a row to ncol columns (zsolve, then zsolve of the result): load(row, col) gives the right-hand
+// side, store(stage, row, col, value) receives the result of application `stage`.  16 columns per wavefront in registers, the
+// operand entries of the factor and its inverse staged in `ops` (TDS_LDS_DOUBLES of LDS) for all wavefronts.  Called by every
+// thread of the workgroup (barriers inside).
+template <int NAPPLY, class FL, class FS>
+__device__ __forceinline__ void wg_zsolve(int d1, int ncol, const double* __restrict__ U, long ldu, const double* __restrict__ dinv, int refine, double* ops,
+                                          FL load, FS store) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int q = lane >> 4, nn = lane & 15;
+  for (int g0 = 0; g0 < ncol; g0 += nw * 16) {               // (uniform trip count)
+    const int c0 = g0 + wave * 16;
+    const bool active = c0 < ncol;
+    const bool inb = c0 + nn < ncol;
+    const int col = min(c0 + nn, ncol - 1);
+    d4_t y[4], x[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * t + q + 4 * r;
+        y[t][r] = (row < d1 && inb) ? load(min(row, d1 - 1), col) : 0.0;
+      }
+#pragma unroll
+    for (int stage = 0; stage < NAPPLY; ++stage) {
+      __syncthreads();
+      tds_stage_ops<true>(U, ldu, dinv, d1, ops);
+      __syncthreads();
+      if (active) tds_apply_lds<true>(ops, d1, refine, y, x);     // forward: U'^-1
+      __syncthreads();
+      tds_stage_ops<false>(U, ldu, dinv, d1, ops);
+      __syncthreads();
+      if (active) tds_apply_lds<false>(ops, d1, refine, x, y);    // backward: U^-1
+      if (inb) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * t + q + 4 * r;
+            if (row < d1) store(stage, row, col, y[t][r]);
+          }
+      }
+    }
+  }
+}
+
+// sum over the workgroup of 256 strided partial sums (threads >= 256 pass 0) by the tree trace_kernel / hp_first_row_kernel use
+__device__ __forceinline__ double wg_tree256(double v, double* red /* [256] */) {
+  const int tid = threadIdx.x;
+  __syncthreads();
+  if (tid < 256) red[tid] = v;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) red[tid] += red[tid + off];
+    __syncthreads();
+  }
+  return red[0];
+}
+
+// update_feas (:107-123) in one launch: W, W' copied out of the point, Z = u^2 I - W W', its upper Cholesky factor in LDS
+// (right-looking, two barriers per column), the factor's inverse by back substitution (16 lanes per column), both written in the
+// layouts of potrf_upper_batched.  rec[0] = u, rec[1] = 0 / the 1-based index of the first non-positive pivot / -1 (u <= eps).
+__global__ __launch_bounds__(EF_THREADS) void ens_feas_fused_kernel(int d1, int d2, const double* __restrict__ point, double* __restrict__ W,
+                                                                    double* __restrict__ WT, double* __restrict__ Zfact, double* __restrict__ Zdinv,
+                                                                    double* __restrict__ rec) {
+  extern __shared__ __attribute__((aligned(16))) double ef_lds[];
+  double* Zs = ef_lds;                     // d1 x d1, ld d1
+  volatile double* Ds = ef_lds + (long)d1 * d1;
+  const int tid = threadIdx.x;
+  const double u = point[0];
+  const double* Wp = point + 1;
+  for (int e = tid; e < d1 * d2; e += EF_THREADS) {
+    const double w = Wp[e];
+    W[e] = w;
+    WT[(e / d1) + (long)(e % d1) * d2] = w;
+  }
+  if (!(u > EPS)) {
+    if (tid == 0) { rec[0] = u; rec[1] = -1.0; }
+    return;
+  }
+  const double u2 = u * u;
+  wg_mm(d1, d1, d2, [&](int m, int k) { return Wp[m + (long)k * d1]; }, [&](int k, int n) { return Wp[n + (long)k * d1]; },
+        [&](int m, int n, double acc) {
+          double v = -1.0 * acc;
+          v += (m == n) ? u2 : 0.0;
+          Zs[m + n * d1] = v;
+        });
+  __syncthreads();
+  int fail = 0;
+  for (int k = 0; k < d1; ++k) {
+    const double piv = Zs[k + k * d1];
+    if (!(piv > 0.0)) { fail = k + 1; break; }                // (uniform: every thread reads the same word)
+    const double s = sqrt(piv);
+    __syncthreads();                                           // (everyone has read the pivot before it is replaced)
+    for (int j = k + tid; j < d1; j += EF_THREADS) Zs[k + j * d1] = (j == k) ? s : Zs[k + j * d1] / s;
+    __syncthreads();
+    const int w = d1 - k - 1;
+    for (int idx = tid; idx < w * w; idx += EF_THREADS) {
+      const int i = k + 1 + idx % w, j = k + 1 + idx / w;
+      if (i <= j) Zs[i + j * d1] = fma(-Zs[k + i * d1], Zs[k + j * d1], Zs[i + j * d1]);
+    }
+    __syncthreads();
+  }
+  if (fail) {
+    if (tid == 0) { rec[0] = u; rec[1] = (double)fail; }
+    return;
+  }
+  // D = U^-1 (upper), column j by back substitution: d_jj = 1 / u_jj, d_ij = -(sum_{i < k <= j} u_ik d_kj) / u_ii
+  for (int e = tid; e < d1 * d1; e += EF_THREADS) Ds[e] = 0.0;
+  __syncthreads();
+  {
+    const int g = tid >> 4, l = tid & 15;
+    for (int j = g; j < d1; j += EF_THREADS / 16) {
+      if (l == 0) Ds[j + j * d1] = 1.0 / Zs[j + j * d1];
+      for (int i = j - 1; i >= 0; --i) {
+        double sacc = 0.0;
+        for (int k = i + 1 + l; k <= j; k += 16) sacc = fma(Zs[i + k * d1], Ds[k + j * d1], sacc);
+        sacc += __shfl_xor(sacc, 8, 16);
+        sacc += __shfl_xor(sacc, 4, 16);
+        sacc += __shfl_xor(sacc, 2, 16);
+        sacc += __shfl_xor(sacc, 1, 16);
+        if (l == 0) Ds[i + j * d1] = -sacc / Zs[i + i * d1];
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < d1 * d1; e += EF_THREADS) {
+    const int i = e % d1, j = e / d1;
+    Zfact[e] = (i <= j) ? Zs[e] : 0.0;
+    const double dij = Ds[e];
+    Zdinv[i + (long)j * NB] = dij;                            // inv(U)
+    Zdinv[(long)NB * NB + j + (long)i * NB] = dij;            // its transpose
+  }
+  if (tid == 0) { rec[0] = u; rec[1] = 0.0; }
+}
+
+// update_grad + update_hess_aux (:134-170) in one launch: tau = Z^-1 W, Zitau = Z^-1 tau, grad, HuW = -4 u Zitau, Zi = U^-1 U^-T,
+// WtauI = I + W' tau; rec[2..5] = tr(Zi), <Zi, Zi>, g0, Huu
+__global__ __launch_bounds__(EF_THREADS) void ens_grad_aux_fused_kernel(int d1, int d2, double u, const double* __restrict__ W,
+                                                                        const double* __restrict__ U, const double* __restrict__ dinv, int refine,
+                                                                        double* __restrict__ tau, double* __restrict__ Zi, double* __restrict__ grad,
+                                                                        double* __restrict__ Zitau, double* __restrict__ HuW, double* __restrict__ WtauI,
+                                                                        double* __restrict__ rec) {
+  extern __shared__ __attribute__((aligned(16))) double ef_lds[];
+  __shared__ double red[256];
+  double* TauS = ef_lds;                   // d1 x d2
+  double* ZiS = ef_lds + (long)d1 * d2;    // d1 x d1
+  double* ops = ZiS + (long)d1 * d1;       // TDS_LDS_DOUBLES
+  const int tid = threadIdx.x;
+  const double c4u = -4.0 * u;
+  wg_zsolve<2>(d1, d2, U, d1, dinv, refine, ops, [&](int row, int col) { return W[row + (long)col * d1]; },
+               [&](int stage, int row, int col, double v) {
+                 const long e = row + (long)col * d1;
+                 if (stage == 0) { tau[e] = v; TauS[e] = v; grad[1 + e] = 2.0 * v; }
+                 else { Zitau[e] = v; HuW[e] = c4u * v; }
+               });
+  wg_mm(d1, d1, d1, [&](int m, int k) { return (k >= m) ? dinv[m + (long)k * NB] : 0.0; },
+        [&](int k, int n) { return (k >= n) ? dinv[n + (long)k * NB] : 0.0; },
+        [&](int m, int n, double acc) { ZiS[m + n * d1] = acc; Zi[m + (long)n * d1] = acc; });
+  __syncthreads();
+  double tr = 0.0;
+  if (tid < 256) for (int i = tid; i < d1; i += 256) tr += ZiS[i + i * d1];
+  const double trZi = wg_tree256(tr, red);
+  double s2 = 0.0;
+  if (tid < 256) for (int e = tid; e < d1 * d1; e += 256) s2 = fma(ZiS[e], ZiS[e], s2);
+  const double trZi2 = wg_tree256(s2, red);
+  wg_mm(d2, d2, d1, [&](int m, int k) { return W[k + (long)m * d1]; }, [&](int k, int n) { return TauS[k + n * d1]; },
+        [&](int m, int n, double acc) {
+          double v = acc;
+          v += (m == n) ? 1.0 : 0.0;
+          WtauI[m + (long)n * d2] = v;
+        });
+  if (tid == 0) {
+    // g0 = (-u trZi) 2 + (d1 - 1) / u ; Huu = 4 u u trZi2 + (g0 - 2 (d1 - 1) / u) / u   (as the host forms them, no contraction)
+    const double dm1 = (double)(d1 - 1);
+    const double g0 = __dadd_rn(__dmul_rn(__dmul_rn(-u, trZi), 2.0), __ddiv_rn(dm1, u));
+    const double huu = __dadd_rn(__dmul_rn(__dmul_rn(__dmul_rn(4.0, u), u), trZi2),
+                                 __ddiv_rn(__dadd_rn(g0, -__ddiv_rn(__dmul_rn(2.0, dm1), u)), u));
+    grad[0] = g0;
+    rec[2] = trZi; rec[3] = trZi2; rec[4] = g0; rec[5] = huu;
+  }
+}
+
+// hess_prod (:211-239), one workgroup per column: out_u = Huu a_u + <HuW, A>; T = A W', S = T + T' - 2 u a_u I,
+// out_W = Z^-1 (2 S tau + 2 A)
+__global__ __launch_bounds__(EF_THREADS) void ens_hess_prod_fused_kernel(int d1, int d2, double u, double Huu, const double* __restrict__ HuW,
+                                                                         const double* __restrict__ WT, const double* __restrict__ tau,
+                                                                         const double* __restrict__ U, const double* __restrict__ dinv, int refine,
+                                                                         const double* __restrict__ arr, long lda, double* __restrict__ prod, long ldp) {
+  extern __shared__ __attribute__((aligned(16))) double ef_lds[];
+  __shared__ double red[256];
+  double* Ts = ef_lds;                          // d1 x d1
+  double* Ss = Ts + (long)d1 * d1;              // d1 x d1
+  double* Rs = Ss + (long)d1 * d1;              // d1 x d2
+  double* ops = Rs + (long)d1 * d2;             // TDS_LDS_DOUBLES
+  const int tid = threadIdx.x, dw = d1 * d2;
+  const double* a = arr + (long)blockIdx.x * lda;
+  double* p = prod + (long)blockIdx.x * ldp;
+  const double a0 = a[0];
+  const double* A = a + 1;
+  double s = 0.0;
+  if (tid < 256) for (int i = tid; i < dw; i += 256) s += HuW[i] * A[i];
+  const double hw = wg_tree256(s, red);
+  if (tid == 0) p[0] = Huu * a0 + hw;
+  wg_mm(d1, d1, d2, [&](int m, int k) { return A[m + (long)k * d1]; }, [&](int k, int n) { return WT[k + (long)n * d2]; },
+        [&](int m, int n, double acc) { Ts[m + n * d1] = acc; });
+  __syncthreads();
+  for (int e = tid; e < d1 * d1; e += EF_THREADS) {
+    const int r = e % d1, c = e / d1;
+    double v = Ts[c * d1 + r] + Ts[r * d1 + c];
+    if (r == c) v -= 2.0 * u * a0;
+    Ss[c * d1 + r] = v;
+  }
+  __syncthreads();
+  wg_mm(d1, d2, d1, [&](int m, int k) { return Ss[k + m * d1]; }, [&](int k, int n) { return tau[k + (long)n * d1]; },
+        [&](int m, int n, double acc) {
+          double v = 2.0 * acc;
+          v += 2.0 * A[m + (long)n * d1];
+          Rs[m + n * d1] = v;
+        });
+  __syncthreads();
+  wg_zsolve<1>(d1, d2, U, d1, dinv, refine, ops, [&](int row, int col) { return Rs[row + col * d1]; },
+               [&](int, int row, int col, double v) { p[1 + row + (long)col * d1] = v; });
+}
+
+// closed_inv_apply, one workgroup per column (see the derivation at update_svd): Rt = U' R, R1 = Rt V1, T = z / 2 (Rt - R1 V1') +
+// A1 V1', out_W = U T
+__global__ __launch_bounds__(EF_THREADS) void ens_closed_inv_fused_kernel(int d1, int d2, double u, const double* __restrict__ Usvd,
+                                                                          const double* __restrict__ V1, const double* __restrict__ V1T,
+                                                                          const double* __restrict__ sig, const double* __restrict__ arr, long lda,
+                                                                          double* __restrict__ prod, long ldp) {
+  extern __shared__ __attribute__((aligned(16))) double ef_lds[];
+  __shared__ double red[2][256];
+  __shared__ double a_sh;
+  double* Rt = ef_lds;                          // d1 x d2
+  double* T = Rt + (long)d1 * d2;               // d1 x d2
+  double* R1 = T + (long)d1 * d2;               // d1 x d1
+  double* A1 = R1 + (long)d1 * d1;              // d1 x d1
+  const double* a = arr + (long)blockIdx.x * lda;
+  double* p = prod + (long)blockIdx.x * ldp;
+  const double* A = a + 1;
+  wg_mm(d1, d2, d1, [&](int m, int k) { return Usvd[k + (long)m * d1]; }, [&](int k, int n) { return A[k + (long)n * d1]; },
+        [&](int m, int n, double acc) { Rt[m + n * d1] = acc; });
+  __syncthreads();
+  wg_mm(d1, d1, d2, [&](int m, int k) { return Rt[m + k * d1]; }, [&](int k, int n) { return V1[k + (long)n * d2]; },
+        [&](int m, int n, double acc) { R1[m + n * d1] = acc; });
+  __syncthreads();
+  ens_closed_block_body(d1, u, sig, R1, a, A1, p, red, &a_sh);
+  // T = z_i / 2 (Rt - R1 V1')
+  wg_mm(d1, d2, d1, [&](int m, int k) { return R1[m + k * d1]; }, [&](int k, int n) { return V1T[k + (long)n * d1]; },
+        [&](int m, int n, double acc) {
+          const double si = sig[m];
+          T[m + n * d1] = 0.5 * (u * u - si * si) * (Rt[m + n * d1] - acc);
+        });
+  __syncthreads();
+  // T += A1 V1'   (in place: every entry is read and written by the one lane that owns it)
+  wg_mm(d1, d2, d1, [&](int m, int k) { return A1[m + k * d1]; }, [&](int k, int n) { return V1T[k + (long)n * d1]; },
+        [&](int m, int n, double acc) {
+          double v = acc;
+          v += T[m + n * d1];
+          T[m + n * d1] = v;
+        });
+  __syncthreads();
+  wg_mm(d1, d2, d1, [&](int m, int k) { return Usvd[m + (long)k * d1]; }, [&](int k, int n) { return T[k + n * d1]; },
+        [&](int m, int n, double acc) { p[1 + m + (long)n * d1] = acc; });
 }
 
 static void mm(Ctx& c, bool transa, int M, int N, int K, const double* A, long lda, const double* B, long ldb, double* C, long ldc,
@@ -477,6 +853,38 @@ static int read_info(Ctx& ctx, const int* d_info) {
   ctx.d2h(ctx.h_info, d_info, sizeof(int));
   ctx.sync();
   return ctx.h_info[0];
+}
+
+// the one-workgroup kernels apply where the cone's matrices fit: d1 <= 64 (the wavefront program of tds_small.hpp) and the
+// largest LDS layout (closed-form inverse: two d1 x d2 and two d1 x d1 matrices) within 150 KB
+static size_t ens_fused_lds_bytes(int d1, int d2, int which) {
+  const size_t dd = (size_t)d1 * d1, dw = (size_t)d1 * d2;
+  switch (which) {
+    case 0: return 2 * dd * 8;                                   // feas: Z, D
+    case 1: return (dw + dd + TDS_LDS_DOUBLES) * 8;              // grad + aux: tau, Zi, staged operands
+    case 2: return (2 * dd + dw + TDS_LDS_DOUBLES) * 8;          // hess_prod: T, S, R, staged operands
+    default: return (2 * dw + 2 * dd) * 8;                       // closed inverse: Rt, T, R1, A1
+  }
+}
+bool EpiNormSpectralCone::fused() {
+  if (fused_checked) return fused_ok;
+  static const bool on = [] { const char* e = getenv("HYP_ENS_FUSED"); return !(e && e[0] == '0'); }();
+  size_t mx = 0;
+  for (int w = 0; w < 4; ++w) mx = std::max(mx, ens_fused_lds_bytes(d1, d2, w));
+  fused_ok = on && d1 <= 64 && mx <= 150 * 1024;
+  if (fused_ok) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      HYP_CHECK(hipFuncSetAttribute((const void*)ens_feas_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HYP_CHECK(hipFuncSetAttribute((const void*)ens_grad_aux_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HYP_CHECK(hipFuncSetAttribute((const void*)ens_hess_prod_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HYP_CHECK(hipFuncSetAttribute((const void*)ens_closed_inv_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      attr_set = true;
+    }
+    frec.alloc(8 * sizeof(double));
+  }
+  fused_checked = true;
+  return fused_ok;
 }
 
 EpiNormSpectralCone::EpiNormSpectralCone(Ctx& c, int d1_, int d2_, bool use_dual) : GenericHessCone(c, CONE_EPINORMSPECTRAL) {
@@ -508,6 +916,17 @@ void EpiNormSpectralCone::zsolve(double* X, long ldx, int nrhs) {   // ldiv!(fac
 }
 
 bool EpiNormSpectralCone::update_feas() {   // :107-123
+  if (fused()) {
+    hipLaunchKernelGGL(ens_feas_fused_kernel, dim3(1), dim3(EF_THREADS), ens_fused_lds_bytes(d1, d2, 0), ctx.stream, d1, d2, point.d(), W.d(), WT.d(),
+                       Zfact.d(), Zdinv.d(), frec.d());
+    HYP_CHECK(hipGetLastError());
+    ctx.d2h(ctx.h_pinned + 56, frec.d(), 2 * sizeof(double));
+    ctx.sync();
+    u = ctx.h_pinned[56];
+    is_feas_ = (u > EPS) && (ctx.h_pinned[57] == 0.0);
+    feas_updated = true;
+    return is_feas_;
+  }
   u = read_scalar(ctx, point.d());
   if (u > EPS) {
     ctx.d2d(W.p, point.d() + 1, (size_t)d1 * d2 * 8);
@@ -525,14 +944,14 @@ bool EpiNormSpectralCone::update_feas() {   // :107-123
   return is_feas_;
 }
 
-double EpiNormSpectralCone::nuclear_norm(const double* d_mat) {
-  nuclear_norm_launch(d_mat, ctx.dscal.d());
+double EpiNormSpectralCone::nuclear_norm(const double* d_mat, const double* d_decide_u) {
+  nuclear_norm_launch(d_mat, ctx.dscal.d(), d_decide_u);
   return read_scalar(ctx, ctx.dscal.d());
 }
 
 // the device work of the nuclear norm on ctx.stream, the result left in *d_out (no host round trip where the one-launch
 // decomposition applies)
-void EpiNormSpectralCone::nuclear_norm_launch(const double* d_mat, double* d_out) {
+void EpiNormSpectralCone::nuclear_norm_launch(const double* d_mat, double* d_out, const double* d_decide_u) {
   // rows of the d1 x d2 matrix = columns of its transpose V (d2 x d1): orthogonalise them pairwise
   double* V = t12a.d();
   dev_transpose(ctx, d1, d2, d_mat, d1, V, d2, 1, 0, 0);
@@ -551,13 +970,13 @@ void EpiNormSpectralCone::nuclear_norm_launch(const double* d_mat, double* d_out
     } else {
       dual_warm_count = 0;
     }
-    done = jacobi_in_lds(ctx, d2, m, warm ? V2 : V, Jdual.d(), warm, true);
+    done = jacobi_in_lds(ctx, d2, m, warm ? V2 : V, Jdual.d(), warm, true, d_decide_u);
     if (done) {
       dual_prev_ok = true;
       if (warm) V = V2;
     }
   }
-  if (m > 1 && !done && !jacobi_in_lds(ctx, d2, m, V, nullptr, false, true)) {
+  if (m > 1 && !done && !jacobi_in_lds(ctx, d2, m, V, nullptr, false, true, d_decide_u)) {
     for (int sweep = 0; sweep < 40; ++sweep) {
       ctx.zero(Zinfo.p, sizeof(int));
       for (int t = 0; t < mpad - 1; ++t)
@@ -573,7 +992,7 @@ void EpiNormSpectralCone::nuclear_norm_launch(const double* d_mat, double* d_out
 bool EpiNormSpectralCone::is_dual_feas() {   // :125-132
   if (dual_cached) return dual_feas_;
   const double ud = read_scalar(ctx, dual_point.d());
-  if (ud > EPS) return (ud - nuclear_norm(dual_point.d() + 1)) > EPS;
+  if (ud > EPS) return (ud - nuclear_norm(dual_point.d() + 1, dual_point.d())) > EPS;
   return false;
 }
 
@@ -594,7 +1013,7 @@ void EpiNormSpectralCone::prefetch_feas() {
   {
     StreamSwap on_helper(ctx);
     double* res = ctx.dscal.d() + 40;
-    nuclear_norm_launch(dual_point.d() + 1, res);
+    nuclear_norm_launch(dual_point.d() + 1, res, dual_point.d());
     ctx.d2h(ctx.h_pinned + 40, res, sizeof(double));
     ctx.d2h(ctx.h_pinned + 41, dual_point.d(), sizeof(double));
   }
@@ -639,6 +1058,19 @@ bool EpiNormSpectralCone::early_reject(double irtmu, double bound2) {
 
 void EpiNormSpectralCone::update_grad() {   // :134-150
   ctx.kstat[7] += 1;
+  if (fused()) {   // gradient and the Hessian's auxiliary matrices together (update_hess_aux then finds them)
+    hipLaunchKernelGGL(ens_grad_aux_fused_kernel, dim3(1), dim3(EF_THREADS), ens_fused_lds_bytes(d1, d2, 1), ctx.stream, d1, d2, u, W.d(), Zfact.d(),
+                       Zdinv.d(), trsm_refine_steps(), tau.d(), Zi.d(), grad.d(), Zitau.d(), HuW.d(), WtauI.d(), frec.d());
+    HYP_CHECK(hipGetLastError());
+    ctx.d2h(ctx.h_pinned + 58, frec.d() + 2, 4 * sizeof(double));
+    ctx.sync();
+    trZi2 = ctx.h_pinned[59];
+    g0_host = ctx.h_pinned[60];
+    Huu = ctx.h_pinned[61];
+    grad_updated = true;
+    hess_aux_updated = true;
+    return;
+  }
   ctx.d2d(tau.p, W.p, (size_t)d1 * d2 * 8);
   zsolve(tau.d(), d1, d2);                                              // tau = Z^-1 W
   // Zi = Z^-1 = U^-1 U^-T
@@ -659,6 +1091,7 @@ void EpiNormSpectralCone::update_grad() {   // :134-150
 
 void EpiNormSpectralCone::update_hess_aux() {   // :152-170
   get_grad();
+  if (hess_aux_updated) return;   // (the one-workgroup gradient kernel forms the auxiliary matrices as well)
   ctx.d2d(Zitau.p, tau.p, (size_t)d1 * d2 * 8);
   zsolve(Zitau.d(), d1, d2);
   dev_scale_copy(ctx, d1 * d2, -4.0 * u, Zitau.d(), HuW.d());
@@ -682,6 +1115,12 @@ void EpiNormSpectralCone::update_hess() {   // :172-209
 void EpiNormSpectralCone::hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) {   // :211-239
   if (!hess_aux_updated) update_hess_aux();
   if (ncols <= 0) return;
+  if (fused() && ncols <= 4096) {   // (a few columns: directions, residuals, bounds; the explicit-Hessian callers come with thousands)
+    hipLaunchKernelGGL(ens_hess_prod_fused_kernel, dim3(ncols), dim3(EF_THREADS), ens_fused_lds_bytes(d1, d2, 2), ctx.stream, d1, d2, u, Huu, HuW.d(),
+                       WT.d(), tau.d(), Zfact.d(), Zdinv.d(), trsm_refine_steps(), arr, lda, prod, ldp);
+    HYP_CHECK(hipGetLastError());
+    return;
+  }
   const int dw = d1 * d2;
   const long cap = 1L << 25;   // doubles per workspace
   int chunk = (int)std::min<long>(std::min(ncols, 32768), std::max<long>(1, cap / std::max((long)d1 * d1, (long)dw)));
@@ -830,6 +1269,12 @@ void EpiNormSpectralCone::inv_hess_prod(double* prod, long ldp, const double* ar
 // point before it: prox_lower_bound) and the epigraph variable u_used that belongs to it
 void EpiNormSpectralCone::closed_inv_apply(double u_used, double* prod, long ldp, const double* arr, long lda, int ncols) {
   const double u = u_used;
+  if (fused() && ncols > 0 && ncols <= 4096) {
+    hipLaunchKernelGGL(ens_closed_inv_fused_kernel, dim3(ncols), dim3(EF_THREADS), ens_fused_lds_bytes(d1, d2, 3), ctx.stream, d1, d2, u, Usvd.d(), V1.d(),
+                       V1T.d(), sig.d(), arr, lda, prod, ldp);
+    HYP_CHECK(hipGetLastError());
+    return;
+  }
   const int dw = d1 * d2;
   const size_t b11 = (size_t)d1 * d1 * 8, b12 = (size_t)dw * 8;
   cw1.ensure(b12); cw2.ensure(b11); cw3.ensure(b12); cw4.ensure(b11); cw5.ensure(b12);

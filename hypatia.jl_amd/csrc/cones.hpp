@@ -388,8 +388,15 @@ struct EpiNormSpectralCone : GenericHessCone {   // src/Cones/epinormspectral.jl
   void hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;   // :211-239
   const double* dder3(const double* d_dir) override;                                          // :241-294
   void zsolve(double* X, long ldx, int nrhs);    // X <- Z^-1 X
-  double nuclear_norm(const double* d_mat /* d1 x d2 col-major */);
-  void nuclear_norm_launch(const double* d_mat, double* d_out);
+  // one-workgroup forms of update_feas / update_grad + update_hess_aux / hess_prod / closed_inv_apply where the matrices fit one
+  // CU's LDS (d1 <= 64; HYP_ENS_FUSED, cone_epinormspectral.hip)
+  bool fused();
+  bool fused_checked = false, fused_ok = false;
+  DBuf frec;                  // device record of the fused kernels: u, info, tr(Zi), <Zi, Zi>, g0, Huu
+  // d_decide_u: device address of the epigraph variable the caller compares the norm with (dual feasibility test): the sweeps of the
+  // decomposition stop as soon as rigorous bounds put the norm on one side of it (HYP_ENS_DUAL_DECIDE, cone_epinormspectral.hip)
+  double nuclear_norm(const double* d_mat /* d1 x d2 col-major */, const double* d_decide_u = nullptr);
+  void nuclear_norm_launch(const double* d_mat, double* d_out, const double* d_decide_u = nullptr);
   void prefetch_feas() override;
   bool early_reject(double irtmu, double bound2) override;
   void closed_inv_apply(double u_used, double* prod, long ldp, const double* arr, long lda, int ncols);

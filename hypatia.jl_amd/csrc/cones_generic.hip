@@ -525,6 +525,26 @@ void WsosCone::hess_prod_slow(double* prod, long ldp, const double* arr, long ld
     hess_prod(prod, ldp, arr, lda, ncols);
     return;
   }
+  // the K chains of a column (two Gram-type products, a symmetrization, the column sums: ~95-130 us each at U = 4845, eight and
+  // more columns per iteration through apply_lhs and the right-hand sides) are independent: on the lanes like dder3's, partial
+  // sums per k added in the order of k (the one-stream form's bits)
+  static const bool par = [] { const char* e = getenv("HYP_WSOS_PAR"); return !(e && e[0] == '0'); }();
+  if (par && K >= 2 && K <= 64) {
+    const int nl = std::min(K, Ctx::max_lanes());
+    gparts.ensure((size_t)K * U * sizeof(double));
+    for (int j = 0; j < ncols; ++j) {
+      fork_lanes(ctx, nl);
+      for (int k = 0; k < K; ++k) {
+        LaneSwitch on_lane(ctx, k % nl);
+        partial_lambda(k, arr + (long)j * lda);
+        col_dot(ctx, Ls[k], U, LFLP[k].d(), Ls[k], LU[k].d(), Ls[k], 1.0, false, gparts.d() + (long)k * U);
+      }
+      join_lanes(ctx, nl);
+      hipLaunchKernelGGL(sum_parts_kernel, dim3((U + 255) / 256), dim3(256), 0, ctx.stream, U, K, gparts.d(), prod + (long)j * ldp);
+    }
+    HYP_CHECK(hipGetLastError());
+    return;
+  }
   for (int j = 0; j < ncols; ++j) {
     for (int k = 0; k < K; ++k) {
       partial_lambda(k, arr + (long)j * lda);

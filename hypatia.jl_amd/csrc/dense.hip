@@ -12,6 +12,7 @@
 // run block by block against the same inverted diagonal blocks (one fused launch per block).
 // All reductions have a fixed order: results are bitwise reproducible run to run.
 #include <malloc.h>
+#include "tds_small.hpp"
 #include "hyp_internal.hpp"
 
 #include <fcntl.h>
@@ -629,41 +630,17 @@ __global__ __launch_bounds__(256) void trsm_diag_refined_kernel(const double* __
 // registers -- no LDS, no barrier; the <= 40 + 40 operand entries per lane of D and T are requested up front.  The 128-row
 // kernel above spends its fixed ~14 us (72 + 72 operands, three slabs through LDS) on such a block whatever its size: at
 // config 3b 2700 launches per solve, 0.8 ms per iteration.
-template <bool LOWER>
-__device__ __forceinline__ constexpr int tds_idx(int t, int kk) {   // position of (tile t, k-step kk) among the steps a triangle keeps
-  int n = 0;
-  for (int a = 0; a < 4; ++a)
-    for (int k = 0; k < 16; ++k) {
-      const bool keep = LOWER ? (k < 4 * a + 4) : (k >= 4 * a);
-      if (a == t && k == kk) return keep ? n : -1;
-      if (keep) ++n;
-    }
-  return -1;
-}
 template <bool TRANS>
 __global__ __launch_bounds__(256) void trsm_diag_refined_small_kernel(const double* __restrict__ T, long ldt, const double* __restrict__ dinv_blk,
                                                                       int nb, double* __restrict__ X, long ldx, int nrhs, int refine) {
-  constexpr bool LOWER = TRANS;
-  constexpr int NOPS = 40;                                    // 4 + 8 + 12 + 16 k-steps of a 4-tile triangle
+  // (the wavefront program itself: tds_small.hpp -- shared with the one-workgroup kernels of the spectral cone, ens_fused.hip)
   const int lane = threadIdx.x & 63, q = lane >> 4, nn = lane & 15;
   const int c0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
   if (c0 >= nrhs) return;
   const bool inb = c0 + nn < nrhs;
   double* colp = X + (long)min(c0 + nn, nrhs - 1) * ldx;
-  const double* Dop = dinv_blk + (TRANS ? (long)NB * NB : 0);
-  double dop[NOPS], top[NOPS];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      constexpr int dummy = 0; (void)dummy;
-      const int id = tds_idx<LOWER>(t, kk);
-      if (id >= 0) {
-        const int rc = min(16 * t + nn, nb - 1), kc = min(4 * kk + q, nb - 1);   // (clamped: always a valid address)
-        dop[id] = Dop[(long)kc * NB + rc];
-        top[id] = TRANS ? T[(long)rc * ldt + kc] : T[(long)kc * ldt + rc];
-      }
-    }
+  double dop[TDS_NOPS], top[TDS_NOPS];
+  tds_load_ops<TRANS>(T, ldt, dinv_blk, nb, dop, top);
   d4_t y[4], x[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -671,40 +648,9 @@ __global__ __launch_bounds__(256) void trsm_diag_refined_small_kernel(const doub
     for (int r = 0; r < 4; ++r) {
       const int row = 16 * t + q + 4 * r;
       y[t][r] = (row < nb && inb) ? colp[min(row, nb - 1)] : 0.0;
-      x[t][r] = 0.0;
     }
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      const int id = tds_idx<LOWER>(t, kk);
-      if (id >= 0) {
-        const int r = 16 * t + nn, k = 4 * kk + q;
-        const bool ok = (r < nb) && (k < nb) && (LOWER ? (k <= r) : (k >= r));
-        dop[id] = ok ? dop[id] : 0.0;
-        top[id] = ok ? -top[id] : 0.0;
-      }
-    }
-  // out[t] += sum_kk op[t][kk] v[kk >> 2][kk & 3]: k-steps outside, tiles inside (four independent accumulator chains)
-  auto product = [&](const double (&op)[NOPS], const d4_t (&v)[4], d4_t (&out)[4]) {
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      if (4 * kk >= nb) continue;                             // (wave-uniform: beyond the block)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int id = tds_idx<LOWER>(t, kk);
-        if (id >= 0 && 16 * t < nb) out[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[id], v[kk >> 2][kk & 3], out[t], 0, 0, 0);
-      }
-    }
-  };
-  product(dop, y, x);                                         // x0 = op(D) y
-  for (int it = 0; it < refine; ++it) {
-    d4_t res[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) res[t] = y[t];
-    product(top, x, res);                                     // r = y - op(T) x
-    product(dop, res, x);                                     // x += op(D) r
-  }
+  tds_mask_ops<TRANS>(nb, dop, top);
+  tds_apply<TRANS>(dop, top, nb, refine, y, x);
   if (inb) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)

@@ -202,6 +202,7 @@ inline size_t dinv_elems(int n) { return (size_t)((n + NB - 1) / NB) * DINV_BLK;
 // x <- U^-T x (trans = true) or U^-1 x (trans = false), U upper triangular n x n with inverted
 // diagonal blocks dinv; nrhs right-hand sides, x col-major with leading dimension ldx.
 void trsv_upper(Ctx& c, int n, const double* U, long ldu, const double* dinv, bool trans, double* x);
+int trsm_refine_steps();   // HYP_TRSM_REFINE (default 2): refinement steps of the solves with inverted diagonal blocks
 void trsm_upper_left(Ctx& c, int n, int nrhs, const double* U, long ldu, const double* dinv, bool trans, double* X,
                      long ldx, double* work /* NB x nrhs */);
 // the forward solve (U'^-1) for a batch of equally sized factors: member b at U + b strideU, dinv + b strideD, X + b strideX

@@ -79,6 +79,10 @@ def _run(name, env_extra):
     ("epinormspectral3_3x4_dual", "HYP_PROX_LB"),
     ("polymin_large_primal", "HYP_PROX_LB"),              # candidates rejected on a lower bound of the proximity value (U = 680 >= 512)
     ("polymin_large_dual", "HYP_PROX_LB"),
+    ("matrixcompletion", "HYP_ENS_FUSED"),                # EpiNormSpectral: an oracle = one launch of one workgroup (d1 <= 64) / the launch chains
+    ("epinormspectral3_3x4_dual", "HYP_ENS_FUSED"),
+    ("epinormspectral2_primal", "HYP_ENS_FUSED"),
+    ("epinormspectral4_dual", "HYP_ENS_FUSED"),
 ])
 def test_side_by_side_candidate_evaluation_matches_sequential(name, switch):
     on = _run(name, {switch: "1"})
@@ -86,6 +90,17 @@ def test_side_by_side_candidate_evaluation_matches_sequential(name, switch):
     assert on["status"] == off["status"] == "Optimal"
     assert on["iters"] == off["iters"]
     assert abs(on["obj"] - off["obj"]) <= 1e-6 * (1 + abs(off["obj"]))
+
+
+@pytest.mark.parametrize("name", ["matrixcompletion", "epinormspectral3_3x4_dual", "epinormspectral2_primal", "epinormspectral4_dual"])
+def test_dual_feasibility_decided_on_bounds_changes_no_bit(name):
+    """HYP_ENS_DUAL_DECIDE (round 5, default 1): the decomposition behind EpiNormSpectral's dual feasibility test stops sweeping once
+    rigorous bounds of the nuclear norm lie on one side of the epigraph variable.  Only the yes / no of the test enters the search:
+    same candidates accepted, same iterates to the last bit."""
+    on = _run(name, {"HYP_ENS_DUAL_DECIDE": "1"})
+    off = _run(name, {"HYP_ENS_DUAL_DECIDE": "0"})
+    assert on["status"] == off["status"] == "Optimal"
+    assert on["trace"] == off["trace"] and on["trials"] == off["trials"]
 
 
 @pytest.mark.parametrize("name", ["polymin_primal", "polymin_large_primal", "polymin_large_dual"])

@@ -19,7 +19,8 @@ if ROOT not in sys.path:
 COLS = ("p_obj", "d_obj", "gap", "x_feas", "z_feas", "tau", "kap", "mu", "alpha")
 
 # route = the switches that take the device path off the reference's order of operations
-REFERENCE_ROUTE = {"HYP_ENS_CLOSED_INV": "0", "HYP_PROX_LB": "0", "HYP_ENS_PREFETCH": "0", "HYP_WSOS_PAR": "0", "HYP_BK_HYBRID": "0"}
+REFERENCE_ROUTE = {"HYP_ENS_CLOSED_INV": "0", "HYP_PROX_LB": "0", "HYP_ENS_PREFETCH": "0", "HYP_WSOS_PAR": "0", "HYP_BK_HYBRID": "0",
+                   "HYP_ENS_DUAL_DECIDE": "0", "HYP_ENS_FUSED": "0"}
 DEFAULT_ROUTE = {}
 
 
