@@ -545,27 +545,35 @@ __global__ void ens_identity_bases_kernel(int d1, int d2, double* __restrict__ U
 // ---------------------------------------------------------------------------------------------
 constexpr int EF_THREADS = 512;
 
-// fs(m, n, sum_k fa(m, k) fb(k, n)) for the M x N outputs; operands outside M / N / K read as zero
+// fs(m, n, sum_k fa(m, k) fb(k, n)) for the outputs m < M, n0 <= n < N; operands outside M / N / K read as zero.  The operand
+// entries of 16 k-steps (K <= 64: all of them) are requested before the first MFMA: a tile costs one memory round trip per 64 of K,
+// not one per unrolled group (operands in L2: 11 us per product of config 3b's sizes with four steps in flight, the launch
+// chain's GEMM takes 8-11).
 template <class FA, class FB, class FS>
-__device__ __forceinline__ void wg_mm(int M, int N, int K, FA fa, FB fb, FS fs) {
+__device__ __forceinline__ void wg_mm(int M, int N, int K, FA fa, FB fb, FS fs, int n0 = 0) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
-  const int tm = (M + 15) >> 4, tn = (N + 15) >> 4;
+  const int tm = (M + 15) >> 4, tn = (N - n0 + 15) >> 4;
   for (int t = wave; t < tm * tn; t += nw) {
     const int mt = t % tm, nt = t / tm;
-    const int m = mt * 16 + li, n = nt * 16 + li;
+    const int m = mt * 16 + li, n = n0 + nt * 16 + li;
     const bool mok = m < M, nok = n < N;
     d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-    for (int k0 = 0; k0 < K; k0 += 4) {
-      const int k = k0 + lk;
-      const double a = (mok && k < K) ? fa(m, k) : 0.0;
-      const double b = (nok && k < K) ? fb(k, n) : 0.0;
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    for (int kb = 0; kb < K; kb += 64) {
+      double av[16], bv[16];
+#pragma unroll
+      for (int st = 0; st < 16; ++st) {
+        const int k = kb + 4 * st + lk;
+        av[st] = (mok && k < K) ? fa(m, k) : 0.0;
+        bv[st] = (nok && k < K) ? fb(k, n) : 0.0;
+      }
+#pragma unroll
+      for (int st = 0; st < 16; ++st)
+        if (kb + 4 * st < K) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st], bv[st], acc, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int mo = mt * 16 + 4 * r + lk, no = nt * 16 + li;
+      const int mo = mt * 16 + 4 * r + lk, no = n0 + nt * 16 + li;
       if (mo < M && no < N) fs(mo, no, acc[r]);
     }
   }
@@ -577,10 +585,10 @@ __device__ __forceinline__ void wg_mm(int M, int N, int K, FA fa, FB fb, FS fs) 
 // thread of the workgroup (barriers inside).
 template <int NAPPLY, class FL, class FS>
 __device__ __forceinline__ void wg_zsolve(int d1, int ncol, const double* __restrict__ U, long ldu, const double* __restrict__ dinv, int refine, double* ops,
-                                          FL load, FS store) {
+                                          FL load, FS store, int col0 = 0) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int q = lane >> 4, nn = lane & 15;
-  for (int g0 = 0; g0 < ncol; g0 += nw * 16) {               // (uniform trip count)
+  for (int g0 = col0; g0 < ncol; g0 += nw * 16) {            // (uniform trip count; columns col0 .. ncol - 1)
     const int c0 = g0 + wave * 16;
     const bool active = c0 < ncol;
     const bool inb = c0 + nn < ncol;
@@ -712,9 +720,13 @@ __global__ __launch_bounds__(EF_THREADS) void ens_grad_aux_fused_kernel(int d1, 
                                                                         const double* __restrict__ U, const double* __restrict__ dinv, int refine,
                                                                         double* __restrict__ tau, double* __restrict__ Zi, double* __restrict__ grad,
                                                                         double* __restrict__ Zitau, double* __restrict__ HuW, double* __restrict__ WtauI,
-                                                                        double* __restrict__ rec) {
+                                                                        double* __restrict__ rec, int chained) {
   extern __shared__ __attribute__((aligned(16))) double ef_lds[];
   __shared__ double red[256];
+  if (chained) {   // queued behind ens_feas_fused_kernel without a host round trip: its record says whether there is anything to do, and u
+    if (rec[1] != 0.0) return;
+    u = rec[0];
+  }
   double* TauS = ef_lds;                   // d1 x d2
   double* ZiS = ef_lds + (long)d1 * d2;    // d1 x d1
   double* ops = ZiS + (long)d1 * d1;       // TDS_LDS_DOUBLES
@@ -753,28 +765,44 @@ __global__ __launch_bounds__(EF_THREADS) void ens_grad_aux_fused_kernel(int d1, 
   }
 }
 
-// hess_prod (:211-239), one workgroup per column: out_u = Huu a_u + <HuW, A>; T = A W', S = T + T' - 2 u a_u I,
-// out_W = Z^-1 (2 S tau + 2 A)
+// hess_prod (:211-239): out_u = Huu a_u + <HuW, A>; T = A W', S = T + T' - 2 u a_u I, out_W = Z^-1 (2 S tau + 2 A).
+// blockIdx.x = column; blockIdx.y = a share of the column's d2 matrix columns: the solve with Z is the long part (370 MFMAs of 64
+// cycles per 16 columns: 20 us for 100 columns on one CU's four matrix cores), so it is dealt out to gridDim.y workgroups of at
+// most four 16-column groups each; every share forms T and S for itself (2 x 16 tiles) and its own columns of the right-hand side.
+// A, W' and tau go through LDS (one coalesced pass each).
 __global__ __launch_bounds__(EF_THREADS) void ens_hess_prod_fused_kernel(int d1, int d2, double u, double Huu, const double* __restrict__ HuW,
                                                                          const double* __restrict__ WT, const double* __restrict__ tau,
                                                                          const double* __restrict__ U, const double* __restrict__ dinv, int refine,
-                                                                         const double* __restrict__ arr, long lda, double* __restrict__ prod, long ldp) {
+                                                                         const double* __restrict__ arr, long lda, double* __restrict__ prod, long ldp,
+                                                                         const double* __restrict__ rec) {
   extern __shared__ __attribute__((aligned(16))) double ef_lds[];
   __shared__ double red[256];
+  if (rec) {   // queued behind the feasibility test and the gradient kernel without a host round trip: u and Huu from their record
+    if (rec[1] != 0.0) return;
+    u = rec[0];
+    Huu = rec[5];
+  }
   double* Ts = ef_lds;                          // d1 x d1
   double* Ss = Ts + (long)d1 * d1;              // d1 x d1
-  double* Rs = Ss + (long)d1 * d1;              // d1 x d2
-  double* ops = Rs + (long)d1 * d2;             // TDS_LDS_DOUBLES
+  double* Rs = Ss + (long)d1 * d1;              // d1 x d2: A, then the right-hand side in its place
+  double* X = Rs + (long)d1 * d2;               // max(d1 d2, TDS_LDS_DOUBLES): W', then tau, then the staged operands of the solve
   const int tid = threadIdx.x, dw = d1 * d2;
+  const int groups = (d2 + 15) >> 4, gper = (groups + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int col0 = min(d2, (int)blockIdx.y * gper * 16), col1 = min(d2, ((int)blockIdx.y + 1) * gper * 16);
+  if (col0 >= col1 && blockIdx.y > 0) return;
   const double* a = arr + (long)blockIdx.x * lda;
   double* p = prod + (long)blockIdx.x * ldp;
   const double a0 = a[0];
   const double* A = a + 1;
-  double s = 0.0;
-  if (tid < 256) for (int i = tid; i < dw; i += 256) s += HuW[i] * A[i];
-  const double hw = wg_tree256(s, red);
-  if (tid == 0) p[0] = Huu * a0 + hw;
-  wg_mm(d1, d1, d2, [&](int m, int k) { return A[m + (long)k * d1]; }, [&](int k, int n) { return WT[k + (long)n * d2]; },
+  for (int e = tid; e < dw; e += EF_THREADS) { Rs[e] = A[e]; X[e] = WT[e]; }
+  if (blockIdx.y == 0) {
+    double s = 0.0;
+    if (tid < 256) for (int i = tid; i < dw; i += 256) s += HuW[i] * A[i];
+    const double hw = wg_tree256(s, red);
+    if (tid == 0) p[0] = Huu * a0 + hw;
+  }
+  __syncthreads();
+  wg_mm(d1, d1, d2, [&](int m, int k) { return Rs[m + k * d1]; }, [&](int k, int n) { return X[k + n * d2]; },
         [&](int m, int n, double acc) { Ts[m + n * d1] = acc; });
   __syncthreads();
   for (int e = tid; e < d1 * d1; e += EF_THREADS) {
@@ -783,16 +811,17 @@ __global__ __launch_bounds__(EF_THREADS) void ens_hess_prod_fused_kernel(int d1,
     if (r == c) v -= 2.0 * u * a0;
     Ss[c * d1 + r] = v;
   }
+  for (int e = col0 * d1 + tid; e < col1 * d1; e += EF_THREADS) X[e] = tau[e];
   __syncthreads();
-  wg_mm(d1, d2, d1, [&](int m, int k) { return Ss[k + m * d1]; }, [&](int k, int n) { return tau[k + (long)n * d1]; },
+  wg_mm(d1, col1, d1, [&](int m, int k) { return Ss[k + m * d1]; }, [&](int k, int n) { return X[k + n * d1]; },
         [&](int m, int n, double acc) {
           double v = 2.0 * acc;
-          v += 2.0 * A[m + (long)n * d1];
+          v += 2.0 * Rs[m + n * d1];
           Rs[m + n * d1] = v;
-        });
+        }, col0);
   __syncthreads();
-  wg_zsolve<1>(d1, d2, U, d1, dinv, refine, ops, [&](int row, int col) { return Rs[row + col * d1]; },
-               [&](int, int row, int col, double v) { p[1 + row + (long)col * d1] = v; });
+  wg_zsolve<1>(d1, col1, U, d1, dinv, refine, X, [&](int row, int col) { return Rs[row + col * d1]; },
+               [&](int, int row, int col, double v) { p[1 + row + (long)col * d1] = v; }, col0);
 }
 
 // closed_inv_apply, one workgroup per column (see the derivation at update_svd): Rt = U' R, R1 = Rt V1, T = z / 2 (Rt - R1 V1') +
@@ -862,7 +891,7 @@ static size_t ens_fused_lds_bytes(int d1, int d2, int which) {
   switch (which) {
     case 0: return 2 * dd * 8;                                   // feas: Z, D
     case 1: return (dw + dd + TDS_LDS_DOUBLES) * 8;              // grad + aux: tau, Zi, staged operands
-    case 2: return (2 * dd + dw + TDS_LDS_DOUBLES) * 8;          // hess_prod: T, S, R, staged operands
+    case 2: return (2 * dd + dw + std::max(dw, (size_t)TDS_LDS_DOUBLES)) * 8;   // hess_prod: T, S, A / R, W' / tau / staged operands
     default: return (2 * dw + 2 * dd) * 8;                       // closed inverse: Rt, T, R1, A1
   }
 }
@@ -1037,6 +1066,44 @@ void EpiNormSpectralCone::prefetch_feas() {
 bool EpiNormSpectralCone::early_reject(double irtmu, double bound2) {
   static const bool on = [] { const char* e = getenv("HYP_PROX_LB"); return !(e && e[0] == '0'); }();
   static const bool cf = [] { const char* e = getenv("HYP_ENS_CLOSED_INV"); return !(e && e[0] == '0'); }();
+  static const bool chain_on = [] { const char* e = getenv("HYP_ENS_CHAIN"); return !(e && e[0] == '0'); }();
+  // One-workgroup kernels: feasibility test, gradient, the bound's two products and its scalar products queued back to back, ONE
+  // read-back for all of them (three host round trips of 20-30 us each otherwise; a kernel behind a failed feasibility test returns
+  // at once on the test's device record).  Same kernels on the same data as the step-by-step form below: same numbers.
+  if (chain_on && fused() && !feas_updated && !grad_updated && on && cf && svd_prev_ok && !svd_updated && !hess_fact_updated && d1 >= 2) {
+    const size_t vb = (size_t)dim * sizeof(double);
+    prox_out.ensure(vb);
+    hipLaunchKernelGGL(ens_feas_fused_kernel, dim3(1), dim3(EF_THREADS), ens_fused_lds_bytes(d1, d2, 0), ctx.stream, d1, d2, point.d(), W.d(), WT.d(),
+                       Zfact.d(), Zdinv.d(), frec.d());
+    hipLaunchKernelGGL(ens_grad_aux_fused_kernel, dim3(1), dim3(EF_THREADS), ens_fused_lds_bytes(d1, d2, 1), ctx.stream, d1, d2, 0.0, W.d(), Zfact.d(),
+                       Zdinv.d(), trsm_refine_steps(), tau.d(), Zi.d(), grad.d(), Zitau.d(), HuW.d(), WtauI.d(), frec.d(), 1);
+    ctx.d2d(vec1.p, grad.p, vb);
+    dev_axpby(ctx, dim, irtmu, dual_point.d(), 1.0, vec1.d());          // v
+    closed_inv_apply(u_svd, vec2.d(), dim, vec1.d(), dim, 1);            // w (the decomposition of an EARLIER point)
+    const int shares = std::max(1, ((d2 + 15) / 16 + 3) / 4);
+    hipLaunchKernelGGL(ens_hess_prod_fused_kernel, dim3(1, shares), dim3(EF_THREADS), ens_fused_lds_bytes(d1, d2, 2), ctx.stream, d1, d2, 0.0, 0.0, HuW.d(),
+                       WT.d(), tau.d(), Zfact.d(), Zdinv.d(), trsm_refine_steps(), vec2.d(), (long)dim, prox_out.d(), (long)dim, (const double*)frec.d());
+    HYP_CHECK(hipGetLastError());
+    double* ds = ctx.dscal.d() + 44;
+    dev_dot(ctx, dim, vec1.d(), vec2.d(), ds);
+    dev_dot(ctx, dim, vec2.d(), prox_out.d(), ds + 1);
+    ctx.d2h(ctx.h_pinned + 56, frec.d(), 6 * sizeof(double));
+    ctx.d2h(ctx.h_pinned + 44, ds, 2 * sizeof(double));
+    ctx.sync();
+    u = ctx.h_pinned[56];
+    is_feas_ = (u > EPS) && (ctx.h_pinned[57] == 0.0);
+    feas_updated = true;
+    if (!is_feas_) return true;                                          // search.jl:120-124: not in the cone
+    ctx.kstat[7] += 1;
+    trZi2 = ctx.h_pinned[59];
+    g0_host = ctx.h_pinned[60];
+    Huu = ctx.h_pinned[61];
+    grad_updated = true;
+    hess_aux_updated = true;
+    const double a = ctx.h_pinned[44], b = ctx.h_pinned[45];
+    if (!(b > 0.0) || !(a == a) || !(b < INFINITY)) return false;
+    return a * a / b > bound2 * (1.0 + 1e-9);
+  }
   if (!(feas_updated ? is_feas_ : update_feas())) return true;      // search.jl:120-124: not in the cone
   if (!on || !cf || !svd_prev_ok || svd_updated || hess_fact_updated || d1 < 2) return false;
   const size_t vb = (size_t)dim * sizeof(double);
@@ -1060,7 +1127,7 @@ void EpiNormSpectralCone::update_grad() {   // :134-150
   ctx.kstat[7] += 1;
   if (fused()) {   // gradient and the Hessian's auxiliary matrices together (update_hess_aux then finds them)
     hipLaunchKernelGGL(ens_grad_aux_fused_kernel, dim3(1), dim3(EF_THREADS), ens_fused_lds_bytes(d1, d2, 1), ctx.stream, d1, d2, u, W.d(), Zfact.d(),
-                       Zdinv.d(), trsm_refine_steps(), tau.d(), Zi.d(), grad.d(), Zitau.d(), HuW.d(), WtauI.d(), frec.d());
+                       Zdinv.d(), trsm_refine_steps(), tau.d(), Zi.d(), grad.d(), Zitau.d(), HuW.d(), WtauI.d(), frec.d(), 0);
     HYP_CHECK(hipGetLastError());
     ctx.d2h(ctx.h_pinned + 58, frec.d() + 2, 4 * sizeof(double));
     ctx.sync();
@@ -1116,8 +1183,9 @@ void EpiNormSpectralCone::hess_prod(double* prod, long ldp, const double* arr, l
   if (!hess_aux_updated) update_hess_aux();
   if (ncols <= 0) return;
   if (fused() && ncols <= 4096) {   // (a few columns: directions, residuals, bounds; the explicit-Hessian callers come with thousands)
-    hipLaunchKernelGGL(ens_hess_prod_fused_kernel, dim3(ncols), dim3(EF_THREADS), ens_fused_lds_bytes(d1, d2, 2), ctx.stream, d1, d2, u, Huu, HuW.d(),
-                       WT.d(), tau.d(), Zfact.d(), Zdinv.d(), trsm_refine_steps(), arr, lda, prod, ldp);
+    const int shares = std::max(1, ((d2 + 15) / 16 + 3) / 4);   // at most four 16-column groups of the solve per workgroup
+    hipLaunchKernelGGL(ens_hess_prod_fused_kernel, dim3(ncols, shares), dim3(EF_THREADS), ens_fused_lds_bytes(d1, d2, 2), ctx.stream, d1, d2, u, Huu, HuW.d(),
+                       WT.d(), tau.d(), Zfact.d(), Zdinv.d(), trsm_refine_steps(), arr, lda, prod, ldp, (const double*)nullptr);
     HYP_CHECK(hipGetLastError());
     return;
   }
