@@ -720,13 +720,9 @@ __global__ __launch_bounds__(EF_THREADS) void ens_grad_aux_fused_kernel(int d1, 
                                                                         const double* __restrict__ U, const double* __restrict__ dinv, int refine,
                                                                         double* __restrict__ tau, double* __restrict__ Zi, double* __restrict__ grad,
                                                                         double* __restrict__ Zitau, double* __restrict__ HuW, double* __restrict__ WtauI,
-                                                                        double* __restrict__ rec, int chained) {
+                                                                        double* __restrict__ rec) {
   extern __shared__ __attribute__((aligned(16))) double ef_lds[];
   __shared__ double red[256];
-  if (chained) {   // queued behind ens_feas_fused_kernel without a host round trip: its record says whether there is anything to do, and u
-    if (rec[1] != 0.0) return;
-    u = rec[0];
-  }
   double* TauS = ef_lds;                   // d1 x d2
   double* ZiS = ef_lds + (long)d1 * d2;    // d1 x d1
   double* ops = ZiS + (long)d1 * d1;       // TDS_LDS_DOUBLES
@@ -773,15 +769,9 @@ __global__ __launch_bounds__(EF_THREADS) void ens_grad_aux_fused_kernel(int d1, 
 __global__ __launch_bounds__(EF_THREADS) void ens_hess_prod_fused_kernel(int d1, int d2, double u, double Huu, const double* __restrict__ HuW,
                                                                          const double* __restrict__ WT, const double* __restrict__ tau,
                                                                          const double* __restrict__ U, const double* __restrict__ dinv, int refine,
-                                                                         const double* __restrict__ arr, long lda, double* __restrict__ prod, long ldp,
-                                                                         const double* __restrict__ rec) {
+                                                                         const double* __restrict__ arr, long lda, double* __restrict__ prod, long ldp) {
   extern __shared__ __attribute__((aligned(16))) double ef_lds[];
   __shared__ double red[256];
-  if (rec) {   // queued behind the feasibility test and the gradient kernel without a host round trip: u and Huu from their record
-    if (rec[1] != 0.0) return;
-    u = rec[0];
-    Huu = rec[5];
-  }
   double* Ts = ef_lds;                          // d1 x d1
   double* Ss = Ts + (long)d1 * d1;              // d1 x d1
   double* Rs = Ss + (long)d1 * d1;              // d1 x d2: A, then the right-hand side in its place
@@ -1066,44 +1056,6 @@ void EpiNormSpectralCone::prefetch_feas() {
 bool EpiNormSpectralCone::early_reject(double irtmu, double bound2) {
   static const bool on = [] { const char* e = getenv("HYP_PROX_LB"); return !(e && e[0] == '0'); }();
   static const bool cf = [] { const char* e = getenv("HYP_ENS_CLOSED_INV"); return !(e && e[0] == '0'); }();
-  static const bool chain_on = [] { const char* e = getenv("HYP_ENS_CHAIN"); return !(e && e[0] == '0'); }();
-  // One-workgroup kernels: feasibility test, gradient, the bound's two products and its scalar products queued back to back, ONE
-  // read-back for all of them (three host round trips of 20-30 us each otherwise; a kernel behind a failed feasibility test returns
-  // at once on the test's device record).  Same kernels on the same data as the step-by-step form below: same numbers.
-  if (chain_on && fused() && !feas_updated && !grad_updated && on && cf && svd_prev_ok && !svd_updated && !hess_fact_updated && d1 >= 2) {
-    const size_t vb = (size_t)dim * sizeof(double);
-    prox_out.ensure(vb);
-    hipLaunchKernelGGL(ens_feas_fused_kernel, dim3(1), dim3(EF_THREADS), ens_fused_lds_bytes(d1, d2, 0), ctx.stream, d1, d2, point.d(), W.d(), WT.d(),
-                       Zfact.d(), Zdinv.d(), frec.d());
-    hipLaunchKernelGGL(ens_grad_aux_fused_kernel, dim3(1), dim3(EF_THREADS), ens_fused_lds_bytes(d1, d2, 1), ctx.stream, d1, d2, 0.0, W.d(), Zfact.d(),
-                       Zdinv.d(), trsm_refine_steps(), tau.d(), Zi.d(), grad.d(), Zitau.d(), HuW.d(), WtauI.d(), frec.d(), 1);
-    ctx.d2d(vec1.p, grad.p, vb);
-    dev_axpby(ctx, dim, irtmu, dual_point.d(), 1.0, vec1.d());          // v
-    closed_inv_apply(u_svd, vec2.d(), dim, vec1.d(), dim, 1);            // w (the decomposition of an EARLIER point)
-    const int shares = std::max(1, ((d2 + 15) / 16 + 3) / 4);
-    hipLaunchKernelGGL(ens_hess_prod_fused_kernel, dim3(1, shares), dim3(EF_THREADS), ens_fused_lds_bytes(d1, d2, 2), ctx.stream, d1, d2, 0.0, 0.0, HuW.d(),
-                       WT.d(), tau.d(), Zfact.d(), Zdinv.d(), trsm_refine_steps(), vec2.d(), (long)dim, prox_out.d(), (long)dim, (const double*)frec.d());
-    HYP_CHECK(hipGetLastError());
-    double* ds = ctx.dscal.d() + 44;
-    dev_dot(ctx, dim, vec1.d(), vec2.d(), ds);
-    dev_dot(ctx, dim, vec2.d(), prox_out.d(), ds + 1);
-    ctx.d2h(ctx.h_pinned + 56, frec.d(), 6 * sizeof(double));
-    ctx.d2h(ctx.h_pinned + 44, ds, 2 * sizeof(double));
-    ctx.sync();
-    u = ctx.h_pinned[56];
-    is_feas_ = (u > EPS) && (ctx.h_pinned[57] == 0.0);
-    feas_updated = true;
-    if (!is_feas_) return true;                                          // search.jl:120-124: not in the cone
-    ctx.kstat[7] += 1;
-    trZi2 = ctx.h_pinned[59];
-    g0_host = ctx.h_pinned[60];
-    Huu = ctx.h_pinned[61];
-    grad_updated = true;
-    hess_aux_updated = true;
-    const double a = ctx.h_pinned[44], b = ctx.h_pinned[45];
-    if (!(b > 0.0) || !(a == a) || !(b < INFINITY)) return false;
-    return a * a / b > bound2 * (1.0 + 1e-9);
-  }
   if (!(feas_updated ? is_feas_ : update_feas())) return true;      // search.jl:120-124: not in the cone
   if (!on || !cf || !svd_prev_ok || svd_updated || hess_fact_updated || d1 < 2) return false;
   const size_t vb = (size_t)dim * sizeof(double);
@@ -1127,7 +1079,7 @@ void EpiNormSpectralCone::update_grad() {   // :134-150
   ctx.kstat[7] += 1;
   if (fused()) {   // gradient and the Hessian's auxiliary matrices together (update_hess_aux then finds them)
     hipLaunchKernelGGL(ens_grad_aux_fused_kernel, dim3(1), dim3(EF_THREADS), ens_fused_lds_bytes(d1, d2, 1), ctx.stream, d1, d2, u, W.d(), Zfact.d(),
-                       Zdinv.d(), trsm_refine_steps(), tau.d(), Zi.d(), grad.d(), Zitau.d(), HuW.d(), WtauI.d(), frec.d(), 0);
+                       Zdinv.d(), trsm_refine_steps(), tau.d(), Zi.d(), grad.d(), Zitau.d(), HuW.d(), WtauI.d(), frec.d());
     HYP_CHECK(hipGetLastError());
     ctx.d2h(ctx.h_pinned + 58, frec.d() + 2, 4 * sizeof(double));
     ctx.sync();
@@ -1185,7 +1137,7 @@ void EpiNormSpectralCone::hess_prod(double* prod, long ldp, const double* arr, l
   if (fused() && ncols <= 4096) {   // (a few columns: directions, residuals, bounds; the explicit-Hessian callers come with thousands)
     const int shares = std::max(1, ((d2 + 15) / 16 + 3) / 4);   // at most four 16-column groups of the solve per workgroup
     hipLaunchKernelGGL(ens_hess_prod_fused_kernel, dim3(ncols, shares), dim3(EF_THREADS), ens_fused_lds_bytes(d1, d2, 2), ctx.stream, d1, d2, u, Huu, HuW.d(),
-                       WT.d(), tau.d(), Zfact.d(), Zdinv.d(), trsm_refine_steps(), arr, lda, prod, ldp, (const double*)nullptr);
+                       WT.d(), tau.d(), Zfact.d(), Zdinv.d(), trsm_refine_steps(), arr, lda, prod, ldp);
     HYP_CHECK(hipGetLastError());
     return;
   }
