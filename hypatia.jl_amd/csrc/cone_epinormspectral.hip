@@ -197,12 +197,14 @@ __device__ __forceinline__ double jl_dpp(double v) {
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double jl_sum32(double v) {   // total over the 32 lanes of a half wavefront, in every lane
-  v += jl_dpp<0xB1>(v);    // quad_perm [1, 0, 3, 2]
-  v += jl_dpp<0x4E>(v);    // quad_perm [2, 3, 0, 1]
-  v += jl_dpp<0x141>(v);   // row_half_mirror
-  v += jl_dpp<0x140>(v);   // row_mirror
-  return v + __shfl_xor(v, 16, 32);
+// total over a group of GL = 32 / 16 lanes, in every lane of the group (16: the four DPP steps stay inside a row of 16 lanes)
+template <int GL>
+__device__ __forceinline__ double jl_sum(double v) {
+  v += jl_dpp<0xB1>(v);
+  v += jl_dpp<0x4E>(v);
+  v += jl_dpp<0x141>(v);
+  v += jl_dpp<0x140>(v);
+  return GL == 32 ? v + __shfl_xor(v, 16, 32) : v;
 }
 __device__ __forceinline__ double jl_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);
@@ -230,7 +232,11 @@ __device__ __forceinline__ double jl_rsqrt(double x) {
 // arbitrary cosines).  Once both bounds are on one side of u by more than 1e-10 relatively the sweeps stop: the sum of the column
 // norms the caller then forms decides as the converged value would (it is the upper bound; where the LOWER bound says "outside",
 // so does it).  Closer than that to the boundary the sweeps run to the end as without the test.
-__global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double* __restrict__ Vg, double* __restrict__ Jg, int max_sweeps, int load_j,
+// GL lanes per column pair, 32 pairs side by side (GL * 32 threads).  GL = 16 (HYP_JACOBI_GL=16: a wavefront carries four pairs
+// through the rotation's scalar chain instead of two, 7 wavefronts instead of 13 for config 3b's 25 pairs) measured the same time
+// per sweep as 32: a round is bound by its chain of dependent FP64 operations, not by instruction issue (EXPERIMENTS r05-22).
+template <int GL>
+__global__ __launch_bounds__(GL * 32) void jacobi_lds_kernel(int len, int m, double* __restrict__ Vg, double* __restrict__ Jg, int max_sweeps, int load_j,
                                                           int* __restrict__ sweeps_out, double tol_rot, double tol_big, double floor_rel,
                                                           const double* __restrict__ decide_u, double decide_eps) {
   extern __shared__ __attribute__((aligned(16))) double jl_lds[];
@@ -240,17 +246,18 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double
   const int ldj = m | 1;
   __shared__ int rotated;
   const int tid = threadIdx.x;
-  for (long e = tid; e < (long)len * m; e += 1024) V[(e / len) * ldv + (e % len)] = Vg[e];
-  if (Jg) for (long e = tid; e < (long)m * m; e += 1024) J[(e / m) * ldj + (e % m)] = load_j ? Jg[e] : (((e / m) == (e % m)) ? 1.0 : 0.0);   // (load_j: warm start, the rotations continue an earlier product)
+  constexpr int NT = GL * 32, NR = 128 / GL;   // threads; entries per lane of a column held in registers (len <= 128)
+  for (long e = tid; e < (long)len * m; e += NT) V[(e / len) * ldv + (e % len)] = Vg[e];
+  if (Jg) for (long e = tid; e < (long)m * m; e += NT) J[(e / m) * ldj + (e % m)] = load_j ? Jg[e] : (((e / m) == (e % m)) ? 1.0 : 0.0);   // (load_j: warm start, the rotations continue an earlier product)
   __syncthreads();
   double floor2 = 0.0;
   __shared__ double fr[1024];   // (the static part has to stay small: 150 KB of the CU's 160 are the caller's to ask for dynamically)
   if (floor_rel > 0.0) {   // ||B||_F^2 (invariant under the rotations), fixed summation order
     double f = 0.0;
-    for (long e = tid; e < (long)len * m; e += 1024) { const double x = V[(e / len) * ldv + (e % len)]; f = fma(x, x, f); }
+    for (long e = tid; e < (long)len * m; e += NT) { const double x = V[(e / len) * ldv + (e % len)]; f = fma(x, x, f); }
     fr[tid] = f;
     __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
+    for (int off = NT / 2; off > 0; off >>= 1) {
       if (tid < off) fr[tid] += fr[tid + off];
       __syncthreads();
     }
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double
     __syncthreads();   // (fr is written again by the bounds pass)
   }
   const int mm = (m % 2 == 0) ? m : m + 1;
-  const int sub = tid & 31, grp = tid >> 5;      // 32 groups of 32 lanes
+  const int sub = tid & (GL - 1), grp = tid / GL;   // 32 groups of GL lanes
   double* dc_n2 = fr;            // [256] (fr is free again once floor2 is formed)
   double* dc_part = fr + 256;    // [32]
   __shared__ int dc_done;
@@ -270,8 +277,8 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double
       for (int i = grp; i < m; i += 32) {                       // squared column norms of the current state
         const double* vi = V + (long)i * ldv;
         double a = 0.0;
-        for (int r = sub; r < len; r += 32) { const double x = vi[r]; a = fma(x, x, a); }
-        a = jl_sum32(a);
+        for (int r = sub; r < len; r += GL) { const double x = vi[r]; a = fma(x, x, a); }
+        a = jl_sum<GL>(a);
         if (sub == 0) dc_n2[i] = a;
       }
       __syncthreads();
@@ -290,8 +297,8 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double
           const double* vp = V + (long)p * ldv;
           const double* vq = V + (long)q * ldv;
           double g = 0.0;
-          for (int r = sub; r < len; r += 32) g = fma(vp[r], vq[r], g);
-          g = jl_sum32(g);
+          for (int r = sub; r < len; r += GL) g = fma(vp[r], vq[r], g);
+          g = jl_sum<GL>(g);
           c2 += (g * g) / (ap * aq);
         }
       if (sub == 0) dc_part[grp] = c2;
@@ -322,23 +329,23 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double
         // columns of up to 128 entries stay in registers between the scalar products and the rotation (all LDS reads of the
         // pair issued at once, none repeated); same sums in the same order as the loop form
         const bool in_regs = (len <= 128);
-        double xr[4], yr[4];
+        double xr[NR], yr[NR];
         if (in_regs) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int r = sub + 32 * k;
+          for (int k = 0; k < NR; ++k) {
+            const int r = sub + GL * k;
             xr[k] = (r < len) ? vp[r] : 0.0;
             yr[k] = (r < len) ? vq[r] : 0.0;
           }
 #pragma unroll
-          for (int k = 0; k < 4; ++k) { a = fma(xr[k], xr[k], a); b = fma(yr[k], yr[k], b); g = fma(xr[k], yr[k], g); }
+          for (int k = 0; k < NR; ++k) { a = fma(xr[k], xr[k], a); b = fma(yr[k], yr[k], b); g = fma(xr[k], yr[k], g); }
         } else {
-          for (int r = sub; r < len; r += 32) {
+          for (int r = sub; r < len; r += GL) {
             const double x = vp[r], y = vq[r];
             a = fma(x, x, a); b = fma(y, y, b); g = fma(x, y, g);
           }
         }
-        a = jl_sum32(a); b = jl_sum32(b); g = jl_sum32(g);
+        a = jl_sum<GL>(a); b = jl_sum<GL>(b); g = jl_sum<GL>(g);
         // |g| <= tol sqrt(a b) compared on the squares (the double-precision square root expands to ~15 dependent operations in
         // the middle of the round's critical path); outside the range where a b and g^2 are safely representable, as written
         const double ab = a * b, g2 = g * g;
@@ -368,15 +375,15 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double
         if (sub == 0 && (sq_ok ? (g2 > tol_big * tol_big * ab) : (ag > tol_big * sqrt(ab)))) rotated = 1;
         if (in_regs) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int r = sub + 32 * k;
+          for (int k = 0; k < NR; ++k) {
+            const int r = sub + GL * k;
             if (r < len) {
               vp[r] = cs * xr[k] - sn * yr[k];
               vq[r] = sn * xr[k] + cs * yr[k];
             }
           }
         } else {
-          for (int r = sub; r < len; r += 32) {
+          for (int r = sub; r < len; r += GL) {
             const double x = vp[r], y = vq[r];
             vp[r] = cs * x - sn * y;
             vq[r] = sn * x + cs * y;
@@ -385,7 +392,7 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double
         if (Jg) {
           double* jp = J + (long)p * ldj;
           double* jq = J + (long)q * ldj;
-          for (int r = sub; r < m; r += 32) {
+          for (int r = sub; r < m; r += GL) {
             const double x = jp[r], y = jq[r];
             jp[r] = cs * x - sn * y;
             jq[r] = sn * x + cs * y;
@@ -399,8 +406,8 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(int len, int m, double
     __syncthreads();
   }
   __syncthreads();
-  for (long e = tid; e < (long)len * m; e += 1024) Vg[e] = V[(e / len) * ldv + (e % len)];
-  if (Jg) for (long e = tid; e < (long)m * m; e += 1024) Jg[e] = J[(e / m) * ldj + (e % m)];
+  for (long e = tid; e < (long)len * m; e += NT) Vg[e] = V[(e / len) * ldv + (e % len)];
+  if (Jg) for (long e = tid; e < (long)m * m; e += NT) Jg[e] = J[(e / m) * ldj + (e % m)];
 }
 // bytes of LDS the one-launch form needs; 0 = does not fit
 static size_t jacobi_lds_bytes(int len, int m, bool with_j) {
@@ -420,15 +427,22 @@ static bool jacobi_in_lds(Ctx& ctx, int len, int m, double* V, double* J, bool l
   if (!on || lds == 0) return false;
   static bool attr_set = false;
   if (!attr_set) {
-    HYP_CHECK(hipFuncSetAttribute((const void*)jacobi_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HYP_CHECK(hipFuncSetAttribute((const void*)jacobi_lds_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HYP_CHECK(hipFuncSetAttribute((const void*)jacobi_lds_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_set = true;
   }
   static const bool dbg = [] { const char* e = getenv("HYP_JACOBI_DBG"); return e && e[0] == '1'; }();   // sweeps of every call on stderr
   int* sw = dbg ? reinterpret_cast<int*>(ctx.dscal.d() + 63) : nullptr;
   const double tol_rot = values_only ? 1e-10 : 1e-15, tol_big = values_only ? 1e-6 : 1e-8, floor_rel = values_only ? 2.220446049250313e-16 : 0.0;
   static const bool decide_on = [] { const char* e = getenv("HYP_ENS_DUAL_DECIDE"); return !(e && e[0] == '0'); }();
-  hipLaunchKernelGGL(jacobi_lds_kernel, dim3(1), dim3(1024), lds, ctx.stream, len, m, V, J, 60, load_j ? 1 : 0, sw, tol_rot, tol_big, floor_rel,
-                     (decide_on && values_only) ? d_decide_u : nullptr, EPS);
+  static const int gl_env = [] { const char* e = getenv("HYP_JACOBI_GL"); return e ? atoi(e) : 32; }();   // 16 / 32 lanes per column pair
+  const int gl = (gl_env == 16) ? 16 : 32;   // (16 measured equal at 50 x 100, EXPERIMENTS r05-22: the round is bound by its dependent chain, not by issue)
+  if (gl == 16)
+    hipLaunchKernelGGL(jacobi_lds_kernel<16>, dim3(1), dim3(512), lds, ctx.stream, len, m, V, J, 60, load_j ? 1 : 0, sw, tol_rot, tol_big, floor_rel,
+                       (decide_on && values_only) ? d_decide_u : nullptr, EPS);
+  else
+    hipLaunchKernelGGL(jacobi_lds_kernel<32>, dim3(1), dim3(1024), lds, ctx.stream, len, m, V, J, 60, load_j ? 1 : 0, sw, tol_rot, tol_big, floor_rel,
+                       (decide_on && values_only) ? d_decide_u : nullptr, EPS);
   HYP_CHECK(hipGetLastError());
   if (dbg) {
     ctx.d2h(ctx.h_info + 32, sw, sizeof(int));
