@@ -231,9 +231,10 @@ def U_big(nvars, halfdeg):
     return None if nvars < 3 else False
 
 
-# (ens: sides up to 64 take the one-workgroup kernels of cone_epinormspectral.hip -- 1 x 1, a ragged 20 x 33, config 3b's 50 x 100, the
-#  largest side 64 --, 130 x 140 the launch chains)
-@pytest.mark.parametrize("kind,args", [("ens", (3, 4)), ("ens", (20, 33)), ("ens", (50, 100)), ("ens", (64, 64)), ("ens", (130, 140)),
+# (ens: sides up to 64 take the one-workgroup kernels of cone_epinormspectral.hip -- a ragged 20 x 33, 6 x 150 (more columns than one pass
+#  of the solve's eight wavefronts holds, three shares of the Hessian product, three K chunks), config 3b's 50 x 100, the largest side 64 --,
+#  130 x 140 the launch chains)
+@pytest.mark.parametrize("kind,args", [("ens", (3, 4)), ("ens", (20, 33)), ("ens", (6, 150)), ("ens", (50, 100)), ("ens", (64, 64)), ("ens", (130, 140)),
                                        ("wsos", (2, 3)), ("wsos", (3, 3)), ("wsos", (2, 10))])
 def test_generic_oracle_vs_hip(kind, args):
     hc, oc = _generic_pair(kind, *args)
