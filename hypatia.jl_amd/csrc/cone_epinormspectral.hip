@@ -742,12 +742,25 @@ __global__ __launch_bounds__(EF_THREADS) void ens_grad_aux_fused_kernel(int d1, 
   double* ops = ZiS + (long)d1 * d1;       // TDS_LDS_DOUBLES
   const int tid = threadIdx.x;
   const double c4u = -4.0 * u;
-  wg_zsolve<2>(d1, d2, U, d1, dinv, refine, ops, [&](int row, int col) { return W[row + (long)col * d1]; },
+  // blockIdx.x = a share of the d2 columns (at most four 16-column groups: one per SIMD in the two solves): tau, Zitau, the gradient,
+  // HuW and the columns of W' tau in WtauI depend on their own columns of W only; the first share forms Zi and the scalars as well
+  const int groups = (d2 + 15) >> 4, gper = (groups + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int col0 = min(d2, (int)blockIdx.x * gper * 16), col1 = min(d2, ((int)blockIdx.x + 1) * gper * 16);
+  if (col0 >= col1 && blockIdx.x > 0) return;
+  wg_zsolve<2>(d1, col1, U, d1, dinv, refine, ops, [&](int row, int col) { return W[row + (long)col * d1]; },
                [&](int stage, int row, int col, double v) {
                  const long e = row + (long)col * d1;
                  if (stage == 0) { tau[e] = v; TauS[e] = v; grad[1 + e] = 2.0 * v; }
                  else { Zitau[e] = v; HuW[e] = c4u * v; }
-               });
+               }, col0);
+  __syncthreads();
+  wg_mm(d2, col1, d1, [&](int m, int k) { return W[k + (long)m * d1]; }, [&](int k, int n) { return TauS[k + n * d1]; },
+        [&](int m, int n, double acc) {
+          double v = acc;
+          v += (m == n) ? 1.0 : 0.0;
+          WtauI[m + (long)n * d2] = v;
+        }, col0);
+  if (blockIdx.x > 0) return;
   wg_mm(d1, d1, d1, [&](int m, int k) { return (k >= m) ? dinv[m + (long)k * NB] : 0.0; },
         [&](int k, int n) { return (k >= n) ? dinv[n + (long)k * NB] : 0.0; },
         [&](int m, int n, double acc) { ZiS[m + n * d1] = acc; Zi[m + (long)n * d1] = acc; });
@@ -758,12 +771,6 @@ __global__ __launch_bounds__(EF_THREADS) void ens_grad_aux_fused_kernel(int d1, 
   double s2 = 0.0;
   if (tid < 256) for (int e = tid; e < d1 * d1; e += 256) s2 = fma(ZiS[e], ZiS[e], s2);
   const double trZi2 = wg_tree256(s2, red);
-  wg_mm(d2, d2, d1, [&](int m, int k) { return W[k + (long)m * d1]; }, [&](int k, int n) { return TauS[k + n * d1]; },
-        [&](int m, int n, double acc) {
-          double v = acc;
-          v += (m == n) ? 1.0 : 0.0;
-          WtauI[m + (long)n * d2] = v;
-        });
   if (tid == 0) {
     // g0 = (-u trZi) 2 + (d1 - 1) / u ; Huu = 4 u u trZi2 + (g0 - 2 (d1 - 1) / u) / u   (as the host forms them, no contraction)
     const double dm1 = (double)(d1 - 1);
@@ -1092,7 +1099,8 @@ bool EpiNormSpectralCone::early_reject(double irtmu, double bound2) {
 void EpiNormSpectralCone::update_grad() {   // :134-150
   ctx.kstat[7] += 1;
   if (fused()) {   // gradient and the Hessian's auxiliary matrices together (update_hess_aux then finds them)
-    hipLaunchKernelGGL(ens_grad_aux_fused_kernel, dim3(1), dim3(EF_THREADS), ens_fused_lds_bytes(d1, d2, 1), ctx.stream, d1, d2, u, W.d(), Zfact.d(),
+    const int shares = std::max(1, ((d2 + 15) / 16 + 3) / 4);
+    hipLaunchKernelGGL(ens_grad_aux_fused_kernel, dim3(shares), dim3(EF_THREADS), ens_fused_lds_bytes(d1, d2, 1), ctx.stream, d1, d2, u, W.d(), Zfact.d(),
                        Zdinv.d(), trsm_refine_steps(), tau.d(), Zi.d(), grad.d(), Zitau.d(), HuW.d(), WtauI.d(), frec.d());
     HYP_CHECK(hipGetLastError());
     ctx.d2h(ctx.h_pinned + 58, frec.d() + 2, 4 * sizeof(double));

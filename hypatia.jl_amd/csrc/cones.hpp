@@ -257,10 +257,8 @@ struct WsosCone : GenericHessCone {   // src/Cones/wsosinterpnonnegative.jl (rea
   void set_initial_point(double* h_out) override;
   void hess_prod_slow(double* prod, long ldp, const double* arr, long lda, int ncols) override;   // :152-175
   const double* dder3(const double* d_dir) override;                                               // :177-188
-  void partial_lambda(int k, const double* d_dir, bool half = false);                              // :190-200 -> LU[k]
-  void lambda_of(int k, const double* d_dir, bool half = false);                                   // its first half -> LL[k] (symmetric; half: upper triangle, diagonal halved)
-  void lu_from_ll(int k, bool half);                                                               // its second half: LU[k] = LL[k] LFLP[k]
-  static bool tri_half();                                                                          // HYP_WSOS_TRI
+  void partial_lambda(int k, const double* d_dir);                                                 // :190-200 -> LU[k]
+  void lambda_of(int k, const double* d_dir);                                                      // its first half -> LL[k] (symmetric)
   bool prox_lower_bound(double irtmu, double limit, double* lb) override;
   void gram_norms(const double* d_dir, double* d_out);     // d_out[k] = || LFLP_k diag(dir) LFLP_k' ||_F^2 (LL[k] left in place), both streams
   void hess_vec_from_LL(double* d_out);                    // H dir from the LL[k] of the last gram_norms(dir): sum_k diag(LFLP_k' LL_k LFLP_k)

@@ -33,18 +33,6 @@ __global__ __launch_bounds__(256) void col_dot_kernel(int m, int n, const double
   if (lane == 0) out[col] = (accumulate ? out[col] : 0.0) + sign * s;
 }
 
-// upper triangle kept, diagonal halved, strict lower triangle zeroed: with M symmetric, v' M v = 2 v' Mh v for this Mh
-__global__ void upper_half_kernel(int n, double* __restrict__ A, long lda) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // row
-  const int j = blockIdx.y;                               // col
-  if (i >= n) return;
-  if (i > j) A[(long)j * lda + i] = 0.0;
-  else if (i == j) A[(long)j * lda + i] *= 0.5;
-}
-static void upper_half(Ctx& c, int n, double* A, long lda) {
-  hipLaunchKernelGGL(upper_half_kernel, dim3((n + 127) / 128, n), dim3(128), 0, c.stream, n, A, lda);
-  HYP_CHECK(hipGetLastError());
-}
 static void row_scale(Ctx& c, int m, int n, const double* s, const double* in, long ldi, double* out, long ldo) {
   hipLaunchKernelGGL(row_scale_kernel, dim3((m + 255) / 256, std::min(n, 2048)), dim3(256), 0, c.stream, m, n, s, in, ldi, out, ldo);
   HYP_CHECK(hipGetLastError());
@@ -399,12 +387,7 @@ void WsosCone::update_hess() {   // :135-150: H = sum_k (LFLP_k' LFLP_k) .^ 2
   hess_updated = true;
 }
 
-bool WsosCone::tri_half() {   // HYP_WSOS_TRI (default 1; the reference route HYP_WSOS_PAR=0 keeps the full products)
-  static const bool on = [] { const char* e = getenv("HYP_WSOS_TRI"); return !(e && e[0] == '0'); }();
-  static const bool par = [] { const char* e = getenv("HYP_WSOS_PAR"); return !(e && e[0] == '0'); }();
-  return on && par;
-}
-void WsosCone::lambda_of(int k, const double* d_dir, bool half) {   // LL_k = LFLP_k diag(dir) LFLP_k'  (L x L, both triangles; half: see partial_lambda)
+void WsosCone::lambda_of(int k, const double* d_dir) {   // LL_k = LFLP_k diag(dir) LFLP_k'  (L x L, both triangles)
   const int Lk = Ls[k];
   // LU' = diag(dir) LFLP'  (U x L) ; LL = LU LFLP' = (diag(dir) LFLP')' LFLP'
   row_scale(ctx, U, Lk, d_dir, LFLPT[k].d(), U, SP[k].d(), U);
@@ -412,8 +395,7 @@ void WsosCone::lambda_of(int k, const double* d_dir, bool half) {   // LL_k = LF
   a.M = Lk; a.N = Lk; a.K = U; a.A = SP[k].d(); a.lda = U; a.B = LFLPT[k].d(); a.ldb = U; a.C = LL[k].d(); a.ldc = Lk;
   a.alpha = 1; a.beta = 0; a.tri = GEMM_UPPER; a.batch = 1;
   gemm(ctx, true, a);
-  if (half) upper_half(ctx, Lk, LL[k].d(), Lk);
-  else dev_symmetrize_from_upper(ctx, Lk, LL[k].d(), Lk, 1, 0);   // Hermitian(LLk)
+  dev_symmetrize_from_upper(ctx, Lk, LL[k].d(), Lk, 1, 0);   // Hermitian(LLk)
 }
 
 // <v, H^-1 v> >= <v, w>^2 / <w, H w> with w = M v, M = the inverse of the Hessian at an EARLIER point -- whatever Cholesky factor
@@ -439,10 +421,11 @@ void WsosCone::hess_vec_from_LL(double* d_out) {   // :152-175 (the matrix-free 
   for (int k = 0; k < K; ++k) {
     const int Lk = Ls[k];
     LaneSwitch on_lane(ctx, k % nl);
-    const bool half = tri_half();
-    if (half) upper_half(ctx, Lk, LL[k].d(), Lk);   // (the symmetric LL of gram_norms is not needed again)
-    lu_from_ll(k, half);
-    col_dot(ctx, Lk, U, LFLP[k].d(), Lk, LU[k].d(), Lk, half ? 2.0 : 1.0, false, gparts.d() + (long)k * U);
+    GemmArgs b{};   // LU = LL * LFLP  (L x U)
+    b.M = Lk; b.N = U; b.K = Lk; b.A = LL[k].d(); b.lda = Lk; b.B = LFLP[k].d(); b.ldb = Lk; b.C = LU[k].d(); b.ldc = Lk;
+    b.alpha = 1; b.beta = 0; b.batch = 1;
+    gemm(ctx, true, b);
+    col_dot(ctx, Lk, U, LFLP[k].d(), Lk, LU[k].d(), Lk, 1.0, false, gparts.d() + (long)k * U);
   }
   join_lanes(ctx, nl);
   hipLaunchKernelGGL(sum_parts_kernel, dim3((U + 255) / 256), dim3(256), 0, ctx.stream, U, K, gparts.d(), d_out);
@@ -527,26 +510,13 @@ bool WsosCone::prox_lower_bound(double irtmu, double limit, double* lb) {
   return true;
 }
 
-// half: the caller only wants diag(LFLP' LL LFLP) = the column sums of LFLP .* (LL LFLP).  LL is symmetric, so that is TWICE the
-// column sums of LFLP .* (LLh LFLP) with LLh = LL's upper triangle, diagonal halved: a product with a triangular first operand,
-// whose tile rows start their K range at their own row (KR_GE_M) -- 55 % of the full product's MFMA steps at L = 495 on 64-wide
-// tiles, 52 % at L = 330 (the product is the largest kernel of the matrix-free Hessian product: 69 / 38 us of a 140 / 97 us chain).
-void WsosCone::partial_lambda(int k, const double* d_dir, bool half) {   // :190-200
+void WsosCone::partial_lambda(int k, const double* d_dir) {   // :190-200
   const int Lk = Ls[k];
-  lambda_of(k, d_dir, half);
-  lu_from_ll(k, half);
-}
-void WsosCone::lu_from_ll(int k, bool half) {
-  const int Lk = Ls[k];
+  lambda_of(k, d_dir);
   GemmArgs b{};   // LU = LL * LFLP  (L x U)
   b.M = Lk; b.N = U; b.K = Lk; b.A = LL[k].d(); b.lda = Lk; b.B = LFLP[k].d(); b.ldb = Lk; b.C = LU[k].d(); b.ldc = Lk;
   b.alpha = 1; b.beta = 0; b.batch = 1;
-  if (half) {   // A(m, k) = LLh[m + k L]: the upper triangle as stored (no transposed reading), k >= the tile row's first row
-    b.krange = KR_GE_M;
-    gemm(ctx, false, b);
-  } else {
-    gemm(ctx, true, b);
-  }
+  gemm(ctx, true, b);
 }
 
 void WsosCone::hess_prod_slow(double* prod, long ldp, const double* arr, long lda, int ncols) {   // :152-175
@@ -566,8 +536,8 @@ void WsosCone::hess_prod_slow(double* prod, long ldp, const double* arr, long ld
       fork_lanes(ctx, nl);
       for (int k = 0; k < K; ++k) {
         LaneSwitch on_lane(ctx, k % nl);
-        partial_lambda(k, arr + (long)j * lda, tri_half());
-        col_dot(ctx, Ls[k], U, LFLP[k].d(), Ls[k], LU[k].d(), Ls[k], tri_half() ? 2.0 : 1.0, false, gparts.d() + (long)k * U);
+        partial_lambda(k, arr + (long)j * lda);
+        col_dot(ctx, Ls[k], U, LFLP[k].d(), Ls[k], LU[k].d(), Ls[k], 1.0, false, gparts.d() + (long)k * U);
       }
       join_lanes(ctx, nl);
       hipLaunchKernelGGL(sum_parts_kernel, dim3((U + 255) / 256), dim3(256), 0, ctx.stream, U, K, gparts.d(), prod + (long)j * ldp);
