@@ -7,6 +7,7 @@ python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tai
 python bench.py > gpurun_out/bench_cfg2_1gpu.json 2> gpurun_out/bench_cfg2_1gpu.err; tail -c 300 gpurun_out/bench_cfg2_1gpu.json
 rm -f gpurun_out/other_configs.jsonl
 for c in 3b 5p 5d; do python bench.py --config $c 2>/dev/null | tail -1 >> gpurun_out/other_configs.jsonl; done
+for v in 1 0 1 0; do HYP_ENS_FUSED=$v HYP_ENS_DUAL_DECIDE=$v python bench.py --config 3b --cpu-iters 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('3b one-workgroup kernels + bound-decided dual test = $v:', round(d['ms_per_step'],3), d['phases_ms_per_step'])"; done > gpurun_out/cfg3b_fused_ab.txt; cat gpurun_out/cfg3b_fused_ab.txt
 python bench.py --config 4 2>/dev/null | tail -1 > gpurun_out/bench_cfg4_1gpu.json
 HYP_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --config 4 --no-secondary 2>/dev/null | tail -1 > gpurun_out/bench_cfg4_rccl_world1.json
 python -c "
