@@ -6,6 +6,16 @@
 
 namespace hyp {
 
+// tools/probe_gemm64.hip builds this file with -DHYP_GEMM_PROBE: every wavefront adds the shader cycles (s_memtime) it spent in the
+// four parts of its K steps -- requesting the next tile, LDS fragment reads + MFMA issue, waiting for the requested tile + LDS stores,
+// the barrier -- to gemm_probe_acc[0..3], its K steps to [4], itself to [5], its whole life to [6].  Not compiled into the library.
+#ifdef HYP_GEMM_PROBE
+__device__ unsigned long long gemm_probe_acc[8];
+#define GEMM_PROBE_T(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
+#else
+#define GEMM_PROBE_T(x)
+#endif
+
 constexpr int BK = 16, LDS_S = BK + 2;
 constexpr int GEMM_THREADS = 256;
 
@@ -195,18 +205,37 @@ void gemm_f64_kernel(GemmArgs p) {
   };
 
   const int nkt = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+#ifdef HYP_GEMM_PROBE
+  unsigned long long pr_req = 0, pr_mma = 0, pr_sto = 0, pr_bar = 0;
+  GEMM_PROBE_T(pr_birth);
+#endif
   if (nkt > 0) {
     load_tiles(kbeg);
     store_tiles(0, kbeg);
     __syncthreads();
     for (int t = 0; t < nkt; ++t) {
       const int buf = t & 1;
+      GEMM_PROBE_T(c0);
       if (t + 1 < nkt) load_tiles(kbeg + (t + 1) * BK);
+      GEMM_PROBE_T(c1);
       compute(buf);
+      GEMM_PROBE_T(c2);
       if (t + 1 < nkt) store_tiles(buf ^ 1, kbeg + (t + 1) * BK);
+      GEMM_PROBE_T(c3);
       __syncthreads();
+#ifdef HYP_GEMM_PROBE
+      const unsigned long long c4 = __builtin_amdgcn_s_memtime();
+      pr_req += c1 - c0; pr_mma += c2 - c1; pr_sto += c3 - c2; pr_bar += c4 - c3;
+#endif
     }
   }
+#ifdef HYP_GEMM_PROBE
+  if (lane == 0) {
+    atomicAdd(&gemm_probe_acc[0], pr_req); atomicAdd(&gemm_probe_acc[1], pr_mma); atomicAdd(&gemm_probe_acc[2], pr_sto);
+    atomicAdd(&gemm_probe_acc[3], pr_bar); atomicAdd(&gemm_probe_acc[4], (unsigned long long)nkt); atomicAdd(&gemm_probe_acc[5], 1ull);
+    atomicAdd(&gemm_probe_acc[6], __builtin_amdgcn_s_memtime() - pr_birth);
+  }
+#endif
 
   // epilogue: lane (fr, fk), accumulator register r of tile (j, i) is
   //   C[m0 + wm*WT + i*16 + fr, n0 + wn*WT + j*16 + fk + 4r]
