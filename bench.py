@@ -81,6 +81,9 @@ def algorithm_record():
             # (the candidate screen needs the proximity bound: off with HYP_PROX_LB=0)
             # behind a failed Cholesky: the rook-pivoted elimination only from the failing pivot's block on (round 4; 0: the whole matrix)
             "fallback_keeps_cholesky_blocks": on("HYP_BK_HYBRID"),
+            # EpiNormSpectral with d1 <= 64 (config 3b): an oracle as one launch of one workgroup; the dual feasibility test decided on
+            # rigorous bounds of the nuclear norm in front of every Jacobi sweep (round 5)
+            "ens_one_workgroup_oracles": on("HYP_ENS_FUSED"), "ens_dual_test_on_bounds": on("HYP_ENS_DUAL_DECIDE"),
             "reference_route": not (on("HYP_ENS_CLOSED_INV") or on("HYP_PROX_LB") or on("HYP_ENS_PREFETCH") or on("HYP_WSOS_PAR") or on("HYP_BK_HYBRID") or on("HYP_ENS_DUAL_DECIDE") or on("HYP_ENS_FUSED"))}
 
 
