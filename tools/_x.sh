@@ -1,5 +1,10 @@
-# scratch batch (rewritten per call): last sanity run of the round's tree
+# scratch batch (rewritten per call): the whole GPU suite and one line per configuration on the round's last commit
 export TMPDIR=/tmp
+python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu_head.log 2>&1; tail -2 gpurun_out/pytest_gpu_head.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python -m pytest tests -m gpu -q -n 4 -k "test_hip_dense or test_hip_cones or test_hip_solver or test_capi" 2>&1 | tail -2
-python bench.py 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bench.py default:', d['metric'], round(d['value'],2), d['unit'], round(d['ms_per_step'],3), 'frac', round(d['roofline']['frac'],3), 'cpu_baseline' in d)"
+rm -f gpurun_out/head_configs.jsonl
+python bench.py 2>/dev/null | tail -1 >> gpurun_out/head_configs.jsonl
+for c in 3b 5p 5d; do python bench.py --config $c --cpu-iters 0 2>/dev/null | tail -1 >> gpurun_out/head_configs.jsonl; done
+python -c "
+import json
+for l in open('gpurun_out/head_configs.jsonl'): d=json.loads(l); print(d['config']['workload'][:60], round(d['ms_per_step'],3), d['roofline'].get('frac'))"
