@@ -843,7 +843,51 @@ def main_other(args, world=1, rank=0, local_rank=0, multi=False):
             pass
 
 
+def pin_near_gpu(local_rank, do_pin=True):
+    """HYP_BENCH_PIN=1 (experiment, EXPERIMENTS.md r05-32): restrict this process to the host CPUs that sysfs lists as local to the GPU
+    (`local_cpulist` of the local_rank-th AMD accelerator on the PCI bus) -- the launch-heavy configurations (config 5: ~1500 launches
+    per iteration) depend on the host's distance to the device.  Returns what it did, for the bench line."""
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(local_rank)) != 0:
+            return {"pinned": False, "why": "hipDeviceGetPCIBusId failed"}
+        bdf = buf.value.decode().lower()
+        base = "/sys/bus/pci/devices/" + bdf
+        if not os.path.exists(base + "/local_cpulist"):
+            return {"pinned": False, "why": "no sysfs entry for " + bdf}
+        txt = open(base + "/local_cpulist").read().strip()
+        node = open(base + "/numa_node").read().strip() if os.path.exists(base + "/numa_node") else "?"
+        cpus = set()
+        for part in txt.split(","):
+            if "-" in part:
+                a, b = part.split("-"); cpus.update(range(int(a), int(b) + 1))
+            elif part:
+                cpus.add(int(part))
+        before = len(os.sched_getaffinity(0))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return {"pinned": False, "why": "empty local_cpulist", "device": os.path.basename(base)}
+        try:
+            here = int(open("/proc/self/stat").read().rsplit(")", 1)[1].split()[36])   # the CPU this thread last ran on
+        except Exception:
+            here = -1
+        if do_pin == "far":   # (experiment: the CPUs of the OTHER node(s))
+            far = os.sched_getaffinity(0) - cpus
+            if far:
+                os.sched_setaffinity(0, far)
+        elif do_pin:
+            os.sched_setaffinity(0, cpus)
+        return {"pinned": do_pin if do_pin == "far" else bool(do_pin), "device": os.path.basename(base), "numa_node": node, "cpus": len(cpus), "cpus_before": before,
+                "running_on_cpu": here, "cpu_is_local": here in cpus}
+    except Exception as e:   # (sysfs layout differs: run unpinned)
+        return {"pinned": False, "why": repr(e)}
+
+
 def main():
+    if os.environ.get("HYP_BENCH_PIN") in ("0", "1", "far"):   # 0: report the placement only, 1: pin, far: pin to the other node's CPUs
+        mode = os.environ["HYP_BENCH_PIN"]
+        print("[bench] host affinity:", pin_near_gpu(int(os.environ.get("LOCAL_RANK", "0")), "far" if mode == "far" else mode == "1"), file=sys.stderr)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed IPM iterations (default: 220 at config 2 = ~5 s of timed region; 30 at config 4)")

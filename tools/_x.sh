@@ -1,10 +1,12 @@
-# scratch batch (rewritten per call): the whole GPU suite and one line per configuration on the round's last commit
+# scratch batch (rewritten per call): host affinity near the GPU / on the other NUMA node vs the default
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu_head.log 2>&1; tail -2 gpurun_out/pytest_gpu_head.log
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-rm -f gpurun_out/head_configs.jsonl
-python bench.py 2>/dev/null | tail -1 >> gpurun_out/head_configs.jsonl
-for c in 3b 5p 5d; do python bench.py --config $c --cpu-iters 0 2>/dev/null | tail -1 >> gpurun_out/head_configs.jsonl; done
-python -c "
-import json
-for l in open('gpurun_out/head_configs.jsonl'): d=json.loads(l); print(d['config']['workload'][:60], round(d['ms_per_step'],3), d['roofline'].get('frac'))"
+run() { python bench.py --config $1 --cpu-iters 0 $3 2>gpurun_out/x_pin.err | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$2', round(d['ms_per_step'],3), {k:round(v,2) for k,v in d['phases_ms_per_step'].items()})"; grep "host affinity" gpurun_out/x_pin.err | cut -c1-230; }
+for i in 1 2; do
+  HYP_BENCH_PIN=0 run 5p "5p default (report):"
+  HYP_BENCH_PIN=1 run 5p "5p pinned LOCAL    :"
+  HYP_BENCH_PIN=far run 5p "5p pinned FAR      :"
+done
+HYP_BENCH_PIN=1 run 3b "3b pinned LOCAL    :"
+HYP_BENCH_PIN=far run 3b "3b pinned FAR      :"
+HYP_BENCH_PIN=1 run 2 "cfg2 pinned LOCAL  :" "--steps 120"
+HYP_BENCH_PIN=far run 2 "cfg2 pinned FAR    :" "--steps 120"
