@@ -1,12 +1,13 @@
-# scratch batch (rewritten per call): host affinity near the GPU / on the other NUMA node vs the default
+# scratch batch (rewritten per call)
 export TMPDIR=/tmp
-run() { python bench.py --config $1 --cpu-iters 0 $3 2>gpurun_out/x_pin.err | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$2', round(d['ms_per_step'],3), {k:round(v,2) for k,v in d['phases_ms_per_step'].items()})"; grep "host affinity" gpurun_out/x_pin.err | cut -c1-230; }
-for i in 1 2; do
-  HYP_BENCH_PIN=0 run 5p "5p default (report):"
-  HYP_BENCH_PIN=1 run 5p "5p pinned LOCAL    :"
-  HYP_BENCH_PIN=far run 5p "5p pinned FAR      :"
+python -m pytest tests -m gpu -q -n 4 -k "dense or gemm or epinorm or matrixcompletion or mc_ or trajectory or fullsize_configs" > gpurun_out/x_pytest.log 2>&1; tail -3 gpurun_out/x_pytest.log
+for s in "" _off; do
+  if [ "$s" = _off ]; then export HYP_GEMM_AUTOSPLIT_MAX=128; else unset HYP_GEMM_AUTOSPLIT_MAX; fi
+  python bench.py --config 3b --cpu-iters 0 2>/dev/null | tail -1 > gpurun_out/x_3b$s.json
 done
-HYP_BENCH_PIN=1 run 3b "3b pinned LOCAL    :"
-HYP_BENCH_PIN=far run 3b "3b pinned FAR      :"
-HYP_BENCH_PIN=1 run 2 "cfg2 pinned LOCAL  :" "--steps 120"
-HYP_BENCH_PIN=far run 2 "cfg2 pinned FAR    :" "--steps 120"
+unset HYP_GEMM_AUTOSPLIT_MAX
+python bench.py --config 5p --cpu-iters 0 2>/dev/null | tail -1 > gpurun_out/x_5p.json
+python -c "
+import json
+for c,s in (('3b',''),('3b','_off'),('5p','')):
+    d=json.load(open('gpurun_out/x_%s%s.json'%(c,s))); print(c+s, round(d['ms_per_step'],3), {k:round(v,2) for k,v in d['phases_ms_per_step'].items()})"
