@@ -1507,9 +1507,9 @@ Ctx::Ctx(int dev) : device(dev) {
   HYP_CHECK(hipMemset(dscal.p, 0, 128 * sizeof(double)));
   for (int i = 0; i < 6; ++i) HYP_CHECK(hipEventCreate(&ev[i]));
   host_allocator_keep_pages();
-  HYP_CHECK(hipHostMalloc((void**)&h_info, 8192 * sizeof(int), hipHostMallocDefault));   // [0..63] general; [64 + 2 k, 64 + 2 k + 1] cone k of a batched feasibility sweep
+  HYP_CHECK(hipHostMalloc((void**)&h_info, (8192 + 16) * sizeof(int), hipHostMallocDefault));   // [0..63] general; [64 + 2 k, 64 + 2 k + 1] cone k of a batched feasibility sweep; [H_INFO_FACT]: the system solver's factorization
   h_pinned_n = 1 << 16;
-  HYP_CHECK(hipHostMalloc((void**)&h_pinned, h_pinned_n * sizeof(double), hipHostMallocDefault));
+  HYP_CHECK(hipHostMalloc((void**)&h_pinned, (h_pinned_n + H_SC_N) * sizeof(double), hipHostMallocDefault));   // (+ the mirror of the direction solves' scalars behind the general staging: h_sc())
 }
 Ctx::~Ctx() {
   if (device_lock_fd >= 0) (void)close(device_lock_fd);   // (releases the lock)

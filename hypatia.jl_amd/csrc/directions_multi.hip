@@ -751,14 +751,17 @@ void SysSolver::get_directions2(double* h_dirs, const double* h_rhss, double mu,
 // out[:, r] = k0_r x0[:, r] (*) k1_r x1[:, r] (*) k2_r x2[:, r] for r < nr columns in ONE launch, with exactly the roundings of the
 // dev_scale_copy / dev_axpby sequence it replaces (a product, then one fused multiply-add per further term; x1 / x2 may be null);
 // a leading dimension of 0 = the same vector for every column.  The paired solve issued 9 of those small launches per column.
-struct LinK { double k0[3], k1[3], k2[3]; };
+// A coefficient may live on the device (p0 / p1 non-null: the tau of a solve whose scalars the host has not seen, round 6).
+struct LinK { double k0[3], k1[3], k2[3]; const double* p0[3]; const double* p1[3]; };
 __global__ void lincomb_cols_kernel(int n, const double* __restrict__ x0, long ld0, const double* __restrict__ x1, long ld1,
                                     const double* __restrict__ x2, long ld2, double* __restrict__ out, long ldo, LinK k) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int r = blockIdx.y;
   if (i >= n) return;
-  double v = __dmul_rn(k.k0[r], x0[(long)r * ld0 + i]);
-  if (x1) v = __fma_rn(k.k1[r], x1[(long)r * ld1 + i], v);
+  const double k0 = k.p0[r] ? *k.p0[r] : k.k0[r];
+  const double k1 = k.p1[r] ? *k.p1[r] : k.k1[r];
+  double v = __dmul_rn(k0, x0[(long)r * ld0 + i]);
+  if (x1) v = __fma_rn(k1, x1[(long)r * ld1 + i], v);
   if (x2) v = __fma_rn(k.k2[r], x2[(long)r * ld2 + i], v);
   out[(long)r * ldo + i] = v;
 }
@@ -769,41 +772,68 @@ static void lincomb_cols(Ctx& c, int n, int nr, const double* x0, long ld0, cons
   HYP_CHECK(hipGetLastError());
 }
 
-// two right-hand sides already on the device (rhs2 = two Point vectors, tau / kap slots zero, scalars in rs):
-// directions are left in m_dir, their tau / kap in dsc
+// ---- scalars of a solve on the device (round 6) ---------------------------------------------------------------
+// solve_subsystem4's tau (common.jl:155-161) and the kap that follows from it, for nr columns, with the host's operations in the
+// host's order (no contraction: the host code is compiled for x86-64 without FMA).  const_mode: dot_const = sc[4] + sc[5] (the
+// constant column came out of THIS solve: its two scalar products are the third column's) instead of the argument.
+// base_on: the direction's scalars are base - (the solve's) (refinement: dir = dir_best - correction).
+struct TauArgs { double rs_tau[2], rs_kap[2], base_tau[2], base_kap[2]; double mu, taubar, dot_const; int nr, const_mode, base_on; };
+__global__ void cols_tau_kernel(double* __restrict__ sc, TauArgs a) {
+#pragma clang fp contract(off)
+  if (threadIdx.x != 0) return;
+  double dc = a.dot_const;
+  if (a.const_mode) dc = sc[SysSolver::SC_SOLVE + 4] + sc[SysSolver::SC_SOLVE + 5];
+  sc[SysSolver::SC_DOTC] = dc;
+  const double m2 = a.mu / a.taubar / a.taubar;
+  for (int r = 0; r < a.nr; ++r) {
+    const double dot_sub = sc[SysSolver::SC_SOLVE + 2 * r] + sc[SysSolver::SC_SOLVE + 2 * r + 1];
+    const double sol_tau = (a.rs_tau[r] + a.rs_kap[r] + dot_sub) / (m2 - dc);
+    const double sol_kap = -a.mu / a.taubar / a.taubar * sol_tau + a.rs_kap[r];
+    sc[SysSolver::SC_CSC + 2 * r] = sol_tau;
+    sc[SysSolver::SC_CSC + 2 * r + 1] = sol_kap;
+    sc[SysSolver::SC_DSC + 2 * r] = a.base_on ? a.base_tau[r] - sol_tau : sol_tau;
+    sc[SysSolver::SC_DSC + 2 * r + 1] = a.base_on ? a.base_kap[r] - sol_kap : sol_kap;
+  }
+}
+
+// one-column products of column-wise cones go through the multi-column kernels (a column has the same sums wherever it is formed);
+// only ever switched on for ONE column -- the paired refinement, which runs on models of column-wise cones only
+struct GemvOneGuard {
+  Ctx& c;
+  bool keep;
+  GemvOneGuard(Ctx& ctx, bool on) : c(ctx), keep(ctx.gemv_one) { if (on) c.gemv_one = true; }
+  ~GemvOneGuard() { c.gemv_one = keep; }
+};
+
+bool SysSolver::dirs_resident() const {
+  static const bool on = [] { const char* e = getenv("HYP_DIR_RESIDENT"); return !(e && e[0] == '0'); }();
+  return on && p == 0 && !dist();
+}
+
+// solve_system for nr columns (common.jl:129-182, qrchol.jl:16-37); see syssolver.hpp
 // with_const: the constant column of update_lhs (qrchol.jl:191-197: rhs_const = (-c, H h), solved once per iteration) rides
 // along as a THIRD column of this call's solve_subsystem3 -- its two passes over G, its cone product and its scalar products
 // cost the pair nothing extra; sol_const / dot_const are set before the pair's tau is formed from them (common.jl:155-161)
-void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
-                                  double min_impr_tol, Scal* dsc, double* res_norms, int* n_solves, bool with_const, bool joint_const) {
+void SysSolver::cols_solve(double* sol, const double* rhs, int nr, const Scal* rs, double mu, double taubar, bool with_const, bool joint_const,
+                           bool resident, bool both, const Scal* base, Scal* dsc_host) {
   const size_t d = sizeof(double);
-  const int dv = dimv(), it = n + p + q, ik = dv - 1;
-  HYP_REQUIRE(p == 0, "pair_solve_device: p = 0 only");
+  const int dv = dimv();
+  HYP_REQUIRE(p == 0 && nr >= 1 && nr <= MR, "cols_solve: p = 0, one or two columns");
+  HYP_REQUIRE(!(with_const || joint_const) || nr == MR, "cols_solve: the constant column rides with a pair");
   const int oz = n, os = n + q + 1;
   const long ld3 = n + q;
-  for (DBuf* b : {&m_dir, &m_res}) b->ensure((size_t)MR * dv * d);
   for (DBuf* b : {&m_subr, &m_subs}) b->ensure((size_t)(MR + 1) * ld3 * d);
   for (DBuf* b : {&m_Gx, &m_HGx, &m_Gxd}) b->ensure((size_t)(MR + 1) * q * d);
-  double* dir = m_dir.d();
-  double* res = m_res.d();
+  d_sc.ensure(64 * d);
   double* sr = m_subr.d();
   double* ss = m_subs.d();
-  Scal rsc[MR];
-  {   // (the tau / kap slots of the work vectors stay zero: eight doubles, one launch)
-    ZeroSlots z;
-    for (int r = 0; r < MR; ++r) {
-      z.add(dir + (long)r * dv + it); z.add(dir + (long)r * dv + ik);
-      z.add(res + (long)r * dv + it); z.add(res + (long)r * dv + ik);
-    }
-    dev_zero_slots(ctx, z);
-  }
-
-  // ---- solve_system for both columns (common.jl:129-182, qrchol.jl:16-37).  with_const: the constant column is a genuine
-  // third INPUT column, (x, z, s) = (-c, -h, 0), so that its right-hand side H h (= -H (-h) - 0 below) and its H (G x) come out
-  // of the same three-column cone products (z_const = H G x - H h cancels to ~mu of its terms late in a solve)
-  const int ncol = with_const ? MR + 1 : MR;
+  double* sc = d_sc.d();
+  // with_const: the constant column is a genuine third INPUT column, (x, z, s) = (-c, -h, 0), so that its right-hand side H h
+  // (= -H (-h) - 0 below) and its H (G x) come out of the same three-column cone products (z_const = H G x - H h cancels to ~mu
+  // of its terms late in a solve)
+  const int ncol = with_const ? nr + 1 : nr;
   if (with_const) {
-    double* rc = rhs + (long)MR * dv;                    // (the caller's buffer holds MR + 1 Point vectors)
+    double* rc = const_cast<double*>(rhs) + (long)MR * dv;                    // (the caller's buffer holds MR + 1 Point vectors)
     ctx.zero(rc, (size_t)dv * d);
     dev_scale_copy(ctx, n, -1.0, mc.d(), rc);
     dev_scale_copy(ctx, q, -1.0, mh.d(), rc + oz);
@@ -827,174 +857,357 @@ void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double
       for (int r = 0; r < ncol; ++r) dev_axpby(ctx, dk, -1.0, rhs + (long)r * dv + os + o, -1.0, sr + r * ld3 + oz + o);
     }
   }
-  solve3_multi(ss, sr, ncol, joint_const ? sol_const.d() : nullptr);
-  double* ds = ctx.dscal.d();
+  {
+    GemvOneGuard g1(ctx, ncol == 1);
+    solve3_multi(ss, sr, ncol, joint_const ? sol_const.d() : nullptr);
+  }
   {
     DotSpecs sp;
     for (int r = 0; r < ncol; ++r) {
-      sp.add(n, mc.d(), ss + r * ld3, ds + 2 * r);
-      sp.add(q, mh.d(), ss + r * ld3 + oz, ds + 2 * r + 1);
+      sp.add(n, mc.d(), ss + r * ld3, sc + SC_SOLVE + 2 * r);
+      sp.add(q, mh.d(), ss + r * ld3 + oz, sc + SC_SOLVE + 2 * r + 1);
     }
     if (joint_const) {   // the rest of the constant solve (solve3 after its triangular solves) and its two dot products
       update_const_post();
-      sp.add(n, mc.d(), sol_const.d(), ds + 2 * MR);
-      sp.add(q, mh.d(), sol_const.d() + n, ds + 2 * MR + 1);
+      sp.add(n, mc.d(), sol_const.d(), sc + SC_SOLVE + 2 * MR);
+      sp.add(q, mh.d(), sol_const.d() + n, sc + SC_SOLVE + 2 * MR + 1);
     }
     dev_dots(ctx, sp);
   }
-  ctx.d2h(ctx.h_pinned, ds, 2 * (MR + 1) * d);
-  ctx.sync();
-  if (joint_const) dot_const = ctx.h_pinned[2 * MR] + ctx.h_pinned[2 * MR + 1];
-  if (dist()) {   // h' z over all ranks' rows
-    double hz[MR + 1] = {ctx.h_pinned[1], ctx.h_pinned[3], ctx.h_pinned[5]};
-    allreduce_host(hz, ncol, 0, 2);
-    ctx.h_pinned[1] = hz[0];
-    ctx.h_pinned[3] = hz[1];
-    ctx.h_pinned[5] = hz[2];
-  }
-  if (with_const) {
-    ctx.d2d(sol_const.p, ss + (long)MR * ld3, (size_t)ld3 * d);
-    dot_const = ctx.h_pinned[2 * MR] + ctx.h_pinned[2 * MR + 1];
-  }
-  {
-    LinK k{};
-    for (int r = 0; r < MR; ++r) {
-      const double dot_sub = ctx.h_pinned[2 * r] + ctx.h_pinned[2 * r + 1];
+  const bool own_const = with_const || joint_const;
+  LinK k{};
+  if (resident) {
+    TauArgs a{};
+    for (int r = 0; r < nr; ++r) {
+      a.rs_tau[r] = rs[r].tau; a.rs_kap[r] = rs[r].kap;
+      if (base) { a.base_tau[r] = base[r].tau; a.base_kap[r] = base[r].kap; }
+    }
+    a.mu = mu; a.taubar = taubar; a.dot_const = dot_const; a.nr = nr; a.const_mode = own_const ? 1 : 0; a.base_on = base ? 1 : 0;
+    hipLaunchKernelGGL(cols_tau_kernel, dim3(1), dim3(64), 0, ctx.stream, sc, a);
+    HYP_CHECK(hipGetLastError());
+    for (int r = 0; r < nr; ++r) { k.k0[r] = 1.0; k.p1[r] = sc + SC_CSC + 2 * r; }
+  } else {
+    double* hp = ctx.h_sc();
+    ctx.d2h(hp, sc, 2 * (MR + 1) * d);
+    ctx.sync();
+    if (joint_const) dot_const = hp[2 * MR] + hp[2 * MR + 1];
+    if (dist()) {   // h' z over all ranks' rows
+      double hz[MR + 1] = {hp[1], hp[3], hp[5]};
+      allreduce_host(hz, ncol, 0, 2);
+      hp[1] = hz[0];
+      hp[3] = hz[1];
+      hp[5] = hz[2];
+    }
+    if (with_const) dot_const = hp[2 * MR] + hp[2 * MR + 1];
+    for (int r = 0; r < nr; ++r) {
+      const double dot_sub = hp[2 * r] + hp[2 * r + 1];
       const double sol_tau = (rs[r].tau + rs[r].kap + dot_sub) / (mu / taubar / taubar - dot_const);
-      dsc[r].tau = sol_tau;
-      dsc[r].kap = -mu / taubar / taubar * sol_tau + rs[r].kap;
+      const double sol_kap = -mu / taubar / taubar * sol_tau + rs[r].kap;
+      dsc_host[r].tau = base ? base[r].tau - sol_tau : sol_tau;
+      dsc_host[r].kap = base ? base[r].kap - sol_kap : sol_kap;
       k.k0[r] = 1.0; k.k1[r] = sol_tau;
     }
-    lincomb_cols(ctx, (int)ld3, MR, ss, ld3, sol_const.d(), 0, nullptr, 0, dir, dv, k);   // sol = sol_sub + sol_tau sol_const
   }
+  if (with_const) ctx.d2d(sol_const.p, ss + (long)MR * ld3, (size_t)ld3 * d);
+  lincomb_cols(ctx, (int)ld3, nr, ss, ld3, sol_const.d(), 0, nullptr, 0, sol, dv, k);   // sol = sol_sub + sol_tau sol_const
   // sol.s = h tau - rhs.z - G sol.x  (G sol.x from the rounded sol.x, see solve_system; kept for the residual)
-  // (with a residual to follow, G' dir.z of apply_lhs rides along in the same pass over G)
-  const bool both = (max_ref_steps > 0) && gemv_both_ok(q, n, G.d(), q);
+  // (both: with a residual of THIS vector to follow, G' sol.z of apply_lhs rides along in the same pass over G)
   if (both) {
     m_t.ensure((size_t)MR * n * d);
-    gemv_both(ctx, q, n, MR, G.d(), q, dir, dv, 0.0, m_Gxd.d(), q, dir + oz, dv, 0.0, m_t.d(), n);
+    gemv_both(ctx, q, n, nr, G.d(), q, sol, dv, 0.0, m_Gxd.d(), q, sol + oz, dv, 0.0, m_t.d(), n);
   } else {
-    gemv_multi(ctx, false, q, n, MR, 1.0, G.d(), q, dir, dv, 0.0, m_Gxd.d(), q);
+    GemvOneGuard g1(ctx, nr == 1);
+    gemv_multi(ctx, false, q, n, nr, 1.0, G.d(), q, sol, dv, 0.0, m_Gxd.d(), q);
+  }
+  {
+    LinK k2{};
+    for (int r = 0; r < nr; ++r) { k2.k0[r] = k.k1[r]; k2.p0[r] = k.p1[r]; k2.k1[r] = -1.0; k2.k2[r] = -1.0; }
+    lincomb_cols(ctx, q, nr, mh.d(), 0, rhs + oz, dv, m_Gxd.d(), q, sol + os, dv, k2);
+  }
+}
+
+// residual of nr directions (apply_lhs, common.jl:79-121, minus rhs); see syssolver.hpp
+void SysSolver::cols_residual(double* res, const double* dir, const double* rhs, int nr, const Scal* dsc_host, bool resident, bool fresh, bool both) {
+  const size_t d = sizeof(double);
+  const int dv = dimv();
+  const int oz = n, os = n + q + 1;
+  double* sc = d_sc.d();
+  if (fresh && both) {
+    m_t.ensure((size_t)MR * n * d);
+    gemv_both(ctx, q, n, nr, G.d(), q, dir, dv, 0.0, m_Gxd.d(), q, dir + oz, dv, 0.0, m_t.d(), n);
+  } else if (fresh) {
+    GemvOneGuard g1(ctx, nr == 1);
+    gemv_multi(ctx, false, q, n, nr, 1.0, G.d(), q, dir, dv, 0.0, m_Gxd.d(), q);
   }
   {
     LinK k{};
-    for (int r = 0; r < MR; ++r) { k.k0[r] = dsc[r].tau; k.k1[r] = -1.0; k.k2[r] = -1.0; }
-    lincomb_cols(ctx, q, MR, mh.d(), 0, rhs + oz, dv, m_Gxd.d(), q, dir + os, dv, k);
+    for (int r = 0; r < nr; ++r) {
+      if (resident) k.p0[r] = sc + SC_DSC + 2 * r;
+      else k.k0[r] = dsc_host[r].tau;
+      k.k1[r] = -1.0; k.k2[r] = -1.0;
+    }
+    lincomb_cols(ctx, n, nr, mc.d(), 0, nullptr, 0, nullptr, 0, res, dv, k);                       // res.x = c tau (+ G' z below)
+    lincomb_cols(ctx, q, nr, mh.d(), 0, dir + os, dv, m_Gxd.d(), q, res + oz, dv, k);              // res.z = h tau - s - G x
   }
-  *n_solves += MR;
-  for (int r = 0; r < MR; ++r) res_norms[r] = 0.0;
+  // Sharded, round 4: the residual's three exchanges -- G' z (n-vectors, SUM), the h' z of the directions (SUM) and the residual
+  // norms (MAX) -- travel in ONE all-reduce (allreduce_fused): everything a rank contributes is local (the z / s rows of the
+  // residual do not depend on the summed G' z; only the x rows do, and those are replicated afterwards), so the local maxima
+  // and scalar products are formed first and ride behind the n-vectors.
+  const bool fuse = dist() && fused_ok();
+  if (dist() || both) {
+    if (!both) {
+      m_t.ensure((size_t)MR * n * d);
+      gemv_multi(ctx, true, q, n, nr, 1.0, G.d(), q, dir + oz, dv, 0.0, m_t.d(), n);
+    }
+    if (dist() && !fuse) allreduce_dev(m_t.d(), (long)nr * n, 0, 3);
+    if (!fuse)
+      for (int r = 0; r < nr; ++r) dev_axpby(ctx, n, 1.0, m_t.d() + (long)r * n, 1.0, res + (long)r * dv);
+  } else {
+    GemvOneGuard g1(ctx, nr == 1);
+    gemv_multi(ctx, true, q, n, nr, 1.0, G.d(), q, dir + oz, dv, 1.0, res, dv);
+  }
+  for (size_t k = 0; k < cones.size(); ++k) {   // res.s_k = H_k prim_dir_k + dual_dir_k
+    Cone* ck = cones[k];
+    const int o = offs[k], dk = ck->dim;
+    const int po = ck->use_dual_barrier ? oz + o : os + o, du = ck->use_dual_barrier ? os + o : oz + o;
+    if (const int used = run_hess_prod(k, res + os + o, dv, dir + po, dv, nr)) {   // (PosSemidefTri: hess_prod_slow! = hess_prod!)
+      for (int r = 0; r < nr; ++r) dev_axpby(ctx, offs[k + used] - o, 1.0, dir + (long)r * dv + du, 1.0, res + (long)r * dv + os + o);
+      k += used - 1;
+      continue;
+    }
+    ck->hess_prod_slow(res + os + o, dv, dir + po, dv, nr);
+    for (int r = 0; r < nr; ++r) dev_axpby(ctx, dk, 1.0, dir + (long)r * dv + du, 1.0, res + (long)r * dv + os + o);
+  }
+  {
+    DotSpecs sp;
+    for (int r = 0; r < nr; ++r) {
+      sp.add(n, mc.d(), dir + (long)r * dv, sc + SC_RESD + 2 * r);
+      sp.add(q, mh.d(), dir + (long)r * dv + oz, sc + SC_RESD + 2 * r + 1);
+    }
+    dev_dots(ctx, sp);
+  }
+  double* hp = ctx.h_sc();
+  if (fuse) {
+    HYP_REQUIRE(nr == MR, "cols_residual: the fused exchange carries a pair");
+    double* ds = ctx.dscal.d();
+    for (int r = 0; r < MR; ++r) dev_sub_absmax(ctx, dv - oz, res + (long)r * dv + oz, rhs + (long)r * dv + oz, ds + 8 + r);   // this rank's rows
+    if (m_t.bytes < ((size_t)MR * n + 64 + 2 * (size_t)MR * comm_world_) * d) {   // (room for the tail behind the n-vectors)
+      DBuf bigger(((size_t)MR * n + 64 + 2 * (size_t)MR * comm_world_) * d);
+      ctx.d2d(bigger.p, m_t.p, (size_t)MR * n * d);
+      ctx.sync();
+      m_t = std::move(bigger);
+    }
+    FusedTail t;
+    t.nsum = MR; t.nmax = MR;
+    for (int r = 0; r < MR; ++r) { t.sum_src[r] = sc + SC_RESD + 2 * r + 1; t.max_src[r] = ds + 8 + r; }
+    double ho[2 * MR];
+    allreduce_fused(m_t.d(), (long)MR * n, t, ho, 3);
+    for (int r = 0; r < MR; ++r) dev_axpby(ctx, n, 1.0, m_t.d() + (long)r * n, 1.0, res + (long)r * dv);
+    for (int r = 0; r < MR; ++r) dev_sub_absmax(ctx, oz, res + (long)r * dv, rhs + (long)r * dv, sc + SC_AMAX + r);                // the replicated x rows
+    ctx.d2h(hp, sc, SC_N * d);
+    ctx.sync();
+    for (int r = 0; r < MR; ++r) {
+      hp[SC_RESD + 2 * r + 1] = ho[r];
+      const double a = ho[MR + r], b = hp[SC_AMAX + r];
+      hp[SC_AMAX + r] = (a != a || b != b) ? __builtin_nan("") : std::max(a, b);
+    }
+    return;
+  }
+  for (int r = 0; r < nr; ++r) dev_sub_absmax(ctx, dv, res + (long)r * dv, rhs + (long)r * dv, sc + SC_AMAX + r);
+  if (dist()) {
+    ctx.d2h(hp, sc, SC_N * d);
+    ctx.sync();
+    double hz[MR] = {hp[SC_RESD + 1], hp[SC_RESD + 3]};
+    allreduce_host(hz, MR, 0, 4);
+    hp[SC_RESD + 1] = hz[0];
+    hp[SC_RESD + 3] = hz[1];
+    double v[2 * MR];   // residual norms: max over the ranks, NaN flags first
+    for (int r = 0; r < MR; ++r) {
+      const double m = hp[SC_AMAX + r];
+      v[r] = (m != m) ? 1.0 : 0.0;
+      v[MR + r] = (m != m) ? 0.0 : m;
+    }
+    allreduce_host(v, 2 * MR, 1, 5);
+    for (int r = 0; r < MR; ++r) hp[SC_AMAX + r] = (v[r] > 0.5) ? __builtin_nan("") : v[MR + r];
+  }
+}
 
-  if (max_ref_steps > 0) {
-    // ---- residual of both columns (apply_lhs, common.jl:79-121)
-    {
-      LinK k{};
-      for (int r = 0; r < MR; ++r) { k.k0[r] = dsc[r].tau; k.k1[r] = -1.0; k.k2[r] = -1.0; }
-      lincomb_cols(ctx, n, MR, mc.d(), 0, nullptr, 0, nullptr, 0, res, dv, k);                       // res.x = c tau (+ G' z below)
-      lincomb_cols(ctx, q, MR, mh.d(), 0, dir + os, dv, m_Gxd.d(), q, res + oz, dv, k);              // res.z = h tau - s - G x
-    }
-    // Sharded, round 4: the residual's three exchanges -- G' z (n-vectors, SUM), the h' z of the directions (SUM) and the residual
-    // norms (MAX) -- travel in ONE all-reduce (allreduce_fused): everything a rank contributes is local (the z / s rows of the
-    // residual do not depend on the summed G' z; only the x rows do, and those are replicated afterwards), so the local maxima
-    // and scalar products are formed first and ride behind the n-vectors.
-    const bool fuse = dist() && fused_ok();
-    if (dist() || both) {
-      if (!both) {
-        m_t.ensure((size_t)MR * n * d);
-        gemv_multi(ctx, true, q, n, MR, 1.0, G.d(), q, dir + oz, dv, 0.0, m_t.d(), n);
-      }
-      if (dist() && !fuse) allreduce_dev(m_t.d(), (long)MR * n, 0, 3);
-      if (!fuse)
-        for (int r = 0; r < MR; ++r) dev_axpby(ctx, n, 1.0, m_t.d() + (long)r * n, 1.0, res + (long)r * dv);
-    } else {
-      gemv_multi(ctx, true, q, n, MR, 1.0, G.d(), q, dir + oz, dv, 1.0, res, dv);
-    }
-    for (size_t k = 0; k < cones.size(); ++k) {   // res.s_k = H_k prim_dir_k + dual_dir_k
-      Cone* ck = cones[k];
-      const int o = offs[k], dk = ck->dim;
-      const int po = ck->use_dual_barrier ? oz + o : os + o, du = ck->use_dual_barrier ? os + o : oz + o;
-      if (const int used = run_hess_prod(k, res + os + o, dv, dir + po, dv, MR)) {   // (PosSemidefTri: hess_prod_slow! = hess_prod!)
-        for (int r = 0; r < MR; ++r) dev_axpby(ctx, offs[k + used] - o, 1.0, dir + (long)r * dv + du, 1.0, res + (long)r * dv + os + o);
-        k += used - 1;
+void SysSolver::cols_read_scalars() {
+  if (dist()) return;   // (the sharded residual has read and completed the mirror itself)
+  ctx.d2h(ctx.h_sc(), d_sc.d(), SC_N * sizeof(double));
+}
+
+void SysSolver::cols_finish(int nr, const Scal* rs, double mu, double taubar, bool resident, Scal* dsc, Scal* rsc, double* res_norms) {
+  const double* hp = ctx.h_sc();
+  for (int r = 0; r < nr; ++r) {
+    if (resident) dsc[r] = Scal{hp[SC_DSC + 2 * r], hp[SC_DSC + 2 * r + 1]};
+    rsc[r].tau = -hp[SC_RESD + 2 * r] - hp[SC_RESD + 2 * r + 1] - dsc[r].kap - rs[r].tau;
+    rsc[r].kap = mu / taubar * dsc[r].tau / taubar + dsc[r].kap - rs[r].kap;
+    const double m = hp[SC_AMAX + r];
+    res_norms[r] = (m != m || rsc[r].tau != rsc[r].tau || rsc[r].kap != rsc[r].kap)
+                       ? __builtin_nan("")
+                       : std::max(m, std::max(std::fabs(rsc[r].tau), std::fabs(rsc[r].kap)));
+  }
+}
+
+// The refinement loop of get_directions (common.jl:38-72) for the columns of a pair that need it, through the column routines:
+// a step = solve_system on the residual(s), dir = dir_best - correction, the new residual(s), ONE host round trip; two columns
+// that both need a step share its passes over G and the factor (each column's sums are those it gets alone).  v_tmp holds
+// the best directions so far.  Every column follows its own acceptance / stopping rule, exactly as SysSolver::refine does.
+void SysSolver::refine_cols(double* rhs, double* dir, double* res, const Scal* rs, Scal* dsc, Scal* rsc, double* res_norms, double mu,
+                            double taubar, int max_ref_steps, double res_norm_cutoff, double min_impr_tol, int* n_solves, bool resident) {
+  const size_t d = sizeof(double);
+  const int dv = dimv();
+  v_tmp.ensure((size_t)MR * dv * d);
+  double* tmp = v_tmp.d();
+  bool active[MR], prev_slow[MR];
+  Scal tsc[MR];
+  double prev_norm[MR];
+  int steps[MR];
+  for (int r = 0; r < MR; ++r) {
+    active[r] = res_norms[r] > res_norm_cutoff;
+    prev_slow[r] = false;
+    tsc[r] = dsc[r];
+    prev_norm[r] = res_norms[r];
+    steps[r] = 0;
+    if (active[r]) ctx.d2d(tmp + (long)r * dv, dir + (long)r * dv, (size_t)dv * d);
+  }
+  const bool both = gemv_both_ok(q, n, G.d(), q);
+  while (true) {
+    for (int r = 0; r < MR; ++r) active[r] = active[r] && steps[r] < max_ref_steps;
+    if (!active[0] && !active[1]) break;
+    const int c0 = active[0] ? 0 : 1, nr = (active[0] && active[1]) ? 2 : 1;
+    const long o = (long)c0 * dv;
+    Scal csc[MR];
+    // dir = dir_best - solve(res)
+    cols_solve(dir + o, res + o, nr, rsc + c0, mu, taubar, false, false, resident, false, tsc + c0, csc);
+    *n_solves += nr;
+    for (int r = 0; r < nr; ++r) dev_axpby(ctx, dv, 1.0, tmp + o + (long)r * dv, -1.0, dir + o + (long)r * dv);
+    cols_residual(res + o, dir + o, rhs + o, nr, csc, resident, true, both);
+    cols_read_scalars();
+    ctx.sync();
+    Scal rsc2[MR];
+    double nn[MR];
+    cols_finish(nr, rs + c0, mu, taubar, resident, csc, rsc2, nn);
+    for (int i = 0; i < nr; ++i) {
+      const int r = c0 + i;
+      ++steps[r];
+      if (!(nn[i] < res_norms[r])) {   // (>= or NaN: keep the previous direction)
+        ctx.d2d(dir + (long)r * dv, tmp + (long)r * dv, (size_t)dv * d);
+        dsc[r] = tsc[r];
+        active[r] = false;
         continue;
       }
-      ck->hess_prod_slow(res + os + o, dv, dir + po, dv, MR);
-      for (int r = 0; r < MR; ++r) dev_axpby(ctx, dk, 1.0, dir + (long)r * dv + du, 1.0, res + (long)r * dv + os + o);
-    }
-    {
-      DotSpecs sp;
-      for (int r = 0; r < MR; ++r) {
-        sp.add(n, mc.d(), dir + (long)r * dv, ds + 2 * r);
-        sp.add(q, mh.d(), dir + (long)r * dv + oz, ds + 2 * r + 1);
-      }
-      dev_dots(ctx, sp);
-    }
-    if (fuse) {
-      for (int r = 0; r < MR; ++r) dev_sub_absmax(ctx, dv - oz, res + (long)r * dv + oz, rhs + (long)r * dv + oz, ds + 8 + r);   // this rank's rows
-      if (m_t.bytes < ((size_t)MR * n + 64 + 2 * (size_t)MR * comm_world_) * d) {   // (room for the tail behind the n-vectors)
-        DBuf bigger(((size_t)MR * n + 64 + 2 * (size_t)MR * comm_world_) * d);
-        ctx.d2d(bigger.p, m_t.p, (size_t)MR * n * d);
-        ctx.sync();
-        m_t = std::move(bigger);
-      }
-      FusedTail t;
-      t.nsum = MR; t.nmax = MR;
-      for (int r = 0; r < MR; ++r) { t.sum_src[r] = ds + 2 * r + 1; t.max_src[r] = ds + 8 + r; }
-      double ho[2 * MR];
-      allreduce_fused(m_t.d(), (long)MR * n, t, ho, 3);
-      for (int r = 0; r < MR; ++r) dev_axpby(ctx, n, 1.0, m_t.d() + (long)r * n, 1.0, res + (long)r * dv);
-      for (int r = 0; r < MR; ++r) dev_sub_absmax(ctx, oz, res + (long)r * dv, rhs + (long)r * dv, ds + 12 + r);                // the replicated x rows
-      ctx.d2h(ctx.h_pinned, ds, 16 * d);
-      ctx.sync();
-      for (int r = 0; r < MR; ++r) {
-        ctx.h_pinned[2 * r + 1] = ho[r];
-        const double a = ho[MR + r], b = ctx.h_pinned[12 + r];
-        ctx.h_pinned[8 + r] = (a != a || b != b) ? __builtin_nan("") : std::max(a, b);
-      }
-    } else {
-    for (int r = 0; r < MR; ++r) dev_sub_absmax(ctx, dv, res + (long)r * dv, rhs + (long)r * dv, ds + 8 + r);
-    ctx.d2h(ctx.h_pinned, ds, 16 * d);
-    ctx.sync();
-    }
-    if (dist() && !fuse) {
-      double hz[MR] = {ctx.h_pinned[1], ctx.h_pinned[3]};
-      allreduce_host(hz, MR, 0, 4);
-      ctx.h_pinned[1] = hz[0];
-      ctx.h_pinned[3] = hz[1];
-      double v[2 * MR];   // residual norms: max over the ranks, NaN flags first
-      for (int r = 0; r < MR; ++r) {
-        const double m = ctx.h_pinned[8 + r];
-        v[r] = (m != m) ? 1.0 : 0.0;
-        v[MR + r] = (m != m) ? 0.0 : m;
-      }
-      allreduce_host(v, 2 * MR, 1, 5);
-      for (int r = 0; r < MR; ++r) ctx.h_pinned[8 + r] = (v[r] > 0.5) ? __builtin_nan("") : v[MR + r];
-    }
-    for (int r = 0; r < MR; ++r) {
-      rsc[r].tau = -ctx.h_pinned[2 * r] - ctx.h_pinned[2 * r + 1] - dsc[r].kap - rs[r].tau;
-      rsc[r].kap = mu / taubar * dsc[r].tau / taubar + dsc[r].kap - rs[r].kap;
-      const double m = ctx.h_pinned[8 + r];
-      res_norms[r] = (m != m || rsc[r].tau != rsc[r].tau || rsc[r].kap != rsc[r].kap)
-                         ? __builtin_nan("")
-                         : std::max(m, std::max(std::fabs(rsc[r].tau), std::fabs(rsc[r].kap)));
-    }
-    // ---- a column that needs refinement continues alone (single-column routines)
-    Gx_dir_valid = false;
-    for (int r = 0; r < MR; ++r) {
-      if (!(res_norms[r] > res_norm_cutoff)) continue;
-      double* tmp = v_tmp.d();
-      ctx.d2d(tmp, dir + (long)r * dv, (size_t)dv * d);
-      res_norms[r] = refine(rhs + (long)r * dv, dir + (long)r * dv, res + (long)r * dv, tmp, rs[r], dsc[r], rsc[r], res_norms[r], mu, taubar,
-                            max_ref_steps, res_norm_cutoff, min_impr_tol, n_solves);
+      ctx.d2d(tmp + (long)r * dv, dir + (long)r * dv, (size_t)dv * d);
+      dsc[r] = csc[i];
+      tsc[r] = csc[i];
+      rsc[r] = rsc2[i];
+      res_norms[r] = nn[i];
+      if (res_norms[r] < res_norm_cutoff) { active[r] = false; continue; }
+      const bool cur_slow = res_norms[r] > min_impr_tol * prev_norm[r];
+      if (prev_slow[r] && cur_slow) { active[r] = false; continue; }
+      prev_norm[r] = res_norms[r];
+      prev_slow[r] = cur_slow;
     }
   }
+}
+
+// two right-hand sides already on the device (rhs2 = two Point vectors, tau / kap slots zero, scalars in rs): directions are left
+// in m_dir, their residuals in m_res, the scalars in d_sc (and, queued, in its pinned mirror)
+void SysSolver::pair_enqueue(double* rhs, const Scal* rs, double mu, double taubar, int max_ref_steps, bool with_const, bool joint_const,
+                             bool resident, Scal* dsc_host) {
+  const size_t d = sizeof(double);
+  const int dv = dimv(), it = n + p + q, ik = dv - 1;
+  HYP_REQUIRE(p == 0, "pair_solve_device: p = 0 only");
+  for (DBuf* b : {&m_dir, &m_res}) b->ensure((size_t)MR * dv * d);
+  double* dir = m_dir.d();
+  double* res = m_res.d();
+  {   // (the tau / kap slots of the work vectors stay zero: eight doubles, one launch)
+    ZeroSlots z;
+    for (int r = 0; r < MR; ++r) {
+      z.add(dir + (long)r * dv + it); z.add(dir + (long)r * dv + ik);
+      z.add(res + (long)r * dv + it); z.add(res + (long)r * dv + ik);
+    }
+    dev_zero_slots(ctx, z);
+  }
+  const bool both = (max_ref_steps > 0) && gemv_both_ok(q, n, G.d(), q);
+  cols_solve(dir, rhs, MR, rs, mu, taubar, with_const, joint_const, resident, both, nullptr, dsc_host);
+  if (max_ref_steps > 0) cols_residual(res, dir, rhs, MR, dsc_host, resident, false, both);
+  cols_read_scalars();
+}
+
+void SysSolver::pair_finish(double* rhs, const Scal* rs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
+                            double min_impr_tol, bool with_const, bool joint_const, bool resident, Scal* dsc, double* res_norms, int* n_solves) {
+  const size_t d = sizeof(double);
+  const int dv = dimv();
+  double* dir = m_dir.d();
+  double* res = m_res.d();
+  const double* hp = ctx.h_sc();
+  if (resident && (with_const || joint_const)) dot_const = hp[SC_DOTC];
+  *n_solves += MR;
+  Scal rsc[MR];
+  if (max_ref_steps <= 0) {
+    for (int r = 0; r < MR; ++r) {
+      if (resident) dsc[r] = Scal{hp[SC_DSC + 2 * r], hp[SC_DSC + 2 * r + 1]};
+      res_norms[r] = 0.0;
+    }
+    return;
+  }
+  cols_finish(MR, rs, mu, taubar, resident, dsc, rsc, res_norms);
+  Gx_dir_valid = false;
+  if (!(res_norms[0] > res_norm_cutoff) && !(res_norms[1] > res_norm_cutoff)) return;
+  bool cones_ok = true;
+  for (const Cone* ck : cones) cones_ok = cones_ok && ck->products_columnwise();
+  static const bool paired = [] { const char* e = getenv("HYP_REFINE_PAIRED"); return !(e && e[0] == '0'); }();
+  if (paired && cones_ok && !dist()) {
+    refine_cols(rhs, dir, res, rs, dsc, rsc, res_norms, mu, taubar, max_ref_steps, res_norm_cutoff, min_impr_tol, n_solves, resident);
+    return;
+  }
+  // ---- a column that needs refinement continues alone (single-column routines)
+  for (int r = 0; r < MR; ++r) {
+    if (!(res_norms[r] > res_norm_cutoff)) continue;
+    double* tmp = v_tmp.d();
+    ctx.d2d(tmp, dir + (long)r * dv, (size_t)dv * d);
+    res_norms[r] = refine(rhs + (long)r * dv, dir + (long)r * dv, res + (long)r * dv, tmp, rs[r], dsc[r], rsc[r], res_norms[r], mu, taubar,
+                          max_ref_steps, res_norm_cutoff, min_impr_tol, n_solves);
+  }
+}
+
+void SysSolver::pair_solve_device(double* rhs, const Scal* rs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
+                                  double min_impr_tol, Scal* dsc, double* res_norms, int* n_solves, bool with_const, bool joint_const) {
+  const bool resident = dirs_resident();
+  pair_enqueue(rhs, rs, mu, taubar, max_ref_steps, with_const, joint_const, resident, dsc);
+  ctx.sync();
+  pair_finish(rhs, rs, mu, taubar, max_ref_steps, res_norm_cutoff, min_impr_tol, with_const, joint_const, resident, dsc, res_norms, n_solves);
 }
 
 
 // ---- right-hand sides of the stepper on the device (steppers/common.jl:7-118) -----------------------------
 // stage 0: columns (cent, pred); stage 1: columns (centadj from dir_cent, predadj from dir_pred).  rhs2 = two
 // Point vectors on the device (tau / kap slots zero, the scalars go to rs).
+// The acceptance tests of the third-order terms (steppers/common.jl:37-55, 96-113) taken on the device (round 6): for cone
+// blockIdx.y of nc cones of dk rows each, from its four scalar products, the centering column gets dder3 and the prediction column
+// H dir + dder3 where the test passes (the host's comparison in the host's operations; the columns were zeroed before)
+__global__ void dder3_gate_kernel(int dk, const double* __restrict__ dots, double irtrtmu, double rteps, const double* __restrict__ D3c,
+                                  const double* __restrict__ Hqp, const double* __restrict__ D3p, double* __restrict__ c0, double* __restrict__ c1) {
+#pragma clang fp contract(off)
+  const int k = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= dk) return;
+  const double* dd = dots + 4 * k;
+  const long e = (long)k * dk + i;
+  {
+    const double dot1 = dd[0], dot2 = dd[1];
+    if (fabs(dot1 - dot2) / (rteps + fabs(dot2)) < 1e-4) c0[e] = D3c[e];
+  }
+  {
+    const double dot1 = dd[2], dot2 = irtrtmu * dd[3];
+    if (fabs(dot1 - dot2) / (rteps + fabs(dot2)) < 1e-4) c1[e] = Hqp[e] + D3p[e];
+  }
+}
+
 void SysSolver::build_rhs_pair(int stage, double* rhs2, const double* pt, double mu, double tau, double kap, double tau_residual,
-                               const double* dirs2, const double* dir_tau2, double* rs_flat) {
+                               const double* dirs2, const double* dir_tau2, double* rs_flat, bool resident) {
   const size_t d = sizeof(double);
   const int dv = dimv(), oz = n + p, os = n + p + q + 1;
   ctx.zero(rhs2, (size_t)MR * dv * d);
@@ -1073,6 +1286,26 @@ void SysSolver::build_rhs_pair(int stage, double* rhs2, const double* pt, double
       dev_dot(ctx, dk, scal + (long)r * q + o, Hq + (long)r * q + o, dots + 4 * k + 2 * r + 1);
     }
   }
+  const double tc = dir_tau2[0] / tau, tp = dir_tau2[1] / tau;
+  rs[0] = Scal{0.0, tc * mu / tau * tc};
+  rs[1] = Scal{0.0, tp * mu / tau * (1.0 + tp)};
+  if (resident) {   // the tests on the device: no host round trip between the two pairs of solves
+    if (wr) {       // (equal cones back to back: one launch)
+      const int dk = cones[0]->dim;
+      hipLaunchKernelGGL(dder3_gate_kernel, dim3((dk + 255) / 256, (unsigned)nc), dim3(256), 0, ctx.stream, dk, dots, irtrtmu, rteps, D3, Hq + q,
+                         D3 + q, c0 + os, c1 + os);
+    } else {
+      for (size_t k = 0; k < nc; ++k) {
+        Cone* ck = cones[k];
+        if (!ck->use_dder3()) continue;
+        const int o = offs[k], dk = ck->dim;
+        hipLaunchKernelGGL(dder3_gate_kernel, dim3((dk + 255) / 256, 1), dim3(256), 0, ctx.stream, dk, dots + 4 * k, irtrtmu, rteps, D3 + o,
+                           Hq + q + o, D3 + q + o, c0 + os + o, c1 + os + o);
+      }
+    }
+    HYP_CHECK(hipGetLastError());
+    return;
+  }
   std::vector<double> hd(4 * std::max<size_t>(nc, 1));
   ctx.d2h(hd.data(), dots, 4 * nc * d);
   ctx.sync();
@@ -1092,9 +1325,6 @@ void SysSolver::build_rhs_pair(int stage, double* rhs2, const double* pt, double
       }
     }
   }
-  const double tc = dir_tau2[0] / tau, tp = dir_tau2[1] / tau;
-  rs[0] = Scal{0.0, tc * mu / tau * tc};
-  rs[1] = Scal{0.0, tp * mu / tau * (1.0 + tp)};
 }
 
 void SysSolver::step_directions(const double* h_point, const double* h_res, double tau_residual, double mu, int max_ref_steps,
@@ -1123,45 +1353,123 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   ctx.h2d(s_point.p, hs_point, (size_t)dv * d);
   ctx.h2d(s_resid.p, hs_res, (size_t)it * d);
   const auto t0 = std::chrono::steady_clock::now();
-  if (nmp > 0) update_lhs_fact(info, used_fallback);                 // combined.jl:64
-  if (use_sqrt_out)
-    for (size_t k = 0; k < cones.size(); ++k) use_sqrt_out[k] = use_sqrt[k];
-  if (*info != 0) { ctx.sync(); return; }
-  // The constant column of update_lhs (qrchol.jl:191-197: rhs_const = (-c, H h), one solve_subsystem3 per iteration) rides along
-  // as a THIRD column of the first paired solve: its right-hand side, both passes over G, the cone products and the triangular
-  // solves come out of the pair's launches (two passes over G, ~70 launches and a host synchronisation fewer per iteration).
-  // Every column of every kernel on that path is computed with exactly the sums it gets when computed alone (the multi-column
-  // G x kernel has the one-column kernel's four partial sums since round 3 -- that was the one kernel that differed, and the
-  // reason this was off until then: tools/diag_const3.py), so the iterates are bitwise those of the separate solve
-  // (tests/test_hip_switches.py).  Not with a Bunch-Kaufman factor (gather / scatter of two columns) and only for cones whose
-  // multi-column products are column-wise the one-column ones.  HYP_CONST_COL3=0: off.
-  static const bool const3_env = [] { const char* e = getenv("HYP_CONST_COL3"); return !(e && e[0] == '0'); }();
-  bool cones_ok = true;   // (see Cone::products_columnwise; config 5's WSOS cone: with the switch forced on, 0.48 instead of 0.13
-                          //  Bunch-Kaufman fall-backs per iteration and 10.3 instead of 6.6 ms in the directions)
-  for (const Cone* ck : cones) cones_ok = cones_ok && ck->products_columnwise();
-  const bool const3 = const3_env && !use_bk && cones_ok;
-  // With HYP_CONST_COL3=0: the constant column keeps its own right-hand side, its own passes over G and cone products (the numbers of
-  // update_const()), but its two triangular solves -- 60 launches of ~5 us -- ride along with the first pair's as a third column
-  // of the same launches (coldot3: per column the very sums of the separate kernels).  HYP_CONST_TRI3=0: solved on its own first.
-  static const bool tri3 = [] { const char* e = getenv("HYP_CONST_TRI3"); return !(e && e[0] == '0'); }();
-  const bool joint = !const3 && tri3 && !dist() && !use_bk && nmp > 0 && tri.ready(nmp) && tri.sb > 0 && tri.sb <= 1024;
-  if (!const3 && !joint) {
-    update_const();
-    if (h_sol_const) ctx.d2h(hs_const, sol_const.p, (size_t)it * d);   // (host mirror of sys.sol_const)
-  }
-  if (joint) update_const_pre();
-  last_update_lhs_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   const double tau = h_point[it], kap = h_point[ik];
   m_rhs.ensure((size_t)(MR + 1) * dv * d);   // (+ the constant column of the first pair)
-  v_tmp.ensure((size_t)MR * dv * d);   // (also the keeper of dir_cent / dir_pred between the two pairs: v_res below)
+  v_tmp.ensure((size_t)MR * dv * d);
+  // Round 6 (HYP_DIR_RESIDENT, default on): the factorization's info word is NOT waited for.  The first pair of solves -- right-hand
+  // sides, constant column, both passes, residuals -- is queued behind the Cholesky as if it had succeeded (it almost always has);
+  // the host reads info together with that pair's scalars.  Behind a failed Cholesky the pair's numbers are discarded, the fall-back
+  // chain runs and the call continues the way it always did.
+  const bool resident = dirs_resident() && nmp > 0 && !getenv_on("HYP_FORCE_BK") && !getenv_on("HYP_FORCE_FACT_FAIL");
+  if (!resident) {
+    if (nmp > 0) update_lhs_fact(info, used_fallback);                 // combined.jl:64
+    if (use_sqrt_out)
+      for (size_t k = 0; k < cones.size(); ++k) use_sqrt_out[k] = use_sqrt[k];
+    if (*info != 0) { ctx.sync(); return; }
+    step_directions_rest(false, tau, kap, tau_residual, mu, max_ref_steps, res_norm_cutoff, min_impr_tol, h_dirs, res_norms, n_solves,
+                         h_sol_const, hs_const, hs_dirs, false, nullptr, nullptr);
+    last_update_lhs_s = last_rest_update_lhs_s + std::chrono::duration<double>(t_rest0 - t0).count();
+    return;
+  }
+  assemble_lhs();
+  factor_lhs_begin();
+  if (use_sqrt_out)
+    for (size_t k = 0; k < cones.size(); ++k) use_sqrt_out[k] = use_sqrt[k];
+  bool cones_ok = true;
+  for (const Cone* ck : cones) cones_ok = cones_ok && ck->products_columnwise();
+  const bool const3 = const3_on() && cones_ok;
+  const bool joint = !const3 && tri3_on() && tri.ready(nmp) && tri.sb > 0 && tri.sb <= 1024;
+  if (!const3 && !joint) {
+    update_const();   // (synchronises: models without a solve plan -- small ones)
+    if (h_sol_const) ctx.d2h(hs_const, sol_const.p, (size_t)it * d);
+  }
+  if (joint) update_const_pre();
+  HYP_CHECK(hipEventRecord(ctx.ev[5], ctx.stream));   // (end of the update_lhs part: timed on the device, the host does not wait here)
   Scal rs[MR], dsc[MR];
   double rn[MR];
   int ns = 0;
-  // (cent, pred)
-  build_rhs_pair(0, m_rhs.d(), s_point.d(), mu, tau, kap, tau_residual, nullptr, nullptr, reinterpret_cast<double*>(rs));
-  pair_solve_device(m_rhs.d(), rs, mu, tau, max_ref_steps, res_norm_cutoff, min_impr_tol, dsc, rn, &ns, const3, joint);
+  build_rhs_pair(0, m_rhs.d(), s_point.d(), mu, tau, kap, tau_residual, nullptr, nullptr, reinterpret_cast<double*>(rs), true);
+  pair_enqueue(m_rhs.d(), rs, mu, tau, max_ref_steps, const3, joint, true, dsc);
+  ctx.sync();
+  const auto tf0 = std::chrono::steady_clock::now();
+  factor_lhs_end(info, used_fallback);
+  const double fallback_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count();
+  {
+    float ms = 0;
+    HYP_CHECK(hipEventElapsedTime(&ms, ctx.ev[0], ctx.ev[5]));
+    last_update_lhs_s = 1e-3 * ms;
+  }
+  if (*info != 0) return;
+  if (use_bk) {   // the Cholesky failed, a fall-back factorization stands: everything queued behind the attempt is void
+    const double dev_s = last_update_lhs_s;
+    step_directions_rest(false, tau, kap, tau_residual, mu, max_ref_steps, res_norm_cutoff, min_impr_tol, h_dirs, res_norms, n_solves,
+                         h_sol_const, hs_const, hs_dirs, false, nullptr, nullptr);
+    last_update_lhs_s = dev_s + fallback_s + last_rest_update_lhs_s;
+    return;
+  }
+  pair_finish(m_rhs.d(), rs, mu, tau, max_ref_steps, res_norm_cutoff, min_impr_tol, const3, joint, true, dsc, rn, &ns);
   if ((const3 || joint) && h_sol_const) ctx.d2h(hs_const, sol_const.p, (size_t)it * d);   // (host mirror of sys.sol_const)
   *n_solves += ns;
+  step_directions_rest(true, tau, kap, tau_residual, mu, max_ref_steps, res_norm_cutoff, min_impr_tol, h_dirs, res_norms, n_solves, h_sol_const,
+                       hs_const, hs_dirs, true, dsc, rn);
+}
+
+static bool env_default_on(const char* name) {
+  const char* e = getenv(name);
+  return !(e && e[0] == '0');
+}
+bool SysSolver::const3_on() { static const bool on = env_default_on("HYP_CONST_COL3"); return on; }
+bool SysSolver::tri3_on() { static const bool on = env_default_on("HYP_CONST_TRI3"); return on; }
+bool SysSolver::getenv_on(const char* name) {
+  const char* e = getenv(name);
+  return e && e[0] && e[0] != '0';
+}
+
+// the part of step_directions behind a standing factorization (first_pair_done: the resident form has solved the first pair already)
+void SysSolver::step_directions_rest(bool resident, double tau, double kap, double tau_residual, double mu, int max_ref_steps,
+                                     double res_norm_cutoff, double min_impr_tol, double* h_dirs, double* res_norms, int* n_solves,
+                                     double* h_sol_const, double* hs_const, double* hs_dirs, bool first_pair_done, Scal* d01_in, double* rn01) {
+  const size_t d = sizeof(double);
+  const int dv = dimv(), it = n + p + q, ik = dv - 1;
+  t_rest0 = std::chrono::steady_clock::now();
+  last_rest_update_lhs_s = 0.0;
+  Scal rs[MR], dsc[MR];
+  double rn[MR];
+  int ns = 0;
+  if (!first_pair_done) {
+    // The constant column of update_lhs (qrchol.jl:191-197: rhs_const = (-c, H h), one solve_subsystem3 per iteration) rides along
+    // as a THIRD column of the first paired solve: its right-hand side, both passes over G, the cone products and the triangular
+    // solves come out of the pair's launches (two passes over G, ~70 launches and a host synchronisation fewer per iteration).
+    // Every column of every kernel on that path is computed with exactly the sums it gets when computed alone (the multi-column
+    // G x kernel has the one-column kernel's four partial sums since round 3 -- that was the one kernel that differed, and the
+    // reason this was off until then: tools/diag_const3.py), so the iterates are bitwise those of the separate solve
+    // (tests/test_hip_switches.py).  Not with a Bunch-Kaufman factor (gather / scatter of two columns) and only for cones whose
+    // multi-column products are column-wise the one-column ones.  HYP_CONST_COL3=0: off.
+    bool cones_ok = true;   // (see Cone::products_columnwise; config 5's WSOS cone: with the switch forced on, 0.48 instead of 0.13
+                            //  Bunch-Kaufman fall-backs per iteration and 10.3 instead of 6.6 ms in the directions)
+    for (const Cone* ck : cones) cones_ok = cones_ok && ck->products_columnwise();
+    const bool const3 = const3_on() && !use_bk && cones_ok;
+    // With HYP_CONST_COL3=0: the constant column keeps its own right-hand side, its own passes over G and cone products (the numbers of
+    // update_const()), but its two triangular solves -- 60 launches of ~5 us -- ride along with the first pair's as a third column
+    // of the same launches (coldot3: per column the very sums of the separate kernels).  HYP_CONST_TRI3=0: solved on its own first.
+    const bool joint = !const3 && tri3_on() && !dist() && !use_bk && nmp > 0 && tri.ready(nmp) && tri.sb > 0 && tri.sb <= 1024;
+    if (!const3 && !joint) {
+      update_const();
+      if (h_sol_const) ctx.d2h(hs_const, sol_const.p, (size_t)it * d);   // (host mirror of sys.sol_const)
+    }
+    if (joint) update_const_pre();
+    last_rest_update_lhs_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_rest0).count();
+    // (cent, pred)
+    build_rhs_pair(0, m_rhs.d(), s_point.d(), mu, tau, kap, tau_residual, nullptr, nullptr, reinterpret_cast<double*>(rs), resident);
+    pair_enqueue(m_rhs.d(), rs, mu, tau, max_ref_steps, const3, joint, resident, dsc);
+    ctx.sync();
+    pair_finish(m_rhs.d(), rs, mu, tau, max_ref_steps, res_norm_cutoff, min_impr_tol, const3, joint, resident, dsc, rn, &ns);
+    if ((const3 || joint) && h_sol_const) ctx.d2h(hs_const, sol_const.p, (size_t)it * d);   // (host mirror of sys.sol_const)
+    *n_solves += ns;
+  } else {
+    dsc[0] = d01_in[0]; dsc[1] = d01_in[1];
+    rn[0] = rn01[0]; rn[1] = rn01[1];
+  }
   res_norms[0] = rn[0];
   res_norms[1] = rn[1];
   ctx.d2h(hs_dirs, m_dir.d(), (size_t)MR * dv * d);
@@ -1170,13 +1478,20 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   const double dtau[MR] = {dsc[0].tau, dsc[1].tau};
   const Scal d01[MR] = {dsc[0], dsc[1]};
   // (centadj, predadj)
-  build_rhs_pair(1, m_rhs.d(), s_point.d(), mu, tau, kap, tau_residual, s_dirs.d(), dtau, reinterpret_cast<double*>(rs));
+  build_rhs_pair(1, m_rhs.d(), s_point.d(), mu, tau, kap, tau_residual, s_dirs.d(), dtau, reinterpret_cast<double*>(rs), resident);
   ns = 0;
-  pair_solve_device(m_rhs.d(), rs, mu, tau, max_ref_steps, res_norm_cutoff, min_impr_tol, dsc, rn, &ns);
+  pair_enqueue(m_rhs.d(), rs, mu, tau, max_ref_steps, false, false, resident, dsc);
+  // (the raw directions travel to the host under the same synchronisation; a refined column is copied again below)
+  ctx.d2h(hs_dirs + (long)MR * dv, m_dir.d(), (size_t)MR * dv * d);
+  ctx.sync();
+  const int ns_before = ns;
+  pair_finish(m_rhs.d(), rs, mu, tau, max_ref_steps, res_norm_cutoff, min_impr_tol, false, false, resident, dsc, rn, &ns);
   *n_solves += ns;
   res_norms[2] = rn[0];
   res_norms[3] = rn[1];
-  ctx.d2h(hs_dirs + (long)MR * dv, m_dir.d(), (size_t)MR * dv * d);
+  if (ns > ns_before + MR) {   // refinement moved a direction of the second pair
+    ctx.d2h(hs_dirs + (long)MR * dv, m_dir.d(), (size_t)MR * dv * d);
+  }
   ctx.d2d(s_dirs.d() + (long)MR * dv, m_dir.p, (size_t)MR * dv * d);
   ctx.sync();
   std::memcpy(h_dirs, hs_dirs, (size_t)2 * MR * dv * d);

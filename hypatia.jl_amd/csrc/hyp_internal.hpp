@@ -123,8 +123,11 @@ struct Ctx {
     return third < trsv_sb ? third : trsv_sb;
   }
   int* h_info = nullptr;    // pinned host word(s)
+  static constexpr int H_INFO_FACT = 8192;   // the system solver's factorization info (read back asynchronously: nobody else's slot)
   double* h_pinned = nullptr;   // pinned host staging (small vectors / scalars)
   size_t h_pinned_n = 0;
+  static constexpr int H_SC_N = 128;         // pinned mirror of the direction solves' device scalars (SysSolver::d_sc), behind the general staging
+  double* h_sc() const { return h_pinned + h_pinned_n; }
   double* h_stage = nullptr;    // growable pinned staging for large caller-owned vectors (see stage_host)
   size_t h_stage_n = 0;
   double* stage_host(size_t n_doubles);

@@ -679,30 +679,42 @@ void SysSolver::assemble_lhs() {
   allreduce_lhs();   // the one large exchange: sum of the ranks' Schur contributions (cones or K panels)
 }
 
-void SysSolver::factor_lhs(int* info, int* used_fallback) {   // qrchol.jl:249-250
+static bool force_bk_env() {
+  const char* fb = getenv("HYP_FORCE_BK");
+  return fb && fb[0] && fb[0] != '0';
+}
+
+// posdef_fact_copy! (dense.jl:194-215) in two halves.  begin: the Cholesky attempt, the read-back of its info word and the solve
+// plan of the (almost always successful) factor are QUEUED; nothing waits.  end (after the caller's synchronisation): info is
+// read, and behind a failed Cholesky the fall-back chain runs.  factor_lhs() is begin + synchronise + end; step_directions
+// (round 6) puts the first pair of direction solves between the two, so that the host learns info together with that pair's
+// scalars instead of stopping the device for a round trip of its own.
+void SysSolver::factor_lhs_begin() {
+  if (nmp == 0 || force_bk_env()) return;
+  use_bk = false;
+  ctx.d2d(lhs_fact.p, lhs.p, (size_t)nmp * nmp * sizeof(double));
+  HYP_CHECK(hipEventRecord(ctx.ev[3], ctx.stream));
+  potrf_upper_batched(ctx, nmp, lhs_fact.d(), nmp, 0, 1, dinv.d(), d_info.i());
+  HYP_CHECK(hipEventRecord(ctx.ev[4], ctx.stream));
+  ctx.d2h(ctx.h_info + Ctx::H_INFO_FACT, d_info.p, sizeof(int));
+  // the solve plan is queued BEFORE the host learns info: reading info first left the device idle for the round trip (~0.2 ms
+  // per iteration, profiles/r02_iteration_timeline.txt); after a failed Cholesky the plan's kernels ran on meaningless numbers
+  // and the plan is discarded in factor_lhs_end
+  tri.invalidate();
+  if (ctx.trsv_plan_sb(nmp) > 0) tri.build(ctx, nmp, lhs_fact.d(), nmp, dinv.d());
+}
+
+void SysSolver::factor_lhs_end(int* info, int* used_fallback) {
   *info = 0;
   *used_fallback = 0;
   if (nmp == 0) return;
-  // posdef_fact_copy! (dense.jl:194-215): Cholesky; on failure Bunch-Kaufman with rook pivoting (symm_fact!,
-  // dense.jl:164-165); if that finds an exactly singular pivot, increase_diag! (dense.jl:106-113) and Bunch-Kaufman
-  // again.  used_fallback: 0 Cholesky, 1 Bunch-Kaufman, 2 diagonal shift + Bunch-Kaufman.
-  // HYP_FORCE_BK=1 (tests) treats the Cholesky as failed.
-  const char* fb = getenv("HYP_FORCE_BK");
-  const bool force_bk = fb && fb[0] && fb[0] != '0';
+  // Cholesky; on failure Bunch-Kaufman with rook pivoting (symm_fact!, dense.jl:164-165); if that finds an exactly singular
+  // pivot, increase_diag! (dense.jl:106-113) and Bunch-Kaufman again.  used_fallback: 0 Cholesky, 1 Bunch-Kaufman, 2 diagonal
+  // shift + Bunch-Kaufman.  HYP_FORCE_BK=1 (tests) treats the Cholesky as failed.
+  const bool force_bk = force_bk_env();
   use_bk = false;
   if (!force_bk) {
-    ctx.d2d(lhs_fact.p, lhs.p, (size_t)nmp * nmp * sizeof(double));
-    HYP_CHECK(hipEventRecord(ctx.ev[3], ctx.stream));
-    potrf_upper_batched(ctx, nmp, lhs_fact.d(), nmp, 0, 1, dinv.d(), d_info.i());
-    HYP_CHECK(hipEventRecord(ctx.ev[4], ctx.stream));
-    ctx.d2h(ctx.h_info, d_info.p, sizeof(int));
-    // the solve plan of the (almost always successful) factorization is queued BEFORE the host learns info: reading info
-    // first left the device idle for the round trip (~0.2 ms per iteration, profiles/r02_iteration_timeline.txt); after a
-    // failed Cholesky the plan's kernels ran on meaningless numbers and the plan is discarded below
-    tri.invalidate();
-    if (ctx.trsv_plan_sb(nmp) > 0) tri.build(ctx, nmp, lhs_fact.d(), nmp, dinv.d());
-    ctx.sync();
-    *info = ctx.h_info[0];
+    *info = ctx.h_info[Ctx::H_INFO_FACT];
     float ms = 0;
     HYP_CHECK(hipEventElapsedTime(&ms, ctx.ev[0], ctx.ev[1])); ctx.kstat[0] += ms;
     HYP_CHECK(hipEventElapsedTime(&ms, ctx.ev[1], ctx.ev[2])); ctx.kstat[1] += ms;
@@ -729,6 +741,15 @@ void SysSolver::factor_lhs(int* info, int* used_fallback) {   // qrchol.jl:249-2
   fact_ok = (*info == 0);
   if (use_bk || !fact_ok) tri.invalidate();
   if (fact_ok && !tri.ready(nmp) && ctx.trsv_plan_sb(nmp) > 0) tri.build(ctx, nmp, lhs_fact.d(), nmp, dinv.d());
+}
+
+void SysSolver::factor_lhs(int* info, int* used_fallback) {   // qrchol.jl:249-250
+  *info = 0;
+  *used_fallback = 0;
+  if (nmp == 0) return;
+  factor_lhs_begin();
+  if (!force_bk_env()) ctx.sync();
+  factor_lhs_end(info, used_fallback);
 }
 
 // x <- lhs^-1 x.  Cholesky: U'^-1 then U^-1.  Bunch-Kaufman: the same two sweeps with the unit factor, between a

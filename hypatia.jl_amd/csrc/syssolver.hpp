@@ -1,5 +1,6 @@
 // Device-resident QRCholDenseSystemSolver (/root/reference/src/Solvers/systemsolvers/qrchol.jl:104-257).
 #pragma once
+#include <chrono>
 #include "cones.hpp"
 
 namespace hyp {
@@ -55,6 +56,8 @@ struct SysSolver {
   void update_lhs_fact(int* info, int* used_fallback);                         // qrchol.jl:201-257
   void assemble_lhs();                                                         //   :214-246 (Schur sum over this process's cones)
   void factor_lhs(int* info, int* used_fallback);                              //   :249-250
+  void factor_lhs_begin();                                                     //   ... queued: Cholesky attempt, info read-back, solve plan
+  void factor_lhs_end(int* info, int* used_fallback);                          //   ... after a synchronisation: info, fall-back chain
   void tri_solves(double* d_x);                                                // both triangular solves of the potrs
   void potrs(double* d_x);                                                     // x <- lhs^-1 x with the current factor (:66-69)
   void solve3(double* d_sol, const double* d_rhs);                             // qrchol.jl:39-85
@@ -202,12 +205,46 @@ struct SysSolver {
   DBuf s_point, s_resid, s_dots, s_dirs;
   double last_update_lhs_s = 0.0;   // wall seconds of the update_lhs part of the last step_directions call
   void build_rhs_pair(int stage, double* rhs2, const double* d_point, double mu, double tau, double kap, double tau_residual,
-                      const double* d_dirs2, const double* dir_tau2, double* rs_flat /* 2 x (tau, kap) */);
+                      const double* d_dirs2, const double* dir_tau2, double* rs_flat /* 2 x (tau, kap) */, bool resident = false);
   void step_directions(const double* h_point, const double* h_res, double tau_residual, double mu, int max_ref_steps,
                        double res_norm_cutoff, double min_impr_tol, double* h_dirs, double* res_norms, int* n_solves, int* use_sqrt_out,
                        int* info, int* used_fallback, double* h_sol_const);
   void pair_solve_device(double* rhs2, const Scal* rs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
                          double min_impr_tol, Scal* dsc, double* res_norms, int* n_solves, bool with_const = false, bool joint_const = false);
+  // Round 6: the same in pieces whose scalars may stay ON THE DEVICE (resident = true): the tau / kap of a solve are formed by a
+  // one-thread kernel from the scalar products (the host's operations in the host's order) and read by the kernels behind it from
+  // device memory, so that a paired solve with its residual is queued without a single host round trip; the host reads the
+  // scalar block once per pair (pair_finish), decides about refinement, and refines with the SAME column routines (one
+  // round trip per refinement step; two columns that both need a step share its passes over G and the factor).
+  // d_sc: [0, 6) solve dots (c'x, h'z per column), [8, 12) residual dots, [12, 14) residual maxima, [16, 20) tau / kap of the
+  // direction per column, [20] dot_const, [24, 28) tau / kap of the last solve_system per column; mirrored to ctx.h_sc().
+  DBuf d_sc;
+  enum { SC_SOLVE = 0, SC_RESD = 8, SC_AMAX = 12, SC_DSC = 16, SC_DOTC = 20, SC_CSC = 24, SC_N = 32 };
+  bool dirs_resident() const;   // HYP_DIR_RESIDENT (default on): single process, p = 0
+  // solve_system (common.jl:129-182) for nr columns: rhs -> sol (Point layout, columns dimv() apart); base != null: the
+  // direction's scalars become base - (the solve's) (a refinement step's correction), else the solve's own
+  void cols_solve(double* sol, const double* rhs, int nr, const Scal* rs, double mu, double taubar, bool with_const, bool joint_const,
+                  bool resident, bool both, const Scal* base, Scal* dsc_host);
+  // apply_lhs (common.jl:79-121) of nr directions minus their right-hand sides; scalar products and maxima left in d_sc.
+  // fresh: G dir.x / G' dir.z are formed here (else they are the ones cols_solve left in m_Gxd / m_t)
+  void cols_residual(double* res, const double* dir, const double* rhs, int nr, const Scal* dsc_host, bool resident, bool fresh, bool both);
+  void cols_read_scalars();   // queue the copy of d_sc to its pinned mirror
+  // the host's part behind a synchronisation: scalars of the nr directions and residuals out of the mirror
+  void cols_finish(int nr, const Scal* rs, double mu, double taubar, bool resident, Scal* dsc, Scal* rsc, double* res_norms);
+  void refine_cols(double* rhs, double* dir, double* res, const Scal* rs, Scal* dsc, Scal* rsc, double* res_norms, double mu, double taubar,
+                   int max_ref_steps, double res_norm_cutoff, double min_impr_tol, int* n_solves, bool resident);
+  void pair_enqueue(double* rhs2, const Scal* rs, double mu, double taubar, int max_ref_steps, bool with_const, bool joint_const,
+                    bool resident, Scal* dsc_host);
+  void pair_finish(double* rhs2, const Scal* rs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff, double min_impr_tol,
+                   bool with_const, bool joint_const, bool resident, Scal* dsc, double* res_norms, int* n_solves);
+  static bool const3_on();    // HYP_CONST_COL3 (default on)
+  static bool tri3_on();      // HYP_CONST_TRI3 (default on)
+  static bool getenv_on(const char* name);
+  std::chrono::steady_clock::time_point t_rest0;
+  double last_rest_update_lhs_s = 0.0;
+  void step_directions_rest(bool resident, double tau, double kap, double tau_residual, double mu, int max_ref_steps, double res_norm_cutoff,
+                            double min_impr_tol, double* h_dirs, double* res_norms, int* n_solves, double* h_sol_const, double* hs_const,
+                            double* hs_dirs, bool first_pair_done, Scal* d01, double* rn01);
   // returns res_norm; dir / rhs are HOST Point vectors (common.jl:15-76)
   double get_directions(double* h_dir, const double* h_rhs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
                         double min_impr_tol, int* n_solves);

@@ -236,3 +236,36 @@ def test_wsos_candidate_screen_changes_no_bit(name):
     assert off["screens"] == [0, 0]
     for r in (on, wide, chk):
         assert r["screens"][0] > 0 and r["screens"][1] > 0   # (it ran, and it rejected something)
+
+
+@pytest.mark.parametrize("name", ["psd_plan", "psd_smoke", "psd_pair", "psd_run", "matrixcompletion", "polymin_large_primal", "polymin_large_dual"])
+def test_device_resident_direction_scalars_change_no_bit(name):
+    """round 6, HYP_DIR_RESIDENT (default on; csrc/directions_multi.hip): the tau / kap of every solve of step_directions are formed
+    on the device by a one-thread kernel (the host's operations in the host's order) and read from device memory by the kernels
+    behind it; the acceptance tests of the third-order terms (steppers/common.jl:37-55, 96-113) are taken on the device; the
+    Cholesky's info word is read together with the first pair's scalars instead of being waited for.  With the switch off the
+    same kernels run with host scalars and a host round trip at each of those points: every iterate must agree to the last bit
+    -- PSD models with and without a solve plan (paired refinement), a run of equal cones, a spectral cone and a WSOS cone in both
+    forms (Bunch-Kaufman fall-backs behind the optimistic Cholesky read)"""
+    on = _run(name, {"HYP_DIR_RESIDENT": "1"})
+    off = _run(name, {"HYP_DIR_RESIDENT": "0"})
+    assert on["status"] == off["status"] == "Optimal"
+    assert on["iters"] == off["iters"] >= 6
+    assert on["trace"] == off["trace"], name
+    assert on["trials"] == off["trials"]
+
+
+@pytest.mark.parametrize("name", ["psd_plan", "psd_pair", "psd_run"])
+def test_paired_refinement_solves_the_same_problem(name):
+    """round 6, HYP_REFINE_PAIRED (default on): the refinement steps of get_directions (common.jl:38-72) of the two columns of a pair
+    through the pair's own column routines -- two columns that both need a step share its passes over G and the factor, a step
+    costs one host round trip -- instead of one column after the other through the single-column routines.  The products of a
+    refined direction's residual are formed in one pass over G (another summation order than the two one-sided passes), so the
+    iterates agree to rounding, not bitwise: same status and iteration count, the objective trace to 1e-9"""
+    on = _run(name, {"HYP_REFINE_PAIRED": "1"})
+    off = _run(name, {"HYP_REFINE_PAIRED": "0"})
+    assert on["status"] == off["status"] == "Optimal"
+    assert abs(on["iters"] - off["iters"]) <= 1
+    assert abs(on["obj"] - off["obj"]) <= 1e-9 * (1 + abs(off["obj"]))
+    for a, b in list(zip(on["trace"], off["trace"]))[: min(on["iters"], off["iters"]) // 2]:
+        assert abs(a[0] - b[0]) <= 1e-8 * (1 + abs(b[0]))

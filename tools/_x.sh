@@ -1,4 +1,7 @@
-# scratch batch (rewritten per call): a quick sanity run
+# scratch batch (rewritten per call)
 export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python bench.py --steps 60 --cpu-iters 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],2), d['unit'], round(d['ms_per_step'],3), 'ms, frac', round(d['roofline']['frac'],3))"
+timeout 1500 python -m pytest tests/test_hip_switches.py -q -x -k "resident or paired_refinement or constant_column" 2>&1 | tail -15
+for v in 1 0 1 0; do HYP_DIR_RESIDENT=$v python bench.py --steps 100 --cpu-iters 0 2>/dev/null | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('resident=$v', round(d['ms_per_step'],3), 'ms frac', round(d['roofline']['frac'],3), d['phases_ms_per_step'], d.get('ms_per_kkt_solve'), d.get('kkt_solves_per_step'))"; done
