@@ -13,6 +13,7 @@ from . import polyutils as pu
 from . import arrayutil as au
 
 RT2 = np.sqrt(2.0)
+EPS = float(np.finfo(np.float64).eps)
 RT3 = np.sqrt(3.0)
 TEST_TOL = float(np.sqrt(np.sqrt(np.finfo(np.float64).eps)))   # test_tol(T), nativeinstances.jl:29
 
@@ -649,6 +650,91 @@ def polymin(nvars, halfdeg, use_primal, seed=1, keep=None):
                 [("wsosinterpnonnegative", U, Ps, False)], dict(status="Optimal"))
     return (vals, np.ones((1, U)), np.array([1.0]), -np.eye(U), np.zeros(U),
             [("wsosinterpnonnegative", U, Ps, True)], dict(status="Optimal"))
+
+
+# ---- predefined polynomials with known minima over boxes: examples/polymin/data_real.jl:36-152 (real_poly_data).  Each entry:
+# (number of variables, f on the columns of a point matrix, box lower bounds, box upper bounds, true_obj, line range of its branch).
+# The domains are NOT the unit box (butcher, caprasse, goldsteinprice, heart, lotkavolterra, reactiondiffusion, rosenbrock,
+# schwefel): they exercise the shifted / scaled interpolation of interp_box (src/PolyUtils/realinterp.jl:84-106).  The ball and
+# ellipsoid variants of the same file are not restated.
+def _goldsteinprice(x):
+    return ((1 + (x[0] + x[1] + 1) ** 2 * (19 - 14 * x[0] + 3 * x[0] ** 2 - 14 * x[1] + 6 * x[0] * x[1] + 3 * x[1] ** 2))
+            * (30 + (2 * x[0] - 3 * x[1]) ** 2 * (18 - 32 * x[0] + 12 * x[0] ** 2 + 48 * x[1] - 36 * x[0] * x[1] + 27 * x[1] ** 2)))
+
+
+REAL_POLY = {
+    "butcher": (6, lambda x: x[5] * x[1] ** 2 + x[4] * x[2] ** 2 - x[0] * x[3] ** 2 + x[3] ** 3 + x[3] ** 2 - 1 / 3 * x[0] + 4 / 3 * x[3],
+                [-1, -0.1, -0.1, -1, -0.1, -0.1], [0, 0.9, 0.5, -0.1, -0.05, -0.03], -1.4393333333, "38-43"),
+    "caprasse": (4, lambda x: (-x[0] * x[2] ** 3 + 4 * x[1] * x[2] ** 2 * x[3] + 4 * x[0] * x[2] * x[3] ** 2 + 2 * x[1] * x[3] ** 3
+                               + 4 * x[0] * x[2] + 4 * x[2] ** 2 - 10 * x[1] * x[3] - 10 * x[3] ** 2 + 2),
+                 [-0.5] * 4, [0.5] * 4, -3.1800966258, "44-49"),
+    "goldsteinprice": (2, _goldsteinprice, [-2] * 2, [2] * 2, 3.0, "50-55"),
+    "heart": (8, lambda x: (x[0] * x[5] ** 3 - 3 * x[0] * x[5] * x[6] ** 2 + x[2] * x[6] ** 3 - 3 * x[2] * x[6] * x[5] ** 2 + x[1] * x[4] ** 3
+                            - 3 * x[1] * x[4] * x[7] ** 2 + x[3] * x[7] ** 3 - 3 * x[3] * x[7] * x[4] ** 2 + 0.9563453),
+              [-0.1, 0.4, -0.7, -0.7, 0.1, -0.1, -0.3, -1.1], [0.4, 1, -0.4, 0.4, 0.2, 0.2, 1.1, -0.3], -1.36775, "70-76"),
+    "lotkavolterra": (4, lambda x: x[0] * (x[1] ** 2 + x[2] ** 2 + x[3] ** 2 - 1.1) + 1, [-2] * 4, [2] * 4, -20.8, "77-81"),
+    "magnetism7": (7, lambda x: (x[0] ** 2 + 2 * x[1] ** 2 + 2 * x[2] ** 2 + 2 * x[3] ** 2 + 2 * x[4] ** 2 + 2 * x[5] ** 2 + 2 * x[6] ** 2 - x[0]),
+                   [-1] * 7, [1] * 7, -0.25, "82-86"),
+    "motzkin": (2, lambda x: 1 - 48 * x[0] ** 2 * x[1] ** 2 + 64 * x[0] ** 2 * x[1] ** 4 + 64 * x[0] ** 4 * x[1] ** 2, [-1] * 2, [1] * 2, 0.0, "92-96"),
+    "reactiondiffusion": (3, lambda x: -x[0] + 2 * x[1] - x[2] - 0.835634534 * x[1] * (1 + x[1]), [-5] * 3, [5] * 3, -36.71269068, "110-114"),
+    "robinson": (2, lambda x: (1 + x[0] ** 6 + x[1] ** 6 - x[0] ** 4 * x[1] ** 2 + x[0] ** 4 - x[0] ** 2 * x[1] ** 4 + x[1] ** 4 - x[0] ** 2
+                               + x[1] ** 2 + 3 * x[0] ** 2 * x[1] ** 2), [-1] * 2, [1] * 2, 0.814814, "115-120"),
+    "rosenbrock": (2, lambda x: (1 - x[0]) ** 2 + 100 * (x[0] ** 2 - x[1]) ** 2, [-5] * 2, [10] * 2, 0.0, "127-131"),
+    "schwefel": (3, lambda x: (x[0] - x[1] ** 2) ** 2 + (x[1] - 1) ** 2 + (x[0] - x[2] ** 2) ** 2 + (x[2] - 1) ** 2, [-10] * 3, [10] * 3, 0.0, "137-141"),
+}
+
+# the box-domain members of examples/polymin/native_test.jl's "minimal" and "fast" lists: (name, halfdeg, use_primal, use_wsos)
+REAL_POLY_INSTANCES = [
+    ("butcher", 2, True, True), ("caprasse", 4, True, True), ("goldsteinprice", 7, True, True), ("heart", 2, True, True),
+    ("lotkavolterra", 3, True, True), ("magnetism7", 2, True, True), ("motzkin", 3, True, True), ("reactiondiffusion", 4, True, True),
+    ("robinson", 8, True, True), ("rosenbrock", 5, True, True), ("schwefel", 2, True, True),
+    ("lotkavolterra", 3, False, True), ("motzkin", 3, False, True), ("schwefel", 2, False, True),
+    ("lotkavolterra", 3, False, False), ("motzkin", 3, False, False),
+]
+
+
+def polymin_named(name, halfdeg, use_primal, use_wsos=True, seed=1):
+    """examples/polymin/native.jl:26-34 (a predefined polynomial: get_interp_data, data_real.jl:10-20) and :56-112 (build_real: the
+    WSOS formulation in primal or dual form, and the dual PSD formulation with one PosSemidefTri / Nonnegative block per basis
+    matrix).  expect: Optimal and primal_obj = +-true_obj at the example's own tolerance eps^0.1 (native.jl:136-144).  Boxes in 7
+    or more variables take the sampling branch of interpolate (realinterp.jl:23-25): the candidates come from numpy's generator
+    instead of Julia's -- the optimum does not depend on the points."""
+    nv, fn, lo, up, true_obj, _ = REAL_POLY[name]
+    rng = np.random.default_rng(seed)
+    U, pts, Ps = pu.interpolate_box([float(v) for v in lo], [float(v) for v in up], halfdeg, rng=rng)
+    vals = np.array([float(fn(pts[j, :])) for j in range(U)])
+    tol = EPS ** 0.1
+    expect = dict(status="Optimal", primal_obj=(-1.0 if use_primal else 1.0) * true_obj, tol=tol, true_obj=true_obj)
+    if use_primal:
+        assert use_wsos, "primal psd formulation is not implemented (native.jl:52-54)"
+        return (np.array([-1.0]), np.zeros((0, 1)), np.zeros(0), np.ones((U, 1)), vals,
+                [("wsosinterpnonnegative", U, Ps, False)], expect)
+    if use_wsos:
+        return (vals, np.ones((1, U)), np.array([1.0]), -np.eye(U), np.zeros(U), [("wsosinterpnonnegative", U, Ps, True)], expect)
+    # dual PSD formulation (:82-108): rows of G are the scaled lower triangles of -P_k[u, :]' P_k[u, :], one column per point
+    specs, blocks = [], []
+    nonneg = 0
+    for Pk in Ps:
+        Lk = Pk.shape[1]
+        dk = Lk * (Lk + 1) // 2
+        if dk == 1:
+            nonneg += 1
+        else:
+            if nonneg > 0:
+                specs.append(("nonnegative", nonneg))
+            specs.append(("possemideftri", dk))
+        Gk = np.zeros((dk, U))
+        l = 0
+        for i in range(Lk):
+            for j in range(i + 1):
+                Gk[l, :] = -Pk[:, i] * Pk[:, j] * (1.0 if i == j else RT2)   # (scale_svec!: off-diagonals times sqrt(2))
+                l += 1
+        blocks.append(Gk)
+    # (the reference pushes a pending Nonnegative cone BEFORE the next PSD cone and once more at the end, without resetting the
+    #  count -- every polynomial of the lists has L_k > 1 for all k, so the count stays 0)
+    assert nonneg == 0, "a one-dimensional basis block: outside the instances of native_test.jl"
+    G = np.vstack(blocks)
+    return (vals, np.ones((1, U)), np.array([1.0]), G, np.zeros(G.shape[0]), specs, expect)
 
 
 def matrixcompletion(d1, d2, seed=1, known_frac=0.8, with_replacement=False):

@@ -1,0 +1,92 @@
+"""The reference's own known minima on the polymin / WSOS path (VERDICT r05 missing #1): the named polynomials of
+/root/reference/examples/polymin/data_real.jl:36-152 on their box domains (most of them NOT the unit box: the shifted / scaled
+interpolation of src/PolyUtils/realinterp.jl:84-106), the instances of examples/polymin/native_test.jl -- WSOS formulation in
+primal and dual form and the dual PSD formulation -- with the example's own assertion (native.jl:136-144): status Optimal and
+primal_obj = +-true_obj at eps^0.1.  The true_obj values, boxes and instance lists are DATA (tests/golden/polymin_known_minima.json,
+line provenance inside); the polynomials and build_real are restated in oracle/instances.py (polymin_named).
+
+CPU: the oracle reproduces every minimum (an independent pin of oracle/polyutils.py, the WSOSInterpNonnegative restatement and the
+solver: none of these numbers come from the restatement itself).  GPU (-m gpu): the HIP path through the C-ABI reaches the same
+minima, with the oracle's iteration count and objective."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import instances as I
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "polymin_known_minima.json")
+DATA = json.load(open(GOLD))
+EPS = float(np.finfo(np.float64).eps)
+CASES = [(r["poly"], r["halfdeg"], r["use_primal"], r["use_wsos"]) for r in DATA["instances"]]
+IDS = ["%s-%d-%s-%s" % (n, h, "primal" if pr else "dual", "wsos" if w else "psd") for (n, h, pr, w) in CASES]
+
+
+def test_restated_data_is_the_fixture():
+    """boxes, true_obj and the instance list of oracle/instances.py are the committed reference data"""
+    assert sorted(DATA["polys"]) == sorted(I.REAL_POLY)
+    for name, rec in DATA["polys"].items():
+        nv, _, lo, up, tobj, lines = I.REAL_POLY[name]
+        assert rec["nvars"] == nv and rec["true_obj"] == tobj
+        assert rec["l"] == [float(v) for v in lo] and rec["u"] == [float(v) for v in up]
+        assert rec["source"].endswith(":" + lines)
+    assert CASES == [tuple(t) for t in I.REAL_POLY_INSTANCES]
+
+
+def test_polynomials_at_their_known_minimisers():
+    """spot values that do not depend on any solver: f at published minimisers equals true_obj (motzkin at (+-1/2, +-1/2): 0;
+    rosenbrock at (1, 1): 0; schwefel at (1, 1, 1): 0; goldsteinprice at (0, -1): 3; magnetism7 at (1/2, 0, ...): -1/4;
+    lotkavolterra at (-2, +-2, +-2, +-2): -20.8; reactiondiffusion at (5, -5, 5): -36.71269068), and the interpolant's values
+    at the chosen points never fall below it"""
+    P = I.REAL_POLY
+    f = lambda n, x: float(P[n][1](np.asarray(x, dtype=float)))
+    assert abs(f("motzkin", [0.5, 0.5]) - 0.0) < 1e-14
+    assert abs(f("rosenbrock", [1, 1])) < 1e-14 and abs(f("schwefel", [1, 1, 1])) < 1e-14
+    assert abs(f("goldsteinprice", [0, -1]) - 3.0) < 1e-12
+    assert abs(f("magnetism7", [0.5, 0, 0, 0, 0, 0, 0]) + 0.25) < 1e-15
+    assert abs(f("lotkavolterra", [-2, 2, 2, 2]) + 20.8) < 1e-12
+    assert abs(f("reactiondiffusion", [5, -5, 5]) + 36.71269068) < 1e-7
+    for name in ("motzkin", "rosenbrock", "lotkavolterra", "caprasse"):
+        inst = I.polymin_named(name, 3 if name != "caprasse" else 4, True)
+        assert inst[4].min() >= P[name][4] - 1e-6 * (1 + abs(P[name][4]))   # h = the interpolant values (primal form)
+
+
+def _check(solver, inst):
+    exp = inst[6]
+    assert solver.get_status() == "Optimal"
+    tol = EPS ** DATA["tol_power"]
+    p_obj = solver.get_primal_obj()
+    assert abs(p_obj - exp["primal_obj"]) <= tol + tol * max(abs(p_obj), abs(exp["primal_obj"])), (p_obj, exp["primal_obj"])   # isapprox(atol, rtol)
+    return p_obj
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_oracle_reaches_the_known_minimum(case):
+    from oracle.build import make_model
+    from oracle.solvers import Solver
+    inst = I.polymin_named(*case)
+    s = Solver(default_tol_relax=10, iter_limit=250)   # test/runexamplestests.jl:16-23
+    s.load(make_model(inst))
+    s.solve()
+    p_obj = _check(s, inst)
+    # (far inside the example's tolerance: what the pin is worth)
+    assert abs(p_obj - inst[6]["primal_obj"]) <= 5e-3 * (1 + abs(inst[6]["primal_obj"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_hip_path_reaches_the_known_minimum(case):
+    import hypatia_jl_amd as H
+    from oracle.build import make_model
+    from oracle.solvers import Solver
+    inst = I.polymin_named(*case)
+    hs = H.Solver(default_tol_relax=10, iter_limit=250)
+    hs.load(H.make_model(inst))
+    hs.solve()
+    p_hip = _check(hs, inst)
+    os_ = Solver(default_tol_relax=10, iter_limit=250)
+    os_.load(make_model(inst))
+    os_.solve()
+    assert abs(hs.get_num_iters() - os_.get_num_iters()) <= 1, (hs.get_num_iters(), os_.get_num_iters())
+    assert abs(p_hip - os_.get_primal_obj()) <= 1e-6 * (1 + abs(os_.get_primal_obj())), (p_hip, os_.get_primal_obj())
