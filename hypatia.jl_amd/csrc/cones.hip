@@ -472,4 +472,20 @@ const double* PsdCone::dder3(const double* d_dir) {   // :197-207  svec(X^-1 D X
   return dder3v.d();
 }
 
+void PsdCone::dder3_cols(const double* d_dirs, long ldd, int nc, double* d_out, long ldo) {   // :197-207 for nc columns
+  ensure_inverses();
+  if (nc <= 0) return;
+  const long s2 = (long)side * side;
+  for (DBuf* b : {&ws1, &ws2, &ws3}) b->ensure((size_t)nc * s2 * sizeof(double));
+  svec_unpack(ctx, side, nc, d_dirs, ldd, ws1.d());
+  two_sided_core(ctx, side, nc, Uinv.d(), KR_LE_N, KR_LE_M, ws1.d(), ws2.d());   // P_j = U^-T D_j U^-1 in ws1
+  GemmArgs q{};   // Q_j = P_j' P_j, one launch for all columns
+  q.M = side; q.N = side; q.K = side; q.A = ws1.d(); q.lda = side; q.strideA = s2; q.B = ws1.d(); q.ldb = side; q.strideB = s2;
+  q.C = ws3.d(); q.ldc = side; q.strideC = s2;
+  q.alpha = 1; q.beta = 0; q.batch = nc;
+  gemm(ctx, true, q);
+  two_sided_core(ctx, side, nc, UinvT.d(), KR_GE_N, KR_GE_M, ws3.d(), ws2.d());   // U^-1 Q_j U^-T in ws3
+  svec_pack(ctx, side, nc, ws3.d(), d_out, ldo, 1.0);
+}
+
 }  // namespace hyp

@@ -149,6 +149,7 @@ struct PsdCone : Cone {   // src/Cones/possemideftri.jl (real symmetric)
   DBuf dinvb;    // inverted diagonal blocks from potrf
   DBuf tmpmat, tmpmat2, d_info;
   DBuf ws1, ws2; // batched workspaces (chunk * side^2)
+  DBuf ws3;      // dder3_cols: the squared middle factor of every column
   bool inv_ready = false;   // Uinv / UinvT / Xinv computed for the current point
   // A run of equal cones of one model keeps X, U, U', U^-1, U^-T, X^-1 and the inverted diagonal blocks of all its members
   // in one arena (member g at offset g * side^2), so that the group's inverses are ONE batched launch sequence
@@ -178,6 +179,9 @@ struct PsdCone : Cone {   // src/Cones/possemideftri.jl (real symmetric)
   void sqrt_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;
   void inv_sqrt_hess_prod(double* prod, long ldp, const double* arr, long lda, int ncols) override;
   const double* dder3(const double* d_dir) override;
+  // dder3 of nc directions at once (columns ldd apart -> out, columns ldo apart): the launches of one column serve all of them
+  // (stacked / batched products: every column gets the sums it gets alone)
+  void dder3_cols(const double* d_dirs, long ldd, int nc, double* d_out, long ldo);
 };
 
 // PosSemidefTri{T, Complex{T}} (src/Cones/possemideftri.jl:9-207 with R = Complex{T}; complex vectorisation of

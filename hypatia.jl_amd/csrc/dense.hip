@@ -17,6 +17,7 @@
 
 #include <fcntl.h>
 #include <sys/file.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 namespace hyp {
@@ -1069,7 +1070,7 @@ void TriSolvePlan::build(Ctx& c, int n_, const double* U, long ldu, const double
 }
 
 void TriSolvePlan::solve(Ctx& c, const double* U, long ldu, bool trans, double* x) {
-  if (ol_usable(c, ldu)) { ol_sweep(c, U, trans ? 0 : 1, x, 0, nullptr, 1); return; }
+  if (ol_usable(c, ldu, 1)) { ol_sweep(c, U, trans ? 0 : 1, x, 0, nullptr, 1); return; }
   const int nsb = (n + sb - 1) / sb;
   const size_t blk = (size_t)sb * sb;
   double* t = work.d();
@@ -1496,7 +1497,11 @@ Ctx::Ctx(int dev) : device(dev) {
     const char* dir = getenv("TMPDIR");
     char path[256];
     snprintf(path, sizeof(path), "%s/hypatia_hip_%s.lock", (dir && dir[0]) ? dir : "/tmp", bus);
-    device_lock_fd = open(path, O_CREAT | O_RDWR, 0666);
+    // (flock works on a read-only descriptor: another user's processes can open the file whatever the creator's umask made of its
+    //  mode; no symlink is followed, and the descriptor -- with the lock -- does not leak into exec'd children.  The lock does not
+    //  reach across mount namespaces: containers with private /tmp that share a GPU need HYP_PERSISTENT=0 in all but one)
+    device_lock_fd = open(path, O_RDONLY | O_CREAT | O_NOFOLLOW | O_CLOEXEC, 0666);
+    if (device_lock_fd >= 0) (void)fchmod(device_lock_fd, 0666);   // (succeeds for the creator; harmless otherwise)
     persistent_ok = (device_lock_fd >= 0 && flock(device_lock_fd, LOCK_EX | LOCK_NB) == 0);
     if (const char* e = getenv("HYP_PERSISTENT")) persistent_ok = (atoi(e) != 0);   // (1: whatever the lock says; 0: never)
   }
@@ -1507,14 +1512,26 @@ Ctx::Ctx(int dev) : device(dev) {
   HYP_CHECK(hipMemset(dscal.p, 0, 128 * sizeof(double)));
   for (int i = 0; i < 6; ++i) HYP_CHECK(hipEventCreate(&ev[i]));
   host_allocator_keep_pages();
+  HYP_CHECK(hipHostMalloc((void**)&ol_abort_host, 64, hipHostMallocMapped));
+  *ol_abort_host = 0u;
+  HYP_CHECK(hipHostGetDevicePointer((void**)&ol_abort_dev, ol_abort_host, 0));
   HYP_CHECK(hipHostMalloc((void**)&h_info, (8192 + 16) * sizeof(int), hipHostMallocDefault));   // [0..63] general; [64 + 2 k, 64 + 2 k + 1] cone k of a batched feasibility sweep; [H_INFO_FACT]: the system solver's factorization
   h_pinned_n = 1 << 16;
   HYP_CHECK(hipHostMalloc((void**)&h_pinned, (h_pinned_n + H_SC_N) * sizeof(double), hipHostMallocDefault));   // (+ the mirror of the direction solves' scalars behind the general staging: h_sc())
 }
+void Ctx::check_persistent_abort() {
+  if (!ol_abort_host || !*ol_abort_host) return;
+  *ol_abort_host = 0u;
+  persistent_ok = false;
+  throw HipError(-2, "a persistent triangular-solve launch timed out waiting for its own workgroups (co-residency lost: another kernel held "
+                     "the CUs): its results are void; this context uses the launch chains from now on (HYP_PERSISTENT=0 avoids the attempt)");
+}
+
 Ctx::~Ctx() {
   if (device_lock_fd >= 0) (void)close(device_lock_fd);   // (releases the lock)
   for (int i = 0; i < 6; ++i)
     if (ev[i]) (void)hipEventDestroy(ev[i]);
+  if (ol_abort_host) (void)hipHostFree(ol_abort_host);
   if (h_info) (void)hipHostFree(h_info);
   if (h_pinned) (void)hipHostFree(h_pinned);
   if (h_stage) (void)hipHostFree(h_stage);

@@ -579,7 +579,7 @@ static void coldot3(Ctx& c, int m, int ncols, int mode, const double* M, long ld
 // the pair x[:, 0:2] (leading dimension ldx) and a third right-hand side x3 through the super-block sweeps together: the steps of
 // solve_multi (nr = 2) and solve() with every product of the three columns in one launch
 void TriSolvePlan::solve_multi3(Ctx& c, const double* U, long ldu, bool trans, double* x, long ldx, double* x3) {
-  if (ol_usable(c, ldu)) { ol_sweep(c, U, trans ? 0 : 1, x, ldx, x3, MR + 1); return; }
+  if (ol_usable(c, ldu, MR + 1)) { ol_sweep(c, U, trans ? 0 : 1, x, ldx, x3, MR + 1); return; }
   const int nsb = (n + sb - 1) / sb;
   const size_t blk = (size_t)sb * sb;
   work.ensure((size_t)2 * (MR + 1) * sb * sizeof(double));
@@ -619,7 +619,7 @@ void TriSolvePlan::solve_multi3(Ctx& c, const double* U, long ldu, bool trans, d
 void TriSolvePlan::solve_both(Ctx& c, const double* U, long ldu, double* x, long ldx, int nr, double* x3) {
   HYP_REQUIRE(nr >= 1 && nr <= MR + 1 && (!x3 || nr == MR + 1), "TriSolvePlan::solve_both: 1, 2 or 3 right-hand sides");
   static const bool fused = [] { const char* e = getenv("HYP_TRSV_ONE_LAUNCH"); return !(e && atoi(e) == 1); }();   // (1: one launch per sweep)
-  if (fused && ol_usable(c, ldu)) { ol_sweep(c, U, 2, x, ldx, x3, nr); return; }
+  if (fused && ol_usable(c, ldu, nr)) { ol_sweep(c, U, 2, x, ldx, x3, nr); return; }
   for (int pass = 0; pass < 2; ++pass) {
     if (x3) solve_multi3(c, U, ldu, pass == 0, x, ldx, x3);
     else solve_multi(c, U, ldu, pass == 0, x, ldx, nr);
@@ -627,7 +627,7 @@ void TriSolvePlan::solve_both(Ctx& c, const double* U, long ldu, double* x, long
 }
 
 void TriSolvePlan::solve_multi(Ctx& c, const double* U, long ldu, bool trans, double* x, long ldx, int nr) {
-  if (ol_usable(c, ldu) && nr >= 1 && nr <= MR + 1) { ol_sweep(c, U, trans ? 0 : 1, x, ldx, nullptr, nr); return; }
+  if (ol_usable(c, ldu, nr)) { ol_sweep(c, U, trans ? 0 : 1, x, ldx, nullptr, nr); return; }
   if (nr == 1) {
     solve(c, U, ldu, trans, x);
     return;
@@ -667,6 +667,31 @@ void TriSolvePlan::solve_multi(Ctx& c, const double* U, long ldu, bool trans, do
       coldot2(c, m, r0, 0, UT.d() + r0, n, xb, ldx, x, ldx, -1.0, x, ldx);
     }
   }
+  HYP_CHECK(hipGetLastError());
+}
+
+// out[:, r] = k0_r x0[:, r] (*) k1_r x1[:, r] (*) k2_r x2[:, r] for r < nr columns in ONE launch, with exactly the roundings of the
+// dev_scale_copy / dev_axpby sequence it replaces (a product, then one fused multiply-add per further term; x1 / x2 may be null);
+// a leading dimension of 0 = the same vector for every column.  The paired solve issued 9 of those small launches per column.
+// A coefficient may live on the device (p0 / p1 non-null: the tau of a solve whose scalars the host has not seen, round 6).
+struct LinK { double k0[3], k1[3], k2[3]; const double* p0[3]; const double* p1[3]; };
+// (no __restrict__: out may be x0 or x1 -- in-place updates, entry by entry)
+__global__ void lincomb_cols_kernel(int n, const double* x0, long ld0, const double* x1, long ld1, const double* x2, long ld2, double* out, long ldo,
+                                    LinK k) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (i >= n) return;
+  const double k0 = k.p0[r] ? *k.p0[r] : k.k0[r];
+  const double k1 = k.p1[r] ? *k.p1[r] : k.k1[r];
+  double v = __dmul_rn(k0, x0[(long)r * ld0 + i]);
+  if (x1) v = __fma_rn(k1, x1[(long)r * ld1 + i], v);
+  if (x2) v = __fma_rn(k.k2[r], x2[(long)r * ld2 + i], v);
+  out[(long)r * ldo + i] = v;
+}
+static void lincomb_cols(Ctx& c, int n, int nr, const double* x0, long ld0, const double* x1, long ld1, const double* x2, long ld2, double* out,
+                         long ldo, const LinK& k) {
+  if (n <= 0 || nr <= 0) return;
+  hipLaunchKernelGGL(lincomb_cols_kernel, dim3((n + 255) / 256, nr), dim3(256), 0, c.stream, n, x0, ld0, x1, ld1, x2, ld2, out, ldo, k);
   HYP_CHECK(hipGetLastError());
 }
 
@@ -713,7 +738,11 @@ void SysSolver::solve3_multi(double* sol, const double* rhs, int nr, double* x_t
     if (ck->use_dual_barrier) ck->inv_hess_prod(m_HGx.d() + offs[k], q, m_Gx.d() + offs[k], q, nr);
     else ck->hess_prod(m_HGx.d() + offs[k], q, m_Gx.d() + offs[k], q, nr);
   }
-  for (int r = 0; r < nr; ++r) dev_axpby(ctx, q, 1.0, m_HGx.d() + (long)r * q, -1.0, sol + r * ld3 + n);
+  {
+    LinK k{};   // (HGx - z: the value of dev_axpby(1, HGx, -1, z))
+    for (int r = 0; r < nr; ++r) { k.k0[r] = 1.0; k.k1[r] = -1.0; }
+    lincomb_cols(ctx, q, nr, m_HGx.d(), q, sol + n, ld3, nullptr, 0, sol + n, ld3, k);
+  }
 }
 
 void SysSolver::get_directions2(double* h_dirs, const double* h_rhss, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
@@ -746,30 +775,6 @@ void SysSolver::get_directions2(double* h_dirs, const double* h_rhss, double mu,
     h_dirs[(long)r * dv + it] = dsc[r].tau;
     h_dirs[(long)r * dv + ik] = dsc[r].kap;
   }
-}
-
-// out[:, r] = k0_r x0[:, r] (*) k1_r x1[:, r] (*) k2_r x2[:, r] for r < nr columns in ONE launch, with exactly the roundings of the
-// dev_scale_copy / dev_axpby sequence it replaces (a product, then one fused multiply-add per further term; x1 / x2 may be null);
-// a leading dimension of 0 = the same vector for every column.  The paired solve issued 9 of those small launches per column.
-// A coefficient may live on the device (p0 / p1 non-null: the tau of a solve whose scalars the host has not seen, round 6).
-struct LinK { double k0[3], k1[3], k2[3]; const double* p0[3]; const double* p1[3]; };
-__global__ void lincomb_cols_kernel(int n, const double* __restrict__ x0, long ld0, const double* __restrict__ x1, long ld1,
-                                    const double* __restrict__ x2, long ld2, double* __restrict__ out, long ldo, LinK k) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int r = blockIdx.y;
-  if (i >= n) return;
-  const double k0 = k.p0[r] ? *k.p0[r] : k.k0[r];
-  const double k1 = k.p1[r] ? *k.p1[r] : k.k1[r];
-  double v = __dmul_rn(k0, x0[(long)r * ld0 + i]);
-  if (x1) v = __fma_rn(k1, x1[(long)r * ld1 + i], v);
-  if (x2) v = __fma_rn(k.k2[r], x2[(long)r * ld2 + i], v);
-  out[(long)r * ldo + i] = v;
-}
-static void lincomb_cols(Ctx& c, int n, int nr, const double* x0, long ld0, const double* x1, long ld1, const double* x2, long ld2, double* out,
-                         long ldo, const LinK& k) {
-  if (n <= 0 || nr <= 0) return;
-  hipLaunchKernelGGL(lincomb_cols_kernel, dim3((n + 255) / 256, nr), dim3(256), 0, c.stream, n, x0, ld0, x1, ld1, x2, ld2, out, ldo, k);
-  HYP_CHECK(hipGetLastError());
 }
 
 // ---- scalars of a solve on the device (round 6) ---------------------------------------------------------------
@@ -805,6 +810,12 @@ struct GemvOneGuard {
   ~GemvOneGuard() { c.gemv_one = keep; }
 };
 
+void SysSolver::ensure_d_sc() {
+  if (d_sc.bytes >= SC_TOTAL * sizeof(double)) return;
+  d_sc.alloc(SC_TOTAL * sizeof(double));
+  ctx.zero(d_sc.p, SC_TOTAL * sizeof(double));   // (the tickets of the column maxima start at zero)
+}
+
 bool SysSolver::dirs_resident() const {
   static const bool on = [] { const char* e = getenv("HYP_DIR_RESIDENT"); return !(e && e[0] == '0'); }();
   return on && p == 0 && !dist();
@@ -824,7 +835,7 @@ void SysSolver::cols_solve(double* sol, const double* rhs, int nr, const Scal* r
   const long ld3 = n + q;
   for (DBuf* b : {&m_subr, &m_subs}) b->ensure((size_t)(MR + 1) * ld3 * d);
   for (DBuf* b : {&m_Gx, &m_HGx, &m_Gxd}) b->ensure((size_t)(MR + 1) * q * d);
-  d_sc.ensure(64 * d);
+  ensure_d_sc();
   double* sr = m_subr.d();
   double* ss = m_subs.d();
   double* sc = d_sc.d();
@@ -839,6 +850,8 @@ void SysSolver::cols_solve(double* sol, const double* rhs, int nr, const Scal* r
     dev_scale_copy(ctx, q, -1.0, mh.d(), rc + oz);
   }
   for (int r = 0; r < ncol; ++r) ctx.d2d(sr + r * ld3, rhs + (long)r * dv, (size_t)n * d);
+  LinK neg2{};   // y <- -y - x: the value of dev_axpby(-1, x, -1, y) (two exact negations, one rounded sum)
+  for (int r = 0; r < MR + 1; ++r) { neg2.k0[r] = -1.0; neg2.k1[r] = -1.0; }
   for (size_t k = 0; k < cones.size(); ++k) {
     Cone* ck = cones[k];
     const int o = offs[k], dk = ck->dim;
@@ -850,11 +863,11 @@ void SysSolver::cols_solve(double* sol, const double* rhs, int nr, const Scal* r
       }
       ck->inv_hess_prod(sr + oz + o, ld3, ss + oz + o, ld3, ncol);
     } else if (const int used = run_hess_prod(k, sr + oz + o, ld3, rhs + oz + o, dv, ncol)) {
-      for (int r = 0; r < ncol; ++r) dev_axpby(ctx, offs[k + used] - o, -1.0, rhs + (long)r * dv + os + o, -1.0, sr + r * ld3 + oz + o);
+      lincomb_cols(ctx, offs[k + used] - o, ncol, sr + oz + o, ld3, rhs + os + o, dv, nullptr, 0, sr + oz + o, ld3, neg2);   // -H z - s, all columns in one launch
       k += used - 1;
     } else {
       ck->hess_prod(sr + oz + o, ld3, rhs + oz + o, dv, ncol);
-      for (int r = 0; r < ncol; ++r) dev_axpby(ctx, dk, -1.0, rhs + (long)r * dv + os + o, -1.0, sr + r * ld3 + oz + o);
+      lincomb_cols(ctx, dk, ncol, sr + oz + o, ld3, rhs + os + o, dv, nullptr, 0, sr + oz + o, ld3, neg2);
     }
   }
   {
@@ -946,7 +959,13 @@ void SysSolver::cols_residual(double* res, const double* dir, const double* rhs,
       else k.k0[r] = dsc_host[r].tau;
       k.k1[r] = -1.0; k.k2[r] = -1.0;
     }
-    lincomb_cols(ctx, n, nr, mc.d(), 0, nullptr, 0, nullptr, 0, res, dv, k);                       // res.x = c tau (+ G' z below)
+    if (both && !dist()) {   // res.x = c tau + G' z in one launch (the value of the separate addition: a rounded product, one rounded sum)
+      LinK kx = k;
+      for (int r = 0; r < nr; ++r) kx.k1[r] = 1.0;
+      lincomb_cols(ctx, n, nr, mc.d(), 0, m_t.d(), n, nullptr, 0, res, dv, kx);
+    } else {
+      lincomb_cols(ctx, n, nr, mc.d(), 0, nullptr, 0, nullptr, 0, res, dv, k);                     // res.x = c tau (+ G' z below)
+    }
     lincomb_cols(ctx, q, nr, mh.d(), 0, dir + os, dv, m_Gxd.d(), q, res + oz, dv, k);              // res.z = h tau - s - G x
   }
   // Sharded, round 4: the residual's three exchanges -- G' z (n-vectors, SUM), the h' z of the directions (SUM) and the residual
@@ -960,7 +979,7 @@ void SysSolver::cols_residual(double* res, const double* dir, const double* rhs,
       gemv_multi(ctx, true, q, n, nr, 1.0, G.d(), q, dir + oz, dv, 0.0, m_t.d(), n);
     }
     if (dist() && !fuse) allreduce_dev(m_t.d(), (long)nr * n, 0, 3);
-    if (!fuse)
+    if (dist() && !fuse)
       for (int r = 0; r < nr; ++r) dev_axpby(ctx, n, 1.0, m_t.d() + (long)r * n, 1.0, res + (long)r * dv);
   } else {
     GemvOneGuard g1(ctx, nr == 1);
@@ -970,13 +989,15 @@ void SysSolver::cols_residual(double* res, const double* dir, const double* rhs,
     Cone* ck = cones[k];
     const int o = offs[k], dk = ck->dim;
     const int po = ck->use_dual_barrier ? oz + o : os + o, du = ck->use_dual_barrier ? os + o : oz + o;
+    LinK add2{};   // y <- y + x
+    for (int r = 0; r < MR; ++r) { add2.k0[r] = 1.0; add2.k1[r] = 1.0; }
     if (const int used = run_hess_prod(k, res + os + o, dv, dir + po, dv, nr)) {   // (PosSemidefTri: hess_prod_slow! = hess_prod!)
-      for (int r = 0; r < nr; ++r) dev_axpby(ctx, offs[k + used] - o, 1.0, dir + (long)r * dv + du, 1.0, res + (long)r * dv + os + o);
+      lincomb_cols(ctx, offs[k + used] - o, nr, res + os + o, dv, dir + du, dv, nullptr, 0, res + os + o, dv, add2);
       k += used - 1;
       continue;
     }
     ck->hess_prod_slow(res + os + o, dv, dir + po, dv, nr);
-    for (int r = 0; r < nr; ++r) dev_axpby(ctx, dk, 1.0, dir + (long)r * dv + du, 1.0, res + (long)r * dv + os + o);
+    lincomb_cols(ctx, dk, nr, res + os + o, dv, dir + du, dv, nullptr, 0, res + os + o, dv, add2);
   }
   {
     DotSpecs sp;
@@ -1013,7 +1034,7 @@ void SysSolver::cols_residual(double* res, const double* dir, const double* rhs,
     }
     return;
   }
-  for (int r = 0; r < nr; ++r) dev_sub_absmax(ctx, dv, res + (long)r * dv, rhs + (long)r * dv, sc + SC_AMAX + r);
+  dev_sub_absmax_cols(ctx, dv, nr, res, rhs, dv, sc + SC_AMAX, sc + SC_WORK);   // (one launch for the pair: a maximum does not depend on the order)
   if (dist()) {
     ctx.d2h(hp, sc, SC_N * d);
     ctx.sync();
@@ -1262,9 +1283,29 @@ void SysSolver::build_rhs_pair(int stage, double* rhs2, const double* pt, double
       seg_dots(ctx, (int)nc, cones[0]->dim, scal + (long)r * q, Hq + (long)r * q, 2 * r + 1, 4, dots);
     }
   }
+  // (round 6, HYP_DDER3_PAIRED, default on) PosSemidefTri: the two columns of a cone through ONE set of launches -- the Hessian products
+  // as a two-column product, the third-order term's five GEMMs stacked / batched over the columns, the four scalar products in one
+  // launch; every column gets the sums it gets alone (tests/test_hip_switches.py)
+  static const bool d3_paired = [] { const char* e = getenv("HYP_DDER3_PAIRED"); return !(e && e[0] == '0'); }();
+  std::vector<char> done_k(nc, 0);
+  for (size_t k = 0; k < nc && !wr && d3_paired; ++k) {
+    PsdCone* pk = dynamic_cast<PsdCone*>(cones[k]);
+    if (!pk || !pk->use_dder3() || MR != 2) continue;
+    const int o = offs[k], dk = pk->dim;
+    const int po = (pk->use_dual_barrier ? oz : os) + o;
+    m_subs.ensure((size_t)(MR + 1) * (n + q) * d);
+    double* Hin = m_subs.d();   // [dk x 2]: (scaled dir_cent, dir_pred) -- free between the two paired solves
+    LinK ks{}, kh{};
+    for (int r = 0; r < MR; ++r) { ks.k0[r] = irtrtmu; kh.k0[r] = (r == 0) ? irtrtmu : 1.0; }
+    lincomb_cols(ctx, dk, MR, dirs2 + po, dv, nullptr, 0, nullptr, 0, scal + o, q, ks);
+    lincomb_cols(ctx, dk, MR, dirs2 + po, dv, nullptr, 0, nullptr, 0, Hin, dk, kh);
+    pk->hess_prod_slow(Hq + o, q, Hin, dk, MR);                 // centadj: H (scaled dir); predadj: H dir
+    pk->dder3_cols(scal + o, q, MR, D3 + o, q);
+    done_k[k] = 1;
+  }
   for (size_t k = 0; k < nc && !wr; ++k) {
     Cone* ck = cones[k];
-    if (!ck->use_dder3()) continue;
+    if (!ck->use_dder3() || done_k[k]) continue;
     const int o = offs[k], dk = ck->dim;
     const int po = (ck->use_dual_barrier ? oz : os) + o;
     for (int r = 0; r < MR; ++r) {
@@ -1281,6 +1322,15 @@ void SysSolver::build_rhs_pair(int stage, double* rhs2, const double* pt, double
     Cone* ck = cones[k];
     if (!ck->use_dder3()) continue;
     const int o = offs[k], dk = ck->dim;
+    if (d3_paired) {   // (one launch; every sum is the one dot_kernel forms)
+      DotSpecs sp;
+      for (int r = 0; r < MR; ++r) {
+        sp.add(dk, D3 + (long)r * q + o, ck->point.d(), dots + 4 * k + 2 * r);
+        sp.add(dk, scal + (long)r * q + o, Hq + (long)r * q + o, dots + 4 * k + 2 * r + 1);
+      }
+      dev_dots(ctx, sp);
+      continue;
+    }
     for (int r = 0; r < MR; ++r) {
       dev_dot(ctx, dk, D3 + (long)r * q + o, ck->point.d(), dots + 4 * k + 2 * r);
       dev_dot(ctx, dk, scal + (long)r * q + o, Hq + (long)r * q + o, dots + 4 * k + 2 * r + 1);
@@ -1391,14 +1441,18 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   build_rhs_pair(0, m_rhs.d(), s_point.d(), mu, tau, kap, tau_residual, nullptr, nullptr, reinterpret_cast<double*>(rs), true);
   pair_enqueue(m_rhs.d(), rs, mu, tau, max_ref_steps, const3, joint, true, dsc);
   ctx.sync();
+  // (the device is idle from here until the second pair's first launches arrive: nothing that can wait is done before them --
+  //  the phases' event times are read at the end of the call)
   const auto tf0 = std::chrono::steady_clock::now();
-  factor_lhs_end(info, used_fallback);
+  factor_lhs_end(info, used_fallback, true);
   const double fallback_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count();
-  {
+  auto read_times = [&] {
+    factor_lhs_times();
     float ms = 0;
     HYP_CHECK(hipEventElapsedTime(&ms, ctx.ev[0], ctx.ev[5]));
     last_update_lhs_s = 1e-3 * ms;
-  }
+  };
+  if (*info != 0 || use_bk) read_times();
   if (*info != 0) return;
   if (use_bk) {   // the Cholesky failed, a fall-back factorization stands: everything queued behind the attempt is void
     const double dev_s = last_update_lhs_s;
@@ -1412,6 +1466,7 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   *n_solves += ns;
   step_directions_rest(true, tau, kap, tau_residual, mu, max_ref_steps, res_norm_cutoff, min_impr_tol, h_dirs, res_norms, n_solves, h_sol_const,
                        hs_const, hs_dirs, true, dsc, rn);
+  read_times();
 }
 
 static bool env_default_on(const char* name) {
@@ -1472,13 +1527,14 @@ void SysSolver::step_directions_rest(bool resident, double tau, double kap, doub
   }
   res_norms[0] = rn[0];
   res_norms[1] = rn[1];
-  ctx.d2h(hs_dirs, m_dir.d(), (size_t)MR * dv * d);
   s_dirs.ensure((size_t)2 * MR * dv * d);   // (all four directions stay here for search_alpha(..., resident))
-  ctx.d2d(s_dirs.p, m_dir.p, (size_t)MR * dv * d);
   const double dtau[MR] = {dsc[0].tau, dsc[1].tau};
   const Scal d01[MR] = {dsc[0], dsc[1]};
-  // (centadj, predadj)
-  build_rhs_pair(1, m_rhs.d(), s_point.d(), mu, tau, kap, tau_residual, s_dirs.d(), dtau, reinterpret_cast<double*>(rs), resident);
+  // (centadj, predadj) -- right-hand sides from the first pair's directions where they lie; their copies (to the host's staging and
+  // to the resident block of the line search) are queued behind the right-hand sides' launches: the device is waiting for work here
+  build_rhs_pair(1, m_rhs.d(), s_point.d(), mu, tau, kap, tau_residual, m_dir.d(), dtau, reinterpret_cast<double*>(rs), resident);
+  ctx.d2h(hs_dirs, m_dir.d(), (size_t)MR * dv * d);
+  ctx.d2d(s_dirs.p, m_dir.p, (size_t)MR * dv * d);
   ns = 0;
   pair_enqueue(m_rhs.d(), rs, mu, tau, max_ref_steps, false, false, resident, dsc);
   // (the raw directions travel to the host under the same synchronisation; a refined column is copied again below)

@@ -88,6 +88,9 @@ struct Ctx {
   // launch them; every other context on that device uses the launch chains.
   bool persistent_ok = false;
   int device_lock_fd = -1;
+  unsigned* ol_abort_host = nullptr;   // pinned, device-visible: raised by a persistent kernel whose poll timed out (trsv_onelaunch.hip) ...
+  unsigned* ol_abort_dev = nullptr;    // ... the same word as the device sees it
+  void check_persistent_abort();       // throws (and switches the persistent kernels off) if the word is raised
   std::vector<hipEvent_t> ev_pool;          // ordering events between stream and stream2
   hipEvent_t pool_event(size_t i);
   hipEvent_t aux[4] = {nullptr, nullptr, nullptr, nullptr};   // fork / join events of the two-stream sections (not the look-ahead pool)
@@ -133,7 +136,10 @@ struct Ctx {
   double* stage_host(size_t n_doubles);
   Ctx(int dev);
   ~Ctx();
-  void sync() { HYP_CHECK(hipStreamSynchronize(stream)); }
+  void sync() {
+    HYP_CHECK(hipStreamSynchronize(stream));
+    if (ol_abort_host && *ol_abort_host) check_persistent_abort();
+  }
   void h2d(void* dst, const void* src, size_t bytes) {
     if (bytes) HYP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
   }
@@ -241,7 +247,9 @@ struct TriSolvePlan {
   DBuf probe_ws;
   void measure_quality(Ctx& c, const double* U, long ldu);
   // only on the context's main stream: two such launches side by side on two streams could each hold CUs the other's wavefronts wait for
-  bool ol_usable(const Ctx& c, long ldu) const { return ol_ok && c.persistent_ok && refine >= 0 && refine <= 3 && ol_have[refine] && ldu == ol_ldu && c.stream == c.stream_primary; }
+  bool ol_fit[4] = {false, false, false, false};   // per number of right-hand sides: the instance's 512 workgroups are resident at once on this device (ol_fits)
+  static bool ol_fits(Ctx& c, int nr);
+  bool ol_usable(const Ctx& c, long ldu, int nr) const { return ol_ok && nr >= 1 && nr <= 3 && ol_fit[nr] && c.persistent_ok && refine >= 0 && refine <= 3 && ol_have[refine] && ldu == ol_ldu && c.stream == c.stream_primary; }
   void ol_sweep(Ctx& c, const double* U, int which, double* x, long ldx, double* x3, int nr);
   // both sweeps, x <- (U'U)^-1 x on nr = 1, 2 or 3 columns (x3 != nullptr: the third column lives there instead of x + 2 ldx)
   void solve_both(Ctx& c, const double* U, long ldu, double* x, long ldx, int nr, double* x3 = nullptr);

@@ -324,7 +324,9 @@ __global__ void tri_pack_rows_kernel(int n, int r0, int r1, const double* __rest
 }
 
 bool SysSolver::assemble_lhs_overlapped(long kr0, long kr1, int groups) {
-  if (!rccl_comm || groups < 2 || nmp < 1024 || kr1 - kr0 < 1024) return false;
+  // (every condition here is the same on every rank: the ranks must issue the same collectives -- ADVICE r05; a rank with few or no
+  //  rows of its own still takes part, its share of a group is a zero block)
+  if (!rccl_comm || groups < 2 || nmp < 1024) return false;
   const int T = (nmp + 127) / 128;
   groups = std::min(groups, T);
   // tile-row boundaries of groups of (nearly) equal area; tile row i has T - i tiles
@@ -358,7 +360,8 @@ bool SysSolver::assemble_lhs_overlapped(long kr0, long kr1, int groups) {
     int S = (int)std::max<long>(1, std::min<long>(8, (1024 + nblk / 2) / std::max<long>(nblk, 1)));
     while (S > 1 && s.K / S < 1024) --S;
     s.splitk_req = S;
-    gemm(ctx, true, s);
+    if (s.K > 0) gemm(ctx, true, s);
+    else HYP_CHECK(hipMemset2DAsync(s.C, (size_t)nmp * sizeof(double), 0, (size_t)rows * sizeof(double), (size_t)cols, ctx.stream));
     HYP_CHECK(hipEventRecord(ov_events[2 * g], ctx.stream));
     HYP_CHECK(hipStreamWaitEvent(ctx.stream2, ov_events[2 * g], 0));
     const long h = rows;
@@ -617,10 +620,28 @@ void SysSolver::assemble_lhs() {
   for (size_t k = 0; k < cones.size(); ++k) use_sqrt[k] = cones[k]->use_sqrt_hess_oracles(nmp) ? 1 : 0;   // :214-216
   bool any_sqrt = false;
   for (int v : use_sqrt) any_sqrt |= (v != 0);
+  // (round 5, HYP_DIST_OVERLAP=G: row groups, each exchanged on the helper stream under the next one's product)
+  // The choice between the grouped exchange and the single one must be the SAME on every rank (they issue different collectives --
+  // ADVICE r05): with the cones sharded, "every cone of mine went through its square root" is a per-rank fact (a cone loses its
+  // square-root oracle behind a Bunch-Kaufman fall-back of its Hessian), so the ranks agree on the minimum first -- one scalar
+  // exchange, only with the switch on, in front of everything a rank may or may not do.  K-panel sharding replicates the model: the
+  // flag is the same everywhere by construction.  A rank without rows of its own still takes part (zero blocks).
+  static const int ov_groups = [] { const char* e = getenv("HYP_DIST_OVERLAP"); return e ? atoi(e) : 0; }();
+  bool use_ov = ov_groups >= 2 && (dist() || ks_world > 1) && rccl_comm != nullptr && nmp >= 1024;
+  if (use_ov) {
+    bool all_sqrt = true;
+    for (int v : use_sqrt) all_sqrt &= (v != 0);
+    if (dist()) {
+      double f = all_sqrt ? 1.0 : 0.0;
+      allreduce_host(&f, 1, 2, 15);
+      all_sqrt = f > 0.5;
+    }
+    use_ov = all_sqrt;
+  }
   HYP_CHECK(hipEventRecord(ctx.ev[0], ctx.stream));
   HYP_CHECK(hipEventRecord(ctx.ev[1], ctx.stream));
   HYP_CHECK(hipEventRecord(ctx.ev[2], ctx.stream));
-  if (any_sqrt) {   // :219-234
+  if (any_sqrt || use_ov) {   // :219-234
     int idx = 0;
     for (size_t k = 0; k < cones.size(); ++k) {
       if (!use_sqrt[k]) continue;
@@ -637,11 +658,7 @@ void SysSolver::assemble_lhs() {
       r0 = std::min<long>((long)idx, per * ks_rank);
       r1 = std::min<long>((long)idx, r0 + per);
     }
-    // (round 5, HYP_DIST_OVERLAP=G: row groups, each exchanged on the helper stream under the next one's product)
-    static const int ov_groups = [] { const char* e = getenv("HYP_DIST_OVERLAP"); return e ? atoi(e) : 0; }();
-    bool all_sqrt = true;
-    for (int v : use_sqrt) all_sqrt &= (v != 0);
-    if (ov_groups >= 2 && all_sqrt && (dist() || ks_world > 1) && assemble_lhs_overlapped(r0, r1, ov_groups)) {
+    if (use_ov && assemble_lhs_overlapped(r0, r1, ov_groups)) {
       HYP_CHECK(hipEventRecord(ctx.ev[2], ctx.stream));
       ctx.kstat[4] += 1;
       return;   // (the exchange is done)
@@ -704,7 +721,15 @@ void SysSolver::factor_lhs_begin() {
   if (ctx.trsv_plan_sb(nmp) > 0) tri.build(ctx, nmp, lhs_fact.d(), nmp, dinv.d());
 }
 
-void SysSolver::factor_lhs_end(int* info, int* used_fallback) {
+void SysSolver::factor_lhs_times() {   // HIP-event times of the update_lhs phases (every event has completed)
+  float ms = 0;
+  HYP_CHECK(hipEventElapsedTime(&ms, ctx.ev[0], ctx.ev[1])); ctx.kstat[0] += ms;
+  HYP_CHECK(hipEventElapsedTime(&ms, ctx.ev[1], ctx.ev[2])); ctx.kstat[1] += ms;
+  HYP_CHECK(hipEventElapsedTime(&ms, ctx.ev[3], ctx.ev[4])); ctx.kstat[2] += ms;
+  ctx.kstat[3] += 1;
+}
+
+void SysSolver::factor_lhs_end(int* info, int* used_fallback, bool times_later) {
   *info = 0;
   *used_fallback = 0;
   if (nmp == 0) return;
@@ -715,11 +740,7 @@ void SysSolver::factor_lhs_end(int* info, int* used_fallback) {
   use_bk = false;
   if (!force_bk) {
     *info = ctx.h_info[Ctx::H_INFO_FACT];
-    float ms = 0;
-    HYP_CHECK(hipEventElapsedTime(&ms, ctx.ev[0], ctx.ev[1])); ctx.kstat[0] += ms;
-    HYP_CHECK(hipEventElapsedTime(&ms, ctx.ev[1], ctx.ev[2])); ctx.kstat[1] += ms;
-    HYP_CHECK(hipEventElapsedTime(&ms, ctx.ev[3], ctx.ev[4])); ctx.kstat[2] += ms;
-    ctx.kstat[3] += 1;
+    if (!times_later) factor_lhs_times();
   }
   if (force_bk || *info != 0) {
     use_bk = true;
@@ -875,6 +896,53 @@ __global__ __launch_bounds__(256) void sub_absmax_kernel(int n, double* __restri
       *ticket = 0u;
     }
   }
+}
+
+// the same for nr columns (a, b: columns ld apart; out[r]) in ONE launch: column blockIdx.y with its own partial maxima and ticket
+// (work: nr x (SA_WGS doubles + one ticket word), zeroed at allocation, reset by every call)
+__global__ __launch_bounds__(256) void sub_absmax_cols_kernel(int n, double* __restrict__ a, const double* __restrict__ b, long ld,
+                                                              double* __restrict__ out, double* __restrict__ work) {
+  __shared__ double red[4];
+  __shared__ bool last;
+  const int r = blockIdx.y;
+  a += (long)r * ld;
+  b += (long)r * ld;
+  double* part = work + (long)r * (SA_WGS + 1);
+  unsigned* ticket = reinterpret_cast<unsigned*>(part + SA_WGS);
+  double m = 0.0;
+  bool bad = false;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += SA_WGS * 256) {
+    const double v = a[i] - b[i];
+    a[i] = v;
+    bad |= (v != v);
+    m = fmax(m, fabs(v));
+  }
+  if (bad) m = __builtin_nan("");
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = nanmax(m, __shfl_down(m, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = nanmax(nanmax(red[0], red[1]), nanmax(red[2], red[3]));
+    __threadfence();
+    last = (atomicAdd(ticket, 1u) == SA_WGS - 1);
+  }
+  __syncthreads();
+  if (last && threadIdx.x < 64) {
+    __threadfence();
+    double v = (threadIdx.x < SA_WGS) ? reinterpret_cast<volatile double*>(part)[threadIdx.x] : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = nanmax(v, __shfl_down(v, off));
+    if (threadIdx.x == 0) {
+      out[r] = v;
+      *ticket = 0u;
+    }
+  }
+}
+void dev_sub_absmax_cols(Ctx& c, int n, int nr, double* a, const double* b, long ld, double* d_out, double* work) {
+  if (nr <= 0) return;
+  hipLaunchKernelGGL(sub_absmax_cols_kernel, dim3(SA_WGS, nr), dim3(256), 0, c.stream, n, a, b, ld, d_out, work);
+  HYP_CHECK(hipGetLastError());
 }
 
 void dev_sub_absmax(Ctx& c, int n, double* a, const double* b, double* d_out) {

@@ -7,6 +7,8 @@ namespace hyp {
 
 // a <- a - b in place and *d_out = max |a_i| (NaN if any), one launch
 void dev_sub_absmax(Ctx& c, int n, double* a, const double* b, double* d_out);
+// nr columns ld apart in one launch (d_out[r]); work: nr x 33 doubles, zero when first used
+void dev_sub_absmax_cols(Ctx& c, int n, int nr, double* a, const double* b, long ld, double* d_out, double* work);
 
 struct SysSolver {
   Ctx& ctx;
@@ -57,7 +59,8 @@ struct SysSolver {
   void assemble_lhs();                                                         //   :214-246 (Schur sum over this process's cones)
   void factor_lhs(int* info, int* used_fallback);                              //   :249-250
   void factor_lhs_begin();                                                     //   ... queued: Cholesky attempt, info read-back, solve plan
-  void factor_lhs_end(int* info, int* used_fallback);                          //   ... after a synchronisation: info, fall-back chain
+  void factor_lhs_end(int* info, int* used_fallback, bool times_later = false);   //   ... after a synchronisation: info, fall-back chain
+  void factor_lhs_times();                                                     //   ... the phases' HIP-event times into ctx.kstat (times_later: the caller's job, off the critical path)
   void tri_solves(double* d_x);                                                // both triangular solves of the potrs
   void potrs(double* d_x);                                                     // x <- lhs^-1 x with the current factor (:66-69)
   void solve3(double* d_sol, const double* d_rhs);                             // qrchol.jl:39-85
@@ -219,7 +222,8 @@ struct SysSolver {
   // d_sc: [0, 6) solve dots (c'x, h'z per column), [8, 12) residual dots, [12, 14) residual maxima, [16, 20) tau / kap of the
   // direction per column, [20] dot_const, [24, 28) tau / kap of the last solve_system per column; mirrored to ctx.h_sc().
   DBuf d_sc;
-  enum { SC_SOLVE = 0, SC_RESD = 8, SC_AMAX = 12, SC_DSC = 16, SC_DOTC = 20, SC_CSC = 24, SC_N = 32 };
+  enum { SC_SOLVE = 0, SC_RESD = 8, SC_AMAX = 12, SC_DSC = 16, SC_DOTC = 20, SC_CSC = 24, SC_N = 32, SC_WORK = 64, SC_TOTAL = 64 + 3 * 33 + 5 };
+  void ensure_d_sc();
   bool dirs_resident() const;   // HYP_DIR_RESIDENT (default on): single process, p = 0
   // solve_system (common.jl:129-182) for nr columns: rhs -> sol (Point layout, columns dimv() apart); base != null: the
   // direction's scalars become base - (the solve's) (a refinement step's correction), else the solve's own

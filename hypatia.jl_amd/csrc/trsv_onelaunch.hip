@@ -68,6 +68,7 @@ struct OlArgs {
   long asz;
   double* x; long ldx; double* x3;   // the caller's vectors: columns 0, 1 at x, x + ldx; column 2 at x3
   int direct_poll;                   // HYP_TRSV_OL_POLL=1: no one-word poll in front of the staging loads (experiment)
+  unsigned* abort_word;              // host-visible: raised by a poll that timed out (see OlWatch)
 };
 
 __device__ __forceinline__ unsigned long long ol_load(const unsigned long long* p) {
@@ -80,17 +81,25 @@ __device__ __forceinline__ void ol_publish(unsigned long long* p, double v) {
 }
 __device__ __forceinline__ double ol_val(unsigned long long b) { return __longlong_as_double((long long)b); }
 
-// a poll that sees no progress for ~2 s of the 100 MHz wall clock ends the kernel with a trap
+// A poll that sees no progress for ~2 s of the 100 MHz wall clock gives up WITHOUT killing the HIP context (round 6; it used to
+// trap): it raises a word in host-visible pinned memory and its wavefront leaves the kernel; every other poll looks at that word
+// each 1024 spins and leaves too.  The launch's results are void; the host finds the word raised at its next synchronisation
+// (Ctx::sync), throws, and the context uses the launch chains from then on.
 struct OlWatch {
   unsigned long long t0 = 0;
   unsigned spins = 0;
-  __device__ __forceinline__ void tick() {
+  __device__ __forceinline__ bool tick(unsigned* abort_word) {
     __builtin_amdgcn_s_sleep(1);
     if ((++spins & 1023u) == 0) {
+      if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return true;
       const unsigned long long t = wall_clock64();
       if (t0 == 0) t0 = t;
-      else if (t - t0 > 200000000ULL) __builtin_trap();
+      else if (t - t0 > 200000000ULL) {
+        __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return true;
+      }
     }
+    return false;
   }
 };
 
@@ -155,7 +164,8 @@ __global__ __launch_bounds__(256, 2) void trsv_onelaunch_kernel(const OlRound* _
     OlWatch watch;
     if (!a.direct_poll) {
       const unsigned long long* key = ar[NR - 1] + R.v_off + (hi - 1);
-      while (ol_load(key) == OL_SENT) watch.tick();
+      while (ol_load(key) == OL_SENT)
+        if (watch.tick(a.abort_word)) return;
     }
     unsigned long long bb[NR];
     const int hl2 = (hi - 1) & ~1;   // the even row of the last pair (>= lo2)
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void trsv_onelaunch_kernel(const OlRound* _
       const int all_ok = okf[att & 1][0] & okf[att & 1][1] & okf[att & 1][2] & okf[att & 1][3];
       ++att;
       if (all_ok) break;
-      watch.tick();
+      if (watch.tick(a.abort_word)) return;
     }
     const double* v0 = vl[buf][0];
     const double* v1 = vl[buf][NR > 1 ? 1 : 0];
@@ -374,17 +384,36 @@ static void ol_append_sweep(std::vector<OlRound>& chain, std::vector<OlRound>& u
   }
 }
 
+bool TriSolvePlan::ol_fits(Ctx& c, int nr) {
+  static int fits[16][4];   // per device and instance: 0 not asked, 1 fits, -1 does not
+  const int dev = (c.device >= 0 && c.device < 16) ? c.device : 0;
+  if (nr < 1 || nr > 3) return false;
+  if (fits[dev][nr] == 0) {
+    int cus = 0, per_cu = 0;
+    hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device);
+    if (e == hipSuccess) {
+      if (nr == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trsv_onelaunch_kernel<1>, 256, 0);
+      else if (nr == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trsv_onelaunch_kernel<2>, 256, 0);
+      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trsv_onelaunch_kernel<3>, 256, 0);
+    }
+    if (e != hipSuccess) (void)hipGetLastError();
+    fits[dev][nr] = (e == hipSuccess && (long)per_cu * cus >= 2 * OL_W / 4) ? 1 : -1;
+  }
+  return fits[dev][nr] > 0;
+}
+
 void TriSolvePlan::ol_prepare(Ctx& c, long ldu) {
   ol_ok = false;
   if (!trsv_one_launch_on() || n <= 0 || sb <= 0 || sb > 1024 || refine < 0 || refine > 3) return;
   // (asked once: hipDeviceGetAttribute is a driver round trip -- 0.19 ms of idle GPU behind every plan build when it sat here per call,
   //  profiles/r05_iteration_timeline.txt against the final one)
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    return n;
-  }();
-  if (cus * 2 < 2 * OL_W / 4) return;   // 512 four-wavefront workgroups must be resident at once: at most two per CU asked for
+  // All 2 OL_W / 4 = 512 four-wavefront workgroups of a launch must be RESIDENT at once (a wavefront polls words that other workgroups
+  // publish).  Asked per instance of the kernel and per device, once (driver round trips: 0.19 ms of idle GPU behind every plan build when
+  // the attribute query sat here per call, profiles/r05_iteration_timeline.txt): the occupancy the runtime computes from the instance's
+  // registers, its static LDS (NR = 3: 48 KB) and the launch bounds, times the CU count of the CONTEXT's device.  An instance that does
+  // not fit (a part with less LDS per CU, a register-allocation regression) takes the launch chains -- ol_fits() is asked per sweep.
+  for (int r = 1; r <= 3; ++r) ol_fit[r] = ol_fits(c, r);
+  if (!ol_fit[1] && !ol_fit[2] && !ol_fit[3]) return;
   // (the arena is laid out for the most refinement steps this plan can run: the per-right-hand-side stride and what a launch clears do
   //  not change when the adaptive rule moves between tables)
   const int rmax = std::max(std::max(refine, refine_req), 0);
@@ -448,6 +477,7 @@ void TriSolvePlan::ol_sweep(Ctx& c, const double* U, int which, double* x, long 
   a.x = x; a.ldx = ldx; a.x3 = x3 ? x3 : x + 2 * ldx;
   static const int direct = [] { const char* e = getenv("HYP_TRSV_OL_POLL"); return e ? atoi(e) : 0; }();
   a.direct_poll = direct;
+  a.abort_word = c.ol_abort_dev;
   ol_set = 1 - ol_set;
   const dim3 grid(2 * OL_W / 4), blk(256);
   if (nr == 1) hipLaunchKernelGGL(trsv_onelaunch_kernel<1>, grid, blk, 0, c.stream, rounds, a);

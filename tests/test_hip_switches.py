@@ -269,3 +269,17 @@ def test_paired_refinement_solves_the_same_problem(name):
     assert abs(on["obj"] - off["obj"]) <= 1e-9 * (1 + abs(off["obj"]))
     for a, b in list(zip(on["trace"], off["trace"]))[: min(on["iters"], off["iters"]) // 2]:
         assert abs(a[0] - b[0]) <= 1e-8 * (1 + abs(b[0]))
+
+
+@pytest.mark.parametrize("name", ["psd_plan", "psd_pair", "psd_single_wide", "psd_smoke"])
+def test_paired_third_order_terms_change_no_bit(name):
+    """round 6, HYP_DDER3_PAIRED (default on): the right-hand sides of the adjusted directions (steppers/common.jl:37-55, 96-113) of
+    a PosSemidefTri cone -- H dir of both columns as ONE two-column product, the five GEMMs of dder3 (possemideftri.jl:197-207)
+    stacked / batched over the two columns, the four scalar products in one launch.  Every kernel on that path forms a column with
+    the sums it forms alone: every iterate must be the separate launches', to the last bit"""
+    on = _run(name, {"HYP_DDER3_PAIRED": "1"})
+    off = _run(name, {"HYP_DDER3_PAIRED": "0"})
+    assert on["status"] == off["status"] == "Optimal"
+    assert on["iters"] == off["iters"] >= 8
+    assert on["trace"] == off["trace"], name
+    assert on["trials"] == off["trials"]
