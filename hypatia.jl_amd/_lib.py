@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhypatia_hip.so")
+LIB_PATH = os.environ.get("HYP_LIB_PATH") or os.path.join(HERE, "libhypatia_hip.so")   # (HYP_LIB_PATH: another build of the same library, for A/B measurements)
 
 c_int, c_dbl, c_vp = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
 P = ctypes.POINTER

@@ -710,6 +710,7 @@ void SysSolver::solve3_multi(double* sol, const double* rhs, int nr, double* x_t
   } else {
     gemv_multi(ctx, true, q, n, nr, 1.0, G.d(), q, sol + n, ld3, 1.0, sol, ld3);
   }
+  join_plan();
   if (tri.ready(nmp)) {
     double* y = use_bk ? bk.gather(ctx, sol, ld3, nr) : sol;   // Bunch-Kaufman factor: P before, D^-1 between, P' after
     const long ldy = use_bk ? nmp : ld3;
@@ -1535,10 +1536,16 @@ void SysSolver::step_directions_rest(bool resident, double tau, double kap, doub
   build_rhs_pair(1, m_rhs.d(), s_point.d(), mu, tau, kap, tau_residual, m_dir.d(), dtau, reinterpret_cast<double*>(rs), resident);
   ctx.d2h(hs_dirs, m_dir.d(), (size_t)MR * dv * d);
   ctx.d2d(s_dirs.p, m_dir.p, (size_t)MR * dv * d);
+  if (!dirs_copied_ev) HYP_CHECK(hipEventCreateWithFlags(&dirs_copied_ev, hipEventDisableTiming));
+  HYP_CHECK(hipEventRecord(dirs_copied_ev, ctx.stream));
   ns = 0;
   pair_enqueue(m_rhs.d(), rs, mu, tau, max_ref_steps, false, false, resident, dsc);
-  // (the raw directions travel to the host under the same synchronisation; a refined column is copied again below)
+  // (the raw directions travel to the host and to the resident block under the same synchronisation; a refined pair is copied again below)
   ctx.d2h(hs_dirs + (long)MR * dv, m_dir.d(), (size_t)MR * dv * d);
+  ctx.d2d(s_dirs.d() + (long)MR * dv, m_dir.p, (size_t)MR * dv * d);
+  // the first pair's directions reach the caller's (pageable) block while the device works on the second pair
+  HYP_CHECK(hipEventSynchronize(dirs_copied_ev));
+  std::memcpy(h_dirs, hs_dirs, (size_t)MR * dv * d);
   ctx.sync();
   const int ns_before = ns;
   pair_finish(m_rhs.d(), rs, mu, tau, max_ref_steps, res_norm_cutoff, min_impr_tol, false, false, resident, dsc, rn, &ns);
@@ -1547,10 +1554,10 @@ void SysSolver::step_directions_rest(bool resident, double tau, double kap, doub
   res_norms[3] = rn[1];
   if (ns > ns_before + MR) {   // refinement moved a direction of the second pair
     ctx.d2h(hs_dirs + (long)MR * dv, m_dir.d(), (size_t)MR * dv * d);
+    ctx.d2d(s_dirs.d() + (long)MR * dv, m_dir.p, (size_t)MR * dv * d);
+    ctx.sync();
   }
-  ctx.d2d(s_dirs.d() + (long)MR * dv, m_dir.p, (size_t)MR * dv * d);
-  ctx.sync();
-  std::memcpy(h_dirs, hs_dirs, (size_t)2 * MR * dv * d);
+  std::memcpy(h_dirs + (long)MR * dv, hs_dirs + (long)MR * dv, (size_t)MR * dv * d);
   if (h_sol_const) std::memcpy(h_sol_const, hs_const, (size_t)it * d);
   for (int r = 0; r < MR; ++r) {
     h_dirs[(long)r * dv + it] = d01[r].tau;

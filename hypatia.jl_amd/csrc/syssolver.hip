@@ -718,7 +718,33 @@ void SysSolver::factor_lhs_begin() {
   // per iteration, profiles/r02_iteration_timeline.txt); after a failed Cholesky the plan's kernels ran on meaningless numbers
   // and the plan is discarded in factor_lhs_end
   tri.invalidate();
-  if (ctx.trsv_plan_sb(nmp) > 0) tri.build(ctx, nmp, lhs_fact.d(), nmp, dinv.d());
+  if (ctx.trsv_plan_sb(nmp) <= 0) return;
+  // HYP_PLAN_LANE=1 (round 6): the plan's launches -- inversions of the diagonal super-blocks, transposes: ~0.3 ms of latency-bound
+  // chains at n = 5000 -- go to a lane of their own, so that whatever the caller queues next on the main stream and does not need
+  // the plan (the first pair's right-hand sides, cone products and G' z) runs beside them; the first user of the plan joins (join_plan)
+  static const bool plan_lane = [] { const char* e = getenv("HYP_PLAN_LANE"); return e && e[0] == '1'; }();
+  if (plan_lane && Ctx::max_lanes() >= 3 && ctx.stream == ctx.stream_primary) {
+    if (!plan_ev_fork) {
+      HYP_CHECK(hipEventCreateWithFlags(&plan_ev_fork, hipEventDisableTiming));
+      HYP_CHECK(hipEventCreateWithFlags(&plan_ev_done, hipEventDisableTiming));
+    }
+    HYP_CHECK(hipEventRecord(plan_ev_fork, ctx.stream));
+    {
+      LaneSwitch on_lane(ctx, 2);
+      HYP_CHECK(hipStreamWaitEvent(ctx.stream, plan_ev_fork, 0));
+      tri.build(ctx, nmp, lhs_fact.d(), nmp, dinv.d());
+      HYP_CHECK(hipEventRecord(plan_ev_done, ctx.stream));
+    }
+    plan_join_pending = true;
+    return;
+  }
+  tri.build(ctx, nmp, lhs_fact.d(), nmp, dinv.d());
+}
+
+void SysSolver::join_plan() {
+  if (!plan_join_pending) return;
+  HYP_CHECK(hipStreamWaitEvent(ctx.stream_primary, plan_ev_done, 0));
+  plan_join_pending = false;
 }
 
 void SysSolver::factor_lhs_times() {   // HIP-event times of the update_lhs phases (every event has completed)
@@ -738,6 +764,7 @@ void SysSolver::factor_lhs_end(int* info, int* used_fallback, bool times_later) 
   // shift + Bunch-Kaufman.  HYP_FORCE_BK=1 (tests) treats the Cholesky as failed.
   const bool force_bk = force_bk_env();
   use_bk = false;
+  join_plan();   // (nothing below may touch the factor under a plan build that still reads it)
   if (!force_bk) {
     *info = ctx.h_info[Ctx::H_INFO_FACT];
     if (!times_later) factor_lhs_times();
@@ -776,6 +803,7 @@ void SysSolver::factor_lhs(int* info, int* used_fallback) {   // qrchol.jl:249-2
 // x <- lhs^-1 x.  Cholesky: U'^-1 then U^-1.  Bunch-Kaufman: the same two sweeps with the unit factor, between a
 // gather by P, the block-diagonal solve and a scatter.
 void SysSolver::tri_solves(double* d_x) {
+  join_plan();
   if (!use_bk && tri.ready(nmp)) { tri.solve_both(ctx, lhs_fact.d(), nmp, d_x, nmp, 1); return; }
   double* y = use_bk ? bk.gather(ctx, d_x, nmp, 1) : d_x;
   for (int pass = 0; pass < 2; ++pass) {

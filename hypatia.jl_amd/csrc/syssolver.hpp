@@ -60,6 +60,9 @@ struct SysSolver {
   void factor_lhs(int* info, int* used_fallback);                              //   :249-250
   void factor_lhs_begin();                                                     //   ... queued: Cholesky attempt, info read-back, solve plan
   void factor_lhs_end(int* info, int* used_fallback, bool times_later = false);   //   ... after a synchronisation: info, fall-back chain
+  hipEvent_t plan_ev_fork = nullptr, plan_ev_done = nullptr;
+  bool plan_join_pending = false;   // the solve plan is being built on a lane of its own (HYP_PLAN_LANE): its first user waits
+  void join_plan();
   void factor_lhs_times();                                                     //   ... the phases' HIP-event times into ctx.kstat (times_later: the caller's job, off the critical path)
   void tri_solves(double* d_x);                                                // both triangular solves of the potrs
   void potrs(double* d_x);                                                     // x <- lhs^-1 x with the current factor (:66-69)
@@ -244,6 +247,7 @@ struct SysSolver {
   static bool const3_on();    // HYP_CONST_COL3 (default on)
   static bool tri3_on();      // HYP_CONST_TRI3 (default on)
   static bool getenv_on(const char* name);
+  hipEvent_t dirs_copied_ev = nullptr;   // the first pair's directions have reached the pinned staging
   std::chrono::steady_clock::time_point t_rest0;
   double last_rest_update_lhs_s = 0.0;
   void step_directions_rest(bool resident, double tau, double kap, double tau_residual, double mu, int max_ref_steps, double res_norm_cutoff,
