@@ -70,6 +70,9 @@ struct GemmArgs {
   // of the tiles at launch positions >= tail_first -- are cut into tail_q sub-slices of tail_chunk k each, which run as the
   // extra z layers splitk_base .. splitk - 1 (positions < tail_first leave at once there) and write partial slots of their own
   int splitk_base, tail_q, tail_first, tail_chunk;
+  // fused split-K reduction of the Schur syrk (set by the launcher): the slices of a tile count their arrivals in tile_cnt[launch
+  // position]; the last one to arrive adds the partial sums in slice order (the sums of splitk_reduce_kernel) and writes C
+  int* tile_cnt;
 };
 
 // Launcher state that belongs to the caller's context (one per hyp_ctx, i.e. per device and stream pair): the split-K
@@ -80,10 +83,13 @@ struct GemmScratch {
   size_t splitk_ws_bytes = 0;
   int* tile_map = nullptr;     // (tm, tn) per launch position, then the inverse: launch position per tile tm + tn * T
   int tile_map_T = -1;
+  int* tile_cnt = nullptr;     // arrival counters of the fused split-K reduction (zero between launches: the last arrival resets its tile's)
+  long tile_cnt_n = 0;
   void release() {
     if (splitk_ws) (void)hipFree(splitk_ws);
     if (tile_map) (void)hipFree(tile_map);
-    splitk_ws = nullptr; splitk_ws_bytes = 0; tile_map = nullptr; tile_map_T = -1;
+    if (tile_cnt) (void)hipFree(tile_cnt);
+    splitk_ws = nullptr; splitk_ws_bytes = 0; tile_map = nullptr; tile_map_T = -1; tile_cnt = nullptr; tile_cnt_n = 0;
   }
 };
 

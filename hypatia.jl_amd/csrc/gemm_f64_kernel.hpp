@@ -253,6 +253,57 @@ void gemm_f64_kernel(GemmArgs p) {
   const bool upper = (p.tri != GEMM_FULL);
   if (p.splitk > 1) {   // raw partial sums; alpha / beta / epilogue are applied by splitk_reduce_kernel
     double* __restrict__ W = p.part + ((long)bz * p.splitk + blockIdx.z) * p.part_stride;   // [batch member][slice] (one matrix: bz = 0)
+    if (TAG == 1 && p.tile_cnt != nullptr) {
+      // Round 6: the reduction rides in this launch.  Partial sums leave as device-coherent (write-through) stores -- the slices of a
+      // tile run on different XCDs, whose L2s do not see each other's dirty lines --; a workgroup waits for its stores, counts itself
+      // in, and the LAST slice of a tile to arrive adds the partial sums in slice order -- the very sums of splitk_reduce_kernel -- from
+      // device-coherent loads and writes C.  What that kernel did in 0.2 ms behind the product now hides under other tiles' MFMAs.
+#pragma unroll
+      for (int j = 0; j < TW; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + wn * WT + j * 16 + fk + 4 * r;
+          if (n >= p.N) continue;
+#pragma unroll
+          for (int i = 0; i < TW; ++i) {
+            const int m = m0 + wm * WT + i * 16 + fr;
+            if (m >= p.M || (upper && m > n + p.tri_off)) continue;
+            __hip_atomic_store(&W[(long)n * p.part_ld + m], acc[j][i][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __shared__ int last_in;
+      __syncthreads();
+      if (tid == 0) {
+        const int expect = (p.tail_q > 1 && (int)blockIdx.x >= p.tail_first) ? p.splitk_base - 1 + p.tail_q : p.splitk_base;
+        const int old = __hip_atomic_fetch_add(&p.tile_cnt[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_in = (old == expect - 1) ? 1 : 0;
+        if (last_in) __hip_atomic_store(&p.tile_cnt[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (ready for the next launch)
+      }
+      __syncthreads();
+      if (!last_in) return;
+      const int S = p.splitk_base;
+      const int S_extra = (p.tail_q > 1 && (int)blockIdx.x >= p.tail_first) ? p.tail_q - 1 : 0;
+      const double* __restrict__ P0 = p.part + (long)bz * p.splitk * p.part_stride;
+#pragma unroll
+      for (int j = 0; j < TW; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + wn * WT + j * 16 + fk + 4 * r;
+          if (n >= p.N) continue;
+#pragma unroll
+          for (int i = 0; i < TW; ++i) {
+            const int m = m0 + wm * WT + i * 16 + fr;
+            if (m >= p.M || (upper && m > n + p.tri_off)) continue;
+            const long off = (long)n * p.part_ld + m;
+            double s = 0.0;
+            for (int z = 0; z < S + S_extra; ++z) s += __hip_atomic_load(&P0[(long)z * p.part_stride + off], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double* cp = C + (long)n * p.ldc + m;
+            *cp = p.alpha * s + (p.beta != 0.0 ? p.beta * (*cp) : 0.0);
+          }
+        }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < TW; ++j)
 #pragma unroll
@@ -573,6 +624,21 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch*
   if (gs && a.tag == 1 && a.tri == GEMM_UPPER && !small && a.batch == 1 && nblk >= 64) a.tile_map = upper_tile_map(*gs, a.tiles_n, nblk);
   if (a.tail_q > 1 && !a.tile_map) { a.splitk = a.splitk_base; a.tail_q = 1; }
   dim3 grid((unsigned)nblk, (unsigned)a.batch, (unsigned)a.splitk);
+  // (round 6, HYP_SYRK_FUSED_REDUCE=1) the Schur syrk's split-K reduction inside the product's launch: see the kernel's epilogue.
+  // Bitwise the separate kernel's matrix, but SLOWER (config 2: syrk phase 8.59 - 8.63 ms against 8.44 - 8.46 with the reduction kernel's
+  // 0.2 ms included, same box, alternating): 64 write-through 8-byte stores per lane instead of stores the L2 merges, and a tile's
+  // 640 KB of partial sums fetched by ONE workgroup at its latency.  Default off (EXPERIMENTS.md r06-9).
+  a.tile_cnt = nullptr;
+  static const bool fuse_red = [] { const char* e = getenv("HYP_SYRK_FUSED_REDUCE"); return e && atoi(e) == 1; }();
+  if (fuse_red && gs && a.splitk > 1 && a.tag == 1 && transa && !small && a.batch == 1 && a.tile_map) {
+    if (gs->tile_cnt_n < nblk) {
+      if (gs->tile_cnt) (void)hipFree(gs->tile_cnt);
+      gs->tile_cnt = nullptr; gs->tile_cnt_n = 0;
+      if (hipMalloc((void**)&gs->tile_cnt, (size_t)nblk * sizeof(int)) == hipSuccess && hipMemset(gs->tile_cnt, 0, (size_t)nblk * sizeof(int)) == hipSuccess)
+        gs->tile_cnt_n = nblk;
+    }
+    if (gs->tile_cnt_n >= nblk) a.tile_cnt = gs->tile_cnt;
+  }
   if (a.tag == 1 && transa && !small) {
     hipLaunchKernelGGL((gemm_f64_kernel<true, 4, 1>), grid, dim3(GEMM_THREADS), 0, st, a);
   } else if (transa) {
@@ -582,7 +648,7 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch*
     if (small) hipLaunchKernelGGL((gemm_f64_kernel<false, 2, 0>), grid, dim3(GEMM_THREADS), 0, st, a);
     else hipLaunchKernelGGL((gemm_f64_kernel<false, 4, 0>), grid, dim3(GEMM_THREADS), 0, st, a);
   }
-  if (a.splitk > 1)
+  if (a.splitk > 1 && a.tile_cnt == nullptr)
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((a.M + 255) / 256, a.N, a.batch), dim3(256), 0, st, a.M, a.N, a.tri != GEMM_FULL ? 1 : 0, a.tri_off,
                        a.splitk_base, a.part, a.part_ld, a.part_stride, a.alpha, a.beta, a.C, a.ldc, a.tail_q - 1, a.tail_first,
                        a.tile_map ? a.tile_map + 2 * nblk : nullptr, a.tiles_n, (long)a.splitk * a.part_stride, a.strideC);

@@ -283,3 +283,46 @@ def test_paired_third_order_terms_change_no_bit(name):
     assert on["iters"] == off["iters"] >= 8
     assert on["trace"] == off["trace"], name
     assert on["trials"] == off["trials"]
+
+
+SYRK_SNIPPET = r"""
+import ctypes, hashlib, json, sys
+import numpy as np
+sys.path.insert(0, %r)
+from hypatia_jl_amd import _lib as L
+lib = L.lib()
+ctx = ctypes.c_void_p()
+assert lib.hyp_ctx_create(0, ctypes.byref(ctx)) == 0
+N, K = int(sys.argv[1]), int(sys.argv[2])
+rng = np.random.default_rng(N + K)
+A = np.asfortranarray(rng.standard_normal((K, N), dtype=np.float32).astype(np.float64))
+fp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+out = []
+for rep in range(3):
+    C = np.full((N, N), 3.0, order="F")
+    L.check(lib.hyp_dense_syrk(ctx, N, K, fp(A), K, fp(C), N), "syrk")
+    out.append(hashlib.sha256(C.tobytes()).hexdigest())
+cols = [0, 127, 128, N // 2, N - 1]
+ref = A.T @ A[:, cols]
+err = max(float(np.max(np.abs(C[:c + 1, c] - ref[:c + 1, t]))) for t, c in enumerate(cols))
+print(json.dumps({"hashes": out, "err": err, "scale": float(np.max(np.abs(ref)))}))
+"""
+
+
+@pytest.mark.parametrize("N,K", [(1300, 4100), (2056, 8200), (5000, 20100)])
+def test_syrk_reduction_inside_the_product_changes_no_bit(N, K):
+    """round 6, HYP_SYRK_FUSED_REDUCE=1 (measured slower than the reduction kernel, default off; csrc/gemm_f64_kernel.hpp): the split-K slices of the Schur syrk (dense.jl:80-86,
+    qrchol.jl:234) count their arrivals per tile and the last one adds the partial sums -- in slice order, from device-coherent
+    loads -- and writes C, instead of a reduction kernel behind the product.  Same sums in the same order: the matrix must be the
+    separate kernel's to the last bit, launch after launch (an arrival counted before its partial sums were visible would show as a
+    changing hash), at sizes with and without the cut last round (tail sub-slices) and the thin edge columns"""
+    runs = {}
+    for v in ("1", "0"):
+        env = dict(os.environ, HYP_SYRK_FUSED_REDUCE=v)
+        env.setdefault("HYP_PERSISTENT", "1")
+        r = subprocess.run([sys.executable, "-c", SYRK_SNIPPET % ROOT, str(N), str(K)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs[v] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert len(set(runs["1"]["hashes"])) == 1 and len(set(runs["0"]["hashes"])) == 1
+    assert runs["1"]["hashes"][0] == runs["0"]["hashes"][0]
+    assert runs["1"]["err"] <= 1e-12 * K * max(1.0, runs["1"]["scale"])
