@@ -101,7 +101,7 @@ def pmc_traffic(n, q):
     """HBM bytes per syrk launch from the committed PMC passes (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE); only
     valid for the configuration they were collected on, else None."""
     try:
-        for rnd in ("r05", "r04"):   # (the newest committed passes)
+        for rnd in ("r06", "r05", "r04"):   # (the newest committed passes)
             path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", rnd + "_pmc_summary.json")
             if not os.path.exists(path):
                 continue
@@ -467,6 +467,12 @@ def run_headline(args, world, rank, local_rank, multi, comm=None):
     from threadpoolctl import threadpool_limits
     if args.config == "4":      # the multi-GPU workload on one GPU: the same blocks from the same streams
         side4, nc4 = 80, 64
+        # HYP_BENCH_RANK_SHARE=N (diagnostic, docs/MULTIGPU.md): only the first 64 / N blocks -- the cones ONE rank of N holds -- so that the
+        # phases of this line are what a rank computes per iteration at N ranks, minus the exchanges.  A different (smaller) model: its
+        # phase times are the measurement, not its iterations/s; the line says so in config.workload.
+        share = int(os.environ.get("HYP_BENCH_RANK_SHARE", "1"))
+        if share > 1:
+            nc4 = max(1, 64 // share)
         dim4 = side4 * (side4 + 1) // 2
         G = np.empty((dim4 * nc4, args.n), order="F")
         for k in range(nc4):
@@ -559,13 +565,16 @@ def run_headline(args, world, rank, local_rank, multi, comm=None):
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": ("configs[1]: single PosSemidefTri side=%d (q=%d), dense random G q x n, n=%d, p=0" % (args.side, q, args.n)) if args.config == "2"
-                               else ("configs[3]: 64 x PosSemidefTri side=80 (q=%d), dense random G q x n, n=%d, p=0, all cones on one GPU" % (q, args.n)),
+                               else (("configs[3]: 64 x PosSemidefTri side=80 (q=%d), dense random G q x n, n=%d, p=0, all cones on one GPU" % (q, args.n))
+                                     if int(os.environ.get("HYP_BENCH_RANK_SHARE", "1")) <= 1 else
+                                     ("RANK-SHARE EMULATION (HYP_BENCH_RANK_SHARE=%s): the first %d of configs[3]'s 64 PosSemidefTri(80) blocks (q=%d), n=%d -- the cones one "
+                                      "rank holds; a different model, read its phases_ms_per_step only" % (os.environ["HYP_BENCH_RANK_SHARE"], q // 3240, q, args.n))),
                    "n": args.n, "q": q, "seed": args.seed, "algorithm": algorithm_record(),
                    **({"parallelism": "K-panel shard of the Schur product x%d, model replicated; one RCCL all-reduce (sum, f64, n x n) per iteration" % world}
                       if comm is not None else {})},
         "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<true, 4, 1> (Schur syrk, upper)", "achieved": achieved,
                      "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                     "traffic": pmc_traffic(args.n, q), "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 PMC, profiles/r05_pmc_summary.json; r04_ if absent)",
+                     "traffic": pmc_traffic(args.n, q), "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 PMC, profiles/r06_pmc_summary.json; r05_ / r04_ if absent)",
                      "launch_ms": syrk_ms, "flops_per_launch": syrk_flops},
         "phases_ms_per_step": {"sqrt_hess_prod": ks[0] / args.steps, "syrk": ks[1] / args.steps, "cholesky": ks[2] / args.steps,
                                "update_lhs": solver.time_upsys / args.steps * 1e3, "get_directions": solver.time_getdir / args.steps * 1e3,

@@ -783,13 +783,14 @@ void SysSolver::get_directions2(double* h_dirs, const double* h_rhss, double mu,
 // host's order (no contraction: the host code is compiled for x86-64 without FMA).  const_mode: dot_const = sc[4] + sc[5] (the
 // constant column came out of THIS solve: its two scalar products are the third column's) instead of the argument.
 // base_on: the direction's scalars are base - (the solve's) (refinement: dir = dir_best - correction).
-struct TauArgs { double rs_tau[2], rs_kap[2], base_tau[2], base_kap[2]; double mu, taubar, dot_const; int nr, const_mode, base_on; };
+struct TauArgs { double rs_tau[2], rs_kap[2], base_tau[2], base_kap[2]; double mu, taubar, dot_const, seq; int nr, const_mode, base_on; };
 __global__ void cols_tau_kernel(double* __restrict__ sc, TauArgs a) {
 #pragma clang fp contract(off)
   if (threadIdx.x != 0) return;
   double dc = a.dot_const;
   if (a.const_mode) dc = sc[SysSolver::SC_SOLVE + 4] + sc[SysSolver::SC_SOLVE + 5];
   sc[SysSolver::SC_DOTC] = dc;
+  sc[SysSolver::SC_SEQ] = a.seq;   // (the stamp the host's wait on the pinned mirror looks for: SysSolver::wait_scalars)
   const double m2 = a.mu / a.taubar / a.taubar;
   for (int r = 0; r < a.nr; ++r) {
     const double dot_sub = sc[SysSolver::SC_SOLVE + 2 * r] + sc[SysSolver::SC_SOLVE + 2 * r + 1];
@@ -897,6 +898,7 @@ void SysSolver::cols_solve(double* sol, const double* rhs, int nr, const Scal* r
       if (base) { a.base_tau[r] = base[r].tau; a.base_kap[r] = base[r].kap; }
     }
     a.mu = mu; a.taubar = taubar; a.dot_const = dot_const; a.nr = nr; a.const_mode = own_const ? 1 : 0; a.base_on = base ? 1 : 0;
+    a.seq = (double)(++sc_seq);
     hipLaunchKernelGGL(cols_tau_kernel, dim3(1), dim3(64), 0, ctx.stream, sc, a);
     HYP_CHECK(hipGetLastError());
     for (int r = 0; r < nr; ++r) { k.k0[r] = 1.0; k.p1[r] = sc + SC_CSC + 2 * r; }
@@ -1059,6 +1061,38 @@ void SysSolver::cols_read_scalars() {
   ctx.d2h(ctx.h_sc(), d_sc.d(), SC_N * sizeof(double));
 }
 
+// The host's wait for the scalars of the solve it queued last (resident flow).  A stream synchronisation blocks in the runtime until
+// the queue's completion signal has travelled back -- tens of microseconds, and far more under a profiler --, while the device sits
+// idle; the mirror block itself tells when it has landed: its last word is the solve's sequence number, stamped on the device by
+// cols_tau_kernel and copied with the block (writes of one copy reach host memory in order: when the last word is there, the block
+// is, and so is everything queued in front of the copy).  The host spins on that word; every few thousand spins it asks the stream
+// for an error (a faulted queue would never deliver the stamp), and a stream found idle with the old stamp is an error too.
+void SysSolver::wait_scalars() {
+  static const bool poll_on = [] { const char* e = getenv("HYP_DIR_POLL"); return !(e && e[0] == '0'); }();
+  if (!poll_on) { ctx.sync(); return; }
+  volatile const double* seqp = ctx.h_sc() + SC_SEQ;
+  const double want = (double)sc_seq;
+  unsigned spins = 0;
+  int idle_seen = 0;
+  while (*seqp != want) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xFFFu) == 0) {
+      const hipError_t e = hipStreamQuery(ctx.stream);
+      if (e == hipSuccess) {
+        if (++idle_seen > 4) {   // (the queue has drained and the stamp is not ours: take the runtime's word and re-read)
+          ctx.sync();
+          HYP_REQUIRE(*seqp == want, "step_directions: the scalar mirror was not updated by the queued solve");
+          break;
+        }
+      } else if (e != hipErrorNotReady) {
+        HYP_CHECK(e);
+      }
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  if (ctx.ol_abort_host && *ctx.ol_abort_host) ctx.check_persistent_abort();
+}
+
 void SysSolver::cols_finish(int nr, const Scal* rs, double mu, double taubar, bool resident, Scal* dsc, Scal* rsc, double* res_norms) {
   const double* hp = ctx.h_sc();
   for (int r = 0; r < nr; ++r) {
@@ -1107,7 +1141,8 @@ void SysSolver::refine_cols(double* rhs, double* dir, double* res, const Scal* r
     for (int r = 0; r < nr; ++r) dev_axpby(ctx, dv, 1.0, tmp + o + (long)r * dv, -1.0, dir + o + (long)r * dv);
     cols_residual(res + o, dir + o, rhs + o, nr, csc, resident, true, both);
     cols_read_scalars();
-    ctx.sync();
+    if (resident) wait_scalars();
+    else ctx.sync();
     Scal rsc2[MR];
     double nn[MR];
     cols_finish(nr, rs + c0, mu, taubar, resident, csc, rsc2, nn);
@@ -1137,7 +1172,7 @@ void SysSolver::refine_cols(double* rhs, double* dir, double* res, const Scal* r
 // two right-hand sides already on the device (rhs2 = two Point vectors, tau / kap slots zero, scalars in rs): directions are left
 // in m_dir, their residuals in m_res, the scalars in d_sc (and, queued, in its pinned mirror)
 void SysSolver::pair_enqueue(double* rhs, const Scal* rs, double mu, double taubar, int max_ref_steps, bool with_const, bool joint_const,
-                             bool resident, Scal* dsc_host) {
+                             bool resident, Scal* dsc_host, bool read_scalars) {
   const size_t d = sizeof(double);
   const int dv = dimv(), it = n + p + q, ik = dv - 1;
   HYP_REQUIRE(p == 0, "pair_solve_device: p = 0 only");
@@ -1155,7 +1190,7 @@ void SysSolver::pair_enqueue(double* rhs, const Scal* rs, double mu, double taub
   const bool both = (max_ref_steps > 0) && gemv_both_ok(q, n, G.d(), q);
   cols_solve(dir, rhs, MR, rs, mu, taubar, with_const, joint_const, resident, both, nullptr, dsc_host);
   if (max_ref_steps > 0) cols_residual(res, dir, rhs, MR, dsc_host, resident, false, both);
-  cols_read_scalars();
+  if (read_scalars) cols_read_scalars();
 }
 
 void SysSolver::pair_finish(double* rhs, const Scal* rs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
@@ -1441,7 +1476,7 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   int ns = 0;
   build_rhs_pair(0, m_rhs.d(), s_point.d(), mu, tau, kap, tau_residual, nullptr, nullptr, reinterpret_cast<double*>(rs), true);
   pair_enqueue(m_rhs.d(), rs, mu, tau, max_ref_steps, const3, joint, true, dsc);
-  ctx.sync();
+  wait_scalars();   // (the factorization's info word was copied in front of the scalars: it has landed with them)
   // (the device is idle from here until the second pair's first launches arrive: nothing that can wait is done before them --
   //  the phases' event times are read at the end of the call)
   const auto tf0 = std::chrono::steady_clock::now();
@@ -1539,14 +1574,17 @@ void SysSolver::step_directions_rest(bool resident, double tau, double kap, doub
   if (!dirs_copied_ev) HYP_CHECK(hipEventCreateWithFlags(&dirs_copied_ev, hipEventDisableTiming));
   HYP_CHECK(hipEventRecord(dirs_copied_ev, ctx.stream));
   ns = 0;
-  pair_enqueue(m_rhs.d(), rs, mu, tau, max_ref_steps, false, false, resident, dsc);
-  // (the raw directions travel to the host and to the resident block under the same synchronisation; a refined pair is copied again below)
+  pair_enqueue(m_rhs.d(), rs, mu, tau, max_ref_steps, false, false, resident, dsc, false);
+  // (the raw directions travel to the host and to the resident block IN FRONT of the scalars: when those have landed, so have they;
+  //  a refined pair is copied again below)
   ctx.d2h(hs_dirs + (long)MR * dv, m_dir.d(), (size_t)MR * dv * d);
   ctx.d2d(s_dirs.d() + (long)MR * dv, m_dir.p, (size_t)MR * dv * d);
+  cols_read_scalars();
   // the first pair's directions reach the caller's (pageable) block while the device works on the second pair
   HYP_CHECK(hipEventSynchronize(dirs_copied_ev));
   std::memcpy(h_dirs, hs_dirs, (size_t)MR * dv * d);
-  ctx.sync();
+  if (resident) wait_scalars();
+  else ctx.sync();
   const int ns_before = ns;
   pair_finish(m_rhs.d(), rs, mu, tau, max_ref_steps, res_norm_cutoff, min_impr_tol, false, false, resident, dsc, rn, &ns);
   *n_solves += ns;

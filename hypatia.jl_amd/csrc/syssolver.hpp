@@ -225,7 +225,9 @@ struct SysSolver {
   // d_sc: [0, 6) solve dots (c'x, h'z per column), [8, 12) residual dots, [12, 14) residual maxima, [16, 20) tau / kap of the
   // direction per column, [20] dot_const, [24, 28) tau / kap of the last solve_system per column; mirrored to ctx.h_sc().
   DBuf d_sc;
-  enum { SC_SOLVE = 0, SC_RESD = 8, SC_AMAX = 12, SC_DSC = 16, SC_DOTC = 20, SC_CSC = 24, SC_N = 32, SC_WORK = 64, SC_TOTAL = 64 + 3 * 33 + 5 };
+  enum { SC_SOLVE = 0, SC_RESD = 8, SC_AMAX = 12, SC_DSC = 16, SC_DOTC = 20, SC_CSC = 24, SC_SEQ = 31, SC_N = 32, SC_WORK = 64, SC_TOTAL = 64 + 3 * 33 + 5 };
+  unsigned long sc_seq = 0;   // sequence number of the last solve queued with device scalars (stamped into d_sc[SC_SEQ] by its tau kernel)
+  void wait_scalars();        // host: until the pinned mirror carries that solve's stamp (HYP_DIR_POLL=0: a stream synchronisation)
   void ensure_d_sc();
   bool dirs_resident() const;   // HYP_DIR_RESIDENT (default on): single process, p = 0
   // solve_system (common.jl:129-182) for nr columns: rhs -> sol (Point layout, columns dimv() apart); base != null: the
@@ -241,7 +243,7 @@ struct SysSolver {
   void refine_cols(double* rhs, double* dir, double* res, const Scal* rs, Scal* dsc, Scal* rsc, double* res_norms, double mu, double taubar,
                    int max_ref_steps, double res_norm_cutoff, double min_impr_tol, int* n_solves, bool resident);
   void pair_enqueue(double* rhs2, const Scal* rs, double mu, double taubar, int max_ref_steps, bool with_const, bool joint_const,
-                    bool resident, Scal* dsc_host);
+                    bool resident, Scal* dsc_host, bool read_scalars = true);
   void pair_finish(double* rhs2, const Scal* rs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff, double min_impr_tol,
                    bool with_const, bool joint_const, bool resident, Scal* dsc, double* res_norms, int* n_solves);
   static bool const3_on();    // HYP_CONST_COL3 (default on)

@@ -250,6 +250,7 @@ def compare(ht, ot, pt, mu_alpha=1e-7, mu_tight=1e-3, tight=1e-10, label=""):
         raise AssertionError("%s: step size differs at iterate %d where the oracle is stable: HIP alpha %.6g, oracle %.6g (mu %.3e); "
                              "alphas HIP %s / oracle %s" % (label, i, H[i, 8], O[i, 8], O[i, 7], H[:k, 8].tolist(), O[:k, 8].tolist()))
     worst = {}
+    margin = {}   # per column: (largest deviation / its bar while mu >= mu_tight, largest deviation / 100x-sensitivity limit on the prefix): < 1 passes
     for col, cname in ((0, "p_obj"), (1, "d_obj"), (7, "mu"), (5, "tau"), (3, "x_feas"), (4, "z_feas")):
         # residual norms sit at rounding level once the iterate is feasible: compare them relative to the model's scale 1
         scale = np.abs(O[:kp, col]) + (1e-300 if col in (0, 1, 5, 7) else 1e-6)
@@ -267,7 +268,9 @@ def compare(ht, ot, pt, mu_alpha=1e-7, mu_tight=1e-3, tight=1e-10, label=""):
         lim = 100 * np.maximum.accumulate(np.maximum(floor, 1e-13))
         assert np.all(dev <= lim), "%s: %s beyond 100x the oracle's own 1-ulp sensitivity: %s vs %s" % (label, cname, dev, lim)
         worst[cname] = float(dev[well].max()) if well.any() else 0.0
-    return dict(prefix=kp, iters_hip=len(H) - 1, iters_oracle=len(O) - 1, worst=worst)
+        margin[cname] = (float((dev[well] / bar[well]).max()) if well.any() else 0.0, float((dev / lim).max()) if len(dev) else 0.0,
+                         float(np.maximum.accumulate(floor)[well].max()) if well.any() else 0.0)
+    return dict(prefix=kp, iters_hip=len(H) - 1, iters_oracle=len(O) - 1, worst=worst, margin=margin)
 
 
 if __name__ == "__main__":

@@ -5,15 +5,15 @@ R=$GRAFT_REPO_ROOT
 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 python bench.py > gpurun_out/bench_cfg2_1gpu.json 2> gpurun_out/bench_cfg2_1gpu.err; tail -c 300 gpurun_out/bench_cfg2_1gpu.json
+python bench.py --steps 220 --cpu-iters 0 2>/dev/null | tail -1 > gpurun_out/bench_cfg2_220steps.json
 rm -f gpurun_out/other_configs.jsonl
 for c in 3b 5p 5d; do python bench.py --config $c 2>/dev/null | tail -1 >> gpurun_out/other_configs.jsonl; done
-for v in 1 0 1 0; do HYP_ENS_FUSED=$v HYP_ENS_DUAL_DECIDE=$v python bench.py --config 3b --cpu-iters 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('3b one-workgroup kernels + bound-decided dual test = $v:', round(d['ms_per_step'],3), d['phases_ms_per_step'])"; done > gpurun_out/cfg3b_fused_ab.txt; cat gpurun_out/cfg3b_fused_ab.txt
 python bench.py --config 4 2>/dev/null | tail -1 > gpurun_out/bench_cfg4_1gpu.json
 HYP_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --config 4 --no-secondary 2>/dev/null | tail -1 > gpurun_out/bench_cfg4_rccl_world1.json
 python -c "
 import json
-for l in open('gpurun_out/other_configs.jsonl'): d=json.loads(l); print(d['config']['workload'][:50], d['ms_per_step'], d['roofline']['frac'], d['roofline']['executed_frac'], d.get('solve_plans'))
-for f in ('bench_cfg4_1gpu','bench_cfg4_rccl_world1'):
+for l in open('gpurun_out/other_configs.jsonl'): d=json.loads(l); print(d['config']['workload'][:50], d['ms_per_step'], d['roofline']['frac'], d['roofline'].get('executed_frac'), d.get('solve_plans'))
+for f in ('bench_cfg2_220steps','bench_cfg4_1gpu','bench_cfg4_rccl_world1'):
     d=json.loads(open('gpurun_out/%s.json'%f).read()); print(f, d['ms_per_step'], d['roofline']['frac'], d['phases_ms_per_step'])"
 cd /tmp; rm -rf /tmp/prof2; rocprofv3 --kernel-trace --stats -d /tmp/prof2 -o b -- python $R/bench.py --steps 40 > $R/gpurun_out/bench_under_profiler.json 2>/dev/null; cd $R
 DB2=$(find /tmp/prof2 -name "*.db" | head -1)
@@ -23,7 +23,6 @@ python tools/rocpd_timeline.py $DB2 "splitk_reduce_kernel" 140 > gpurun_out/chol
 for c in 3b 5p 5d 4; do rm -rf /tmp/prof_$c; cd /tmp; rocprofv3 --kernel-trace --stats -d /tmp/prof_$c -o b -- python $R/bench.py --config $c $( [ $c = 4 ] && echo "--steps 6 --warmup 2" ) > /dev/null 2>&1; cd $R; python tools/rocpd_stats.py $(find /tmp/prof_$c -name "*.db" | head -1) 2>/dev/null | head -25 > gpurun_out/cfg${c}_kernel_stats.csv; done
 python tools/bench_potrf.py > gpurun_out/bench_potrf.txt 2>&1; cat gpurun_out/bench_potrf.txt
 python tools/bench_trsv.py 5000 4845 2250 999 > gpurun_out/bench_trsv.txt 2>&1; cat gpurun_out/bench_trsv.txt
-(python tools/bench_bk.py nearpd 4845; python tools/bench_bk.py indef 5000) 2>&1 | grep device > gpurun_out/bench_bk.txt; cat gpurun_out/bench_bk.txt
 # PMC passes: one counter group per run, kernel trace only (no other trace domains)
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   tag=$(echo $grp | cut -d' ' -f1); [ $tag = SQ_VALU_MFMA_BUSY_CYCLES ] && tag=SQ_GRBM; rm -rf /tmp/pmc_$tag
@@ -31,3 +30,10 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GR
   python tools/rocpd_pmc.py $(find /tmp/pmc_$tag -name "*.db" | head -1) > gpurun_out/pmc_$tag.txt 2>&1; head -12 gpurun_out/pmc_$tag.txt
 done
 python tools/pmc_summarize.py gpurun_out/pmc
+# LDS bank conflicts of the GEMM instances (config 5 primal: the 64 x 64-tile instance; config 2: the Schur syrk)
+for cfg in 5p 2; do
+  rm -rf /tmp/pmc_lds_$cfg; cd /tmp
+  rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-include-regex "gemm_f64_kernel|trsm_diag_refined_fwd_batched" -d /tmp/pmc_lds_$cfg -o b -- python $R/bench.py --config $cfg --steps 2 --warmup 1 --cpu-iters 0 > /dev/null 2>&1; cd $R
+  python tools/rocpd_pmc.py $(find /tmp/pmc_lds_$cfg -name "*.db" | head -1) > gpurun_out/pmc_lds_cfg$cfg.txt 2>&1; head -8 gpurun_out/pmc_lds_cfg$cfg.txt
+done
+python tools/parity_margins.py > gpurun_out/parity_margins.txt 2>&1; tail -50 gpurun_out/parity_margins.txt
