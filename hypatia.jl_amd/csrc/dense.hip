@@ -1518,6 +1518,12 @@ Ctx::Ctx(int dev) : device(dev) {
   HYP_CHECK(hipHostMalloc((void**)&h_info, (8192 + 16) * sizeof(int), hipHostMallocDefault));   // [0..63] general; [64 + 2 k, 64 + 2 k + 1] cone k of a batched feasibility sweep; [H_INFO_FACT]: the system solver's factorization
   h_pinned_n = 1 << 16;
   HYP_CHECK(hipHostMalloc((void**)&h_pinned, (h_pinned_n + H_SC_N) * sizeof(double), hipHostMallocDefault));   // (+ the mirror of the direction solves' scalars behind the general staging: h_sc())
+  {
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, h_pinned, 0) == hipSuccess && dp) h_sc_dev = reinterpret_cast<double*>(dp) + h_pinned_n;
+    else (void)hipGetLastError();
+    for (int i = 0; i < H_SC_N; ++i) h_sc()[i] = 0.0;
+  }
 }
 void Ctx::check_persistent_abort() {
   if (!ol_abort_host || !*ol_abort_host) return;

@@ -790,7 +790,6 @@ __global__ void cols_tau_kernel(double* __restrict__ sc, TauArgs a) {
   double dc = a.dot_const;
   if (a.const_mode) dc = sc[SysSolver::SC_SOLVE + 4] + sc[SysSolver::SC_SOLVE + 5];
   sc[SysSolver::SC_DOTC] = dc;
-  sc[SysSolver::SC_SEQ] = a.seq;   // (the stamp the host's wait on the pinned mirror looks for: SysSolver::wait_scalars)
   const double m2 = a.mu / a.taubar / a.taubar;
   for (int r = 0; r < a.nr; ++r) {
     const double dot_sub = sc[SysSolver::SC_SOLVE + 2 * r] + sc[SysSolver::SC_SOLVE + 2 * r + 1];
@@ -1056,20 +1055,41 @@ void SysSolver::cols_residual(double* res, const double* dir, const double* rhs,
   }
 }
 
+// The scalar block written into the pinned mirror by ONE wavefront: every word but the stamp, a system-scope fence, then the stamp --
+// so that a host that sees the stamp sees the block.  (First form of round 6: a plain copy of the block with the stamp as its last
+// word.  A copy kernel's lanes store independently and their writes reach host memory in no particular order: one solve in ~50 read
+// a stale word and took another path -- tools/stress_determinism.py, EXPERIMENTS r06-11.)
+__global__ __launch_bounds__(64) void publish_scalars_kernel(const double* __restrict__ sc, double* __restrict__ mirror, double seq) {
+  const int i = threadIdx.x;
+  if (i < SysSolver::SC_N && i != SysSolver::SC_SEQ)
+    __hip_atomic_store(mirror + i, sc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  if (i == 0) __hip_atomic_store(mirror + SysSolver::SC_SEQ, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+static bool dir_poll_on() {
+  static const bool on = [] { const char* e = getenv("HYP_DIR_POLL"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 void SysSolver::cols_read_scalars() {
   if (dist()) return;   // (the sharded residual has read and completed the mirror itself)
+  if (dir_poll_on() && ctx.h_sc_dev != nullptr) {
+    hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(64), 0, ctx.stream, d_sc.d(), ctx.h_sc_dev, (double)sc_seq);
+    HYP_CHECK(hipGetLastError());
+    return;
+  }
   ctx.d2h(ctx.h_sc(), d_sc.d(), SC_N * sizeof(double));
 }
 
 // The host's wait for the scalars of the solve it queued last (resident flow).  A stream synchronisation blocks in the runtime until
 // the queue's completion signal has travelled back -- tens of microseconds, and far more under a profiler --, while the device sits
-// idle; the mirror block itself tells when it has landed: its last word is the solve's sequence number, stamped on the device by
-// cols_tau_kernel and copied with the block (writes of one copy reach host memory in order: when the last word is there, the block
-// is, and so is everything queued in front of the copy).  The host spins on that word; every few thousand spins it asks the stream
+// idle; the mirror block itself tells when it has landed: its last word is the solve's sequence number, written by
+// publish_scalars_kernel BEHIND a system-scope fence (when the stamp is there, the block is, and so is everything queued in front
+// of that kernel).  The host spins on that word; every few thousand spins it asks the stream
 // for an error (a faulted queue would never deliver the stamp), and a stream found idle with the old stamp is an error too.
 void SysSolver::wait_scalars() {
-  static const bool poll_on = [] { const char* e = getenv("HYP_DIR_POLL"); return !(e && e[0] == '0'); }();
-  if (!poll_on) { ctx.sync(); return; }
+  if (!dir_poll_on() || ctx.h_sc_dev == nullptr) { ctx.sync(); return; }
   volatile const double* seqp = ctx.h_sc() + SC_SEQ;
   const double want = (double)sc_seq;
   unsigned spins = 0;

@@ -131,6 +131,7 @@ struct Ctx {
   size_t h_pinned_n = 0;
   static constexpr int H_SC_N = 128;         // pinned mirror of the direction solves' device scalars (SysSolver::d_sc), behind the general staging
   double* h_sc() const { return h_pinned + h_pinned_n; }
+  double* h_sc_dev = nullptr;   // the same block as the device addresses it (written by publish_scalars_kernel)
   double* h_stage = nullptr;    // growable pinned staging for large caller-owned vectors (see stage_host)
   size_t h_stage_n = 0;
   double* stage_host(size_t n_doubles);

@@ -94,3 +94,20 @@ def test_hip_path_reaches_the_known_minimum(case):
     # the model and two roundings of the same path end a few 1e-5 apart (iterate-level agreement: the trajectory tests)
     p_or = os_.get_primal_obj()
     assert abs(p_hip - p_or) <= 1e-6 * (1 + abs(p_or)) + 2 * abs(p_or - inst[6]["primal_obj"]), (p_hip, p_or, inst[6]["primal_obj"])
+
+
+@pytest.mark.gpu
+def test_hip_solve_is_the_same_run_after_run():
+    """40 solves of one instance in one process end at the same iterate, bit for bit.  (Round 6: the host reads the direction
+    solves' scalars from a pinned mirror as soon as a stamp says they have landed; with the stamp copied as the last word of a
+    plain block copy, one solve in ~50 read a stale word and took another path -- tools/stress_determinism.py.  The stamp is now
+    written behind a system-scope fence by the kernel that writes the block.)"""
+    import hypatia_jl_amd as H
+    inst = I.polymin_named("rosenbrock", 5, True, True)
+    seen = set()
+    for _ in range(40):
+        hs = H.Solver(default_tol_relax=10, iter_limit=250)
+        hs.load(H.make_model(inst))
+        hs.solve()
+        seen.add((hs.get_num_iters(), float(hs.get_primal_obj())))
+    assert len(seen) == 1, seen

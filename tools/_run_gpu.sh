@@ -9,11 +9,12 @@ python bench.py --steps 220 --cpu-iters 0 2>/dev/null | tail -1 > gpurun_out/ben
 rm -f gpurun_out/other_configs.jsonl
 for c in 3b 5p 5d; do python bench.py --config $c 2>/dev/null | tail -1 >> gpurun_out/other_configs.jsonl; done
 python bench.py --config 4 2>/dev/null | tail -1 > gpurun_out/bench_cfg4_1gpu.json
+HYP_BENCH_RANK_SHARE=8 python bench.py --config 4 --steps 30 2>/dev/null | tail -1 > gpurun_out/bench_cfg4_rank_share8.json
 HYP_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --config 4 --no-secondary 2>/dev/null | tail -1 > gpurun_out/bench_cfg4_rccl_world1.json
 python -c "
 import json
 for l in open('gpurun_out/other_configs.jsonl'): d=json.loads(l); print(d['config']['workload'][:50], d['ms_per_step'], d['roofline']['frac'], d['roofline'].get('executed_frac'), d.get('solve_plans'))
-for f in ('bench_cfg2_220steps','bench_cfg4_1gpu','bench_cfg4_rccl_world1'):
+for f in ('bench_cfg2_220steps','bench_cfg4_1gpu','bench_cfg4_rank_share8','bench_cfg4_rccl_world1'):
     d=json.loads(open('gpurun_out/%s.json'%f).read()); print(f, d['ms_per_step'], d['roofline']['frac'], d['phases_ms_per_step'])"
 cd /tmp; rm -rf /tmp/prof2; rocprofv3 --kernel-trace --stats -d /tmp/prof2 -o b -- python $R/bench.py --steps 40 > $R/gpurun_out/bench_under_profiler.json 2>/dev/null; cd $R
 DB2=$(find /tmp/prof2 -name "*.db" | head -1)
