@@ -817,6 +817,11 @@ void SysSolver::ensure_d_sc() {
   ctx.zero(d_sc.p, SC_TOTAL * sizeof(double));   // (the tickets of the column maxima start at zero)
 }
 
+static bool dir_poll_on() {
+  static const bool on = [] { const char* e = getenv("HYP_DIR_POLL"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 bool SysSolver::dirs_resident() const {
   static const bool on = [] { const char* e = getenv("HYP_DIR_RESIDENT"); return !(e && e[0] == '0'); }();
   return on && p == 0 && !dist();
@@ -1059,23 +1064,22 @@ void SysSolver::cols_residual(double* res, const double* dir, const double* rhs,
 // so that a host that sees the stamp sees the block.  (First form of round 6: a plain copy of the block with the stamp as its last
 // word.  A copy kernel's lanes store independently and their writes reach host memory in no particular order: one solve in ~50 read
 // a stale word and took another path -- tools/stress_determinism.py, EXPERIMENTS r06-11.)
-__global__ __launch_bounds__(64) void publish_scalars_kernel(const double* __restrict__ sc, double* __restrict__ mirror, double seq) {
+__global__ __launch_bounds__(64) void publish_scalars_kernel(const double* __restrict__ sc, double* __restrict__ mirror, double seq,
+                                                             const int* __restrict__ fact_info) {
   const int i = threadIdx.x;
-  if (i < SysSolver::SC_N && i != SysSolver::SC_SEQ)
-    __hip_atomic_store(mirror + i, sc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (i < SysSolver::SC_N && i != SysSolver::SC_SEQ) {
+    // (slot SC_INFO: the info word of the factorization queued in front of this solve rides along -- the host reads it from the block)
+    const double v = (i == SysSolver::SC_INFO) ? (fact_info ? (double)fact_info[0] : 0.0) : sc[i];
+    __hip_atomic_store(mirror + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   __threadfence_system();
   if (i == 0) __hip_atomic_store(mirror + SysSolver::SC_SEQ, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-static bool dir_poll_on() {
-  static const bool on = [] { const char* e = getenv("HYP_DIR_POLL"); return !(e && e[0] == '0'); }();
-  return on;
 }
 
 void SysSolver::cols_read_scalars() {
   if (dist()) return;   // (the sharded residual has read and completed the mirror itself)
   if (dir_poll_on() && ctx.h_sc_dev != nullptr) {
-    hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(64), 0, ctx.stream, d_sc.d(), ctx.h_sc_dev, (double)sc_seq);
+    hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(64), 0, ctx.stream, d_sc.d(), ctx.h_sc_dev, (double)sc_seq, (const int*)d_info.p);
     HYP_CHECK(hipGetLastError());
     return;
   }
@@ -1496,7 +1500,8 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   int ns = 0;
   build_rhs_pair(0, m_rhs.d(), s_point.d(), mu, tau, kap, tau_residual, nullptr, nullptr, reinterpret_cast<double*>(rs), true);
   pair_enqueue(m_rhs.d(), rs, mu, tau, max_ref_steps, const3, joint, true, dsc);
-  wait_scalars();   // (the factorization's info word was copied in front of the scalars: it has landed with them)
+  wait_scalars();
+  if (dir_poll_on() && ctx.h_sc_dev != nullptr) ctx.h_info[Ctx::H_INFO_FACT] = (int)ctx.h_sc()[SC_INFO];   // (the info word came with the block)
   // (the device is idle from here until the second pair's first launches arrive: nothing that can wait is done before them --
   //  the phases' event times are read at the end of the call)
   const auto tf0 = std::chrono::steady_clock::now();

@@ -47,6 +47,14 @@ SysSolver::SysSolver(Ctx& c, int n_, int p_, int q_, const std::vector<Cone*>& c
 }
 
 // Runs of equal PSD cones: one arena per run, the members' matrices become views into it (see PsdCone::group_arena).
+SysSolver::~SysSolver() {
+  if (const char* e = getenv("HYP_RP_PREFETCH_STATS"))
+    if (e[0] == '1') fprintf(stderr, "[residual_products prefetch] handed out %ld, recomputed %ld\n", rp_pre_hits, rp_pre_misses);
+  if (rp_pre_host) (void)hipHostFree(rp_pre_host);
+  for (hipEvent_t e : {rp_pre_ev, plan_ev_fork, plan_ev_done, dirs_copied_ev})
+    if (e) (void)hipEventDestroy(e);
+}
+
 void SysSolver::make_psd_runs() {
   static const bool on = [] { const char* e = getenv("HYP_PSD_GROUP"); return !(e && e[0] == '0'); }();
   if (!on) return;
@@ -247,6 +255,7 @@ int SysSolver::run_hess_prod(size_t k, double* prod, long ldp, const double* arr
 void SysSolver::load(const double* hG, const double* hGQ1, const double* hGQ2, const double* hQ, const double* hR) {
   const size_t d = sizeof(double);
   s_resident = false;   // (resident directions belong to the G they were computed with)
+  rp_pre_valid = false;
   ctx.h2d(G.p, hG, (size_t)q * n * d);
   if (p > 0) {
     HYP_REQUIRE(hQ && hR, "sys: Q, R are required when p > 0");
@@ -533,6 +542,23 @@ void SysSolver::residual_products2(const double* h_x, const double* h_z, const d
                                    double* h_norms) {
   HYP_REQUIRE(model_loaded, "residual_products: load_model first");
   const size_t d = sizeof(double);
+  if (rp_pre_valid) {   // queued at accept time (prefetch_residual_products): valid only for exactly the point they were formed from
+    rp_pre_valid = false;
+    if (!h_norms && !dist() && q > 0 && rp_pre_cand.size() == 2 * (size_t)q + 2) {
+      HYP_CHECK(hipEventSynchronize(rp_pre_ev));
+      const double* pre = rp_pre_host;
+      if (std::memcmp(h_x, pre + n + 2 + q, (size_t)n * d) == 0 && std::memcmp(h_z, rp_pre_cand.data(), (size_t)q * d) == 0 &&
+          std::memcmp(h_s, rp_pre_cand.data() + q + 1, (size_t)q * d) == 0) {
+        std::memcpy(h_Gtz, pre, (size_t)n * d);
+        h_dots[0] = pre[n];
+        h_dots[1] = pre[n + 1];
+        std::memcpy(h_Gx_s, pre + n + 2, (size_t)q * d);
+        ++rp_pre_hits;
+        return;
+      }
+      ++rp_pre_misses;
+    }
+  }
   rp_x.ensure(std::max<size_t>(n, 1) * d);
   rp_t.ensure(((size_t)n + 2 + 2 + 2 * (size_t)std::max(comm_world_, 1)) * d);   // [G' z (n); h' z; z' s | the two local maxima | their slots]: ONE sum over the ranks
   for (DBuf* b : {&rp_z, &rp_s, &rp_g}) b->ensure(std::max<size_t>(q, 1) * d);
@@ -1003,6 +1029,7 @@ void SysSolver::load_model(const double* hc, const double* hb, const double* hh,
   screen_agreed = -1;
   gprev_acc_ = -1;
   s_resident = false;   // (the point and directions of an earlier model are not this model's)
+  rp_pre_valid = false;
 }
 
 // rhs_const = [-c; b; H h], sol_const = solve_subsystem3(rhs_const)   (qrchol.jl:191-197)
@@ -1784,6 +1811,64 @@ bool SysSolver::cand_scalars(const double* h, double min_prox, double prox_bound
   return true;
 }
 
+// the x rows of update_stepper_points (combined.jl:124-170) on the device: the host mirror's operations in the host mirror's order
+__global__ __launch_bounds__(256) void point_form_kernel(int n, const double* __restrict__ pt, const double* __restrict__ dc,
+                                                         const double* __restrict__ dp, const double* __restrict__ dca,
+                                                         const double* __restrict__ dpa, int mode, double al, double a2, double am1, double am1s,
+                                                         double* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double v;
+  if (mode == 0) v = pt[i] + al * dc[i];
+  else if (mode == 1) v = pt[i] + (al * dp[i] + am1 * dc[i]);
+  else if (mode == 2) v = pt[i] + (al * dc[i] + a2 * dca[i]);
+  else v = pt[i] + (((al * dp[i] + a2 * dpa[i]) + am1 * dc[i]) + am1s * dca[i]);
+  out[i] = v;
+}
+
+// Round 6: the products calc_convergence_params needs of the NEXT iterate (G' z, G x + s, h' z, z' s: residual_products) are queued
+// the moment a candidate is accepted -- z / s are the accepted candidate on the device, x is formed there with the host mirror's
+// roundings -- and run while the host does its end-of-iteration bookkeeping; residual_products hands them out if the point it is
+// called with is, bit for bit, the one they were formed from (the x it downloads, the candidate it kept), and computes as before
+// otherwise.  HYP_RP_PREFETCH=0: off.
+void SysSolver::prefetch_residual_products(int mode, double alpha, const double* d_cand, const double* h_cand) {
+  static const bool on = [] { const char* e = getenv("HYP_RP_PREFETCH"); return !(e && e[0] == '0'); }();
+  rp_pre_valid = false;
+  if (!on || dist() || ks_world > 1 || p != 0 || n <= 0 || q <= 0 || !s_resident || !gemv_both_ok(q, n, G.d(), q)) return;
+  const size_t d = sizeof(double);
+  const long dv = dimv();
+  rp_x.ensure((size_t)n * d);
+  rp_t.ensure(((size_t)n + 2 + 2 + 2 * (size_t)std::max(comm_world_, 1)) * d);
+  for (DBuf* b : {&rp_z, &rp_s, &rp_g}) b->ensure((size_t)q * d);
+  const size_t need = (size_t)n + 2 + (size_t)q + (size_t)n;   // [G' z (n); h' z; z' s | G x + s (q) | x (n)]
+  if (rp_pre_host_n < need) {
+    if (rp_pre_host) (void)hipHostFree(rp_pre_host);
+    rp_pre_host = nullptr; rp_pre_host_n = 0;
+    HYP_CHECK(hipHostMalloc((void**)&rp_pre_host, need * d, hipHostMallocDefault));
+    rp_pre_host_n = need;
+  }
+  if (!rp_pre_ev) HYP_CHECK(hipEventCreateWithFlags(&rp_pre_ev, hipEventDisableTiming));
+  const double a2 = alpha * alpha, am1 = 1.0 - alpha, am1s = am1 * am1;
+  const double* D = s_dirs.d();
+  hipLaunchKernelGGL(point_form_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx.stream, n, s_point.d(), D, D + dv, D + 2 * dv, D + 3 * dv, mode, alpha,
+                     a2, am1, am1s, rp_x.d());
+  HYP_CHECK(hipGetLastError());
+  ctx.zero(rp_t.p, ((size_t)n + 2) * d);
+  ctx.d2d(rp_z.p, d_cand, (size_t)q * d);
+  ctx.d2d(rp_s.p, d_cand + q + 1, (size_t)q * d);
+  ctx.d2d(rp_g.p, rp_s.p, (size_t)q * d);
+  gemv_both(ctx, q, n, 1, G.d(), q, rp_x.d(), n, 1.0, rp_g.d(), q, rp_z.d(), q, 0.0, rp_t.d(), n);
+  dev_dot(ctx, q, mh.d(), rp_z.d(), rp_t.d() + n);
+  dev_dot(ctx, q, rp_z.d(), rp_s.d(), rp_t.d() + n + 1);
+  ctx.d2h(rp_pre_host, rp_t.p, ((size_t)n + 2) * d);
+  ctx.d2h(rp_pre_host + n + 2, rp_g.p, (size_t)q * d);
+  ctx.d2h(rp_pre_host + n + 2 + q, rp_x.p, (size_t)n * d);
+  HYP_CHECK(hipEventRecord(rp_pre_ev, ctx.stream));
+  rp_pre_cand.assign(h_cand, h_cand + 2 * (size_t)q + 2);   // [z; tau; s; kap] as handed to the caller
+  rp_pre_valid = true;
+}
+
 int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp, const double* dca, const double* dpa, bool unadj_only,
                             bool cent_only, const double* sched, int nsched, int start, double min_prox, double prox_bound,
                             bool use_max_prox, double nup1, double* cand, double* prox_out, int* n_trials, int* n_loaded,
@@ -1899,6 +1984,7 @@ int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp
         screen_pass_g_ = -1;
         if (acc) {
           std::memcpy(out, cand, (size_t)len * sizeof(double));
+          if (resident) prefetch_residual_products(mode, sched[idx + g], cd + (size_t)g * len, cand);
           return idx + g;
         }
       }

@@ -51,6 +51,9 @@ struct SysSolver {
   DBuf bk_work;
 
   SysSolver(Ctx& c, int n_, int p_, int q_, const std::vector<Cone*>& cs);
+  ~SysSolver();
+  SysSolver(const SysSolver&) = delete;
+  SysSolver& operator=(const SysSolver&) = delete;
   const double* GQ2() const { return p == 0 ? G.d() : GQ2s.d(); }
   // host pointers; GQ1/GQ2/Q/R may be null when p == 0 (then GQ2 = G, Q = I)
   void load(const double* hG, const double* hGQ1, const double* hGQ2, const double* hQ, const double* hR);
@@ -129,6 +132,14 @@ struct SysSolver {
   // ranks taken here: Gtz (n, summed) = G' z; Gx_s (q, these rows) = G x + s; dots = {h' z, z' s} (summed)
   DBuf rp_x, rp_z, rp_s, rp_t, rp_g;
   DBuf rp_loc;   // residual_products2: the two local maxima in front of their exchange
+  // round 6: the same products of the NEXT iterate, queued when the line search accepts a candidate (see syssolver.hip)
+  void prefetch_residual_products(int mode, double alpha, const double* d_cand, const double* h_cand);
+  bool rp_pre_valid = false;
+  double* rp_pre_host = nullptr;   // pinned: [G' z (n); h' z; z' s | G x + s (q) | x (n)]
+  size_t rp_pre_host_n = 0;
+  hipEvent_t rp_pre_ev = nullptr;
+  std::vector<double> rp_pre_cand;
+  long rp_pre_hits = 0, rp_pre_misses = 0;
   void residual_products2(const double* h_x, const double* h_z, const double* h_s, double tau, double* h_Gtz, double* h_Gx_s, double* h_dots,
                           double* h_norms);
   void residual_products(const double* h_x, const double* h_z, const double* h_s, double* h_Gtz, double* h_Gx_s, double* h_dots);
@@ -225,7 +236,7 @@ struct SysSolver {
   // d_sc: [0, 6) solve dots (c'x, h'z per column), [8, 12) residual dots, [12, 14) residual maxima, [16, 20) tau / kap of the
   // direction per column, [20] dot_const, [24, 28) tau / kap of the last solve_system per column; mirrored to ctx.h_sc().
   DBuf d_sc;
-  enum { SC_SOLVE = 0, SC_RESD = 8, SC_AMAX = 12, SC_DSC = 16, SC_DOTC = 20, SC_CSC = 24, SC_SEQ = 31, SC_N = 32, SC_WORK = 64, SC_TOTAL = 64 + 3 * 33 + 5 };
+  enum { SC_SOLVE = 0, SC_RESD = 8, SC_AMAX = 12, SC_DSC = 16, SC_DOTC = 20, SC_CSC = 24, SC_INFO = 30, SC_SEQ = 31, SC_N = 32, SC_WORK = 64, SC_TOTAL = 64 + 3 * 33 + 5 };
   unsigned long sc_seq = 0;   // sequence number of the last solve queued with device scalars (stamped into d_sc[SC_SEQ] by its tau kernel)
   void wait_scalars();        // host: until the pinned mirror carries that solve's stamp (HYP_DIR_POLL=0: a stream synchronisation)
   void ensure_d_sc();

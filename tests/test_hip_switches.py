@@ -34,6 +34,8 @@ elif name == "psd_pair":
     inst = I.psd_blocks(50, [40, 33], seed=6)
 elif name == "psd_plan":                     # n = 600: the factor has a super-block solve plan (n >= 512)
     inst = I.psd_blocks(600, [36, 20], seed=7)
+elif name == "psd_wide_plan":                # one cone of side 60 (q = 1830) over n = 600: a solve plan, the resident line search, passes over G in one sweep
+    inst = I.psd_blocks(600, [60], seed=17)
 elif name == "psd_smoke":                    # __graft_entry__.smoke()'s instance
     inst = I.psd_blocks(40, [12, 7], seed=5)
 elif name == "polymin_primal":
@@ -326,3 +328,25 @@ def test_syrk_reduction_inside_the_product_changes_no_bit(N, K):
     assert len(set(runs["1"]["hashes"])) == 1 and len(set(runs["0"]["hashes"])) == 1
     assert runs["1"]["hashes"][0] == runs["0"]["hashes"][0]
     assert runs["1"]["err"] <= 1e-12 * K * max(1.0, runs["1"]["scale"])
+
+
+@pytest.mark.parametrize("name", ["psd_single_wide", "psd_wide_plan"])
+def test_residual_products_queued_at_accept_time_change_no_bit(name):
+    """round 6, HYP_RP_PREFETCH (default on): G' z, G x + s, h' z and z' s of the NEXT iterate (calc_convergence_params, Solvers.jl:425-483)
+    are queued the moment the line search accepts a candidate -- x formed on the device with the host mirror's roundings -- and handed
+    out by residual_products only if the point it is called with is bit for bit the one they were formed from.  Same kernels on the
+    same numbers: every iterate agrees to the last bit with the switch off, and the prefetched products were actually used"""
+    runs = {}
+    for v in ("1", "0"):
+        env = dict(os.environ, HYP_RP_PREFETCH=v, HYP_RP_PREFETCH_STATS="1")
+        env.setdefault("HYP_PERSISTENT", "1")
+        r = subprocess.run([sys.executable, "-c", SNIPPET % ROOT, name], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs[v] = (json.loads(r.stdout.strip().splitlines()[-1]), r.stderr)
+    on, off = runs["1"][0], runs["0"][0]
+    assert on["status"] == off["status"] == "Optimal"
+    assert on["iters"] == off["iters"] >= 8
+    assert on["trace"] == off["trace"], name
+    import re
+    m = re.search(r"handed out (\d+), recomputed (\d+)", runs["1"][1])
+    assert m and int(m.group(1)) >= on["iters"] - 2 and int(m.group(2)) == 0, runs["1"][1][-500:]
