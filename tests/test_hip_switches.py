@@ -34,8 +34,8 @@ elif name == "psd_pair":
     inst = I.psd_blocks(50, [40, 33], seed=6)
 elif name == "psd_plan":                     # n = 600: the factor has a super-block solve plan (n >= 512)
     inst = I.psd_blocks(600, [36, 20], seed=7)
-elif name == "psd_wide_plan":                # one cone of side 60 (q = 1830) over n = 600: a solve plan, the resident line search, passes over G in one sweep
-    inst = I.psd_blocks(600, [60], seed=17)
+elif name == "psd_wide_plan":                # one cone of side 63 (q = 2016, a multiple of 4: the one-pass kernel applies) over n = 600: a solve plan, the resident line search, passes over G in one sweep
+    inst = I.psd_blocks(600, [63], seed=17)
 elif name == "psd_smoke":                    # __graft_entry__.smoke()'s instance
     inst = I.psd_blocks(40, [12, 7], seed=5)
 elif name == "polymin_primal":
@@ -62,8 +62,8 @@ print(json.dumps({"status": s.get_status(), "iters": s.get_num_iters(), "obj": s
 
 
 def _run(name, env_extra):
-    env = dict(os.environ, **env_extra)
-    env.setdefault("HYP_PERSISTENT", "1")   # (the pytest process may hold the device's persistent-kernel lock; it launches nothing meanwhile)
+    from conftest import child_env
+    env = child_env(env_extra)   # (HYP_PERSISTENT=1 only if this pytest process holds a context -- and with it possibly the device's lock)
     r = subprocess.run([sys.executable, "-c", SNIPPET % ROOT, name], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
@@ -320,8 +320,8 @@ def test_syrk_reduction_inside_the_product_changes_no_bit(N, K):
     changing hash), at sizes with and without the cut last round (tail sub-slices) and the thin edge columns"""
     runs = {}
     for v in ("1", "0"):
-        env = dict(os.environ, HYP_SYRK_FUSED_REDUCE=v)
-        env.setdefault("HYP_PERSISTENT", "1")
+        from conftest import child_env
+        env = child_env({"HYP_SYRK_FUSED_REDUCE": v})
         r = subprocess.run([sys.executable, "-c", SYRK_SNIPPET % ROOT, str(N), str(K)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         runs[v] = json.loads(r.stdout.strip().splitlines()[-1])
@@ -338,8 +338,8 @@ def test_residual_products_queued_at_accept_time_change_no_bit(name):
     same numbers: every iterate agrees to the last bit with the switch off, and the prefetched products were actually used"""
     runs = {}
     for v in ("1", "0"):
-        env = dict(os.environ, HYP_RP_PREFETCH=v, HYP_RP_PREFETCH_STATS="1")
-        env.setdefault("HYP_PERSISTENT", "1")
+        from conftest import child_env
+        env = child_env({"HYP_RP_PREFETCH": v, "HYP_RP_PREFETCH_STATS": "1"})
         r = subprocess.run([sys.executable, "-c", SNIPPET % ROOT, name], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         runs[v] = (json.loads(r.stdout.strip().splitlines()[-1]), r.stderr)

@@ -206,7 +206,9 @@ def hip_trajectory(name, route, timeout=1800, **opts):
     for k in REFERENCE_ROUTE:
         env.pop(k, None)
     env.update(route)
-    env.setdefault("HYP_PERSISTENT", "1")   # (the pytest process may hold the device's persistent-kernel lock; it launches nothing meanwhile)
+    holds = any(getattr(m, "_ctx", None) is not None for n, m in list(sys.modules.items()) if n.endswith("_lib") and hasattr(m, "load_library"))
+    if holds:   # (this process holds a context and with it possibly the device's persistent-kernel lock; it launches nothing meanwhile.
+        env.setdefault("HYP_PERSISTENT", "1")   #  Without one, the child takes the lock the normal way: ADVICE r05)
     r = subprocess.run([sys.executable, os.path.abspath(__file__), name, json.dumps(opts)], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
