@@ -783,16 +783,17 @@ void SysSolver::get_directions2(double* h_dirs, const double* h_rhss, double mu,
 // host's order (no contraction: the host code is compiled for x86-64 without FMA).  const_mode: dot_const = sc[4] + sc[5] (the
 // constant column came out of THIS solve: its two scalar products are the third column's) instead of the argument.
 // base_on: the direction's scalars are base - (the solve's) (refinement: dir = dir_best - correction).
-struct TauArgs { double rs_tau[2], rs_kap[2], base_tau[2], base_kap[2]; double mu, taubar, dot_const, seq; int nr, const_mode, base_on; };
+struct TauArgs { double rs_tau[2], rs_kap[2], base_tau[2], base_kap[2]; double mu, taubar, dot_const, seq; int nr, const_mode, base_on, hz_sep; };
 __global__ void cols_tau_kernel(double* __restrict__ sc, TauArgs a) {
 #pragma clang fp contract(off)
   if (threadIdx.x != 0) return;
   double dc = a.dot_const;
-  if (a.const_mode) dc = sc[SysSolver::SC_SOLVE + 4] + sc[SysSolver::SC_SOLVE + 5];
+  // (hz_sep: cone-sharded -- the h'z of the columns, summed over the ranks, sit in slots of their own)
+  if (a.const_mode) dc = sc[SysSolver::SC_SOLVE + 4] + (a.hz_sep ? sc[SysSolver::SC_HZ + 2] : sc[SysSolver::SC_SOLVE + 5]);
   sc[SysSolver::SC_DOTC] = dc;
   const double m2 = a.mu / a.taubar / a.taubar;
   for (int r = 0; r < a.nr; ++r) {
-    const double dot_sub = sc[SysSolver::SC_SOLVE + 2 * r] + sc[SysSolver::SC_SOLVE + 2 * r + 1];
+    const double dot_sub = sc[SysSolver::SC_SOLVE + 2 * r] + (a.hz_sep ? sc[SysSolver::SC_HZ + r] : sc[SysSolver::SC_SOLVE + 2 * r + 1]);
     const double sol_tau = (a.rs_tau[r] + a.rs_kap[r] + dot_sub) / (m2 - dc);
     const double sol_kap = -a.mu / a.taubar / a.taubar * sol_tau + a.rs_kap[r];
     sc[SysSolver::SC_CSC + 2 * r] = sol_tau;
@@ -824,7 +825,11 @@ static bool dir_poll_on() {
 
 bool SysSolver::dirs_resident() const {
   static const bool on = [] { const char* e = getenv("HYP_DIR_RESIDENT"); return !(e && e[0] == '0'); }();
-  return on && p == 0 && !dist();
+  // cone-sharded (round 6, HYP_DIST_RESIDENT, default on): the scalars that cross the ranks -- h'z of a solve, h'z and the norm of a
+  // residual -- are summed / max-ed ON THE DEVICE (all-reduces of device slots, the maxima through a slot per rank) and the host of
+  // every rank reads the finished block; needs the communicator's layout (the fused exchange)
+  static const bool dist_on = [] { const char* e = getenv("HYP_DIST_RESIDENT"); return !(e && e[0] == '0'); }();
+  return on && p == 0 && (!dist() || (dist_on && fused_ok()));
 }
 
 // solve_system for nr columns (common.jl:129-182, qrchol.jl:16-37); see syssolver.hpp
@@ -880,11 +885,12 @@ void SysSolver::cols_solve(double* sol, const double* rhs, int nr, const Scal* r
     GemvOneGuard g1(ctx, ncol == 1);
     solve3_multi(ss, sr, ncol, joint_const ? sol_const.d() : nullptr);
   }
+  const bool dist_res = resident && dist();
   {
     DotSpecs sp;
     for (int r = 0; r < ncol; ++r) {
       sp.add(n, mc.d(), ss + r * ld3, sc + SC_SOLVE + 2 * r);
-      sp.add(q, mh.d(), ss + r * ld3 + oz, sc + SC_SOLVE + 2 * r + 1);
+      sp.add(q, mh.d(), ss + r * ld3 + oz, dist_res ? sc + SC_HZ + r : sc + SC_SOLVE + 2 * r + 1);
     }
     if (joint_const) {   // the rest of the constant solve (solve3 after its triangular solves) and its two dot products
       update_const_post();
@@ -893,6 +899,7 @@ void SysSolver::cols_solve(double* sol, const double* rhs, int nr, const Scal* r
     }
     dev_dots(ctx, sp);
   }
+  if (dist_res) allreduce_dev(sc + SC_HZ, ncol, 0, 2);   // h' z over all ranks' rows, on the device
   const bool own_const = with_const || joint_const;
   LinK k{};
   if (resident) {
@@ -903,6 +910,7 @@ void SysSolver::cols_solve(double* sol, const double* rhs, int nr, const Scal* r
     }
     a.mu = mu; a.taubar = taubar; a.dot_const = dot_const; a.nr = nr; a.const_mode = own_const ? 1 : 0; a.base_on = base ? 1 : 0;
     a.seq = (double)(++sc_seq);
+    a.hz_sep = dist_res ? 1 : 0;
     hipLaunchKernelGGL(cols_tau_kernel, dim3(1), dim3(64), 0, ctx.stream, sc, a);
     HYP_CHECK(hipGetLastError());
     for (int r = 0; r < nr; ++r) { k.k0[r] = 1.0; k.p1[r] = sc + SC_CSC + 2 * r; }
@@ -944,6 +952,24 @@ void SysSolver::cols_solve(double* sol, const double* rhs, int nr, const Scal* r
     for (int r = 0; r < nr; ++r) { k2.k0[r] = k.k1[r]; k2.p0[r] = k.p1[r]; k2.k1[r] = -1.0; k2.k2[r] = -1.0; }
     lincomb_cols(ctx, q, nr, mh.d(), 0, rhs + oz, dv, m_Gxd.d(), q, sol + os, dv, k2);
   }
+}
+
+// Behind the fused exchange of a cone-sharded residual (tail = [h'z sums (nr) | a slot per rank and column: the rank's maximum over
+// its rows]): the summed h'z and the residual's maximum over all ranks' rows and the replicated x rows (NaN wins) into the scalar
+// block -- what allreduce_fused's caller does on the host, with the host's rules
+__global__ void dist_resid_finish_kernel(const double* __restrict__ tail, int nr, int world, const double* __restrict__ xmax, double* __restrict__ sc) {
+  const int r = threadIdx.x;
+  if (r >= nr) return;
+  sc[SysSolver::SC_RESD + 2 * r + 1] = tail[r];
+  double m = tail[nr + r];
+  bool bad = (m != m);
+  for (int w = 1; w < world; ++w) {
+    const double v = tail[nr + w * nr + r];
+    bad = bad || (v != v);
+    if (v > m) m = v;
+  }
+  const double b = xmax[r];
+  sc[SysSolver::SC_AMAX + r] = (bad || b != b) ? __builtin_nan("") : fmax(m, b);
 }
 
 // residual of nr directions (apply_lhs, common.jl:79-121, minus rhs); see syssolver.hpp
@@ -1015,6 +1041,25 @@ void SysSolver::cols_residual(double* res, const double* dir, const double* rhs,
     dev_dots(ctx, sp);
   }
   double* hp = ctx.h_sc();
+  if (fuse && resident) {   // (round 6) the same exchange with its sums and maxima finished ON THE DEVICE: no host round trip here
+    double* ds = ctx.dscal.d();
+    for (int r = 0; r < nr; ++r) dev_sub_absmax(ctx, dv - oz, res + (long)r * dv + oz, rhs + (long)r * dv + oz, ds + 8 + r);   // this rank's rows
+    if (m_t.bytes < ((size_t)MR * n + 64 + 2 * (size_t)MR * comm_world_) * d) {   // (room for the tail behind the n-vectors)
+      DBuf bigger(((size_t)MR * n + 64 + 2 * (size_t)MR * comm_world_) * d);
+      ctx.d2d(bigger.p, m_t.p, (size_t)MR * n * d);
+      ctx.sync();
+      m_t = std::move(bigger);
+    }
+    FusedTail t;
+    t.nsum = nr; t.nmax = nr;
+    for (int r = 0; r < nr; ++r) { t.sum_src[r] = sc + SC_RESD + 2 * r + 1; t.max_src[r] = ds + 8 + r; }
+    allreduce_fused_dev(m_t.d(), (long)nr * n, t, 3);
+    for (int r = 0; r < nr; ++r) dev_axpby(ctx, n, 1.0, m_t.d() + (long)r * n, 1.0, res + (long)r * dv);
+    for (int r = 0; r < nr; ++r) dev_sub_absmax(ctx, oz, res + (long)r * dv, rhs + (long)r * dv, ds + 12 + r);                      // the replicated x rows
+    hipLaunchKernelGGL(dist_resid_finish_kernel, dim3(1), dim3(64), 0, ctx.stream, m_t.d() + (long)nr * n, nr, comm_world_, ds + 12, sc);
+    HYP_CHECK(hipGetLastError());
+    return;
+  }
   if (fuse) {
     HYP_REQUIRE(nr == MR, "cols_residual: the fused exchange carries a pair");
     double* ds = ctx.dscal.d();
@@ -1076,8 +1121,8 @@ __global__ __launch_bounds__(64) void publish_scalars_kernel(const double* __res
   if (i == 0) __hip_atomic_store(mirror + SysSolver::SC_SEQ, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-void SysSolver::cols_read_scalars() {
-  if (dist()) return;   // (the sharded residual has read and completed the mirror itself)
+void SysSolver::cols_read_scalars(bool resident) {
+  if (dist() && !resident) return;   // (the host-scalar sharded residual has read and completed the mirror itself)
   if (dir_poll_on() && ctx.h_sc_dev != nullptr) {
     hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(64), 0, ctx.stream, d_sc.d(), ctx.h_sc_dev, (double)sc_seq, (const int*)d_info.p);
     HYP_CHECK(hipGetLastError());
@@ -1164,7 +1209,7 @@ void SysSolver::refine_cols(double* rhs, double* dir, double* res, const Scal* r
     *n_solves += nr;
     for (int r = 0; r < nr; ++r) dev_axpby(ctx, dv, 1.0, tmp + o + (long)r * dv, -1.0, dir + o + (long)r * dv);
     cols_residual(res + o, dir + o, rhs + o, nr, csc, resident, true, both);
-    cols_read_scalars();
+    cols_read_scalars(resident);
     if (resident) wait_scalars();
     else ctx.sync();
     Scal rsc2[MR];
@@ -1214,7 +1259,7 @@ void SysSolver::pair_enqueue(double* rhs, const Scal* rs, double mu, double taub
   const bool both = (max_ref_steps > 0) && gemv_both_ok(q, n, G.d(), q);
   cols_solve(dir, rhs, MR, rs, mu, taubar, with_const, joint_const, resident, both, nullptr, dsc_host);
   if (max_ref_steps > 0) cols_residual(res, dir, rhs, MR, dsc_host, resident, false, both);
-  if (read_scalars) cols_read_scalars();
+  if (read_scalars) cols_read_scalars(resident);
 }
 
 void SysSolver::pair_finish(double* rhs, const Scal* rs, double mu, double taubar, int max_ref_steps, double res_norm_cutoff,
@@ -1240,7 +1285,7 @@ void SysSolver::pair_finish(double* rhs, const Scal* rs, double mu, double tauba
   bool cones_ok = true;
   for (const Cone* ck : cones) cones_ok = cones_ok && ck->products_columnwise();
   static const bool paired = [] { const char* e = getenv("HYP_REFINE_PAIRED"); return !(e && e[0] == '0'); }();
-  if (paired && cones_ok && !dist()) {
+  if (paired && cones_ok && (!dist() || resident)) {
     refine_cols(rhs, dir, res, rs, dsc, rsc, res_norms, mu, taubar, max_ref_steps, res_norm_cutoff, min_impr_tol, n_solves, resident);
     return;
   }
@@ -1488,7 +1533,7 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   bool cones_ok = true;
   for (const Cone* ck : cones) cones_ok = cones_ok && ck->products_columnwise();
   const bool const3 = const3_on() && cones_ok;
-  const bool joint = !const3 && tri3_on() && tri.ready(nmp) && tri.sb > 0 && tri.sb <= 1024;
+  const bool joint = !const3 && tri3_on() && !dist() && tri.ready(nmp) && tri.sb > 0 && tri.sb <= 1024;
   if (!const3 && !joint) {
     update_const();   // (synchronises: models without a solve plan -- small ones)
     if (h_sol_const) ctx.d2h(hs_const, sol_const.p, (size_t)it * d);
@@ -1604,7 +1649,7 @@ void SysSolver::step_directions_rest(bool resident, double tau, double kap, doub
   //  a refined pair is copied again below)
   ctx.d2h(hs_dirs + (long)MR * dv, m_dir.d(), (size_t)MR * dv * d);
   ctx.d2d(s_dirs.d() + (long)MR * dv, m_dir.p, (size_t)MR * dv * d);
-  cols_read_scalars();
+  cols_read_scalars(resident);
   // the first pair's directions reach the caller's (pageable) block while the device works on the second pair
   HYP_CHECK(hipEventSynchronize(dirs_copied_ev));
   std::memcpy(h_dirs, hs_dirs, (size_t)MR * dv * d);

@@ -486,6 +486,16 @@ void SysSolver::allreduce_fused(double* d_buf, long npay, const FusedTail& t, do
     h_out[t.nsum + j] = nan ? __builtin_nan("") : m;
   }
 }
+void SysSolver::allreduce_fused_dev(double* d_buf, long npay, const FusedTail& t, int site) {
+  HYP_REQUIRE(dist() && comm_world_ > 0 && t.nsum <= 8 && t.nmax <= 8, "allreduce_fused_dev: communicator layout");
+  const int ntail = t.nsum + comm_world_ * t.nmax;
+  FusedPtrs fp{};
+  for (int i = 0; i < t.nsum; ++i) fp.sum_src[i] = t.sum_src[i];
+  for (int j = 0; j < t.nmax; ++j) fp.max_src[j] = t.max_src[j];
+  hipLaunchKernelGGL(fused_tail_kernel, dim3(1), dim3(64), 0, ctx.stream, d_buf + npay, fp, t.nsum, t.nmax, comm_rank_, comm_world_);
+  HYP_CHECK(hipGetLastError());
+  allreduce_dev(d_buf, npay + ntail, 0, site);
+}
 void SysSolver::allreduce_host(double* h_buf, int count, int op, int site) {
   if (!dist() || count <= 0) return;
   comm_calls += 1;

@@ -125,6 +125,8 @@ struct SysSolver {
   struct FusedTail { int nsum = 0, nmax = 0; const double* sum_src[8]; const double* max_src[8]; };
   // d_buf must have room for npay + nsum + world * nmax doubles; h_out receives nsum sums, then nmax maxima
   void allreduce_fused(double* d_buf, long npay, const FusedTail& t, double* h_out, int site);
+  // the same exchange left on the device: the summed tail stays behind the payload ([sums | world x nmax slots]) for a kernel of the caller's
+  void allreduce_fused_dev(double* d_buf, long npay, const FusedTail& t, int site);
   double screen_sz_[18];      // sharded: the screen's all-reduced <z, s> and failure flag of each candidate ...
   double screen_szfail_[18];
   int screen_pass_g_ = -1;                 // ... and which of them check_cone_points is being asked about (-1: none)
@@ -236,7 +238,7 @@ struct SysSolver {
   // d_sc: [0, 6) solve dots (c'x, h'z per column), [8, 12) residual dots, [12, 14) residual maxima, [16, 20) tau / kap of the
   // direction per column, [20] dot_const, [24, 28) tau / kap of the last solve_system per column; mirrored to ctx.h_sc().
   DBuf d_sc;
-  enum { SC_SOLVE = 0, SC_RESD = 8, SC_AMAX = 12, SC_DSC = 16, SC_DOTC = 20, SC_CSC = 24, SC_INFO = 30, SC_SEQ = 31, SC_N = 32, SC_WORK = 64, SC_TOTAL = 64 + 3 * 33 + 5 };
+  enum { SC_SOLVE = 0, SC_RESD = 8, SC_AMAX = 12, SC_DSC = 16, SC_DOTC = 20, SC_HZ = 21, SC_CSC = 24, SC_INFO = 30, SC_SEQ = 31, SC_N = 32, SC_WORK = 64, SC_TOTAL = 64 + 3 * 33 + 5 };
   unsigned long sc_seq = 0;   // sequence number of the last solve queued with device scalars (stamped into d_sc[SC_SEQ] by its tau kernel)
   void wait_scalars();        // host: until the pinned mirror carries that solve's stamp (HYP_DIR_POLL=0: a stream synchronisation)
   void ensure_d_sc();
@@ -248,7 +250,7 @@ struct SysSolver {
   // apply_lhs (common.jl:79-121) of nr directions minus their right-hand sides; scalar products and maxima left in d_sc.
   // fresh: G dir.x / G' dir.z are formed here (else they are the ones cols_solve left in m_Gxd / m_t)
   void cols_residual(double* res, const double* dir, const double* rhs, int nr, const Scal* dsc_host, bool resident, bool fresh, bool both);
-  void cols_read_scalars();   // queue the copy of d_sc to its pinned mirror
+  void cols_read_scalars(bool resident);   // queue the copy of d_sc to its pinned mirror
   // the host's part behind a synchronisation: scalars of the nr directions and residuals out of the mirror
   void cols_finish(int nr, const Scal* rs, double mu, double taubar, bool resident, Scal* dsc, Scal* rsc, double* res_norms);
   void refine_cols(double* rhs, double* dir, double* res, const Scal* rs, Scal* dsc, Scal* rsc, double* res_norms, double mu, double taubar,
