@@ -1501,12 +1501,31 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   double* hs_res = hs_point + dv;
   double* hs_const = hs_res + it;
   double* hs_dirs = hs_const + it;
-  std::memcpy(hs_point, h_point, (size_t)dv * d);
-  std::memcpy(hs_res, h_res, (size_t)it * d);
   s_point.ensure((size_t)dv * d);
   s_resid.ensure((size_t)it * d);
-  ctx.h2d(s_point.p, hs_point, (size_t)dv * d);
-  ctx.h2d(s_resid.p, hs_res, (size_t)it * d);
+  // (round 6) The point and the residuals are needed by the right-hand sides, not by the Schur assembly: in the resident flow they are
+  // staged and uploaded AFTER the assembly and the factorization have been queued -- on the helper stream, behind an event that orders
+  // them after whatever still reads the previous iterate on the main stream -- so that neither the host's copy into pinned memory
+  // (0.4 ms at config 4's 3.3 MB point) nor the transfer sits between two iterations with the device idle
+  auto upload = [&](hipStream_t st) {
+    std::memcpy(hs_point, h_point, (size_t)dv * d);
+    std::memcpy(hs_res, h_res, (size_t)it * d);
+    HYP_CHECK(hipMemcpyAsync(s_point.p, hs_point, (size_t)dv * d, hipMemcpyHostToDevice, st));
+    HYP_CHECK(hipMemcpyAsync(s_resid.p, hs_res, (size_t)it * d, hipMemcpyHostToDevice, st));
+  };
+  const bool resident_flow = dirs_resident() && nmp > 0 && !getenv_on("HYP_FORCE_BK") && !getenv_on("HYP_FORCE_FACT_FAIL");
+  static const bool late_upload = [] { const char* e = getenv("HYP_LATE_UPLOAD"); return !(e && e[0] == '0'); }();
+  // (measured, same box, alternating: config 4 -- a 3.3 MB point -- 108.0 / 108.1 ms late against 109.0 / 108.6 early; config 2 -- 0.36 MB --
+  //  17.67 / 17.54 late against 17.48 / 17.48: the cross-stream hand-over costs a small model more than its copies do: from 1 MB on)
+  const bool upload_late = resident_flow && late_upload && ctx.stream == ctx.stream_primary && (size_t)dv * d >= (1u << 20);
+  if (upload_late) {
+    if (!up_ev0) {
+      HYP_CHECK(hipEventCreateWithFlags(&up_ev0, hipEventDisableTiming));
+      HYP_CHECK(hipEventCreateWithFlags(&up_ev1, hipEventDisableTiming));
+    }
+    HYP_CHECK(hipEventRecord(up_ev0, ctx.stream));
+  }   // (everything queued so far: the last readers of the old point)
+  if (!upload_late) upload(ctx.stream);
   const auto t0 = std::chrono::steady_clock::now();
   const double tau = h_point[it], kap = h_point[ik];
   m_rhs.ensure((size_t)(MR + 1) * dv * d);   // (+ the constant column of the first pair)
@@ -1515,7 +1534,7 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   // sides, constant column, both passes, residuals -- is queued behind the Cholesky as if it had succeeded (it almost always has);
   // the host reads info together with that pair's scalars.  Behind a failed Cholesky the pair's numbers are discarded, the fall-back
   // chain runs and the call continues the way it always did.
-  const bool resident = dirs_resident() && nmp > 0 && !getenv_on("HYP_FORCE_BK") && !getenv_on("HYP_FORCE_FACT_FAIL");
+  const bool resident = resident_flow;
   if (!resident) {
     if (nmp > 0) update_lhs_fact(info, used_fallback);                 // combined.jl:64
     if (use_sqrt_out)
@@ -1528,6 +1547,17 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   }
   assemble_lhs();
   factor_lhs_begin();
+  if (upload_late) {
+    // (the staging block is taken again: a cone oracle of the assembly may have asked for a larger one meanwhile)
+    hs_point = ctx.stage_host((size_t)dv + 2 * (size_t)it + 2 * (size_t)MR * dv);
+    hs_res = hs_point + dv;
+    hs_const = hs_res + it;
+    hs_dirs = hs_const + it;
+    HYP_CHECK(hipStreamWaitEvent(ctx.stream2, up_ev0, 0));
+    upload(ctx.stream2);
+    HYP_CHECK(hipEventRecord(up_ev1, ctx.stream2));
+    HYP_CHECK(hipStreamWaitEvent(ctx.stream, up_ev1, 0));
+  }
   if (use_sqrt_out)
     for (size_t k = 0; k < cones.size(); ++k) use_sqrt_out[k] = use_sqrt[k];
   bool cones_ok = true;

@@ -51,7 +51,7 @@ SysSolver::~SysSolver() {
   if (const char* e = getenv("HYP_RP_PREFETCH_STATS"))
     if (e[0] == '1') fprintf(stderr, "[residual_products prefetch] handed out %ld, recomputed %ld\n", rp_pre_hits, rp_pre_misses);
   if (rp_pre_host) (void)hipHostFree(rp_pre_host);
-  for (hipEvent_t e : {rp_pre_ev, plan_ev_fork, plan_ev_done, dirs_copied_ev})
+  for (hipEvent_t e : {rp_pre_ev, plan_ev_fork, plan_ev_done, dirs_copied_ev, up_ev0, up_ev1})
     if (e) (void)hipEventDestroy(e);
 }
 

@@ -262,6 +262,7 @@ struct SysSolver {
   static bool const3_on();    // HYP_CONST_COL3 (default on)
   static bool tri3_on();      // HYP_CONST_TRI3 (default on)
   static bool getenv_on(const char* name);
+  hipEvent_t up_ev0 = nullptr, up_ev1 = nullptr;   // ordering of the late upload of the point / residuals on the helper stream
   hipEvent_t dirs_copied_ev = nullptr;   // the first pair's directions have reached the pinned staging
   std::chrono::steady_clock::time_point t_rest0;
   double last_rest_update_lhs_s = 0.0;
