@@ -96,6 +96,7 @@ SIGNATURES = {
     "hyp_qrcp_apply_q": [c_vp, c_int, c_vp],
     "hyp_qrcp_destroy": [c_vp],
     "hyp_sys_set_kshard": [c_vp, c_int, c_int],
+    "hyp_sys_set_direction_rows": [c_vp, c_int],
     "hyp_sys_last_update_lhs_seconds": [c_vp, P(c_dbl)],
     "hyp_sys_bench_gemv": [c_vp, c_int, c_vp],
     "hyp_sys_search_alpha": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_dbl, c_dbl, c_int, c_dbl, c_vp,

@@ -747,6 +747,11 @@ int hyp_sys_comm_stats(hyp_sys* sys, double* out2) {
   out2[1] = sys->s->comm_doubles;
   API_END(sys->ctx)
 }
+int hyp_sys_set_direction_rows(hyp_sys* sys, int x_rows_only) {
+  API_BEGIN
+  sys->s->dirs_x_only = (x_rows_only != 0);
+  API_END(sys->ctx)
+}
 int hyp_sys_last_update_lhs_seconds(hyp_sys* sys, double* out) {
   API_BEGIN
   *out = sys->s->last_update_lhs_s;

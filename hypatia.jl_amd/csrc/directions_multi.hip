@@ -1669,7 +1669,18 @@ void SysSolver::step_directions_rest(bool resident, double tau, double kap, doub
   // (centadj, predadj) -- right-hand sides from the first pair's directions where they lie; their copies (to the host's staging and
   // to the resident block of the line search) are queued behind the right-hand sides' launches: the device is waiting for work here
   build_rhs_pair(1, m_rhs.d(), s_point.d(), mu, tau, kap, tau_residual, m_dir.d(), dtau, reinterpret_cast<double*>(rs), resident);
-  ctx.d2h(hs_dirs, m_dir.d(), (size_t)MR * dv * d);
+  // (dirs_x_only: only the x rows travel; columns stay dv apart in the staging block, the z / s rows of the caller's block are not touched)
+  const size_t rows_down = dirs_x_only ? (size_t)n : (size_t)dv;
+  auto dirs_d2h = [&](int half) {
+    double* dst = hs_dirs + (long)half * MR * dv;
+    if (!dirs_x_only) { ctx.d2h(dst, m_dir.d(), (size_t)MR * dv * d); return; }
+    HYP_CHECK(hipMemcpy2DAsync(dst, (size_t)dv * d, m_dir.d(), (size_t)dv * d, rows_down * d, MR, hipMemcpyDeviceToHost, ctx.stream));
+  };
+  auto dirs_out = [&](int half) {
+    for (int r = 0; r < MR; ++r)
+      std::memcpy(h_dirs + ((long)half * MR + r) * dv, hs_dirs + ((long)half * MR + r) * dv, rows_down * d);
+  };
+  dirs_d2h(0);
   ctx.d2d(s_dirs.p, m_dir.p, (size_t)MR * dv * d);
   if (!dirs_copied_ev) HYP_CHECK(hipEventCreateWithFlags(&dirs_copied_ev, hipEventDisableTiming));
   HYP_CHECK(hipEventRecord(dirs_copied_ev, ctx.stream));
@@ -1677,12 +1688,12 @@ void SysSolver::step_directions_rest(bool resident, double tau, double kap, doub
   pair_enqueue(m_rhs.d(), rs, mu, tau, max_ref_steps, false, false, resident, dsc, false);
   // (the raw directions travel to the host and to the resident block IN FRONT of the scalars: when those have landed, so have they;
   //  a refined pair is copied again below)
-  ctx.d2h(hs_dirs + (long)MR * dv, m_dir.d(), (size_t)MR * dv * d);
+  dirs_d2h(1);
   ctx.d2d(s_dirs.d() + (long)MR * dv, m_dir.p, (size_t)MR * dv * d);
   cols_read_scalars(resident);
   // the first pair's directions reach the caller's (pageable) block while the device works on the second pair
   HYP_CHECK(hipEventSynchronize(dirs_copied_ev));
-  std::memcpy(h_dirs, hs_dirs, (size_t)MR * dv * d);
+  dirs_out(0);
   if (resident) wait_scalars();
   else ctx.sync();
   const int ns_before = ns;
@@ -1691,11 +1702,11 @@ void SysSolver::step_directions_rest(bool resident, double tau, double kap, doub
   res_norms[2] = rn[0];
   res_norms[3] = rn[1];
   if (ns > ns_before + MR) {   // refinement moved a direction of the second pair
-    ctx.d2h(hs_dirs + (long)MR * dv, m_dir.d(), (size_t)MR * dv * d);
+    dirs_d2h(1);
     ctx.d2d(s_dirs.d() + (long)MR * dv, m_dir.p, (size_t)MR * dv * d);
     ctx.sync();
   }
-  std::memcpy(h_dirs + (long)MR * dv, hs_dirs + (long)MR * dv, (size_t)MR * dv * d);
+  dirs_out(1);
   if (h_sol_const) std::memcpy(h_sol_const, hs_const, (size_t)it * d);
   for (int r = 0; r < MR; ++r) {
     h_dirs[(long)r * dv + it] = d01[r].tau;

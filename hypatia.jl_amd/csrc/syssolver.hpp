@@ -262,6 +262,7 @@ struct SysSolver {
   static bool const3_on();    // HYP_CONST_COL3 (default on)
   static bool tri3_on();      // HYP_CONST_TRI3 (default on)
   static bool getenv_on(const char* name);
+  bool dirs_x_only = false;   // hyp_sys_set_direction_rows: step_directions hands the host only the x rows and tau / kap of the directions
   hipEvent_t up_ev0 = nullptr, up_ev1 = nullptr;   // ordering of the late upload of the point / residuals on the helper stream
   hipEvent_t dirs_copied_ev = nullptr;   // the first pair's directions have reached the pinned staging
   std::chrono::steady_clock::time_point t_rest0;

@@ -144,6 +144,15 @@ class QRCholDenseSystemSolver:
         resn = (ctypes.c_double * 4)()
         resid = np.concatenate([solver.x_residual, solver.y_residual, solver.z_residual])
         dirs4 = stepper.dirs4
+        if not hasattr(self, "_dir_rows_set"):
+            # the line search walks the schedule on the directions this call leaves on the device and hands back the accepted candidate's
+            # z / tau / s / kap rows (search_alpha_native); update_stepper_points_x then reads only the x rows of the four directions:
+            # only those are downloaded (q = 207 360: 13 MB per iteration otherwise).  HYP_DIRS_X_ONLY=0: the whole vectors.
+            from .solvers import _cap
+            x_only = (os.environ.get("HYP_DIRS_X_ONLY", "1") != "0" and _cap(self, "search") and getattr(self, "cand_in_temp", True)
+                      and not getattr(self, "row_local", False) and self._screen_ok())
+            L.check(L.lib().hyp_sys_set_direction_rows(self._h, 1 if x_only else 0), "hyp_sys_set_direction_rows")
+            self._dir_rows_set = True
         L.check(L.lib().hyp_sys_step_directions(self._h, L.vec_ptr(solver.point.vec), L.vec_ptr(resid), float(solver.tau_residual), float(solver.mu),
                                                 int(solver.max_ref_steps), float(solver.res_norm_cutoff), 0.5, dirs4.ctypes.data_as(c_vp), resn,
                                                 ctypes.byref(ns), flags, ctypes.byref(info), ctypes.byref(fb), L.vec_ptr(self.sol_const.vec)),

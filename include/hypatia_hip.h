@@ -267,6 +267,12 @@ int hyp_sys_comm_times(hyp_sys* sys, double* out16);
 int hyp_sys_set_kshard(hyp_sys* sys, int rank, int world);
 /* out2 = {exchanges issued by this solver since its creation, doubles moved by them} */
 int hyp_sys_comm_stats(hyp_sys* sys, double* out2);
+/* Which rows of the four directions hyp_sys_step_directions copies into dir_vecs4: 0 (default) the whole Point vectors; 1 only
+ * the x rows and tau / kap of each direction -- what update_stepper_points (steppers/combined.jl:124-170) still needs on the host when
+ * the line search runs on the directions the call left on the device (hyp_sys_search_alpha_resident hands back the accepted
+ * candidate's z / tau / s / kap rows); the z / s rows of the caller's block are then left as they are.  At q = 207 360 the whole
+ * block is 13 MB over PCIe and through a pageable copy per iteration. */
+int hyp_sys_set_direction_rows(hyp_sys* sys, int x_rows_only);
 /* wall seconds the update_lhs part (solver.time_upsys) took inside the last hyp_sys_step_directions call */
 int hyp_sys_last_update_lhs_seconds(hyp_sys* sys, double* out);
 /* Measurement helper: HIP-event time (ms, averaged over reps back-to-back launches) of the four passes over the resident

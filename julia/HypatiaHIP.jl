@@ -628,6 +628,14 @@ function step_directions!(dirs4::Matrix{Float64}, res_norms::Vector{Float64}, sy
     return (info[] == 0, Int(ns[]))
 end
 
+# Only the x rows and tau / kap of the four directions are copied into dirs4 by step_directions! (x_rows_only = true): all a stepper
+# needs on the host when it walks the schedule with search_alpha_resident (the accepted candidate's z / tau / s / kap rows come back
+# from there; update_stepper_points, steppers/combined.jl:124-170, then forms the x rows only)
+function set_direction_rows!(sys::HIPQRCholDenseSystemSolver, x_rows_only::Bool)
+    check(ccall((:hyp_sys_set_direction_rows, lib), Cint, (Ptr{Cvoid}, Cint), sys.handle, x_rows_only ? 1 : 0), "hyp_sys_set_direction_rows")
+    return sys
+end
+
 function search_screen_usable(sys::HIPQRCholDenseSystemSolver)
     usable = Ref{Cint}(0); screens = Ref{Clonglong}(0); rejected = Ref{Clonglong}(0)
     check(ccall((:hyp_sys_search_screen_stats, lib), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Clonglong}, Ptr{Clonglong}),

@@ -455,7 +455,7 @@ def test_native_search_alpha_matches_host_walk():
     assert abs(prox_native - st.searcher.prox) <= 1e-9 * (1 + prox_native)
 
 
-def test_resident_search_alpha_same_candidate_and_error_paths():
+def test_resident_search_alpha_same_candidate_and_error_paths(monkeypatch):
     """hyp_sys_search_alpha_resident (one PosSemidefTri cone: candidates formed on the device from what step_directions left
     there, screened side by side) against hyp_sys_search_alpha on the host vectors of the same step: same accepted index, the
     accepted candidate bit for bit, same proximity value, same number of candidates visited.  And its contract: an error
@@ -465,6 +465,9 @@ def test_resident_search_alpha_same_candidate_and_error_paths():
     from hypatia_jl_amd import _lib as L
     from oracle import instances as I
     inst = I.psd_blocks(40, [48], seed=5)
+    # (the host-vector search of this comparison reads the z / s rows of the directions: the whole vectors are downloaded here, not
+    #  only the x rows a stepper on the resident search needs -- hyp_sys_set_direction_rows, round 6)
+    monkeypatch.setenv("HYP_DIRS_X_ONLY", "0")
     hs = H.Solver(iter_limit=3)
     hs.load(H.make_model(inst)); hs.solve()
     st, sysv = hs.stepper, hs.syssolver

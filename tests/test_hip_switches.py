@@ -350,3 +350,16 @@ def test_residual_products_queued_at_accept_time_change_no_bit(name):
     import re
     m = re.search(r"handed out (\d+), recomputed (\d+)", runs["1"][1])
     assert m and int(m.group(1)) >= on["iters"] - 2 and int(m.group(2)) == 0, runs["1"][1][-500:]
+
+
+@pytest.mark.parametrize("name", ["psd_single_wide", "psd_run"])
+def test_x_rows_only_download_of_the_directions_changes_no_bit(name):
+    """round 6, hyp_sys_set_direction_rows (HYP_DIRS_X_ONLY, default on where the line search runs on the resident directions): only the x
+    rows and tau / kap of the four directions are copied to the host -- all update_stepper_points (combined.jl:124-170) reads there once
+    the accepted candidate's z / tau / s / kap rows come back from the search.  Same iterates to the last bit as with whole vectors"""
+    on = _run(name, {"HYP_DIRS_X_ONLY": "1"})
+    off = _run(name, {"HYP_DIRS_X_ONLY": "0"})
+    assert on["status"] == off["status"] == "Optimal"
+    assert on["iters"] == off["iters"] >= 8
+    assert on["trace"] == off["trace"], name
+    assert on["trials"] == off["trials"]
