@@ -36,6 +36,16 @@ namespace hyp {
 
 namespace {
 
+// Fragment reads are VOLATILE loads from the LDS address space (round 6): left to itself the compiler pairs the reads of two k chunks into
+// ds_read2_b64 -- half the rate of ds_read_b64 and banked modulo 32 dwords, where rows j and j + 8 of the 18-double row stride collide.  This
+// kernel reads one fragment per one or two MFMAs: at that ratio the paired, conflicting reads keep the LDS busy for as long as the matrix
+// cores (EXPERIMENTS r06-16).  -DHYP_TS4_READ2: the plain loads of rounds 4-5, for A/B builds.
+#ifdef HYP_TS4_READ2
+#define TS4_LDS_RD(P) (*(P))
+#else
+typedef const volatile double __attribute__((address_space(3))) ts4_lds_cv;
+#define TS4_LDS_RD(P) (*(ts4_lds_cv*)(P))
+#endif
 constexpr int T4_LDK = 18;   // LDS row stride of the 16-wide slices (conflict-free 64-bit fragment reads, as psd_twosided.hip)
 
 struct Ts4Args {
@@ -225,7 +235,7 @@ __device__ __forceinline__ void ts4_wave(const Ts4Args& p, double* __restrict__ 
           if (p1[ci]) {
             const double* bs = Rr + (16 * AC[ci] + fj) * T4_LDK + fq;
 #pragma unroll
-            for (int ch = 0; ch < 4; ++ch) bf[ci][ch] = bs[4 * ch];
+            for (int ch = 0; ch < 4; ++ch) bf[ci][ch] = TS4_LDS_RD(bs + 4 * ch);
           }
         // Tile rows in pairs: consecutive MFMAs go to different accumulators even when only one block column is active (a dependent
         // FP64 MFMA waits ~95 cycles for its predecessor, an independent one issues after 64: tools/probe_potrf.hip).  The fragments
@@ -237,7 +247,7 @@ __device__ __forceinline__ void ts4_wave(const Ts4Args& p, double* __restrict__ 
         for (int mm = 0; mm < 2; ++mm) {
           const double* as = Vs + (16 * mm + fj) * T4_LDK + fq;
 #pragma unroll
-          for (int ch = 0; ch < 4; ++ch) afn[mm][ch] = as[4 * ch];
+          for (int ch = 0; ch < 4; ++ch) afn[mm][ch] = TS4_LDS_RD(as + 4 * ch);
         }
 #pragma unroll
         for (int mp = 0; mp < NP; ++mp) {
@@ -254,7 +264,7 @@ __device__ __forceinline__ void ts4_wave(const Ts4Args& p, double* __restrict__ 
               if (2 * (mp + 1) + mm >= T) continue;
               const double* as = Vs + (16 * (2 * (mp + 1) + mm) + fj) * T4_LDK + fq;
 #pragma unroll
-              for (int ch = 0; ch < 4; ++ch) afn[mm][ch] = as[4 * ch];
+              for (int ch = 0; ch < 4; ++ch) afn[mm][ch] = TS4_LDS_RD(as + 4 * ch);
             }
           }
 #pragma unroll
@@ -282,7 +292,7 @@ __device__ __forceinline__ void ts4_wave(const Ts4Args& p, double* __restrict__ 
         {
           const double* rs = Rc + fj * LDC + fq;
 #pragma unroll
-          for (int ch = 0; ch < 4; ++ch) rfn[ch] = rs[4 * ch];
+          for (int ch = 0; ch < 4; ++ch) rfn[ch] = TS4_LDS_RD(rs + 4 * ch);
         }
 #pragma unroll
         for (int kt = 0; kt <= t; ++kt) {
@@ -296,7 +306,7 @@ __device__ __forceinline__ void ts4_wave(const Ts4Args& p, double* __restrict__ 
           if (kt + 1 <= t) {
             const double* rs = Rc + fj * LDC + 16 * (kt + 1) + fq;
 #pragma unroll
-            for (int ch = 0; ch < 4; ++ch) rfn[ch] = rs[4 * ch];
+            for (int ch = 0; ch < 4; ++ch) rfn[ch] = TS4_LDS_RD(rs + 4 * ch);
           }
 #pragma unroll
           for (int ch = 0; ch < 4; ++ch) {

@@ -36,6 +36,14 @@ namespace hyp {
 
 namespace {
 
+// (round 6) fragment reads as volatile LDS loads: ds_read_b64 instead of the compiler's half-rate ds_read2_b64 pairs (see psd_twosided4.hip);
+// -DHYP_TS5_READ2: plain loads, for A/B builds
+#ifdef HYP_TS5_READ2
+#define TS5_LDS_RD(P) (*(P))
+#else
+typedef const volatile double __attribute__((address_space(3))) ts5_lds_cv;
+#define TS5_LDS_RD(P) (*(ts5_lds_cv*)(P))
+#endif
 struct Ts5Args {
   int s, ncols;
   const double* A;   // svec columns
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       //  hoisting every chunk's reads to the top of the step)
       double bfn[T];
 #pragma unroll
-      for (int a = t; a < T; ++a) bfn[a] = Rs[(16 * t + q) * S + 16 * a + nn];
+      for (int a = t; a < T; ++a) bfn[a] = TS5_LDS_RD(Rs + (16 * t + q) * S + 16 * a + nn);
 #pragma unroll
       for (int ch = 0; ch < 4; ++ch) {
         double bf[T];
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int a = t; a < T; ++a) bf[a] = bfn[a];
         if (ch + 1 < 4) {
 #pragma unroll
-          for (int a = t; a < T; ++a) bfn[a] = Rs[(16 * t + 4 * (ch + 1) + q) * S + 16 * a + nn];
+          for (int a = t; a < T; ++a) bfn[a] = TS5_LDS_RD(Rs + (16 * t + 4 * (ch + 1) + q) * S + 16 * a + nn);
         }
 #pragma unroll
         for (int m = 0; m < T; ++m)
@@ -188,13 +196,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       d4_t Y[NY];
 #pragma unroll
       for (int a = 0; a < NY; ++a) Y[a] = zero4;
-      double rfn = Rs[q * S + 16 * t + nn];
+      double rfn = TS5_LDS_RD(Rs + q * S + 16 * t + nn);
 #pragma unroll
       for (int kt = 0; kt <= t; ++kt)
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
           const double rf = rfn;
-          if (4 * kt + ch + 1 < 4 * (t + 1)) rfn = Rs[(4 * (4 * kt + ch + 1) + q) * S + 16 * t + nn];   // (chunk index 4 kt + ch: rows 4 (4 kt + ch) + q)
+          if (4 * kt + ch + 1 < 4 * (t + 1)) rfn = TS5_LDS_RD(Rs + (4 * (4 * kt + ch + 1) + q) * S + 16 * t + nn);   // (chunk index 4 kt + ch: rows 4 (4 kt + ch) + q)
           if constexpr (t == 0) {
             Y[ch & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(rf, Z[0][0][ch], Y[ch & 1], 0, 0, 0);
           } else {
