@@ -15,6 +15,38 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def run_ranks(target, args_of_rank, world, timeout):
+    """start `world` spawned processes target(*args_of_rank(rank, port)), wait for them together; a rank that dies takes the others
+    down at once (they would wait for it until the timeout and, on a GPU, keep the device busy for every test behind), stragglers
+    are terminated at the timeout, and a failed attempt is repeated ONCE on another port (the port found free by _free_port can be
+    taken by the time the store binds it: EADDRINUSE killed a whole GPU batch once).  Returns the exit codes of the last attempt."""
+    import multiprocessing as mp_
+    import time as time_
+    codes = []
+    for attempt in range(2):
+        port = _free_port()
+        ctx = mp_.get_context("spawn")
+        procs = [ctx.Process(target=target, args=args_of_rank(r, port)) for r in range(world)]
+        for p_ in procs:
+            p_.start()
+        t0 = time_.time()
+        while time_.time() - t0 < timeout:
+            if all(p_.exitcode is not None for p_ in procs) or any(p_.exitcode not in (None, 0) for p_ in procs):
+                break
+            time_.sleep(0.2)
+        for p_ in procs:
+            if p_.exitcode is None:
+                p_.join(5 if any(q_.exitcode not in (None, 0) for q_ in procs) else max(0.0, timeout - (time_.time() - t0)))
+        for p_ in procs:
+            if p_.exitcode is None:
+                p_.terminate()
+                p_.join(10)
+        codes = [p_.exitcode for p_ in procs]
+        if all(c == 0 for c in codes):
+            break
+    return codes
+
+
 def test_partition_cones():
     from hypatia_jl_amd.distributed import partition_cones
     assert partition_cones(64, 8) == [r for r in range(8) for _ in range(8)]
@@ -30,15 +62,9 @@ def test_sharded_solve_matches_single_process(world):
     from oracle.build import make_model
     from oracle.solvers import Solver as OSolver
     inst_args = (40, [6, 5, 4], 3)
-    port = _free_port()
     out = os.path.join(tempfile.mkdtemp(), "dist_out.npz")
-    ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=dist_worker.run, args=(r, world, port, inst_args, out)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(280)
-    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    codes = run_ranks(dist_worker.run, lambda r, port: (r, world, port, inst_args, out), world, 280)
+    assert all(c == 0 for c in codes), codes
     res = np.load(out)
     ref = OSolver(verbose=False)
     ref.load(make_model(I.psd_blocks(*inst_args)))
@@ -66,15 +92,9 @@ def test_kshard_schur_sum_matches_full_assembly():
     """world-2 gloo: the K-panel split of outer_prod! (qrchol.jl:234) for a single-cone model -- partial Gram matrices over
     kshard_range rows, one all-reduce -- against the oracle's full sqrt-Hessian assembly"""
     import dist_worker
-    port = _free_port()
     out = os.path.join(tempfile.mkdtemp(), "kshard.npz")
-    ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=dist_worker.run_kshard, args=(r, 2, port, (30, [9], 5), out)) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(280)
-    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    codes = run_ranks(dist_worker.run_kshard, lambda r, port: (r, 2, port, (30, [9], 5), out), 2, 280)
+    assert all(c == 0 for c in codes), codes
     res = np.load(out)
     assert np.allclose(res["lhs"], res["full"], rtol=1e-13, atol=1e-13)
     assert res["ranges"].tolist() == [[0, 32], [32, 45]]
@@ -88,15 +108,9 @@ def test_library_communicator_bringup_is_agreed_on_by_all_ranks(fail, bad_rank):
     both without (falling back to the callback transport), the rank whose own step succeeded having destroyed what it created;
     nobody raises alone, nobody waits in a collective the other never enters (the test would time out)."""
     import dist_worker
-    port = _free_port()
     out_dir = tempfile.mkdtemp()
-    ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=dist_worker.run_rccl_bringup, args=(r, 2, port, fail, bad_rank, out_dir)) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(120)
-    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    codes = run_ranks(dist_worker.run_rccl_bringup, lambda r, port: (r, 2, port, fail, bad_rank, out_dir), 2, 120)
+    assert all(c == 0 for c in codes), codes
     res = [np.load(os.path.join(out_dir, "bringup_%d.npz" % r)) for r in range(2)]
     want = (fail == "none")
     for r in range(2):

@@ -7,7 +7,7 @@ import tempfile
 import numpy as np
 import pytest
 
-from test_distributed_gloo import _free_port
+from test_distributed_gloo import _free_port, run_ranks
 
 pytestmark = pytest.mark.gpu
 
@@ -88,15 +88,9 @@ def test_sharded_total_factorization_failure(native, monkeypatch):
     monkeypatch.setenv("HYP_DIST_NATIVE", native)
     monkeypatch.setenv("HYP_FORCE_FACT_FAIL", "1")
     import dist_worker
-    port = _free_port()
     out = os.path.join(tempfile.mkdtemp(), "dist_fail.npz")
-    ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=dist_worker.run, args=(r, 2, port, (60, [8, 6, 7], 4), out, "hip", "gloo")) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(300)
-    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    codes = run_ranks(dist_worker.run, lambda r, port: (r, 2, port, (60, [8, 6, 7], 4), out, "hip", "gloo"), 2, 300)
+    assert all(c == 0 for c in codes), codes
     res = np.load(out)
     assert str(res["status"]) == "NumericalFailure" and int(res["iters"]) == 0
 
@@ -146,15 +140,9 @@ def _run_sharded(native, inst_args=(120, [20, 12, 16, 9], 4), world=2, transport
     from oracle import instances as I
     from oracle.build import make_model
     from oracle.solvers import Solver as OSolver
-    port = _free_port()
     out = os.path.join(tempfile.mkdtemp(), "dist_hip.npz")
-    ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=dist_worker.run, args=(r, world, port, inst_args, out, "hip", transport)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(500)
-    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    codes = run_ranks(dist_worker.run, lambda r, port: (r, world, port, inst_args, out, "hip", transport), world, 500)
+    assert all(c == 0 for c in codes), codes
     res = np.load(out)
     ref = OSolver(verbose=False)
     ref.load(make_model(I.psd_blocks(*inst_args)))
@@ -183,15 +171,9 @@ def test_kshard_single_cone_solve_matches_oracle():
     from oracle.build import make_model
     from oracle.solvers import Solver as OSolver
     inst_args = (150, [30], 2)
-    port = _free_port()
     out = os.path.join(tempfile.mkdtemp(), "kshard_hip.npz")
-    ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=dist_worker.run_kshard, args=(r, 2, port, inst_args, out, "hip")) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(500)
-    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    codes = run_ranks(dist_worker.run_kshard, lambda r, port: (r, 2, port, inst_args, out, "hip"), 2, 500)
+    assert all(c == 0 for c in codes), codes
     res = np.load(out)
     ref = OSolver(verbose=False)
     ref.load(make_model(I.psd_blocks(*inst_args)))
@@ -217,15 +199,9 @@ def test_kshard_cone_without_square_root(monkeypatch):
     from oracle.solvers import Solver as OSolver
     monkeypatch.setenv("HYP_FORCE_BK", "1")
     inst_args = ("polymin", 2, 3, False, 2)   # dual form: n = U - 1 = 27 after the reduction, one WSOS cone of dimension 28
-    port = _free_port()
     out = os.path.join(tempfile.mkdtemp(), "kshard_nosqrt.npz")
-    ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=dist_worker.run_kshard, args=(r, 2, port, inst_args, out, "hip")) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(500)
-    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    codes = run_ranks(dist_worker.run_kshard, lambda r, port: (r, 2, port, inst_args, out, "hip"), 2, 500)
+    assert all(c == 0 for c in codes), codes
     res = np.load(out)
     ref = OSolver(verbose=False)
     ref.load(make_model(I.polymin(2, 3, False, seed=2)))
