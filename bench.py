@@ -271,6 +271,9 @@ def _run_cone_sharded(args, world, rank, comm, H, D, torch):
     strong = (args.config == "4")
     side = 80 if strong else args.side
     ncones = 64 if strong else world
+    share = int(os.environ.get("HYP_BENCH_RANK_SHARE", "1"))
+    if strong and share > 1:   # (diagnostic, docs/MULTIGPU.md: the cones one rank of `share` holds, through the SHARDED driver at this world size)
+        ncones = max(world, 64 // share)
     dim = side * (side + 1) // 2
     q = dim * ncones
     owners = D.partition_cones(ncones, world)
@@ -379,7 +382,10 @@ def _run_cone_sharded(args, world, rank, comm, H, D, torch):
             "ms_per_step": elapsed / args.steps * 1e3, "iterations_per_s": its,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("configs[3]: %d x PosSemidefTri side=%d (q=%d), dense random G q x n, n=%d, p=0; the fixed instance at every N, "
-                                    "%d cones per rank" % (ncones, side, q, n, len(mine))) if strong else
+                                    "%d cones per rank" % (ncones, side, q, n, len(mine))
+                                    + (" -- RANK-SHARE EMULATION (HYP_BENCH_RANK_SHARE=%s): only the cones one rank of that many holds, through the sharded "
+                                       "driver; a different model, read its phases only" % os.environ["HYP_BENCH_RANK_SHARE"]
+                                       if int(os.environ.get("HYP_BENCH_RANK_SHARE", "1")) > 1 else "")) if strong else
                                    ("configs[1] block per GPU: %d x PosSemidefTri side=%d (q=%d total), dense random G, n=%d, p=0" % (world, side, q, n)),
                        "n": n, "q": q, "seed": args.seed, "algorithm": algorithm_record(), "parallelism": "cone-shard x%d" % world,
                        "exchange": "RCCL all-reduce (sum, f64, n x n) of the Schur matrix per iteration + small per-solve / per-trial all-reduces, "

@@ -528,7 +528,17 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
         vec_l = np.concatenate([pt.x, pt.z[rows], [pt.tau], pt.s[rows], [pt.kap]])
         res_l = np.concatenate([solver.x_residual, solver.z_residual[rows]])
         dv_l = n + 2 * ql + 2
-        dirs_l = np.zeros((4, dv_l))
+        if getattr(self, "_dirs_l", None) is None or self._dirs_l.shape != (4, dv_l):
+            self._dirs_l = np.zeros((4, dv_l))      # (kept: 13 MB of fresh zeros per iteration at q_local = 207 360 otherwise)
+        dirs_l = self._dirs_l
+        if not hasattr(self, "_dir_rows_set"):
+            # row-local driver with the resident line search: of the four directions the host reads the x rows and tau / kap only
+            # (update_stepper_points_x; the accepted candidate's z / tau / s / kap rows come back from the search): only those are
+            # downloaded (hyp_sys_set_direction_rows).  Decided once per load, the same on every rank (_screen_ok is agreed).
+            import os
+            self._x_only = bool(self.row_local and os.environ.get("HYP_DIRS_X_ONLY", "1") != "0" and self._screen_ok())
+            L.check(L.lib().hyp_sys_set_direction_rows(self.local._h, 1 if self._x_only else 0), "hyp_sys_set_direction_rows")
+            self._dir_rows_set = True
         nc_l = len(model.local_ks)
         flags = (c_int * max(nc_l, 1))()
         info, fb, ns = c_int(0), c_int(0), c_int(0)
@@ -546,8 +556,9 @@ class DistQRCholDenseSystemSolver(QRCholDenseSystemSolver):
         if self.row_local:   # every rank keeps its own rows of the directions; nobody needs the others'
             for k, d in enumerate((stepper.dir_cent, stepper.dir_pred, stepper.dir_centadj, stepper.dir_predadj)):
                 d.x[:] = dirs_l[k, :n]
-                d.z[self.rsl] = dirs_l[k, n:n + ql]
-                d.s[self.rsl] = dirs_l[k, n + ql + 1:n + 2 * ql + 1]
+                if not self._x_only:
+                    d.z[self.rsl] = dirs_l[k, n:n + ql]
+                    d.s[self.rsl] = dirs_l[k, n + ql + 1:n + 2 * ql + 1]
                 d.tau = dirs_l[k, n + ql]
                 d.kap = dirs_l[k, -1]
         else:
