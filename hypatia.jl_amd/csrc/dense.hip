@@ -31,8 +31,9 @@ int potrf_diag_own_cu_lds();
 void potrf_panel_solve_launch(hipStream_t st, int batch, double* A, long lda, long strideA, int k0, int mcols);
 // potrf_mfma.hip: the same two steps cut into 16 x 16 MFMA tiles (default; HYP_POTRF_MFMA=0 restores the first generation)
 void potrf_diag_mfma_launch(hipStream_t st, int batch, double* A, long lda, long strideA, int n, int k0, int* info, int own_cu_lds,
-                            double* tinv = nullptr, long tinv_stride = 0);
+                            double* tinv = nullptr, long tinv_stride = 0, bool prev_update = false);
 bool potrf_tinv_on();
+bool potrf_diag_prev_ok();
 int potrf_diag_mfma_own_cu_lds();
 void potrf_panel_mfma_launch(hipStream_t st, int batch, double* A, long lda, long strideA, int k0, int mcols, int coff = 0,
                              const double* tinv = nullptr, long tinv_stride = 0);
@@ -163,22 +164,38 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
   const long tinv_stride = (long)nblk * 2048;
   if (tinv_on) c.potrf_tinv.ensure((size_t)batch * tinv_stride * sizeof(double));
   int last_la = -1;   // last block step whose trailing update went to the helper stream and has not been joined yet
+  // HYP_POTRF_DIAGUPD=1 (default off): the look-ahead step does not update block row k+1 on the main stream.  The update of the next
+  // DIAGONAL block moves into the next diagonal-block kernel (potrf_mfma.hip: t4_prev_update, the same bits), the update of the rest
+  // of block row k+1 to the helper stream, in front of the big remainder and with an event of its own: the main stream's chain per
+  // block step is  diagonal block -> panel  instead of  diagonal block -> panel -> row update.  Measured (n = 5000): 2.92 - 2.94 ms
+  // against 2.85 - 2.91 -- the 128^3 flops of the block update cost one CU >= 7 us at its FP64 MFMA rate (128 flop / cycle), which is
+  // what the row update on the whole chip took (EXPERIMENTS.md r06-18).
+  static const int du_env = [] { const char* e = getenv("HYP_POTRF_DIAGUPD"); return e ? atoi(e) : 0; }();
+  const bool diagupd = lookahead && du_env != 0 && tiles && potrf_diag_prev_ok() && kb_stop < 0;
+  const size_t ev_strip0 = 2 * (size_t)nblk;   // pool events: 2 kb = T_kb, 2 kb + 1 = R_kb (remainder done), ev_strip0 + kb = row strip of step kb done
+  bool prev_du = false;                        // the previous step left the update of this step's diagonal block to its kernel
+  static const int la_min = [] { const char* e = getenv("HYP_POTRF_LA_MIN"); return e ? atoi(e) : 1536; }();
   for (int kb = 0; kb < nblk; ++kb) {
     if (kb_stop >= 0 && kb >= kb_stop) break;
     const int k0 = kb * NB;
     const int nb = std::min(NB, n - k0);
     const int m = n - k0 - nb;
     double* tinv = tinv_on ? c.potrf_tinv.d() + (long)kb * 2048 : nullptr;
+    // (the last block steps, whose whole trailing update is a ~15 us GEMM, run on the main stream alone: the two ordering
+    //  events of a look-ahead step cost more there -- ~6 us of queue hand-over each -- than the update they would hide)
+    const bool la_step = lookahead && m > la_min;
+    if (diagupd && prev_du && kb >= 2 && last_la == kb - 1) {
+      // this block has the updates of steps <= kb-2 once the remainder of step kb-2 is done (step kb-1's comes with the kernel)
+      HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(2 * (kb - 2) + 1), 0));
+    }
     // factor only: the inverses of all diagonal blocks are produced by ONE launch after the loop
-    if (tiles) potrf_diag_mfma_launch(c.stream, batch, A, lda, strideA, n, k0, d_info, own_cu_lds, tinv, tinv_stride);
+    if (tiles) potrf_diag_mfma_launch(c.stream, batch, A, lda, strideA, n, k0, d_info, own_cu_lds, tinv, tinv_stride, prev_du);
     else potrf_diag_launch(c.stream, true, false, batch, 1, A, lda, strideA, n, k0, dinv, strideD, d_info, own_cu_lds);
     if (m <= 0) break;
     double* A12 = A + (long)(k0 + nb) * lda + k0;
     double* A22 = A + (long)(k0 + nb) * lda + (k0 + nb);
-    // (the last block steps, whose whole trailing update is a ~15 us GEMM, run on the main stream alone: the two ordering
-    //  events of a look-ahead step cost more there -- ~6 us of queue hand-over each -- than the update they would hide)
-    static const int la_min = [] { const char* e = getenv("HYP_POTRF_LA_MIN"); return e ? atoi(e) : 1536; }();
-    const bool la_step = lookahead && m > la_min;
+    if (prev_du) HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(ev_strip0 + kb - 1), 0));   // block row kb right of the diagonal: step kb-1's update
+    prev_du = false;
     if (tiles) potrf_panel_mfma_launch(c.stream, batch, A, lda, strideA, k0, m, 0, tinv, tinv_stride);
     else potrf_panel_solve_launch(c.stream, batch, A, lda, strideA, k0, m);   // A12 <- U11^-T A12 (substitution)
     if (!la_step) {
@@ -191,8 +208,24 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
     }
     const int nb1 = std::min(NB, m);       // block row k+1
     const int mr = m - nb1;                // rows beyond it
-    last_la = kb;
     hipEvent_t Tk = c.pool_event(2 * kb), Rk = c.pool_event(2 * kb + 1);
+    static const int trail_tile = [] { const char* e = getenv("HYP_POTRF_TRAIL_TILE"); return e ? atoi(e) : 64; }();
+    if (diagupd) {
+      last_la = kb;
+      prev_du = true;
+      HYP_CHECK(hipEventRecord(Tk, c.stream));
+      HYP_CHECK(hipStreamWaitEvent(c.stream2, Tk, 0));
+      static const int strip_tile = [] { const char* e = getenv("HYP_POTRF_STRIP_TILE"); return e ? atoi(e) : 0; }();
+      if (mr > 0)   // block row k+1 right of its diagonal block (behind the remainder of step k-1 in the helper's queue, which touched it)
+        potrf_step_gemms(c, c.stream2, nb, nb1, mr, A12, A12 + (long)nb1 * lda, lda, strideA, A22 + (long)nb1 * lda, GEMM_FULL, 1, strip_tile);
+      HYP_CHECK(hipEventRecord(c.pool_event(ev_strip0 + kb), c.stream2));
+      if (mr > 0)
+        potrf_step_gemms(c, c.stream2, nb, mr, mr, A12 + (long)nb1 * lda, A12 + (long)nb1 * lda, lda, strideA, A22 + (long)nb1 * lda + nb1, GEMM_UPPER, 1,
+                         trail_tile);
+      HYP_CHECK(hipEventRecord(Rk, c.stream2));
+      continue;
+    }
+    last_la = kb;
     if (kb >= 1) HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(2 * (kb - 1) + 1), 0));   // rest(k-1) touched block row k+1 too
     static const int look_tile = [] { const char* e = getenv("HYP_POTRF_LOOK_TILE"); return e ? atoi(e) : 0; }();
     potrf_step_gemms(c, c.stream, nb, nb1, m, A12, A12, lda, strideA, A22, GEMM_UPPER_RECT, 1, look_tile, potrf_hiprio());   // block row k+1: diagonal block (upper) + its row panel
@@ -201,7 +234,6 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
     HYP_CHECK(hipEventRecord(Tk, c.stream));
     if (mr > 0) {
       HYP_CHECK(hipStreamWaitEvent(c.stream2, Tk, 0));
-      static const int trail_tile = [] { const char* e = getenv("HYP_POTRF_TRAIL_TILE"); return e ? atoi(e) : 64; }();
       potrf_step_gemms(c, c.stream2, nb, mr, mr, A12 + (long)nb1 * lda, A12 + (long)nb1 * lda, lda, strideA,
                        A22 + (long)nb1 * lda + nb1, GEMM_UPPER, 1, trail_tile);                                // everything below, on the helper stream
     }

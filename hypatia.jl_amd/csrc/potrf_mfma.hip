@@ -953,15 +953,77 @@ __device__ __forceinline__ void t4_steps(d4_t (&acc0)[8], d4_t (&acc1)[8], doubl
   ((JBs < nbt ? t4_step<W, JBs>(acc0, acc1, colp0, colp1, l0, l1, nb, lane, Dt, rinv, Pt, sfail, dflag, Mi, tinv) : (void)0), ...);
 }
 
+// The previous block step's update of THIS diagonal block, folded into its factorization (HYP_POTRF_DIAGUPD, dense.hip): the block
+// C = A[k0:k0+nb, k0:k0+nb] still lacks  C -= P' P,  P = the 128 x nb panel block right above it (solved by the previous step's panel
+// kernel).  Each wavefront forms the products of its own tiles -- the panel's 16-row slices travel through the LDS ring, eight rounds
+// of one barrier -- in accumulators that start at zero, in the k order of the GEMM that used to do it (16-row tiles ascending, MFMA
+// chunks of 4 ascending), and subtracts them from the loaded block with one rounding: the bits of  gemm(alpha = -1, beta = 1).
 template <int W>
+__device__ __forceinline__ void t4_prev_update(d4_t (&acc0)[8], d4_t (&acc1)[8], const double* __restrict__ Pg, long lda, int nb, int lane, double* Pt) {
+  constexpr int C0 = W, C1 = t4_col1(W);
+  const int q = lane >> 4, nn = lane & 15;
+  const double* pc0 = Pg + (long)min(16 * C0 + nn, nb - 1) * lda + q;
+  const double* pc1 = Pg + (long)min(16 * C1 + nn, nb - 1) * lda + q;
+#pragma unroll
+  for (int a = 0; a <= C0; ++a) acc0[a] = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int a = 0; a <= C1; ++a) acc1[a] = (d4_t){0.0, 0.0, 0.0, 0.0};
+  d4_t n0, n1;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { n0[g] = pc0[4 * g]; n1[g] = pc1[4 * g]; }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const d4_t p0 = n0, p1 = n1;
+    if (r + 1 < 8) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { n0[g] = pc0[16 * (r + 1) + 4 * g]; n1[g] = pc1[16 * (r + 1) + 4 * g]; }
+    }
+    double* Pc = Pt + (r % 3) * 8 * TL;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      Pc[C0 * TL + (4 * g + q) * TS + nn] = p0[g];
+      Pc[C1 * TL + (4 * g + q) * TS + nn] = p1[g];
+    }
+    lds_barrier();
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+#pragma unroll
+      for (int a = 0; a <= C0; ++a) acc0[a] = mfma4(Pc[a * TL + (4 * kc + q) * TS + nn], p0[kc], acc0[a]);
+#pragma unroll
+      for (int a = 0; a <= C1; ++a) acc1[a] = mfma4(Pc[a * TL + (4 * kc + q) * TS + nn], p1[kc], acc1[a]);
+    }
+  }
+  lds_barrier();   // (the ring is the factorization's from here)
+}
+
+template <int W, bool HASP>
 __device__ __forceinline__ void t4_wave(double* __restrict__ Ab, long lda, int nb, int nbt, int lane, double* Dt, double* rinv, double* Pt, int* sfail,
-                                        int* dflag, double* Mi, double* tinv) {
+                                        int* dflag, double* Mi, double* tinv, const double* __restrict__ Pg) {
   constexpr int C0 = W, C1 = t4_col1(W);
   const int q = lane >> 4, nn = lane & 15;
   const int l0 = 16 * C0 + nn, l1 = 16 * C1 + nn;
   double* colp0 = Ab + (long)min(l0, nb - 1) * lda;
   double* colp1 = Ab + (long)min(l1, nb - 1) * lda;
   d4_t acc0[8], acc1[8];
+  if constexpr (HASP) {
+    t4_prev_update<W>(acc0, acc1, Pg, lda, nb, lane, Pt);
+#pragma unroll
+    for (int a = 0; a <= C0; ++a) {
+      d4_t c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[r] = colp0[min(16 * a + q + 4 * r, nb - 1)];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc0[a][r] = c[r] - acc0[a][r];
+    }
+#pragma unroll
+    for (int a = 0; a <= C1; ++a) {
+      d4_t c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[r] = colp1[min(16 * a + q + 4 * r, nb - 1)];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc1[a][r] = c[r] - acc1[a][r];
+    }
+  } else {
   // loads: unconditional on clamped addresses (a predicated load is waited for individually), identity padding applied after
 #pragma unroll
   for (int a = 0; a <= C0; ++a)
@@ -971,6 +1033,7 @@ __device__ __forceinline__ void t4_wave(double* __restrict__ Ab, long lda, int n
   for (int a = 0; a <= C1; ++a)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc1[a][r] = colp1[min(16 * a + q + 4 * r, nb - 1)];
+  }
 #pragma unroll
   for (int a = 0; a <= C0; ++a)
 #pragma unroll
@@ -990,6 +1053,7 @@ __device__ __forceinline__ void t4_wave(double* __restrict__ Ab, long lda, int n
   STAMP(5);
 }
 
+template <bool HASP>
 __global__ __launch_bounds__(256) void potrf_tiles4_kernel(double* __restrict__ A, long lda, long strideA, int n, int k0, int* __restrict__ info,
                                                            double* __restrict__ tinv_base, long tinv_stride, int potrf_prio) {
   extern __shared__ __attribute__((aligned(16))) double pm_lds[];
@@ -1009,11 +1073,12 @@ __global__ __launch_bounds__(256) void potrf_tiles4_kernel(double* __restrict__ 
   if (tid == 0) { *sfail = 0; *dflag = 0; }
   STAMP(7);
   lds_barrier();
+  const double* Pg = HASP ? Ab - NB : nullptr;   // the panel block above: rows k0 - 128 .. k0 - 1 of the same columns
   switch (w) {
-    case 0: t4_wave<0>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail, dflag, Mi, tinv); break;
-    case 1: t4_wave<1>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail, dflag, Mi, tinv); break;
-    case 2: t4_wave<2>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail, dflag, Mi, tinv); break;
-    default: t4_wave<3>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail, dflag, Mi, tinv); break;
+    case 0: t4_wave<0, HASP>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail, dflag, Mi, tinv, Pg); break;
+    case 1: t4_wave<1, HASP>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail, dflag, Mi, tinv, Pg); break;
+    case 2: t4_wave<2, HASP>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail, dflag, Mi, tinv, Pg); break;
+    default: t4_wave<3, HASP>(Ab, lda, nb, nbt, lane, Dt, rinv, Pt, sfail, dflag, Mi, tinv, Pg); break;
   }
   lds_barrier();   // (the failure record of the last step is written behind its barrier)
   if (tid == 0 && *sfail && *sfail <= nb) atomicCAS(&info[blockIdx.x], 0, k0 + *sfail);
@@ -1161,16 +1226,25 @@ bool potrf_tinv_on() {
   static const bool on = [] { const char* e = getenv("HYP_POTRF_TINV"); return !(e && atoi(e) == 0); }();
   return on && potrf_la_on();
 }
+bool potrf_diag_prev_ok() {   // the diagonal-block kernel that can take the previous step's update of its block (prev_update below)
+  static const bool defer = [] { const char* e = getenv("HYP_POTRF_DEFER"); return !(e && atoi(e) == 0); }();
+  return potrf_la_on() && potrf_tinv_on() && defer;
+}
 void potrf_diag_mfma_launch(hipStream_t st, int batch, double* A, long lda, long strideA, int n, int k0, int* info, int own_cu_lds, double* tinv,
-                            long tinv_stride) {
+                            long tinv_stride, bool prev_update) {
+  if (prev_update && !(potrf_diag_prev_ok() && k0 >= NB)) {
+    fprintf(stderr, "potrf_diag_mfma_launch: prev_update needs the tiles4 kernel and a full panel block above\n");
+    abort();
+  }
   if (potrf_la_on()) {
     const size_t lds = (size_t)(TL + 16 + 2 * 8 * TL + 2 + TL) * sizeof(double);
     const size_t want = own_cu_lds > 0 ? std::max<size_t>(lds, (size_t)own_cu_lds) : lds;
     static const bool defer = [] { const char* e = getenv("HYP_POTRF_DEFER"); return !(e && atoi(e) == 0); }();
     if (potrf_tinv_on() && defer) {
       const size_t lds4 = (size_t)(2 * TL + 16 + 3 * 8 * TL + 2) * sizeof(double);
-      hipLaunchKernelGGL(potrf_tiles4_kernel, dim3(batch), dim3(256), own_cu_lds > 0 ? std::max<size_t>(lds4, (size_t)own_cu_lds) : lds4, st, A, lda,
-                         strideA, n, k0, info, tinv, tinv_stride, potrf_hiprio());
+      const size_t l4 = own_cu_lds > 0 ? std::max<size_t>(lds4, (size_t)own_cu_lds) : lds4;
+      if (prev_update) hipLaunchKernelGGL(potrf_tiles4_kernel<true>, dim3(batch), dim3(256), l4, st, A, lda, strideA, n, k0, info, tinv, tinv_stride, potrf_hiprio());
+      else hipLaunchKernelGGL(potrf_tiles4_kernel<false>, dim3(batch), dim3(256), l4, st, A, lda, strideA, n, k0, info, tinv, tinv_stride, potrf_hiprio());
     } else if (potrf_tinv_on()) hipLaunchKernelGGL((potrf_tiles_kernel<4, 8, true>), dim3(batch), dim3(256), want, st, A, lda, strideA, n, k0, info, tinv, tinv_stride);
     else hipLaunchKernelGGL((potrf_tiles_kernel<4, 8, false>), dim3(batch), dim3(256), want, st, A, lda, strideA, n, k0, info, nullptr, 0L);
   } else {
@@ -1183,7 +1257,8 @@ void potrf_diag_mfma_launch(hipStream_t st, int batch, double* A, long lda, long
 int potrf_diag_mfma_own_cu_lds() {
   const int want = 124 * 1024;
   hipError_t e = !potrf_la_on() ? hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_diag_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want)
-                 : potrf_tinv_on() ? ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_tiles4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want),
+                 : potrf_tinv_on() ? ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_tiles4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, want),
+                                      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_tiles4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, want),
                                       hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_tiles_kernel<4, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, want))
                                    : hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_tiles_kernel<4, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
   if (e != hipSuccess) {

@@ -388,3 +388,17 @@ def test_potrf_forms_of_the_diagonal_block_kernel(n, cond):
     assert new["sha"] != subst["sha"]                     # (different rounding: the comparison below is not vacuous)
     assert new["berr"] <= 1.5 * subst["berr"] + 1e-19, (new["berr"], subst["berr"])
     assert new["berr"] <= 4e-16 / n ** 0.5                # || U'U - A || / (n || A ||): a few eps over n^1.5
+
+
+@pytest.mark.parametrize("n,cond", [(1900, 0), (2250, 1e10), (5000, 0)])
+def test_potrf_diag_update_in_the_diagonal_block_kernel(n, cond):
+    """round 6: with look-ahead, the previous block step's update of the next diagonal block is formed inside that block's
+    factorization kernel (potrf_mfma.hip: t4_prev_update) and the rest of the block row is updated on the helper stream
+    (dense.hip: HYP_POTRF_DIAGUPD=1; measured and left off, EXPERIMENTS.md r06-18).  Same products in the same order as the GEMM that did it before: the same bits as
+    HYP_POTRF_DIAGUPD=0, and as the factorization without look-ahead."""
+    new = _potrf_variant(n, cond, {"HYP_POTRF_DIAGUPD": "1"})
+    old = _potrf_variant(n, cond, {"HYP_POTRF_DIAGUPD": "0"})
+    plain = _potrf_variant(n, cond, {"HYP_POTRF_LOOKAHEAD": "0"})
+    assert new["info"] == old["info"] == plain["info"] == 0
+    assert new["sha"] == old["sha"] == plain["sha"]
+    assert new["berr"] <= 4e-16 / n ** 0.5
