@@ -40,8 +40,9 @@ void potrf_panel_mfma_launch(hipStream_t st, int batch, double* A, long lda, lon
 
 int potrf_hiprio();   // potrf_mfma.hip
 static void potrf_step_gemms(Ctx& c, hipStream_t st, int nb, int M, int N, const double* U12a, const double* U12b, long lda, long strideA,
-                             double* C, int tri, int batch, int tile_hint = 0, int hiprio = 0) {
+                             double* C, int tri, int batch, int tile_hint = 0, int hiprio = 0, int tri_off = 0) {
   GemmArgs s{};   // C <- C - U12a' U12b
+  s.tri_off = tri_off;
   s.tile_hint = tile_hint;
   s.hiprio = hiprio;
   s.M = M; s.N = N; s.K = nb;
@@ -138,9 +139,21 @@ hipEvent_t Ctx::pool_event(size_t i) {
   return ev_pool[i];
 }
 
-void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int batch, double* dinv, int* d_info, int kb_stop) {
+// One run of the blocked factorization: block steps kb_start .. (kb_stop or the end) of the leading n x n matrix, on the queues
+// `main` (the critical chain) and `helper` (the look-ahead's remainders).  potrf_upper_batched is the whole factorization on the
+// context's two streams; the split factorization of the Schur complement (potrf_split_*, below) runs a leading part on other queues
+// while the product still forms the rest of the matrix, and later continues from block step kb_start.
+struct PotrfRun {
+  hipStream_t main, helper;
+  int kb_start = 0, kb_stop = -1;
+  bool zero_info = true;
+  size_t ev_base = 0;     // first event of the context's pool this run may use (3 per block step)
+  int tinv_nblk = 0;      // block steps the tile-inverse record must hold (0: this run's own count)
+};
+static void potrf_upper_run(Ctx& c, int n, double* A, long lda, long strideA, int batch, double* dinv, int* d_info, const PotrfRun& R) {
   if (n <= 0 || batch <= 0) return;
-  c.zero(d_info, sizeof(int) * batch);
+  const int kb_stop = R.kb_stop;
+  if (R.zero_info) HYP_CHECK(hipMemsetAsync(d_info, 0, sizeof(int) * batch, R.main));
   const long strideD = (long)dinv_elems(n);
   const int nblk = (n + NB - 1) / NB;
   // Look-ahead (one big matrix): after the panel solve of step k, the main stream only updates block
@@ -161,7 +174,7 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
   // written by the diagonal-block kernel of step kb, read by that step's panel kernels (which may still run, on the helper queue,
   // when the next diagonal block is being factored: hence a record per step)
   const bool tinv_on = tiles && potrf_tinv_on();
-  const long tinv_stride = (long)nblk * 2048;
+  const long tinv_stride = (long)std::max(nblk, R.tinv_nblk) * 2048;
   if (tinv_on) c.potrf_tinv.ensure((size_t)batch * tinv_stride * sizeof(double));
   int last_la = -1;   // last block step whose trailing update went to the helper stream and has not been joined yet
   // HYP_POTRF_DIAGUPD=1 (default off): the look-ahead step does not update block row k+1 on the main stream.  The update of the next
@@ -175,7 +188,7 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
   const size_t ev_strip0 = 2 * (size_t)nblk;   // pool events: 2 kb = T_kb, 2 kb + 1 = R_kb (remainder done), ev_strip0 + kb = row strip of step kb done
   bool prev_du = false;                        // the previous step left the update of this step's diagonal block to its kernel
   static const int la_min = [] { const char* e = getenv("HYP_POTRF_LA_MIN"); return e ? atoi(e) : 1536; }();
-  for (int kb = 0; kb < nblk; ++kb) {
+  for (int kb = R.kb_start; kb < nblk; ++kb) {
     if (kb_stop >= 0 && kb >= kb_stop) break;
     const int k0 = kb * NB;
     const int nb = std::min(NB, n - k0);
@@ -186,61 +199,172 @@ void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int b
     const bool la_step = lookahead && m > la_min;
     if (diagupd && prev_du && kb >= 2 && last_la == kb - 1) {
       // this block has the updates of steps <= kb-2 once the remainder of step kb-2 is done (step kb-1's comes with the kernel)
-      HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(2 * (kb - 2) + 1), 0));
+      HYP_CHECK(hipStreamWaitEvent(R.main, c.pool_event(R.ev_base + 2 * (kb - 2) + 1), 0));
     }
     // factor only: the inverses of all diagonal blocks are produced by ONE launch after the loop
-    if (tiles) potrf_diag_mfma_launch(c.stream, batch, A, lda, strideA, n, k0, d_info, own_cu_lds, tinv, tinv_stride, prev_du);
-    else potrf_diag_launch(c.stream, true, false, batch, 1, A, lda, strideA, n, k0, dinv, strideD, d_info, own_cu_lds);
+    if (tiles) potrf_diag_mfma_launch(R.main, batch, A, lda, strideA, n, k0, d_info, own_cu_lds, tinv, tinv_stride, prev_du);
+    else potrf_diag_launch(R.main, true, false, batch, 1, A, lda, strideA, n, k0, dinv, strideD, d_info, own_cu_lds);
     if (m <= 0) break;
     double* A12 = A + (long)(k0 + nb) * lda + k0;
     double* A22 = A + (long)(k0 + nb) * lda + (k0 + nb);
-    if (prev_du) HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(ev_strip0 + kb - 1), 0));   // block row kb right of the diagonal: step kb-1's update
+    if (prev_du) HYP_CHECK(hipStreamWaitEvent(R.main, c.pool_event(R.ev_base + ev_strip0 + kb - 1), 0));   // block row kb right of the diagonal: step kb-1's update
     prev_du = false;
-    if (tiles) potrf_panel_mfma_launch(c.stream, batch, A, lda, strideA, k0, m, 0, tinv, tinv_stride);
-    else potrf_panel_solve_launch(c.stream, batch, A, lda, strideA, k0, m);   // A12 <- U11^-T A12 (substitution)
+    if (tiles) potrf_panel_mfma_launch(R.main, batch, A, lda, strideA, k0, m, 0, tinv, tinv_stride);
+    else potrf_panel_solve_launch(R.main, batch, A, lda, strideA, k0, m);   // A12 <- U11^-T A12 (substitution)
     if (!la_step) {
       if (lookahead && last_la >= 0) {   // the helper stream's last update touched everything below: join it once
-        HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(2 * last_la + 1), 0));
+        HYP_CHECK(hipStreamWaitEvent(R.main, c.pool_event(R.ev_base + 2 * last_la + 1), 0));
         last_la = -1;
       }
-      potrf_step_gemms(c, c.stream, nb, m, m, A12, A12, lda, strideA, A22, GEMM_UPPER, batch);   // A22 -= A12' A12 (upper)
+      potrf_step_gemms(c, R.main, nb, m, m, A12, A12, lda, strideA, A22, GEMM_UPPER, batch);   // A22 -= A12' A12 (upper)
       continue;
     }
     const int nb1 = std::min(NB, m);       // block row k+1
     const int mr = m - nb1;                // rows beyond it
-    hipEvent_t Tk = c.pool_event(2 * kb), Rk = c.pool_event(2 * kb + 1);
+    hipEvent_t Tk = c.pool_event(R.ev_base + 2 * kb), Rk = c.pool_event(R.ev_base + 2 * kb + 1);
     static const int trail_tile = [] { const char* e = getenv("HYP_POTRF_TRAIL_TILE"); return e ? atoi(e) : 64; }();
     if (diagupd) {
       last_la = kb;
       prev_du = true;
-      HYP_CHECK(hipEventRecord(Tk, c.stream));
-      HYP_CHECK(hipStreamWaitEvent(c.stream2, Tk, 0));
+      HYP_CHECK(hipEventRecord(Tk, R.main));
+      HYP_CHECK(hipStreamWaitEvent(R.helper, Tk, 0));
       static const int strip_tile = [] { const char* e = getenv("HYP_POTRF_STRIP_TILE"); return e ? atoi(e) : 0; }();
       if (mr > 0)   // block row k+1 right of its diagonal block (behind the remainder of step k-1 in the helper's queue, which touched it)
-        potrf_step_gemms(c, c.stream2, nb, nb1, mr, A12, A12 + (long)nb1 * lda, lda, strideA, A22 + (long)nb1 * lda, GEMM_FULL, 1, strip_tile);
-      HYP_CHECK(hipEventRecord(c.pool_event(ev_strip0 + kb), c.stream2));
+        potrf_step_gemms(c, R.helper, nb, nb1, mr, A12, A12 + (long)nb1 * lda, lda, strideA, A22 + (long)nb1 * lda, GEMM_FULL, 1, strip_tile);
+      HYP_CHECK(hipEventRecord(c.pool_event(R.ev_base + ev_strip0 + kb), R.helper));
       if (mr > 0)
-        potrf_step_gemms(c, c.stream2, nb, mr, mr, A12 + (long)nb1 * lda, A12 + (long)nb1 * lda, lda, strideA, A22 + (long)nb1 * lda + nb1, GEMM_UPPER, 1,
+        potrf_step_gemms(c, R.helper, nb, mr, mr, A12 + (long)nb1 * lda, A12 + (long)nb1 * lda, lda, strideA, A22 + (long)nb1 * lda + nb1, GEMM_UPPER, 1,
                          trail_tile);
-      HYP_CHECK(hipEventRecord(Rk, c.stream2));
+      HYP_CHECK(hipEventRecord(Rk, R.helper));
       continue;
     }
     last_la = kb;
-    if (kb >= 1) HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(2 * (kb - 1) + 1), 0));   // rest(k-1) touched block row k+1 too
+    if (kb >= 1) HYP_CHECK(hipStreamWaitEvent(R.main, c.pool_event(R.ev_base + 2 * (kb - 1) + 1), 0));   // rest(k-1) touched block row k+1 too
     static const int look_tile = [] { const char* e = getenv("HYP_POTRF_LOOK_TILE"); return e ? atoi(e) : 0; }();
-    potrf_step_gemms(c, c.stream, nb, nb1, m, A12, A12, lda, strideA, A22, GEMM_UPPER_RECT, 1, look_tile, potrf_hiprio());   // block row k+1: diagonal block (upper) + its row panel
+    potrf_step_gemms(c, R.main, nb, nb1, m, A12, A12, lda, strideA, A22, GEMM_UPPER_RECT, 1, look_tile, potrf_hiprio());   // block row k+1: diagonal block (upper) + its row panel
     // the big remainder starts only after the main stream's small updates are queued: it then runs
     // underneath the next diagonal-block kernel + panel solve instead of competing with them
-    HYP_CHECK(hipEventRecord(Tk, c.stream));
+    HYP_CHECK(hipEventRecord(Tk, R.main));
     if (mr > 0) {
-      HYP_CHECK(hipStreamWaitEvent(c.stream2, Tk, 0));
-      potrf_step_gemms(c, c.stream2, nb, mr, mr, A12 + (long)nb1 * lda, A12 + (long)nb1 * lda, lda, strideA,
+      HYP_CHECK(hipStreamWaitEvent(R.helper, Tk, 0));
+      potrf_step_gemms(c, R.helper, nb, mr, mr, A12 + (long)nb1 * lda, A12 + (long)nb1 * lda, lda, strideA,
                        A22 + (long)nb1 * lda + nb1, GEMM_UPPER, 1, trail_tile);                                // everything below, on the helper stream
     }
+    HYP_CHECK(hipEventRecord(Rk, R.helper));
+  }
+  if (lookahead && last_la >= 0) HYP_CHECK(hipStreamWaitEvent(R.main, c.pool_event(R.ev_base + 2 * last_la + 1), 0));
+  if (dinv && kb_stop < 0) {
+    if (R.main != c.stream) { fprintf(stderr, "potrf_upper_run: the block inverses are formed on the context's stream\n"); abort(); }
+    potrf_invert_diag_blocks(c, n, A, lda, strideA, batch, dinv);
+  }
+}
+
+void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int batch, double* dinv, int* d_info, int kb_stop) {
+  PotrfRun R;
+  R.main = c.stream; R.helper = c.stream2; R.kb_stop = kb_stop;
+  potrf_upper_run(c, n, A, lda, strideA, batch, dinv, d_info, R);
+}
+
+
+// ---- the Schur complement's product and factorization in two column groups (round 6, HYP_CHOL_SPLIT) ---------------------------
+// The upper Cholesky factor of the leading n1 x n1 block needs only that block: the Schur syrk forms the block columns [0, n1) first,
+// and while it forms the rest (the trapezoid of the columns [n1, n): at config 2 more than half of its 8.4 ms) the leading block is
+// factored on two other queues -- a chain of ~60 us block steps that leaves the chip to the product.  What remains behind the
+// product is (a) the block steps 0 .. n1/128 - 1 REPLAYED for the late columns -- panel solve and rank-128 update of step k
+// restricted to the columns >= n1, the operations the one-piece factorization applies to these columns, in its order, so every
+// entry sees the same sequence of roundings --, and (b) the block steps of the trailing (n - n1) block.
+// schur_split_begin: everything up to the end of the product (on the context's stream; the leading factorization on the queues
+// `lane` and the context's helper stream).  schur_split_finish: the rest, on the context's streams.
+bool potrf_split_ok(int n, int n1) {
+  static const int mfma_env = [] { const char* e = getenv("HYP_POTRF_MFMA"); return e ? atoi(e) : 1; }();
+  return mfma_env != 0 && n1 % NB == 0 && n1 >= 6 * NB && n - n1 >= NB;
+}
+
+// A queue whose kernels leave `free_per_xcd` compute units of every XCD alone (hipExtStreamCreateWithCUMask; mask bit b = CU b / 8
+// of XCD b mod 8, tools/probe_cumask.hip).  Beside a product that fills every CU with two workgroups of 70 KB of LDS and 1.3 ms of
+// life, the factorization's kernels (77 - 124 KB of LDS) found no compute unit for milliseconds: the first diagonal block waited
+// 1.4 ms, the first panel 4 ms (profiles/r06_chol_split_timeline_unmasked.txt).
+static hipStream_t masked_stream(Ctx& c, int free_per_xcd) {
+  static hipStream_t st[9] = {};
+  static int dev[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
+  free_per_xcd = std::min(8, std::max(1, free_per_xcd));
+  if (st[free_per_xcd] && dev[free_per_xcd] == c.device) return st[free_per_xcd];
+  std::vector<uint32_t> m(8, 0xffffffffu);
+  for (int b = 0; b < 8 * free_per_xcd; ++b) m[b / 32] &= ~(1u << (b % 32));
+  hipStream_t s;
+  HYP_CHECK(hipExtStreamCreateWithCUMask(&s, 8, m.data()));
+  st[free_per_xcd] = s; dev[free_per_xcd] = c.device;
+  return s;
+}
+
+void schur_split_begin(Ctx& c, int n, int K, const double* A, long lda, double* C, double* F, int n1, int* d_info, hipStream_t lane,
+                       hipEvent_t left_ready, hipEvent_t left_done) {
+  GemmArgs s{};
+  s.M = n; s.N = n; s.K = K; s.A = A; s.lda = lda; s.B = A; s.ldb = lda; s.C = C; s.ldc = n;
+  s.alpha = 1; s.beta = 0; s.tri = GEMM_UPPER; s.krange = KR_ALL; s.batch = 1; s.tag = 1;
+  static const int free_cu = [] { const char* e = getenv("HYP_CHOL_SPLIT_FREE"); return e ? atoi(e) : 2; }();
+  static const bool serial = [] { const char* e = getenv("HYP_CHOL_SPLIT_SERIAL"); return e && atoi(e) == 1; }();   // (measurement: no overlap)
+  HYP_CHECK(schur_syrk_cols(c.stream, s, 0, n1, &c.gemm_scratch));
+  c.d2d(F, C, (size_t)n1 * n * sizeof(double));   // (block columns are contiguous)
+  HYP_CHECK(hipEventRecord(left_ready, c.stream));
+  if (!serial) HYP_CHECK(hipStreamWaitEvent(lane, left_ready, 0));
+  hipEvent_t right_done = c.pool_event(6 * (size_t)((n + NB - 1) / NB) + 1);
+  auto right = [&] {
+    if (free_cu > 0) {
+      hipStream_t ms = masked_stream(c, free_cu);
+      HYP_CHECK(hipStreamWaitEvent(ms, left_ready, 0));
+      HYP_CHECK(schur_syrk_cols(ms, s, n1, n, &c.gemm_scratch));
+      HYP_CHECK(hipEventRecord(right_done, ms));
+      HYP_CHECK(hipStreamWaitEvent(c.stream, right_done, 0));
+    } else {
+      HYP_CHECK(schur_syrk_cols(c.stream, s, n1, n, &c.gemm_scratch));
+    }
+  };
+  if (serial) {
+    right();
+    HYP_CHECK(hipEventRecord(right_done, c.stream));
+    HYP_CHECK(hipStreamWaitEvent(lane, right_done, 0));
+  }
+  PotrfRun R;
+  R.main = lane; R.helper = c.stream2; R.tinv_nblk = (n + NB - 1) / NB;
+  potrf_upper_run(c, n1, F, n, 0, 1, nullptr, d_info, R);
+  HYP_CHECK(hipEventRecord(left_done, lane));
+  if (!serial) right();
+}
+
+void schur_split_finish(Ctx& c, int n, const double* C, double* F, int n1, double* dinv, int* d_info, hipEvent_t left_done) {
+  const int nblk = (n + NB - 1) / NB, p = n1 / NB, m2 = n - n1;
+  c.d2d(F + (size_t)n1 * n, C + (size_t)n1 * n, (size_t)m2 * n * sizeof(double));
+  HYP_CHECK(hipStreamWaitEvent(c.stream, left_done, 0));
+  const bool tinv_on = potrf_tinv_on();
+  const long tinv_stride = (long)nblk * 2048;
+  const size_t ev0 = 3 * (size_t)nblk;
+  static const int cu_la = [] { const char* e = getenv("HYP_CHOL_SPLIT_LA"); return e ? atoi(e) : 1; }();
+  static const int trail_tile = [] { const char* e = getenv("HYP_POTRF_TRAIL_TILE"); return e ? atoi(e) : 64; }();
+  for (int k = 0; k < p; ++k) {
+    const int k0 = k * NB, r0 = k0 + NB;
+    potrf_panel_mfma_launch(c.stream, 1, F, n, 0, k0, m2, n1 - r0, tinv_on ? c.potrf_tinv.d() + (long)k * 2048 : nullptr, tinv_stride);
+    const double* Pa = F + (long)r0 * n + k0;      // row panel k from column r0 on: the rows of the update
+    const double* Pb = F + (long)n1 * n + k0;      // ... its late columns
+    double* Cu = F + (long)n1 * n + r0;
+    const int M = n - r0;                          // rows r0 .. n - 1, of which row i meets the columns >= max(i, n1)
+    if (!cu_la || M <= NB) {
+      potrf_step_gemms(c, c.stream, NB, M, m2, Pa, Pb, n, 0, Cu, GEMM_UPPER_RECT, 1, 0, 0, n1 - r0);
+      continue;
+    }
+    // block row k+1 (all the next panel solve needs) here, the rest on the helper stream underneath the following steps
+    hipEvent_t Tk = c.pool_event(ev0 + 2 * k), Rk = c.pool_event(ev0 + 2 * k + 1);
+    if (k >= 1) HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(ev0 + 2 * (k - 1) + 1), 0));
+    potrf_step_gemms(c, c.stream, NB, NB, m2, Pa, Pb, n, 0, Cu, GEMM_UPPER_RECT, 1, 0, potrf_hiprio(), n1 - r0);
+    HYP_CHECK(hipEventRecord(Tk, c.stream));
+    HYP_CHECK(hipStreamWaitEvent(c.stream2, Tk, 0));
+    potrf_step_gemms(c, c.stream2, NB, M - NB, m2, Pa + (long)NB * n, Pb, n, 0, Cu + NB, GEMM_UPPER_RECT, 1, trail_tile, 0, n1 - r0 - NB);
     HYP_CHECK(hipEventRecord(Rk, c.stream2));
   }
-  if (lookahead && last_la >= 0) HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(2 * last_la + 1), 0));
-  if (dinv && kb_stop < 0) potrf_invert_diag_blocks(c, n, A, lda, strideA, batch, dinv);
+  if (cu_la && p >= 1 && n - p * NB > NB) HYP_CHECK(hipStreamWaitEvent(c.stream, c.pool_event(ev0 + 2 * (p - 1) + 1), 0));
+  PotrfRun R;
+  R.main = c.stream; R.helper = c.stream2; R.kb_start = p; R.zero_info = false; R.tinv_nblk = nblk;
+  potrf_upper_run(c, n, F, n, 0, 1, dinv, d_info, R);
 }
 
 void potrf_invert_diag_blocks(Ctx& c, int n, double* A, long lda, long strideA, int batch, double* dinv, long strideD) {

@@ -95,5 +95,7 @@ struct GemmScratch {
 
 // launch on `st`; returns the HIP launch status
 hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch* scratch = nullptr);
+// block columns [c0, c1) of the upper Schur syrk described by `a` (c0 = 0: the leading block; c0 > 0: the rest, c1 = a.N)
+hipError_t schur_syrk_cols(hipStream_t st, GemmArgs a, int c0, int c1, GemmScratch* scratch);
 
 }  // namespace hyp

@@ -500,6 +500,23 @@ __global__ __launch_bounds__(256) void syrk_edge_kernel(int K, int N, int N0, in
   }
 }
 
+// the r <= 32 edge columns of the Schur syrk (columns N0 .. N0 + r - 1, every row up to the diagonal) by syrk_edge_kernel
+static bool syrk_edge_ok(const GemmArgs& a) {
+  static const bool edge_on = [] { const char* e = getenv("HYP_SYRK_EDGE"); return !(e && atoi(e) == 0); }();
+  return edge_on && ((uintptr_t)a.A % 16 == 0) && (a.lda % 2 == 0);
+}
+static hipError_t syrk_edge_launch(hipStream_t st, const GemmArgs& a, int N0, int r) {
+  // columns of A per workgroup: every workgroup re-reads the edge columns from L2 (R K doubles); eight measured better than
+  // four at K = 207 360 (config 4: 1.66 vs 2.19 ms per launch) and at K = 20 100 (config 2: syrk phase 8.30 vs 8.36 ms)
+  static const int cb_env = [] { const char* e = getenv("HYP_SYRK_EDGE_CB"); return e ? atoi(e) : 8; }();
+  const int cb = cb_env;
+  for (int e0 = 0; e0 < r; e0 += 8) {
+    if (cb == 8) hipLaunchKernelGGL((syrk_edge_kernel<8, 8>), dim3((a.N + 7) / 8), dim3(256), 0, st, a.K, a.N, N0, e0, r, a.A, a.lda, a.alpha, a.beta, a.C, a.ldc);
+    else hipLaunchKernelGGL((syrk_edge_kernel<4, 8>), dim3((a.N + 3) / 4), dim3(256), 0, st, a.K, a.N, N0, e0, r, a.A, a.lda, a.alpha, a.beta, a.C, a.ldc);
+  }
+  return hipGetLastError();
+}
+
 hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch* gs) {
   if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return hipSuccess;
   // Schur syrk with a thin last tile column (n = 5000 = 39 x 128 + 8): the 128-wide edge workgroup tiles
@@ -518,18 +535,7 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch*
     s.C = a.C + (long)N0 * a.ldc;
     s.tri = GEMM_UPPER_RECT; s.tri_off = N0;
     s.tile_hint = 64; s.splitk_req = 8;
-    static const bool edge_on = [] { const char* e = getenv("HYP_SYRK_EDGE"); return !(e && atoi(e) == 0); }();
-    if (edge_on && ((uintptr_t)a.A % 16 == 0) && (a.lda % 2 == 0)) {
-      // columns of A per workgroup: every workgroup re-reads the edge columns from L2 (R K doubles); eight measured better than
-      // four at K = 207 360 (config 4: 1.66 vs 2.19 ms per launch) and at K = 20 100 (config 2: syrk phase 8.30 vs 8.36 ms)
-      static const int cb_env = [] { const char* e = getenv("HYP_SYRK_EDGE_CB"); return e ? atoi(e) : 8; }();
-      const int cb = cb_env;
-      for (int e0 = 0; e0 < r; e0 += 8) {
-        if (cb == 8) hipLaunchKernelGGL((syrk_edge_kernel<8, 8>), dim3((a.N + 7) / 8), dim3(256), 0, st, a.K, a.N, N0, e0, r, a.A, a.lda, a.alpha, a.beta, a.C, a.ldc);
-        else hipLaunchKernelGGL((syrk_edge_kernel<4, 8>), dim3((a.N + 3) / 4), dim3(256), 0, st, a.K, a.N, N0, e0, r, a.A, a.lda, a.alpha, a.beta, a.C, a.ldc);
-      }
-      return hipGetLastError();
-    }
+    if (syrk_edge_ok(a)) return syrk_edge_launch(st, a, N0, r);
     return gemm_f64_launch(st, transa, s, gs);
   }
   // tile choice: the 128 x 128 tile unless the product is too small to fill the chip with it
@@ -653,6 +659,47 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch*
                        a.splitk_base, a.part, a.part_ld, a.part_stride, a.alpha, a.beta, a.C, a.ldc, a.tail_q - 1, a.tail_first,
                        a.tile_map ? a.tile_map + 2 * nblk : nullptr, a.tiles_n, (long)a.splitk * a.part_stride, a.strideC);
   return hipGetLastError();
+}
+
+// Block columns [c0, c1) of the Schur syrk  C = A'A (upper; `a` = the whole product's arguments, tag 1): c0 = 0 is the syrk of the
+// leading c1 columns, c0 > 0 (a multiple of 128, c1 = N) the trapezoid  C[0:N, c0:N], rows <= columns  -- for the factorization
+// that starts on the leading block while the rest is still being formed (dense.hip: schur_split_begin).  The slice count of the
+// trapezoid is chosen on the tiles that do work (the launch's grid is the full rectangle; tiles below the diagonal exit).
+hipError_t schur_syrk_cols(hipStream_t st, GemmArgs a, int c0, int c1, GemmScratch* gs) {
+  static const int s_env = [] { const char* e = getenv("HYP_CHOL_SPLIT_S"); return e ? atoi(e) : 0; }();
+  if (c0 == 0) {
+    GemmArgs l = a;
+    l.M = l.N = c1;
+    if (s_env > 0) l.splitk_req = s_env;
+    return gemm_f64_launch(st, true, l, gs);
+  }
+  const int N = a.N;
+  int r = N % 128, N0 = N - r;
+  if (!(r > 0 && r <= 32 && a.K >= 4096 && syrk_edge_ok(a))) { r = 0; N0 = N; }
+  GemmArgs t = a;
+  t.M = N0; t.N = N0 - c0;
+  t.B = a.A + (long)c0 * a.lda;
+  t.C = a.C + (long)c0 * a.ldc;
+  t.tri = GEMM_UPPER_RECT; t.tri_off = c0;
+  if (t.N > 0) {
+    const long tm = (t.M + 127) / 128, tn = (t.N + 127) / 128, tc0 = c0 / 128;
+    long real = 0;
+    for (long j = 0; j < tn; ++j) real += std::min(tm, tc0 + j + 1);
+    int S = 1;
+    double best = 1e30;
+    const double eps = ((double)t.M * t.N * 4.6e-12) / (2.6e-7 * a.K);   // (the partial sums' traffic, as for the square product)
+    for (int q = 1; q <= 8; ++q) {
+      if (a.K / q < 1024) break;
+      const double cost = (double)((real * q + 511) / 512) / q + (q > 1 ? q * eps : 0.0);
+      if (cost < best - 1e-9) { best = cost; S = q; }
+    }
+    if (s_env > 0) S = s_env;
+    t.splitk_req = S;
+    hipError_t e = gemm_f64_launch(st, true, t, gs);
+    if (e != hipSuccess) return e;
+  }
+  if (r > 0) return syrk_edge_launch(st, a, N0, r);
+  return hipSuccess;
 }
 
 }  // namespace hyp

@@ -204,6 +204,12 @@ void join_lanes(Ctx& c, int nlanes);   // the main stream waits for lanes 1 .. n
 void potrf_upper_batched(Ctx& c, int n, double* A, long lda, long strideA, int batch, double* dinv, int* d_info, int kb_stop = -1);
 // (kb_stop >= 0: only block steps 0 .. kb_stop - 1, each with its whole trailing update: rows < NB kb_stop hold rows of the factor, the
 //  trailing block its Schur complement -- the start of the hybrid factorization of BKFact::factor_from)
+// The Schur complement C = A'A (A: K x n, ld lda; C n x n, ld n) and its factorization F = chol(C) in two column groups, the leading
+// n1 x n1 block factored (queues `lane` + the helper stream) while the product forms the columns >= n1 (dense.hip)
+bool potrf_split_ok(int n, int n1);
+void schur_split_begin(Ctx& c, int n, int K, const double* A, long lda, double* C, double* F, int n1, int* d_info, hipStream_t lane,
+                       hipEvent_t left_ready, hipEvent_t left_done);
+void schur_split_finish(Ctx& c, int n, const double* C, double* F, int n1, double* dinv, int* d_info, hipEvent_t left_done);
 void potrf_invert_diag_blocks(Ctx& c, int n, double* A /* factored */, long lda, long strideA, int batch, double* dinv,
                               long strideD = 0 /* doubles between the batch members' dinv; 0: dinv_elems(n) */);
 constexpr long DINV_BLK = 2L * NB * NB;

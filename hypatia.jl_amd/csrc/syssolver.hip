@@ -50,8 +50,10 @@ SysSolver::SysSolver(Ctx& c, int n_, int p_, int q_, const std::vector<Cone*>& c
 SysSolver::~SysSolver() {
   if (const char* e = getenv("HYP_RP_PREFETCH_STATS"))
     if (e[0] == '1') fprintf(stderr, "[residual_products prefetch] handed out %ld, recomputed %ld\n", rp_pre_hits, rp_pre_misses);
+  if (const char* e = getenv("HYP_CHOL_SPLIT_STATS"))
+    if (e[0] == '1') fprintf(stderr, "[chol split] %ld factorizations in two column groups\n", chol_split_count);
   if (rp_pre_host) (void)hipHostFree(rp_pre_host);
-  for (hipEvent_t e : {rp_pre_ev, plan_ev_fork, plan_ev_done, dirs_copied_ev, up_ev0, up_ev1})
+  for (hipEvent_t e : {rp_pre_ev, plan_ev_fork, plan_ev_done, dirs_copied_ev, up_ev0, up_ev1, split_ev_ready, split_ev_done})
     if (e) (void)hipEventDestroy(e);
 }
 
@@ -649,7 +651,14 @@ void SysSolver::update_lhs_fact(int* info, int* used_fallback) {   // qrchol.jl:
   factor_lhs(info, used_fallback);
 }
 
+static bool force_bk_env();
+
 void SysSolver::assemble_lhs() {
+  if (split_unjoined) {   // (a split factorization nobody finished: its lane must not run into this assembly's copies)
+    HYP_CHECK(hipStreamWaitEvent(ctx.stream, split_ev_done, 0));
+    split_unjoined = false;
+  }
+  chol_split_n1 = 0;
   group_inverses();   // qrchol.jl:214-246 (this process's cones only; the multi-GPU glue sums the result)
   if (nmp == 0) return;
   const double* gq2 = GQ2();
@@ -701,6 +710,26 @@ void SysSolver::assemble_lhs() {
     }
     s.M = nmp; s.N = nmp; s.K = (int)(r1 - r0); s.A = HGQ2.d() + r0; s.lda = q; s.B = HGQ2.d() + r0; s.ldb = q; s.C = lhs.d(); s.ldc = nmp;
     s.alpha = 1; s.beta = 0; s.tri = GEMM_UPPER; s.krange = KR_ALL; s.batch = 1; s.tag = 1;
+    // HYP_CHOL_SPLIT (round 6): product and factorization in two column groups, the leading block of the Schur complement factored
+    // underneath the product of the rest (dense.hip: schur_split_begin / _finish).  Only when this product IS the Schur complement
+    // (every cone through its square root, nothing to add or to exchange afterwards) and the Cholesky will be attempted.
+    {
+      bool all_sqrt = true;
+      for (int v : use_sqrt) all_sqrt &= (v != 0);
+      const int n1 = chol_split_point(nmp, s.K);
+      if (n1 > 0 && all_sqrt && !dist() && ks_world == 1 && !force_bk_env() && ctx.stream == ctx.stream_primary) {
+        if (!split_ev_ready) {
+          HYP_CHECK(hipEventCreateWithFlags(&split_ev_ready, hipEventDisableTiming));
+          HYP_CHECK(hipEventCreateWithFlags(&split_ev_done, hipEventDisableTiming));
+        }
+        schur_split_begin(ctx, nmp, s.K, s.A, q, lhs.d(), lhs_fact.d(), n1, d_info.i(), ctx.lane(2).s, split_ev_ready, split_ev_done);
+        chol_split_n1 = n1;
+        split_unjoined = true;
+        HYP_CHECK(hipEventRecord(ctx.ev[2], ctx.stream));
+        ctx.kstat[4] += 1;
+        return;   // (all_sqrt, one process: nothing below applies)
+      }
+    }
     gemm(ctx, true, s);
     HYP_CHECK(hipEventRecord(ctx.ev[2], ctx.stream));
     ctx.kstat[4] += 1;
@@ -742,12 +771,34 @@ static bool force_bk_env() {
 // read, and behind a failed Cholesky the fall-back chain runs.  factor_lhs() is begin + synchronise + end; step_directions
 // (round 6) puts the first pair of direction solves between the two, so that the host learns info together with that pair's
 // scalars instead of stopping the device for a round trip of its own.
+// Where the Schur complement is cut for HYP_CHOL_SPLIT (0: not at all).  The leading block's factorization -- ~60 us per block step,
+// up to twice that beside the product -- has to fit under the product of the remaining columns: with T = n / 128 tile columns the
+// leading t hold t (t + 1) / 2 of the T (T + 1) / 2 upper tiles.  HYP_CHOL_SPLIT=<fraction of n, in percent>; default 0 = off:
+// measured at config 2 (EXPERIMENTS.md r06-19) the iteration gets 1.8 - 2.8 ms LONGER -- the product in two launches costs 1.5 ms
+// (the trapezoid of the late columns has neither the upper-tile order nor the cut last round of the one-piece product), and the
+// factorization's kernels find no compute unit beside it (profiles/r06_chol_split_timeline_*.txt).
+int SysSolver::chol_split_point(int n, int K) {
+  static const int pct = [] { const char* e = getenv("HYP_CHOL_SPLIT"); return e ? atoi(e) : 0; }();
+  static const int min_n = [] { const char* e = getenv("HYP_CHOL_SPLIT_MIN_N"); return e ? atoi(e) : 3072; }();
+  if (pct <= 0 || n < min_n || K < 4096) return 0;
+  int n1 = (int)((long)n * std::min(pct, 95) / 100) / 128 * 128;
+  return potrf_split_ok(n, n1) ? n1 : 0;
+}
+
 void SysSolver::factor_lhs_begin() {
   if (nmp == 0 || force_bk_env()) return;
   use_bk = false;
-  ctx.d2d(lhs_fact.p, lhs.p, (size_t)nmp * nmp * sizeof(double));
-  HYP_CHECK(hipEventRecord(ctx.ev[3], ctx.stream));
-  potrf_upper_batched(ctx, nmp, lhs_fact.d(), nmp, 0, 1, dinv.d(), d_info.i());
+  if (chol_split_n1 > 0) {   // (assemble_lhs has factored the leading block)
+    HYP_CHECK(hipEventRecord(ctx.ev[3], ctx.stream));
+    schur_split_finish(ctx, nmp, lhs.d(), lhs_fact.d(), chol_split_n1, dinv.d(), d_info.i(), split_ev_done);
+    chol_split_n1 = 0;
+    split_unjoined = false;
+    ++chol_split_count;
+  } else {
+    ctx.d2d(lhs_fact.p, lhs.p, (size_t)nmp * nmp * sizeof(double));
+    HYP_CHECK(hipEventRecord(ctx.ev[3], ctx.stream));
+    potrf_upper_batched(ctx, nmp, lhs_fact.d(), nmp, 0, 1, dinv.d(), d_info.i());
+  }
   HYP_CHECK(hipEventRecord(ctx.ev[4], ctx.stream));
   ctx.d2h(ctx.h_info + Ctx::H_INFO_FACT, d_info.p, sizeof(int));
   // the solve plan is queued BEFORE the host learns info: reading info first left the device idle for the round trip (~0.2 ms

@@ -61,6 +61,11 @@ struct SysSolver {
   void update_lhs_fact(int* info, int* used_fallback);                         // qrchol.jl:201-257
   void assemble_lhs();                                                         //   :214-246 (Schur sum over this process's cones)
   void factor_lhs(int* info, int* used_fallback);                              //   :249-250
+  int chol_split_point(int n, int K);                                          //   HYP_CHOL_SPLIT: columns of the leading block factored under the product (0: none)
+  int chol_split_n1 = 0;                                                       //   ... pending between assemble_lhs and factor_lhs_begin
+  long chol_split_count = 0;
+  bool split_unjoined = false;                                                 //   ... the leading factorization may still run on its lane
+  hipEvent_t split_ev_ready = nullptr, split_ev_done = nullptr;
   void factor_lhs_begin();                                                     //   ... queued: Cholesky attempt, info read-back, solve plan
   void factor_lhs_end(int* info, int* used_fallback, bool times_later = false);   //   ... after a synchronisation: info, fall-back chain
   hipEvent_t plan_ev_fork = nullptr, plan_ev_done = nullptr;

@@ -36,6 +36,8 @@ elif name == "psd_plan":                     # n = 600: the factor has a super-b
     inst = I.psd_blocks(600, [36, 20], seed=7)
 elif name == "psd_wide_plan":                # one cone of side 63 (q = 2016, a multiple of 4: the one-pass kernel applies) over n = 600: a solve plan, the resident line search, passes over G in one sweep
     inst = I.psd_blocks(600, [63], seed=17)
+elif name == "psd_split":                    # n = 1900, q = 4656: a Schur complement large enough to be formed and factored in two column groups
+    inst = I.psd_blocks(1900, [96], seed=19)
 elif name == "psd_smoke":                    # __graft_entry__.smoke()'s instance
     inst = I.psd_blocks(40, [12, 7], seed=5)
 elif name == "polymin_primal":
@@ -61,12 +63,15 @@ print(json.dumps({"status": s.get_status(), "iters": s.get_num_iters(), "obj": s
 """
 
 
-def _run(name, env_extra):
+def _run(name, env_extra, with_stderr=False):
     from conftest import child_env
     env = child_env(env_extra)   # (HYP_PERSISTENT=1 only if this pytest process holds a context -- and with it possibly the device's lock)
     r = subprocess.run([sys.executable, "-c", SNIPPET % ROOT, name], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    if with_stderr:
+        out["stderr"] = r.stderr
+    return out
 
 
 @pytest.mark.parametrize("name,switch", [
@@ -363,3 +368,20 @@ def test_x_rows_only_download_of_the_directions_changes_no_bit(name):
     assert on["iters"] == off["iters"] >= 8
     assert on["trace"] == off["trace"], name
     assert on["trials"] == off["trials"]
+
+
+def test_schur_complement_formed_and_factored_in_two_column_groups_changes_no_bit():
+    """round 6, HYP_CHOL_SPLIT=<percent> (measured slower, default off; dense.hip: schur_split_begin / _finish): the Schur syrk (qrchol.jl:234)
+    forms the leading block columns first, their Cholesky factorization (dense.jl:194-215) runs on other queues while the product
+    forms the rest, and the block steps of the leading part are replayed for the late columns behind it.  Every entry of the factor
+    sees the operations of the one-piece factorization in the same order; with the same K slices on both sides (the one-piece
+    product's cut last round off, its slice count forced) the Schur matrix is the same too: the iterates must agree to the bit."""
+    import re
+    common = {"HYP_SYRK_TAIL": "0", "HYP_SYRK_S": "3", "HYP_CHOL_SPLIT_S": "3", "HYP_CHOL_SPLIT_MIN_N": "1024", "HYP_CHOL_SPLIT_STATS": "1"}
+    one = _run("psd_split", dict(common, HYP_CHOL_SPLIT="0"), True)
+    two = _run("psd_split", dict(common, HYP_CHOL_SPLIT="60"), True)
+    plain = _run("psd_split", dict(common, HYP_CHOL_SPLIT="45", HYP_CHOL_SPLIT_FREE="0", HYP_CHOL_SPLIT_LA="0"), True)
+    count = lambda r: int(re.search(r"\[chol split\] (\d+) factorizations", r["stderr"]).group(1))
+    assert count(one) == 0 and count(two) >= one["iters"] and count(plain) >= one["iters"]   # (the comparison is not vacuous)
+    assert one["status"] == two["status"] == plain["status"] == "Optimal"
+    assert one["trace"] == two["trace"] == plain["trace"]
