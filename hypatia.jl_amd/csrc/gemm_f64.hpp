@@ -85,7 +85,13 @@ struct GemmScratch {
   int tile_map_T = -1;
   int* tile_cnt = nullptr;     // arrival counters of the fused split-K reduction (zero between launches: the last arrival resets its tile's)
   long tile_cnt_n = 0;
+  // the same two tables for upper TRAPEZOIDS (GEMM_UPPER_RECT: row groups of the overlapped exchange, column groups of the split
+  // factorization), a few kept by (tiles_m, tiles_n, tri_off); the inverse is indexed tm + tn * tiles_m
+  struct TrapMap { int tiles_m = 0, tiles_n = 0, tri_off = 0; long nblk = 0; int* map = nullptr; unsigned long used = 0; };
+  TrapMap trap[8];
+  unsigned long trap_clock = 0;
   void release() {
+    for (TrapMap& t : trap) { if (t.map) (void)hipFree(t.map); t = TrapMap(); }
     if (splitk_ws) (void)hipFree(splitk_ws);
     if (tile_map) (void)hipFree(tile_map);
     if (tile_cnt) (void)hipFree(tile_cnt);
@@ -97,5 +103,8 @@ struct GemmScratch {
 hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch* scratch = nullptr);
 // block columns [c0, c1) of the upper Schur syrk described by `a` (c0 = 0: the leading block; c0 > 0: the rest, c1 = a.N)
 hipError_t schur_syrk_cols(hipStream_t st, GemmArgs a, int c0, int c1, GemmScratch* scratch);
+// the thin last columns (N mod 128 <= 32 of them) of the upper Schur syrk described by `a`, every row up to the diagonal, by the
+// skinny-product kernel; *N0 = the first column it took (a.N: none -- the caller's tiles cover everything)
+hipError_t schur_syrk_edge(hipStream_t st, const GemmArgs& a, int* N0);
 
 }  // namespace hyp

@@ -426,6 +426,47 @@ static const int* upper_tile_map(GemmScratch& gs, int T, long nblk) {
   return gs.tile_map;
 }
 
+// The same order for the tiles of an upper trapezoid that do work (GEMM_UPPER_RECT: tile (tm, tn) of a tiles_m x tiles_n grid unless
+// 128 tm > 128 tn + 127 + tri_off): launch positions exist only for those, in super-tile-major order dealt out to the XCDs in
+// contiguous runs.  *nblk_out = their number (the launch's grid).  A table per shape, eight shapes kept (least recently used goes).
+static const int* trap_tile_map(GemmScratch& gs, int tiles_m, int tiles_n, int tri_off, long* nblk_out) {
+  for (GemmScratch::TrapMap& t : gs.trap)
+    if (t.map && t.tiles_m == tiles_m && t.tiles_n == tiles_n && t.tri_off == tri_off) { t.used = ++gs.trap_clock; *nblk_out = t.nblk; return t.map; }
+  GemmScratch::TrapMap* slot = &gs.trap[0];   // an empty slot, else the least recently used one
+  for (GemmScratch::TrapMap& t : gs.trap) {
+    if (!t.map) { slot = &t; break; }
+    if (t.used < slot->used) slot = &t;
+  }
+  std::vector<int> logical;
+  const int ST = 8, nsm = (tiles_m + ST - 1) / ST, nsn = (tiles_n + ST - 1) / ST;
+  for (int J = 0; J < nsn; ++J)
+    for (int I = 0; I < nsm; ++I)
+      for (int j = 0; j < ST; ++j)
+        for (int i = 0; i < ST; ++i) {
+          const int tm = I * ST + i, tn = J * ST + j;
+          if (tm < tiles_m && tn < tiles_n && !(128L * tm > 128L * tn + 127 + tri_off)) { logical.push_back(tm); logical.push_back(tn); }
+        }
+  const long nblk = (long)logical.size() / 2;
+  std::vector<int> hw(2 * nblk + (size_t)tiles_m * tiles_n, -1);
+  const long q = nblk / 8, r = nblk % 8;
+  for (long b = 0; b < nblk; ++b) {
+    const long x = b % 8, k = b / 8;
+    const long start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    const long L = start + k;
+    hw[2 * b] = logical[2 * L];
+    hw[2 * b + 1] = logical[2 * L + 1];
+    hw[2 * nblk + hw[2 * b] + (size_t)hw[2 * b + 1] * tiles_m] = (int)b;
+  }
+  if (slot->map) { (void)hipDeviceSynchronize(); (void)hipFree(slot->map); }   // (a launch may still read the table that goes)
+  *slot = GemmScratch::TrapMap();
+  int* d = nullptr;
+  if (hipMalloc((void**)&d, hw.size() * sizeof(int)) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, hw.data(), hw.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+  slot->map = d; slot->tiles_m = tiles_m; slot->tiles_n = tiles_n; slot->tri_off = tri_off; slot->nblk = nblk; slot->used = ++gs.trap_clock;
+  *nblk_out = nblk;
+  return d;
+}
+
 // The thin last tile column of the Schur syrk (n = 5000 = 39 x 128 + 8): C[i, N0 + e] = alpha * <A[:, i], A[:, N0 + e]> + beta * C for
 // the r <= 32 edge columns and every row i <= N0 + e.  As a GEMM with 64-wide tiles it took 0.31 ms at K = 20100 (MFMA tiles that
 // are mostly padding behind a loader shaped for square tiles: 2.6 TB/s); it is n dot products per edge column over ONE pass
@@ -545,11 +586,18 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch*
   a.tiles_m = (a.M + BT - 1) / BT;
   a.tiles_n = (a.N + BT - 1) / BT;
   long nblk;
+  const int* trap_map = nullptr;   // Schur-type product on an upper trapezoid: only the tiles that do work, in the XCD-aware order
+  static const bool trap_on = [] { const char* e = getenv("HYP_GEMM_TRAP_MAP"); return !(e && atoi(e) == 0); }();
   if (a.tri == GEMM_UPPER) {
     int T = a.tiles_n;   // square
     nblk = (long)T * (T + 1) / 2;
   } else {
     nblk = (long)a.tiles_m * a.tiles_n;
+    if (trap_on && gs && a.tag == 1 && transa && a.tri == GEMM_UPPER_RECT && !small && a.batch == 1 && a.epi == 0 && a.krange == KR_ALL && nblk >= 64) {
+      long real = 0;
+      trap_map = trap_tile_map(*gs, a.tiles_m, a.tiles_n, a.tri_off, &real);
+      if (trap_map) nblk = real;
+    }
   }
   // split-K for the tall Schur syrk: pick the slice count that minimises the number of rounds of
   // 512 resident workgroups (2 per CU) per unit of work, so the last round is not mostly empty
@@ -558,11 +606,24 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch*
     // cost in units of one full-K round of 512 workgroups: rounds(S) / S, plus the partial-sum traffic of S
     // slices (N^2 / 2 doubles written and read back per slice at ~3.5 TB/s against 2.6e-7 K s per round;
     // measured at n = 5000, q = 20100: S = 3 -> 8.71 ms, S = 5 -> 8.42 ms, S = 7 -> 8.45 ms)
-    const double eps = ((double)a.N * a.N * 2.3e-12) / (2.6e-7 * a.K);
+    const double eps = (trap_map ? (double)nblk * 16384.0 * 4.6e-12 : (double)a.N * a.N * 2.3e-12) / (2.6e-7 * a.K);
     double best = 1e30;
     for (int S = 1; S <= 8; ++S) {
       if (a.K / S < 1024) break;
-      const double cost = (double)((nblk * S + 511) / 512) / S + (S > 1 ? S * eps : 0.0);
+      double rounds = (double)((nblk * S + 511) / 512);
+      if (trap_map && S > 1) {   // (trapezoids: with the cut last round the launch below would make of it -- a 225-tile row group is 0.88 of
+        const long rem = (nblk * S) % 512;   //  an even split with 2 slices in one round and 0.99 with 3 slices and a last round cut in 3)
+        const int kc = (((a.K + S - 1) / S) + BK - 1) / BK * BK;
+        if (rem > 0 && rem <= nblk) {
+          double last = 1.0;
+          for (int q = 2; q <= 4; ++q) {
+            const double t = (double)((rem * q + 511) / 512) / q;
+            if (t < last - 1e-9 && kc / q >= 256) last = t;
+          }
+          rounds = (double)((nblk * S) / 512) + last;
+        }
+      }
+      const double cost = rounds / S + (S > 1 ? S * eps : 0.0);
       if (cost < best - 1e-9) { best = cost; a.splitk = S; }
     }
     static const int s_env = [] { const char* e = getenv("HYP_SYRK_S"); return e ? atoi(e) : 0; }();
@@ -595,7 +656,7 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch*
     // more than the last round's workgroups: slower) -- the workgroups do not run in lock-step rounds, most of the tail was
     // already filled.
     static const bool tail_on = [] { const char* e = getenv("HYP_SYRK_TAIL"); return !(e && atoi(e) == 0); }();
-    if (tail_on && gs && a.tag == 1 && transa && a.tri == GEMM_UPPER && !small && a.batch == 1 && nblk >= 64) {
+    if (tail_on && gs && a.tag == 1 && transa && (a.tri == GEMM_UPPER || trap_map) && !small && a.batch == 1 && nblk >= 64) {
       const long rem = (nblk * a.splitk) % 512;
       if (rem > 0 && rem <= nblk) {
         int best_q = 1;
@@ -628,6 +689,7 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch*
             (a.strideA % 2 == 0) && (a.strideB % 2 == 0) && a.krange != KR_GE_M && a.krange != KR_GE_N) ? 1 : 0;
   a.tile_map = nullptr;
   if (gs && a.tag == 1 && a.tri == GEMM_UPPER && !small && a.batch == 1 && nblk >= 64) a.tile_map = upper_tile_map(*gs, a.tiles_n, nblk);
+  if (trap_map) a.tile_map = trap_map;
   if (a.tail_q > 1 && !a.tile_map) { a.splitk = a.splitk_base; a.tail_q = 1; }
   dim3 grid((unsigned)nblk, (unsigned)a.batch, (unsigned)a.splitk);
   // (round 6, HYP_SYRK_FUSED_REDUCE=1) the Schur syrk's split-K reduction inside the product's launch: see the kernel's epilogue.
@@ -657,7 +719,7 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch*
   if (a.splitk > 1 && a.tile_cnt == nullptr)
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((a.M + 255) / 256, a.N, a.batch), dim3(256), 0, st, a.M, a.N, a.tri != GEMM_FULL ? 1 : 0, a.tri_off,
                        a.splitk_base, a.part, a.part_ld, a.part_stride, a.alpha, a.beta, a.C, a.ldc, a.tail_q - 1, a.tail_first,
-                       a.tile_map ? a.tile_map + 2 * nblk : nullptr, a.tiles_n, (long)a.splitk * a.part_stride, a.strideC);
+                       a.tile_map ? a.tile_map + 2 * nblk : nullptr, trap_map ? a.tiles_m : a.tiles_n, (long)a.splitk * a.part_stride, a.strideC);
   return hipGetLastError();
 }
 
@@ -700,6 +762,14 @@ hipError_t schur_syrk_cols(hipStream_t st, GemmArgs a, int c0, int c1, GemmScrat
   }
   if (r > 0) return syrk_edge_launch(st, a, N0, r);
   return hipSuccess;
+}
+
+hipError_t schur_syrk_edge(hipStream_t st, const GemmArgs& a, int* N0) {
+  const int r = a.N % 128;
+  *N0 = a.N;
+  if (!(r > 0 && r <= 32 && a.N >= 1024 && a.K >= 4096 && a.M == a.N && syrk_edge_ok(a))) return hipSuccess;
+  *N0 = a.N - r;
+  return syrk_edge_launch(st, a, *N0, r);
 }
 
 }  // namespace hyp

@@ -53,7 +53,7 @@ SysSolver::~SysSolver() {
   if (const char* e = getenv("HYP_CHOL_SPLIT_STATS"))
     if (e[0] == '1') fprintf(stderr, "[chol split] %ld factorizations in two column groups\n", chol_split_count);
   if (rp_pre_host) (void)hipHostFree(rp_pre_host);
-  for (hipEvent_t e : {rp_pre_ev, plan_ev_fork, plan_ev_done, dirs_copied_ev, up_ev0, up_ev1, split_ev_ready, split_ev_done})
+  for (hipEvent_t e : {rp_pre_ev, plan_ev_fork, plan_ev_done, dirs_copied_ev, up_ev0, up_ev1, split_ev_ready, split_ev_done, ov_ev_fork})
     if (e) (void)hipEventDestroy(e);
 }
 
@@ -356,6 +356,22 @@ bool SysSolver::assemble_lhs_overlapped(long kr0, long kr1, int groups) {
   hipEvent_t ev_whole = nullptr;
   comm_time_begin(14, &ev_whole);
   long seg = 0;
+  // (round 6) the products of consecutive row groups run on TWO lanes in turn, each with its own split-K scratch: a launch ends in a
+  // round of workgroups that drains for milliseconds (a K slice of a tile lives 6 ms at config 4) -- one after the other the four
+  // products took 92.6 ms where the one-piece product takes 80 (profiles/r06_dist_overlap_timeline.txt); side by side the next
+  // group's workgroups fill the compute units the previous one frees.  The thin last columns (n mod 128) come first, from the skinny
+  // kernel of the one-piece product, instead of as a last tile column that is 6 % of every group's tiles.  HYP_DIST_OVERLAP_OLD=1:
+  // one queue, the round-5 slice counts, no tile order.
+  static const bool old_launch = [] { const char* e = getenv("HYP_DIST_OVERLAP_OLD"); return e && atoi(e) == 1; }();
+  int N0 = nmp;
+  if (!old_launch && kr1 > kr0) {
+    GemmArgs w{};
+    w.M = nmp; w.N = nmp; w.K = (int)(kr1 - kr0); w.A = HGQ2.d() + kr0; w.lda = q; w.B = w.A; w.ldb = q; w.C = lhs.d(); w.ldc = nmp;
+    w.alpha = 1; w.beta = 0; w.tri = GEMM_UPPER; w.krange = KR_ALL; w.batch = 1; w.tag = 1;
+    HYP_CHECK(schur_syrk_edge(ctx.stream, w, &N0));
+  }
+  if (!ov_ev_fork) HYP_CHECK(hipEventCreateWithFlags(&ov_ev_fork, hipEventDisableTiming));
+  HYP_CHECK(hipEventRecord(ov_ev_fork, ctx.stream));
   for (int g = 0; g < ng; ++g) {
     const int r0 = bound[g] * 128, r1 = std::min(nmp, bound[g + 1] * 128);
     const int rows = r1 - r0, cols = nmp - r0;
@@ -367,13 +383,24 @@ bool SysSolver::assemble_lhs_overlapped(long kr0, long kr1, int groups) {
     s.B = s.A; s.ldb = q;
     s.C = lhs.d() + (long)r0 * nmp + r0; s.ldc = nmp;
     s.alpha = 1; s.beta = 0; s.tri = GEMM_UPPER_RECT; s.krange = KR_ALL; s.batch = 1; s.tile_hint = 128;
-    // K slices so that the group is about two rounds of 512 resident workgroups
-    int S = (int)std::max<long>(1, std::min<long>(8, (1024 + nblk / 2) / std::max<long>(nblk, 1)));
-    while (S > 1 && s.K / S < 1024) --S;
-    s.splitk_req = S;
-    if (s.K > 0) gemm(ctx, true, s);
-    else HYP_CHECK(hipMemset2DAsync(s.C, (size_t)nmp * sizeof(double), 0, (size_t)rows * sizeof(double), (size_t)cols, ctx.stream));
-    HYP_CHECK(hipEventRecord(ov_events[2 * g], ctx.stream));
+    if (old_launch) {   // K slices so that the group is about two rounds of 512 resident workgroups (for 5 slices of 205 - 225 tiles: three)
+      int S = (int)std::max<long>(1, std::min<long>(8, (1024 + nblk / 2) / std::max<long>(nblk, 1)));
+      while (S > 1 && s.K / S < 1024) --S;
+      s.splitk_req = S;
+      if (s.K > 0) gemm(ctx, true, s);
+      else HYP_CHECK(hipMemset2DAsync(s.C, (size_t)nmp * sizeof(double), 0, (size_t)rows * sizeof(double), (size_t)cols, ctx.stream));
+      HYP_CHECK(hipEventRecord(ov_events[2 * g], ctx.stream));
+    } else {
+      // an instance of the Schur product (tag 1): only the tiles that do work, in the XCD-aware order, slice count and cut last round
+      // chosen as for the one-piece product (gemm_f64_kernel.hpp: trap_tile_map); the edge columns are done
+      s.tag = 1;
+      s.M = std::min(r1, N0) - r0; s.N = N0 - r0;
+      LaneSwitch on_lane(ctx, 2 + (g & 1));
+      HYP_CHECK(hipStreamWaitEvent(ctx.stream, ov_ev_fork, 0));
+      if (s.K > 0 && s.M > 0 && s.N > 0) gemm(ctx, true, s);
+      else if (s.K <= 0) HYP_CHECK(hipMemset2DAsync(lhs.d() + (long)r0 * nmp + r0, (size_t)nmp * sizeof(double), 0, (size_t)rows * sizeof(double), (size_t)cols, ctx.stream));
+      HYP_CHECK(hipEventRecord(ov_events[2 * g], ctx.stream));
+    }
     HYP_CHECK(hipStreamWaitEvent(ctx.stream2, ov_events[2 * g], 0));
     const long h = rows;
     const long segcnt = h * (h + 1) / 2 + (long)(cols - rows) * h;

@@ -66,6 +66,7 @@ struct SysSolver {
   long chol_split_count = 0;
   bool split_unjoined = false;                                                 //   ... the leading factorization may still run on its lane
   hipEvent_t split_ev_ready = nullptr, split_ev_done = nullptr;
+  hipEvent_t ov_ev_fork = nullptr;                                             //   overlapped exchange: the row groups' lanes start behind this
   void factor_lhs_begin();                                                     //   ... queued: Cholesky attempt, info read-back, solve plan
   void factor_lhs_end(int* info, int* used_fallback, bool times_later = false);   //   ... after a synchronisation: info, fall-back chain
   hipEvent_t plan_ev_fork = nullptr, plan_ev_done = nullptr;
