@@ -611,8 +611,14 @@ hipError_t gemm_f64_launch(hipStream_t st, bool transa, GemmArgs a, GemmScratch*
     for (int S = 1; S <= 8; ++S) {
       if (a.K / S < 1024) break;
       double rounds = (double)((nblk * S + 511) / 512);
-      if (trap_map && S > 1) {   // (trapezoids: with the cut last round the launch below would make of it -- a 225-tile row group is 0.88 of
-        const long rem = (nblk * S) % 512;   //  an even split with 2 slices in one round and 0.99 with 3 slices and a last round cut in 3)
+      // (round 6) the rounds as the launch below will run them, i.e. with its last round cut into sub-slices: a 225-tile row group of
+      // the overlapped exchange is 0.88 of an even split with 2 slices in one round and 0.99 with 3 slices and a last round cut in 3;
+      // config 2 (780 tiles, K = 20 100) goes from 7 slices to 5: 7.92 - 7.94 ms against 8.01 - 8.03 back to back
+      // (profiles/r06_syrk_slices.txt).  HYP_SYRK_S_PLAIN=1: the choice without the cut.
+      static const bool s_plain = [] { const char* e = getenv("HYP_SYRK_S_PLAIN"); return e && atoi(e) == 1; }();
+      static const bool tail_sel = [] { const char* e = getenv("HYP_SYRK_TAIL"); return !(e && atoi(e) == 0); }();
+      if (!s_plain && tail_sel && transa && (trap_map || a.tri == GEMM_UPPER) && nblk >= 64 && S > 1) {
+        const long rem = (nblk * S) % 512;
         const int kc = (((a.K + S - 1) / S) + BK - 1) / BK * BK;
         if (rem > 0 && rem <= nblk) {
           double last = 1.0;
