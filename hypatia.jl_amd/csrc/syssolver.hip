@@ -757,6 +757,7 @@ void SysSolver::assemble_lhs() {
         return;   // (all_sqrt, one process: nothing below applies)
       }
     }
+    // (the thin last columns on a lane beside the product instead of behind it: 8.66 against 8.32 - 8.38 ms, EXPERIMENTS.md r06-22 -- as in r01-4)
     gemm(ctx, true, s);
     HYP_CHECK(hipEventRecord(ctx.ev[2], ctx.stream));
     ctx.kstat[4] += 1;
