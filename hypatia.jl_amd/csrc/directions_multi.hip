@@ -1525,7 +1525,12 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
     }
     HYP_CHECK(hipEventRecord(up_ev0, ctx.stream));
   }   // (everything queued so far: the last readers of the old point)
-  if (!upload_late) upload(ctx.stream);
+  // Smaller points: the same stream, but still BEHIND the assembly and the factorization in its queue (their kernels do not read the
+  // point) -- the host's copy into pinned memory (0.7 MB at config 2: ~80 us) then runs while the device already multiplies instead of
+  // in the gap between two iterations; no cross-stream hand-over.  HYP_UPLOAD_AFTER=0: in front, as before.
+  static const bool after_env = [] { const char* e = getenv("HYP_UPLOAD_AFTER"); return !(e && e[0] == '0'); }();
+  const bool upload_after = resident_flow && !upload_late && after_env;
+  if (!upload_late && !upload_after) upload(ctx.stream);
   const auto t0 = std::chrono::steady_clock::now();
   const double tau = h_point[it], kap = h_point[ik];
   m_rhs.ensure((size_t)(MR + 1) * dv * d);   // (+ the constant column of the first pair)
@@ -1547,6 +1552,13 @@ void SysSolver::step_directions(const double* h_point, const double* h_res, doub
   }
   assemble_lhs();
   factor_lhs_begin();
+  if (upload_after) {
+    hs_point = ctx.stage_host((size_t)dv + 2 * (size_t)it + 2 * (size_t)MR * dv);   // (taken again: see below)
+    hs_res = hs_point + dv;
+    hs_const = hs_res + it;
+    hs_dirs = hs_const + it;
+    upload(ctx.stream);
+  }
   if (upload_late) {
     // (the staging block is taken again: a cone oracle of the assembly may have asked for a larger one meanwhile)
     hs_point = ctx.stage_host((size_t)dv + 2 * (size_t)it + 2 * (size_t)MR * dv);
