@@ -86,9 +86,9 @@ struct GemmScratch {
   int* tile_cnt = nullptr;     // arrival counters of the fused split-K reduction (zero between launches: the last arrival resets its tile's)
   long tile_cnt_n = 0;
   // the same two tables for upper TRAPEZOIDS (GEMM_UPPER_RECT: row groups of the overlapped exchange, column groups of the split
-  // factorization), a few kept by (tiles_m, tiles_n, tri_off); the inverse is indexed tm + tn * tiles_m
+  // factorization), sixteen kept by (tiles_m, tiles_n, tri_off); the inverse is indexed tm + tn * tiles_m
   struct TrapMap { int tiles_m = 0, tiles_n = 0, tri_off = 0; long nblk = 0; int* map = nullptr; unsigned long used = 0; };
-  TrapMap trap[8];
+  TrapMap trap[16];
   unsigned long trap_clock = 0;
   void release() {
     for (TrapMap& t : trap) { if (t.map) (void)hipFree(t.map); t = TrapMap(); }

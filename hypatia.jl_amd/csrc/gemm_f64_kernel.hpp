@@ -428,7 +428,7 @@ static const int* upper_tile_map(GemmScratch& gs, int T, long nblk) {
 
 // The same order for the tiles of an upper trapezoid that do work (GEMM_UPPER_RECT: tile (tm, tn) of a tiles_m x tiles_n grid unless
 // 128 tm > 128 tn + 127 + tri_off): launch positions exist only for those, in super-tile-major order dealt out to the XCDs in
-// contiguous runs.  *nblk_out = their number (the launch's grid).  A table per shape, eight shapes kept (least recently used goes).
+// contiguous runs.  *nblk_out = their number (the launch's grid).  A table per shape, sixteen shapes kept (least recently used goes).
 static const int* trap_tile_map(GemmScratch& gs, int tiles_m, int tiles_n, int tri_off, long* nblk_out) {
   for (GemmScratch::TrapMap& t : gs.trap)
     if (t.map && t.tiles_m == tiles_m && t.tiles_n == tiles_n && t.tri_off == tri_off) { t.used = ++gs.trap_clock; *nblk_out = t.nblk; return t.map; }

@@ -69,6 +69,20 @@ def test_schur_exchange_overlapped_with_its_production_one_rank(monkeypatch):
     assert hist[0] >= 3 * int(res["iters"]), (hist[0], int(res["iters"]))
 
 
+@pytest.mark.timeout(1500)
+def test_schur_exchange_overlapped_row_groups_as_schur_products_one_rank(monkeypatch):
+    """round 6: at sizes where a row group has 64 tiles or more it is launched as an instance of the Schur product -- a launch position
+    only for the tiles of the trapezoid that do work, in the XCD-aware order (gemm_f64_kernel.hpp: trap_tile_map), split-K with the
+    cut last round, the thin last columns by the skinny kernel, consecutive groups on two lanes.  n = 3000 + 8 (24 tile rows and an
+    8-column edge) in 3 groups of ~100 tiles, K = 9840: the solve must be the oracle's."""
+    monkeypatch.setenv("HYP_DIST_NATIVE", "1")
+    monkeypatch.setenv("HYP_DIST_OVERLAP", "3")
+    res = _run_sharded("1", inst_args=(3008, [40] * 12, 9), world=1, transport="nccl")
+    assert bool(res["rccl_in_library"])
+    hist = [int(v) for v in res["comm_hist"]]
+    assert hist[0] >= 3 * int(res["iters"]), (hist[0], int(res["iters"]))
+
+
 def test_library_rccl_allreduce_on_a_device_buffer():
     """hyp_comm_unique_id / _init_rank / _allreduce / _destroy on a device buffer (one rank; in a fresh process, torch first:
     one HIP runtime per process)"""
