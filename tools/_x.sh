@@ -1,9 +1,9 @@
 export TMPDIR=/tmp
-run() { echo -n "$* : "; env "$@" python bench.py --steps 150 --warmup 20 --cpu-iters 0 2>&1 | tail -1 | python -c "
+R=$GRAFT_REPO_ROOT
+prof() { tag=$1; shift; cd /tmp; rm -rf /tmp/pp_$tag; env "$@" timeout 600 rocprofv3 --kernel-trace -d /tmp/pp_$tag -o b -- python $R/bench.py --steps 60 --warmup 10 --cpu-iters 0 > /tmp/pp_$tag.json 2>/dev/null; cd $R; tail -1 /tmp/pp_$tag.json | python -c "
 import json,sys
-d=json.loads(sys.stdin.read())
-p=d['phases_ms_per_step']; print(round(d['ms_per_step'],3), 'syrk %.2f chol %.2f lhs %.2f dirs %.2f search %.2f' % (p['syrk'],p['cholesky'],p['update_lhs'],p['get_directions'],p['search']))"; }
-for i in 1 2 3; do run HYP_SYNC_SPIN=0; run HYP_SYNC_SPIN=1; run HYP_SYNC_SPIN=0 HSA_ENABLE_INTERRUPT=0; run HYP_SYNC_SPIN=1 HSA_ENABLE_INTERRUPT=0; done
-for c in 3b 5p; do for v in 0 1; do echo -n "config $c HYP_SYNC_SPIN=$v : "; HYP_SYNC_SPIN=$v timeout 600 python bench.py --config $c 2>/dev/null | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3))"; done; done
+d=json.loads(sys.stdin.read()); p=d['phases_ms_per_step']; print('$tag', round(d['ms_per_step'],3), 'dirs %.2f' % p['get_directions'])"; python tools/rocpd_stats.py $(find /tmp/pp_$tag -name "*.db" | head -1) 2>/dev/null | head -70 > gpurun_out/stats_$tag.csv; }
+prof a HYP_SYRK_S_PLAIN=1
+prof b HYP_SYRK_S_PLAIN=1 HYP_SPLITK_WS_MIN_MB=2048
+prof a2 HYP_SYRK_S_PLAIN=1
+prof b2 HYP_SYRK_S_PLAIN=1 HYP_SPLITK_WS_MIN_MB=2048
