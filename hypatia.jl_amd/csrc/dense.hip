@@ -284,6 +284,8 @@ bool potrf_split_ok(int n, int n1) {
 // of XCD b mod 8, tools/probe_cumask.hip).  Beside a product that fills every CU with two workgroups of 70 KB of LDS and 1.3 ms of
 // life, the factorization's kernels (77 - 124 KB of LDS) found no compute unit for milliseconds: the first diagonal block waited
 // 1.4 ms, the first panel 4 ms (profiles/r06_chol_split_timeline_unmasked.txt).
+// (an experiment's queue: one per mask width and process, created on first use and kept for the process's life; not for two contexts
+//  on different devices or threads at once -- the switch that reaches it is off by default)
 static hipStream_t masked_stream(Ctx& c, int free_per_xcd) {
   static hipStream_t st[9] = {};
   static int dev[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};

@@ -385,3 +385,16 @@ def test_schur_complement_formed_and_factored_in_two_column_groups_changes_no_bi
     assert count(one) == 0 and count(two) >= one["iters"] and count(plain) >= one["iters"]   # (the comparison is not vacuous)
     assert one["status"] == two["status"] == plain["status"] == "Optimal"
     assert one["trace"] == two["trace"] == plain["trace"]
+
+
+@pytest.mark.parametrize("name", ["psd_single_wide", "psd_wide_plan", "polymin_large_dual"])
+def test_point_upload_behind_the_queued_assembly_changes_no_bit(name):
+    """round 6, HYP_UPLOAD_AFTER (default on; step_directions, combined.jl:64-121): the point and the residuals -- read by the right-hand
+    sides, not by the Schur assembly or the factorization -- are staged and uploaded behind those in the stream's queue instead of in
+    front of them.  The same data in the same buffers before their first reader: the same iterates to the last bit"""
+    after = _run(name, {"HYP_UPLOAD_AFTER": "1"})
+    front = _run(name, {"HYP_UPLOAD_AFTER": "0"})
+    assert after["status"] == front["status"] == "Optimal"
+    assert after["iters"] == front["iters"]
+    assert after["trace"] == front["trace"], name
+    assert after["trials"] == front["trials"]
