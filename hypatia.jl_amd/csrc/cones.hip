@@ -17,10 +17,12 @@ void Cone::alloc_common() {
 }
 
 void Cone::load_point(const double* d_pt, double scal) {   // Cones.jl:157-166
+  ++ctx.cone_epoch;
   if (scal == 1.0) ctx.d2d(point.p, d_pt, (size_t)dim * sizeof(double));
   else dev_scale_copy(ctx, dim, scal, d_pt, point.d());
 }
 void Cone::load_dual_point(const double* d_pt) {   // :168-171
+  ++ctx.cone_epoch;
   ctx.d2d(dual_point.p, d_pt, (size_t)dim * sizeof(double));
   dual_cached = false;
 }

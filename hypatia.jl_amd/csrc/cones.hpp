@@ -41,7 +41,7 @@ struct Cone {
   // Cones.jl:157-171, 185-186
   void load_point(const double* d_pt, double scal);   // point = scal * pt
   void load_dual_point(const double* d_pt);
-  virtual void reset_data() { feas_updated = grad_updated = hess_updated = inv_hess_updated = hess_fact_updated = false; }
+  virtual void reset_data() { ++ctx.cone_epoch; feas_updated = grad_updated = hess_updated = inv_hess_updated = hess_fact_updated = false; }
 
   // Cones.jl:56, 63, 71
   bool is_feas() { return feas_updated ? is_feas_ : update_feas(); }

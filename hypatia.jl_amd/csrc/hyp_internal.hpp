@@ -73,6 +73,7 @@ constexpr int NB = 128;   // Cholesky / triangular-solve block size
 // Context: one HIP device, one stream; owns scratch and the host<->device staging buffers.
 struct Ctx {
   int device = 0;
+  unsigned long cone_epoch = 0;   // bumped whenever a cone of this context takes a new point or forgets its data (SysSolver::prelaunch_sqrt_hess)
   hipStream_t stream = nullptr;
   std::string last_error;
   double timers[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

@@ -50,6 +50,8 @@ SysSolver::SysSolver(Ctx& c, int n_, int p_, int q_, const std::vector<Cone*>& c
 SysSolver::~SysSolver() {
   if (const char* e = getenv("HYP_RP_PREFETCH_STATS"))
     if (e[0] == '1') fprintf(stderr, "[residual_products prefetch] handed out %ld, recomputed %ld\n", rp_pre_hits, rp_pre_misses);
+  if (const char* e = getenv("HYP_SHP_PRELAUNCH_STATS"))
+    if (e[0] == '1') fprintf(stderr, "[sqrt_hess_prod prelaunch] used %ld, not used %ld\n", shp_used, shp_unused);
   if (const char* e = getenv("HYP_CHOL_SPLIT_STATS"))
     if (e[0] == '1') fprintf(stderr, "[chol split] %ld factorizations in two column groups\n", chol_split_count);
   if (rp_pre_host) (void)hipHostFree(rp_pre_host);
@@ -257,6 +259,7 @@ int SysSolver::run_hess_prod(size_t k, double* prod, long ldp, const double* arr
 void SysSolver::load(const double* hG, const double* hGQ1, const double* hGQ2, const double* hQ, const double* hR) {
   const size_t d = sizeof(double);
   s_resident = false;   // (resident directions belong to the G they were computed with)
+  shp_prelaunched = false; shp_wasted = 0;   // (so do prelaunched cone products)
   rp_pre_valid = false;
   ctx.h2d(G.p, hG, (size_t)q * n * d);
   if (p > 0) {
@@ -680,16 +683,63 @@ void SysSolver::update_lhs_fact(int* info, int* used_fallback) {   // qrchol.jl:
 
 static bool force_bk_env();
 
+// HYP_SHP_PRELAUNCH=1 (round 6; default off -- measured: 17.41 / 17.65 / 17.46 ms per iteration with it against 17.38 / 17.42 / 17.33
+// without, alternating on one box: outside the profiler the gap it closes is smaller than what the extra launches inside the search
+// call cost, EXPERIMENTS.md r06-24): when the line search accepts a candidate, every cone holds the state the NEXT update_lhs
+// starts from, and nothing the host does until then (convergence check, stepper bookkeeping, the call into step_directions: ~0.2 ms,
+// the last gap above 100 us of an iteration) feeds the cones' square-root Hessian products (qrchol.jl:219-233).  They are queued right
+// there, behind the prefetched residual products; assemble_lhs finds HGQ2 filled and continues with the Schur product -- provided no
+// cone has taken a point or been reset since (Ctx::cone_epoch).  If the solve ends instead (converged), 2 ms of device time were spent
+// for nothing, once; a host that reloads the cones every iteration makes every prelaunch useless: after two in a row it stays off.
+void SysSolver::prelaunch_sqrt_hess() {
+  static const bool on = [] { const char* e = getenv("HYP_SHP_PRELAUNCH"); return e && e[0] == '1'; }();
+  shp_prelaunched = false;
+  if (!on || shp_wasted >= 2 || nmp <= 0 || p != 0 || dist() || ks_world > 1 || !dirs_resident() || force_bk_env() ||
+      ctx.stream != ctx.stream_primary)
+    return;
+  {
+    const char* ff = getenv("HYP_FORCE_FACT_FAIL");
+    if (ff && ff[0] && ff[0] != '0') return;
+  }
+  group_inverses();
+  bool all_sqrt = true;
+  for (size_t k = 0; k < cones.size(); ++k) {
+    use_sqrt[k] = cones[k]->use_sqrt_hess_oracles(nmp) ? 1 : 0;
+    all_sqrt &= (use_sqrt[k] != 0);
+  }
+  if (!all_sqrt) return;   // (a cone that adds G' (H G) instead: assemble_lhs as a whole, later)
+  const double* gq2 = GQ2();
+  HYP_CHECK(hipEventRecord(ctx.ev[0], ctx.stream));
+  int idx = 0;
+  for (size_t k = 0; k < cones.size(); ++k) {
+    Cone* ck = cones[k];
+    if (ck->use_dual_barrier) ck->inv_sqrt_hess_prod(HGQ2.d() + idx, q, gq2 + offs[k], q, nmp);
+    else ck->sqrt_hess_prod(HGQ2.d() + idx, q, gq2 + offs[k], q, nmp);
+    idx += ck->dim;
+  }
+  HYP_CHECK(hipEventRecord(ctx.ev[1], ctx.stream));
+  shp_prelaunched = true;
+  shp_epoch = ctx.cone_epoch;
+}
+
 void SysSolver::assemble_lhs() {
   if (split_unjoined) {   // (a split factorization nobody finished: its lane must not run into this assembly's copies)
     HYP_CHECK(hipStreamWaitEvent(ctx.stream, split_ev_done, 0));
     split_unjoined = false;
   }
   chol_split_n1 = 0;
-  group_inverses();   // qrchol.jl:214-246 (this process's cones only; the multi-GPU glue sums the result)
+  // (the cones' products of this assembly may be in HGQ2 already: prelaunch_sqrt_hess)
+  const bool pre = shp_prelaunched && shp_epoch == ctx.cone_epoch && nmp > 0 && !dist() && ks_world == 1;
+  if (shp_prelaunched) {
+    if (pre) { shp_wasted = 0; ++shp_used; }
+    else { ++shp_wasted; ++shp_unused; }
+  }
+  shp_prelaunched = false;
+  if (!pre) group_inverses();   // qrchol.jl:214-246 (this process's cones only; the multi-GPU glue sums the result)
   if (nmp == 0) return;
   const double* gq2 = GQ2();
-  for (size_t k = 0; k < cones.size(); ++k) use_sqrt[k] = cones[k]->use_sqrt_hess_oracles(nmp) ? 1 : 0;   // :214-216
+  if (!pre)
+    for (size_t k = 0; k < cones.size(); ++k) use_sqrt[k] = cones[k]->use_sqrt_hess_oracles(nmp) ? 1 : 0;   // :214-216
   bool any_sqrt = false;
   for (int v : use_sqrt) any_sqrt |= (v != 0);
   // (round 5, HYP_DIST_OVERLAP=G: row groups, each exchanged on the helper stream under the next one's product)
@@ -710,19 +760,23 @@ void SysSolver::assemble_lhs() {
     }
     use_ov = all_sqrt;
   }
-  HYP_CHECK(hipEventRecord(ctx.ev[0], ctx.stream));
-  HYP_CHECK(hipEventRecord(ctx.ev[1], ctx.stream));
+  if (!pre) {
+    HYP_CHECK(hipEventRecord(ctx.ev[0], ctx.stream));
+    HYP_CHECK(hipEventRecord(ctx.ev[1], ctx.stream));
+  }
   HYP_CHECK(hipEventRecord(ctx.ev[2], ctx.stream));
   if (any_sqrt || use_ov) {   // :219-234
     int idx = 0;
     for (size_t k = 0; k < cones.size(); ++k) {
       if (!use_sqrt[k]) continue;
       Cone* ck = cones[k];
-      if (ck->use_dual_barrier) ck->inv_sqrt_hess_prod(HGQ2.d() + idx, q, gq2 + offs[k], q, nmp);
-      else ck->sqrt_hess_prod(HGQ2.d() + idx, q, gq2 + offs[k], q, nmp);
+      if (!pre) {
+        if (ck->use_dual_barrier) ck->inv_sqrt_hess_prod(HGQ2.d() + idx, q, gq2 + offs[k], q, nmp);
+        else ck->sqrt_hess_prod(HGQ2.d() + idx, q, gq2 + offs[k], q, nmp);
+      }
       idx += ck->dim;
     }
-    HYP_CHECK(hipEventRecord(ctx.ev[1], ctx.stream));
+    if (!pre) HYP_CHECK(hipEventRecord(ctx.ev[1], ctx.stream));
     GemmArgs s{};   // lhs = HGQ2[1:idx, :]' HGQ2[1:idx, :]  (outer_prod!, dense.jl:80-86)
     long r0 = 0, r1 = idx;
     if (ks_world > 1) {   // this rank's K panel (16-row granularity keeps the aligned fast loader); the sum over ranks follows
@@ -1118,6 +1172,7 @@ void SysSolver::load_model(const double* hc, const double* hb, const double* hh,
   screen_agreed = -1;
   gprev_acc_ = -1;
   s_resident = false;   // (the point and directions of an earlier model are not this model's)
+  shp_prelaunched = false; shp_wasted = 0;
   rp_pre_valid = false;
 }
 
@@ -2073,7 +2128,10 @@ int SysSolver::search_alpha(const double* pt, const double* dc, const double* dp
         screen_pass_g_ = -1;
         if (acc) {
           std::memcpy(out, cand, (size_t)len * sizeof(double));
-          if (resident) prefetch_residual_products(mode, sched[idx + g], cd + (size_t)g * len, cand);
+          if (resident) {
+            prefetch_residual_products(mode, sched[idx + g], cd + (size_t)g * len, cand);
+            prelaunch_sqrt_hess();
+          }
           return idx + g;
         }
       }

@@ -61,6 +61,11 @@ struct SysSolver {
   void update_lhs_fact(int* info, int* used_fallback);                         // qrchol.jl:201-257
   void assemble_lhs();                                                         //   :214-246 (Schur sum over this process's cones)
   void factor_lhs(int* info, int* used_fallback);                              //   :249-250
+  void prelaunch_sqrt_hess();                                                  //   HYP_SHP_PRELAUNCH: the next update_lhs's cone products queued when the search accepts
+  bool shp_prelaunched = false;                                                //   ... HGQ2 holds them, for the cone states of epoch shp_epoch
+  unsigned long shp_epoch = 0;
+  int shp_wasted = 0;                                                          //   ... consecutive prelaunches nobody used (2: off for this model)
+  long shp_used = 0, shp_unused = 0;
   int chol_split_point(int n, int K);                                          //   HYP_CHOL_SPLIT: columns of the leading block factored under the product (0: none)
   int chol_split_n1 = 0;                                                       //   ... pending between assemble_lhs and factor_lhs_begin
   long chol_split_count = 0;

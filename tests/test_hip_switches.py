@@ -398,3 +398,26 @@ def test_point_upload_behind_the_queued_assembly_changes_no_bit(name):
     assert after["iters"] == front["iters"]
     assert after["trace"] == front["trace"], name
     assert after["trials"] == front["trials"]
+
+
+@pytest.mark.parametrize("name,expect_used", [("psd_single_wide", True), ("psd_wide_plan", True), ("psd_run", True), ("polymin_large_dual", False),
+                                               ("matrixcompletion", False)])
+def test_cone_products_queued_at_accept_time_change_no_bit(name, expect_used):
+    """round 6, HYP_SHP_PRELAUNCH=1 (measured: no gain outside the profiler, default off): the square-root Hessian products of the NEXT update_lhs (qrchol.jl:219-233) are queued the
+    moment the line search accepts a candidate -- the cones then hold the state that assembly starts from -- and assemble_lhs continues
+    with the Schur product if no cone has taken a point or been reset since.  The same kernels on the same data, earlier in the queue:
+    the same iterates to the last bit; models with a cone that does not go through its square root never prelaunch."""
+    import re
+    on = _run(name, {"HYP_SHP_PRELAUNCH": "1", "HYP_SHP_PRELAUNCH_STATS": "1"}, True)
+    off = _run(name, {"HYP_SHP_PRELAUNCH": "0", "HYP_SHP_PRELAUNCH_STATS": "1"}, True)
+    m = re.search(r"\[sqrt_hess_prod prelaunch\] used (\d+), not used (\d+)", on["stderr"])
+    used, unused = int(m.group(1)), int(m.group(2))
+    if expect_used:
+        assert used >= on["iters"] - 2 and unused <= 1, (used, unused, on["iters"])   # (every iteration but the first; the last one's is never asked for)
+    else:
+        assert used == 0
+    assert re.search(r"used 0, not used 0", off["stderr"])
+    assert on["status"] == off["status"] == "Optimal"
+    assert on["iters"] == off["iters"]
+    assert on["trace"] == off["trace"], name
+    assert on["trials"] == off["trials"]
